@@ -1,0 +1,127 @@
+/*
+ * rb3gpu.h -- C ABI of the MI355X-native BWT-merge engine (librb3gpu.so).
+ *
+ * This is the drop-in boundary for the hot path of `ropebwt3 build`: every entry
+ * point replaces one call the reference's build.c makes on an `mrope_t*`
+ * (citations are file:line in the reference tree).  The opaque `rb3gpu_t`
+ * stands where `mrope_t*` stood; it owns a flat run/bit-plane block array in
+ * HBM instead of the reference's B+-tree of RLE leaves.  Plain C types only:
+ * no HIP, torch or C++ types cross this boundary.  All functions return 0 on
+ * success or a negative RB3GPU_E* code (the reference asserts/aborts instead,
+ * fm-index.c:125,246); nothing here ever falls back to a CPU implementation.
+ */
+#ifndef RB3GPU_H
+#define RB3GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RB3GPU_ASIZE 6           /* $ACGTN = 0..5, fm-index.h:15 (RB3_ASIZE) */
+
+#define RB3GPU_OK         0
+#define RB3GPU_ENODEV    -1      /* no usable HIP device / HIP runtime error */
+#define RB3GPU_ENOMEM    -2      /* device or host allocation failed */
+#define RB3GPU_EINVAL    -3      /* bad argument (NULL, negative length, ...) */
+#define RB3GPU_ESYMBOL   -4      /* a BWT byte is outside 0..5 (fm-index.c:124-125) */
+#define RB3GPU_ESTATE    -5      /* call not valid in this state (e.g. merge into an empty index) */
+#define RB3GPU_EINTERNAL -6      /* invariant violated on the device (fm-index.c:246 analogue) */
+
+typedef struct rb3gpu_s rb3gpu_t;
+
+typedef struct {
+	int32_t device;              /* HIP device ordinal */
+	int32_t split_log2;          /* long-chain splitting: start an extra LF walker at every row whose
+	                                hashed id is 0 mod 2^split_log2; 0 = automatic, <0 = never split */
+	int32_t verbose;             /* >=3: per-phase "[M::...]" lines on stderr like the reference */
+	int32_t reserved;
+} rb3gpu_opt_t;
+
+/* per-handle counters, all cumulative since rb3gpu_create()/rb3gpu_stats_reset() */
+typedef struct {
+	double  ms_h2d;              /* host->device copies of partial BWTs */
+	double  ms_lf;               /* LF-array construction of B2 (fm-index.c:206-216) */
+	double  ms_rank;             /* LF-chain / rank kernels (fm-index.c:160-175, 217-224) */
+	double  ms_build;            /* interleave + block-array rebuild (fm-index.c:237-249, 294-299) */
+	double  ms_export;           /* run / symbol export kernels + D2H */
+	int64_t n_rank_launches;     /* launches of the chain kernel */
+	int64_t n_lf_steps;          /* LF steps executed by the chain kernel (incl. speculative ones) */
+	int64_t n_symbols_merged;    /* sum of `len` over merge calls */
+	int64_t n_rounds;            /* chain-resolution rounds over all merges */
+	int64_t bytes_index;         /* current size of the block array + group directory in HBM */
+	int64_t bytes_peak;          /* high-water mark of device memory owned by the handle */
+} rb3gpu_stats_t;
+
+void rb3gpu_opt_init(rb3gpu_opt_t *opt);
+const char *rb3gpu_strerror(int err);
+
+/* mr_init (mrope.c:15-26) / mr_destroy (mrope.c:28-34) */
+rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt);
+void rb3gpu_destroy(rb3gpu_t *h);
+
+/* rb3_enc_plain2fmr(len, bwt, max_nodes, block_len, n_threads), fm-index.c:114-137,
+ * called at build.c:77,223 -- index the first batch.  `bwt` is caller-owned host memory,
+ * read-only during the call.  Any previous content of the handle is dropped. */
+int rb3gpu_from_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt);
+
+/* rb3_fmi_merge_plain(r, len, seq, n_threads), fm-index.c:279-303, called at
+ * build.c:78,226 -- merge the partial BWT of a later batch in place. */
+int rb3gpu_merge_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt);
+
+/* Same two operations with the partial BWT already resident in HBM on the handle's
+ * device (`d_bwt` is a device pointer).  Used by the pipelined build and by bench.py,
+ * whose timed region starts with inputs in HBM.  commit=0 computes the merged block
+ * array and then discards it, leaving the index unchanged (repeatable benchmark step). */
+int rb3gpu_from_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt);
+int rb3gpu_merge_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int commit);
+
+/* rb3_mg_rank_plain(fa, len, seq, rb, acc, n_threads), fm-index.c:202-225 -- the rank phase
+ * alone, for parity tests against the reference's rb[] array: on return pos[kb] = ka[kb]+kb,
+ * the merged position of row kb of B2 (= rb[kb]>>6 in the reference), and acc2[7] the C array
+ * of B2.  The index is not modified.  `pos` is host memory of `len` int64. */
+int rb3gpu_mg_rank_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1]);
+
+/* rb3_fmi_rank1a(f, k, ok), fm-index.h:109-112 -> mr_rank2a, mrope.c:71-121: for each of the
+ * n query offsets k[i] in [0, total], ok[6*i+c] = #{j < k[i] : B[j] = c}.  Host arrays. */
+int rb3gpu_rank1a_batch(rb3gpu_t *h, int64_t n, const int64_t *k, int64_t *ok);
+
+/* rb3_fmi_get_acc (fm-index.c:544-550) -> mr_get_ac (mrope.h:113-120): acc[a] = #symbols < a */
+int rb3gpu_get_acc(const rb3gpu_t *h, int64_t acc[RB3GPU_ASIZE+1]);
+int64_t rb3gpu_get_tot(const rb3gpu_t *h);          /* mr_get_tot, mrope.h:122-130 */
+
+/* Ordered export of the index as runs, replacing the leaf-block iteration of
+ * rb3_enc_fmr2fmd (fm-index.c:31-54) / mr_print_bwt (mrope.c:201-214): emit(c, l, data) is
+ * called on the host for consecutive runs, in BWT order; adjacent calls may carry the same
+ * symbol (the FMD writer coalesces, rld0.c:153-161).  A non-zero return from emit aborts. */
+typedef int (*rb3gpu_emit_f)(void *data, int c, int64_t l);
+int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data);
+
+/* The whole BWT as one symbol per byte (0..5) into host memory of rb3gpu_get_tot() bytes;
+ * small indexes / tests only. */
+int rb3gpu_export_plain(rb3gpu_t *h, uint8_t *out);
+
+/* Import for `build -i` (rb3_enc_fmd2fmr fm-index.c:56-85, mr_restore mrope.c:161-177):
+ * runs[i] = len<<3 | sym in BWT order (host memory). */
+int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs);
+
+int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st);
+void rb3gpu_stats_reset(rb3gpu_t *h);
+
+/* device scratch helpers so that callers without a HIP binding (C host code, ctypes) can
+ * keep a partial BWT resident in HBM: plain hipMalloc/hipMemcpy/hipFree on the handle's device */
+int rb3gpu_dev_alloc(rb3gpu_t *h, int64_t n_bytes, void **d_ptr);
+int rb3gpu_dev_upload(rb3gpu_t *h, void *d_dst, const void *src, int64_t n_bytes);
+int rb3gpu_dev_download(rb3gpu_t *h, void *dst, const void *d_src, int64_t n_bytes);
+int rb3gpu_dev_free(rb3gpu_t *h, void *d_ptr);
+int rb3gpu_sync(rb3gpu_t *h);
+
+/* number of HIP devices visible, or a negative error */
+int rb3gpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,601 @@
+/*
+ * rb3gpu.hip -- host side of librb3gpu.so: the C ABI declared in include/rb3gpu.h on top of
+ * the gfx950 kernels in rb3gpu_kernels.h.  One handle = one HIP device + one stream.
+ *
+ * The call sequence of a merge mirrors rb3_fmi_merge_plain (fm-index.c:279-303):
+ *   C array of B1 (286-287)            -> kept in the handle / folded into the group directory
+ *   rb3_mg_rank_plain (288-289)        -> k_tile_hist + scan + k_lf2, then k_chain
+ *   kt_for(worker_mgins) (294-299)     -> k_group_rows + k_pass1 + scan + k_pass2
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "rb3gpu.h"
+#include "rb3gpu_kernels.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+		if (h && h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+		return e_ == hipErrorOutOfMemory ? RB3GPU_ENOMEM : RB3GPU_ENODEV; } } while (0)
+
+struct Buf {
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct rb3gpu_s {
+	int dev = 0;
+	hipStream_t st = nullptr;
+	rb3gpu_opt_t opt;
+	rb3gpu_stats_t stt;
+	// the index
+	int64_t n = 0, ngrp = 0, nslots = 0;
+	int64_t acc[7] = {0, 0, 0, 0, 0, 0, 0};
+	rb3_grp_t *grp = nullptr;
+	rb3_slot_t *slots = nullptr;
+	// scratch, grown on demand and kept between calls
+	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf;
+	hipEvent_t ev[6];
+	int64_t bytes_owned = 0;
+	double t0 = 0;
+};
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+static int dev_malloc(rb3gpu_t *h, void **p, size_t bytes)
+{
+	*p = nullptr;
+	if (bytes == 0) bytes = 256;
+	HIPCHK(hipMalloc(p, bytes));
+	h->bytes_owned += (int64_t)bytes;
+	if (h->bytes_owned > h->stt.bytes_peak) h->stt.bytes_peak = h->bytes_owned;
+	return 0;
+}
+
+static void dev_free(rb3gpu_t *h, void *p, size_t bytes)
+{
+	if (p == nullptr) return;
+	(void)hipFree(p);
+	h->bytes_owned -= (int64_t)(bytes ? bytes : 256);
+}
+
+static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes)
+{
+	if (b.cap >= bytes && b.p) return 0;
+	if (b.p) dev_free(h, b.p, b.cap);
+	b.p = nullptr, b.cap = 0;
+	size_t want = bytes + (bytes >> 3) + 256; // a little slack so that growing batches do not realloc every time
+	int r = dev_malloc(h, &b.p, want);
+	if (r == RB3GPU_ENOMEM && want != bytes) r = dev_malloc(h, &b.p, want = bytes);
+	if (r < 0) return r;
+	b.cap = want;
+	return 0;
+}
+
+static void buf_release(rb3gpu_t *h, Buf &b)
+{
+	if (b.p) dev_free(h, b.p, b.cap);
+	b.p = nullptr, b.cap = 0;
+}
+
+static float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+	float ms = 0;
+	if (hipEventElapsedTime(&ms, a, b) != hipSuccess) ms = 0;
+	return ms;
+}
+
+static IdxView view_of(const rb3gpu_t *h)
+{
+	IdxView v;
+	v.grp64 = (const uint64_t*)h->grp, v.slot16 = (const uint4*)h->slots, v.n = h->n, v.m = h->acc[1];
+	return v;
+}
+
+extern "C" {
+
+void rb3gpu_opt_init(rb3gpu_opt_t *opt)
+{
+	memset(opt, 0, sizeof(*opt));
+	opt->device = 0, opt->split_log2 = 0, opt->verbose = 1;
+}
+
+const char *rb3gpu_strerror(int err)
+{
+	switch (err) {
+	case RB3GPU_OK: return "success";
+	case RB3GPU_ENODEV: return "HIP device or runtime error";
+	case RB3GPU_ENOMEM: return "out of memory";
+	case RB3GPU_EINVAL: return "invalid argument";
+	case RB3GPU_ESYMBOL: return "BWT symbol outside 0..5";
+	case RB3GPU_ESTATE: return "operation not valid in this state";
+	case RB3GPU_EINTERNAL: return "device-side invariant violated";
+	default: return "unknown error";
+	}
+}
+
+int rb3gpu_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return RB3GPU_ENODEV;
+	return n;
+}
+
+rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
+{
+	rb3gpu_opt_t o;
+	int ndev = 0;
+	if (opt) o = *opt; else rb3gpu_opt_init(&o);
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || o.device < 0 || o.device >= ndev) {
+		if (o.verbose >= 1) fprintf(stderr, "[E::rb3gpu_create] no usable HIP device (count=%d, requested=%d); this engine has no CPU fallback\n", ndev, o.device);
+		return nullptr;
+	}
+	if (hipSetDevice(o.device) != hipSuccess) return nullptr;
+	rb3gpu_t *h = new (std::nothrow) rb3gpu_s();
+	if (!h) return nullptr;
+	h->dev = o.device, h->opt = o;
+	memset(&h->stt, 0, sizeof(h->stt));
+	if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
+	for (int i = 0; i < 6; ++i)
+		if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return nullptr; }
+	h->t0 = now_s();
+	return h;
+}
+
+static void index_drop(rb3gpu_t *h)
+{
+	dev_free(h, h->grp, (size_t)h->ngrp * sizeof(rb3_grp_t));
+	dev_free(h, h->slots, (size_t)h->nslots * sizeof(rb3_slot_t));
+	h->grp = nullptr, h->slots = nullptr, h->n = h->ngrp = h->nslots = 0;
+	memset(h->acc, 0, sizeof(h->acc));
+	h->stt.bytes_index = 0;
+}
+
+void rb3gpu_destroy(rb3gpu_t *h)
+{
+	if (!h) return;
+	(void)hipSetDevice(h->dev);
+	(void)hipStreamSynchronize(h->st);
+	index_drop(h);
+	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf };
+	for (Buf *b : all) buf_release(h, *b);
+	for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev[i]);
+	(void)hipStreamDestroy(h->st);
+	delete h;
+}
+
+/* exclusive scan of nrec records of 8 x u32 -> 8 x u64 (7 columns used); totals to host */
+static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t *out, uint64_t total[8])
+{
+	const int64_t nchunk = (nrec + RB3_SCAN_CHUNK - 1) / RB3_SCAN_CHUNK;
+	int r;
+	if ((r = buf_ensure(h, h->ctot, (size_t)(nchunk + 1) * 64)) < 0) return r;
+	uint64_t *ctot = (uint64_t*)h->ctot.p, *dtotal = ctot + nchunk * 8;
+	hipLaunchKernelGGL(k_scan_chunk_totals, dim3((unsigned)nchunk), dim3(256), 0, h->st, in, nrec, ctot);
+	hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(256), 0, h->st, ctot, nchunk, dtotal);
+	hipLaunchKernelGGL(k_scan_records, dim3((unsigned)nchunk), dim3(256), 0, h->st, in, nrec, (const uint64_t*)ctot, out);
+	HIPCHK(hipMemcpyAsync(total, dtotal, 64, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
+/* build a block array for ntot symbols; FROM_PLAIN: symbols are d_b2[0..ntot); otherwise the
+ * interleave of the current index with d_b2 at merged positions pos[].  On success the new
+ * arrays are returned through the out parameters (not yet installed). */
+extern "C++" {
+template<bool FROM_PLAIN>
+static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64_t *d_pos, int64_t ntot,
+		rb3_grp_t **ogrp, rb3_slot_t **oslots, int64_t *ongrp, int64_t *onslots, int64_t oacc[7])
+{
+	const int64_t ngrp = (ntot >> RB3_GRP_BITS) + 1;
+	int r;
+	if (ngrp > 0x7fffffffLL) return RB3GPU_EINVAL;
+	if ((r = buf_ensure(h, h->gstat, (size_t)ngrp * 32)) < 0) return r;
+	if ((r = buf_ensure(h, h->gpre, (size_t)ngrp * 64)) < 0) return r;
+	int64_t *jg = nullptr;
+	if (!FROM_PLAIN) {
+		if ((r = buf_ensure(h, h->jg, (size_t)(ngrp + 1) * 8)) < 0) return r;
+		jg = (int64_t*)h->jg.p;
+		const int64_t nt = n2 + 1;
+		hipLaunchKernelGGL(k_group_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, ngrp);
+	}
+	IdxView old = view_of(h);
+	uint32_t *gstat = (uint32_t*)h->gstat.p;
+	uint64_t *gpre = (uint64_t*)h->gpre.p;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, gstat, ngrp);
+	uint64_t total[8];
+	if ((r = scan_records(h, gstat, ngrp, gpre, total)) < 0) return r;
+	Acc7 acc;
+	acc.a[0] = 0;
+	for (int a = 0; a < 6; ++a) acc.a[a + 1] = acc.a[a] + (int64_t)total[a];
+	if (acc.a[6] != ntot) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] symbol counts do not add up: %lld vs %lld\n", (long long)acc.a[6], (long long)ntot);
+		return RB3GPU_EINTERNAL;
+	}
+	const int64_t nslots = (int64_t)total[6];
+	rb3_grp_t *grp = nullptr;
+	rb3_slot_t *slots = nullptr;
+	if ((r = dev_malloc(h, (void**)&grp, (size_t)ngrp * sizeof(rb3_grp_t))) < 0) return r;
+	if ((r = dev_malloc(h, (void**)&slots, (size_t)nslots * sizeof(rb3_slot_t))) < 0) { dev_free(h, grp, (size_t)ngrp * sizeof(rb3_grp_t)); return r; }
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
+			(const uint32_t*)gstat, (const uint64_t*)gpre, acc, grp, (uint4*)slots, ngrp);
+	*ogrp = grp, *oslots = slots, *ongrp = ngrp, *onslots = nslots;
+	memcpy(oacc, acc.a, sizeof(acc.a));
+	return 0;
+}
+} // extern "C++"
+
+static void index_install(rb3gpu_t *h, rb3_grp_t *grp, rb3_slot_t *slots, int64_t ngrp, int64_t nslots, int64_t ntot, const int64_t acc[7])
+{
+	index_drop(h);
+	h->grp = grp, h->slots = slots, h->ngrp = ngrp, h->nslots = nslots, h->n = ntot;
+	memcpy(h->acc, acc, sizeof(h->acc));
+	h->stt.bytes_index = ngrp * (int64_t)sizeof(rb3_grp_t) + nslots * (int64_t)sizeof(rb3_slot_t);
+}
+
+/* histogram + LF array of B2; acc2 to host */
+static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t acc2[7])
+{
+	const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
+	int r;
+	if ((r = buf_ensure(h, h->tcnt, (size_t)ntile * 32)) < 0) return r;
+	if ((r = buf_ensure(h, h->tpre, (size_t)ntile * 64)) < 0) return r;
+	if ((r = buf_ensure(h, h->lf2, (size_t)len * 8)) < 0) return r;
+	hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (uint32_t*)h->tcnt.p);
+	uint64_t total[8];
+	if ((r = scan_records(h, (const uint32_t*)h->tcnt.p, ntile, (uint64_t*)h->tpre.p, total)) < 0) return r;
+	if (total[6] != 0) return RB3GPU_ESYMBOL; // fm-index.c:124-125
+	Acc7 a2;
+	a2.a[0] = 0;
+	for (int a = 0; a < 6; ++a) a2.a[a + 1] = a2.a[a] + (int64_t)total[a];
+	memcpy(acc2, a2.a, sizeof(a2.a));
+	hipLaunchKernelGGL(k_lf2, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (const uint64_t*)h->tpre.p, a2, (uint64_t*)h->lf2.p);
+	return 0;
+}
+
+static int pick_split(const rb3gpu_t *h, int64_t len, int64_t m2)
+{
+	if (h->opt.split_log2 < 0) return 0;
+	if (h->opt.split_log2 > 0) return h->opt.split_log2 > 40 ? 40 : h->opt.split_log2;
+	// automatic: aim at ~64k walkers; never split strings that are already short
+	int lg = 8;
+	while ((len >> lg) > 65536 && lg < 30) ++lg;
+	if (m2 > 0 && len / m2 <= (2LL << lg)) return 0;
+	return lg;
+}
+
+/* the rank phase: on return h->pos holds ka[kb]+kb for every row of B2 */
+static int rank_phase(rb3gpu_t *h, int64_t len, const int64_t acc2[7])
+{
+	int r;
+	if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, 256)) < 0) return r;
+	const int64_t m2 = acc2[1];
+	const int logM = pick_split(h, len, m2);
+	int64_t nwalk = m2;
+	if (logM > 0) {
+		const int64_t M = 1LL << logM, first = (m2 + M - 1) >> logM << logM;
+		if (first < len) nwalk += (len - first + M - 1) >> logM;
+	}
+	HIPCHK(hipMemsetAsync(h->pos.p, 0xff, (size_t)len * 8, h->st));
+	HIPCHK(hipMemsetAsync(h->misc.p, 0, 256, h->st));
+	unsigned long long *qhead = (unsigned long long*)h->misc.p, *nsteps = qhead + 1;
+	int64_t nblk = (nwalk + 31) / 32;
+	if (nblk > 256 * 8) nblk = 256 * 8;
+	if (nblk < 1) nblk = 1;
+	hipLaunchKernelGGL(k_chain, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, (int64_t*)h->pos.p,
+			len, m2, logM, nwalk, qhead, nsteps);
+	h->stt.n_rank_launches += 1;
+	h->stt.n_rounds += 1;
+	return 0;
+}
+
+static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only)
+{
+	int r;
+	int64_t acc2[7];
+	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	if ((r = lf_build(h, len, d_b2, acc2)) < 0) return r;
+	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	if ((r = rank_phase(h, len, acc2)) < 0) return r;
+	HIPCHK(hipEventRecord(h->ev[2], h->st));
+	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
+	rb3_grp_t *grp = nullptr;
+	rb3_slot_t *slots = nullptr;
+	int64_t ngrp = 0, nslots = 0, acc[7], ntot = h->n + len;
+	if (!rank_only) {
+		if ((r = build_index<false>(h, len, d_b2, (const int64_t*)h->pos.p, ntot, &grp, &slots, &ngrp, &nslots, acc)) < 0) return r;
+	}
+	HIPCHK(hipEventRecord(h->ev[3], h->st));
+	if (host_pos) HIPCHK(hipMemcpyAsync(host_pos, h->pos.p, (size_t)len * 8, hipMemcpyDeviceToHost, h->st));
+	unsigned long long hsteps[2] = {0, 0};
+	HIPCHK(hipMemcpyAsync(hsteps, h->misc.p, 16, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_lf += ev_ms(h->ev[0], h->ev[1]);
+	h->stt.ms_rank += ev_ms(h->ev[1], h->ev[2]);
+	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
+	h->stt.n_lf_steps += (int64_t)hsteps[1];
+	h->stt.n_symbols_merged += len;
+	if (!rank_only) {
+		int bad = 0;
+		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + acc2[a]) bad = 1;
+		if (bad) {
+			dev_free(h, grp, (size_t)ngrp * sizeof(rb3_grp_t));
+			dev_free(h, slots, (size_t)nslots * sizeof(rb3_slot_t));
+			return RB3GPU_EINTERNAL;
+		}
+		if (commit) index_install(h, grp, slots, ngrp, nslots, ntot, acc);
+		else {
+			dev_free(h, grp, (size_t)ngrp * sizeof(rb3_grp_t));
+			dev_free(h, slots, (size_t)nslots * sizeof(rb3_slot_t));
+		}
+	}
+	if (h->opt.verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f] merged %lld symbols (%lld strings): lf %.3f ms, rank %.3f ms (%llu LF steps), rebuild %.3f ms\n", __func__,
+				now_s() - h->t0, (long long)len, (long long)acc2[1], ev_ms(h->ev[0], h->ev[1]), ev_ms(h->ev[1], h->ev[2]), hsteps[1], ev_ms(h->ev[2], h->ev[3]));
+	return 0;
+}
+
+static int upload_b2(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
+{
+	int r;
+	if ((r = buf_ensure(h, h->b2, (size_t)len + 16)) < 0) return r;
+	HIPCHK(hipEventRecord(h->ev[4], h->st));
+	HIPCHK(hipMemcpyAsync(h->b2.p, bwt, (size_t)len, hipMemcpyHostToDevice, h->st));
+	HIPCHK(hipEventRecord(h->ev[5], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_h2d += ev_ms(h->ev[4], h->ev[5]);
+	return 0;
+}
+
+int rb3gpu_from_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt)
+{
+	if (!h || len <= 0 || !d_bwt) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	int r;
+	rb3_grp_t *grp;
+	rb3_slot_t *slots;
+	int64_t ngrp, nslots, acc[7];
+	// validate symbols with the tile histogram (fm-index.c:122-125)
+	const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
+	if ((r = buf_ensure(h, h->tcnt, (size_t)ntile * 32)) < 0) return r;
+	if ((r = buf_ensure(h, h->tpre, (size_t)ntile * 64)) < 0) return r;
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)ntile), dim3(256), 0, h->st, d_bwt, len, (uint32_t*)h->tcnt.p);
+	uint64_t total[8];
+	if ((r = scan_records(h, (const uint32_t*)h->tcnt.p, ntile, (uint64_t*)h->tpre.p, total)) < 0) return r;
+	if (total[6] != 0) return RB3GPU_ESYMBOL;
+	index_drop(h);
+	if ((r = build_index<true>(h, len, d_bwt, nullptr, len, &grp, &slots, &ngrp, &nslots, acc)) < 0) return r;
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_build += ev_ms(h->ev[0], h->ev[1]);
+	index_install(h, grp, slots, ngrp, nslots, len, acc);
+	if (h->opt.verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f] encoded %lld symbols into %lld slots (%.3f ms)\n", __func__, now_s() - h->t0, (long long)len, (long long)nslots, ev_ms(h->ev[0], h->ev[1]));
+	return 0;
+}
+
+int rb3gpu_from_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
+{
+	if (!h || len <= 0 || !bwt) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	int r;
+	if ((r = upload_b2(h, len, bwt)) < 0) return r;
+	return rb3gpu_from_plain_dev(h, len, (const uint8_t*)h->b2.p);
+}
+
+int rb3gpu_merge_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int commit)
+{
+	if (!h || len <= 0 || !d_bwt) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0);
+}
+
+int rb3gpu_merge_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
+{
+	if (!h || len <= 0 || !bwt) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->n <= 0) return RB3GPU_ESTATE;
+	int r;
+	if ((r = upload_b2(h, len, bwt)) < 0) return r;
+	return merge_core(h, len, (const uint8_t*)h->b2.p, 1, nullptr, nullptr, 0);
+}
+
+int rb3gpu_mg_rank_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1])
+{
+	if (!h || len <= 0 || !bwt || !pos) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->n <= 0) return RB3GPU_ESTATE;
+	int r;
+	if ((r = upload_b2(h, len, bwt)) < 0) return r;
+	return merge_core(h, len, (const uint8_t*)h->b2.p, 0, pos, acc2, 1);
+}
+
+int rb3gpu_rank1a_batch(rb3gpu_t *h, int64_t n, const int64_t *k, int64_t *ok)
+{
+	if (!h || n < 0 || (n > 0 && (!k || !ok))) return RB3GPU_EINVAL;
+	if (n == 0) return 0;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	int r;
+	if ((r = buf_ensure(h, h->xbuf, (size_t)n * 56)) < 0) return r;
+	int64_t *dk = (int64_t*)h->xbuf.p, *dok = dk + n;
+	HIPCHK(hipMemcpyAsync(dk, k, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+	Acc7 acc;
+	memcpy(acc.a, h->acc, sizeof(acc.a));
+	int64_t nblk = (n * 8 + 255) / 256;
+	if (nblk > 4096) nblk = 4096;
+	hipLaunchKernelGGL(k_rank_batch, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), acc, n, (const int64_t*)dk, dok);
+	HIPCHK(hipMemcpyAsync(ok, dok, (size_t)n * 48, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
+int rb3gpu_get_acc(const rb3gpu_t *h, int64_t acc[RB3GPU_ASIZE+1])
+{
+	if (!h || !acc) return RB3GPU_EINVAL;
+	memcpy(acc, h->acc, sizeof(h->acc));
+	return 0;
+}
+
+int64_t rb3gpu_get_tot(const rb3gpu_t *h)
+{
+	return h ? h->n : RB3GPU_EINVAL;
+}
+
+#define RB3_XCHUNK (64LL << 20)
+
+static int export_chunk(rb3gpu_t *h, int64_t beg, int64_t end, uint8_t *host)
+{
+	int r;
+	if ((r = buf_ensure(h, h->xbuf, (size_t)RB3_XCHUNK)) < 0) return r;
+	int64_t nblk = (end - beg + 255) / 256;
+	if (nblk > 65536) nblk = 65536;
+	hipLaunchKernelGGL(k_export_plain, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), beg, end, (uint8_t*)h->xbuf.p);
+	HIPCHK(hipMemcpyAsync(host, h->xbuf.p, (size_t)(end - beg), hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
+int rb3gpu_export_plain(rb3gpu_t *h, uint8_t *out)
+{
+	if (!h || !out) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	double t = now_s();
+	for (int64_t beg = 0; beg < h->n; beg += RB3_XCHUNK) {
+		int64_t end = beg + RB3_XCHUNK < h->n ? beg + RB3_XCHUNK : h->n;
+		int r = export_chunk(h, beg, end, out + beg);
+		if (r < 0) return r;
+	}
+	h->stt.ms_export += (now_s() - t) * 1e3;
+	return 0;
+}
+
+int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
+{
+	if (!h || !emit) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	double t = now_s();
+	const int64_t cap = RB3_XCHUNK < h->n ? RB3_XCHUNK : h->n;
+	uint8_t *buf = (uint8_t*)malloc((size_t)(cap > 0 ? cap : 1));
+	if (!buf) return RB3GPU_ENOMEM;
+	int c = -1, ret = 0;
+	int64_t l = 0;
+	for (int64_t beg = 0; beg < h->n && ret == 0; beg += RB3_XCHUNK) {
+		int64_t end = beg + RB3_XCHUNK < h->n ? beg + RB3_XCHUNK : h->n;
+		if ((ret = export_chunk(h, beg, end, buf)) < 0) break;
+		for (int64_t i = 0; i < end - beg; ++i) {
+			if (buf[i] == c) ++l;
+			else {
+				if (l > 0 && emit(data, c, l) != 0) { ret = RB3GPU_EINVAL; break; }
+				c = buf[i], l = 1;
+			}
+		}
+	}
+	if (ret == 0 && l > 0 && emit(data, c, l) != 0) ret = RB3GPU_EINVAL;
+	free(buf);
+	h->stt.ms_export += (now_s() - t) * 1e3;
+	return ret;
+}
+
+int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs)
+{
+	if (!h || n_runs <= 0 || !runs) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	int64_t tot = 0;
+	for (int64_t i = 0; i < n_runs; ++i) {
+		if ((runs[i] & 7) > 5) return RB3GPU_ESYMBOL;
+		tot += (int64_t)(runs[i] >> 3);
+	}
+	if (tot <= 0) return RB3GPU_EINVAL;
+	int r;
+	if ((r = buf_ensure(h, h->b2, (size_t)tot + 16)) < 0) return r;
+	const int64_t cap = RB3_XCHUNK;
+	uint8_t *buf = (uint8_t*)malloc((size_t)cap);
+	if (!buf) return RB3GPU_ENOMEM;
+	int64_t off = 0, fill = 0;
+	for (int64_t i = 0; i < n_runs; ++i) {
+		int64_t l = (int64_t)(runs[i] >> 3);
+		const int c = (int)(runs[i] & 7);
+		while (l > 0) {
+			int64_t t = l < cap - fill ? l : cap - fill;
+			memset(buf + fill, c, (size_t)t);
+			fill += t, l -= t;
+			if (fill == cap) {
+				if (hipMemcpy((uint8_t*)h->b2.p + off, buf, (size_t)fill, hipMemcpyHostToDevice) != hipSuccess) { free(buf); return RB3GPU_ENODEV; }
+				off += fill, fill = 0;
+			}
+		}
+	}
+	if (fill > 0 && hipMemcpy((uint8_t*)h->b2.p + off, buf, (size_t)fill, hipMemcpyHostToDevice) != hipSuccess) { free(buf); return RB3GPU_ENODEV; }
+	free(buf);
+	return rb3gpu_from_plain_dev(h, tot, (const uint8_t*)h->b2.p);
+}
+
+int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st)
+{
+	if (!h || !st) return RB3GPU_EINVAL;
+	*st = h->stt;
+	return 0;
+}
+
+void rb3gpu_stats_reset(rb3gpu_t *h)
+{
+	if (!h) return;
+	int64_t bi = h->stt.bytes_index;
+	memset(&h->stt, 0, sizeof(h->stt));
+	h->stt.bytes_index = bi, h->stt.bytes_peak = h->bytes_owned;
+}
+
+int rb3gpu_dev_alloc(rb3gpu_t *h, int64_t n_bytes, void **d_ptr)
+{
+	if (!h || n_bytes < 0 || !d_ptr) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipMalloc(d_ptr, (size_t)(n_bytes > 0 ? n_bytes : 1)));
+	return 0;
+}
+
+int rb3gpu_dev_upload(rb3gpu_t *h, void *d_dst, const void *src, int64_t n_bytes)
+{
+	if (!h || !d_dst || !src || n_bytes < 0) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipMemcpy(d_dst, src, (size_t)n_bytes, hipMemcpyHostToDevice));
+	return 0;
+}
+
+int rb3gpu_dev_download(rb3gpu_t *h, void *dst, const void *d_src, int64_t n_bytes)
+{
+	if (!h || !dst || !d_src || n_bytes < 0) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipMemcpy(dst, d_src, (size_t)n_bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int rb3gpu_dev_free(rb3gpu_t *h, void *d_ptr)
+{
+	if (!h) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipFree(d_ptr));
+	return 0;
+}
+
+int rb3gpu_sync(rb3gpu_t *h)
+{
+	if (!h) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,726 @@
+/*
+ * rb3gpu_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the merge engine.
+ *
+ * Reference functions restated on the device (file:line in the reference tree):
+ *   k_tile_hist + k_lf2      rb3_mg_rank_plain prologue, fm-index.c:206-216
+ *   k_chain                  rb3_mg_rank1_plain, fm-index.c:160-175 (+ kt_for 217-224)
+ *   oct_rank                 rb3_fmi_rank1a -> mr_rank2a -> rope_rank2a -> rle_rank2a
+ *                            (fm-index.h:109-112, mrope.c:71-121, rope.c:150-206, rle.c:134-199)
+ *   k_pass1 / k_pass2        worker_mgins + rope_insert_run (fm-index.c:237-249, rope.c:114-148)
+ *                            and rb3_enc_plain2fmr (fm-index.c:114-137), as one streaming
+ *                            interleave that rebuilds the block array
+ *   k_export_plain           mr_print_bwt / leaf iteration (mrope.c:133-147, 201-214)
+ *
+ * No MFMA anywhere: this is integer pointer chasing bound by HBM/L2 latency and bandwidth.
+ */
+#ifndef RB3GPU_KERNELS_H
+#define RB3GPU_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rb3gpu_layout.h"
+
+#define RB3_UNSET (-1LL)
+
+struct IdxView {
+	const uint64_t *grp64;   // rb3_grp_t viewed as 8 x u64
+	const uint4 *slot16;     // rb3_slot_t viewed as 8 x uint4
+	int64_t n;               // number of symbols
+	int64_t m;               // number of sentinels (= acc[1])
+};
+
+struct Acc7 { int64_t a[7]; };
+
+/* ----------------------------------------------------------------------------------------- */
+/* cross-lane helpers for an OCTET (8 consecutive lanes of a wave64), DPP only, no LDS         */
+/* ----------------------------------------------------------------------------------------- */
+
+template<int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+/* sum over the 8 lanes of an octet; every lane gets the total */
+__device__ __forceinline__ uint32_t oct_sum(uint32_t v)
+{
+	v += dpp_mov<0x141>(v); // row_half_mirror: lane i <- lane 7-i
+	v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+	v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+	return v;
+}
+
+/* value of octet lane 0 in every lane of the octet */
+__device__ __forceinline__ uint32_t oct_bcast0(uint32_t v, int j)
+{
+	uint32_t a = dpp_mov<0x00>(v);  // quad_perm [0,0,0,0]
+	uint32_t b = dpp_mov<0x114>(a); // row_shr:4
+	return (j & 4) ? b : a;
+}
+
+/* exclusive prefix sum over the 8 lanes of an octet */
+__device__ __forceinline__ uint32_t oct_exscan(uint32_t v, int j)
+{
+	uint32_t inc = v, t;
+	t = dpp_mov<0x111>(inc); if (j >= 1) inc += t; // row_shr:1
+	t = dpp_mov<0x112>(inc); if (j >= 2) inc += t; // row_shr:2
+	t = dpp_mov<0x114>(inc); if (j >= 4) inc += t; // row_shr:4
+	return inc - v;
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* rank: #{i < k : B[i] = c} + C[c], eight lanes per query                                     */
+/* ----------------------------------------------------------------------------------------- */
+
+struct RankLoad { // everything that depends on k only, so loads can be issued before c is known
+	uint64_t gw;     // word j of the group entry
+	uint4 sl;        // slice j of the slot
+	uint32_t koff;   // k & 8191
+};
+
+__device__ __forceinline__ void oct_rank_issue(const IdxView &ix, int64_t k, int j, RankLoad &r)
+{
+	const int64_t g = k >> RB3_GRP_BITS;
+	r.koff = (uint32_t)k & (RB3_GRP - 1);
+	const uint32_t lw = r.koff >> RB3_WIN_BITS;
+	r.gw = ix.grp64[g * 8 + j];
+	const uint64_t sm = ix.grp64[g * 8 + 6];
+	const uint32_t slot0 = (uint32_t)sm, mask = (uint32_t)(sm >> 32);
+	const uint32_t s = slot0 + __popc(mask & ((2u << lw) - 1u)) - 1u;
+	r.sl = ix.slot16[(int64_t)s * 8 + j];
+}
+
+/* number of symbols equal to c among the first `off` symbols of the slot, this lane's share */
+__device__ __forceinline__ uint32_t slice_count(const uint4 &sl, uint32_t hdr0, uint32_t off, int c, int j)
+{
+	uint32_t cnt;
+	if (!(hdr0 & RB3_SLOT_RLE)) { // bit planes: symbols [32j, 32j+32)
+		int t = (int)off - 32 * j;
+		t = t < 0 ? 0 : t > 32 ? 32 : t;
+		const uint32_t m0 = (c & 1) ? sl.y : ~sl.y, m1 = (c & 2) ? sl.z : ~sl.z, m2 = (c & 4) ? sl.w : ~sl.w;
+		const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
+		cnt = __popc(m0 & m1 & m2 & lim);
+	} else { // six run codes per lane
+		uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
+		uint32_t len[6], tot = 0;
+#pragma unroll
+		for (int i = 0; i < 6; ++i) {
+			len[i] = (e[i] & 7u) == 7u ? 0u : (e[i] >> 3) + 1u;
+			tot += len[i];
+		}
+		int pos = (int)oct_exscan(tot, j);
+		cnt = 0;
+#pragma unroll
+		for (int i = 0; i < 6; ++i) {
+			int d = (int)off - pos;
+			d = d < 0 ? 0 : d > (int)len[i] ? (int)len[i] : d;
+			if ((int)(e[i] & 7u) == c) cnt += (uint32_t)d;
+			pos += (int)len[i];
+		}
+	}
+	return cnt;
+}
+
+__device__ __forceinline__ int64_t oct_rank_finish(const RankLoad &r, int c, int j)
+{
+	const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
+	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
+	uint32_t part = slice_count(r.sl, hdr0, off, c, j);
+	if (j == c + 1) part += r.sl.x; // hdr[c+1] = count of c between group start and slot start
+	const uint32_t sum = oct_sum(part);
+	const uint32_t lo = oct_sum(j == c ? (uint32_t)r.gw : 0u);
+	const uint32_t hi = oct_sum(j == c ? (uint32_t)(r.gw >> 32) : 0u);
+	return (int64_t)(((uint64_t)hi << 32 | lo) + sum);
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* batched rank (tests): one octet per query, all six symbols                                  */
+/* ----------------------------------------------------------------------------------------- */
+
+__global__ void __launch_bounds__(256) k_rank_batch(IdxView ix, Acc7 acc, int64_t nq, const int64_t *k, int64_t *ok)
+{
+	const int lane = threadIdx.x & 63, j = lane & 7;
+	int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+	const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 3;
+	for (; q < nq; q += stride) {
+		int64_t kk = k[q];
+		kk = kk < 0 ? 0 : kk > ix.n ? ix.n : kk;
+		RankLoad r;
+		oct_rank_issue(ix, kk, j, r);
+		for (int c = 0; c < 6; ++c) {
+			int64_t v = oct_rank_finish(r, c, j) - acc.a[c];
+			if (j == 0) ok[q * 6 + c] = v;
+		}
+	}
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* LF array of the partial BWT B2 (fm-index.c:206-216)                                         */
+/* ----------------------------------------------------------------------------------------- */
+
+#define RB3_TILE 4096 // bytes of B2 per workgroup (256 threads x 16 B)
+
+/* per-tile symbol histogram: tcnt[tile*8 + a], a = 0..5; [6] = #bytes outside 0..5 */
+__global__ void __launch_bounds__(256) k_tile_hist(const uint8_t *b2, int64_t n2, uint32_t *tcnt)
+{
+	__shared__ uint32_t sh[8];
+	const int64_t tile = blockIdx.x;
+	if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+	__syncthreads();
+	const int64_t base = tile * RB3_TILE + (int64_t)threadIdx.x * 16;
+	uint32_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+	if (base + 16 <= n2) {
+		const uint4 v = *(const uint4*)(b2 + base);
+		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const uint32_t a = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+#pragma unroll
+			for (int s = 0; s < 6; ++s) c[s] += (a == (uint32_t)s);
+			c[6] += (a > 5u);
+		}
+	} else {
+		for (int i = 0; i < 16 && base + i < n2; ++i) {
+			const uint32_t a = b2[base + i];
+#pragma unroll
+			for (int s = 0; s < 6; ++s) c[s] += (a == (uint32_t)s);
+			c[6] += (a > 5u);
+		}
+	}
+#pragma unroll
+	for (int s = 0; s < 7; ++s) {
+		uint32_t v = c[s];
+		for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+		if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh[s], v);
+	}
+	__syncthreads();
+	if (threadIdx.x < 8) tcnt[tile * 8 + threadIdx.x] = threadIdx.x < 7 ? sh[threadIdx.x] : 0;
+}
+
+/* Exclusive scan of records of 8 x u32 (7 used) into records of 8 x u64, three kernels. */
+#define RB3_SCAN_CHUNK 1024 // records per workgroup
+
+__global__ void __launch_bounds__(256) k_scan_chunk_totals(const uint32_t *in, int64_t nrec, uint64_t *ctot)
+{
+	__shared__ uint64_t sh[7];
+	if (threadIdx.x < 7) sh[threadIdx.x] = 0;
+	__syncthreads();
+	const int64_t r0 = (int64_t)blockIdx.x * RB3_SCAN_CHUNK;
+	uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
+	for (int i = threadIdx.x; i < RB3_SCAN_CHUNK; i += 256) {
+		const int64_t r = r0 + i;
+		if (r < nrec) {
+			const uint4 a = *(const uint4*)(in + r * 8), b = *(const uint4*)(in + r * 8 + 4);
+			s[0] += a.x, s[1] += a.y, s[2] += a.z, s[3] += a.w, s[4] += b.x, s[5] += b.y, s[6] += b.z;
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < 7; ++q) {
+		uint64_t v = s[q];
+		for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+		if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&sh[q], (unsigned long long)v);
+	}
+	__syncthreads();
+	if (threadIdx.x < 8) ctot[(int64_t)blockIdx.x * 8 + threadIdx.x] = threadIdx.x < 7 ? sh[threadIdx.x] : 0;
+}
+
+/* single workgroup: ctot[] -> exclusive prefix in place; total[8] receives the grand totals */
+__global__ void __launch_bounds__(256) k_scan_chunks(uint64_t *ctot, int64_t nchunk, uint64_t *total)
+{
+	__shared__ uint64_t sh[256][7];
+	const int t = threadIdx.x;
+	const int64_t per = (nchunk + 255) / 256, c0 = (int64_t)t * per, c1 = c0 + per < nchunk ? c0 + per : nchunk;
+	uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
+	for (int64_t c = c0; c < c1; ++c)
+		for (int q = 0; q < 7; ++q) s[q] += ctot[c * 8 + q];
+	for (int q = 0; q < 7; ++q) sh[t][q] = s[q];
+	__syncthreads();
+	if (t < 7) { // sequential exclusive scan over 256 partials, one thread per column
+		uint64_t run = 0;
+		for (int i = 0; i < 256; ++i) { uint64_t v = sh[i][t]; sh[i][t] = run; run += v; }
+		total[t] = run;
+	}
+	if (t == 7) total[7] = 0;
+	__syncthreads();
+	for (int q = 0; q < 7; ++q) s[q] = sh[t][q];
+	for (int64_t c = c0; c < c1; ++c)
+		for (int q = 0; q < 7; ++q) { uint64_t v = ctot[c * 8 + q]; ctot[c * 8 + q] = s[q]; s[q] += v; }
+}
+
+__global__ void __launch_bounds__(256) k_scan_records(const uint32_t *in, int64_t nrec, const uint64_t *ctot, uint64_t *out)
+{
+	__shared__ uint64_t sh[256][7];
+	const int t = threadIdx.x;
+	const int64_t r0 = (int64_t)blockIdx.x * RB3_SCAN_CHUNK + (int64_t)t * 4;
+	uint32_t v[4][7];
+	uint64_t s[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int64_t r = r0 + i;
+		if (r < nrec) {
+			const uint4 a = *(const uint4*)(in + r * 8), b = *(const uint4*)(in + r * 8 + 4);
+			v[i][0] = a.x, v[i][1] = a.y, v[i][2] = a.z, v[i][3] = a.w, v[i][4] = b.x, v[i][5] = b.y, v[i][6] = b.z;
+		} else {
+#pragma unroll
+			for (int q = 0; q < 7; ++q) v[i][q] = 0;
+		}
+#pragma unroll
+		for (int q = 0; q < 7; ++q) s[q] += v[i][q];
+	}
+#pragma unroll
+	for (int q = 0; q < 7; ++q) sh[t][q] = s[q];
+	__syncthreads();
+	for (int d = 1; d < 256; d <<= 1) { // Hillis-Steele inclusive scan over threads
+		uint64_t add[7];
+#pragma unroll
+		for (int q = 0; q < 7; ++q) add[q] = t >= d ? sh[t - d][q] : 0;
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < 7; ++q) sh[t][q] += add[q];
+		__syncthreads();
+	}
+	uint64_t run[7];
+#pragma unroll
+	for (int q = 0; q < 7; ++q) run[q] = ctot[(int64_t)blockIdx.x * 8 + q] + sh[t][q] - s[q];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int64_t r = r0 + i;
+		if (r < nrec) {
+#pragma unroll
+			for (int q = 0; q < 7; ++q) { out[r * 8 + q] = run[q]; run[q] += v[i][q]; }
+			out[r * 8 + 7] = 0;
+		}
+	}
+}
+
+/* lf2[i] = (C2[a] + #{i' < i : B2[i'] = a}) << 3 | a, a = B2[i]   (fm-index.c:211-216) */
+__global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, const uint64_t *tpre, Acc7 acc2, uint64_t *lf2)
+{
+	__shared__ uint64_t shbase[6];
+	__shared__ uint64_t shw[4][2];
+	const int64_t tile = blockIdx.x;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	if (t < 6) shbase[t] = (uint64_t)acc2.a[t] + tpre[tile * 8 + t];
+	const int64_t base = tile * RB3_TILE + (int64_t)t * 16;
+	uint8_t sym[16];
+	int nv = 0;
+	if (base + 16 <= n2) {
+		const uint4 v = *(const uint4*)(b2 + base);
+		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int i = 0; i < 16; ++i) sym[i] = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+		nv = 16;
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; ++i) { sym[i] = base + i < n2 ? b2[base + i] : 7; nv += (base + i < n2); }
+	}
+	// per-thread counts packed as 3 x 16-bit fields in two words (a = 0,1,2 | 3,4,5)
+	uint64_t c0 = 0, c1 = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t a = sym[i];
+		if (a < 3) c0 += 1ull << (16 * a); else if (a < 6) c1 += 1ull << (16 * (a - 3));
+	}
+	// exclusive scan over the 256 threads of the tile
+	uint64_t i0 = c0, i1 = c1;
+	for (int d = 1; d < 64; d <<= 1) {
+		uint64_t u0 = __shfl_up(i0, d), u1 = __shfl_up(i1, d);
+		if (lane >= d) i0 += u0, i1 += u1;
+	}
+	if (lane == 63) shw[wv][0] = i0, shw[wv][1] = i1;
+	__syncthreads();
+	uint64_t p0 = i0 - c0, p1 = i1 - c1;
+	for (int w = 0; w < wv; ++w) p0 += shw[w][0], p1 += shw[w][1];
+	// walk the 16 symbols
+	uint64_t out[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t a = sym[i] < 6 ? sym[i] : 0;
+		const uint64_t word = a < 3 ? p0 : p1;
+		const uint32_t sh = 16 * (a < 3 ? a : a - 3);
+		const uint64_t in_tile = (word >> sh) & 0xFFFFull;
+		out[i] = (shbase[a] + in_tile) << 3 | a;
+		if (a < 3) p0 += 1ull << sh; else p1 += 1ull << sh;
+	}
+	if (nv == 16) {
+#pragma unroll
+		for (int i = 0; i < 16; i += 2) {
+			ulonglong2 v; v.x = out[i], v.y = out[i + 1];
+			*(ulonglong2*)(lf2 + base + i) = v;
+		}
+	} else {
+		for (int i = 0; i < nv; ++i) lf2[base + i] = out[i];
+	}
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* LF chains (fm-index.c:160-175), one octet per walker                                        */
+/* ----------------------------------------------------------------------------------------- */
+
+/* A WALKER follows one string of the batch right to left: row kb of B2 and its insertion point
+ * ka in B1 advance together, ka' = C1[c] + rank_B1(c, ka), kb' = LF_B2(kb), and pos[kb] = ka+kb
+ * is recorded (fm-index.c:166-173).  Walkers 0..m2-1 start at the sentinel rows with the exact
+ * ka = m1 (fm-index.c:164).  To get parallelism out of long strings, extra walkers start at
+ * every row kb >= m2 with kb % 2^logM == 0, knowing only lo = 0 <= ka <= hi = n1.  Both bounds
+ * obey the same recurrence and LF is monotone, so lo <= ka <= hi stays true; once lo == hi
+ * (the suffix read so far no longer occurs in B1's text) the walker is exact and starts
+ * recording.  A walker stops at the next start row unless it is exact, in which case it keeps
+ * going through rows nobody has recorded yet (the unresolved head of the next segment) until it
+ * meets a recorded row or the start of the string.  Every recorded value is exact, so two
+ * walkers that overlap write identical numbers and no ordering between workgroups is needed.
+ */
+__device__ __forceinline__ int64_t ld_pos(const int64_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_pos(int64_t *p, int64_t v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, int64_t *pos, int64_t n2, int64_t m2,
+		int logM, int64_t nwalk, unsigned long long *qhead, unsigned long long *nsteps)
+{
+	const int lane = threadIdx.x & 63, j = lane & 7;
+	const int64_t M = logM > 0 ? (1LL << logM) : 0;
+	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
+	bool active = false, exact = false, foreign = false;
+	int64_t kb = 0, lo = 0, hi = 0;
+	unsigned long long steps = 0;
+	for (;;) {
+		if (!active) {
+			uint32_t w0 = 0, w1 = 0;
+			if (j == 0) {
+				unsigned long long w = atomicAdd(qhead, 1ull);
+				w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+			}
+			w0 = oct_bcast0(w0, j), w1 = oct_bcast0(w1, j);
+			const int64_t wid = (int64_t)((uint64_t)w1 << 32 | w0);
+			if (wid >= nwalk) break;
+			if (wid < m2) {
+				kb = wid, lo = hi = b1.m, exact = true;
+			} else {
+				kb = first_marked + ((wid - m2) << logM);
+				lo = 0, hi = b1.n, exact = (b1.n == 0);
+				if (ld_pos(&pos[kb]) != RB3_UNSET) continue; // an exact walker already came through
+			}
+			foreign = false, active = true;
+		}
+		// one LF step
+		const uint64_t x = lf2[kb];
+		RankLoad rl, rh;
+		oct_rank_issue(b1, lo, j, rl);
+		if (!exact) oct_rank_issue(b1, hi, j, rh);
+		const int c = (int)(x & 7u);
+		++steps;
+		if (exact) {
+			if (foreign && ld_pos(&pos[kb]) != RB3_UNSET) { active = false; continue; }
+			if (j == 0) st_pos(&pos[kb], lo + kb);
+		}
+		if (c == 0) { active = false; continue; }
+		lo = oct_rank_finish(rl, c, j);
+		if (!exact) {
+			hi = oct_rank_finish(rh, c, j);
+			exact = (lo == hi);
+		}
+		kb = (int64_t)(x >> 3);
+		if (M && kb >= m2 && (kb & (M - 1)) == 0) {
+			if (!exact) { active = false; continue; }
+			foreign = true;
+		}
+	}
+	// per-wave step count (statistics only)
+	unsigned long long s = steps;
+	for (int d = 32; d >= 8; d >>= 1) s += __shfl_xor(s, d);
+	if (lane == 0) atomicAdd(nsteps, s);
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* interleave + rebuild                                                                        */
+/* ----------------------------------------------------------------------------------------- */
+
+/* symbol at offset i of an existing index, one lane */
+__device__ __forceinline__ uint32_t idx_sym(const IdxView &ix, int64_t i)
+{
+	const int64_t g = i >> RB3_GRP_BITS;
+	const uint32_t koff = (uint32_t)i & (RB3_GRP - 1), lw = koff >> RB3_WIN_BITS;
+	const uint64_t sm = ix.grp64[g * 8 + 6];
+	const uint32_t s = (uint32_t)sm + __popc((uint32_t)(sm >> 32) & ((2u << lw) - 1u)) - 1u;
+	const uint32_t *sp = (const uint32_t*)(ix.slot16 + (int64_t)s * 8);
+	const uint32_t hdr0 = sp[0];
+	const uint32_t off = koff - (hdr0 & 0xFFFFu);
+	if (!(hdr0 & RB3_SLOT_RLE)) {
+		const uint32_t jj = off >> 5, bit = off & 31;
+		const uint4 sl = ix.slot16[(int64_t)s * 8 + jj];
+		return ((sl.y >> bit) & 1u) | ((sl.z >> bit) & 1u) << 1 | ((sl.w >> bit) & 1u) << 2;
+	} else {
+		uint32_t p = 0;
+		for (int q = 0; q < RB3_RLE_CODES; ++q) {
+			const uint32_t word = sp[(q / 6) * 4 + 1 + (q % 6) / 2];
+			const uint32_t code = (q & 1) ? word >> 16 : word & 0xFFFFu; // q%6 and q have the same parity
+			const uint32_t sym = code & 7u, len = sym == 7u ? 0u : (code >> 3) + 1u;
+			if (off < p + len) return sym;
+			p += len;
+		}
+		return 7;
+	}
+}
+
+/* jg[g] = #{rows kb : pos[kb] < g * 8192}, g = 0..ngrp  (pos is strictly increasing) */
+__global__ void __launch_bounds__(256) k_group_rows(const int64_t *pos, int64_t n2, int64_t *jg, int64_t ngrp)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n2) return;
+	const int64_t a = i == 0 ? -1 : pos[i - 1] >> RB3_GRP_BITS; // group of the previous row
+	const int64_t b = i == n2 ? ngrp : pos[i] >> RB3_GRP_BITS;   // group of this row
+	for (int64_t g = a + 1; g <= b && g <= ngrp; ++g) jg[g] = i;
+}
+
+/* The 256 symbols of window [p0, p0+256) of the merged BWT.  Lane t gets positions
+ * p0 + 64u + t, u = 0..3, in sym[u]; 7 marks positions past the end.  `j` is the number of
+ * B2 rows placed before p0 and is advanced past this window.  One wave per workgroup. */
+template<bool FROM_PLAIN>
+__device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
+		int64_t p0, int64_t &j, uint8_t *symbuf, uint32_t sym[4], int lane)
+{
+	if (FROM_PLAIN) {
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int64_t p = p0 + 64 * u + lane;
+			sym[u] = p < ntot ? b2[p] : 7u;
+		}
+		return;
+	}
+	((uint32_t*)symbuf)[lane] = 0xFFFFFFFFu;
+	__syncthreads();
+	int nb2 = 0;
+	for (int u = 0; u < 4; ++u) {
+		const int64_t jj = j + 64 * u + lane;
+		const int64_t r = jj < n2 ? pos[jj] : INT64_MAX;
+		const bool in = r < p0 + RB3_WIN;
+		if (in) symbuf[r - p0] = b2[jj];
+		const uint64_t m = __ballot(in);
+		nb2 += __popcll(m);
+		if (m != ~0ull) break;
+	}
+	__syncthreads();
+	const int64_t a1 = p0 - j;
+	int before = 0;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		uint32_t s = symbuf[64 * u + lane];
+		const bool isb2 = s != 0xFFu;
+		const uint64_t m = __ballot(isb2);
+		const int mine = before + __popcll(m & ((1ull << lane) - 1ull));
+		before += __popcll(m);
+		if (!isb2) {
+			const int64_t p = p0 + 64 * u + lane;
+			s = p < ntot ? idx_sym(old, a1 + 64 * u + lane - mine) : 7u;
+		}
+		sym[u] = s;
+	}
+	j += nb2;
+	__syncthreads();
+}
+
+/* run heads of a window: H[u] bit t set <=> position 64u+t starts a run */
+__device__ __forceinline__ void window_heads(const uint32_t sym[4], int lane, uint64_t H[4])
+{
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		uint32_t prev = __shfl_up(sym[u], 1);
+		if (lane == 0) prev = 8u;
+		if (u > 0) { const uint32_t pl = __shfl(sym[u - 1], 63); if (lane == 0) prev = pl; }
+		H[u] = __ballot(sym[u] != 7u && sym[u] != prev);
+	}
+}
+
+/* pass 1: per group of the NEW index, symbol counts and the slot partition.
+ * gstat[g*8 + 0..5] = symbol counts, [6] = #slots, [7] = slot-start mask. */
+template<bool FROM_PLAIN>
+__global__ void __launch_bounds__(64) k_pass1(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
+		const int64_t *jg, uint32_t *gstat, int64_t ngrp)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t symbuf[RB3_WIN];
+	const int lane = threadIdx.x;
+	const int64_t g = blockIdx.x;
+	const int64_t W = (ntot >> RB3_WIN_BITS) + 1;
+	const int nvw = (int)(W - g * RB3_GRP_WINS < RB3_GRP_WINS ? W - g * RB3_GRP_WINS : RB3_GRP_WINS);
+	int64_t j = FROM_PLAIN ? 0 : jg[g];
+	uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+	int my_nruns = 0;
+	uint32_t my_first = 7, my_last = 7;
+	for (int lw = 0; lw < nvw; ++lw) {
+		const int64_t p0 = (g * RB3_GRP_WINS + lw) << RB3_WIN_BITS;
+		uint32_t sym[4];
+		gen_window<FROM_PLAIN>(old, pos, b2, n2, ntot, p0, j, symbuf, sym, lane);
+		uint64_t H[4];
+		window_heads(sym, lane, H);
+		const int nruns = __popcll(H[0]) + __popcll(H[1]) + __popcll(H[2]) + __popcll(H[3]);
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+#pragma unroll
+			for (int a = 0; a < 6; ++a) cnt[a] += __popcll(__ballot(sym[u] == (uint32_t)a));
+		const int64_t rem = ntot - p0;
+		const int nv = rem >= RB3_WIN ? RB3_WIN : rem > 0 ? (int)rem : 0;
+		const uint32_t first = __shfl(sym[0], 0);
+		uint32_t last = 7;
+		if (nv > 0) {
+			const int lu = (nv - 1) >> 6, ll = (nv - 1) & 63;
+			const uint32_t v = lu == 0 ? sym[0] : lu == 1 ? sym[1] : lu == 2 ? sym[2] : sym[3];
+			last = __shfl(v, ll);
+		}
+		if (lane == lw) my_nruns = nruns, my_first = first, my_last = last;
+	}
+	// partition the windows into slots: the largest aligned power-of-two groups with <= 48 runs
+	const uint32_t prev_last = __shfl_up(my_last, 1);
+	const int b = (lane > 0 && lane < nvw && my_nruns > 0 && prev_last == my_first) ? 1 : 0;
+	const int e = lane < nvw ? my_nruns - b : 0;
+	int P = e;
+	for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(P, d); if (lane >= d) P += t; }
+	int level = 0;
+#pragma unroll
+	for (int jl = 1; jl <= 5; ++jl) {
+		const int sz = 1 << jl, a = lane & ~(sz - 1);
+		const int Pa = __shfl(P, a), Pe = __shfl(P, (a + sz - 1) & 63), na = __shfl(my_nruns, a);
+		const bool ok = (a + sz <= nvw) && (Pe - Pa + na <= RB3_RLE_CODES);
+		if (ok && level == jl - 1) level = jl;
+	}
+	const bool start = lane < nvw && (lane & ((1 << level) - 1)) == 0;
+	const uint32_t mask = (uint32_t)__ballot(start);
+	if (lane < 8) {
+		uint32_t v = lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : lane == 3 ? cnt[3] : lane == 4 ? cnt[4] :
+			lane == 5 ? cnt[5] : lane == 6 ? (uint32_t)__popc(mask) : mask;
+		gstat[g * 8 + lane] = v;
+	}
+}
+
+/* pass 2: regenerate the symbols of each group and emit its slots and directory entry.
+ * gpre[g*8 + 0..5] = symbol counts before the group, [6] = slots before the group. */
+template<bool FROM_PLAIN>
+__global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
+		const int64_t *jg, const uint32_t *gstat, const uint64_t *gpre, Acc7 acc, rb3_grp_t *grp, uint4 *slot16, int64_t ngrp)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t symbuf[RB3_WIN];
+	__shared__ uint64_t ball[12];
+	__shared__ uint32_t csym[RB3_RLE_CODES + 16], clen[RB3_RLE_CODES + 16];
+	__shared__ uint32_t code16[RB3_RLE_CODES / 2];
+	const int lane = threadIdx.x;
+	const int64_t g = blockIdx.x;
+	const int64_t W = (ntot >> RB3_WIN_BITS) + 1;
+	const int nvw = (int)(W - g * RB3_GRP_WINS < RB3_GRP_WINS ? W - g * RB3_GRP_WINS : RB3_GRP_WINS);
+	const uint32_t mask = gstat[g * 8 + 7];
+	const uint64_t slot0 = gpre[g * 8 + 6];
+	if (lane == 0) {
+		rb3_grp_t e;
+		for (int a = 0; a < 6; ++a) e.cnt[a] = (uint64_t)acc.a[a] + gpre[g * 8 + a];
+		e.slot0 = (uint32_t)slot0, e.mask = mask, e.spare = 0;
+		grp[g] = e;
+	}
+	int64_t j = FROM_PLAIN ? 0 : jg[g];
+	uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, rel[6] = {0, 0, 0, 0, 0, 0};
+	int64_t sidx = (int64_t)slot0 - 1;
+	int slot_w0 = 0, slot_sz = 1, nc = 0;
+	for (int lw = 0; lw < nvw; ++lw) {
+		const int64_t p0 = (g * RB3_GRP_WINS + lw) << RB3_WIN_BITS;
+		uint32_t sym[4];
+		gen_window<FROM_PLAIN>(old, pos, b2, n2, ntot, p0, j, symbuf, sym, lane);
+		if (mask >> lw & 1u) { // a new slot begins
+			++sidx, slot_w0 = lw, nc = 0;
+			const uint32_t above = lw == 31 ? 0u : mask >> (lw + 1);
+			const int nxt = above ? lw + 1 + (__ffs(above) - 1) : nvw;
+			slot_sz = nxt - lw;
+#pragma unroll
+			for (int a = 0; a < 6; ++a) rel[a] = cnt[a];
+		}
+		const int64_t srem = ntot - ((g * RB3_GRP_WINS + slot_w0) << RB3_WIN_BITS);
+		const uint32_t nsym = srem <= 0 ? 0u : srem < (int64_t)slot_sz * RB3_WIN ? (uint32_t)srem : (uint32_t)(slot_sz * RB3_WIN);
+		const uint32_t hq = lane == 0 ? (uint32_t)(slot_w0 * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
+			lane == 1 ? rel[0] : lane == 2 ? rel[1] : lane == 3 ? rel[2] : lane == 4 ? rel[3] : lane == 5 ? rel[4] :
+			lane == 6 ? rel[5] : nsym;
+		if (slot_sz == 1) { // bit-plane slot
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+#pragma unroll
+				for (int p = 0; p < 3; ++p) {
+					const uint64_t m = __ballot((sym[u] >> p) & 1u);
+					if (lane == u * 3 + p) ball[u * 3 + p] = m;
+				}
+			__syncthreads();
+			if (lane < 8) {
+				const uint32_t *b32 = (const uint32_t*)ball;
+				uint4 v;
+				v.x = hq;
+				v.y = b32[(lane >> 1) * 6 + 0 + (lane & 1)];
+				v.z = b32[(lane >> 1) * 6 + 2 + (lane & 1)];
+				v.w = b32[(lane >> 1) * 6 + 4 + (lane & 1)];
+				slot16[sidx * 8 + lane] = v;
+			}
+			__syncthreads();
+		} else { // run slot: append this window's runs, merging across the window boundary
+			uint64_t H[4];
+			window_heads(sym, lane, H);
+			const int64_t rem = ntot - p0;
+			const int nv = rem >= RB3_WIN ? RB3_WIN : rem > 0 ? (int)rem : 0;
+			const int nr = __popcll(H[0]) + __popcll(H[1]) + __popcll(H[2]) + __popcll(H[3]);
+			const uint32_t fs = __shfl(sym[0], 0);
+			const int mg = (nc > 0 && nr > 0 && csym[nc - 1] == fs) ? 1 : 0;
+			int hb = 0;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				if (H[u] >> lane & 1ull) {
+					const int r = hb + __popcll(H[u] & ((1ull << lane) - 1ull));
+					const uint64_t up = lane == 63 ? 0ull : H[u] >> (lane + 1) << (lane + 1);
+					int nxt = nv;
+					if (up) nxt = 64 * u + (__ffsll((unsigned long long)up) - 1);
+					else {
+						for (int v = u + 1; v < 4; ++v)
+							if (H[v]) { nxt = 64 * v + (__ffsll((unsigned long long)H[v]) - 1); break; }
+					}
+					const int len = nxt - (64 * u + lane);
+					const int idx = nc + r - mg;
+					if (r == 0 && mg) clen[idx] += (uint32_t)len;
+					else csym[idx] = sym[u], clen[idx] = (uint32_t)len;
+				}
+				hb += __popcll(H[u]);
+			}
+			nc += nr - mg;
+			__syncthreads();
+			if (lw == slot_w0 + slot_sz - 1) { // flush the slot
+				if (lane < RB3_RLE_CODES) {
+					const uint32_t code = lane < nc ? ((clen[lane] - 1u) << 3 | csym[lane]) : 7u;
+					((uint16_t*)code16)[lane] = (uint16_t)code;
+				}
+				__syncthreads();
+				if (lane < 8) {
+					uint4 v;
+					v.x = hq, v.y = code16[lane * 3], v.z = code16[lane * 3 + 1], v.w = code16[lane * 3 + 2];
+					slot16[sidx * 8 + lane] = v;
+				}
+				__syncthreads();
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+#pragma unroll
+			for (int a = 0; a < 6; ++a) cnt[a] += __popcll(__ballot(sym[u] == (uint32_t)a));
+	}
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* export                                                                                      */
+/* ----------------------------------------------------------------------------------------- */
+
+__global__ void __launch_bounds__(256) k_export_plain(IdxView ix, int64_t beg, int64_t end, uint8_t *out)
+{
+	int64_t i = beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (; i < end; i += stride) out[i - beg] = (uint8_t)idx_sym(ix, i);
+}
+
+__global__ void __launch_bounds__(256) k_fill_iota(int64_t *p, int64_t n)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = i;
+}
+
+#endif

@@ -1,0 +1,203 @@
+"""ctypes binding of the C ABI in include/rb3gpu.h (librb3gpu.so).
+
+This module mirrors the reference's call surface for the merge path: `Rb3Gpu` stands where
+an `mrope_t*` stands in build.c, with `from_plain` = rb3_enc_plain2fmr (fm-index.c:114),
+`merge_plain` = rb3_fmi_merge_plain (fm-index.c:279), `get_acc` = rb3_fmi_get_acc and
+`export_runs` = the leaf iteration of rb3_enc_fmr2fmd (fm-index.c:31-54).
+
+There is NO CPU fallback: importing works anywhere, but creating a handle raises when the
+shared object or a HIP device is missing.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+ASIZE = 6
+
+_ERR = {0: "OK", -1: "ENODEV", -2: "ENOMEM", -3: "EINVAL", -4: "ESYMBOL", -5: "ESTATE", -6: "EINTERNAL"}
+
+
+class Rb3GpuError(RuntimeError):
+    def __init__(self, code, what):
+        RuntimeError.__init__(self, "%s failed: %s (%d)" % (what, _ERR.get(code, "?"), code))
+        self.code = code
+
+
+class Opt(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("split_log2", ctypes.c_int32), ("verbose", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("ms_h2d", ctypes.c_double), ("ms_lf", ctypes.c_double), ("ms_rank", ctypes.c_double),
+                ("ms_build", ctypes.c_double), ("ms_export", ctypes.c_double),
+                ("n_rank_launches", ctypes.c_int64), ("n_lf_steps", ctypes.c_int64), ("n_symbols_merged", ctypes.c_int64),
+                ("n_rounds", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+EMIT_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64)
+
+# name -> (restype, argtypes); every symbol declared in include/rb3gpu.h
+SYMBOLS = {
+    "rb3gpu_opt_init": (None, [ctypes.POINTER(Opt)]),
+    "rb3gpu_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "rb3gpu_create": (ctypes.c_void_p, [ctypes.POINTER(Opt)]),
+    "rb3gpu_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_from_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_merge_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_from_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_merge_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]),
+    "rb3gpu_mg_rank_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_rank1a_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_get_acc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_get_tot": (ctypes.c_int64, [ctypes.c_void_p]),
+    "rb3gpu_export_runs": (ctypes.c_int, [ctypes.c_void_p, EMIT_F, ctypes.c_void_p]),
+    "rb3gpu_export_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
+    "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),
+    "rb3gpu_dev_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "rb3gpu_dev_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "rb3gpu_dev_download": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "rb3gpu_dev_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "rb3gpu_device_count": (ctypes.c_int, []),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load librb3gpu.so (the in-tree build) and declare every prototype.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_GPU
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the engine is HIP-only; there is no CPU fallback)" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(lib, name)  # AttributeError if the header and the library disagree
+        f.restype, f.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+class Rb3Gpu:
+    """One accumulated BWT resident in the HBM of one MI355X."""
+
+    def __init__(self, device=0, split_log2=0, verbose=1):
+        self._lib = load_library()
+        n = self._lib.rb3gpu_device_count()
+        if n <= 0:
+            raise RuntimeError("no HIP device visible (rb3gpu_device_count=%d); the engine has no CPU fallback" % n)
+        opt = Opt()
+        self._lib.rb3gpu_opt_init(ctypes.byref(opt))
+        opt.device, opt.split_log2, opt.verbose = device, split_log2, verbose
+        self._h = self._lib.rb3gpu_create(ctypes.byref(opt))
+        if not self._h:
+            raise RuntimeError("rb3gpu_create failed on device %d" % device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rb3gpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r, what):
+        if r < 0:
+            raise Rb3GpuError(r, what)
+        return r
+
+    # -- the reference's entry points -------------------------------------------------------
+    def from_plain(self, bwt):
+        bwt = _u8(bwt)
+        self._chk(self._lib.rb3gpu_from_plain(self._h, bwt.size, bwt.ctypes.data), "rb3gpu_from_plain")
+
+    def merge_plain(self, bwt):
+        bwt = _u8(bwt)
+        self._chk(self._lib.rb3gpu_merge_plain(self._h, bwt.size, bwt.ctypes.data), "rb3gpu_merge_plain")
+
+    def mg_rank_plain(self, bwt):
+        bwt = _u8(bwt)
+        pos = np.empty(bwt.size, dtype=np.int64)
+        acc2 = np.zeros(7, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_mg_rank_plain(self._h, bwt.size, bwt.ctypes.data, pos.ctypes.data, acc2.ctypes.data), "rb3gpu_mg_rank_plain")
+        return pos, acc2
+
+    def rank1a(self, k):
+        k = np.ascontiguousarray(k, dtype=np.int64)
+        ok = np.empty((k.size, 6), dtype=np.int64)
+        self._chk(self._lib.rb3gpu_rank1a_batch(self._h, k.size, k.ctypes.data, ok.ctypes.data), "rb3gpu_rank1a_batch")
+        return ok
+
+    def get_acc(self):
+        acc = np.zeros(7, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_get_acc(self._h, acc.ctypes.data), "rb3gpu_get_acc")
+        return acc
+
+    def get_tot(self):
+        return int(self._lib.rb3gpu_get_tot(self._h))
+
+    def export_plain(self):
+        out = np.empty(self.get_tot(), dtype=np.uint8)
+        self._chk(self._lib.rb3gpu_export_plain(self._h, out.ctypes.data), "rb3gpu_export_plain")
+        return out
+
+    def export_runs(self):
+        runs = []
+
+        def emit(_data, c, l):
+            runs.append((c, l))
+            return 0
+        cb = EMIT_F(emit)
+        self._chk(self._lib.rb3gpu_export_runs(self._h, cb, None), "rb3gpu_export_runs")
+        return runs
+
+    def from_runs(self, runs):
+        arr = np.array([(l << 3) | c for c, l in runs], dtype=np.uint64)
+        self._chk(self._lib.rb3gpu_from_runs(self._h, arr.size, arr.ctypes.data), "rb3gpu_from_runs")
+
+    # -- device-resident variants ------------------------------------------------------------
+    def dev_upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_dev_alloc(self._h, arr.nbytes + 16, ctypes.byref(p)), "rb3gpu_dev_alloc")
+        self._chk(self._lib.rb3gpu_dev_upload(self._h, p, arr.ctypes.data, arr.nbytes), "rb3gpu_dev_upload")
+        return p
+
+    def dev_free(self, p):
+        self._chk(self._lib.rb3gpu_dev_free(self._h, p), "rb3gpu_dev_free")
+
+    def from_plain_dev(self, d_bwt, length):
+        self._chk(self._lib.rb3gpu_from_plain_dev(self._h, length, d_bwt), "rb3gpu_from_plain_dev")
+
+    def merge_plain_dev(self, d_bwt, length, commit=True):
+        self._chk(self._lib.rb3gpu_merge_plain_dev(self._h, length, d_bwt, 1 if commit else 0), "rb3gpu_merge_plain_dev")
+
+    def sync(self):
+        self._chk(self._lib.rb3gpu_sync(self._h), "rb3gpu_sync")
+
+    def stats(self):
+        st = Stats()
+        self._chk(self._lib.rb3gpu_stats(self._h, ctypes.byref(st)), "rb3gpu_stats")
+        return st.as_dict()
+
+    def stats_reset(self):
+        self._lib.rb3gpu_stats_reset(self._h)

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests import util
+    return util.Oracle()
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One HIP engine handle for the session; fails loudly when the HIP library/device is missing."""
+    from ropebwt3_amd import Rb3Gpu
+    h = Rb3Gpu(verbose=1)
+    yield h
+    h.close()

@@ -1,0 +1,133 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle.  Bit-exact: this is
+integer/byte work, so every comparison is array_equal."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _bwt_of(oracle, seqs, **kw):
+    return oracle.bwt(util.make_text(seqs, **kw))
+
+
+def test_k2_toy(engine, oracle):
+    # AGG then AGC, forward only -> GC$$GGAA through the merge
+    b1 = oracle.bwt(oracle.text(["AGG"], True, False))
+    b2 = oracle.bwt(oracle.text(["AGC"], True, False))
+    engine.from_plain(b1)
+    assert util.sym_str(engine.export_plain()) == "G$GA"
+    pos, acc2 = engine.mg_rank_plain(b2)
+    assert list(pos) == [1, 4, 6, 2]  # hand trace in SURVEY 8(c)
+    engine.merge_plain(b2)
+    assert util.sym_str(engine.export_plain()) == "GC$$GGAA"
+    assert list(engine.get_acc()) == [0, 2, 4, 5, 8, 8, 8]
+
+
+def test_k3_toy_both_strands(engine, oracle):
+    b1 = oracle.bwt(oracle.text(["AGG"]))
+    b2 = oracle.bwt(oracle.text(["AGC"]))
+    engine.from_plain(b1)
+    engine.merge_plain(b2)
+    assert util.sym_str(engine.export_plain()) == "GTCT$$G$CGGA$ACC"
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (255, 2), (256, 3), (257, 4), (8191, 5), (8192, 6), (8193, 7), (100000, 8)])
+def test_from_plain_roundtrip_and_rank(engine, oracle, n, seed):
+    rng = np.random.default_rng(seed)
+    # a mix of random symbols and long runs so that both slot kinds appear
+    parts, tot = [], 0
+    while tot < n:
+        if rng.random() < 0.5:
+            l = int(rng.integers(1, 600))
+            p = rng.integers(0, 6, size=l, dtype=np.uint8)
+        else:
+            l = int(rng.integers(1, 20000))
+            p = np.full(l, rng.integers(0, 6), dtype=np.uint8)
+        parts.append(p)
+        tot += l
+    b = np.concatenate(parts)[:n]
+    engine.from_plain(b)
+    assert engine.get_tot() == n
+    assert np.array_equal(engine.export_plain(), b)
+    runs = engine.export_runs()
+    assert sum(l for _, l in runs) == n
+    # rank at every boundary-ish offset and random offsets, incl. k = n (mrope.c:89-93)
+    ks = np.unique(np.concatenate([rng.integers(0, n + 1, size=2000), np.array([0, n, n // 2]),
+                                   np.arange(0, n + 1, 256)[:2000], np.clip(np.arange(0, n + 1, 8192) - 1, 0, n)]))
+    ok = engine.rank1a(ks)
+    occ = np.zeros((n + 1, 6), dtype=np.int64)
+    for c in range(6):
+        occ[1:, c] = np.cumsum(b == c)
+    assert np.array_equal(ok, occ[ks])
+    acc = engine.get_acc()
+    assert np.array_equal(acc[1:], np.cumsum(occ[n]))
+
+
+def _merge_case(engine, oracle, seqs1, seqs2, split_log2=None):
+    b1 = _bwt_of(oracle, seqs1)
+    b2 = _bwt_of(oracle, seqs2)
+    rb, acc2 = oracle.mg_rank(b1, b2)
+    want = oracle.merge(b1, b2)
+    engine.from_plain(b1)
+    pos, gacc2 = engine.mg_rank_plain(b2)
+    assert np.array_equal(gacc2, acc2)
+    assert np.array_equal(pos, rb >> 6)
+    engine.merge_plain(b2)
+    got = engine.export_plain()
+    assert np.array_equal(got, want)
+    return want
+
+
+def test_merge_random_genomes(engine, oracle):
+    rng = np.random.default_rng(11)
+    g0 = util.random_genome(rng, 30000)
+    g1 = util.mutate(rng, g0, 0.01)
+    _merge_case(engine, oracle, [g0], [g1])
+
+
+def test_merge_reads_with_duplicates(engine, oracle):
+    rng = np.random.default_rng(12)
+    g = util.random_genome(rng, 5000)
+    r1 = util.reads_from(rng, g, 300, 100)
+    r2 = util.reads_from(rng, g, 300, 100, err=0.01)
+    r2 += r1[:20]                      # exact duplicates: ties broken by sentinel order
+    r2.append(util.revcomp(r1[3]))     # reverse-complement duplicate
+    _merge_case(engine, oracle, r1, r2)
+
+
+def test_merge_incremental_many_rounds(engine, oracle):
+    rng = np.random.default_rng(13)
+    g = util.random_genome(rng, 3000)
+    seqs = [util.mutate(rng, g, 0.005) for _ in range(12)]
+    cur = _bwt_of(oracle, seqs[:1])
+    engine.from_plain(cur)
+    for s in seqs[1:]:
+        b2 = _bwt_of(oracle, [s])
+        cur = oracle.merge(cur, b2)
+        engine.merge_plain(b2)
+    assert np.array_equal(engine.export_plain(), cur)
+    # the .fmd is a function of the string list only: one big batch gives the same BWT
+    assert np.array_equal(cur, _bwt_of(oracle, seqs))
+
+
+def test_merge_new_suffix_after_everything(engine, oracle):
+    # ka == n1: the new strings sort after everything already indexed (mrope.c:89-93)
+    a = np.full(300, 1, dtype=np.uint8)
+    t = np.full(300, 4, dtype=np.uint8)
+    n5 = np.full(50, 5, dtype=np.uint8)
+    b1 = oracle.bwt(util.make_text([a], rev=False))
+    b2 = oracle.bwt(util.make_text([t, n5], rev=False))
+    want = oracle.merge(b1, b2)
+    engine.from_plain(b1)
+    engine.merge_plain(b2)
+    assert np.array_equal(engine.export_plain(), want)
+
+
+def test_bad_symbol_rejected(engine):
+    from ropebwt3_amd import Rb3GpuError
+    b = np.array([1, 2, 0, 9, 0], dtype=np.uint8)
+    with pytest.raises(Rb3GpuError) as e:
+        engine.from_plain(b)
+    assert e.value.code == -4

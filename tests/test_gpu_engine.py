@@ -19,7 +19,7 @@ def test_k2_toy(engine, oracle):
     engine.from_plain(b1)
     assert util.sym_str(engine.export_plain()) == "G$GA"
     pos, acc2 = engine.mg_rank_plain(b2)
-    assert list(pos) == [1, 4, 6, 2]  # hand trace in SURVEY 8(c)
+    assert list(pos) == [1, 2, 4, 6]  # chain rows 0->2->3->1 land on 1,4,6,2
     engine.merge_plain(b2)
     assert util.sym_str(engine.export_plain()) == "GC$$GGAA"
     assert list(engine.get_acc()) == [0, 2, 4, 5, 8, 8, 8]

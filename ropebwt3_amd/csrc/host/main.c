@@ -1,0 +1,519 @@
+/*
+ * main.c -- `ropebwt3-amd`: the `build` command of ropebwt3 with the merge path running on an
+ * MI355X through the C ABI of include/rb3gpu.h.  Same options, same input handling and the
+ * same output bytes as the reference's build.c:136-263 (FMD and plain output are byte-identical;
+ * FMR is loadable by the reference but, as in the reference, not canonical).
+ *
+ * Host side stays C: sequence parsing (seqio.c), per-batch suffix sorting (sais.c), FMD/FMR
+ * codecs (fmd.c, fmr.c).  What build.c does on an mrope_t* is done on an rb3gpu_t*:
+ *   rb3_enc_plain2fmr  (build.c:77,223)  -> rb3gpu_from_plain
+ *   rb3_fmi_merge_plain (build.c:78,226) -> rb3gpu_merge_plain
+ *   rb3_enc_fmd2fmr / mr_restore (180-181) -> rb3h_index_read_runs + rb3gpu_from_runs
+ *   rb3_enc_fmr2fmd + rld_dump (249-252), mr_dump (247), mr_print_bwt (254) -> rb3gpu_export_runs
+ *     feeding rb3h_fmdw_* / rb3h_fmrw_* / the plain printer
+ * There is no CPU merge path in this program: without a HIP device it exits with an error.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <getopt.h>
+#include <pthread.h>
+#include "rb3host.h"
+#include "rb3gpu.h"
+
+#define BF_NO_FOR 0x1
+#define BF_NO_REV 0x2
+#define BF_LINE   0x4
+
+enum { FMT_PLAIN = 0, FMT_FMD, FMT_FMR };
+
+typedef struct {
+	int64_t flag, batch_size;
+	int fmt, n_threads, sais_threads, block_len, max_nodes;
+	int device, split_log2, rebatch;
+} bopt_t;
+
+static void bopt_init(bopt_t *o) /* build.c:31-41 */
+{
+	memset(o, 0, sizeof(*o));
+	o->n_threads = 4, o->sais_threads = 0, o->fmt = FMT_PLAIN;
+	o->block_len = 512, o->max_nodes = 64, o->batch_size = 7000000000LL;
+	o->device = 0, o->split_log2 = 0, o->rebatch = 0;
+}
+
+static int usage_build(FILE *fp, const bopt_t *opt)
+{
+	fprintf(fp, "Usage: ropebwt3-amd build [options] <in.fa> [...]\n");
+	fprintf(fp, "Options:\n");
+	fprintf(fp, "  Algorithm:\n");
+	fprintf(fp, "    -m NUM      batch size [7G]\n");
+	fprintf(fp, "    -t INT      total number of threads [%d]\n", opt->n_threads);
+	fprintf(fp, "    -p INT      #threads for sais and run sais and merge together (more RAM) [%d]\n", opt->sais_threads);
+	fprintf(fp, "    -l INT      leaf block size in B+-tree (FMR output only) [%d]\n", opt->block_len);
+	fprintf(fp, "    -n INT      max number children per internal node (FMR output only) [%d]\n", opt->max_nodes);
+	fprintf(fp, "    --gpu INT   HIP device ordinal [%d]\n", opt->device);
+	fprintf(fp, "    --split INT start extra LF walkers every 2^INT rows (0=auto, -1=never) [%d]\n", opt->split_log2);
+	fprintf(fp, "    --rebatch   let a batch span input files (same output, fewer merge rounds)\n");
+	fprintf(fp, "  Input:\n");
+	fprintf(fp, "    -i FILE     read existing index from FILE []\n");
+	fprintf(fp, "    -L          one sequence per line in the input\n");
+	fprintf(fp, "    -F          no forward strand\n");
+	fprintf(fp, "    -R          no reverse strand\n");
+	fprintf(fp, "  Output:\n");
+	fprintf(fp, "    -o FILE     output to FILE [stdout]\n");
+	fprintf(fp, "    -d          dump in the fermi-delta format (FMD)\n");
+	fprintf(fp, "    -b          dump in the ropebwt format (FMR)\n");
+	fprintf(fp, "    -S FILE     save the current index to FILE after each input file []\n");
+	fprintf(fp, "  Not available in this build (ropebwt2 insertion and debugging formats): -2 -s -r -T -e\n");
+	return fp == stdout ? 0 : 1;
+}
+
+/* ---- run sinks --------------------------------------------------------------------------- */
+
+typedef struct { uint64_t *a; int64_t n, m; } runvec_t;
+
+static int sink_runvec(void *data, int c, int64_t l)
+{
+	runvec_t *v = (runvec_t*)data;
+	if (v->n == v->m) {
+		v->m = v->m ? v->m * 2 : 1 << 16;
+		v->a = (uint64_t*)realloc(v->a, (size_t)v->m * 8);
+		if (v->a == 0) return -1;
+	}
+	v->a[v->n++] = (uint64_t)l << 3 | (uint64_t)c;
+	return 0;
+}
+
+static int sink_fmd(void *data, int c, int64_t l) { return rb3h_fmdw_enc((rb3h_fmdw_t*)data, l, c); }
+static int sink_fmr(void *data, int c, int64_t l) { return rb3h_fmrw_enc((rb3h_fmrw_t*)data, l, c); }
+
+static int sink_plain(void *data, int c, int64_t l) /* mr_print_bwt, mrope.c:201-214 */
+{
+	FILE *fp = (FILE*)data;
+	char buf[4096];
+	memset(buf, "$ACGTN"[c], l < 4096 ? (size_t)l : 4096);
+	while (l > 0) {
+		size_t t = l < 4096 ? (size_t)l : 4096;
+		if (fwrite(buf, 1, t, fp) != t) return -1;
+		l -= (int64_t)t;
+	}
+	return 0;
+}
+
+static int dump_fmr(rb3gpu_t *h, const bopt_t *opt, FILE *fp)
+{
+	int64_t acc[7];
+	rb3h_fmrw_t *w;
+	int ret;
+	rb3gpu_get_acc(h, acc);
+	w = rb3h_fmrw_init(acc, opt->max_nodes, opt->block_len);
+	if (w == 0) return -1;
+	ret = rb3gpu_export_runs(h, sink_fmr, w);
+	if (ret == 0) ret = rb3h_fmrw_dump(w, fp);
+	rb3h_fmrw_destroy(w);
+	return ret;
+}
+
+/* ---- batches ----------------------------------------------------------------------------- */
+
+typedef struct { int64_t n_seq, len; uint8_t *bwt; int ret; } batch_t;
+
+static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
+{
+	int ret;
+	if (!*has_index) {
+		ret = rb3gpu_from_plain(h, b->len, b->bwt);
+		if (ret == 0 && rb3h_verbose >= 3)
+			fprintf(stderr, "[M::%s::%.3f*%.2f] encoded the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
+	} else {
+		ret = rb3gpu_merge_plain(h, b->len, b->bwt);
+		if (ret == 0 && rb3h_verbose >= 3)
+			fprintf(stderr, "[M::%s::%.3f*%.2f] merged the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
+	}
+	if (ret < 0) {
+		fprintf(stderr, "ERROR: the GPU engine failed on a batch of %ld symbols: %s\n", (long)b->len, rb3gpu_strerror(ret));
+		return ret;
+	}
+	*has_index = 1;
+	return 0;
+}
+
+/* 2-stage pipeline (build.c:55-83, 186-201): a producer thread reads and suffix-sorts batch
+ * i+1 while the calling thread merges batch i on the GPU. */
+typedef struct {
+	pthread_mutex_t mtx;
+	pthread_cond_t cv;
+	batch_t *slot;       /* one batch in flight */
+	int done;
+} pipe_t;
+
+typedef struct {
+	const bopt_t *opt;
+	int n_files;
+	char **files;
+	pipe_t *q;
+	int64_t n_empty;
+	int err;
+} producer_t;
+
+static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_threads, batch_t **out)
+{
+	batch_t *b;
+	int r = rb3h_build_bwt(n_seq, seq->l, seq->s, n_threads);
+	if (r < 0) {
+		fprintf(stderr, "ERROR: failed to construct the partial BWT (code %d)\n", r);
+		return -1;
+	}
+	if (rb3h_verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)seq->l);
+	b = (batch_t*)calloc(1, sizeof(batch_t));
+	b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s;
+	seq->s = 0, seq->l = seq->m = 0; /* ownership moves to the batch */
+	*out = b;
+	(void)opt;
+	return 0;
+}
+
+/* read every input file, cutting batches as io.c:104-125 does; emit(b) is called per batch */
+static int for_each_batch(const bopt_t *opt, int n_files, char **files, int n_threads, int (*emit)(void*, batch_t*, const char*, int), void *data, int64_t *n_empty)
+{
+	rb3h_buf_t seq = {0, 0, 0};
+	int64_t n_seq_acc = 0;
+	int i, ret = 0;
+	for (i = 0; i < n_files && ret == 0; ++i) {
+		rb3h_seqio_t *fp = rb3h_seq_open(files[i], !!(opt->flag & BF_LINE));
+		int64_t n_seq;
+		if (fp == 0) {
+			if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: failed to open file '%s'\n", files[i]);
+			continue; /* build.c:208-211 */
+		}
+		for (;;) {
+			const int64_t l0 = seq.l;
+			n_seq = rb3h_seq_read(fp, &seq, opt->batch_size, !(opt->flag & BF_NO_FOR), !(opt->flag & BF_NO_REV), n_empty);
+			if (n_seq < 0) {
+				if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: FASTX parsing error (code %ld)\n", (long)n_seq);
+				break;
+			}
+			if (n_seq == 0 && seq.l == l0) break; /* EOF */
+			n_seq_acc += n_seq;
+			if (rb3h_verbose >= 3)
+				fprintf(stderr, "[M::%s::%.3f*%.2f] read %ld symbols from file '%s'\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)(seq.l - l0), files[i]);
+			if (opt->rebatch && !(opt->batch_size > 0 && seq.l > opt->batch_size)) break; /* keep filling from the next file */
+			{
+				batch_t *b;
+				if (sort_batch(opt, &seq, n_seq_acc, n_threads, &b) < 0) { ret = -1; break; }
+				n_seq_acc = 0;
+				if ((ret = emit(data, b, files[i], 0)) != 0) break;
+			}
+		}
+		rb3h_seq_close(fp);
+		if (ret == 0 && !(opt->rebatch && seq.l > 0)) ret = emit(data, 0, files[i], 1); /* end of file i */
+	}
+	if (ret == 0 && seq.l > 0) { /* the last, partly filled re-batched batch */
+		batch_t *b;
+		if (sort_batch(opt, &seq, n_seq_acc, n_threads, &b) < 0) ret = -1;
+		else if ((ret = emit(data, b, files[n_files - 1], 0)) == 0) ret = emit(data, 0, files[n_files - 1], 1);
+	}
+	free(seq.s);
+	return ret;
+}
+
+typedef struct {
+	rb3gpu_t *h;
+	const bopt_t *opt;
+	int has_index;
+	const char *fn_tmp;
+} consumer_t;
+
+static int consume(void *data, batch_t *b, const char *fn, int end_of_file)
+{
+	consumer_t *c = (consumer_t*)data;
+	if (b) {
+		int r = process_batch(c->h, b, &c->has_index);
+		free(b->bwt); free(b);
+		if (r < 0) return r;
+	}
+	if (end_of_file && c->fn_tmp && c->has_index) { /* build.c:232-238 */
+		FILE *fp = fopen(c->fn_tmp, "wb");
+		if (fp != 0) {
+			dump_fmr(c->h, c->opt, fp);
+			fclose(fp);
+			if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] saved the current index to '%s'\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), c->fn_tmp);
+		}
+	}
+	(void)fn;
+	return 0;
+}
+
+static int produce(void *data, batch_t *b, const char *fn, int end_of_file)
+{
+	producer_t *p = (producer_t*)data;
+	(void)fn;
+	if (b == 0) return 0; /* -S is not combined with -p (as in the reference, build.c:186) */
+	pthread_mutex_lock(&p->q->mtx);
+	while (p->q->slot != 0) pthread_cond_wait(&p->q->cv, &p->q->mtx);
+	p->q->slot = b;
+	pthread_cond_broadcast(&p->q->cv);
+	pthread_mutex_unlock(&p->q->mtx);
+	(void)end_of_file;
+	return 0;
+}
+
+static void *producer_main(void *arg)
+{
+	producer_t *p = (producer_t*)arg;
+	p->err = for_each_batch(p->opt, p->n_files, p->files, p->opt->sais_threads, produce, p, &p->n_empty);
+	pthread_mutex_lock(&p->q->mtx);
+	p->q->done = 1;
+	pthread_cond_broadcast(&p->q->cv);
+	pthread_mutex_unlock(&p->q->mtx);
+	return 0;
+}
+
+static const struct option long_opts[] = {
+	{ "gpu", required_argument, 0, 301 },
+	{ "split", required_argument, 0, 302 },
+	{ "rebatch", no_argument, 0, 303 },
+	{ 0, 0, 0, 0 }
+};
+
+int main_build(int argc, char *argv[])
+{
+	bopt_t opt;
+	int c, ret = 0, has_index = 0;
+	char *fn_in = 0, *fn_tmp = 0;
+	rb3gpu_t *h;
+	rb3gpu_opt_t gopt;
+	int64_t n_empty = 0;
+
+	bopt_init(&opt);
+	optind = 1;
+	while ((c = getopt_long(argc, argv, "l:n:m:t:2sri:LFRo:dbTS:p:e", long_opts, 0)) >= 0) {
+		if (c == 'm') opt.batch_size = rb3h_parse_num(optarg);
+		else if (c == 't') opt.n_threads = atoi(optarg);
+		else if (c == 'p') opt.sais_threads = atoi(optarg);
+		else if (c == 'l') opt.block_len = atoi(optarg);
+		else if (c == 'n') opt.max_nodes = atoi(optarg);
+		else if (c == '2' || c == 's' || c == 'r') {
+			fprintf(stderr, "ERROR: -%c selects the ropebwt2 insertion algorithm, which this build does not include; the default (suffix sorting + merge) gives the same BWT for -2\n", c);
+			return 1;
+		} else if (c == 'T' || c == 'e') {
+			fprintf(stderr, "ERROR: output format -%c is not available in this build; use -d (FMD), -b (FMR) or the default plain text\n", c);
+			return 1;
+		} else if (c == 'i') fn_in = optarg;
+		else if (c == 'L') opt.flag |= BF_LINE;
+		else if (c == 'F') opt.flag |= BF_NO_FOR;
+		else if (c == 'R') opt.flag |= BF_NO_REV;
+		else if (c == 'o') { if (freopen(optarg, "wb", stdout) == 0) { fprintf(stderr, "ERROR: failed to write to '%s'\n", optarg); return 1; } }
+		else if (c == 'd') opt.fmt = FMT_FMD;
+		else if (c == 'b') opt.fmt = FMT_FMR;
+		else if (c == 'S') fn_tmp = optarg;
+		else if (c == 301) opt.device = atoi(optarg);
+		else if (c == 302) opt.split_log2 = atoi(optarg);
+		else if (c == 303) opt.rebatch = 1;
+		else if (c == '?') return 1;
+	}
+	if (argc == optind && fn_in == 0) return usage_build(stderr, &opt);
+	if ((opt.flag & BF_NO_FOR) && (opt.flag & BF_NO_REV)) {
+		fprintf(stderr, "ERROR: -F and -R together leave nothing to index\n");
+		return 1;
+	}
+
+	rb3gpu_opt_init(&gopt);
+	gopt.device = opt.device, gopt.split_log2 = opt.split_log2, gopt.verbose = rb3h_verbose;
+	h = rb3gpu_create(&gopt);
+	if (h == 0) {
+		fprintf(stderr, "ERROR: no usable MI355X/HIP device (device %d); the merge path has no CPU fallback\n", opt.device);
+		return 1;
+	}
+
+	if (fn_in) { /* build.c:172-184 */
+		runvec_t rv = {0, 0, 0};
+		int r = rb3h_index_read_runs(fn_in, sink_runvec, &rv);
+		if (r < 0 || rv.n == 0) {
+			if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: failed to open index file '%s'\n", fn_in);
+			free(rv.a); rb3gpu_destroy(h);
+			return 1;
+		}
+		r = rb3gpu_from_runs(h, rv.n, rv.a);
+		free(rv.a);
+		if (r < 0) {
+			fprintf(stderr, "ERROR: failed to load the index into HBM: %s\n", rb3gpu_strerror(r));
+			rb3gpu_destroy(h);
+			return 1;
+		}
+		has_index = 1;
+		if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] loaded the index from file '%s'\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), fn_in);
+	}
+
+	if (opt.sais_threads > 0 && argc - optind >= 1) { /* suffix sorting overlapped with the GPU merge */
+		pipe_t q;
+		producer_t p;
+		pthread_t tid;
+		consumer_t cs = { h, &opt, has_index, 0 };
+		pthread_mutex_init(&q.mtx, 0);
+		pthread_cond_init(&q.cv, 0);
+		q.slot = 0, q.done = 0;
+		memset(&p, 0, sizeof(p));
+		p.opt = &opt, p.n_files = argc - optind, p.files = argv + optind, p.q = &q;
+		pthread_create(&tid, 0, producer_main, &p);
+		for (;;) {
+			batch_t *b;
+			pthread_mutex_lock(&q.mtx);
+			while (q.slot == 0 && !q.done) pthread_cond_wait(&q.cv, &q.mtx);
+			b = q.slot, q.slot = 0;
+			pthread_cond_broadcast(&q.cv);
+			pthread_mutex_unlock(&q.mtx);
+			if (b == 0) break;
+			if (ret == 0) ret = consume(&cs, b, 0, 0);
+			else { free(b->bwt); free(b); }
+		}
+		pthread_join(tid, 0);
+		if (p.err != 0) ret = -1;
+		n_empty = p.n_empty, has_index = cs.has_index;
+	} else if (argc - optind >= 1) {
+		consumer_t cs = { h, &opt, has_index, fn_tmp };
+		ret = for_each_batch(&opt, argc - optind, argv + optind, opt.n_threads, consume, &cs, &n_empty);
+		has_index = cs.has_index;
+	}
+	if (n_empty > 0 && rb3h_verbose >= 2)
+		fprintf(stderr, "WARNING: skipped %ld empty sequence(s)\n", (long)n_empty);
+
+	if (ret != 0 || !has_index) { rb3gpu_destroy(h); return 1; }
+
+	if (opt.fmt == FMT_FMR) { /* build.c:245-260 */
+		ret = dump_fmr(h, &opt, stdout);
+	} else if (opt.fmt == FMT_FMD) {
+		rb3h_fmdw_t *w = rb3h_fmdw_init();
+		ret = w ? rb3gpu_export_runs(h, sink_fmd, w) : -1;
+		if (ret == 0) ret = rb3h_fmdw_finish(w);
+		if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
+		rb3h_fmdw_destroy(w);
+	} else {
+		ret = rb3gpu_export_runs(h, sink_plain, stdout);
+		fputc('\n', stdout);
+	}
+	fflush(stdout);
+	if (rb3h_verbose >= 3) {
+		rb3gpu_stats_t st;
+		rb3gpu_stats(h, &st);
+		fprintf(stderr, "[M::%s] GPU merge path: %ld symbols merged in %.3f ms (H2D %.3f + LF %.3f + rank %.3f + rebuild %.3f); index %.1f MB in HBM\n", __func__,
+				(long)st.n_symbols_merged, st.ms_h2d + st.ms_lf + st.ms_rank + st.ms_build, st.ms_h2d, st.ms_lf, st.ms_rank, st.ms_build, st.bytes_index / 1e6);
+	}
+	rb3gpu_destroy(h);
+	if (ret != 0) { fprintf(stderr, "ERROR: failed to write the index (code %d)\n", ret); return 1; }
+	return 0;
+}
+
+/* plain2fmd, main.c:299-331: every byte of the input is one BWT symbol ('\n' and '$' are 0) */
+int main_plain2fmd(int argc, char *argv[])
+{
+	int c, j;
+	rb3h_fmdw_t *w;
+	static uint8_t buf[0x10000];
+	optind = 1;
+	while ((c = getopt(argc, argv, "o:")) >= 0)
+		if (c == 'o' && freopen(optarg, "wb", stdout) == 0) return 1;
+	if (argc - optind < 1) {
+		fprintf(stdout, "Usage: ropebwt3-amd plain2fmd [-o output.fmd] <in.txt>\n");
+		return 0;
+	}
+	w = rb3h_fmdw_init();
+	for (j = optind; j < argc; ++j) {
+		FILE *fp = strcmp(argv[j], "-") == 0 ? stdin : fopen(argv[j], "r");
+		size_t i, len;
+		if (fp == 0) continue;
+		while ((len = fread(buf, 1, sizeof(buf), fp)) > 0)
+			for (i = 0; i < len; ++i) {
+				uint8_t x = buf[i];
+				if (x == '\n' || x == '$') x = 0;
+				else rb3h_char2nt6(1, &x);
+				rb3h_fmdw_enc(w, 1, x);
+			}
+		if (fp != stdin) fclose(fp);
+	}
+	rb3h_fmdw_finish(w);
+	rb3h_fmdw_dump(w, stdout);
+	rb3h_fmdw_destroy(w);
+	return 0;
+}
+
+/* recode: decode an FMD/FMR file on the host and write it back as plain text (default), FMD (-d)
+ * or FMR (-b).  Host-only utility; also the CPU-side test bench of the two codecs. */
+typedef struct { int64_t cnt[6]; runvec_t rv; } recode_t;
+
+static int sink_recode(void *data, int c, int64_t l)
+{
+	recode_t *r = (recode_t*)data;
+	r->cnt[c] += l;
+	return sink_runvec(&r->rv, c, l);
+}
+
+static int main_recode(int argc, char *argv[])
+{
+	int c, fmt = FMT_PLAIN, ret = 0, block_len = 0, max_nodes = 0;
+	int64_t i;
+	recode_t rc;
+	optind = 1;
+	while ((c = getopt(argc, argv, "dbo:l:n:")) >= 0) {
+		if (c == 'd') fmt = FMT_FMD;
+		else if (c == 'b') fmt = FMT_FMR;
+		else if (c == 'l') block_len = atoi(optarg);
+		else if (c == 'n') max_nodes = atoi(optarg);
+		else if (c == 'o' && freopen(optarg, "wb", stdout) == 0) return 1;
+	}
+	if (argc - optind < 1) { fprintf(stderr, "Usage: ropebwt3-amd recode [-d|-b] [-o out] <in.fmd|in.fmr>\n"); return 1; }
+	memset(&rc, 0, sizeof(rc));
+	if (rb3h_index_read_runs(argv[optind], sink_recode, &rc) < 0) { fprintf(stderr, "ERROR: failed to read '%s'\n", argv[optind]); free(rc.rv.a); return 1; }
+	if (fmt == FMT_FMD) {
+		rb3h_fmdw_t *w = rb3h_fmdw_init();
+		for (i = 0; i < rc.rv.n && ret == 0; ++i) ret = rb3h_fmdw_enc(w, (int64_t)(rc.rv.a[i] >> 3), (int)(rc.rv.a[i] & 7));
+		if (ret == 0) ret = rb3h_fmdw_finish(w);
+		if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
+		rb3h_fmdw_destroy(w);
+	} else if (fmt == FMT_FMR) {
+		int64_t acc[7];
+		rb3h_fmrw_t *w;
+		for (acc[0] = 0, c = 0; c < 6; ++c) acc[c + 1] = acc[c] + rc.cnt[c];
+		w = rb3h_fmrw_init(acc, max_nodes, block_len);
+		for (i = 0; i < rc.rv.n && ret == 0; ++i) ret = rb3h_fmrw_enc(w, (int64_t)(rc.rv.a[i] >> 3), (int)(rc.rv.a[i] & 7));
+		if (ret == 0) ret = rb3h_fmrw_dump(w, stdout);
+		rb3h_fmrw_destroy(w);
+	} else {
+		for (i = 0; i < rc.rv.n && ret == 0; ++i) ret = sink_plain(stdout, (int)(rc.rv.a[i] & 7), (int64_t)(rc.rv.a[i] >> 3));
+		fputc('\n', stdout);
+	}
+	free(rc.rv.a);
+	return ret == 0 ? 0 : 1;
+}
+
+static int usage(FILE *fp)
+{
+	fprintf(fp, "Usage: ropebwt3-amd <command> <arguments>\n");
+	fprintf(fp, "Commands:\n");
+	fprintf(fp, "    build      construct a BWT (merge path on an MI355X)\n");
+	fprintf(fp, "    plain2fmd  convert BWT in plain text to FMD (host only)\n");
+	fprintf(fp, "    recode     convert an FMD/FMR file to plain text, FMD (-d) or FMR (-b) (host only)\n");
+	fprintf(fp, "    version    print the version number\n");
+	return fp == stdout ? 0 : 1;
+}
+
+int main(int argc, char *argv[])
+{
+	int ret = 0;
+	rb3h_init();
+	if (argc == 1) return usage(stdout);
+	else if (strcmp(argv[1], "build") == 0) ret = main_build(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "plain2fmd") == 0) ret = main_plain2fmd(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "recode") == 0) ret = main_recode(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "version") == 0) { printf("%s\n", RB3H_VERSION); return 0; }
+	else { fprintf(stderr, "ERROR: unknown command '%s'\n", argv[1]); return 1; }
+	if (rb3h_verbose >= 3 && argc > 2 && ret == 0) { /* main.c:73-80 */
+		int i;
+		fprintf(stderr, "[M::%s] Version: %s\n", __func__, RB3H_VERSION);
+		fprintf(stderr, "[M::%s] CMD:", __func__);
+		for (i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
+		fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", __func__, rb3h_realtime(), rb3h_cputime(), rb3h_peakrss() / 1024.0 / 1024.0 / 1024.0);
+	}
+	return ret;
+}

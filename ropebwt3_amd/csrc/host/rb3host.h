@@ -1,0 +1,77 @@
+/*
+ * rb3host.h -- host-side C of the MI355X build: everything around the HIP merge engine that
+ * `ropebwt3 build` needs (sequence input, per-batch suffix sorting, FMD / FMR codecs).
+ * Citations are file:line in the reference tree.
+ */
+#ifndef RB3HOST_H
+#define RB3HOST_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RB3H_VERSION "3.10-r281-mi355x-r1"
+
+extern int rb3h_verbose;
+
+/* ---- misc (misc.c:7-16, 116-150) ---- */
+int64_t rb3h_parse_num(const char *str);
+double rb3h_realtime(void);
+double rb3h_cputime(void);
+double rb3h_percent_cpu(void);
+long rb3h_peakrss(void);
+void rb3h_init(void);
+
+/* ---- suffix sorting of one batch (sais-ss.c:50-56) ---- */
+int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads);
+
+/* ---- sequence input (io.c) ---- */
+typedef struct { int64_t l, m; uint8_t *s; } rb3h_buf_t;
+struct rb3h_seqio_s;
+typedef struct rb3h_seqio_s rb3h_seqio_t;
+rb3h_seqio_t *rb3h_seq_open(const char *fn, int is_line);                  /* io.c:60-72 */
+void rb3h_seq_close(rb3h_seqio_t *fp);                                     /* io.c:74-82 */
+/* io.c:104-125: fill `seq` with nt6(forward)+0 and nt6(revcomp)+0 per record until
+ * seq->l > max_len; returns the number of strings appended (0 at EOF) or <0 on a parse error;
+ * *n_empty counts records of length 0, which are skipped (out of contract in the reference) */
+int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is_for, int is_rev, int64_t *n_empty);
+void rb3h_char2nt6(int64_t l, uint8_t *s);                                 /* io.c:23-28 */
+void rb3h_revcomp6(int64_t l, uint8_t *s);                                 /* io.c:30-40 */
+
+/* ---- FMD (rld0) writer / reader ---- */
+struct rb3h_fmdw_s;
+typedef struct rb3h_fmdw_s rb3h_fmdw_t;
+rb3h_fmdw_t *rb3h_fmdw_init(void);                                         /* rld_init(6, 3), rld0.c:57-75 */
+int rb3h_fmdw_enc(rb3h_fmdw_t *w, int64_t l, int c);                        /* rld_enc, rld0.c:153-161 */
+int rb3h_fmdw_finish(rb3h_fmdw_t *w);                                      /* rld_enc_finish, rld0.c:206-216 */
+int rb3h_fmdw_dump(const rb3h_fmdw_t *w, FILE *fp);                         /* rld_dump, rld0.c:222-243 */
+void rb3h_fmdw_destroy(rb3h_fmdw_t *w);
+int64_t rb3h_fmdw_nbytes(const rb3h_fmdw_t *w);
+
+typedef int (*rb3h_run_f)(void *data, int c, int64_t l);
+/* decode every run of an FMD file in order (rld_restore + rld_dec, rld0.c:267-320, rld0.h:85-122) */
+int rb3h_fmd_read_runs(FILE *fp, rb3h_run_f emit, void *data, int64_t mcnt[6]);
+
+/* ---- FMR (mrope) writer / reader ---- */
+struct rb3h_fmrw_s;
+typedef struct rb3h_fmrw_s rb3h_fmrw_t;
+/* stream runs in BWT order, then dump the six ropes (mr_dump, mrope.c:152-159; rope_dump,
+ * rope.c:265-287).  cnt[6] = symbol counts of the whole BWT (rope a holds rows C[a]..C[a+1]). */
+rb3h_fmrw_t *rb3h_fmrw_init(const int64_t acc[7], int max_nodes, int block_len);
+int rb3h_fmrw_enc(rb3h_fmrw_t *w, int64_t l, int c);
+int rb3h_fmrw_dump(rb3h_fmrw_t *w, FILE *fp);
+void rb3h_fmrw_destroy(rb3h_fmrw_t *w);
+/* decode an FMR file (mr_restore, mrope.c:161-177; rope_restore, rope.c:289-330) */
+int rb3h_fmr_read_runs(FILE *fp, rb3h_run_f emit, void *data);
+
+/* open an index file of either kind and stream its runs; returns 0, or <0 on error */
+int rb3h_index_read_runs(const char *fn, rb3h_run_f emit, void *data);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,86 @@
+"""ctypes binding of the host-side C library (librb3host.so): per-batch suffix sorting and the
+FMD/FMR codecs.  These are the host halves of `ropebwt3 build` (sais-ss.c, rld0.c, mrope.c/rope.c
+dump format) written from scratch in C; Python only marshals buffers."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+_lib = None
+RUN_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64)
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB_HOST):
+        raise RuntimeError("%s is missing: run __graft_entry__.build()" % _build.LIB_HOST)
+    L = ctypes.CDLL(_build.LIB_HOST)
+    L.rb3h_build_bwt.restype = ctypes.c_int
+    L.rb3h_build_bwt.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+    L.rb3h_fmdw_init.restype = ctypes.c_void_p
+    L.rb3h_fmdw_enc.restype = ctypes.c_int
+    L.rb3h_fmdw_enc.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+    L.rb3h_fmdw_finish.restype = ctypes.c_int
+    L.rb3h_fmdw_finish.argtypes = [ctypes.c_void_p]
+    L.rb3h_fmdw_destroy.restype = None
+    L.rb3h_fmdw_destroy.argtypes = [ctypes.c_void_p]
+    L.rb3h_seq_open.restype = ctypes.c_void_p
+    L.rb3h_seq_open.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.rb3h_seq_close.restype = None
+    L.rb3h_seq_close.argtypes = [ctypes.c_void_p]
+    L.rb3h_seq_read.restype = ctypes.c_int64
+    L.rb3h_seq_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    L.rb3h_parse_num.restype = ctypes.c_int64
+    L.rb3h_parse_num.argtypes = [ctypes.c_char_p]
+    L.free.argtypes = [ctypes.c_void_p] if hasattr(L, "free") else None
+    _lib = L
+    return L
+
+
+class _Buf(ctypes.Structure):
+    _fields_ = [("l", ctypes.c_int64), ("m", ctypes.c_int64), ("s", ctypes.c_void_p)]
+
+
+def build_bwt(text, n_threads=1):
+    """text: uint8 array of 0-terminated nt6 strings -> its BWT (rb3_build_sais, sais-ss.c:50-56)"""
+    L = load_library()
+    t = np.ascontiguousarray(text, dtype=np.uint8).copy()
+    r = L.rb3h_build_bwt(0, t.size, t.ctypes.data, n_threads)
+    if r < 0:
+        raise ValueError("rb3h_build_bwt failed with code %d" % r)
+    return t
+
+
+def read_batches(path, is_line, max_len, fwd=True, rev=True):
+    """Iterate the batches `build` would cut from one file (rb3_seq_read, io.c:104-125):
+    yields (n_strings, text) with text a uint8 array."""
+    L = load_library()
+    fp = L.rb3h_seq_open(path.encode(), int(is_line))
+    if not fp:
+        raise IOError("cannot open %s" % path)
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    try:
+        while True:
+            b = _Buf(0, 0, None)
+            ne = ctypes.c_int64(0)
+            n = L.rb3h_seq_read(fp, ctypes.byref(b), max_len, int(fwd), int(rev), ctypes.byref(ne))
+            if n <= 0 and b.l == 0:
+                if b.s:
+                    libc.free(b.s)
+                if n < 0:
+                    raise ValueError("parse error %d" % n)
+                break
+            arr = np.ctypeslib.as_array(ctypes.cast(b.s, ctypes.POINTER(ctypes.c_uint8)), shape=(b.l,)).copy()
+            libc.free(b.s)
+            yield int(n), arr
+    finally:
+        L.rb3h_seq_close(fp)
+
+
+def parse_num(s):
+    return int(load_library().rb3h_parse_num(s.encode()))

@@ -1,0 +1,122 @@
+"""Host-side C (librb3host.so + the ropebwt3-amd CLI's host-only commands) against golden files
+written by the reference and against the oracle.  No GPU needed."""
+import gzip
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from ropebwt3_amd import _build, gpu, host
+from tests import util
+
+MAN = json.load(open(os.path.join(util.GOLDEN, "MANIFEST.json")))
+CLI = _build.BIN_CLI
+
+
+def run(cmd, inp=None):
+    r = subprocess.run(cmd, input=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    return r.stdout
+
+
+def test_sais_matches_oracle(oracle):
+    rng = np.random.default_rng(7)
+    for it in range(200):
+        seqs = [rng.integers(1, 1 + int(rng.integers(1, 6)), size=int(rng.integers(1, 30)), dtype=np.uint8) for _ in range(int(rng.integers(1, 6)))]
+        if it % 4 == 0:
+            seqs += [seqs[0].copy(), util.revcomp(seqs[0])]
+        t = util.make_text(seqs, rev=bool(it & 1))
+        assert np.array_equal(host.build_bwt(t), oracle.bwt(t))
+    g = util.random_genome(rng, 20000)
+    t = util.make_text([g, util.mutate(rng, g, 0.001), np.full(3000, 2, dtype=np.uint8)])
+    assert np.array_equal(host.build_bwt(t), oracle.bwt(t))
+
+
+def test_sais_rejects_bad_text():
+    with pytest.raises(ValueError):
+        host.build_bwt(np.array([1, 2, 3], dtype=np.uint8))          # no final sentinel
+    with pytest.raises(ValueError):
+        host.build_bwt(np.array([1, 0, 0, 2, 0], dtype=np.uint8))    # empty string (out of contract)
+    with pytest.raises(ValueError):
+        host.build_bwt(np.array([1, 9, 0], dtype=np.uint8))
+
+
+@pytest.mark.parametrize("name", [k for k, v in MAN.items() if "plain" in v])
+def test_fmd_writer_bit_exact(name, tmp_path):
+    ent = MAN[name]
+    plain = gzip.open(os.path.join(util.GOLDEN, ent["plain"])).read().strip()
+    p = tmp_path / "x.txt"
+    p.write_bytes(plain)  # no trailing newline: plain2fmd would count it as a sentinel (main.c:322)
+    fmd = run([CLI, "plain2fmd", str(p)])
+    assert hashlib.md5(fmd).hexdigest() == ent["fmd_md5"]
+    assert fmd == open(os.path.join(util.GOLDEN, ent["fmd"]), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["genomes12", "reads_fq", "copies3000", "longruns", "edge_chars"])
+def test_fmd_reader_and_recode(name, tmp_path):
+    ent = MAN[name]
+    src = os.path.join(util.GOLDEN, ent["fmd"])
+    plain = run([CLI, "recode", src])
+    assert hashlib.md5(plain).hexdigest() == ent["plain_md5"]
+    assert run([CLI, "recode", "-d", src]) == open(src, "rb").read()
+    fmr = tmp_path / "x.fmr"
+    fmr.write_bytes(run([CLI, "recode", "-b", src]))
+    assert run([CLI, "recode", "-d", str(fmr)]) == open(src, "rb").read()
+    if os.path.exists(util.REF_BIN):  # our FMR must load in the reference
+        assert run([util.REF_BIN, "build", "-i", str(fmr), "-d"]) == open(src, "rb").read()
+
+
+def test_fmr_reader_on_reference_file():
+    r = MAN["resume"]
+    got = run([CLI, "recode", "-d", os.path.join(util.GOLDEN, r["fmr"])])
+    assert got == open(os.path.join(util.GOLDEN, r["fmd"]), "rb").read()
+
+
+def test_seqio_fasta_fastq_lines(tmp_path, oracle):
+    fa = tmp_path / "a.fa"
+    fa.write_bytes(b";junk before the first header\n>s1 comment\nACGT\nacgn\n\n>s2\nTT\r\n>s3\n>s4\nGRY*\n")
+    got = list(host.read_batches(str(fa), False, 0))
+    assert len(got) == 1 and got[0][0] == 6  # s3 is empty and skipped
+    want = util.make_text([np.array([1, 2, 3, 4, 1, 2, 3, 5], dtype=np.uint8), np.array([4, 4], dtype=np.uint8), np.array([3, 5, 5, 5], dtype=np.uint8)])
+    assert np.array_equal(got[0][1], want)
+    fq = tmp_path / "a.fq.gz"
+    with gzip.open(str(fq), "wb") as f:
+        f.write(b"@r1\nACGT\n+\nIIII\n@r2 x\nGG\nCC\n+r2\nII\nII\n")
+    got = list(host.read_batches(str(fq), False, 0, True, False))
+    assert np.array_equal(got[0][1], np.array([1, 2, 3, 4, 0, 3, 3, 2, 2, 0], dtype=np.uint8))
+    ln = tmp_path / "a.txt"
+    ln.write_bytes(b"ACG\nTT\r\nA")
+    got = list(host.read_batches(str(ln), True, 0, True, False))
+    assert np.array_equal(got[0][1], np.array([1, 2, 3, 0, 4, 4, 0, 1, 0], dtype=np.uint8))
+    # batching rule io.c:114,119: stop after the record that makes the batch longer than max_len
+    got = list(host.read_batches(str(ln), True, 5, True, True))
+    assert [g[0] for g in got] == [2, 2, 2] or [g[0] for g in got] == [4, 2]
+    assert np.array_equal(np.concatenate([g[1] for g in got]), util.make_text([np.array([1, 2, 3], dtype=np.uint8), np.array([4, 4], dtype=np.uint8), np.array([1], dtype=np.uint8)]))
+
+
+def test_parse_num():
+    assert host.parse_num("7g") == 7000000000 and host.parse_num("500k") == 500000 and host.parse_num("2.5M") == 2500000 and host.parse_num("13") == 13
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(_build.INCLUDE, "rb3gpu.h")).read()
+    declared = set(re.findall(r"\b(rb3gpu_[a-z0-9_]+)\s*\(", hdr)) - {"rb3gpu_emit_f"}
+    assert declared == set(gpu.SYMBOLS), (declared ^ set(gpu.SYMBOLS))
+    lib = gpu.load_library()  # raises if the .so is missing; no compute call is made here
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.rb3gpu_strerror(-4).decode().startswith("BWT symbol")
+
+
+def test_no_cpu_fallback_without_device():
+    lib = gpu.load_library()
+    if lib.rb3gpu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError):
+        gpu.Rb3Gpu()
+    r = subprocess.run([CLI, "build", "-L", os.path.join(util.GOLDEN, "k2_fwd.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"no CPU fallback" in r.stderr

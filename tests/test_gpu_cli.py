@@ -1,0 +1,86 @@
+"""End-to-end `ropebwt3-amd build` on the GPU box: the .fmd must be byte-identical to the file the
+unmodified reference wrote for the same input (tests/golden), for every batching."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from ropebwt3_amd import _build
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+MAN = json.load(open(os.path.join(util.GOLDEN, "MANIFEST.json")))
+CLI = _build.BIN_CLI
+
+
+def run(args, inp=None):
+    r = subprocess.run([CLI] + args, input=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-600:]
+    return r.stdout, r.stderr.decode()
+
+
+CASES = [k for k in MAN if k != "resume"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_build_fmd_identical(name):
+    ent = MAN[name]
+    want = open(os.path.join(util.GOLDEN, ent["fmd"]), "rb").read()
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    for m in ent["m_variants"]:
+        out, err = run(["build"] + ent["flags"] + ["-m" + m, "-d"] + inputs)
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (name, m)
+        assert out == want
+    if "plain_text" in ent:
+        out, _ = run(["build"] + ent["flags"] + ["-m" + ent["m_variants"][-1]] + inputs)
+        assert out.decode().strip() == ent["plain_text"]
+
+
+def test_build_merge_really_ran():
+    ent = MAN["genomes12"]
+    out, err = run(["build", "-m45k", "-d", os.path.join(util.GOLDEN, ent["inputs"][0])])
+    assert err.count("merged the partial BWT") >= 5 and "GPU merge path" in err
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+
+
+@pytest.mark.parametrize("extra", [["-p2"], ["--rebatch", "-m300k"], ["--split", "5"], ["--split", "-1"], ["-p1", "--rebatch", "-m100k"]])
+def test_build_variants(extra):
+    ent = MAN["genomes12_files"]
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    out, _ = run(["build", "-d"] + extra + inputs)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+
+
+def test_stdin_input():
+    out, _ = run(["build", "-LR", "-m1", "-"], b"AGG\nAGC\n")
+    assert out == b"GC$$GGAA\n"
+
+
+@pytest.mark.parametrize("src", ["fmr", "fmd"])
+def test_resume_from_index(src, tmp_path):
+    r = MAN["resume"]
+    out, _ = run(["build", "-d", "-i", os.path.join(util.GOLDEN, r[src]), os.path.join(util.GOLDEN, r["rest"])])
+    assert hashlib.md5(out).hexdigest() == MAN[r["expect"]]["fmd_md5"]
+
+
+def test_fmr_output_and_checkpoint(tmp_path):
+    r = MAN["resume"]
+    ck = tmp_path / "ck.fmr"
+    fmr, _ = run(["build", "-b", "-S", str(ck), os.path.join(util.GOLDEN, r["first"])])
+    # FMR is not canonical; it must decode to the same BWT as the reference's FMD of the same input
+    for blob in (fmr, ck.read_bytes()):
+        p = tmp_path / "x.fmr"
+        p.write_bytes(blob)
+        got = subprocess.run([CLI, "recode", "-d", str(p)], stdout=subprocess.PIPE, check=True).stdout
+        assert got == open(os.path.join(util.GOLDEN, r["fmd"]), "rb").read()
+        if os.path.exists(util.REF_BIN):  # and the reference must be able to continue from it
+            out = subprocess.run([util.REF_BIN, "build", "-d", "-i", str(p), os.path.join(util.GOLDEN, r["rest"])], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+            assert hashlib.md5(out).hexdigest() == MAN[r["expect"]]["fmd_md5"]
+
+
+def test_unsupported_options_fail_cleanly():
+    r = subprocess.run([CLI, "build", "-2", "-L", os.path.join(util.GOLDEN, "k2_fwd.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"ropebwt2" in r.stderr

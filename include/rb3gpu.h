@@ -46,6 +46,7 @@ typedef struct {
 	double  ms_rank;             /* LF-chain / rank kernels (fm-index.c:160-175, 217-224) */
 	double  ms_build;            /* interleave + block-array rebuild (fm-index.c:237-249, 294-299) */
 	double  ms_export;           /* run / symbol export kernels + D2H */
+	double  ms_chain;            /* k_chain alone (HIP events on the launch stream): the dominant kernel */
 	int64_t n_rank_launches;     /* launches of the chain kernel */
 	int64_t n_lf_steps;          /* LF steps executed by the chain kernel (incl. speculative ones) */
 	int64_t n_symbols_merged;    /* sum of `len` over merge calls */

@@ -36,7 +36,7 @@ struct rb3gpu_s {
 	rb3_slot_t *slots = nullptr;
 	// scratch, grown on demand and kept between calls
 	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf;
-	hipEvent_t ev[6];
+	hipEvent_t ev[8];
 	int64_t bytes_owned = 0;
 	double t0 = 0;
 };
@@ -142,7 +142,7 @@ rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
 	h->dev = o.device, h->opt = o;
 	memset(&h->stt, 0, sizeof(h->stt));
 	if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
-	for (int i = 0; i < 6; ++i)
+	for (int i = 0; i < 8; ++i)
 		if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return nullptr; }
 	h->t0 = now_s();
 	return h;
@@ -165,7 +165,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	index_drop(h);
 	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf };
 	for (Buf *b : all) buf_release(h, *b);
-	for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev[i]);
+	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	(void)hipStreamDestroy(h->st);
 	delete h;
 }
@@ -289,8 +289,10 @@ static int rank_phase(rb3gpu_t *h, int64_t len, const int64_t acc2[7])
 	int64_t nblk = (nwalk + 31) / 32;
 	if (nblk > 256 * 8) nblk = 256 * 8;
 	if (nblk < 1) nblk = 1;
+	HIPCHK(hipEventRecord(h->ev[6], h->st));
 	hipLaunchKernelGGL(k_chain, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, (int64_t*)h->pos.p,
 			len, m2, logM, nwalk, qhead, nsteps);
+	HIPCHK(hipEventRecord(h->ev[7], h->st));
 	h->stt.n_rank_launches += 1;
 	h->stt.n_rounds += 1;
 	return 0;
@@ -321,6 +323,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	HIPCHK(hipStreamSynchronize(h->st));
 	h->stt.ms_lf += ev_ms(h->ev[0], h->ev[1]);
 	h->stt.ms_rank += ev_ms(h->ev[1], h->ev[2]);
+	h->stt.ms_chain += ev_ms(h->ev[6], h->ev[7]);
 	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
 	h->stt.n_lf_steps += (int64_t)hsteps[1];
 	h->stt.n_symbols_merged += len;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd (sqlite) outputs into small text/JSON files for profiles/.
+
+    python tools/prof_summary.py stats  <results.db> <out.txt>          # --kernel-trace --stats
+    python tools/prof_summary.py pmc    <results.db> <COUNTER> <out.txt> # one --pmc pass
+"""
+import json
+import sqlite3
+import sys
+
+
+def short(name):
+    for k in ("k_chain", "k_pass1", "k_pass2", "k_lf2", "k_tile_hist", "k_scan_chunk_totals", "k_scan_chunks", "k_scan_records",
+              "k_group_rows", "k_export_plain", "k_rank_batch", "k_pos_check", "k_jump", "k_ckpt"):
+        if k in name:
+            return k + ("<plain>" if ("ILb1" in name or "<true>" in name) else "<merge>" if ("ILb0" in name or "<false>" in name) else "")
+    return name[:60]
+
+
+def stats(db, out):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats summary (durations in us)\n")
+        f.write("%-28s %8s %14s %12s %12s %12s %7s\n" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
+        for name, n, s, a, mn, mx in rows:
+            f.write("%-28s %8d %14.1f %12.2f %12.2f %12.2f %6.2f%%\n" % (short(name), n, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+    print(open(out).read())
+
+
+def pmc(db, counter, out):
+    con = sqlite3.connect(db)
+    cols = [d[0] for d in con.execute("select * from counters_collection limit 1").description]
+    ncol = "counter_name" if "counter_name" in cols else "name"
+    kcol = "kernel_name" if "kernel_name" in cols else "name"
+    q = "select %s, count(*), sum(value), avg(value) from counters_collection where %s = ? group by %s order by sum(value) desc" % (kcol, ncol, kcol)
+    rows = con.execute(q, (counter,)).fetchall()
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --pmc %s summary (raw counter units; see MI355X_MICROARCH.md HBM section)\n" % counter)
+        f.write("%-28s %8s %18s %18s\n" % ("kernel", "calls", "sum", "avg_per_dispatch"))
+        for name, n, s, a in rows:
+            f.write("%-28s %8d %18.1f %18.1f\n" % (short(name), n, s, a))
+    print(open(out).read())
+    return rows
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "cols":
+        con = sqlite3.connect(sys.argv[2])
+        print([d[0] for d in con.execute("select * from counters_collection limit 1").description])
+        print(con.execute("select * from counters_collection limit 3").fetchall())

@@ -78,6 +78,39 @@ int rb3gpu_merge_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt);
 int rb3gpu_from_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt);
 int rb3gpu_merge_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int commit);
 
+/* An LF WALKER follows one string of the batch right to left (the loop of rb3_mg_rank1_plain,
+ * fm-index.c:160-175).  The reference starts one per string; this engine can also start walkers in
+ * the middle of long strings (see rb3gpu_kernels.h).  Callers that still hold the suffix array of
+ * the batch (sais-ss.c:23-26 has it when the BWT is written) can say where: */
+typedef struct {
+	int64_t row;                 /* row of B2 (rank of the suffix in the batch) where the walker starts */
+	int64_t ka0;                 /* exact insertion point of that suffix in B1 if known (sentinel rows:
+	                                acc[1] of the index, fm-index.c:164), else -1 */
+	int64_t nsteps;              /* LF steps to the start row of the next walker to the left (text distance) */
+	int64_t flags;               /* RB3GPU_WK_* */
+} rb3gpu_walker_t;
+#define RB3GPU_KA_SENTINEL (-2)  /* ka0 of a sentinel row: the engine substitutes acc[1] of the index */
+#define RB3GPU_WK_STOP  1        /* stop after nsteps and report the arrival value (next segment is on another GPU) */
+#define RB3GPU_WK_CHECK 2        /* the rows ahead may already be recorded: check each before recording */
+
+/* rb3gpu_merge_plain with an explicit walker list (host memory); same result, more parallelism
+ * and no dependence on how the suffix array scatters the strings */
+int rb3gpu_merge_plain_walkers(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers);
+int rb3gpu_merge_plain_dev_walkers(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit);
+
+/* The same merge in three stages, for a multi-GPU build with the index replicated and the batch's
+ * walkers sharded by text range: every rank calls begin (LF array of the whole batch), walk on ITS
+ * walkers (several calls allowed: hand-off values arriving from the neighbour rank start fix-up
+ * walkers), then the ranks combine pos[] (RCCL all-reduce MAX over the device buffer returned by
+ * rb3gpu_mg_pos_ptr: unset rows are -1) and every rank calls finish.  d_pos_ext, if not NULL, is a
+ * caller-owned device buffer of len int64 to use for pos[].  arrive[i] (host, optional) receives
+ * the value walker i arrived with at the end of its segment when it has RB3GPU_WK_STOP (-1 if it
+ * was still inexact). */
+int rb3gpu_mg_begin(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, void *d_pos_ext, int64_t acc2[RB3GPU_ASIZE+1]);
+int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *arrive);
+int rb3gpu_mg_pos_ptr(rb3gpu_t *h, void **d_pos, int64_t *len);
+int rb3gpu_mg_finish(rb3gpu_t *h, int commit);
+
 /* rb3_mg_rank_plain(fa, len, seq, rb, acc, n_threads), fm-index.c:202-225 -- the rank phase
  * alone, for parity tests against the reference's rb[] array: on return pos[kb] = ka[kb]+kb,
  * the merged position of row kb of B2 (= rb[kb]>>6 in the reference), and acc2[7] the C array

@@ -27,6 +27,10 @@ void rb3h_init(void);
 
 /* ---- suffix sorting of one batch (sais-ss.c:50-56) ---- */
 int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads);
+/* same, plus the LF-walker list for rb3gpu_merge_plain_walkers (layout = rb3gpu_walker_t): the
+ * sampled inverse suffix array is free here because the suffix array is still in memory */
+typedef struct { int64_t row, ka0, nsteps, flags; } rb3h_walker_t;
+int rb3h_build_bwt_walkers(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads, int64_t step, int64_t *n_walkers, rb3h_walker_t **walkers);
 
 /* ---- sequence input (io.c) ---- */
 typedef struct { int64_t l, m; uint8_t *s; } rb3h_buf_t;

@@ -24,20 +24,74 @@
 #undef SIDX
 #undef SSUF
 
-int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
+static int check_text(int64_t *n_seq, int64_t len, const uint8_t *seq)
 {
 	int64_t i, k = 0;
-	(void)n_threads;
 	if (len <= 0 || seq[len - 1] != 0) return -1;
 	for (i = 0; i < len; ++i) {
 		if (seq[i] > 5) return -1;
 		k += (seq[i] == 0);
 	}
-	if (n_seq <= 0) n_seq = k;
-	if (k != n_seq) return -1;
+	if (*n_seq <= 0) *n_seq = k;
+	if (k != *n_seq) return -1;
 	for (i = 1; i < len; ++i) /* empty strings are out of contract */
 		if (seq[i] == 0 && seq[i - 1] == 0) return -2;
 	if (seq[0] == 0) return -2;
-	if (len + n_seq + 16 < INT32_MAX) return sais_bwt_32(n_seq, len, seq); /* sais-ss.c:52 picks 32/64 bit the same way */
-	return sais_bwt_64(n_seq, len, seq);
+	return 0;
+}
+
+int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
+{
+	int r;
+	(void)n_threads;
+	if ((r = check_text(&n_seq, len, seq)) < 0) return r;
+	if (len + n_seq + 16 < INT32_MAX) return sais_bwt_32(n_seq, len, seq, 0, 0); /* sais-ss.c:52 picks 32/64 bit the same way */
+	return sais_bwt_64(n_seq, len, seq, 0, 0);
+}
+
+/* BWT plus the list of LF walkers for the GPU merge: one per string (its sentinel row) and one
+ * at every text position that is a multiple of `step` strictly inside a string, in text order. */
+int rb3h_build_bwt_walkers(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads, int64_t step, int64_t *n_walkers, rb3h_walker_t **walkers)
+{
+	int r;
+	int64_t *ckrow, i, b, j, nw = 0, mw;
+	rb3h_walker_t *w;
+	uint8_t *isend; /* 1 bit per checkpoint slot: position is a sentinel or the first symbol of a string */
+	(void)n_threads;
+	*n_walkers = 0, *walkers = 0;
+	if (step < 2) return -3;
+	if ((r = check_text(&n_seq, len, seq)) < 0) return r;
+	ckrow = (int64_t*)malloc((size_t)(len / step + 2) * 8);
+	isend = (uint8_t*)calloc((size_t)(len / step + 2), 1);
+	mw = n_seq + len / step + 2;
+	w = (rb3h_walker_t*)malloc((size_t)mw * sizeof(rb3h_walker_t));
+	if (!ckrow || !isend || !w) { free(ckrow); free(isend); free(w); return -1; }
+	for (i = 0; i < len; i += step)
+		if (seq[i] == 0 || i == 0 || seq[i - 1] == 0) isend[i / step] = 1;
+	/* string boundaries must be read before the text is overwritten */
+	{
+		int64_t *ends = (int64_t*)malloc((size_t)n_seq * 8);
+		if (!ends) { free(ckrow); free(isend); free(w); return -1; }
+		for (i = 0, j = 0; i < len; ++i) if (seq[i] == 0) ends[j++] = i;
+		r = len + n_seq + 16 < INT32_MAX ? sais_bwt_32(n_seq, len, seq, step, ckrow) : sais_bwt_64(n_seq, len, seq, step, ckrow);
+		if (r < 0) { free(ends); free(ckrow); free(isend); free(w); return r; }
+		for (j = 0, b = 0; j < n_seq; ++j) { /* string j occupies [b, e), sentinel at e */
+			const int64_t e = ends[j];
+			int64_t prev = -1, p = (b / step + 1) * step; /* first multiple of step > b */
+			for (; p < e; p += step) {
+				if (isend[p / step]) continue;
+				w[nw].row = ckrow[p / step], w[nw].ka0 = -1, w[nw].flags = 0;
+				w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : p - prev;
+				prev = p, ++nw;
+			}
+			w[nw].row = j, w[nw].ka0 = -2 /* sentinel row: exact, = acc[1] of the index */, w[nw].flags = 0;
+			w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : e - prev;
+			++nw;
+			b = e + 1;
+		}
+		free(ends);
+	}
+	free(ckrow); free(isend);
+	*n_walkers = nw, *walkers = w;
+	return 0;
 }

@@ -104,8 +104,10 @@ static int SFN(sais_main)(const SIDX *T, SIDX *SA, SIDX n, SIDX K)
 }
 
 /* seq[0..len): symbols 0..5, strings 0-terminated, seq[len-1] == 0.  Replaced in place by the
- * BWT in generalised-suffix-array order (the j-th 0 sorts before the (j+1)-th). */
-static int SFN(sais_bwt)(int64_t n_seq, int64_t len, uint8_t *seq)
+ * BWT in generalised-suffix-array order (the j-th 0 sorts before the (j+1)-th).  If ck_step > 0,
+ * ckrow[p / ck_step] receives the BWT row of the suffix starting at every text position p that is
+ * a multiple of ck_step (a sampled inverse suffix array; ckrow must hold len / ck_step + 1). */
+static int SFN(sais_bwt)(int64_t n_seq, int64_t len, uint8_t *seq, int64_t ck_step, int64_t *ckrow)
 {
 	SIDX n = (SIDX)len + 1, K = (SIDX)n_seq + 6, i, k = 0;
 	SIDX *T = (SIDX*)malloc((size_t)n * sizeof(SIDX));
@@ -117,6 +119,9 @@ static int SFN(sais_bwt)(int64_t n_seq, int64_t len, uint8_t *seq)
 	if (SFN(sais_main)(T, SA, n, K) < 0) { free(T); free(SA); return -1; }
 	free(T);
 	/* SA[0] = n-1 is the virtual sentinel; row i of the BWT is SA[i+1] (sais-ss.c:23-26) */
+	if (ck_step > 0)
+		for (i = 1; i < n; ++i)
+			if (SA[i] % ck_step == 0) ckrow[SA[i] / ck_step] = (int64_t)i - 1;
 	for (i = 1; i < n; ++i) {
 		SIDX p = SA[i];
 		SA[i] = p == 0 ? seq[len - 1] : seq[p - 1];

@@ -35,7 +35,12 @@ struct rb3gpu_s {
 	rb3_grp_t *grp = nullptr;
 	rb3_slot_t *slots = nullptr;
 	// scratch, grown on demand and kept between calls
-	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf;
+	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl;
+	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
+	int mg_active = 0;
+	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
+	const uint8_t *mg_b2 = nullptr;
+	int64_t *mg_pos = nullptr;
 	hipEvent_t ev[8];
 	int64_t bytes_owned = 0;
 	double t0 = 0;
@@ -163,7 +168,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	(void)hipSetDevice(h->dev);
 	(void)hipStreamSynchronize(h->st);
 	index_drop(h);
-	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf };
+	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	(void)hipStreamDestroy(h->st);
@@ -270,66 +275,134 @@ static int pick_split(const rb3gpu_t *h, int64_t len, int64_t m2)
 	return lg;
 }
 
-/* the rank phase: on return h->pos holds ka[kb]+kb for every row of B2 */
-static int rank_phase(rb3gpu_t *h, int64_t len, const int64_t acc2[7])
+/* ---- the merge in three stages (the collective of a multi-GPU build goes between 2 and 3) ---- */
+
+int rb3gpu_mg_begin(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, void *d_pos_ext, int64_t acc2_out[RB3GPU_ASIZE+1])
 {
+	if (!h || len <= 0 || !d_bwt) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
 	int r;
-	if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
-	if ((r = buf_ensure(h, h->misc, 256)) < 0) return r;
-	const int64_t m2 = acc2[1];
-	const int logM = pick_split(h, len, m2);
-	int64_t nwalk = m2;
-	if (logM > 0) {
-		const int64_t M = 1LL << logM, first = (m2 + M - 1) >> logM << logM;
-		if (first < len) nwalk += (len - first + M - 1) >> logM;
+	h->mg_active = 0;
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	if ((r = lf_build(h, len, d_bwt, h->mg_acc2)) < 0) return r;
+	if (h->mg_acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	if (d_pos_ext) h->mg_pos = (int64_t*)d_pos_ext;
+	else {
+		if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
+		h->mg_pos = (int64_t*)h->pos.p;
 	}
-	HIPCHK(hipMemsetAsync(h->pos.p, 0xff, (size_t)len * 8, h->st));
+	if ((r = buf_ensure(h, h->misc, 256)) < 0) return r;
+	HIPCHK(hipMemsetAsync(h->mg_pos, 0xff, (size_t)len * 8, h->st));
 	HIPCHK(hipMemsetAsync(h->misc.p, 0, 256, h->st));
+	HIPCHK(hipEventRecord(h->ev[2], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_lf += ev_ms(h->ev[0], h->ev[1]);
+	h->stt.ms_rank += ev_ms(h->ev[1], h->ev[2]);
+	h->mg_len = len, h->mg_b2 = d_bwt, h->mg_active = 1;
+	if (acc2_out) memcpy(acc2_out, h->mg_acc2, sizeof(h->mg_acc2));
+	return 0;
+}
+
+/* run LF walkers: walkers == NULL -> one per sentinel row plus automatic SA-order splitting */
+int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *arrive)
+{
+	if (!h || (walkers && n_walkers <= 0)) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (!h->mg_active) return RB3GPU_ESTATE;
+	const int64_t len = h->mg_len, m2 = h->mg_acc2[1];
 	unsigned long long *qhead = (unsigned long long*)h->misc.p, *nsteps = qhead + 1;
+	int r, logM = 0;
+	int64_t nwalk;
+	Walker *dwl = nullptr;
+	int64_t *darr = nullptr;
+	if (walkers) {
+		for (int64_t i = 0; i < n_walkers; ++i)
+			if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) return RB3GPU_EINVAL;
+		nwalk = n_walkers;
+		if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
+		dwl = (Walker*)h->wl.p, darr = (int64_t*)((char*)h->wl.p + (size_t)n_walkers * 32);
+		{ // ka0 == RB3GPU_KA_SENTINEL: a sentinel row, whose insertion point is acc[1] of the index (fm-index.c:164)
+			rb3gpu_walker_t *tmp = (rb3gpu_walker_t*)malloc((size_t)n_walkers * sizeof(rb3gpu_walker_t));
+			if (!tmp) return RB3GPU_ENOMEM;
+			memcpy(tmp, walkers, (size_t)n_walkers * sizeof(rb3gpu_walker_t));
+			for (int64_t i = 0; i < n_walkers; ++i)
+				if (tmp[i].ka0 == RB3GPU_KA_SENTINEL) tmp[i].ka0 = h->acc[1];
+			hipError_t e = hipMemcpy(dwl, tmp, (size_t)n_walkers * 32, hipMemcpyHostToDevice);
+			free(tmp);
+			HIPCHK(e);
+		}
+		HIPCHK(hipMemsetAsync(darr, 0xff, (size_t)n_walkers * 8, h->st));
+	} else {
+		logM = pick_split(h, len, m2);
+		nwalk = m2;
+		if (logM > 0) {
+			const int64_t M = 1LL << logM, first = (m2 + M - 1) >> logM << logM;
+			if (first < len) nwalk += (len - first + M - 1) >> logM;
+		}
+	}
+	HIPCHK(hipMemsetAsync(qhead, 0, 8, h->st));
 	int64_t nblk = (nwalk + 31) / 32;
 	if (nblk > 256 * 8) nblk = 256 * 8;
 	if (nblk < 1) nblk = 1;
 	HIPCHK(hipEventRecord(h->ev[6], h->st));
-	hipLaunchKernelGGL(k_chain, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, (int64_t*)h->pos.p,
-			len, m2, logM, nwalk, qhead, nsteps);
+	if (walkers)
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true>), dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, h->mg_pos,
+				len, m2, 0, (const Walker*)dwl, nwalk, darr, qhead, nsteps);
+	else
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, h->mg_pos,
+				len, m2, logM, (const Walker*)nullptr, nwalk, (int64_t*)nullptr, qhead, nsteps);
 	HIPCHK(hipEventRecord(h->ev[7], h->st));
-	h->stt.n_rank_launches += 1;
-	h->stt.n_rounds += 1;
+	if (walkers && arrive) HIPCHK(hipMemcpyAsync(arrive, darr, (size_t)n_walkers * 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	const float ms = ev_ms(h->ev[6], h->ev[7]);
+	h->stt.ms_chain += ms, h->stt.ms_rank += ms;
+	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	return 0;
 }
 
-static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only)
+int rb3gpu_mg_pos_ptr(rb3gpu_t *h, void **d_pos, int64_t *len)
 {
+	if (!h || !d_pos) return RB3GPU_EINVAL;
+	if (!h->mg_active) return RB3GPU_ESTATE;
+	*d_pos = h->mg_pos;
+	if (len) *len = h->mg_len;
+	return 0;
+}
+
+/* stage 3: validate pos[], interleave and rebuild; rank_only skips the rebuild */
+static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
+{
+	if (!h->mg_active) return RB3GPU_ESTATE;
+	const int64_t len = h->mg_len, ntot = h->n + len;
 	int r;
-	int64_t acc2[7];
-	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
-	HIPCHK(hipEventRecord(h->ev[0], h->st));
-	if ((r = lf_build(h, len, d_b2, acc2)) < 0) return r;
-	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
-	HIPCHK(hipEventRecord(h->ev[1], h->st));
-	if ((r = rank_phase(h, len, acc2)) < 0) return r;
+	h->mg_active = 0;
+	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
-	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
+	hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)h->mg_pos, len, ntot, misc + 2);
+	unsigned long long hm[4] = {0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(hm, misc, 32, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.n_lf_steps += (int64_t)hm[1];
+	if (hm[2] != 0 || hm[3] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset and %llu out of order\n", hm[2], hm[3]);
+		return RB3GPU_EINTERNAL;
+	}
 	rb3_grp_t *grp = nullptr;
 	rb3_slot_t *slots = nullptr;
-	int64_t ngrp = 0, nslots = 0, acc[7], ntot = h->n + len;
+	int64_t ngrp = 0, nslots = 0, acc[7];
 	if (!rank_only) {
-		if ((r = build_index<false>(h, len, d_b2, (const int64_t*)h->pos.p, ntot, &grp, &slots, &ngrp, &nslots, acc)) < 0) return r;
+		if ((r = build_index<false>(h, len, h->mg_b2, (const int64_t*)h->mg_pos, ntot, &grp, &slots, &ngrp, &nslots, acc)) < 0) return r;
 	}
 	HIPCHK(hipEventRecord(h->ev[3], h->st));
-	if (host_pos) HIPCHK(hipMemcpyAsync(host_pos, h->pos.p, (size_t)len * 8, hipMemcpyDeviceToHost, h->st));
-	unsigned long long hsteps[2] = {0, 0};
-	HIPCHK(hipMemcpyAsync(hsteps, h->misc.p, 16, hipMemcpyDeviceToHost, h->st));
+	if (host_pos) HIPCHK(hipMemcpyAsync(host_pos, h->mg_pos, (size_t)len * 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
-	h->stt.ms_lf += ev_ms(h->ev[0], h->ev[1]);
-	h->stt.ms_rank += ev_ms(h->ev[1], h->ev[2]);
-	h->stt.ms_chain += ev_ms(h->ev[6], h->ev[7]);
 	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
-	h->stt.n_lf_steps += (int64_t)hsteps[1];
 	h->stt.n_symbols_merged += len;
 	if (!rank_only) {
 		int bad = 0;
-		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + acc2[a]) bad = 1;
+		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + h->mg_acc2[a]) bad = 1;
 		if (bad) {
 			dev_free(h, grp, (size_t)ngrp * sizeof(rb3_grp_t));
 			dev_free(h, slots, (size_t)nslots * sizeof(rb3_slot_t));
@@ -342,9 +415,25 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		}
 	}
 	if (h->opt.verbose >= 3)
-		fprintf(stderr, "[M::%s::%.3f] merged %lld symbols (%lld strings): lf %.3f ms, rank %.3f ms (%llu LF steps), rebuild %.3f ms\n", __func__,
-				now_s() - h->t0, (long long)len, (long long)acc2[1], ev_ms(h->ev[0], h->ev[1]), ev_ms(h->ev[1], h->ev[2]), hsteps[1], ev_ms(h->ev[2], h->ev[3]));
+		fprintf(stderr, "[M::%s::%.3f] merged %lld symbols (%lld strings): %llu LF steps, rebuild %.3f ms\n", __func__,
+				now_s() - h->t0, (long long)len, (long long)h->mg_acc2[1], hm[1], ev_ms(h->ev[2], h->ev[3]));
 	return 0;
+}
+
+int rb3gpu_mg_finish(rb3gpu_t *h, int commit)
+{
+	if (!h) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	return mg_finish(h, commit, nullptr, 0);
+}
+
+static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
+		int64_t n_walkers, const rb3gpu_walker_t *walkers)
+{
+	int r;
+	if ((r = rb3gpu_mg_begin(h, len, d_b2, nullptr, host_acc2)) < 0) return r;
+	if ((r = rb3gpu_mg_walk(h, n_walkers, walkers, nullptr)) < 0) return r;
+	return mg_finish(h, commit, host_pos, rank_only);
 }
 
 static int upload_b2(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
@@ -400,7 +489,7 @@ int rb3gpu_merge_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int c
 {
 	if (!h || len <= 0 || !d_bwt) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
-	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0);
+	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, 0, nullptr);
 }
 
 int rb3gpu_merge_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
@@ -410,7 +499,24 @@ int rb3gpu_merge_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
 	if (h->n <= 0) return RB3GPU_ESTATE;
 	int r;
 	if ((r = upload_b2(h, len, bwt)) < 0) return r;
-	return merge_core(h, len, (const uint8_t*)h->b2.p, 1, nullptr, nullptr, 0);
+	return merge_core(h, len, (const uint8_t*)h->b2.p, 1, nullptr, nullptr, 0, 0, nullptr);
+}
+
+int rb3gpu_merge_plain_walkers(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers)
+{
+	if (!h || len <= 0 || !bwt || n_walkers <= 0 || !walkers) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->n <= 0) return RB3GPU_ESTATE;
+	int r;
+	if ((r = upload_b2(h, len, bwt)) < 0) return r;
+	return merge_core(h, len, (const uint8_t*)h->b2.p, 1, nullptr, nullptr, 0, n_walkers, walkers);
+}
+
+int rb3gpu_merge_plain_dev_walkers(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit)
+{
+	if (!h || len <= 0 || !d_bwt || n_walkers <= 0 || !walkers) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_walkers, walkers);
 }
 
 int rb3gpu_mg_rank_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1])
@@ -420,7 +526,7 @@ int rb3gpu_mg_rank_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t *
 	if (h->n <= 0) return RB3GPU_ESTATE;
 	int r;
 	if ((r = upload_b2(h, len, bwt)) < 0) return r;
-	return merge_core(h, len, (const uint8_t*)h->b2.p, 0, pos, acc2, 1);
+	return merge_core(h, len, (const uint8_t*)h->b2.p, 0, pos, acc2, 1, 0, nullptr);
 }
 
 int rb3gpu_rank1a_batch(rb3gpu_t *h, int64_t n, const int64_t *k, int64_t *ok)

@@ -73,20 +73,33 @@ __device__ __forceinline__ uint32_t oct_exscan(uint32_t v, int j)
 
 struct RankLoad { // everything that depends on k only, so loads can be issued before c is known
 	uint64_t gw;     // word j of the group entry
+	uint64_t sm;     // slot0 | mask << 32 of the group entry
 	uint4 sl;        // slice j of the slot
 	uint32_t koff;   // k & 8191
 };
 
-__device__ __forceinline__ void oct_rank_issue(const IdxView &ix, int64_t k, int j, RankLoad &r)
+/* round trip 1: the group directory entry (one 64-B line, two requests) */
+__device__ __forceinline__ void oct_rank_issue_grp(const IdxView &ix, int64_t k, int j, RankLoad &r)
 {
 	const int64_t g = k >> RB3_GRP_BITS;
 	r.koff = (uint32_t)k & (RB3_GRP - 1);
-	const uint32_t lw = r.koff >> RB3_WIN_BITS;
 	r.gw = ix.grp64[g * 8 + j];
-	const uint64_t sm = ix.grp64[g * 8 + 6];
-	const uint32_t slot0 = (uint32_t)sm, mask = (uint32_t)(sm >> 32);
+	r.sm = ix.grp64[g * 8 + 6];
+}
+
+/* round trip 2: the slot (one 128-B line, 16 B per lane) */
+__device__ __forceinline__ void oct_rank_issue_slot(const IdxView &ix, int j, RankLoad &r)
+{
+	const uint32_t lw = r.koff >> RB3_WIN_BITS;
+	const uint32_t slot0 = (uint32_t)r.sm, mask = (uint32_t)(r.sm >> 32);
 	const uint32_t s = slot0 + __popc(mask & ((2u << lw) - 1u)) - 1u;
 	r.sl = ix.slot16[(int64_t)s * 8 + j];
+}
+
+__device__ __forceinline__ void oct_rank_issue(const IdxView &ix, int64_t k, int j, RankLoad &r)
+{
+	oct_rank_issue_grp(ix, k, j, r);
+	oct_rank_issue_slot(ix, j, r);
 }
 
 /* number of symbols equal to c among the first `off` symbols of the slot, this lane's share */
@@ -358,16 +371,30 @@ __global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, cons
 
 /* A WALKER follows one string of the batch right to left: row kb of B2 and its insertion point
  * ka in B1 advance together, ka' = C1[c] + rank_B1(c, ka), kb' = LF_B2(kb), and pos[kb] = ka+kb
- * is recorded (fm-index.c:166-173).  Walkers 0..m2-1 start at the sentinel rows with the exact
- * ka = m1 (fm-index.c:164).  To get parallelism out of long strings, extra walkers start at
- * every row kb >= m2 with kb % 2^logM == 0, knowing only lo = 0 <= ka <= hi = n1.  Both bounds
- * obey the same recurrence and LF is monotone, so lo <= ka <= hi stays true; once lo == hi
- * (the suffix read so far no longer occurs in B1's text) the walker is exact and starts
- * recording.  A walker stops at the next start row unless it is exact, in which case it keeps
- * going through rows nobody has recorded yet (the unresolved head of the next segment) until it
- * meets a recorded row or the start of the string.  Every recorded value is exact, so two
- * walkers that overlap write identical numbers and no ordering between workgroups is needed.
+ * is recorded (fm-index.c:166-173).  The sentinel rows 0..m2-1 start walkers with the exact
+ * ka = m1 (fm-index.c:164).  To get parallelism out of long strings, extra walkers start in the
+ * middle of strings knowing only lo = 0 <= ka <= hi = n1.  Both bounds obey the same recurrence
+ * and LF is monotone, so lo <= ka <= hi stays true; once lo == hi (the suffix read so far no
+ * longer occurs in B1's text) the walker is exact and starts recording.  At the end of its own
+ * segment (the start row of the next walker to the left) an inexact walker stops; an exact one
+ * keeps going through rows nobody has recorded yet (the unresolved head of the next segment)
+ * until it meets a recorded row or the start of the string.  Every recorded value is exact, so
+ * two walkers that overlap write identical numbers and no ordering between workgroups is needed.
+ *
+ * Where the extra walkers start:
+ *   LIST = false  rows kb >= m2 with kb % 2^logM == 0 (no knowledge of the text needed: this is
+ *                 what the reference's signature rb3_fmi_merge_plain(r, len, bwt) allows)
+ *   LIST = true   an explicit list {row, ka0, nsteps, flags} supplied by the caller, normally the
+ *                 rows of text positions spaced M apart (sampled inverse suffix array, which the
+ *                 host suffix sorter has at hand); nsteps = length of the walker's own segment.
+ *                 RB3_WK_STOP makes a walker stop at the end of its segment and report the value it
+ *                 arrived with (multi-GPU text-range sharding: the next segment lives on another GPU);
+ *                 RB3_WK_CHECK starts it in "check every row" mode (fix-up walkers).
  */
+struct Walker { int64_t row, ka0, nsteps, flags; };
+#define RB3_WK_STOP  1
+#define RB3_WK_CHECK 2
+
 __device__ __forceinline__ int64_t ld_pos(const int64_t *p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -377,14 +404,15 @@ __device__ __forceinline__ void st_pos(int64_t *p, int64_t v)
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template<bool LIST>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, int64_t *pos, int64_t n2, int64_t m2,
-		int logM, int64_t nwalk, unsigned long long *qhead, unsigned long long *nsteps)
+		int logM, const Walker *wl, int64_t nwalk, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps)
 {
 	const int lane = threadIdx.x & 63, j = lane & 7;
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
 	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
-	bool active = false, exact = false, foreign = false;
-	int64_t kb = 0, lo = 0, hi = 0;
+	bool active = false, exact = false, foreign = false, stop = false;
+	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, wid = 0;
 	unsigned long long steps = 0;
 	for (;;) {
 		if (!active) {
@@ -394,26 +422,38 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 				w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
 			}
 			w0 = oct_bcast0(w0, j), w1 = oct_bcast0(w1, j);
-			const int64_t wid = (int64_t)((uint64_t)w1 << 32 | w0);
+			wid = (int64_t)((uint64_t)w1 << 32 | w0);
 			if (wid >= nwalk) break;
-			if (wid < m2) {
-				kb = wid, lo = hi = b1.m, exact = true;
+			if (LIST) {
+				const Walker w = wl[wid];
+				kb = w.row, remaining = w.nsteps, stop = (w.flags & RB3_WK_STOP) != 0, foreign = (w.flags & RB3_WK_CHECK) != 0;
+				if (w.ka0 >= 0) lo = hi = w.ka0, exact = true;
+				else lo = 0, hi = b1.n, exact = (b1.n == 0);
+				if (!exact && !stop && ld_pos(&pos[kb]) != RB3_UNSET) continue; // an exact walker already came through
 			} else {
-				kb = first_marked + ((wid - m2) << logM);
-				lo = 0, hi = b1.n, exact = (b1.n == 0);
-				if (ld_pos(&pos[kb]) != RB3_UNSET) continue; // an exact walker already came through
+				stop = false, foreign = false, remaining = INT64_MAX;
+				if (wid < m2) kb = wid, lo = hi = b1.m, exact = true;
+				else {
+					kb = first_marked + ((wid - m2) << logM);
+					lo = 0, hi = b1.n, exact = (b1.n == 0);
+					if (ld_pos(&pos[kb]) != RB3_UNSET) continue;
+				}
 			}
-			foreign = false, active = true;
+			active = true;
 		}
-		// one LF step
+		// one LF step: issue every load that depends only on (kb, lo, hi) before using any of them
 		const uint64_t x = lf2[kb];
+		int64_t seen = RB3_UNSET;
+		if (exact && foreign) seen = ld_pos(&pos[kb]);
 		RankLoad rl, rh;
-		oct_rank_issue(b1, lo, j, rl);
-		if (!exact) oct_rank_issue(b1, hi, j, rh);
+		oct_rank_issue_grp(b1, lo, j, rl);
+		if (!exact) oct_rank_issue_grp(b1, hi, j, rh);
+		oct_rank_issue_slot(b1, j, rl);
+		if (!exact) oct_rank_issue_slot(b1, j, rh);
 		const int c = (int)(x & 7u);
 		++steps;
 		if (exact) {
-			if (foreign && ld_pos(&pos[kb]) != RB3_UNSET) { active = false; continue; }
+			if (seen != RB3_UNSET) { active = false; continue; }
 			if (j == 0) st_pos(&pos[kb], lo + kb);
 		}
 		if (c == 0) { active = false; continue; }
@@ -423,15 +463,34 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			exact = (lo == hi);
 		}
 		kb = (int64_t)(x >> 3);
-		if (M && kb >= m2 && (kb & (M - 1)) == 0) {
+		bool at_end;
+		if (LIST) at_end = (--remaining == 0);
+		else at_end = M && kb >= m2 && (kb & (M - 1)) == 0;
+		if (at_end) {
+			if (LIST && stop) {
+				if (j == 0) arrive[wid] = exact ? lo : -1;
+				active = false;
+				continue;
+			}
 			if (!exact) { active = false; continue; }
-			foreign = true;
+			foreign = true, remaining = INT64_MAX;
 		}
 	}
 	// per-wave step count (statistics only)
 	unsigned long long s = steps;
 	for (int d = 32; d >= 8; d >>= 1) s += __shfl_xor(s, d);
 	if (lane == 0) atomicAdd(nsteps, s);
+}
+
+/* after the chains: every row must be recorded and pos must be strictly increasing
+ * (ka is non-decreasing in kb).  bad[0] += #unset, bad[1] += #order violations */
+__global__ void __launch_bounds__(256) k_pos_check(const int64_t *pos, int64_t n2, int64_t ntot, unsigned long long *bad)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n2) return;
+	const int64_t p = pos[i];
+	if (p == RB3_UNSET) atomicAdd(&bad[0], 1ull);
+	else if (p < 0 || p >= ntot || (i > 0 && pos[i - 1] != RB3_UNSET && pos[i - 1] >= p)) atomicAdd(&bad[1], 1ull);
 }
 
 /* ----------------------------------------------------------------------------------------- */

@@ -52,6 +52,12 @@ SYMBOLS = {
     "rb3gpu_merge_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_from_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_merge_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]),
+    "rb3gpu_merge_plain_walkers": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_merge_plain_dev_walkers": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]),
+    "rb3gpu_mg_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_mg_walk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_mg_pos_ptr": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
+    "rb3gpu_mg_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rb3gpu_mg_rank_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_rank1a_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_get_acc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -133,6 +139,43 @@ class Rb3Gpu:
     def merge_plain(self, bwt):
         bwt = _u8(bwt)
         self._chk(self._lib.rb3gpu_merge_plain(self._h, bwt.size, bwt.ctypes.data), "rb3gpu_merge_plain")
+
+    @staticmethod
+    def _walkers(w):
+        w = np.ascontiguousarray(w, dtype=np.int64)
+        assert w.ndim == 2 and w.shape[1] == 4, "walkers: (n, 4) int64 rows of (row, ka0, nsteps, flags)"
+        return w
+
+    def merge_plain_walkers(self, bwt, walkers):
+        bwt, w = _u8(bwt), self._walkers(walkers)
+        self._chk(self._lib.rb3gpu_merge_plain_walkers(self._h, bwt.size, bwt.ctypes.data, w.shape[0], w.ctypes.data), "rb3gpu_merge_plain_walkers")
+
+    def merge_plain_dev_walkers(self, d_bwt, length, walkers, commit=True):
+        w = self._walkers(walkers)
+        self._chk(self._lib.rb3gpu_merge_plain_dev_walkers(self._h, length, d_bwt, w.shape[0], w.ctypes.data, 1 if commit else 0), "rb3gpu_merge_plain_dev_walkers")
+
+    # staged merge (multi-GPU): begin -> walk (repeatable) -> [collective on pos] -> finish
+    def mg_begin(self, d_bwt, length, d_pos_ext=None):
+        acc2 = np.zeros(7, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_mg_begin(self._h, length, d_bwt, d_pos_ext, acc2.ctypes.data), "rb3gpu_mg_begin")
+        return acc2
+
+    def mg_walk(self, walkers=None, want_arrive=False):
+        if walkers is None:
+            self._chk(self._lib.rb3gpu_mg_walk(self._h, 0, None, None), "rb3gpu_mg_walk")
+            return None
+        w = self._walkers(walkers)
+        arr = np.full(w.shape[0], -1, dtype=np.int64) if want_arrive else None
+        self._chk(self._lib.rb3gpu_mg_walk(self._h, w.shape[0], w.ctypes.data, arr.ctypes.data if want_arrive else None), "rb3gpu_mg_walk")
+        return arr
+
+    def mg_pos_ptr(self):
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._chk(self._lib.rb3gpu_mg_pos_ptr(self._h, ctypes.byref(p), ctypes.byref(n)), "rb3gpu_mg_pos_ptr")
+        return p.value, n.value
+
+    def mg_finish(self, commit=True):
+        self._chk(self._lib.rb3gpu_mg_finish(self._h, 1 if commit else 0), "rb3gpu_mg_finish")
 
     def mg_rank_plain(self, bwt):
         bwt = _u8(bwt)

@@ -21,6 +21,9 @@ def load_library():
     L = ctypes.CDLL(_build.LIB_HOST)
     L.rb3h_build_bwt.restype = ctypes.c_int
     L.rb3h_build_bwt.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+    L.rb3h_build_bwt_walkers.restype = ctypes.c_int
+    L.rb3h_build_bwt_walkers.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                         ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_void_p)]
     L.rb3h_fmdw_init.restype = ctypes.c_void_p
     L.rb3h_fmdw_enc.restype = ctypes.c_int
     L.rb3h_fmdw_enc.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
@@ -53,6 +56,22 @@ def build_bwt(text, n_threads=1):
     if r < 0:
         raise ValueError("rb3h_build_bwt failed with code %d" % r)
     return t
+
+
+def build_bwt_walkers(text, step=1024, n_threads=1):
+    """BWT of the batch plus its LF-walker list for Rb3Gpu.merge_plain_walkers: an (n, 4) int64
+    array of (row, ka0, nsteps, flags), one walker per string and one per `step` text positions."""
+    L = load_library()
+    t = np.ascontiguousarray(text, dtype=np.uint8).copy()
+    nw, pw = ctypes.c_int64(0), ctypes.c_void_p()
+    r = L.rb3h_build_bwt_walkers(0, t.size, t.ctypes.data, n_threads, step, ctypes.byref(nw), ctypes.byref(pw))
+    if r < 0:
+        raise ValueError("rb3h_build_bwt_walkers failed with code %d" % r)
+    w = np.ctypeslib.as_array(ctypes.cast(pw, ctypes.POINTER(ctypes.c_int64)), shape=(nw.value, 4)).copy()
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    libc.free(pw)
+    return t, w
 
 
 def read_batches(path, is_line, max_len, fwd=True, rev=True):

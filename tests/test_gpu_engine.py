@@ -131,3 +131,48 @@ def test_bad_symbol_rejected(engine):
     with pytest.raises(Rb3GpuError) as e:
         engine.from_plain(b)
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("step", [16, 100, 1024])
+def test_merge_with_host_walkers(engine, oracle, step):
+    """rb3gpu_merge_plain_walkers: text-regular walkers from the host suffix sorter give the same pos[]"""
+    from ropebwt3_amd import host
+    rng = np.random.default_rng(21)
+    g0 = util.random_genome(rng, 20000)
+    seqs2 = [util.mutate(rng, g0, 0.002), util.mutate(rng, g0, 0.01)[:7777], g0[:50].copy(), g0.copy()] + util.reads_from(rng, g0, 30, 80)
+    b1 = oracle.bwt(util.make_text([g0]))
+    t2 = util.make_text(seqs2)
+    b2, w = host.build_bwt_walkers(t2, step)
+    assert np.array_equal(b2, oracle.bwt(t2))
+    assert (w[:, 1] == -2).sum() == 2 * len(seqs2)
+    want = oracle.merge(b1, b2)
+    engine.from_plain(b1)
+    engine.merge_plain_walkers(b2, w)
+    assert np.array_equal(engine.export_plain(), want)
+
+
+def test_staged_merge_with_stop_and_fixup(engine, oracle):
+    """the multi-GPU protocol on one GPU: two 'ranks' own the two halves of the walker list, the
+    boundary walker stops and hands its arrival value to a fix-up walker on the other half"""
+    from ropebwt3_amd import host
+    rng = np.random.default_rng(22)
+    g0 = util.random_genome(rng, 30000)
+    b1 = oracle.bwt(util.make_text([g0]))
+    t2 = util.make_text([util.mutate(rng, g0, 0.003)], rev=False)
+    b2, w = host.build_bwt_walkers(t2, 512)
+    rb, _ = oracle.mg_rank(b1, b2)
+    engine.from_plain(b1)
+    d = engine.dev_upload(b2)
+    cut = w.shape[0] // 2            # walkers are in text order: [0, cut) = left half of the string
+    hi_part = w[cut:].copy()
+    hi_part[0, 3] |= 1               # RB3GPU_WK_STOP: its segment ends where the other rank's territory begins
+    lo_part = w[:cut].copy()
+    engine.mg_begin(d, b2.size)
+    arr = engine.mg_walk(hi_part, want_arrive=True)
+    assert arr[0] >= 0               # exact on arrival (0.3% divergence, 512-step segment: converged)
+    engine.mg_walk(lo_part)
+    fix = np.array([[lo_part[-1, 0], arr[0], 1 << 60, 2]], dtype=np.int64)   # start at the top walker of the low half, exact, CHECK mode
+    engine.mg_walk(fix)
+    engine.mg_finish(commit=True)
+    assert np.array_equal(engine.export_plain(), oracle.merge(b1, b2))
+    engine.dev_free(d)

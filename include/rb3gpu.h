@@ -90,7 +90,6 @@ typedef struct {
 	int64_t flags;               /* RB3GPU_WK_* */
 } rb3gpu_walker_t;
 #define RB3GPU_KA_SENTINEL (-2)  /* ka0 of a sentinel row: the engine substitutes acc[1] of the index */
-#define RB3GPU_WK_STOP  1        /* stop after nsteps and report the arrival value (next segment is on another GPU) */
 #define RB3GPU_WK_CHECK 2        /* the rows ahead may already be recorded: check each before recording */
 
 /* rb3gpu_merge_plain with an explicit walker list (host memory); same result, more parallelism
@@ -103,11 +102,11 @@ int rb3gpu_merge_plain_dev_walkers(rb3gpu_t *h, int64_t len, const uint8_t *d_bw
  * walkers (several calls allowed: hand-off values arriving from the neighbour rank start fix-up
  * walkers), then the ranks combine pos[] (RCCL all-reduce MAX over the device buffer returned by
  * rb3gpu_mg_pos_ptr: unset rows are -1) and every rank calls finish.  d_pos_ext, if not NULL, is a
- * caller-owned device buffer of len int64 to use for pos[].  arrive[i] (host, optional) receives
- * the value walker i arrived with at the end of its segment when it has RB3GPU_WK_STOP (-1 if it
- * was still inexact). */
+ * caller-owned device buffer of len int64 to use for pos[].  stop_row >= 0 names the row where the
+ * territory of the next rank begins (the start row of its top walker): any walker reaching it stops,
+ * and *arrive (host, optional) receives the exact value a walker arrived there with, or -1 if none did. */
 int rb3gpu_mg_begin(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, void *d_pos_ext, int64_t acc2[RB3GPU_ASIZE+1]);
-int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *arrive);
+int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t stop_row, int64_t *arrive);
 int rb3gpu_mg_pos_ptr(rb3gpu_t *h, void **d_pos, int64_t *len);
 int rb3gpu_mg_finish(rb3gpu_t *h, int commit);
 

@@ -306,7 +306,7 @@ int rb3gpu_mg_begin(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, void *d_pos_
 }
 
 /* run LF walkers: walkers == NULL -> one per sentinel row plus automatic SA-order splitting */
-int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *arrive)
+int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t stop_row, int64_t *arrive)
 {
 	if (!h || (walkers && n_walkers <= 0)) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
@@ -323,6 +323,7 @@ int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walker
 		nwalk = n_walkers;
 		if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
 		dwl = (Walker*)h->wl.p, darr = (int64_t*)((char*)h->wl.p + (size_t)n_walkers * 32);
+		if (stop_row >= len) return RB3GPU_EINVAL;
 		{ // ka0 == RB3GPU_KA_SENTINEL: a sentinel row, whose insertion point is acc[1] of the index (fm-index.c:164)
 			rb3gpu_walker_t *tmp = (rb3gpu_walker_t*)malloc((size_t)n_walkers * sizeof(rb3gpu_walker_t));
 			if (!tmp) return RB3GPU_ENOMEM;
@@ -333,7 +334,7 @@ int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walker
 			free(tmp);
 			HIPCHK(e);
 		}
-		HIPCHK(hipMemsetAsync(darr, 0xff, (size_t)n_walkers * 8, h->st));
+		HIPCHK(hipMemsetAsync(darr, 0xff, 8, h->st));
 	} else {
 		logM = pick_split(h, len, m2);
 		nwalk = m2;
@@ -349,12 +350,12 @@ int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walker
 	HIPCHK(hipEventRecord(h->ev[6], h->st));
 	if (walkers)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true>), dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, h->mg_pos,
-				len, m2, 0, (const Walker*)dwl, nwalk, darr, qhead, nsteps);
+				len, m2, 0, (const Walker*)dwl, nwalk, stop_row < 0 ? -1 : stop_row, darr, qhead, nsteps);
 	else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, h->mg_pos,
-				len, m2, logM, (const Walker*)nullptr, nwalk, (int64_t*)nullptr, qhead, nsteps);
+				len, m2, logM, (const Walker*)nullptr, nwalk, (int64_t)-1, (int64_t*)nullptr, qhead, nsteps);
 	HIPCHK(hipEventRecord(h->ev[7], h->st));
-	if (walkers && arrive) HIPCHK(hipMemcpyAsync(arrive, darr, (size_t)n_walkers * 8, hipMemcpyDeviceToHost, h->st));
+	if (walkers && arrive) HIPCHK(hipMemcpyAsync(arrive, darr, 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	const float ms = ev_ms(h->ev[6], h->ev[7]);
 	h->stt.ms_chain += ms, h->stt.ms_rank += ms;
@@ -432,7 +433,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 {
 	int r;
 	if ((r = rb3gpu_mg_begin(h, len, d_b2, nullptr, host_acc2)) < 0) return r;
-	if ((r = rb3gpu_mg_walk(h, n_walkers, walkers, nullptr)) < 0) return r;
+	if ((r = rb3gpu_mg_walk(h, n_walkers, walkers, -1, nullptr)) < 0) return r;
 	return mg_finish(h, commit, host_pos, rank_only);
 }
 

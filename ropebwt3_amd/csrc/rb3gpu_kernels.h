@@ -387,31 +387,39 @@ __global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, cons
  *   LIST = true   an explicit list {row, ka0, nsteps, flags} supplied by the caller, normally the
  *                 rows of text positions spaced M apart (sampled inverse suffix array, which the
  *                 host suffix sorter has at hand); nsteps = length of the walker's own segment.
- *                 RB3_WK_STOP makes a walker stop at the end of its segment and report the value it
- *                 arrived with (multi-GPU text-range sharding: the next segment lives on another GPU);
  *                 RB3_WK_CHECK starts it in "check every row" mode (fix-up walkers).
+ *                 stop_row >= 0 (multi-GPU text-range sharding): the rows from stop_row on belong to
+ *                 another GPU; any walker reaching it stops there and, if exact, leaves the value it
+ *                 arrived with in *arrive for the neighbour rank.
  */
 struct Walker { int64_t row, ka0, nsteps, flags; };
-#define RB3_WK_STOP  1
 #define RB3_WK_CHECK 2
 
 __device__ __forceinline__ int64_t ld_pos(const int64_t *p)
 {
+#ifdef RB3_EXP_LD_PLAIN
+	return *(const volatile int64_t*)p;
+#else
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 __device__ __forceinline__ void st_pos(int64_t *p, int64_t v)
 {
+#ifdef RB3_EXP_ST_PLAIN
+	*(volatile int64_t*)p = v;
+#else
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 template<bool LIST>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, int64_t *pos, int64_t n2, int64_t m2,
-		int logM, const Walker *wl, int64_t nwalk, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps)
+		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps)
 {
 	const int lane = threadIdx.x & 63, j = lane & 7;
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
 	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
-	bool active = false, exact = false, foreign = false, stop = false;
+	bool active = false, exact = false, foreign = false;
 	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, wid = 0;
 	unsigned long long steps = 0;
 	for (;;) {
@@ -426,12 +434,12 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			if (wid >= nwalk) break;
 			if (LIST) {
 				const Walker w = wl[wid];
-				kb = w.row, remaining = w.nsteps, stop = (w.flags & RB3_WK_STOP) != 0, foreign = (w.flags & RB3_WK_CHECK) != 0;
+				kb = w.row, remaining = w.nsteps, foreign = (w.flags & RB3_WK_CHECK) != 0;
 				if (w.ka0 >= 0) lo = hi = w.ka0, exact = true;
 				else lo = 0, hi = b1.n, exact = (b1.n == 0);
-				if (!exact && !stop && ld_pos(&pos[kb]) != RB3_UNSET) continue; // an exact walker already came through
+				if (!exact && ld_pos(&pos[kb]) != RB3_UNSET) continue; // an exact walker already came through
 			} else {
-				stop = false, foreign = false, remaining = INT64_MAX;
+				foreign = false, remaining = INT64_MAX;
 				if (wid < m2) kb = wid, lo = hi = b1.m, exact = true;
 				else {
 					kb = first_marked + ((wid - m2) << logM);
@@ -441,19 +449,32 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			}
 			active = true;
 		}
-		// one LF step: issue every load that depends only on (kb, lo, hi) before using any of them
-		const uint64_t x = lf2[kb];
-		int64_t seen = RB3_UNSET;
-		if (exact && foreign) seen = ld_pos(&pos[kb]);
+		// One LF step.  Two independent dependency chains meet here: kb -> lf2[kb] (one HBM/MALL
+		// access) and ka -> group entry -> slot (two cache-friendlier accesses).  vmcnt retires in
+		// issue order, so the directory loads go first, the slot loads as soon as the directory is
+		// back, and lf2[kb] / the recorded-row check are only waited for at the very end: the step
+		// costs max(latency(lf2), latency(grp) + latency(slot)) instead of their sum.
 		RankLoad rl, rh;
 		oct_rank_issue_grp(b1, lo, j, rl);
 		if (!exact) oct_rank_issue_grp(b1, hi, j, rh);
+		const uint64_t x = lf2[kb];
+		// recorded-row check: always issued (a branch here would make the compiler drain vmcnt inside
+		// it); walkers that do not need it read a fixed, cache-resident word instead
+		const bool need_check = exact && foreign;
+#ifdef RB3_EXP_NO_DUMMY
+		int64_t seen_raw = RB3_UNSET;
+		if (need_check) seen_raw = ld_pos(&pos[kb]);
+#else
+		const int64_t seen_raw = ld_pos(need_check ? &pos[kb] : pos);
+#endif
+		__builtin_amdgcn_sched_barrier(0);
 		oct_rank_issue_slot(b1, j, rl);
 		if (!exact) oct_rank_issue_slot(b1, j, rh);
+		__builtin_amdgcn_sched_barrier(0);
 		const int c = (int)(x & 7u);
 		++steps;
 		if (exact) {
-			if (seen != RB3_UNSET) { active = false; continue; }
+			if (need_check && seen_raw != RB3_UNSET) { active = false; continue; }
 			if (j == 0) st_pos(&pos[kb], lo + kb);
 		}
 		if (c == 0) { active = false; continue; }
@@ -463,15 +484,15 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			exact = (lo == hi);
 		}
 		kb = (int64_t)(x >> 3);
+		if (LIST && kb == stop_row) { // the rest of this string is recorded on another GPU
+			if (exact && j == 0) st_pos(arrive, lo);
+			active = false;
+			continue;
+		}
 		bool at_end;
 		if (LIST) at_end = (--remaining == 0);
 		else at_end = M && kb >= m2 && (kb & (M - 1)) == 0;
 		if (at_end) {
-			if (LIST && stop) {
-				if (j == 0) arrive[wid] = exact ? lo : -1;
-				active = false;
-				continue;
-			}
 			if (!exact) { active = false; continue; }
 			foreign = true, remaining = INT64_MAX;
 		}

@@ -55,7 +55,7 @@ SYMBOLS = {
     "rb3gpu_merge_plain_walkers": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_merge_plain_dev_walkers": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]),
     "rb3gpu_mg_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "rb3gpu_mg_walk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_mg_walk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_mg_pos_ptr": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
     "rb3gpu_mg_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rb3gpu_mg_rank_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -83,7 +83,7 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_GPU
+    path = os.environ.get("RB3GPU_LIB", _build.LIB_GPU)  # override for kernel experiments only
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the engine is HIP-only; there is no CPU fallback)" % path)
@@ -160,14 +160,15 @@ class Rb3Gpu:
         self._chk(self._lib.rb3gpu_mg_begin(self._h, length, d_bwt, d_pos_ext, acc2.ctypes.data), "rb3gpu_mg_begin")
         return acc2
 
-    def mg_walk(self, walkers=None, want_arrive=False):
+    def mg_walk(self, walkers=None, stop_row=-1):
+        """run walkers; returns the exact value a walker arrived at stop_row with, or -1"""
         if walkers is None:
-            self._chk(self._lib.rb3gpu_mg_walk(self._h, 0, None, None), "rb3gpu_mg_walk")
-            return None
+            self._chk(self._lib.rb3gpu_mg_walk(self._h, 0, None, -1, None), "rb3gpu_mg_walk")
+            return -1
         w = self._walkers(walkers)
-        arr = np.full(w.shape[0], -1, dtype=np.int64) if want_arrive else None
-        self._chk(self._lib.rb3gpu_mg_walk(self._h, w.shape[0], w.ctypes.data, arr.ctypes.data if want_arrive else None), "rb3gpu_mg_walk")
-        return arr
+        arr = np.full(1, -1, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_mg_walk(self._h, w.shape[0], w.ctypes.data, stop_row, arr.ctypes.data), "rb3gpu_mg_walk")
+        return int(arr[0])
 
     def mg_pos_ptr(self):
         p, n = ctypes.c_void_p(), ctypes.c_int64()

@@ -1,0 +1,79 @@
+"""CPU stand-in for the four staged-merge calls of the HIP engine (mg_begin / mg_walk / pos /
+mg_finish), for the gloo tests of ropebwt3_amd.multi.  It re-states the walker semantics of
+k_chain<LIST> (rb3gpu_kernels.h) in numpy: bounds (lo, hi), exactness on lo == hi, stopping at the
+end of the own segment when inexact, check mode, stop_row hand-off.  TEST INFRASTRUCTURE ONLY --
+the product never imports it."""
+import numpy as np
+
+UNSET = -1
+
+
+class FakeEngine:
+    def __init__(self, b1):
+        self.b1 = np.asarray(b1, dtype=np.uint8)
+        n = self.b1.size
+        self.occ = np.zeros((6, n + 1), dtype=np.int64)
+        for c in range(6):
+            self.occ[c, 1:] = np.cumsum(self.b1 == c)
+        self.acc = np.concatenate([[0], np.cumsum(self.occ[:, n])])
+        self.steps = 0
+
+    def LF(self, c, k):
+        return int(self.acc[c] + self.occ[c, k])
+
+    def mg_begin(self, b2, length, pos_ptr_unused, pos_tensor=None):
+        b2 = np.asarray(b2, dtype=np.uint8)
+        assert b2.size == length
+        self.b2 = b2
+        cnt = np.bincount(b2, minlength=6)
+        acc2 = np.concatenate([[0], np.cumsum(cnt)])
+        self.acc2 = acc2
+        occ = np.zeros(length, dtype=np.int64)
+        seen = np.zeros(6, dtype=np.int64)
+        for i, c in enumerate(b2):
+            occ[i] = seen[c]
+            seen[c] += 1
+        self.lf2 = acc2[b2] + occ
+        self.pos = pos_tensor.numpy() if pos_tensor is not None else np.full(length, UNSET, dtype=np.int64)
+        self.pos[:] = UNSET
+        return acc2
+
+    def mg_walk(self, walkers, stop_row=-1):
+        arrive = -1
+        n1, m1 = self.b1.size, int(self.acc[1])
+        for row, ka0, nsteps, flags in np.asarray(walkers, dtype=np.int64):
+            kb, remaining, foreign = int(row), int(nsteps), bool(flags & 2)
+            if ka0 == -2:
+                ka0 = m1
+            if ka0 >= 0:
+                lo = hi = int(ka0)
+            else:
+                lo, hi = 0, n1
+                if self.pos[kb] != UNSET:
+                    continue
+            while True:
+                exact = lo == hi
+                c = int(self.b2[kb])
+                self.steps += 1
+                if exact:
+                    if foreign and self.pos[kb] != UNSET:
+                        break
+                    self.pos[kb] = lo + kb
+                if c == 0:
+                    break
+                lo, hi = self.LF(c, lo), self.LF(c, hi)
+                kb = int(self.lf2[kb])
+                if kb == stop_row:
+                    if lo == hi:
+                        arrive = lo
+                    break
+                remaining -= 1
+                if remaining == 0:
+                    if lo != hi:
+                        break
+                    foreign, remaining = True, 1 << 62
+        return arrive
+
+    def mg_finish(self, commit):
+        assert (self.pos != UNSET).all(), "rows left unset"
+        assert (np.diff(self.pos) > 0).all(), "pos not increasing"

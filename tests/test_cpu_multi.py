@@ -1,0 +1,102 @@
+"""world_size-2/3 gloo tests of the multi-GPU orchestration (ropebwt3_amd/multi.py): walker
+partition by text range, stop_row hand-off, fix-up round, all-reduce(MAX) of pos[].  The engine
+calls are served by tests/fake_engine.py (numpy restatement of the walker kernel), the expected
+pos[] comes from the CPU oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ropebwt3_amd import host, multi
+    from tests import util
+    from tests.fake_engine import FakeEngine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        g0 = util.random_genome(rng, 6000)
+        if case == "one_long_string":          # a single string cut across every rank boundary
+            seqs, step, rev = [util.mutate(rng, g0, 0.01)], 200, False
+        elif case == "duplicate":              # identical to indexed text: nothing converges, pure hand-off chain
+            seqs, step, rev = [g0[:3000].copy()], 150, False
+        elif case == "reads":                  # many short strings: no walker inside strings at all
+            seqs, step, rev = util.reads_from(rng, g0, 40, 60), 1024, True
+        else:                                  # mixed
+            seqs, step, rev = [util.mutate(rng, g0, 0.02)[:2500], g0[100:130].copy(), util.mutate(rng, g0, 0.005)[1000:5000]], 128, True
+        orc = util.Oracle()
+        b1 = orc.bwt(util.make_text([g0]))
+        t2 = util.make_text(seqs, rev=rev)
+        b2, walkers = host.build_bwt_walkers(t2, step)
+        rb, _ = orc.mg_rank(b1, b2)
+        eng = FakeEngine(b1)
+        pos = torch.full((b2.size,), -1, dtype=torch.int64)
+        real_begin = eng.mg_begin
+        eng.mg_begin = lambda d, n, ptr: real_begin(d, n, ptr, pos_tensor=pos)
+        rounds = multi.merge_sharded(eng, b2, b2.size, walkers, step, dist, rank, world, pos)
+        ok = bool(np.array_equal(pos.numpy(), rb >> 6))
+        bounds = multi.partition(walkers, world, step)
+        q.put((rank, ok, rounds, eng.steps, bounds[rank + 1] - bounds[rank]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "one_long_string"), (3, "one_long_string"), (2, "duplicate"), (3, "duplicate"), (2, "reads"), (2, "mixed"), (3, "mixed")])
+def test_sharded_merge_gloo(world, case):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert all(r[1] for r in res), res
+    if case == "one_long_string":
+        assert all(r[4] > 0 for r in res)              # every rank really had walkers
+        assert max(r[2] for r in res) >= 1             # and at least one hand-off round happened
+    if case == "duplicate":
+        assert max(r[2] for r in res) == world - 1     # the value has to travel down rank by rank
+    if case == "reads":
+        assert max(r[2] for r in res) == 0             # strings are not cut: no hand-off at all
+
+
+def test_partition_and_plan():
+    from ropebwt3_amd import multi
+    INF = multi.NSTEPS_INF
+    # two strings: the first with 3 checkpoints + sentinel, the second only a sentinel walker
+    w = np.array([[10, -1, INF, 0], [11, -1, 100, 0], [12, -1, 100, 0], [0, -2, 50, 0], [1, -2, INF, 0]], dtype=np.int64)
+    b = multi.partition(w, 2, 100)
+    assert b[0] == 0 and b[-1] == 5 and 0 < b[1] < 5
+    mine0, stop0, src0 = multi.slice_plan(w, b, 0)
+    mine1, stop1, src1 = multi.slice_plan(w, b, 1)
+    assert stop0 == -1                                  # the lowest slice never hands down
+    assert (src0 == 1) == (w[b[1], 2] < INF)            # rank 0 receives iff rank 1's lowest walker flows into it
+    assert (stop1 == w[b[1] - 1, 0]) == (w[b[1], 2] < INF)
+    # more ranks than walkers: empty slices are skipped when looking for the sender
+    b = multi.partition(w[:2], 4, 100)
+    plans = [multi.slice_plan(w[:2], b, r) for r in range(4)]
+    owners = [r for r in range(4) if len(plans[r][0])]
+    assert sum(len(p[0]) for p in plans) == 2
+    if len(owners) == 2:
+        assert plans[owners[0]][2] == owners[1]

@@ -152,27 +152,33 @@ def test_merge_with_host_walkers(engine, oracle, step):
 
 
 def test_staged_merge_with_stop_and_fixup(engine, oracle):
-    """the multi-GPU protocol on one GPU: two 'ranks' own the two halves of the walker list, the
-    boundary walker stops and hands its arrival value to a fix-up walker on the other half"""
-    from ropebwt3_amd import host
+    """the multi-GPU protocol on one GPU: two 'ranks' own the two halves of the walker list; walkers of
+    the upper half stop at the row where the lower half's territory begins and leave the value they
+    arrive with, which a fix-up walker of the lower half picks up"""
+    from ropebwt3_amd import host, multi
     rng = np.random.default_rng(22)
     g0 = util.random_genome(rng, 30000)
     b1 = oracle.bwt(util.make_text([g0]))
-    t2 = util.make_text([util.mutate(rng, g0, 0.003)], rev=False)
-    b2, w = host.build_bwt_walkers(t2, 512)
-    rb, _ = oracle.mg_rank(b1, b2)
-    engine.from_plain(b1)
-    d = engine.dev_upload(b2)
-    cut = w.shape[0] // 2            # walkers are in text order: [0, cut) = left half of the string
-    hi_part = w[cut:].copy()
-    hi_part[0, 3] |= 1               # RB3GPU_WK_STOP: its segment ends where the other rank's territory begins
-    lo_part = w[:cut].copy()
-    engine.mg_begin(d, b2.size)
-    arr = engine.mg_walk(hi_part, want_arrive=True)
-    assert arr[0] >= 0               # exact on arrival (0.3% divergence, 512-step segment: converged)
-    engine.mg_walk(lo_part)
-    fix = np.array([[lo_part[-1, 0], arr[0], 1 << 60, 2]], dtype=np.int64)   # start at the top walker of the low half, exact, CHECK mode
-    engine.mg_walk(fix)
-    engine.mg_finish(commit=True)
-    assert np.array_equal(engine.export_plain(), oracle.merge(b1, b2))
-    engine.dev_free(d)
+    for seqs, step in (([util.mutate(rng, g0, 0.003)], 512), ([g0[5000:9000].copy()], 256)):   # 2nd: nothing converges
+        t2 = util.make_text(seqs, rev=False)
+        b2, w = host.build_bwt_walkers(t2, step)
+        rb, _ = oracle.mg_rank(b1, b2)
+        engine.from_plain(b1)
+        d = engine.dev_upload(b2)
+        bounds = multi.partition(w, 2, step)
+        lo_part, stop_lo, src_lo = multi.slice_plan(w, bounds, 0)
+        hi_part, stop_hi, src_hi = multi.slice_plan(w, bounds, 1)
+        assert stop_lo == -1 and src_lo == 1 and stop_hi == lo_part[-1, 0] and src_hi == -1
+        engine.mg_begin(d, b2.size)
+        val = engine.mg_walk(hi_part, stop_hi)
+        assert val >= 0                  # the sentinel walker is in the upper half: an exact value always arrives
+        engine.mg_walk(lo_part, -1)
+        fix = np.array([[lo_part[-1, 0], val, multi.NSTEPS_INF, multi.WK_CHECK]], dtype=np.int64)
+        engine.mg_walk(fix, -1)
+        p, n = engine.mg_pos_ptr()
+        pos = np.empty(n, dtype=np.int64)
+        engine._chk(engine._lib.rb3gpu_dev_download(engine._h, pos.ctypes.data, p, n * 8), "download")
+        assert np.array_equal(pos, rb >> 6)
+        engine.mg_finish(commit=True)
+        assert np.array_equal(engine.export_plain(), oracle.merge(b1, b2))
+        engine.dev_free(d)

@@ -8,8 +8,10 @@ block array, with B1 and B2 already resident in HBM and the result discarded (co
 every step does identical work.  Workload at N=1 = BASELINE.json configs[1] as SURVEY 8(d)
 defines it without network access: G0 = 4.4 Mbp of uniform random ACGT (seed 1), G1 = G0 with
 0.1 % substitutions (seed 2); the step merges G1 (both strands, 8,800,002 symbols, 2 strings)
-into the index of G0.  At N>1 every rank holds the same B1 and merges its own G_r (seed 2+r):
-fixed work per GPU (weak scaling), aggregate = symbols merged by all ranks / max-over-ranks time.
+into the index of G0.  At N>1 the batch grows with N (weak scaling): it holds N genomes G_1..G_N
+(seeds 2..N+1, 8,800,002 symbols per GPU); the index is replicated, the batch's LF walkers are
+sharded across the ranks by text range and pos[] is combined with one RCCL all-reduce(MAX) per step
+(ropebwt3_amd/multi.py); value = symbols merged by the whole job / max-over-ranks time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -87,6 +89,8 @@ def main():
     ap.add_argument("--div", type=float, default=0.001)
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path even with one rank")
+    ap.add_argument("--walker-step", type=int, default=512)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,10 +113,15 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     t0 = time.time()
-    g0, gs = gen_genomes(args.genome_len, args.div, 1, [2 + rank])
+    sharded = world > 1 or args.sharded
+    g0, gs = gen_genomes(args.genome_len, args.div, 1, [2 + i for i in range(world)])
     from tests import util
     b1 = host.build_bwt(util.make_text([g0]))
-    b2 = host.build_bwt(util.make_text(gs))
+    walkers = None
+    if sharded:
+        b2, walkers = host.build_bwt_walkers(util.make_text(gs), args.walker_step)
+    else:
+        b2 = host.build_bwt(util.make_text(gs))
     log("inputs: B1 %d symbols, B2 %d symbols per GPU; host suffix sorting %.1f s (not timed)" % (b1.size, b2.size, time.time() - t0))
 
     h = Rb3Gpu(device=local_rank, split_log2=args.split, verbose=1)
@@ -125,13 +134,27 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if sharded:
+        from ropebwt3_amd import multi
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        pos = torch.empty(b2.size, dtype=torch.int64, device="cuda")
+
+        def step(commit=False):
+            return multi.merge_sharded(h, d_b2, b2.size, walkers, args.walker_step, dist, rank, world, pos, commit=commit, sync=torch.cuda.synchronize)
+    else:
+        def step(commit=False):
+            h.merge_plain_dev(d_b2, b2.size, commit=commit)
+
     for _ in range(args.warmup):
-        h.merge_plain_dev(d_b2, b2.size, commit=False)
+        step()
     h.stats_reset()
     barrier()
     t = time.perf_counter()
     for _ in range(args.steps):
-        h.merge_plain_dev(d_b2, b2.size, commit=False)
+        step()
     h.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
@@ -143,23 +166,24 @@ def main():
     st = h.stats()
 
     # one committed merge + export, to make sure the timed path produces the right index
-    h.merge_plain_dev(d_b2, b2.size, commit=True)
+    step(commit=True)
     acc = h.get_acc()
     assert acc[6] == b1.size + b2.size
 
     if rank == 0:
-        n_sym = b2.size * world * args.steps
+        n_sym = b2.size * args.steps
         value = n_sym / dt / 1e9
         ms_chain = st["ms_chain"] / max(1, st["n_rank_launches"])
-        algo_bytes = ALGO_BYTES_PER_SYMBOL_RANK * b2.size
+        algo_bytes = ALGO_BYTES_PER_SYMBOL_RANK * b2.size // world   # rows recorded per launch on one rank
         achieved = algo_bytes / (ms_chain * 1e-3) / 1e9
-        workload = "cfg2-synthetic-mtb1: merge G1 (%d bp, 0.1%% subs, both strands, %d symbols, 2 strings) into index of G0 (%d symbols)" % (args.genome_len, b2.size, b1.size)
+        workload = "cfg2-synthetic-mtb1: merge %d genome(s) G_i = G0 + 0.1%% subs (%d bp each, both strands, %d symbols, %d strings) into the index of G0 (%d symbols)" % (world, args.genome_len, b2.size, 2 * world, b1.size)
         out = {
             "metric": "Gbp/s indexed (build merge)", "value": round(value, 6), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": workload, "symbols_per_step_per_gpu": int(b2.size), "strings_per_step_per_gpu": int((b2 == 0).sum()),
-                       "index_symbols": int(b1.size), "parallelism": "replicated-index, one batch per GPU" if world > 1 else "single GPU",
+            "config": {"workload": workload, "symbols_per_step_per_gpu": int(b2.size // world), "strings_per_step": int((b2 == 0).sum()),
+                       "index_symbols": int(b1.size),
+                       "parallelism": ("replicated index, walkers sharded by text range over %d GPUs, all-reduce(MAX) of pos[] per step" % world) if sharded else "single GPU",
                        "split_log2": args.split, "lf_steps_per_step": int(st["n_lf_steps"] // max(1, args.steps))},
             "phases_ms_per_step": {"lf": round(st["ms_lf"] / args.steps, 4), "rank": round(st["ms_rank"] / args.steps, 4),
                                    "rebuild": round(st["ms_build"] / args.steps, 4)},
@@ -168,7 +192,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_chain, 4),
                          "note": "few-long-strings regime: the kernel is bound by dependent-load latency, not bandwidth"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.sharded:
             out["cpu_baseline"] = cpu_baseline(b1, b2)
         print(json.dumps(out), flush=True)
     h.dev_free(d_b2)

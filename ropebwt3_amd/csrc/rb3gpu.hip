@@ -100,6 +100,7 @@ static IdxView view_of(const rb3gpu_t *h)
 {
 	IdxView v;
 	v.grp64 = (const uint64_t*)h->grp, v.slot16 = (const uint4*)h->slots, v.n = h->n, v.m = h->acc[1];
+	v.dense = (h->nslots == (h->n >> RB3_WIN_BITS) + 1);
 	return v;
 }
 
@@ -344,16 +345,25 @@ int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walker
 		}
 	}
 	HIPCHK(hipMemsetAsync(qhead, 0, 8, h->st));
-	int64_t nblk = (nwalk + 31) / 32;
+	// octets per wave: all 8 when there are enough walkers to fill the chip (256 CUs x 32 waves), fewer
+	// when the launch is latency-bound anyway
+	int octs = (int)((nwalk + 8191) / 8192);
+	octs = octs < 1 ? 1 : octs > 8 ? 8 : octs;
+	if (getenv("RB3GPU_OCTS")) octs = atoi(getenv("RB3GPU_OCTS"));
+	int64_t nblk = (nwalk + 4 * octs - 1) / (4 * octs);
 	if (nblk > 256 * 8) nblk = 256 * 8;
 	if (nblk < 1) nblk = 1;
 	HIPCHK(hipEventRecord(h->ev[6], h->st));
-	if (walkers)
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true>), dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, h->mg_pos,
-				len, m2, 0, (const Walker*)dwl, nwalk, stop_row < 0 ? -1 : stop_row, darr, qhead, nsteps);
-	else
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (const uint64_t*)h->lf2.p, h->mg_pos,
-				len, m2, logM, (const Walker*)nullptr, nwalk, (int64_t)-1, (int64_t*)nullptr, qhead, nsteps);
+	{
+		const IdxView iv = view_of(h);
+		const uint64_t *lf2 = (const uint64_t*)h->lf2.p;
+		const int64_t sr = stop_row < 0 ? -1 : stop_row;
+		const dim3 grid((unsigned)nblk), blk(256);
+		if (walkers && iv.dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, true>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, 0, (const Walker*)dwl, nwalk, sr, darr, qhead, nsteps, octs);
+		else if (walkers) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, 0, (const Walker*)dwl, nwalk, sr, darr, qhead, nsteps, octs);
+		else if (iv.dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false, true>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, logM, (const Walker*)nullptr, nwalk, (int64_t)-1, (int64_t*)nullptr, qhead, nsteps, octs);
+		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false, false>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, logM, (const Walker*)nullptr, nwalk, (int64_t)-1, (int64_t*)nullptr, qhead, nsteps, octs);
+	}
 	HIPCHK(hipEventRecord(h->ev[7], h->st));
 	if (walkers && arrive) HIPCHK(hipMemcpyAsync(arrive, darr, 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
@@ -386,6 +396,14 @@ static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
 	HIPCHK(hipMemcpyAsync(hm, misc, 32, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	h->stt.n_lf_steps += (int64_t)hm[1];
+#ifdef RB3_PROF
+	{
+		unsigned long long pr[4];
+		(void)hipMemcpy(pr, misc + 9, 32, hipMemcpyDeviceToHost);
+		fprintf(stderr, "[prof] cycles per step (block 0 wave 0): decode-x %.1f, issue+bookkeeping %.1f, wait+rank %.1f, loop-top/fetch %.1f\n",
+				(double)pr[0] / len, (double)pr[1] / len, (double)pr[2] / len, (double)pr[3] / len);
+	}
+#endif
 	if (hm[2] != 0 || hm[3] != 0) {
 		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset and %llu out of order\n", hm[2], hm[3]);
 		return RB3GPU_EINTERNAL;

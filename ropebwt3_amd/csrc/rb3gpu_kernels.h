@@ -27,6 +27,7 @@ struct IdxView {
 	const uint4 *slot16;     // rb3_slot_t viewed as 8 x uint4
 	int64_t n;               // number of symbols
 	int64_t m;               // number of sentinels (= acc[1])
+	int dense;               // every slot is a bit-plane slot: slot index = position >> 8
 };
 
 struct Acc7 { int64_t a[7]; };
@@ -405,24 +406,84 @@ __device__ __forceinline__ int64_t ld_pos(const int64_t *p)
 }
 __device__ __forceinline__ void st_pos(int64_t *p, int64_t v)
 {
-#ifdef RB3_EXP_ST_PLAIN
-	*(volatile int64_t*)p = v;
+#if defined(RB3_EXP_ST_NONE)
+	(void)p; (void)v;
+#elif defined(RB3_EXP_ST_PLAIN)
+	*p = v;
+#elif defined(RB3_EXP_ST_NT)
+	__builtin_nontemporal_store(v, p);
 #else
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
 
-template<bool LIST>
+/* rank with the symbol known before the loads are issued: every lane of the octet fetches the one
+ * directory word cnt[c] (same address: one request) instead of reducing it across lanes */
+struct RankLoadC {
+	uint64_t gc;     // grp.cnt[c]
+	uint64_t sm;     // slot0 | mask << 32
+	uint4 sl;        // slice j of the slot
+	uint32_t koff;   // k & 8191
+};
+
+template<bool DENSE>
+__device__ __forceinline__ void octc_issue_grp(const IdxView &ix, int64_t k, int c, int j, RankLoadC &r)
+{
+	const int64_t g = k >> RB3_GRP_BITS;
+	r.koff = (uint32_t)k & (RB3_GRP - 1);
+	r.gc = ix.grp64[g * 8 + c];
+	if (DENSE) r.sl = ix.slot16[(k >> RB3_WIN_BITS) * 8 + j]; // every window is its own slot: no directory lookup needed
+	else r.sm = ix.grp64[g * 8 + 6];
+}
+
+template<bool DENSE>
+__device__ __forceinline__ void octc_issue_slot(const IdxView &ix, int j, RankLoadC &r)
+{
+	if (DENSE) return;
+	const uint32_t lw = r.koff >> RB3_WIN_BITS;
+	const uint32_t s = (uint32_t)r.sm + __popc((uint32_t)(r.sm >> 32) & ((2u << lw) - 1u)) - 1u;
+	r.sl = ix.slot16[(int64_t)s * 8 + j];
+}
+
+template<bool DENSE>
+__device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j)
+{
+	uint32_t part;
+	if (DENSE) { // bit planes, slot start = window start
+		int t = (int)(r.koff & (RB3_WIN - 1)) - 32 * j;
+		t = t < 0 ? 0 : t > 32 ? 32 : t;
+		const uint32_t m0 = (c & 1) ? r.sl.y : ~r.sl.y, m1 = (c & 2) ? r.sl.z : ~r.sl.z, m2 = (c & 4) ? r.sl.w : ~r.sl.w;
+		const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
+		part = __popc(m0 & m1 & m2 & lim);
+	} else {
+		const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
+		part = slice_count(r.sl, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
+	}
+	if (j == c + 1) part += r.sl.x;
+	return (int64_t)(r.gc + oct_sum(part));
+}
+
+template<bool LIST, bool DENSE>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, int64_t *pos, int64_t n2, int64_t m2,
-		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps)
+		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs)
 {
 	const int lane = threadIdx.x & 63, j = lane & 7;
+	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
+	// it hosts: the host then enables only the first `octs` octets of each wave and launches more waves.
+	if ((lane >> 3) >= octs) return;
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
 	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
-	bool active = false, exact = false, foreign = false;
-	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, wid = 0;
-	unsigned long long steps = 0;
+	bool active = false, exact = false, check = false;
+	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, seen = RB3_UNSET;
+	uint64_t x = 0;
+	uint32_t steps = 0;
+	// Recorded rows are written through to memory (agent scope) so that walkers on other XCDs can see
+	// them.  Each octet parks up to 8 records in its lanes (lane it&7 takes iteration it) and the whole
+	// wave flushes them with ONE store instruction every 8 iterations.
+	int64_t bkb = -1, bval = 0;
+	uint32_t it = 0;
 	for (;;) {
+		// ---- refill: every octet without a walker pulls the next one from the queue (rare) ----
 		if (!active) {
 			uint32_t w0 = 0, w1 = 0;
 			if (j == 0) {
@@ -430,77 +491,69 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 				w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
 			}
 			w0 = oct_bcast0(w0, j), w1 = oct_bcast0(w1, j);
-			wid = (int64_t)((uint64_t)w1 << 32 | w0);
-			if (wid >= nwalk) break;
+			const int64_t wid = (int64_t)((uint64_t)w1 << 32 | w0);
+			if (wid >= nwalk) {
+				if (bkb >= 0) st_pos(&pos[bkb], bval);
+				break;
+			}
 			if (LIST) {
 				const Walker w = wl[wid];
-				kb = w.row, remaining = w.nsteps, foreign = (w.flags & RB3_WK_CHECK) != 0;
+				kb = w.row, remaining = w.nsteps, check = (w.flags & RB3_WK_CHECK) != 0;
 				if (w.ka0 >= 0) lo = hi = w.ka0, exact = true;
 				else lo = 0, hi = b1.n, exact = (b1.n == 0);
-				if (!exact && ld_pos(&pos[kb]) != RB3_UNSET) continue; // an exact walker already came through
 			} else {
-				foreign = false, remaining = INT64_MAX;
+				check = false, remaining = INT64_MAX;
 				if (wid < m2) kb = wid, lo = hi = b1.m, exact = true;
-				else {
-					kb = first_marked + ((wid - m2) << logM);
-					lo = 0, hi = b1.n, exact = (b1.n == 0);
-					if (ld_pos(&pos[kb]) != RB3_UNSET) continue;
-				}
+				else kb = first_marked + ((wid - m2) << logM), lo = 0, hi = b1.n, exact = (b1.n == 0);
 			}
+			seen = RB3_UNSET;
+			if (!exact || check) {
+				seen = ld_pos(&pos[kb]);
+				if (!exact && seen != RB3_UNSET) continue; // an exact walker already came through
+			}
+			x = lf2[kb];
 			active = true;
 		}
-		// One LF step.  Two independent dependency chains meet here: kb -> lf2[kb] (one HBM/MALL
-		// access) and ka -> group entry -> slot (two cache-friendlier accesses).  vmcnt retires in
-		// issue order, so the directory loads go first, the slot loads as soon as the directory is
-		// back, and lf2[kb] / the recorded-row check are only waited for at the very end: the step
-		// costs max(latency(lf2), latency(grp) + latency(slot)) instead of their sum.
-		RankLoad rl, rh;
-		oct_rank_issue_grp(b1, lo, j, rl);
-		if (!exact) oct_rank_issue_grp(b1, hi, j, rh);
-		const uint64_t x = lf2[kb];
-		// recorded-row check: always issued (a branch here would make the compiler drain vmcnt inside
-		// it); walkers that do not need it read a fixed, cache-resident word instead
-		const bool need_check = exact && foreign;
-#ifdef RB3_EXP_NO_DUMMY
-		int64_t seen_raw = RB3_UNSET;
-		if (need_check) seen_raw = ld_pos(&pos[kb]);
-#else
-		const int64_t seen_raw = ld_pos(need_check ? &pos[kb] : pos);
-#endif
-		__builtin_amdgcn_sched_barrier(0);
-		oct_rank_issue_slot(b1, j, rl);
-		if (!exact) oct_rank_issue_slot(b1, j, rh);
-		__builtin_amdgcn_sched_barrier(0);
-		const int c = (int)(x & 7u);
-		++steps;
-		if (exact) {
-			if (need_check && seen_raw != RB3_UNSET) { active = false; continue; }
-			if (j == 0) st_pos(&pos[kb], lo + kb);
-		}
-		if (c == 0) { active = false; continue; }
-		lo = oct_rank_finish(rl, c, j);
-		if (!exact) {
-			hi = oct_rank_finish(rh, c, j);
-			exact = (lo == hi);
-		}
-		kb = (int64_t)(x >> 3);
-		if (LIST && kb == stop_row) { // the rest of this string is recorded on another GPU
-			if (exact && j == 0) st_pos(arrive, lo);
-			active = false;
-			continue;
-		}
-		bool at_end;
-		if (LIST) at_end = (--remaining == 0);
-		else at_end = M && kb >= m2 && (kb & (M - 1)) == 0;
-		if (at_end) {
-			if (!exact) { active = false; continue; }
-			foreign = true, remaining = INT64_MAX;
-		}
+		// ---- steps: run until some octet of this wave needs a refill.  Two independent dependency
+		// chains meet in a step: kb -> lf2[kb] -> next row, and ka -> directory entry -> slot -> next ka.
+		// The next row's lf2 word (and its recorded-row check) are requested one step ahead, so the
+		// symbol c is known before anything is issued and only the ka chain is on the critical path.
+		// The body is branch-free (selects) except for the second bound of inexact walkers: a lone wave
+		// runs at instruction-issue speed, so instruction count is what a step costs.
+		do {
+			if ((++it & 7u) == 0 && bkb >= 0) { st_pos(&pos[bkb], bval); bkb = -1; }
+			const int c = (int)(x & 7u);
+			const int64_t kbn = (int64_t)(x >> 3);
+			RankLoadC rl, rh;
+			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
+			if (!exact) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
+			const uint64_t xn = lf2[kbn];
+			bool end_next;
+			if (LIST) end_next = remaining == 1;
+			else end_next = M && kbn >= m2 && (kbn & (M - 1)) == 0;
+			const int64_t seen_n = ld_pos((check || end_next) ? &pos[kbn] : pos);
+			octc_issue_slot<DENSE>(b1, j, rl);
+			if (!exact) octc_issue_slot<DENSE>(b1, j, rh);
+			// this row: record it unless somebody already has
+			++steps;
+			const bool dup = exact && check && seen != RB3_UNSET;
+			const bool fin = (c == 0) || dup;
+			if (exact && !dup && j == (int)(it & 7u)) bkb = kb, bval = lo + kb;
+			// next insertion point(s)
+			const int64_t lo_n = octc_finish<DENSE>(rl, c, j);
+			int64_t hi_n = lo_n;
+			if (!exact) hi_n = octc_finish<DENSE>(rh, c, j);
+			const bool exact_n = (lo_n == hi_n);
+			const bool at_stop = LIST && kbn == stop_row; // the rest of this string is recorded on another GPU
+			if (at_stop && exact_n && !fin && j == 0) st_pos(arrive, lo_n);
+			active = !(fin || at_stop || (end_next && !exact_n));
+			check = check || end_next;
+			remaining = end_next ? INT64_MAX : remaining - 1;
+			kb = kbn, x = xn, seen = seen_n, lo = lo_n, hi = hi_n, exact = exact_n;
+		} while (__all(active));
 	}
 	// per-wave step count (statistics only)
-	unsigned long long s = steps;
-	for (int d = 32; d >= 8; d >>= 1) s += __shfl_xor(s, d);
-	if (lane == 0) atomicAdd(nsteps, s);
+	if (j == 0) atomicAdd(nsteps, (unsigned long long)steps);
 }
 
 /* after the chains: every row must be recorded and pos must be strictly increasing

@@ -50,7 +50,8 @@ typedef struct {
 	int64_t n_rank_launches;     /* launches of the chain kernel */
 	int64_t n_lf_steps;          /* LF steps executed by the chain kernel (incl. speculative ones) */
 	int64_t n_symbols_merged;    /* sum of `len` over merge calls */
-	int64_t n_rounds;            /* chain-resolution rounds over all merges */
+	int64_t n_rounds;            /* chain-kernel launches incl. fallbacks */
+	int64_t n_fallbacks;         /* merges whose optimistic (tentative-record) rank phase had to be redone */
 	int64_t bytes_index;         /* current size of the block array + group directory in HBM */
 	int64_t bytes_peak;          /* high-water mark of device memory owned by the handle */
 } rb3gpu_stats_t;

@@ -35,7 +35,7 @@ struct rb3gpu_s {
 	rb3_grp_t *grp = nullptr;
 	rb3_slot_t *slots = nullptr;
 	// scratch, grown on demand and kept between calls
-	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl;
+	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -169,7 +169,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	(void)hipSetDevice(h->dev);
 	(void)hipStreamSynchronize(h->st);
 	index_drop(h);
-	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl };
+	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	(void)hipStreamDestroy(h->st);
@@ -306,8 +306,9 @@ int rb3gpu_mg_begin(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, void *d_pos_
 	return 0;
 }
 
-/* run LF walkers: walkers == NULL -> one per sentinel row plus automatic SA-order splitting */
-int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t stop_row, int64_t *arrive)
+/* run LF walkers: walkers == NULL -> one per sentinel row plus automatic SA-order splitting.
+ * tent: allow tentative records (single-call merges only; see k_chain) */
+static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t stop_row, int64_t *arrive, int tent)
 {
 	if (!h || (walkers && n_walkers <= 0)) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
@@ -344,11 +345,20 @@ int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walker
 			if (first < len) nwalk += (len - first + M - 1) >> logM;
 		}
 	}
+	// tentative records need ids < 2^22 and merged positions < 2^40
+	const int64_t nids = walkers ? n_walkers : nwalk - m2;
+	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
+	if (nids <= 0 || nids > RB3_TENT_IDS || h->n + len >= (1LL << 40) || stop_row >= 0) tent = 0;
+	int32_t *dres = nullptr, *dlink = nullptr;
+	if (tent) {
+		if ((r = buf_ensure(h, h->dl, (size_t)nids * 8)) < 0) return r;
+		dres = (int32_t*)h->dl.p, dlink = dres + nids;
+		HIPCHK(hipMemsetAsync(dres, 0, (size_t)nids * 8, h->st));
+	}
 	HIPCHK(hipMemsetAsync(qhead, 0, 8, h->st));
 	// octets per wave: all 8 when there are enough walkers to fill the chip (256 CUs x 32 waves), fewer
 	// when the launch is latency-bound anyway
-	int octs = (int)((nwalk + 8191) / 8192);
-	octs = octs < 1 ? 1 : octs > 8 ? 8 : octs;
+	int octs = 8; // measured: fewer octets per wave (more waves) is slower even for few walkers
 	if (getenv("RB3GPU_OCTS")) octs = atoi(getenv("RB3GPU_OCTS"));
 	int64_t nblk = (nwalk + 4 * octs - 1) / (4 * octs);
 	if (nblk > 256 * 8) nblk = 256 * 8;
@@ -359,18 +369,37 @@ int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walker
 		const uint64_t *lf2 = (const uint64_t*)h->lf2.p;
 		const int64_t sr = stop_row < 0 ? -1 : stop_row;
 		const dim3 grid((unsigned)nblk), blk(256);
-		if (walkers && iv.dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, true>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, 0, (const Walker*)dwl, nwalk, sr, darr, qhead, nsteps, octs);
-		else if (walkers) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, 0, (const Walker*)dwl, nwalk, sr, darr, qhead, nsteps, octs);
-		else if (iv.dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false, true>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, logM, (const Walker*)nullptr, nwalk, (int64_t)-1, (int64_t*)nullptr, qhead, nsteps, octs);
-		else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false, false>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, logM, (const Walker*)nullptr, nwalk, (int64_t)-1, (int64_t*)nullptr, qhead, nsteps, octs);
+#define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, \
+			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, dres, dlink)
+		const int sel = (walkers ? 4 : 0) | (iv.dense ? 2 : 0) | (tent ? 1 : 0);
+		switch (sel) {
+		case 0: RB3_LAUNCH_CHAIN(false, false, false); break;
+		case 1: RB3_LAUNCH_CHAIN(false, false, true); break;
+		case 2: RB3_LAUNCH_CHAIN(false, true, false); break;
+		case 3: RB3_LAUNCH_CHAIN(false, true, true); break;
+		case 4: RB3_LAUNCH_CHAIN(true, false, false); break;
+		case 5: RB3_LAUNCH_CHAIN(true, false, true); break;
+		case 6: RB3_LAUNCH_CHAIN(true, true, false); break;
+		default: RB3_LAUNCH_CHAIN(true, true, true); break;
+		}
+#undef RB3_LAUNCH_CHAIN
+		HIPCHK(hipEventRecord(h->ev[7], h->st));
+		if (tent) {
+			hipLaunchKernelGGL(k_resolve, dim3((unsigned)((nids + 255) / 256)), dim3(256), 0, h->st, dres, (const int32_t*)dlink, nids, qhead + 2);
+			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, h->mg_pos, len, (const int32_t*)dres, qhead + 2);
+		}
 	}
-	HIPCHK(hipEventRecord(h->ev[7], h->st));
+	HIPCHK(hipEventRecord(h->ev[5], h->st));
 	if (walkers && arrive) HIPCHK(hipMemcpyAsync(arrive, darr, 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
-	const float ms = ev_ms(h->ev[6], h->ev[7]);
-	h->stt.ms_chain += ms, h->stt.ms_rank += ms;
+	h->stt.ms_chain += ev_ms(h->ev[6], h->ev[7]), h->stt.ms_rank += ev_ms(h->ev[6], h->ev[5]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	return 0;
+}
+
+int rb3gpu_mg_walk(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t stop_row, int64_t *arrive)
+{
+	return mg_walk_impl(h, n_walkers, walkers, stop_row, arrive, 0);
 }
 
 int rb3gpu_mg_pos_ptr(rb3gpu_t *h, void **d_pos, int64_t *len)
@@ -392,8 +421,8 @@ static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)h->mg_pos, len, ntot, misc + 2);
-	unsigned long long hm[4] = {0, 0, 0, 0};
-	HIPCHK(hipMemcpyAsync(hm, misc, 32, hipMemcpyDeviceToHost, h->st));
+	unsigned long long hm[5] = {0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(hm, misc, 40, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	h->stt.n_lf_steps += (int64_t)hm[1];
 #ifdef RB3_PROF
@@ -404,8 +433,8 @@ static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
 				(double)pr[0] / len, (double)pr[1] / len, (double)pr[2] / len, (double)pr[3] / len);
 	}
 #endif
-	if (hm[2] != 0 || hm[3] != 0) {
-		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset and %llu out of order\n", hm[2], hm[3]);
+	if (hm[2] != 0 || hm[3] != 0 || hm[4] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu tentative records unsettled\n", hm[2], hm[3], hm[4]);
 		return RB3GPU_EINTERNAL;
 	}
 	rb3_grp_t *grp = nullptr;
@@ -451,7 +480,18 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 {
 	int r;
 	if ((r = rb3gpu_mg_begin(h, len, d_b2, nullptr, host_acc2)) < 0) return r;
-	if ((r = rb3gpu_mg_walk(h, n_walkers, walkers, -1, nullptr)) < 0) return r;
+	if ((r = mg_walk_impl(h, n_walkers, walkers, -1, nullptr, 1)) < 0) return r;
+	{ // tentative records are optimistic: if any is left unsettled, redo the rank phase without them
+		unsigned long long unsettled = 0;
+		HIPCHK(hipMemcpy(&unsettled, (unsigned long long*)h->misc.p + 4, 8, hipMemcpyDeviceToHost));
+		if (unsettled != 0) {
+			h->stt.n_fallbacks += 1;
+			if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled; redoing the rank phase without tentative records\n", unsettled);
+			HIPCHK(hipMemsetAsync(h->mg_pos, 0xff, (size_t)len * 8, h->st));
+			HIPCHK(hipMemsetAsync((unsigned long long*)h->misc.p + 4, 0, 8, h->st));
+			if ((r = mg_walk_impl(h, n_walkers, walkers, -1, nullptr, 0)) < 0) return r;
+		}
+	}
 	return mg_finish(h, commit, host_pos, rank_only);
 }
 

@@ -103,16 +103,20 @@ __device__ __forceinline__ void oct_rank_issue(const IdxView &ix, int64_t k, int
 	oct_rank_issue_slot(ix, j, r);
 }
 
-/* number of symbols equal to c among the first `off` symbols of the slot, this lane's share */
+/* number of symbols equal to c among the first `off` symbols of the slot, this lane's share;
+ * bit 20 of the result is set in the one lane that holds the symbol AT offset `off` if that symbol is c */
+#define RB3_MATCH_BIT 0x100000u
 __device__ __forceinline__ uint32_t slice_count(const uint4 &sl, uint32_t hdr0, uint32_t off, int c, int j)
 {
 	uint32_t cnt;
 	if (!(hdr0 & RB3_SLOT_RLE)) { // bit planes: symbols [32j, 32j+32)
 		int t = (int)off - 32 * j;
-		t = t < 0 ? 0 : t > 32 ? 32 : t;
 		const uint32_t m0 = (c & 1) ? sl.y : ~sl.y, m1 = (c & 2) ? sl.z : ~sl.z, m2 = (c & 4) ? sl.w : ~sl.w;
+		const uint32_t m = m0 & m1 & m2;
+		const uint32_t at = (t >= 0 && t < 32) ? ((m >> t) & 1u) : 0u;
+		t = t < 0 ? 0 : t > 32 ? 32 : t;
 		const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
-		cnt = __popc(m0 & m1 & m2 & lim);
+		cnt = __popc(m & lim) | (at ? RB3_MATCH_BIT : 0u);
 	} else { // six run codes per lane
 		uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
 		uint32_t len[6], tot = 0;
@@ -127,7 +131,10 @@ __device__ __forceinline__ uint32_t slice_count(const uint4 &sl, uint32_t hdr0, 
 		for (int i = 0; i < 6; ++i) {
 			int d = (int)off - pos;
 			d = d < 0 ? 0 : d > (int)len[i] ? (int)len[i] : d;
-			if ((int)(e[i] & 7u) == c) cnt += (uint32_t)d;
+			if ((int)(e[i] & 7u) == c) {
+				cnt += (uint32_t)d;
+				if ((int)off >= pos && (int)off < pos + (int)len[i]) cnt |= RB3_MATCH_BIT;
+			}
 			pos += (int)len[i];
 		}
 	}
@@ -138,7 +145,7 @@ __device__ __forceinline__ int64_t oct_rank_finish(const RankLoad &r, int c, int
 {
 	const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
 	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
-	uint32_t part = slice_count(r.sl, hdr0, off, c, j);
+	uint32_t part = slice_count(r.sl, hdr0, off, c, j) & (RB3_MATCH_BIT - 1u);
 	if (j == c + 1) part += r.sl.x; // hdr[c+1] = count of c between group start and slot start
 	const uint32_t sum = oct_sum(part);
 	const uint32_t lo = oct_sum(j == c ? (uint32_t)r.gw : 0u);
@@ -445,43 +452,83 @@ __device__ __forceinline__ void octc_issue_slot(const IdxView &ix, int j, RankLo
 	r.sl = ix.slot16[(int64_t)s * 8 + j];
 }
 
+/* LF(c, k) for the octet's query; *match = 1 iff the symbol at offset k itself is c (then the suffix
+ * at row k extends by c: used to advance an interval [k, k+1) with a single rank) */
 template<bool DENSE>
-__device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j)
+__device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j, uint32_t *match)
 {
 	uint32_t part;
 	if (DENSE) { // bit planes, slot start = window start
 		int t = (int)(r.koff & (RB3_WIN - 1)) - 32 * j;
-		t = t < 0 ? 0 : t > 32 ? 32 : t;
 		const uint32_t m0 = (c & 1) ? r.sl.y : ~r.sl.y, m1 = (c & 2) ? r.sl.z : ~r.sl.z, m2 = (c & 4) ? r.sl.w : ~r.sl.w;
+		const uint32_t m = m0 & m1 & m2;
+		const uint32_t at = (t >= 0 && t < 32) ? ((m >> t) & 1u) : 0u;
+		t = t < 0 ? 0 : t > 32 ? 32 : t;
 		const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
-		part = __popc(m0 & m1 & m2 & lim);
+		part = __popc(m & lim) | (at ? RB3_MATCH_BIT : 0u);
 	} else {
 		const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
 		part = slice_count(r.sl, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
 	}
 	if (j == c + 1) part += r.sl.x;
-	return (int64_t)(r.gc + oct_sum(part));
+	const uint32_t sum = oct_sum(part);
+	*match = sum >> 20;
+	return (int64_t)(r.gc + (sum & (RB3_MATCH_BIT - 1u)));
 }
 
-template<bool LIST, bool DENSE>
+/* Tentative records (TENT = true).  An inexact walker whose interval has shrunk to [lo, lo+1)
+ * -- exactly one suffix of B1's text starts with what it has read -- knows ka up to one bit
+ * d = ka - lo, and that bit does not change while the interval keeps size 1 (the unique suffix and
+ * the new one extend by the same symbol, so their order is preserved).  Such a walker records
+ * RB3_TENT | id << 40 | (lo + kb) and moves on with ONE rank per step (hi' = lo' + [B1[lo] == c]).
+ * Whoever later walks into those rows knowing more settles the bit instead of redoing the rows:
+ *   an exact walker      -> dres[id] = 1 + d                       and stops;
+ *   a tentative walker   -> dlink[id] = its own id (same unique suffix, same bit) and stops;
+ * a tentative walker that meets a final value learns its own bit the same way.  k_resolve then
+ * follows the links and k_pos_finalize rewrites the tentative records.  The critical path of a merge
+ * drops from the longest variant-free stretch of the batch to about one segment.
+ *
+ * Concurrency.  Records become visible late (lane-parked, written through), so a follower only a
+ * few rows behind a tentative walker would read "unset", record its own value and never notice
+ * the tags.  Three measures: (1) in TENT mode every record is an unsigned 64-bit atomic MIN, and
+ * the encoding orders final < tentative < unset, so the better-informed value always survives
+ * whatever the arrival order; (2) a walker records tentatively only once it is RB3_TENT_MIN_AGE
+ * steps old, so whoever follows it into its segment is that many rows behind; (3) the host counts
+ * unsettled tentative records after the launch and, if there are any, redoes the rank phase without
+ * tentative records (rb3gpu.hip).  Correctness therefore never depends on timing.
+ */
+#define RB3_TENT      (1LL << 62)
+#define RB3_TENT_MASK ((1LL << 40) - 1)
+#define RB3_TENT_IDS  (1 << 22)
+#define RB3_TENT_MIN_AGE 64u
+
+template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t v)
+{
+	if (TENT) atomicMin((unsigned long long*)p, (unsigned long long)v); // final < tentative < unset (0xFFFF...)
+	else st_pos(p, v);
+}
+
+template<bool LIST, bool DENSE, bool TENT>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, int64_t *pos, int64_t n2, int64_t m2,
-		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs)
+		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
+		int32_t *dres, int32_t *dlink)
 {
 	const int lane = threadIdx.x & 63, j = lane & 7;
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
-	// it hosts: the host then enables only the first `octs` octets of each wave and launches more waves.
+	// it hosts: the host may enable only the first `octs` octets of each wave and launch more waves.
 	if ((lane >> 3) >= octs) return;
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
 	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
-	bool active = false, exact = false, check = false;
-	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, seen = RB3_UNSET;
+	bool active = false, check = false;
+	int gap = 0;            // 0: exact (lo == hi), 1: hi == lo + 1, 2: wider
+	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, seen = RB3_UNSET, myid = 0;
 	uint64_t x = 0;
 	uint32_t steps = 0;
 	// Recorded rows are written through to memory (agent scope) so that walkers on other XCDs can see
 	// them.  Each octet parks up to 8 records in its lanes (lane it&7 takes iteration it) and the whole
 	// wave flushes them with ONE store instruction every 8 iterations.
 	int64_t bkb = -1, bval = 0;
-	uint32_t it = 0;
+	uint32_t it = 0, age = 0;
 	for (;;) {
 		// ---- refill: every octet without a walker pulls the next one from the queue (rare) ----
 		if (!active) {
@@ -493,23 +540,26 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			w0 = oct_bcast0(w0, j), w1 = oct_bcast0(w1, j);
 			const int64_t wid = (int64_t)((uint64_t)w1 << 32 | w0);
 			if (wid >= nwalk) {
-				if (bkb >= 0) st_pos(&pos[bkb], bval);
+				if (bkb >= 0) rec_pos<TENT>(&pos[bkb], bval);
 				break;
 			}
 			if (LIST) {
 				const Walker w = wl[wid];
 				kb = w.row, remaining = w.nsteps, check = (w.flags & RB3_WK_CHECK) != 0;
-				if (w.ka0 >= 0) lo = hi = w.ka0, exact = true;
-				else lo = 0, hi = b1.n, exact = (b1.n == 0);
+				if (w.ka0 >= 0) lo = hi = w.ka0;
+				else lo = 0, hi = b1.n;
+				myid = wid;
 			} else {
 				check = false, remaining = INT64_MAX;
-				if (wid < m2) kb = wid, lo = hi = b1.m, exact = true;
-				else kb = first_marked + ((wid - m2) << logM), lo = 0, hi = b1.n, exact = (b1.n == 0);
+				if (wid < m2) kb = wid, lo = hi = b1.m;
+				else kb = first_marked + ((wid - m2) << logM), lo = 0, hi = b1.n;
+				myid = wid - m2;
 			}
-			seen = RB3_UNSET;
-			if (!exact || check) {
+			gap = hi - lo > 1 ? 2 : (int)(hi - lo);
+			seen = RB3_UNSET, age = 0;
+			if (gap || check) {
 				seen = ld_pos(&pos[kb]);
-				if (!exact && seen != RB3_UNSET) continue; // an exact walker already came through
+				if (gap && seen != RB3_UNSET) continue; // somebody already came through
 			}
 			x = lf2[kb];
 			active = true;
@@ -518,46 +568,99 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 		// chains meet in a step: kb -> lf2[kb] -> next row, and ka -> directory entry -> slot -> next ka.
 		// The next row's lf2 word (and its recorded-row check) are requested one step ahead, so the
 		// symbol c is known before anything is issued and only the ka chain is on the critical path.
-		// The body is branch-free (selects) except for the second bound of inexact walkers: a lone wave
-		// runs at instruction-issue speed, so instruction count is what a step costs.
+		// The body is branch-free (selects) except for the second bound of wide walkers and the rare
+		// settle events: a lone wave runs at instruction-issue speed, so instruction count is the cost.
 		do {
-			if ((++it & 7u) == 0 && bkb >= 0) { st_pos(&pos[bkb], bval); bkb = -1; }
+			if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<TENT>(&pos[bkb], bval); bkb = -1; }
 			const int c = (int)(x & 7u);
 			const int64_t kbn = (int64_t)(x >> 3);
+			const bool wide = TENT ? gap == 2 : gap != 0;
+			const bool tentok = TENT && gap == 1 && age >= RB3_TENT_MIN_AGE; // may record tentatively
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
-			if (!exact) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
+			if (wide) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
 			const uint64_t xn = lf2[kbn];
 			bool end_next;
 			if (LIST) end_next = remaining == 1;
 			else end_next = M && kbn >= m2 && (kbn & (M - 1)) == 0;
 			const int64_t seen_n = ld_pos((check || end_next) ? &pos[kbn] : pos);
 			octc_issue_slot<DENSE>(b1, j, rl);
-			if (!exact) octc_issue_slot<DENSE>(b1, j, rh);
+			if (wide) octc_issue_slot<DENSE>(b1, j, rh);
 			// this row: record it unless somebody already has
 			++steps;
-			const bool dup = exact && check && seen != RB3_UNSET;
-			const bool fin = (c == 0) || dup;
-			if (exact && !dup && j == (int)(it & 7u)) bkb = kb, bval = lo + kb;
+			const bool met = check && seen != RB3_UNSET;
+			const bool fin = (c == 0) || met;
+			const int64_t myval = lo + kb;
+			if (TENT && met) { // settle one bit (rare)
+				if (!(seen & RB3_TENT)) { // a final value: my own bit, if I am tentative
+					if (gap == 1 && j == 0) dres[myid] = 1 + (int)(seen - myval);
+				} else {
+					const int id2 = (int)(seen >> 40) & (RB3_TENT_IDS - 1);
+					if (j == 0) {
+						if (gap == 0) dres[id2] = 1 + (int)(myval - (seen & RB3_TENT_MASK));
+						else if (gap == 1) dlink[id2] = (int)myid + 1; // same unique suffix (equal lo), hence the same bit
+					}
+				}
+			}
+			if ((gap == 0 || tentok) && !met && j == (int)(it & 7u))
+				bkb = kb, bval = gap ? (RB3_TENT | (myid << 40) | myval) : myval;
 			// next insertion point(s)
-			const int64_t lo_n = octc_finish<DENSE>(rl, c, j);
+			uint32_t match, mh;
+			const int64_t lo_n = octc_finish<DENSE>(rl, c, j, &match);
 			int64_t hi_n = lo_n;
-			if (!exact) hi_n = octc_finish<DENSE>(rh, c, j);
-			const bool exact_n = (lo_n == hi_n);
+			if (TENT && gap == 1) hi_n = lo_n + match;
+			if (wide) hi_n = octc_finish<DENSE>(rh, c, j, &mh);
+			const int gap_n = hi_n - lo_n > 1 ? 2 : (int)(hi_n - lo_n);
+			++age;
+			// at the end of its own segment a walker goes on only if it is exact or already recording tentatively
+			const bool stop_wide = !(gap_n == 0 || (TENT && gap_n == 1 && age >= RB3_TENT_MIN_AGE));
 			const bool at_stop = LIST && kbn == stop_row; // the rest of this string is recorded on another GPU
-			if (at_stop && exact_n && !fin && j == 0) st_pos(arrive, lo_n);
-			active = !(fin || at_stop || (end_next && !exact_n));
+			if (at_stop && gap_n == 0 && !fin && j == 0) st_pos(arrive, lo_n);
+			active = !(fin || at_stop || (end_next && stop_wide));
 			check = check || end_next;
 			remaining = end_next ? INT64_MAX : remaining - 1;
-			kb = kbn, x = xn, seen = seen_n, lo = lo_n, hi = hi_n, exact = exact_n;
+			kb = kbn, x = xn, seen = seen_n, lo = lo_n, hi = hi_n, gap = gap_n;
 		} while (__all(active));
 	}
-	// per-wave step count (statistics only)
 	if (j == 0) atomicAdd(nsteps, (unsigned long long)steps);
 }
 
-/* after the chains: every row must be recorded and pos must be strictly increasing
- * (ka is non-decreasing in kb).  bad[0] += #unset, bad[1] += #order violations */
+/* settle the tentative bits: follow dlink until a stretch with a known bit; dres[i] becomes 1 + bit */
+__global__ void __launch_bounds__(256) k_resolve(int32_t *dres, const int32_t *dlink, int64_t n, unsigned long long *bad)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (dres[i] != 0 || dlink[i] == 0) return; // known, or never recorded anything tentative
+	int64_t cur = i;
+	int r = 0;
+	for (int hop = 0; hop < 1 << 20; ++hop) {
+		r = __hip_atomic_load(&dres[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (r != 0 || dlink[cur] == 0) break;
+		cur = dlink[cur] - 1;
+	}
+	if (r == 0) atomicAdd(&bad[2], 1ull); // a tentative stretch nobody settled
+	else __hip_atomic_store(&dres[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* after the chains: rewrite tentative records (pos = lo + bit + kb), then every row must be recorded
+ * and pos must be strictly increasing (ka is non-decreasing in kb).
+ * bad[0] += #unset, bad[1] += #order violations, bad[2] += #unsettled tentative records */
+__device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *dres, unsigned long long *bad)
+{
+	if (v < 0 || !(v & RB3_TENT)) return v;
+	const int r = dres[(int)(v >> 40) & (RB3_TENT_IDS - 1)];
+	if (r != 1 && r != 2) { atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
+	return (v & RB3_TENT_MASK) + (r - 1);
+}
+
+__global__ void __launch_bounds__(256) k_pos_finalize(int64_t *pos, int64_t n2, const int32_t *dres, unsigned long long *bad)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n2) return;
+	const int64_t v = pos[i];
+	if (v >= 0 && (v & RB3_TENT)) pos[i] = pos_final(v, dres, bad);
+}
+
 __global__ void __launch_bounds__(256) k_pos_check(const int64_t *pos, int64_t n2, int64_t ntot, unsigned long long *bad)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -34,7 +34,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("ms_h2d", ctypes.c_double), ("ms_lf", ctypes.c_double), ("ms_rank", ctypes.c_double),
                 ("ms_build", ctypes.c_double), ("ms_export", ctypes.c_double), ("ms_chain", ctypes.c_double),
                 ("n_rank_launches", ctypes.c_int64), ("n_lf_steps", ctypes.c_int64), ("n_symbols_merged", ctypes.c_int64),
-                ("n_rounds", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64)]
+                ("n_rounds", ctypes.c_int64), ("n_fallbacks", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

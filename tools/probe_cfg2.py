@@ -19,13 +19,13 @@ def run(name, h, fn, reps=5):
     for _ in range(reps): fn()
     dt = (time.time() - t) / reps
     st = h.stats()
-    print("%-22s %.2f ms/merge (lf %.2f chain %.2f build %.2f) steps=%d -> %.3f Gsym/s" % (name, dt*1e3, st['ms_lf']/reps, st['ms_chain']/reps, st['ms_build']/reps, st['n_lf_steps']//reps, b2.size/dt/1e9))
+    print("%-22s %.2f ms/merge (lf %.2f chain %.2f build %.2f) steps=%d fb=%d -> %.3f Gsym/s" % (name, dt*1e3, st['ms_lf']/reps, st['ms_chain']/reps, st['ms_build']/reps, st['n_lf_steps']//reps, st['n_fallbacks'], b2.size/dt/1e9))
 for sl in [8, 9]:
     h = Rb3Gpu(split_log2=sl, verbose=1); h.from_plain(b1); d = h.dev_upload(b2)
     run("sa-order 2^%d" % sl, h, lambda: h.merge_plain_dev(d, b2.size, commit=False))
     h.dev_free(d); h.close()
 h = Rb3Gpu(verbose=1); h.from_plain(b1); d = h.dev_upload(b2)
-for step in [128, 256, 512, 1024, 2048, 4096]:
+for step in [192, 256, 384, 512, 768, 1024]:
     _, w = host.build_bwt_walkers(t2, step)
     run("text step %d (%d w)" % (step, w.shape[0]), h, lambda: h.merge_plain_dev_walkers(d, b2.size, w, commit=False))
 _, w = host.build_bwt_walkers(t2, 512)

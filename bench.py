@@ -2,22 +2,26 @@
 """bench.py -- merge-path throughput of the MI355X engine (BASELINE.json metric:
 "Gbp/sec indexed (build merge)").
 
-A STEP is one pass of the hot path over one batch: rb3gpu_merge_plain_dev() = LF array of the
-partial BWT B2 + all LF chains against the accumulated BWT B1 (rank) + interleave/rebuild of the
-block array, with B1 and B2 already resident in HBM and the result discarded (commit=0) so that
-every step does identical work.  Workload at N=1 = BASELINE.json configs[1] as SURVEY 8(d)
-defines it without network access: G0 = 4.4 Mbp of uniform random ACGT (seed 1), G1 = G0 with
-0.1 % substitutions (seed 2); the step merges G1 (both strands, 8,800,002 symbols, 2 strings)
-into the index of G0.  At N>1 the batch grows with N (weak scaling): it holds N genomes G_1..G_N
-(seeds 2..N+1, 8,800,002 symbols per GPU); the index is replicated, the batch's LF walkers are
-sharded across the ranks by text range and pos[] is combined with one RCCL all-reduce(MAX) per step
-(ropebwt3_amd/multi.py); value = symbols merged by the whole job / max-over-ranks time.
+A STEP is one pass of the hot path over one batch: LF array of the partial BWT B2 + all LF walkers
+against the accumulated BWT B1 (rank) + interleave/rebuild of the block array, with B1, B2 and the
+walker list already resident / in hand and the result discarded (commit=0) so that every step does
+identical work.
+
+N=1 workload = BASELINE.json configs[1] as SURVEY 8(d) defines it without network access:
+G0 = 4.4 Mbp of uniform random ACGT (seed 1), G1 = G0 with 0.1 % substitutions (seed 2); the step
+merges G1 (both strands, 8,800,002 symbols, 2 strings) into the index of G0.
+
+N>1 (weak scaling, one process per GPU): the input is partitioned across the GPUs -- rank r merges
+its own batch G_{r+1} (seed 2+r, 8,800,002 symbols) into the index its GPU holds; no data-path
+collective inside a step.  value = symbols merged by all ranks / max-over-ranks time.  The
+partitioned build ends with a binary tree of whole-index merges (ropebwt3_amd.multi.tree_merge, plain
+BWTs over RCCL/xGMI); its time is reported separately as tree_merge_ms.  `--sharded` selects the
+alternative decomposition (one batch of N genomes, walkers sharded by text range, all-reduce of pos[]).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -28,7 +32,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_SYMBOL_RANK = 208   # 16 B row entry r/w + 64 B directory line + 128 B block line per LF step
+ALGO_BYTES_PER_STEP = 208          # 16 B row entry r/w + 64 B directory line + 128 B block line per LF step
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -43,8 +47,8 @@ def gen_genomes(n, rate, seed0, seeds):
     return g0, [util.mutate(np.random.default_rng(s), g0, rate) for s in seeds]
 
 
-def cpu_baseline(b1, b2, seconds_cap=60.0):
-    """Time the merge of the SAME workload on the host cores: the unmodified reference
+def cpu_baseline(b1, b2):
+    """Time the merge of the SAME step on the host cores: the unmodified reference
     (oracle/_ref/librb3ref.so: rb3_enc_plain2fmr + rb3_fmi_merge_plain) when it travelled with
     the repository, else the OpenMP port in oracle/liboracle.so.  Checker/baseline only."""
     from tests import util
@@ -65,32 +69,67 @@ def cpu_baseline(b1, b2, seconds_cap=60.0):
         kind = "port"
     n_str = int((b2 == 0).sum())
     return {"value": b2.size / dt / 1e9, "unit": "Gbp/s", "cores": cores, "kind": kind, "seconds": round(dt, 3),
-            "sample": "the full N=1 step (%d symbols, %d strings -> only %d of the %d threads have work, as in the reference's kt_for over strings)" % (b2.size, n_str, min(n_str, cores), cores)}
+            "sample": "the full N=1 step (%d symbols, %d strings -> only %d of the %d threads offered have work, as in the reference's kt_for over strings)" % (b2.size, n_str, min(n_str, cores), cores)}
 
 
-def load_pmc_traffic(workload):
+def load_pmc_traffic():
     """HBM bytes per k_chain launch from the committed rocprofv3 --pmc passes (profiles/), if any."""
-    fn = os.path.join(ROOT, "profiles", "r1_pmc_k_chain.json")
     try:
-        d = json.load(open(fn))
-        if d.get("workload") == workload:
-            return d.get("hbm_bytes_per_launch")
+        return json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k_chain.json"))).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
-        pass
-    return None
+        return None
+
+
+def reads_regime(h_factory, n_reads, seed=11):
+    """Auxiliary measurement in the many-short-strings regime (where the chain kernel is bound by HBM
+    bandwidth rather than latency): merge n_reads x 150 bp reads (both strands) into an index of as many."""
+    from ropebwt3_amd import host
+    from tests import util
+    rng = np.random.default_rng(seed)
+    g = util.random_genome(rng, 10 * n_reads)
+    st = rng.integers(0, len(g) - 150, size=2 * n_reads)
+
+    def reads(idx):
+        r = np.stack([g[s:s + 150] for s in idx])
+        m = rng.random(r.shape) < 0.01
+        r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
+        return list(r)
+    b1 = host.build_bwt(util.make_text(reads(st[:n_reads])))
+    b2 = host.build_bwt(util.make_text(reads(st[n_reads:])))
+    h = h_factory()
+    h.from_plain(b1)
+    d = h.dev_upload(b2)
+    h.merge_plain_dev(d, b2.size, commit=False)
+    h.stats_reset()
+    reps = 5
+    t = time.perf_counter()
+    for _ in range(reps):
+        h.merge_plain_dev(d, b2.size, commit=False)
+    dt = (time.perf_counter() - t) / reps
+    st_ = h.stats()
+    ms_chain = st_["ms_chain"] / reps
+    h.dev_free(d)
+    h.close()
+    ach = ALGO_BYTES_PER_STEP * b2.size / (ms_chain * 1e-3) / 1e9
+    return {"workload": "reads regime: merge %d x 150 bp reads (both strands, %d symbols, %d strings) into an index of %d symbols" % (n_reads, b2.size, 2 * n_reads, b1.size),
+            "value": round(b2.size / dt / 1e9, 4), "unit": "Gbp/s", "ms_per_step": round(dt * 1e3, 3),
+            "roofline": {"bound": "hbm", "kernel": "k_chain", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "ms_per_launch": round(ms_chain, 4), "lf_steps_per_s": round(b2.size / (ms_chain * 1e-3) / 1e9, 3)}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--genome-len", type=int, default=4400000)
     ap.add_argument("--div", type=float, default=0.001)
-    ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--walker-step", type=int, default=512, help="text distance between LF walkers handed to the engine")
+    ap.add_argument("--plain-abi", action="store_true", help="use rb3gpu_merge_plain_dev (the reference's signature, no walker list)")
+    ap.add_argument("--sharded", action="store_true", help="N>1: one batch of N genomes, walkers sharded by text range + all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path even with one rank")
-    ap.add_argument("--walker-step", type=int, default=512)
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary reads-regime measurement")
+    ap.add_argument("--aux-reads", type=int, default=100000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,28 +142,32 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ropebwt3_amd import Rb3Gpu, host
+    from ropebwt3_amd import Rb3Gpu, host, multi
+    from tests import util
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False and the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.sharded
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     t0 = time.time()
-    sharded = world > 1 or args.sharded
-    g0, gs = gen_genomes(args.genome_len, args.div, 1, [2 + i for i in range(world)])
-    from tests import util
+    sharded = args.sharded
+    seeds = [2 + i for i in range(world)] if sharded else [2 + rank]
+    g0, gs = gen_genomes(args.genome_len, args.div, 1, seeds)
     b1 = host.build_bwt(util.make_text([g0]))
     walkers = None
-    if sharded:
-        b2, walkers = host.build_bwt_walkers(util.make_text(gs), args.walker_step)
-    else:
+    if args.plain_abi and not sharded:
         b2 = host.build_bwt(util.make_text(gs))
-    log("inputs: B1 %d symbols, B2 %d symbols per GPU; host suffix sorting %.1f s (not timed)" % (b1.size, b2.size, time.time() - t0))
+    else:
+        b2, walkers = host.build_bwt_walkers(util.make_text(gs), args.walker_step)
+    log("inputs: B1 %d symbols, B2 %d symbols on each GPU; host suffix sorting %.1f s (not timed)" % (b1.size, b2.size, time.time() - t0))
 
-    h = Rb3Gpu(device=local_rank, split_log2=args.split, verbose=1)
+    h = Rb3Gpu(device=local_rank, verbose=1)
     h.from_plain(b1)
     d_b2 = h.dev_upload(b2)
 
@@ -135,15 +178,13 @@ def main():
             dist.barrier()
 
     if sharded:
-        from ropebwt3_amd import multi
-        if world == 1 and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        pos = torch.empty(b2.size, dtype=torch.int64, device="cuda")
+        pos = torch.empty(b2.size, dtype=torch.int64, device=dev)
 
         def step(commit=False):
-            return multi.merge_sharded(h, d_b2, b2.size, walkers, args.walker_step, dist, rank, world, pos, commit=commit, sync=torch.cuda.synchronize)
+            multi.merge_sharded(h, d_b2, b2.size, walkers, args.walker_step, dist, rank, world, pos, commit=commit, sync=torch.cuda.synchronize)
+    elif walkers is not None:
+        def step(commit=False):
+            h.merge_plain_dev_walkers(d_b2, b2.size, walkers, commit=commit)
     else:
         def step(commit=False):
             h.merge_plain_dev(d_b2, b2.size, commit=commit)
@@ -160,44 +201,65 @@ def main():
     dt = time.perf_counter() - t
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     st = h.stats()
 
-    # one committed merge + export, to make sure the timed path produces the right index
+    # one committed merge, to make sure the timed path produces a consistent index
     step(commit=True)
     acc = h.get_acc()
     assert acc[6] == b1.size + b2.size
 
+    tree_ms = None
+    if world > 1 and not sharded:  # the closing phase of a partitioned build: merge the per-GPU indexes into rank 0
+        barrier()
+        t = time.perf_counter()
+        tot = multi.tree_merge(h, dist, rank, world, dev, sync=torch.cuda.synchronize)
+        barrier()
+        tree_ms = (time.perf_counter() - t) * 1e3
+        if rank == 0:
+            assert tot == world * (b1.size + b2.size)
+
     if rank == 0:
-        n_sym = b2.size * args.steps
-        value = n_sym / dt / 1e9
+        sym_per_step = b2.size if sharded else b2.size * world
+        value = sym_per_step * args.steps / dt / 1e9
         ms_chain = st["ms_chain"] / max(1, st["n_rank_launches"])
-        algo_bytes = ALGO_BYTES_PER_SYMBOL_RANK * b2.size // world   # rows recorded per launch on one rank
+        rows_per_launch = b2.size // world if sharded else b2.size
+        algo_bytes = ALGO_BYTES_PER_STEP * rows_per_launch
         achieved = algo_bytes / (ms_chain * 1e-3) / 1e9
-        workload = "cfg2-synthetic-mtb1: merge %d genome(s) G_i = G0 + 0.1%% subs (%d bp each, both strands, %d symbols, %d strings) into the index of G0 (%d symbols)" % (world, args.genome_len, b2.size, 2 * world, b1.size)
+        if sharded:
+            par = "one batch of %d genomes; index replicated, walkers sharded by text range over %d GPUs, all-reduce(MAX) of pos[] per step" % (world, world)
+        elif world > 1:
+            par = "input partitioned over %d GPUs: every GPU merges its own batch into the index it holds; no collective inside a step; closing tree merge reported as tree_merge_ms" % world
+        else:
+            par = "single GPU"
         out = {
             "metric": "Gbp/s indexed (build merge)", "value": round(value, 6), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": workload, "symbols_per_step_per_gpu": int(b2.size // world), "strings_per_step": int((b2 == 0).sum()),
-                       "index_symbols": int(b1.size),
-                       "parallelism": ("replicated index, walkers sharded by text range over %d GPUs, all-reduce(MAX) of pos[] per step" % world) if sharded else "single GPU",
-                       "split_log2": args.split, "lf_steps_per_step": int(st["n_lf_steps"] // max(1, args.steps))},
+            "config": {"workload": "cfg2-synthetic-mtb1: per GPU, merge G_i = G0 + 0.1%% substitutions (%d bp, both strands, %d symbols, 2 strings) into the index of G0 (%d symbols)" % (args.genome_len, rows_per_launch, b1.size),
+                       "symbols_per_step_per_gpu": int(rows_per_launch), "index_symbols": int(b1.size), "parallelism": par,
+                       "entry_point": "rb3gpu_merge_plain_dev (reference signature, SA-order walkers)" if walkers is None else
+                                      "rb3gpu_merge_plain_dev_walkers (BWT + sampled inverse suffix array from the host suffix sorter, text step %d, %d walkers)" % (args.walker_step, len(walkers)),
+                       "lf_steps_per_step": int(st["n_lf_steps"] // max(1, args.steps)), "rank_phase_fallbacks": int(st["n_fallbacks"])},
             "phases_ms_per_step": {"lf": round(st["ms_lf"] / args.steps, 4), "rank": round(st["ms_rank"] / args.steps, 4),
                                    "rebuild": round(st["ms_build"] / args.steps, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_chain", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": load_pmc_traffic("cfg2"),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": load_pmc_traffic(),
                          "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_chain, 4),
-                         "note": "few-long-strings regime: the kernel is bound by dependent-load latency, not bandwidth"},
+                         "note": "8.8 M rows in ~17 k walkers: partly latency-bound; see aux_reads_regime for the bandwidth-bound regime of the same kernel"},
         }
-        if world == 1 and not args.no_cpu_baseline and not args.sharded:
+        if tree_ms is not None:
+            out["tree_merge_ms"] = round(tree_ms, 3)
+        if world == 1 and not args.no_aux:
+            out["aux_reads_regime"] = reads_regime(lambda: Rb3Gpu(device=local_rank, verbose=1), args.aux_reads)
+        if world == 1 and not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(b1, b2)
         print(json.dumps(out), flush=True)
     h.dev_free(d_b2)
     h.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

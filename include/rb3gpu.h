@@ -136,6 +136,11 @@ int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data);
  * small indexes / tests only. */
 int rb3gpu_export_plain(rb3gpu_t *h, uint8_t *out);
 
+/* same into device memory of the handle's GPU (rb3gpu_get_tot() bytes): the plain BWT of an index
+ * is itself a valid partial BWT, so a whole index can be merged into another one with
+ * rb3gpu_merge_plain_dev -- the tree-shaped multi-GPU build (rb3_fmi_merge, fm-index.c:251-277) */
+int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out);
+
 /* Import for `build -i` (rb3_enc_fmd2fmr fm-index.c:56-85, mr_restore mrope.c:161-177):
  * runs[i] = len<<3 | sym in BWT order (host memory). */
 int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs);

@@ -116,7 +116,7 @@ static int dump_fmr(rb3gpu_t *h, const bopt_t *opt, FILE *fp)
 
 /* ---- batches ----------------------------------------------------------------------------- */
 
-typedef struct { int64_t n_seq, len; uint8_t *bwt; int ret; } batch_t;
+typedef struct { int64_t n_seq, len, n_walkers; uint8_t *bwt; rb3h_walker_t *walkers; int ret; } batch_t;
 
 static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 {
@@ -126,7 +126,10 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] encoded the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 	} else {
-		ret = rb3gpu_merge_plain(h, b->len, b->bwt);
+		/* long strings: hand over the sampled inverse suffix array as LF walkers (same result, text-regular
+		 * parallelism); short strings (reads): one walker per string is what the engine does by itself */
+		if (b->walkers) ret = rb3gpu_merge_plain_walkers(h, b->len, b->bwt, b->n_walkers, (const rb3gpu_walker_t*)b->walkers);
+		else ret = rb3gpu_merge_plain(h, b->len, b->bwt);
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] merged the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 	}
@@ -159,7 +162,13 @@ typedef struct {
 static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_threads, batch_t **out)
 {
 	batch_t *b;
-	int r = rb3h_build_bwt(n_seq, seq->l, seq->s, n_threads);
+	int64_t n_walkers = 0;
+	rb3h_walker_t *walkers = 0;
+	const int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : 512;
+	int r;
+	if (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22))
+		r = rb3h_build_bwt_walkers(n_seq, seq->l, seq->s, n_threads, step, &n_walkers, &walkers);
+	else r = rb3h_build_bwt(n_seq, seq->l, seq->s, n_threads);
 	if (r < 0) {
 		fprintf(stderr, "ERROR: failed to construct the partial BWT (code %d)\n", r);
 		return -1;
@@ -167,7 +176,7 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	if (rb3h_verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)seq->l);
 	b = (batch_t*)calloc(1, sizeof(batch_t));
-	b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s;
+	b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s, b->n_walkers = n_walkers, b->walkers = walkers;
 	seq->s = 0, seq->l = seq->m = 0; /* ownership moves to the batch */
 	*out = b;
 	(void)opt;
@@ -230,7 +239,7 @@ static int consume(void *data, batch_t *b, const char *fn, int end_of_file)
 	consumer_t *c = (consumer_t*)data;
 	if (b) {
 		int r = process_batch(c->h, b, &c->has_index);
-		free(b->bwt); free(b);
+		free(b->bwt); free(b->walkers); free(b);
 		if (r < 0) return r;
 	}
 	if (end_of_file && c->fn_tmp && c->has_index) { /* build.c:232-238 */
@@ -366,7 +375,7 @@ int main_build(int argc, char *argv[])
 			pthread_mutex_unlock(&q.mtx);
 			if (b == 0) break;
 			if (ret == 0) ret = consume(&cs, b, 0, 0);
-			else { free(b->bwt); free(b); }
+			else { free(b->bwt); free(b->walkers); free(b); }
 		}
 		pthread_join(tid, 0);
 		if (p.err != 0) ret = -1;

@@ -649,6 +649,18 @@ int rb3gpu_export_plain(rb3gpu_t *h, uint8_t *out)
 	return 0;
 }
 
+int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out)
+{
+	if (!h || !d_out) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	int64_t nblk = (h->n + 255) / 256;
+	if (nblk > 65536) nblk = 65536;
+	hipLaunchKernelGGL(k_export_plain, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (int64_t)0, h->n, d_out);
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
 int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
 {
 	if (!h || !emit) return RB3GPU_EINVAL;

@@ -64,6 +64,7 @@ SYMBOLS = {
     "rb3gpu_get_tot": (ctypes.c_int64, [ctypes.c_void_p]),
     "rb3gpu_export_runs": (ctypes.c_int, [ctypes.c_void_p, EMIT_F, ctypes.c_void_p]),
     "rb3gpu_export_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_export_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),
@@ -203,6 +204,9 @@ class Rb3Gpu:
         out = np.empty(self.get_tot(), dtype=np.uint8)
         self._chk(self._lib.rb3gpu_export_plain(self._h, out.ctypes.data), "rb3gpu_export_plain")
         return out
+
+    def export_plain_dev(self, d_out):
+        self._chk(self._lib.rb3gpu_export_plain_dev(self._h, d_out), "rb3gpu_export_plain_dev")
 
     def export_runs(self):
         runs = []

@@ -91,3 +91,35 @@ def merge_sharded(engine, d_bwt, length, walkers, step, dist, rank, world, pos, 
     sync()
     engine.mg_finish(commit)
     return rounds
+
+
+def tree_merge(engine, dist, rank, world, device, sync=None):
+    """Combine the per-rank indexes of a partitioned build into rank 0's index.
+
+    Every rank has built the index of ITS contiguous slice of the input (slice r before slice r+1).
+    Round k merges the index of rank r + 2^k into rank r for r = 0 mod 2^(k+1): the right-hand index
+    is exported as a plain BWT on its GPU, sent over RCCL (xGMI) and merged with rb3gpu_merge_plain_dev.
+    merge(A, B) ranks every sentinel of B after those of A (fm-index.c:147, 164), so merging adjacent
+    slices left to right reproduces the BWT of the whole input in input order.
+    Returns the number of symbols this rank holds afterwards (rank 0: everything).
+    """
+    import torch
+    sync = sync or (lambda: None)
+    stride = 1
+    while stride < world:
+        if rank % (2 * stride) == 0 and rank + stride < world:
+            n = torch.zeros(1, dtype=torch.int64, device=device)
+            dist.recv(n, src=rank + stride)
+            buf = torch.empty(int(n.item()) + 16, dtype=torch.uint8, device=device)
+            dist.recv(buf, src=rank + stride)
+            sync()
+            engine.merge_plain_dev(buf.data_ptr() if hasattr(buf, "data_ptr") else buf, int(n.item()), True)
+        elif rank % (2 * stride) == stride:
+            tot = engine.get_tot()
+            buf = torch.empty(tot + 16, dtype=torch.uint8, device=device)
+            engine.export_plain_dev(buf.data_ptr())
+            sync()
+            dist.send(torch.tensor([tot], dtype=torch.int64, device=device), dst=rank - stride)
+            dist.send(buf, dst=rank - stride)
+        stride *= 2
+    return engine.get_tot()

@@ -77,3 +77,23 @@ class FakeEngine:
     def mg_finish(self, commit):
         assert (self.pos != UNSET).all(), "rows left unset"
         assert (np.diff(self.pos) > 0).all(), "pos not increasing"
+
+
+class FakePlainEngine:
+    """index = its plain BWT; merge via the CPU oracle.  For the gloo test of multi.tree_merge."""
+
+    def __init__(self, oracle, bwt):
+        self.orc, self.b = oracle, np.asarray(bwt, dtype=np.uint8).copy()
+
+    def get_tot(self):
+        return int(self.b.size)
+
+    def export_plain_dev(self, ptr):
+        import ctypes
+        ctypes.memmove(ptr, self.b.ctypes.data, self.b.size)
+
+    def merge_plain_dev(self, ptr, n, commit=True):
+        import ctypes
+        b2 = np.empty(n, dtype=np.uint8)
+        ctypes.memmove(b2.ctypes.data, ptr, n)
+        self.b = self.orc.merge(self.b, b2)

@@ -100,3 +100,44 @@ def test_partition_and_plan():
     assert sum(len(p[0]) for p in plans) == 2
     if len(owners) == 2:
         assert plans[owners[0]][2] == owners[1]
+
+
+def _tree_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ropebwt3_amd import multi
+    from tests import util
+    from tests.fake_engine import FakePlainEngine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(9)
+        g0 = util.random_genome(rng, 1500)
+        seqs = [util.mutate(rng, g0, 0.01) for _ in range(2 * world + 1)] + [g0[:40].copy(), g0[:40].copy()]
+        cut = [len(seqs) * r // world for r in range(world + 1)]
+        orc = util.Oracle()
+        eng = FakePlainEngine(orc, orc.bwt(util.make_text(seqs[cut[rank]:cut[rank + 1]])))
+        multi.tree_merge(eng, dist, rank, world, torch.device("cpu"))
+        ok = True
+        if rank == 0:
+            ok = bool(np.array_equal(eng.b, orc.bwt(util.make_text(seqs))))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_tree_merge_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res

@@ -8,7 +8,7 @@ TAG=${1:-r1}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/prof
 cd /tmp
-BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-aux"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o $TAG -- $BENCH > $R/gpurun_out/prof/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof/pmc_fetch -o $TAG -- $BENCH > $R/gpurun_out/prof/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof/pmc_write -o $TAG -- $BENCH > $R/gpurun_out/prof/pmc_write.log 2>&1

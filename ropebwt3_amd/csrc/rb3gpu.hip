@@ -29,11 +29,13 @@ struct rb3gpu_s {
 	hipStream_t st = nullptr;
 	rb3gpu_opt_t opt;
 	rb3gpu_stats_t stt;
-	// the index
+	// the index: grp/slots point into ib[cur]; a merge builds into ib[1-cur] and swaps on commit
 	int64_t n = 0, ngrp = 0, nslots = 0;
 	int64_t acc[7] = {0, 0, 0, 0, 0, 0, 0};
 	rb3_grp_t *grp = nullptr;
 	rb3_slot_t *slots = nullptr;
+	struct { rb3_grp_t *grp; size_t grp_cap; rb3_slot_t *slots; size_t slots_cap; } ib[2] = {{nullptr, 0, nullptr, 0}, {nullptr, 0, nullptr, 0}};
+	int cur = 0;
 	// scratch, grown on demand and kept between calls
 	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
@@ -156,11 +158,40 @@ rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
 
 static void index_drop(rb3gpu_t *h)
 {
-	dev_free(h, h->grp, (size_t)h->ngrp * sizeof(rb3_grp_t));
-	dev_free(h, h->slots, (size_t)h->nslots * sizeof(rb3_slot_t));
 	h->grp = nullptr, h->slots = nullptr, h->n = h->ngrp = h->nslots = 0;
 	memset(h->acc, 0, sizeof(h->acc));
 	h->stt.bytes_index = 0;
+}
+
+static void ib_release(rb3gpu_t *h, int i)
+{
+	dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * sizeof(rb3_grp_t));
+	dev_free(h, h->ib[i].slots, h->ib[i].slots_cap * sizeof(rb3_slot_t));
+	h->ib[i].grp = nullptr, h->ib[i].slots = nullptr, h->ib[i].grp_cap = h->ib[i].slots_cap = 0;
+}
+
+/* make ib[i] hold at least ngrp directory entries and nslots slots (contents are not preserved) */
+static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots)
+{
+	int r;
+	if (h->ib[i].grp_cap < (size_t)ngrp) {
+		dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * sizeof(rb3_grp_t));
+		h->ib[i].grp = nullptr, h->ib[i].grp_cap = 0;
+		const size_t want = (size_t)ngrp + (size_t)(ngrp >> 3) + 16;
+		if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * sizeof(rb3_grp_t))) < 0) return r;
+		h->ib[i].grp_cap = want;
+	}
+	if (h->ib[i].slots_cap < (size_t)nslots) {
+		dev_free(h, h->ib[i].slots, h->ib[i].slots_cap * sizeof(rb3_slot_t));
+		h->ib[i].slots = nullptr, h->ib[i].slots_cap = 0;
+		size_t want = (size_t)nslots + (size_t)(nslots >> 3) + 64;
+		if ((r = dev_malloc(h, (void**)&h->ib[i].slots, want * sizeof(rb3_slot_t))) < 0) {
+			want = (size_t)nslots;
+			if ((r = dev_malloc(h, (void**)&h->ib[i].slots, want * sizeof(rb3_slot_t))) < 0) return r;
+		}
+		h->ib[i].slots_cap = want;
+	}
+	return 0;
 }
 
 void rb3gpu_destroy(rb3gpu_t *h)
@@ -169,6 +200,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	(void)hipSetDevice(h->dev);
 	(void)hipStreamSynchronize(h->st);
 	index_drop(h);
+	ib_release(h, 0), ib_release(h, 1);
 	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -176,92 +208,114 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	delete h;
 }
 
-/* exclusive scan of nrec records of 8 x u32 -> 8 x u64 (7 columns used); totals to host */
-static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t *out, uint64_t total[8])
+/* exclusive scan of nrec records of 8 x u32 -> 8 x u64 (7 columns used).  The 8 totals are left in
+ * device memory at `dtot_keep`; if `total` is not NULL they are also copied to the host (one sync). */
+static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t *out, uint64_t *dtot_keep, uint64_t total[8])
 {
 	const int64_t nchunk = (nrec + RB3_SCAN_CHUNK - 1) / RB3_SCAN_CHUNK;
 	int r;
 	if ((r = buf_ensure(h, h->ctot, (size_t)(nchunk + 1) * 64)) < 0) return r;
-	uint64_t *ctot = (uint64_t*)h->ctot.p, *dtotal = ctot + nchunk * 8;
+	uint64_t *ctot = (uint64_t*)h->ctot.p;
 	hipLaunchKernelGGL(k_scan_chunk_totals, dim3((unsigned)nchunk), dim3(256), 0, h->st, in, nrec, ctot);
-	hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(256), 0, h->st, ctot, nchunk, dtotal);
+	hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(256), 0, h->st, ctot, nchunk, dtot_keep);
 	hipLaunchKernelGGL(k_scan_records, dim3((unsigned)nchunk), dim3(256), 0, h->st, in, nrec, (const uint64_t*)ctot, out);
-	HIPCHK(hipMemcpyAsync(total, dtotal, 64, hipMemcpyDeviceToHost, h->st));
-	HIPCHK(hipStreamSynchronize(h->st));
+	if (total) {
+		HIPCHK(hipMemcpyAsync(total, dtot_keep, 64, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+	}
 	return 0;
 }
 
-/* build a block array for ntot symbols; FROM_PLAIN: symbols are d_b2[0..ntot); otherwise the
- * interleave of the current index with d_b2 at merged positions pos[].  On success the new
- * arrays are returned through the out parameters (not yet installed). */
+/* layout of the 64 x u64 words of h->misc (zeroed per merge up to MISC_KEEP):
+ *   [0] walker queue head  [1] LF steps  [2] rows unset  [3] rows out of order  [4] tentative unsettled
+ *   [16..23] totals of the batch scan (symbol counts of B2, [22] = bad bytes)
+ *   [24..31] totals of the rebuild scan (symbol counts of the merged BWT, [30] = slots) */
+#define MISC_WORDS   64
+#define MISC_LF_TOT  16
+#define MISC_IX_TOT  24
+
+/* build a block array for ntot symbols into ib[1-cur]; FROM_PLAIN: symbols are d_b2[0..ntot);
+ * otherwise the interleave of the current index with d_b2 at merged positions pos[].
+ * nosync: size the slot array by its upper bound (one slot per window) and do not wait for the
+ * scan totals; the caller reads them from misc[MISC_IX_TOT..] after its own sync. */
 extern "C++" {
 template<bool FROM_PLAIN>
-static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64_t *d_pos, int64_t ntot,
-		rb3_grp_t **ogrp, rb3_slot_t **oslots, int64_t *ongrp, int64_t *onslots, int64_t oacc[7])
+static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64_t *d_pos, int64_t ntot, bool nosync,
+		int64_t *ongrp, int64_t *onslots, int64_t oacc[7])
 {
-	const int64_t ngrp = (ntot >> RB3_GRP_BITS) + 1;
+	const int64_t ngrp = (ntot >> RB3_GRP_BITS) + 1, nwin = (ntot >> RB3_WIN_BITS) + 1;
+	const int dst = 1 - h->cur;
 	int r;
 	if (ngrp > 0x7fffffffLL) return RB3GPU_EINVAL;
 	if ((r = buf_ensure(h, h->gstat, (size_t)ngrp * 32)) < 0) return r;
 	if ((r = buf_ensure(h, h->gpre, (size_t)ngrp * 64)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	int64_t *jg = nullptr;
 	if (!FROM_PLAIN) {
 		if ((r = buf_ensure(h, h->jg, (size_t)(ngrp + 1) * 8)) < 0) return r;
 		jg = (int64_t*)h->jg.p;
+	}
+	if (nosync && (r = ib_ensure(h, dst, ngrp, nwin)) < 0) return r; // before any launch: hipMalloc may synchronise
+	if (!FROM_PLAIN) {
 		const int64_t nt = n2 + 1;
+		HIPCHK(hipMemsetAsync(jg, 0, (size_t)(ngrp + 1) * 8, h->st)); // defined even if pos[] turns out invalid
 		hipLaunchKernelGGL(k_group_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, ngrp);
 	}
 	IdxView old = view_of(h);
 	uint32_t *gstat = (uint32_t*)h->gstat.p;
-	uint64_t *gpre = (uint64_t*)h->gpre.p;
+	uint64_t *gpre = (uint64_t*)h->gpre.p, *dtot = (uint64_t*)h->misc.p + MISC_IX_TOT;
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, gstat, ngrp);
 	uint64_t total[8];
-	if ((r = scan_records(h, gstat, ngrp, gpre, total)) < 0) return r;
-	Acc7 acc;
-	acc.a[0] = 0;
-	for (int a = 0; a < 6; ++a) acc.a[a + 1] = acc.a[a] + (int64_t)total[a];
-	if (acc.a[6] != ntot) {
-		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] symbol counts do not add up: %lld vs %lld\n", (long long)acc.a[6], (long long)ntot);
-		return RB3GPU_EINTERNAL;
+	if ((r = scan_records(h, gstat, ngrp, gpre, dtot, nosync ? nullptr : total)) < 0) return r;
+	if (!nosync) {
+		oacc[0] = 0;
+		for (int a = 0; a < 6; ++a) oacc[a + 1] = oacc[a] + (int64_t)total[a];
+		if (oacc[6] != ntot) {
+			if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] symbol counts do not add up: %lld vs %lld\n", (long long)oacc[6], (long long)ntot);
+			return RB3GPU_EINTERNAL;
+		}
+		*onslots = (int64_t)total[6];
+		if ((r = ib_ensure(h, dst, ngrp, *onslots)) < 0) return r;
 	}
-	const int64_t nslots = (int64_t)total[6];
-	rb3_grp_t *grp = nullptr;
-	rb3_slot_t *slots = nullptr;
-	if ((r = dev_malloc(h, (void**)&grp, (size_t)ngrp * sizeof(rb3_grp_t))) < 0) return r;
-	if ((r = dev_malloc(h, (void**)&slots, (size_t)nslots * sizeof(rb3_slot_t))) < 0) { dev_free(h, grp, (size_t)ngrp * sizeof(rb3_grp_t)); return r; }
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-			(const uint32_t*)gstat, (const uint64_t*)gpre, acc, grp, (uint4*)slots, ngrp);
-	*ogrp = grp, *oslots = slots, *ongrp = ngrp, *onslots = nslots;
-	memcpy(oacc, acc.a, sizeof(acc.a));
+			(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp);
+	*ongrp = ngrp;
 	return 0;
 }
 } // extern "C++"
 
-static void index_install(rb3gpu_t *h, rb3_grp_t *grp, rb3_slot_t *slots, int64_t ngrp, int64_t nslots, int64_t ntot, const int64_t acc[7])
+/* make ib[1-cur] (just built) the index */
+static void index_install(rb3gpu_t *h, int64_t ngrp, int64_t nslots, int64_t ntot, const int64_t acc[7])
 {
-	index_drop(h);
-	h->grp = grp, h->slots = slots, h->ngrp = ngrp, h->nslots = nslots, h->n = ntot;
+	h->cur = 1 - h->cur;
+	h->grp = h->ib[h->cur].grp, h->slots = h->ib[h->cur].slots, h->ngrp = ngrp, h->nslots = nslots, h->n = ntot;
 	memcpy(h->acc, acc, sizeof(h->acc));
 	h->stt.bytes_index = ngrp * (int64_t)sizeof(rb3_grp_t) + nslots * (int64_t)sizeof(rb3_slot_t);
+	// do not sit on a large spare buffer: the next merge re-allocates it (it is sized for a bigger index anyway)
+	const int o = 1 - h->cur;
+	if (h->ib[o].slots_cap * sizeof(rb3_slot_t) > ((size_t)4 << 30)) ib_release(h, o);
 }
 
-/* histogram + LF array of B2; acc2 to host */
-static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t acc2[7])
+/* histogram + LF array of B2.  Totals stay on the device (misc[MISC_LF_TOT..]); acc2 != NULL also
+ * brings the C array of B2 to the host (one sync) and checks the symbols (fm-index.c:124-125). */
+static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *acc2)
 {
 	const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
 	int r;
 	if ((r = buf_ensure(h, h->tcnt, (size_t)ntile * 32)) < 0) return r;
 	if ((r = buf_ensure(h, h->tpre, (size_t)ntile * 64)) < 0) return r;
 	if ((r = buf_ensure(h, h->lf2, (size_t)len * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	uint64_t *dtot = (uint64_t*)h->misc.p + MISC_LF_TOT;
 	hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (uint32_t*)h->tcnt.p);
 	uint64_t total[8];
-	if ((r = scan_records(h, (const uint32_t*)h->tcnt.p, ntile, (uint64_t*)h->tpre.p, total)) < 0) return r;
-	if (total[6] != 0) return RB3GPU_ESYMBOL; // fm-index.c:124-125
-	Acc7 a2;
-	a2.a[0] = 0;
-	for (int a = 0; a < 6; ++a) a2.a[a + 1] = a2.a[a] + (int64_t)total[a];
-	memcpy(acc2, a2.a, sizeof(a2.a));
-	hipLaunchKernelGGL(k_lf2, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (const uint64_t*)h->tpre.p, a2, (uint64_t*)h->lf2.p);
+	if ((r = scan_records(h, (const uint32_t*)h->tcnt.p, ntile, (uint64_t*)h->tpre.p, dtot, acc2 ? total : nullptr)) < 0) return r;
+	if (acc2) {
+		if (total[6] != 0) return RB3GPU_ESYMBOL;
+		acc2[0] = 0;
+		for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)total[a];
+	}
+	hipLaunchKernelGGL(k_lf2, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (const uint64_t*)h->tpre.p, (const uint64_t*)dtot, (uint64_t*)h->lf2.p);
 	return 0;
 }
 
@@ -294,9 +348,9 @@ int rb3gpu_mg_begin(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, void *d_pos_
 		if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
 		h->mg_pos = (int64_t*)h->pos.p;
 	}
-	if ((r = buf_ensure(h, h->misc, 256)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	HIPCHK(hipMemsetAsync(h->mg_pos, 0xff, (size_t)len * 8, h->st));
-	HIPCHK(hipMemsetAsync(h->misc.p, 0, 256, h->st));
+	HIPCHK(hipMemsetAsync(h->misc.p, 0, 128, h->st)); // words 0..15; the scan totals behind them stay
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	h->stt.ms_lf += ev_ms(h->ev[0], h->ev[1]);
@@ -425,23 +479,13 @@ static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
 	HIPCHK(hipMemcpyAsync(hm, misc, 40, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	h->stt.n_lf_steps += (int64_t)hm[1];
-#ifdef RB3_PROF
-	{
-		unsigned long long pr[4];
-		(void)hipMemcpy(pr, misc + 9, 32, hipMemcpyDeviceToHost);
-		fprintf(stderr, "[prof] cycles per step (block 0 wave 0): decode-x %.1f, issue+bookkeeping %.1f, wait+rank %.1f, loop-top/fetch %.1f\n",
-				(double)pr[0] / len, (double)pr[1] / len, (double)pr[2] / len, (double)pr[3] / len);
-	}
-#endif
 	if (hm[2] != 0 || hm[3] != 0 || hm[4] != 0) {
 		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu tentative records unsettled\n", hm[2], hm[3], hm[4]);
 		return RB3GPU_EINTERNAL;
 	}
-	rb3_grp_t *grp = nullptr;
-	rb3_slot_t *slots = nullptr;
 	int64_t ngrp = 0, nslots = 0, acc[7];
 	if (!rank_only) {
-		if ((r = build_index<false>(h, len, h->mg_b2, (const int64_t*)h->mg_pos, ntot, &grp, &slots, &ngrp, &nslots, acc)) < 0) return r;
+		if ((r = build_index<false>(h, len, h->mg_b2, (const int64_t*)h->mg_pos, ntot, false, &ngrp, &nslots, acc)) < 0) return r;
 	}
 	HIPCHK(hipEventRecord(h->ev[3], h->st));
 	if (host_pos) HIPCHK(hipMemcpyAsync(host_pos, h->mg_pos, (size_t)len * 8, hipMemcpyDeviceToHost, h->st));
@@ -449,18 +493,8 @@ static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
 	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
 	h->stt.n_symbols_merged += len;
 	if (!rank_only) {
-		int bad = 0;
-		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + h->mg_acc2[a]) bad = 1;
-		if (bad) {
-			dev_free(h, grp, (size_t)ngrp * sizeof(rb3_grp_t));
-			dev_free(h, slots, (size_t)nslots * sizeof(rb3_slot_t));
-			return RB3GPU_EINTERNAL;
-		}
-		if (commit) index_install(h, grp, slots, ngrp, nslots, ntot, acc);
-		else {
-			dev_free(h, grp, (size_t)ngrp * sizeof(rb3_grp_t));
-			dev_free(h, slots, (size_t)nslots * sizeof(rb3_slot_t));
-		}
+		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + h->mg_acc2[a]) return RB3GPU_EINTERNAL;
+		if (commit) index_install(h, ngrp, nslots, ntot, acc);
 	}
 	if (h->opt.verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f] merged %lld symbols (%lld strings): %llu LF steps, rebuild %.3f ms\n", __func__,
@@ -475,24 +509,135 @@ int rb3gpu_mg_finish(rb3gpu_t *h, int commit)
 	return mg_finish(h, commit, nullptr, 0);
 }
 
-static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
-		int64_t n_walkers, const rb3gpu_walker_t *walkers)
+/* the staged implementation (several host round trips); also the fallback of merge_fast */
+static int merge_staged(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
+		int64_t n_walkers, const rb3gpu_walker_t *walkers, int tent)
 {
 	int r;
 	if ((r = rb3gpu_mg_begin(h, len, d_b2, nullptr, host_acc2)) < 0) return r;
-	if ((r = mg_walk_impl(h, n_walkers, walkers, -1, nullptr, 1)) < 0) return r;
-	{ // tentative records are optimistic: if any is left unsettled, redo the rank phase without them
+	if ((r = mg_walk_impl(h, n_walkers, walkers, -1, nullptr, tent)) < 0) return r;
+	if (tent) { // tentative records are optimistic: if any is left unsettled, redo the rank phase without them
 		unsigned long long unsettled = 0;
 		HIPCHK(hipMemcpy(&unsettled, (unsigned long long*)h->misc.p + 4, 8, hipMemcpyDeviceToHost));
 		if (unsettled != 0) {
 			h->stt.n_fallbacks += 1;
-			if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled; redoing the rank phase without tentative records\n", unsettled);
 			HIPCHK(hipMemsetAsync(h->mg_pos, 0xff, (size_t)len * 8, h->st));
 			HIPCHK(hipMemsetAsync((unsigned long long*)h->misc.p + 4, 0, 8, h->st));
 			if ((r = mg_walk_impl(h, n_walkers, walkers, -1, nullptr, 0)) < 0) return r;
 		}
 	}
 	return mg_finish(h, commit, host_pos, rank_only);
+}
+
+/* One merge with a single host synchronisation at the end: everything the host would have to read
+ * in between (symbol totals, slot count, validation counters) stays in device memory, the new index
+ * is built into a pooled buffer sized by its upper bound (one slot per window), and all checks are
+ * made after the final copy-back.  Needs an explicit walker list (the automatic SA-order split needs
+ * the number of strings on the host to size its launch) and an index small enough for the upper
+ * bound to be affordable; anything else goes through merge_staged. */
+static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
+		int64_t n_walkers, const rb3gpu_walker_t *walkers)
+{
+	const int64_t ntot = h->n + len, nwin = (ntot >> RB3_WIN_BITS) + 1;
+	int tent = 1;
+	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
+	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
+	if (!walkers || n_walkers > RB3_TENT_IDS || ntot >= (1LL << 40) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED"))
+		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
+	int r;
+	for (int64_t i = 0; i < n_walkers; ++i)
+		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) return RB3GPU_EINVAL;
+	// every allocation first: hipMalloc may synchronise
+	const int64_t ngrp_new = (ntot >> RB3_GRP_BITS) + 1;
+	if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
+	if ((r = buf_ensure(h, h->dl, (size_t)n_walkers * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, nwin)) < 0) return r;
+	rb3gpu_walker_t *tmp = (rb3gpu_walker_t*)malloc((size_t)n_walkers * sizeof(rb3gpu_walker_t));
+	if (!tmp) return RB3GPU_ENOMEM;
+	memcpy(tmp, walkers, (size_t)n_walkers * sizeof(rb3gpu_walker_t));
+	for (int64_t i = 0; i < n_walkers; ++i)
+		if (tmp[i].ka0 == RB3GPU_KA_SENTINEL) tmp[i].ka0 = h->acc[1];
+	unsigned long long *misc = (unsigned long long*)h->misc.p;
+	Walker *dwl = (Walker*)h->wl.p;
+	int32_t *dres = (int32_t*)h->dl.p, *dlink = dres + n_walkers;
+	h->mg_active = 0;
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	if ((r = lf_build(h, len, d_b2, nullptr)) < 0) { free(tmp); return r; }
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	HIPCHK(hipMemsetAsync(h->pos.p, 0xff, (size_t)len * 8, h->st));
+	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
+	HIPCHK(hipMemsetAsync(dres, 0, (size_t)n_walkers * 8, h->st));
+	{
+		hipError_t e = hipMemcpyAsync(dwl, tmp, (size_t)n_walkers * 32, hipMemcpyHostToDevice, h->st); // pageable source: returns once staged
+		free(tmp);
+		HIPCHK(e);
+	}
+	int64_t *dpos = (int64_t*)h->pos.p;
+	{
+		const IdxView iv = view_of(h);
+		int64_t nblk = (n_walkers + 31) / 32;
+		nblk = nblk > 2048 ? 2048 : nblk < 1 ? 1 : nblk;
+		const dim3 grid((unsigned)nblk), blk(256);
+		const uint64_t *lf2 = (const uint64_t*)h->lf2.p;
+		HIPCHK(hipEventRecord(h->ev[6], h->st));
+#define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, lf2, dpos, len, (int64_t)0, 0, \
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, 8, dres, dlink)
+		if (iv.dense && tent) RB3_LAUNCH_FAST(true, true);
+		else if (iv.dense) RB3_LAUNCH_FAST(true, false);
+		else if (tent) RB3_LAUNCH_FAST(false, true);
+		else RB3_LAUNCH_FAST(false, false);
+#undef RB3_LAUNCH_FAST
+		HIPCHK(hipEventRecord(h->ev[7], h->st));
+		if (tent) {
+			hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_walkers + 255) / 256)), dim3(256), 0, h->st, dres, (const int32_t*)dlink, n_walkers, misc + 2);
+			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, (const int32_t*)dres, misc + 2);
+		}
+	}
+	hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, len, ntot, misc + 2);
+	HIPCHK(hipEventRecord(h->ev[2], h->st));
+	int64_t ngrp = 0, nslots = 0, acc[7];
+	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc)) < 0) return r;
+	HIPCHK(hipEventRecord(h->ev[3], h->st));
+	unsigned long long hm[32];
+	HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));
+	if (host_pos) HIPCHK(hipMemcpyAsync(host_pos, dpos, (size_t)len * 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st)); // the only synchronisation of the merge
+	h->stt.ms_lf += ev_ms(h->ev[0], h->ev[1]);
+	h->stt.ms_chain += ev_ms(h->ev[6], h->ev[7]);
+	h->stt.ms_rank += ev_ms(h->ev[1], h->ev[2]);
+	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
+	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
+	h->stt.n_lf_steps += (int64_t)hm[1];
+	if (hm[MISC_LF_TOT + 6] != 0) return RB3GPU_ESYMBOL; // fm-index.c:124-125
+	int64_t acc2[7];
+	acc2[0] = 0;
+	for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)hm[MISC_LF_TOT + a];
+	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
+	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
+	if (tent && hm[4] != 0) { // some tentative record was left unsettled: nothing was installed, redo without them
+		h->stt.n_fallbacks += 1;
+		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled; redoing the merge without tentative records\n", hm[4]);
+		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, 0);
+	}
+	if (hm[2] != 0 || hm[3] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order\n", hm[2], hm[3]);
+		return RB3GPU_EINTERNAL;
+	}
+	h->stt.n_symbols_merged += len;
+	if (!rank_only) {
+		acc[0] = 0;
+		for (int a = 0; a < 6; ++a) acc[a + 1] = acc[a] + (int64_t)hm[MISC_IX_TOT + a];
+		nslots = (int64_t)hm[MISC_IX_TOT + 6];
+		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + acc2[a]) return RB3GPU_EINTERNAL;
+		if (nslots > nwin) return RB3GPU_EINTERNAL;
+		if (commit) index_install(h, ngrp, nslots, ntot, acc);
+	}
+	if (h->opt.verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f] merged %lld symbols (%lld strings): lf %.3f ms, rank %.3f ms (%llu LF steps), rebuild %.3f ms\n", __func__,
+				now_s() - h->t0, (long long)len, (long long)acc2[1], ev_ms(h->ev[0], h->ev[1]), ev_ms(h->ev[1], h->ev[2]), hm[1], ev_ms(h->ev[2], h->ev[3]));
+	return 0;
 }
 
 static int upload_b2(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
@@ -512,24 +657,23 @@ int rb3gpu_from_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt)
 	if (!h || len <= 0 || !d_bwt) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	int r;
-	rb3_grp_t *grp;
-	rb3_slot_t *slots;
-	int64_t ngrp, nslots, acc[7];
+	int64_t ngrp = 0, nslots = 0, acc[7];
 	// validate symbols with the tile histogram (fm-index.c:122-125)
 	const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
 	if ((r = buf_ensure(h, h->tcnt, (size_t)ntile * 32)) < 0) return r;
 	if ((r = buf_ensure(h, h->tpre, (size_t)ntile * 64)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[0], h->st));
 	hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)ntile), dim3(256), 0, h->st, d_bwt, len, (uint32_t*)h->tcnt.p);
 	uint64_t total[8];
-	if ((r = scan_records(h, (const uint32_t*)h->tcnt.p, ntile, (uint64_t*)h->tpre.p, total)) < 0) return r;
+	if ((r = scan_records(h, (const uint32_t*)h->tcnt.p, ntile, (uint64_t*)h->tpre.p, (uint64_t*)h->misc.p + MISC_LF_TOT, total)) < 0) return r;
 	if (total[6] != 0) return RB3GPU_ESYMBOL;
 	index_drop(h);
-	if ((r = build_index<true>(h, len, d_bwt, nullptr, len, &grp, &slots, &ngrp, &nslots, acc)) < 0) return r;
+	if ((r = build_index<true>(h, len, d_bwt, nullptr, len, false, &ngrp, &nslots, acc)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	h->stt.ms_build += ev_ms(h->ev[0], h->ev[1]);
-	index_install(h, grp, slots, ngrp, nslots, len, acc);
+	index_install(h, ngrp, nslots, len, acc);
 	if (h->opt.verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f] encoded %lld symbols into %lld slots (%.3f ms)\n", __func__, now_s() - h->t0, (long long)len, (long long)nslots, ev_ms(h->ev[0], h->ev[1]));
 	return 0;

@@ -314,13 +314,17 @@ __global__ void __launch_bounds__(256) k_scan_records(const uint32_t *in, int64_
 }
 
 /* lf2[i] = (C2[a] + #{i' < i : B2[i'] = a}) << 3 | a, a = B2[i]   (fm-index.c:211-216) */
-__global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, const uint64_t *tpre, Acc7 acc2, uint64_t *lf2)
+__global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, const uint64_t *tpre, const uint64_t *tot, uint64_t *lf2)
 {
 	__shared__ uint64_t shbase[6];
 	__shared__ uint64_t shw[4][2];
 	const int64_t tile = blockIdx.x;
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-	if (t < 6) shbase[t] = (uint64_t)acc2.a[t] + tpre[tile * 8 + t];
+	if (t < 6) { // C2[t] = number of symbols smaller than t in the whole batch (totals of the scan)
+		uint64_t c2 = 0;
+		for (int a = 0; a < t; ++a) c2 += tot[a];
+		shbase[t] = c2 + tpre[tile * 8 + t];
+	}
 	const int64_t base = tile * RB3_TILE + (int64_t)t * 16;
 	uint8_t sym[16];
 	int nv = 0;
@@ -733,7 +737,7 @@ __device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *po
 		const int64_t jj = j + 64 * u + lane;
 		const int64_t r = jj < n2 ? pos[jj] : INT64_MAX;
 		const bool in = r < p0 + RB3_WIN;
-		if (in) symbuf[r - p0] = b2[jj];
+		if (in && r >= p0) symbuf[r - p0] = b2[jj]; // r >= p0 always holds for a valid pos[]; never write outside the window
 		const uint64_t m = __ballot(in);
 		nb2 += __popcll(m);
 		if (m != ~0ull) break;
@@ -750,7 +754,8 @@ __device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *po
 		before += __popcll(m);
 		if (!isb2) {
 			const int64_t p = p0 + 64 * u + lane;
-			s = p < ntot ? idx_sym(old, a1 + 64 * u + lane - mine) : 7u;
+			const int64_t i1 = a1 + 64 * u + lane - mine;
+			s = (p < ntot && i1 >= 0 && i1 < old.n) ? idx_sym(old, i1) : 7u; // the range check only matters if pos[] is invalid
 		}
 		sym[u] = s;
 	}
@@ -834,7 +839,7 @@ __global__ void __launch_bounds__(64) k_pass1(IdxView old, const int64_t *pos, c
  * gpre[g*8 + 0..5] = symbol counts before the group, [6] = slots before the group. */
 template<bool FROM_PLAIN>
 __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
-		const int64_t *jg, const uint32_t *gstat, const uint64_t *gpre, Acc7 acc, rb3_grp_t *grp, uint4 *slot16, int64_t ngrp)
+		const int64_t *jg, const uint32_t *gstat, const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t ngrp)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t symbuf[RB3_WIN];
 	__shared__ uint64_t ball[12];
@@ -848,7 +853,8 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 	const uint64_t slot0 = gpre[g * 8 + 6];
 	if (lane == 0) {
 		rb3_grp_t e;
-		for (int a = 0; a < 6; ++a) e.cnt[a] = (uint64_t)acc.a[a] + gpre[g * 8 + a];
+		uint64_t c = 0; // C[a] of the merged BWT from the symbol totals of the scan
+		for (int a = 0; a < 6; ++a) { e.cnt[a] = c + gpre[g * 8 + a]; c += tot[a]; }
 		e.slot0 = (uint32_t)slot0, e.mask = mask, e.spare = 0;
 		grp[g] = e;
 	}

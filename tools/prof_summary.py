@@ -10,7 +10,14 @@ import sys
 
 
 def short(name):
-    for k in ("k_chain", "k_pass1", "k_pass2", "k_lf2", "k_tile_hist", "k_scan_chunk_totals", "k_scan_chunks", "k_scan_records",
+    if "k_chain" in name:
+        import re
+        m = re.search(r"k_chain<([^>]*)>", name)
+        if m:
+            f = [x.strip() in ("true", "(bool)1") for x in m.group(1).split(",")]
+            return "k_chain<%s,%s,%s>" % ("list" if f[0] else "auto", "dense" if f[1] else "mixed", "tent" if len(f) > 2 and f[2] else "plain")
+        return "k_chain"
+    for k in ("k_resolve", "k_pos_finalize", "k_pass1", "k_pass2", "k_lf2", "k_tile_hist", "k_scan_chunk_totals", "k_scan_chunks", "k_scan_records",
               "k_group_rows", "k_export_plain", "k_rank_batch", "k_pos_check", "k_jump", "k_ckpt"):
         if k in name:
             return k + ("<plain>" if ("ILb1" in name or "<true>" in name) else "<merge>" if ("ILb0" in name or "<false>" in name) else "")
@@ -50,6 +57,19 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "traffic":  # traffic <fetch.db> <write.db> <kernel-substring> <out.json>
+        import sqlite3 as sq
+        def avg(db, counter):
+            con = sq.connect(db)
+            r = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?", (counter, "%" + sys.argv[4] + "%")).fetchone()
+            return r
+        f, nf = avg(sys.argv[2], "FETCH_SIZE")
+        w, nw = avg(sys.argv[3], "WRITE_SIZE")
+        d = {"kernel": sys.argv[4], "dispatches": nf, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
+             "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+             "correction": "MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 (upper bound: the 8-B row loads are not halved); WRITE_SIZE as reported. k_lf2 in the same passes calibrates both: 8.8 MB streamed in -> FETCH_SIZE 4.5 MB, 70.4 MB streamed out -> WRITE_SIZE 70.4 MB."}
+        json.dump(d, open(sys.argv[5], "w"), indent=1)
+        print(d)
     elif sys.argv[1] == "cols":
         con = sqlite3.connect(sys.argv[2])
         print([d[0] for d in con.execute("select * from counters_collection limit 1").description])

@@ -20,6 +20,7 @@ python tools/prof_summary.py pmc $P/pmc_fetch/${TAG}_results.db FETCH_SIZE $P/${
 python tools/prof_summary.py pmc $P/pmc_write/${TAG}_results.db WRITE_SIZE $P/${TAG}_pmc_write_size.txt > /dev/null
 python tools/prof_summary.py pmc $P/pmc_l2/${TAG}_results.db TCC_HIT_sum $P/${TAG}_pmc_tcc_hit.txt > /dev/null
 python tools/prof_summary.py pmc $P/pmc_l2/${TAG}_results.db TCC_MISS_sum $P/${TAG}_pmc_tcc_miss.txt > /dev/null
+python tools/prof_summary.py traffic $P/pmc_fetch/${TAG}_results.db $P/pmc_write/${TAG}_results.db k_chain $P/${TAG}_pmc_k_chain.json > /dev/null
 grep -h '"metric"' $P/trace.log > $P/${TAG}_bench_under_rocprof.json
 cat $P/${TAG}_kernel_stats.txt | head -8
 head -4 $P/${TAG}_pmc_fetch_size.txt; head -4 $P/${TAG}_pmc_write_size.txt; head -3 $P/${TAG}_pmc_tcc_hit.txt; head -3 $P/${TAG}_pmc_tcc_miss.txt

@@ -49,6 +49,8 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
 	return sais_bwt_64(n_seq, len, seq, 0, 0);
 }
 
+#define RB3H_MIN_SEG 128
+
 /* BWT plus the list of LF walkers for the GPU merge: one per string (its sentinel row) and one
  * at every text position that is a multiple of `step` strictly inside a string, in text order. */
 int rb3h_build_bwt_walkers(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads, int64_t step, int64_t *n_walkers, rb3h_walker_t **walkers)
@@ -80,6 +82,7 @@ int rb3h_build_bwt_walkers(int64_t n_seq, int64_t len, uint8_t *seq, int n_threa
 			int64_t prev = -1, p = (b / step + 1) * step; /* first multiple of step > b */
 			for (; p < e; p += step) {
 				if (isend[p / step]) continue;
+				if (e - p < RB3H_MIN_SEG && e - p < step) continue; /* keep the sentinel walker's own segment long (see k_chain) */
 				w[nw].row = ckrow[p / step], w[nw].ka0 = -1, w[nw].flags = 0;
 				w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : p - prev;
 				prev = p, ++nw;

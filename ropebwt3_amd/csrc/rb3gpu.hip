@@ -577,13 +577,19 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int64_t *dpos = (int64_t*)h->pos.p;
 	{
 		const IdxView iv = view_of(h);
-		int64_t nblk = (n_walkers + 31) / 32;
-		nblk = nblk > 2048 ? 2048 : nblk < 1 ? 1 : nblk;
+		int octs = 8;
+		if (getenv("RB3GPU_OCTS")) octs = atoi(getenv("RB3GPU_OCTS"));
+		int64_t nblk = (n_walkers + 4 * octs - 1) / (4 * octs);
+		if (getenv("RB3GPU_BLKMUL")) nblk *= atoi(getenv("RB3GPU_BLKMUL"));
+		nblk = nblk > 4096 ? 4096 : nblk < 1 ? 1 : nblk;
+#ifdef RB3_PROF
+		fprintf(stderr, "[prof] launching %lld blocks x 256 threads, %d octets per wave, %lld walkers\n", (long long)nblk, octs, (long long)n_walkers);
+#endif
 		const dim3 grid((unsigned)nblk), blk(256);
 		const uint64_t *lf2 = (const uint64_t*)h->lf2.p;
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, lf2, dpos, len, (int64_t)0, 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, 8, dres, dlink)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, dres, dlink)
 		if (iv.dense && tent) RB3_LAUNCH_FAST(true, true);
 		else if (iv.dense) RB3_LAUNCH_FAST(true, false);
 		else if (tent) RB3_LAUNCH_FAST(false, true);
@@ -610,6 +616,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	h->stt.n_lf_steps += (int64_t)hm[1];
+#ifdef RB3_PROF
+	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, max iterations %llu -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], hm[12], (double)hm[9] / hm[10]);
+#endif
 	if (hm[MISC_LF_TOT + 6] != 0) return RB3GPU_ESYMBOL; // fm-index.c:124-125
 	int64_t acc2[7];
 	acc2[0] = 0;

@@ -494,17 +494,23 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
  *
  * Concurrency.  Records become visible late (lane-parked, written through), so a follower only a
  * few rows behind a tentative walker would read "unset", record its own value and never notice
- * the tags.  Three measures: (1) in TENT mode every record is an unsigned 64-bit atomic MIN, and
- * the encoding orders final < tentative < unset, so the better-informed value always survives
- * whatever the arrival order; (2) a walker records tentatively only once it is RB3_TENT_MIN_AGE
- * steps old, so whoever follows it into its segment is that many rows behind; (3) the host counts
+ * the tags.  Three measures: (1) a walker records tentatively only once it is RB3_TENT_MIN_AGE
+ * steps old, so whoever follows it into its segment is that many rows behind -- provided the
+ * follower's own segment was at least that long, which the host guarantees for the walker lists it
+ * generates (LIST) but not for the automatic split (segments are geometric there); (2) without that
+ * guarantee every record is an unsigned 64-bit atomic MIN, and the encoding orders
+ * final < tentative < unset, so the better-informed value survives whatever the arrival order
+ * (atomics sustain ~25 G/s on this chip against ~70 G/s for plain stores, hence only there);
+ * (3) the host counts
  * unsettled tentative records after the launch and, if there are any, redoes the rank phase without
  * tentative records (rb3gpu.hip).  Correctness therefore never depends on timing.
  */
 #define RB3_TENT      (1LL << 62)
 #define RB3_TENT_MASK ((1LL << 40) - 1)
 #define RB3_TENT_IDS  (1 << 22)
+#ifndef RB3_TENT_MIN_AGE
 #define RB3_TENT_MIN_AGE 64u
+#endif
 
 template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t v)
 {
@@ -533,6 +539,9 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 	// wave flushes them with ONE store instruction every 8 iterations.
 	int64_t bkb = -1, bval = 0;
 	uint32_t it = 0, age = 0;
+#ifdef RB3_PROF
+	const uint64_t tstart = __builtin_readcyclecounter();
+#endif
 	for (;;) {
 		// ---- refill: every octet without a walker pulls the next one from the queue (rare) ----
 		if (!active) {
@@ -544,7 +553,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			w0 = oct_bcast0(w0, j), w1 = oct_bcast0(w1, j);
 			const int64_t wid = (int64_t)((uint64_t)w1 << 32 | w0);
 			if (wid >= nwalk) {
-				if (bkb >= 0) rec_pos<TENT>(&pos[bkb], bval);
+				if (bkb >= 0) rec_pos<TENT && !LIST>(&pos[bkb], bval);
 				break;
 			}
 			if (LIST) {
@@ -575,7 +584,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 		// The body is branch-free (selects) except for the second bound of wide walkers and the rare
 		// settle events: a lone wave runs at instruction-issue speed, so instruction count is the cost.
 		do {
-			if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<TENT>(&pos[bkb], bval); bkb = -1; }
+			if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&pos[bkb], bval); bkb = -1; }
 			const int c = (int)(x & 7u);
 			const int64_t kbn = (int64_t)(x >> 3);
 			const bool wide = TENT ? gap == 2 : gap != 0;
@@ -587,7 +596,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			bool end_next;
 			if (LIST) end_next = remaining == 1;
 			else end_next = M && kbn >= m2 && (kbn & (M - 1)) == 0;
-			const int64_t seen_n = ld_pos((check || end_next) ? &pos[kbn] : pos);
+			// recorded-row check of the next row: only walkers beyond their own segment need it (a dummy
+			// load from one fixed word here would make every wave of the chip hit the same L2 channel)
+			int64_t seen_n = RB3_UNSET;
+			if (check || end_next) seen_n = ld_pos(&pos[kbn]);
 			octc_issue_slot<DENSE>(b1, j, rl);
 			if (wide) octc_issue_slot<DENSE>(b1, j, rh);
 			// this row: record it unless somebody already has
@@ -627,6 +639,12 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 		} while (__all(active));
 	}
 	if (j == 0) atomicAdd(nsteps, (unsigned long long)steps);
+#ifdef RB3_PROF
+	if (lane == 0) { // wave statistics: [8] max cycles, [9] sum cycles, [10] sum iterations, [11] waves, [12] max iterations
+		const unsigned long long cyc = __builtin_readcyclecounter() - tstart;
+		atomicMax(nsteps + 7, cyc); atomicAdd(nsteps + 8, cyc); atomicAdd(nsteps + 9, (unsigned long long)it); atomicAdd(nsteps + 10, 1ull); atomicMax(nsteps + 11, (unsigned long long)it);
+	}
+#endif
 }
 
 /* settle the tentative bits: follow dlink until a stretch with a known bit; dres[i] becomes 1 + bit */

@@ -117,6 +117,9 @@ int rb3gpu_mg_finish(rb3gpu_t *h, int commit);
  * of B2.  The index is not modified.  `pos` is host memory of `len` int64. */
 int rb3gpu_mg_rank_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1]);
 
+/* the same through the walker-list entry point (tests: pos[] of the single-synchronisation path) */
+int rb3gpu_mg_rank_plain_walkers(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1]);
+
 /* rb3_fmi_rank1a(f, k, ok), fm-index.h:109-112 -> mr_rank2a, mrope.c:71-121: for each of the
  * n query offsets k[i] in [0, total], ok[6*i+c] = #{j < k[i] : B[j] = c}.  Host arrays. */
 int rb3gpu_rank1a_batch(rb3gpu_t *h, int64_t n, const int64_t *k, int64_t *ok);

@@ -46,6 +46,7 @@ struct rb3gpu_s {
 	hipEvent_t ev[8];
 	int64_t bytes_owned = 0;
 	double t0 = 0;
+	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
 };
 
 static double now_s(void)
@@ -204,6 +205,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
+	for (int i = 0; i < 2; ++i) if (h->stage[i]) (void)hipHostFree(h->stage[i]);
 	(void)hipStreamDestroy(h->st);
 	delete h;
 }
@@ -649,15 +651,38 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	return 0;
 }
 
+/* host -> HBM copy of a partial BWT through two pinned staging buffers: the CPU copies chunk i+1
+ * into pinned memory while the DMA engine moves chunk i (a pageable hipMemcpy is staged by the
+ * runtime anyway, single-buffered and several times slower) */
+#define RB3_STAGE_BYTES ((size_t)32 << 20)
 static int upload_b2(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
 {
 	int r;
 	if ((r = buf_ensure(h, h->b2, (size_t)len + 16)) < 0) return r;
-	HIPCHK(hipEventRecord(h->ev[4], h->st));
-	HIPCHK(hipMemcpyAsync(h->b2.p, bwt, (size_t)len, hipMemcpyHostToDevice, h->st));
-	HIPCHK(hipEventRecord(h->ev[5], h->st));
-	HIPCHK(hipStreamSynchronize(h->st));
-	h->stt.ms_h2d += ev_ms(h->ev[4], h->ev[5]);
+	if (h->stage[0] == nullptr) {
+		for (int i = 0; i < 2; ++i)
+			if (hipHostMalloc((void**)&h->stage[i], RB3_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { h->stage[i] = nullptr; break; }
+	}
+	const double t0 = now_s();
+	if (h->stage[0] && h->stage[1] && (size_t)len > (size_t)(1 << 20)) {
+		int64_t off = 0;
+		int i = 0;
+		hipEvent_t done[2] = { h->ev[4], h->ev[5] };
+		bool used[2] = { false, false };
+		while (off < len) {
+			const size_t n = (size_t)(len - off) < RB3_STAGE_BYTES ? (size_t)(len - off) : RB3_STAGE_BYTES;
+			if (used[i]) HIPCHK(hipEventSynchronize(done[i])); // the DMA that last read this staging buffer
+			memcpy(h->stage[i], bwt + off, n);
+			HIPCHK(hipMemcpyAsync((uint8_t*)h->b2.p + off, h->stage[i], n, hipMemcpyHostToDevice, h->st));
+			HIPCHK(hipEventRecord(done[i], h->st));
+			used[i] = true, off += (int64_t)n, i ^= 1;
+		}
+		HIPCHK(hipStreamSynchronize(h->st));
+	} else {
+		HIPCHK(hipMemcpyAsync(h->b2.p, bwt, (size_t)len, hipMemcpyHostToDevice, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+	}
+	h->stt.ms_h2d += (now_s() - t0) * 1e3;
 	return 0;
 }
 
@@ -739,6 +764,16 @@ int rb3gpu_mg_rank_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t *
 	int r;
 	if ((r = upload_b2(h, len, bwt)) < 0) return r;
 	return merge_core(h, len, (const uint8_t*)h->b2.p, 0, pos, acc2, 1, 0, nullptr);
+}
+
+int rb3gpu_mg_rank_plain_walkers(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1])
+{
+	if (!h || len <= 0 || !bwt || !pos || n_walkers <= 0 || !walkers) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->n <= 0) return RB3GPU_ESTATE;
+	int r;
+	if ((r = upload_b2(h, len, bwt)) < 0) return r;
+	return merge_core(h, len, (const uint8_t*)h->b2.p, 0, pos, acc2, 1, n_walkers, walkers);
 }
 
 int rb3gpu_rank1a_batch(rb3gpu_t *h, int64_t n, const int64_t *k, int64_t *ok)

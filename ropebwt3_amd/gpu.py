@@ -58,6 +58,7 @@ SYMBOLS = {
     "rb3gpu_mg_walk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_mg_pos_ptr": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
     "rb3gpu_mg_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rb3gpu_mg_rank_plain_walkers": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_mg_rank_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_rank1a_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_get_acc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -184,6 +185,13 @@ class Rb3Gpu:
         pos = np.empty(bwt.size, dtype=np.int64)
         acc2 = np.zeros(7, dtype=np.int64)
         self._chk(self._lib.rb3gpu_mg_rank_plain(self._h, bwt.size, bwt.ctypes.data, pos.ctypes.data, acc2.ctypes.data), "rb3gpu_mg_rank_plain")
+        return pos, acc2
+
+    def mg_rank_plain_walkers(self, bwt, walkers):
+        bwt, w = _u8(bwt), self._walkers(walkers)
+        pos = np.empty(bwt.size, dtype=np.int64)
+        acc2 = np.zeros(7, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_mg_rank_plain_walkers(self._h, bwt.size, bwt.ctypes.data, w.shape[0], w.ctypes.data, pos.ctypes.data, acc2.ctypes.data), "rb3gpu_mg_rank_plain_walkers")
         return pos, acc2
 
     def rank1a(self, k):

@@ -182,3 +182,61 @@ def test_staged_merge_with_stop_and_fixup(engine, oracle):
         engine.mg_finish(commit=True)
         assert np.array_equal(engine.export_plain(), oracle.merge(b1, b2))
         engine.dev_free(d)
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_stress_walker_modes_vs_oracle(oracle, seed):
+    """randomised inputs through every rank-phase variant (automatic split with atomic-min tentative
+    records, host walker list with plain tentative records, tentative records disabled, fallback
+    conditions such as tiny segments): pos[] must equal the oracle's rb[] >> 6 bit for bit"""
+    import os
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(60000, 200000))
+    g0 = util.random_genome(rng, n)
+    # index: one or several similar genomes (several => the unique-match shortcut does not apply)
+    idx = [g0] + [util.mutate(rng, g0, 0.002) for _ in range(int(rng.integers(0, 3)))]
+    div = float(rng.choice([0.0003, 0.001, 0.005, 0.02]))
+    new = [util.mutate(rng, g0, div)]
+    if seed % 2:
+        new += [g0[1000:1000 + int(rng.integers(500, 40000))].copy()]          # exact duplicate of indexed text
+        new += [np.concatenate([np.full(3000, 1, dtype=np.uint8), g0[:5000]])]  # long homopolymer
+        new += util.reads_from(rng, g0, 50, 120, err=0.02)
+    b1 = host.build_bwt(util.make_text(idx))
+    t2 = util.make_text(new)
+    rb, _ = oracle.mg_rank(b1, host.build_bwt(t2), 8)
+    want = rb >> 6
+    for split, env in ((0, {}), (6, {}), (9, {"RB3GPU_TENT": "0"}), (-1, {})):
+        for k in ("RB3GPU_TENT",):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        h = Rb3Gpu(split_log2=split, verbose=1)
+        try:
+            h.from_plain(b1)
+            pos, _ = h.mg_rank_plain(host.build_bwt(t2))
+            assert np.array_equal(pos, want), ("auto", split, env)
+            for step in (32, 100, 512):
+                b2, w = host.build_bwt_walkers(t2, step)
+                d = h.dev_upload(b2)
+                h.mg_begin(d, b2.size)
+                h.mg_walk(w)          # staged API: no tentative records
+                p, ln = h.mg_pos_ptr()
+                got = np.empty(ln, dtype=np.int64)
+                h._chk(h._lib.rb3gpu_dev_download(h._h, got.ctypes.data, p, ln * 8), "download")
+                h.mg_finish(False)
+                assert np.array_equal(got, want), ("staged", step, env)
+                h.dev_free(d)
+                got, _ = h.mg_rank_plain_walkers(b2, w)                   # single-sync path with tentative records
+                assert np.array_equal(got, want), ("fast", step, env)
+            st = h.stats()
+            assert st["n_fallbacks"] >= 0
+        finally:
+            os.environ.pop("RB3GPU_TENT", None)
+            h.close()
+    # and the committed result of the fast path
+    h = Rb3Gpu(verbose=1)
+    h.from_plain(b1)
+    b2, w = host.build_bwt_walkers(t2, 256)
+    h.merge_plain_walkers(b2, w)
+    assert np.array_equal(h.export_plain(), oracle.merge(b1, b2))
+    h.close()

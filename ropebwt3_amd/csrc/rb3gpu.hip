@@ -37,7 +37,7 @@ struct rb3gpu_s {
 	struct { rb3_grp_t *grp; size_t grp_cap; rb3_slot_t *slots; size_t slots_cap; } ib[2] = {{nullptr, 0, nullptr, 0}, {nullptr, 0, nullptr, 0}};
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl;
+	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -202,7 +202,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	(void)hipStreamSynchronize(h->st);
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl };
+	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	for (int i = 0; i < 2; ++i) if (h->stage[i]) (void)hipHostFree(h->stage[i]);
@@ -257,16 +257,36 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		if ((r = buf_ensure(h, h->jg, (size_t)(ngrp + 1) * 8)) < 0) return r;
 		jg = (int64_t*)h->jg.p;
 	}
-	if (nosync && (r = ib_ensure(h, dst, ngrp, nwin)) < 0) return r; // before any launch: hipMalloc may synchronise
-	if (!FROM_PLAIN) {
-		const int64_t nt = n2 + 1;
-		HIPCHK(hipMemsetAsync(jg, 0, (size_t)(ngrp + 1) * 8, h->st)); // defined even if pos[] turns out invalid
-		hipLaunchKernelGGL(k_group_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, ngrp);
+	// window-parallel kernels (one wave per 256-symbol window, planes cached between the passes) unless
+	// their scratch (120 B per window) would be unreasonably large; then one wave per 8192-symbol group
+	const bool winpar = (size_t)nwin * 120 <= ((size_t)6 << 30) && !getenv("RB3GPU_GROUP_REBUILD");
+	if (winpar) {
+		if ((r = buf_ensure(h, h->wstat, (size_t)nwin * 16)) < 0) return r;
+		if ((r = buf_ensure(h, h->wplane, (size_t)nwin * 96)) < 0) return r;
+		if (!FROM_PLAIN && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
+		jg = (int64_t*)h->jg.p;
 	}
+	if (nosync && (r = ib_ensure(h, dst, ngrp, nwin)) < 0) return r; // before any launch: hipMalloc may synchronise
 	IdxView old = view_of(h);
 	uint32_t *gstat = (uint32_t*)h->gstat.p;
 	uint64_t *gpre = (uint64_t*)h->gpre.p, *dtot = (uint64_t*)h->misc.p + MISC_IX_TOT;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, gstat, ngrp);
+	if (winpar) {
+		if (!FROM_PLAIN) {
+			const int64_t nt = n2 + 1;
+			HIPCHK(hipMemsetAsync(jg, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
+			hipLaunchKernelGGL(k_win_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, nwin);
+		}
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN>), dim3((unsigned)nwin), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
+				(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, nwin);
+		hipLaunchKernelGGL(k_decide, dim3((unsigned)ngrp), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp);
+	} else {
+		if (!FROM_PLAIN) {
+			const int64_t nt = n2 + 1;
+			HIPCHK(hipMemsetAsync(jg, 0, (size_t)(ngrp + 1) * 8, h->st)); // defined even if pos[] turns out invalid
+			hipLaunchKernelGGL(k_group_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, ngrp);
+		}
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, gstat, ngrp);
+	}
 	uint64_t total[8];
 	if ((r = scan_records(h, gstat, ngrp, gpre, dtot, nosync ? nullptr : total)) < 0) return r;
 	if (!nosync) {
@@ -279,8 +299,12 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		*onslots = (int64_t)total[6];
 		if ((r = ib_ensure(h, dst, ngrp, *onslots)) < 0) return r;
 	}
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-			(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp);
+	if (winpar)
+		hipLaunchKernelGGL(k_pass2w, dim3((unsigned)nwin), dim3(64), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, ntot,
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin);
+	else
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp);
 	*ongrp = ngrp;
 	return 0;
 }

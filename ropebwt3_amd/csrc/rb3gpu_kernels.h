@@ -967,6 +967,207 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 }
 
 /* ----------------------------------------------------------------------------------------- */
+/* window-parallel rebuild (same result as k_pass1/k_pass2, one wave per 256-symbol window)     */
+/* ----------------------------------------------------------------------------------------- */
+
+/* jw[w] = #{rows kb : pos[kb] < w * 256}, w = 0..nwin */
+__global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2, int64_t *jw, int64_t nwin)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n2) return;
+	int64_t a = i == 0 ? -1 : pos[i - 1] >> RB3_WIN_BITS;
+	int64_t b = i == n2 ? nwin : pos[i] >> RB3_WIN_BITS;
+	if (a < -1) a = -1;
+	if (b > nwin) b = nwin;
+	for (int64_t w = a + 1; w <= b; ++w) jw[w] = i;
+}
+
+/* per window: symbols -> statistics (wstat: 6 x u16 counts, first, last, u16 runs = 16 B) and the
+ * three bit planes (wplane: 24 dwords, the payload of a bit-plane slot) */
+template<bool FROM_PLAIN>
+__global__ void __launch_bounds__(64) k_pass1w(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
+		const int64_t *jw, uint4 *wstat, uint32_t *wplane, int64_t nwin)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t symbuf[RB3_WIN];
+	__shared__ uint64_t ball[12];
+	const int lane = threadIdx.x;
+	const int64_t w = blockIdx.x;
+	const int64_t p0 = w << RB3_WIN_BITS;
+	int64_t j = FROM_PLAIN ? 0 : jw[w];
+	uint32_t sym[4];
+	gen_window<FROM_PLAIN>(old, pos, b2, n2, ntot, p0, j, symbuf, sym, lane);
+	uint64_t H[4];
+	window_heads(sym, lane, H);
+	const uint32_t nruns = __popcll(H[0]) + __popcll(H[1]) + __popcll(H[2]) + __popcll(H[3]);
+	uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+#pragma unroll
+		for (int a = 0; a < 6; ++a) cnt[a] += __popcll(__ballot(sym[u] == (uint32_t)a));
+#pragma unroll
+		for (int p = 0; p < 3; ++p) {
+			const uint64_t m = __ballot((sym[u] >> p) & 1u);
+			if (lane == u * 3 + p) ball[u * 3 + p] = m;
+		}
+	}
+	const int64_t rem = ntot - p0;
+	const int nv = rem >= RB3_WIN ? RB3_WIN : rem > 0 ? (int)rem : 0;
+	const uint32_t first = __shfl(sym[0], 0);
+	uint32_t last = 7;
+	if (nv > 0) {
+		const int lu = (nv - 1) >> 6, ll = (nv - 1) & 63;
+		const uint32_t v = lu == 0 ? sym[0] : lu == 1 ? sym[1] : lu == 2 ? sym[2] : sym[3];
+		last = __shfl(v, ll);
+	}
+	__syncthreads();
+	if (lane < 24) wplane[w * 24 + lane] = ((const uint32_t*)ball)[lane];
+	if (lane == 0) {
+		uint4 v;
+		v.x = cnt[0] | cnt[1] << 16, v.y = cnt[2] | cnt[3] << 16, v.z = cnt[4] | cnt[5] << 16;
+		v.w = nruns | first << 16 | last << 24;
+		wstat[w] = v;
+	}
+}
+
+/* per group of 32 windows: the slot partition (largest aligned power-of-two window groups with
+ * <= 48 runs) and the group's symbol counts; same output as k_pass1 */
+__global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot, uint32_t *gstat, int64_t ngrp)
+{
+	const int lane = threadIdx.x;
+	const int64_t g = blockIdx.x;
+	const int64_t W = (ntot >> RB3_WIN_BITS) + 1;
+	const int nvw = (int)(W - g * RB3_GRP_WINS < RB3_GRP_WINS ? W - g * RB3_GRP_WINS : RB3_GRP_WINS);
+	uint4 st = make_uint4(0, 0, 0, 7u << 16 | 7u << 24);
+	if (lane < nvw) st = wstat[g * RB3_GRP_WINS + lane];
+	const int my_nruns = (int)(st.w & 0xFFFFu);
+	const uint32_t my_first = st.w >> 16 & 0xFFu, my_last = st.w >> 24;
+	uint32_t cnt[6] = { st.x & 0xFFFFu, st.x >> 16, st.y & 0xFFFFu, st.y >> 16, st.z & 0xFFFFu, st.z >> 16 };
+#pragma unroll
+	for (int a = 0; a < 6; ++a)
+		for (int d = 32; d >= 1; d >>= 1) cnt[a] += __shfl_xor(cnt[a], d);
+	const uint32_t prev_last = __shfl_up(my_last, 1);
+	const int b = (lane > 0 && lane < nvw && my_nruns > 0 && prev_last == my_first) ? 1 : 0;
+	const int e = lane < nvw ? my_nruns - b : 0;
+	int P = e;
+	for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(P, d); if (lane >= d) P += t; }
+	int level = 0;
+#pragma unroll
+	for (int jl = 1; jl <= 5; ++jl) {
+		const int sz = 1 << jl, a = lane & ~(sz - 1);
+		const int Pa = __shfl(P, a), Pe = __shfl(P, (a + sz - 1) & 63), na = __shfl(my_nruns, a);
+		const bool ok = (a + sz <= nvw) && (Pe - Pa + na <= RB3_RLE_CODES);
+		if (ok && level == jl - 1) level = jl;
+	}
+	const bool start = lane < nvw && (lane & ((1 << level) - 1)) == 0;
+	const uint32_t mask = (uint32_t)__ballot(start);
+	if (lane < 8) {
+		uint32_t v = lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : lane == 3 ? cnt[3] : lane == 4 ? cnt[4] :
+			lane == 5 ? cnt[5] : lane == 6 ? (uint32_t)__popc(mask) : mask;
+		gstat[g * 8 + lane] = v;
+	}
+}
+
+/* per window: emit its slot (bit-plane slots straight from the cached planes; the wave of the first
+ * window of a run slot walks the slot's windows and run-length encodes them); window 0 of a group
+ * also writes the directory entry */
+__global__ void __launch_bounds__(64) k_pass2w(const uint4 *wstat, const uint32_t *wplane, int64_t ntot, const uint32_t *gstat,
+		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin)
+{
+	__shared__ uint32_t csym[RB3_RLE_CODES + 16], clen[RB3_RLE_CODES + 16];
+	__shared__ uint32_t code16[RB3_RLE_CODES / 2];
+	const int lane = threadIdx.x;
+	const int64_t w = blockIdx.x, g = w >> 5;
+	const int lw = (int)(w & 31);
+	const int nvw = (int)(nwin - g * RB3_GRP_WINS < RB3_GRP_WINS ? nwin - g * RB3_GRP_WINS : RB3_GRP_WINS);
+	const uint32_t mask = gstat[g * 8 + 7];
+	const uint64_t slot0 = gpre[g * 8 + 6];
+	if (lw == 0 && lane == 0) {
+		rb3_grp_t e;
+		uint64_t c = 0;
+		for (int a = 0; a < 6; ++a) { e.cnt[a] = c + gpre[g * 8 + a]; c += tot[a]; }
+		e.slot0 = (uint32_t)slot0, e.mask = mask, e.spare = 0;
+		grp[g] = e;
+	}
+	if (!(mask >> lw & 1u)) return; // not the first window of a slot
+	const int64_t sidx = (int64_t)slot0 + __popc(mask & ((2u << lw) - 1u)) - 1;
+	const uint32_t above = lw == 31 ? 0u : mask >> (lw + 1);
+	const int slot_sz = (above ? lw + 1 + (__ffs(above) - 1) : nvw) - lw;
+	// symbol counts of the group's windows before this slot
+	uint4 st = make_uint4(0, 0, 0, 0);
+	if (lane < lw) st = wstat[g * RB3_GRP_WINS + lane];
+	uint64_t s0 = (uint64_t)(st.x & 0xFFFFu) | (uint64_t)(st.x >> 16) << 20 | (uint64_t)(st.y & 0xFFFFu) << 40;
+	uint64_t s1 = (uint64_t)(st.y >> 16) | (uint64_t)(st.z & 0xFFFFu) << 20 | (uint64_t)(st.z >> 16) << 40;
+	for (int d = 16; d >= 1; d >>= 1) s0 += __shfl_xor(s0, d), s1 += __shfl_xor(s1, d);
+	const uint32_t rel[6] = { (uint32_t)(s0 & 0xFFFFF), (uint32_t)(s0 >> 20 & 0xFFFFF), (uint32_t)(s0 >> 40),
+	                          (uint32_t)(s1 & 0xFFFFF), (uint32_t)(s1 >> 20 & 0xFFFFF), (uint32_t)(s1 >> 40) };
+	const int64_t srem = ntot - (w << RB3_WIN_BITS);
+	const uint32_t nsym = srem <= 0 ? 0u : srem < (int64_t)slot_sz * RB3_WIN ? (uint32_t)srem : (uint32_t)(slot_sz * RB3_WIN);
+	const uint32_t hq = lane == 0 ? (uint32_t)(lw * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
+		lane == 1 ? rel[0] : lane == 2 ? rel[1] : lane == 3 ? rel[2] : lane == 4 ? rel[3] : lane == 5 ? rel[4] :
+		lane == 6 ? rel[5] : nsym;
+	if (slot_sz == 1) { // bit-plane slot: header + the cached planes
+		if (lane < 8) {
+			const uint32_t *pl = wplane + w * 24;
+			uint4 v;
+			v.x = hq;
+			v.y = pl[(lane >> 1) * 6 + 0 + (lane & 1)];
+			v.z = pl[(lane >> 1) * 6 + 2 + (lane & 1)];
+			v.w = pl[(lane >> 1) * 6 + 4 + (lane & 1)];
+			slot16[sidx * 8 + lane] = v;
+		}
+		return;
+	}
+	int nc = 0;
+	for (int k = 0; k < slot_sz; ++k) { // run slot: append the runs of each window, merging across window boundaries
+		const uint32_t *pl = wplane + (w + k) * 24;
+		uint32_t sym[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int wi = u * 6 + (lane >> 5), bit = lane & 31;
+			sym[u] = (pl[wi] >> bit & 1u) | (pl[wi + 2] >> bit & 1u) << 1 | (pl[wi + 4] >> bit & 1u) << 2;
+		}
+		uint64_t H[4];
+		window_heads(sym, lane, H);
+		const int64_t rem = ntot - ((w + k) << RB3_WIN_BITS);
+		const int nv = rem >= RB3_WIN ? RB3_WIN : rem > 0 ? (int)rem : 0;
+		const int nr = __popcll(H[0]) + __popcll(H[1]) + __popcll(H[2]) + __popcll(H[3]);
+		const uint32_t fs = __shfl(sym[0], 0);
+		const int mg = (nc > 0 && nr > 0 && csym[nc - 1] == fs) ? 1 : 0;
+		int hb = 0;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			if (H[u] >> lane & 1ull) {
+				const int r = hb + __popcll(H[u] & ((1ull << lane) - 1ull));
+				const uint64_t up = lane == 63 ? 0ull : H[u] >> (lane + 1) << (lane + 1);
+				int nxt = nv;
+				if (up) nxt = 64 * u + (__ffsll((unsigned long long)up) - 1);
+				else {
+					for (int v = u + 1; v < 4; ++v)
+						if (H[v]) { nxt = 64 * v + (__ffsll((unsigned long long)H[v]) - 1); break; }
+				}
+				const int len = nxt - (64 * u + lane);
+				const int idx = nc + r - mg;
+				if (r == 0 && mg) clen[idx] += (uint32_t)len;
+				else csym[idx] = sym[u], clen[idx] = (uint32_t)len;
+			}
+			hb += __popcll(H[u]);
+		}
+		nc += nr - mg;
+		__syncthreads();
+	}
+	if (lane < RB3_RLE_CODES) {
+		const uint32_t code = lane < nc ? ((clen[lane] - 1u) << 3 | csym[lane]) : 7u;
+		((uint16_t*)code16)[lane] = (uint16_t)code;
+	}
+	__syncthreads();
+	if (lane < 8) {
+		uint4 v;
+		v.x = hq, v.y = code16[lane * 3], v.z = code16[lane * 3 + 1], v.w = code16[lane * 3 + 2];
+		slot16[sidx * 8 + lane] = v;
+	}
+}
+
+/* ----------------------------------------------------------------------------------------- */
 /* export                                                                                      */
 /* ----------------------------------------------------------------------------------------- */
 

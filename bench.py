@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--genome-len", type=int, default=4400000)
     ap.add_argument("--div", type=float, default=0.001)
-    ap.add_argument("--walker-step", type=int, default=512, help="text distance between LF walkers handed to the engine")
+    ap.add_argument("--walker-step", type=int, default=384, help="text distance between LF walkers handed to the engine")
     ap.add_argument("--plain-abi", action="store_true", help="use rb3gpu_merge_plain_dev (the reference's signature, no walker list)")
     ap.add_argument("--sharded", action="store_true", help="N>1: one batch of N genomes, walkers sharded by text range + all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")

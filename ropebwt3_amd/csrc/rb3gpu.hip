@@ -19,6 +19,8 @@
 		if (h && h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
 		return e_ == hipErrorOutOfMemory ? RB3GPU_ENOMEM : RB3GPU_ENODEV; } } while (0)
 
+#define RB3_STAGE_BYTES ((size_t)32 << 20) // pinned host staging buffers
+
 struct Buf {
 	void *p = nullptr;
 	size_t cap = 0;
@@ -580,25 +582,25 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = buf_ensure(h, h->dl, (size_t)n_walkers * 8)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, nwin)) < 0) return r;
-	rb3gpu_walker_t *tmp = (rb3gpu_walker_t*)malloc((size_t)n_walkers * sizeof(rb3gpu_walker_t));
-	if (!tmp) return RB3GPU_ENOMEM;
-	memcpy(tmp, walkers, (size_t)n_walkers * sizeof(rb3gpu_walker_t));
-	for (int64_t i = 0; i < n_walkers; ++i)
-		if (tmp[i].ka0 == RB3GPU_KA_SENTINEL) tmp[i].ka0 = h->acc[1];
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	Walker *dwl = (Walker*)h->wl.p;
 	int32_t *dres = (int32_t*)h->dl.p, *dlink = dres + n_walkers;
 	h->mg_active = 0;
 	HIPCHK(hipEventRecord(h->ev[0], h->st));
-	if ((r = lf_build(h, len, d_b2, nullptr)) < 0) { free(tmp); return r; }
+	if ((r = lf_build(h, len, d_b2, nullptr)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipMemsetAsync(h->pos.p, 0xff, (size_t)len * 8, h->st));
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
 	HIPCHK(hipMemsetAsync(dres, 0, (size_t)n_walkers * 8, h->st));
-	{
-		hipError_t e = hipMemcpyAsync(dwl, tmp, (size_t)n_walkers * 32, hipMemcpyHostToDevice, h->st); // pageable source: returns once staged
-		free(tmp);
-		HIPCHK(e);
+	{ // walker list: through the pinned staging buffer when it fits (a pageable source is staged by the runtime, slowly)
+		const size_t wb = (size_t)n_walkers * 32;
+		if (h->stage[0] == nullptr)
+			for (int i = 0; i < 2; ++i)
+				if (hipHostMalloc((void**)&h->stage[i], RB3_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { h->stage[i] = nullptr; break; }
+		if (h->stage[0] && wb <= RB3_STAGE_BYTES) {
+			memcpy(h->stage[0], walkers, wb); // safe to reuse: every earlier copy out of it was synchronised
+			HIPCHK(hipMemcpyAsync(dwl, h->stage[0], wb, hipMemcpyHostToDevice, h->st));
+		} else HIPCHK(hipMemcpyAsync(dwl, walkers, wb, hipMemcpyHostToDevice, h->st));
 	}
 	int64_t *dpos = (int64_t*)h->pos.p;
 	{
@@ -624,10 +626,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
 			hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_walkers + 255) / 256)), dim3(256), 0, h->st, dres, (const int32_t*)dlink, n_walkers, misc + 2);
-			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, (const int32_t*)dres, misc + 2);
-		}
+			hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)dres, misc + 2);
+		} else
+			hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, len, ntot, misc + 2);
 	}
-	hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, len, ntot, misc + 2);
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	int64_t ngrp = 0, nslots = 0, acc[7];
 	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc)) < 0) return r;
@@ -678,7 +680,6 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 /* host -> HBM copy of a partial BWT through two pinned staging buffers: the CPU copies chunk i+1
  * into pinned memory while the DMA engine moves chunk i (a pageable hipMemcpy is staged by the
  * runtime anyway, single-buffered and several times slower) */
-#define RB3_STAGE_BYTES ((size_t)32 << 20)
 static int upload_b2(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
 {
 	int r;

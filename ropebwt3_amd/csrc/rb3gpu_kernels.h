@@ -560,6 +560,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 				const Walker w = wl[wid];
 				kb = w.row, remaining = w.nsteps, check = (w.flags & RB3_WK_CHECK) != 0;
 				if (w.ka0 >= 0) lo = hi = w.ka0;
+				else if (w.ka0 == -2) lo = hi = b1.m; // RB3GPU_KA_SENTINEL: a sentinel row, ka = acc[1] of the index (fm-index.c:164)
 				else lo = 0, hi = b1.n;
 				myid = wid;
 			} else {
@@ -671,7 +672,7 @@ __device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *dres, uns
 {
 	if (v < 0 || !(v & RB3_TENT)) return v;
 	const int r = dres[(int)(v >> 40) & (RB3_TENT_IDS - 1)];
-	if (r != 1 && r != 2) { atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
+	if (r != 1 && r != 2) { if (bad) atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
 	return (v & RB3_TENT_MASK) + (r - 1);
 }
 
@@ -681,6 +682,19 @@ __global__ void __launch_bounds__(256) k_pos_finalize(int64_t *pos, int64_t n2, 
 	if (i >= n2) return;
 	const int64_t v = pos[i];
 	if (v >= 0 && (v & RB3_TENT)) pos[i] = pos_final(v, dres, bad);
+}
+
+/* both in one pass over pos[] (each thread finalises its own row and re-derives its left neighbour) */
+__global__ void __launch_bounds__(256) k_pos_finalize_check(int64_t *pos, int64_t n2, int64_t ntot, const int32_t *dres, unsigned long long *bad)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n2) return;
+	const int64_t raw = pos[i];
+	const int64_t p = pos_final(raw, dres, bad);
+	const int64_t q = i > 0 ? pos_final(pos[i - 1], dres, nullptr) : RB3_UNSET; // the neighbour's own thread reports its problems
+	if (p != raw) pos[i] = p;
+	if (p == RB3_UNSET) atomicAdd(&bad[0], 1ull);
+	else if (p < 0 || p >= ntot || (i > 0 && q != RB3_UNSET && q >= p)) atomicAdd(&bad[1], 1ull);
 }
 
 __global__ void __launch_bounds__(256) k_pos_check(const int64_t *pos, int64_t n2, int64_t ntot, unsigned long long *bad)

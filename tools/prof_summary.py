@@ -17,6 +17,9 @@ def short(name):
             f = [x.strip() in ("true", "(bool)1") for x in m.group(1).split(",")]
             return "k_chain<%s,%s,%s>" % ("list" if f[0] else "auto", "dense" if f[1] else "mixed", "tent" if len(f) > 2 and f[2] else "plain")
         return "k_chain"
+    for k in ("k_pos_finalize_check", "k_pass1w", "k_pass2w", "k_win_rows", "k_decide"):
+        if k in name:
+            return k + ("<plain>" if "<true>" in name else "<merge>" if "<false>" in name else "")
     for k in ("k_resolve", "k_pos_finalize", "k_pass1", "k_pass2", "k_lf2", "k_tile_hist", "k_scan_chunk_totals", "k_scan_chunks", "k_scan_records",
               "k_group_rows", "k_export_plain", "k_rank_batch", "k_pos_check", "k_jump", "k_ckpt"):
         if k in name:

@@ -102,7 +102,7 @@ int rb3gpu_merge_plain_dev_walkers(rb3gpu_t *h, int64_t len, const uint8_t *d_bw
  * walkers sharded by text range: every rank calls begin (LF array of the whole batch), walk on ITS
  * walkers (several calls allowed: hand-off values arriving from the neighbour rank start fix-up
  * walkers), then the ranks combine pos[] (RCCL all-reduce MAX over the device buffer returned by
- * rb3gpu_mg_pos_ptr: unset rows are -1) and every rank calls finish.  d_pos_ext, if not NULL, is a
+ * rb3gpu_mg_pos_ptr: rows not yet recorded hold negative words, identical on every rank) and every rank calls finish.  d_pos_ext, if not NULL, is a
  * caller-owned device buffer of len int64 to use for pos[].  stop_row >= 0 names the row where the
  * territory of the next rank begins (the start row of its top walker): any walker reaching it stops,
  * and *arrive (host, optional) receives the exact value a walker arrived there with, or -1 if none did. */

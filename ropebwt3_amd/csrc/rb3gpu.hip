@@ -39,7 +39,7 @@ struct rb3gpu_s {
 	struct { rb3_grp_t *grp; size_t grp_cap; rb3_slot_t *slots; size_t slots_cap; } ib[2] = {{nullptr, 0, nullptr, 0}, {nullptr, 0, nullptr, 0}};
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, lf2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane;
+	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -204,7 +204,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	(void)hipStreamSynchronize(h->st);
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->lf2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane };
+	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	for (int i = 0; i < 2; ++i) if (h->stage[i]) (void)hipHostFree(h->stage[i]);
@@ -324,15 +324,14 @@ static void index_install(rb3gpu_t *h, int64_t ngrp, int64_t nslots, int64_t nto
 	if (h->ib[o].slots_cap * sizeof(rb3_slot_t) > ((size_t)4 << 30)) ib_release(h, o);
 }
 
-/* histogram + LF array of B2.  Totals stay on the device (misc[MISC_LF_TOT..]); acc2 != NULL also
+/* histogram + row words of B2 (LF word of every row, fm-index.c:206-216) into d_row.  Totals stay on the device (misc[MISC_LF_TOT..]); acc2 != NULL also
  * brings the C array of B2 to the host (one sync) and checks the symbols (fm-index.c:124-125). */
-static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *acc2)
+static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_row, int64_t *acc2)
 {
 	const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
 	int r;
 	if ((r = buf_ensure(h, h->tcnt, (size_t)ntile * 32)) < 0) return r;
 	if ((r = buf_ensure(h, h->tpre, (size_t)ntile * 64)) < 0) return r;
-	if ((r = buf_ensure(h, h->lf2, (size_t)len * 8)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	uint64_t *dtot = (uint64_t*)h->misc.p + MISC_LF_TOT;
 	hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (uint32_t*)h->tcnt.p);
@@ -343,7 +342,7 @@ static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *acc2
 		acc2[0] = 0;
 		for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)total[a];
 	}
-	hipLaunchKernelGGL(k_lf2, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (const uint64_t*)h->tpre.p, (const uint64_t*)dtot, (uint64_t*)h->lf2.p);
+	hipLaunchKernelGGL(k_lf2, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (const uint64_t*)h->tpre.p, (const uint64_t*)dtot, (uint64_t*)d_row);
 	return 0;
 }
 
@@ -367,17 +366,16 @@ int rb3gpu_mg_begin(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, void *d_pos_
 	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
 	int r;
 	h->mg_active = 0;
-	HIPCHK(hipEventRecord(h->ev[0], h->st));
-	if ((r = lf_build(h, len, d_bwt, h->mg_acc2)) < 0) return r;
-	if (h->mg_acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
-	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	if (d_pos_ext) h->mg_pos = (int64_t*)d_pos_ext;
 	else {
 		if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
 		h->mg_pos = (int64_t*)h->pos.p;
 	}
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
-	HIPCHK(hipMemsetAsync(h->mg_pos, 0xff, (size_t)len * 8, h->st));
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	if ((r = lf_build(h, len, d_bwt, h->mg_pos, h->mg_acc2)) < 0) return r;
+	if (h->mg_acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipMemsetAsync(h->misc.p, 0, 128, h->st)); // words 0..15; the scan totals behind them stay
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
@@ -448,10 +446,9 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 	HIPCHK(hipEventRecord(h->ev[6], h->st));
 	{
 		const IdxView iv = view_of(h);
-		const uint64_t *lf2 = (const uint64_t*)h->lf2.p;
 		const int64_t sr = stop_row < 0 ? -1 : stop_row;
 		const dim3 grid((unsigned)nblk), blk(256);
-#define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T>), grid, blk, 0, h->st, iv, lf2, h->mg_pos, len, m2, \
+#define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
 			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, dres, dlink)
 		const int sel = (walkers ? 4 : 0) | (iv.dense ? 2 : 0) | (tent ? 1 : 0);
 		switch (sel) {
@@ -549,8 +546,8 @@ static int merge_staged(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commi
 		HIPCHK(hipMemcpy(&unsettled, (unsigned long long*)h->misc.p + 4, 8, hipMemcpyDeviceToHost));
 		if (unsettled != 0) {
 			h->stt.n_fallbacks += 1;
-			HIPCHK(hipMemsetAsync(h->mg_pos, 0xff, (size_t)len * 8, h->st));
-			HIPCHK(hipMemsetAsync((unsigned long long*)h->misc.p + 4, 0, 8, h->st));
+			if ((r = lf_build(h, len, d_b2, h->mg_pos, nullptr)) < 0) return r; // fresh row words
+			HIPCHK(hipMemsetAsync(h->misc.p, 0, 128, h->st));
 			if ((r = mg_walk_impl(h, n_walkers, walkers, -1, nullptr, 0)) < 0) return r;
 		}
 	}
@@ -587,9 +584,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int32_t *dres = (int32_t*)h->dl.p, *dlink = dres + n_walkers;
 	h->mg_active = 0;
 	HIPCHK(hipEventRecord(h->ev[0], h->st));
-	if ((r = lf_build(h, len, d_b2, nullptr)) < 0) return r;
+	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
-	HIPCHK(hipMemsetAsync(h->pos.p, 0xff, (size_t)len * 8, h->st));
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
 	HIPCHK(hipMemsetAsync(dres, 0, (size_t)n_walkers * 8, h->st));
 	{ // walker list: through the pinned staging buffer when it fits (a pageable source is staged by the runtime, slowly)
@@ -614,9 +610,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		fprintf(stderr, "[prof] launching %lld blocks x 256 threads, %d octets per wave, %lld walkers\n", (long long)nblk, octs, (long long)n_walkers);
 #endif
 		const dim3 grid((unsigned)nblk), blk(256);
-		const uint64_t *lf2 = (const uint64_t*)h->lf2.p;
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
-#define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, lf2, dpos, len, (int64_t)0, 0, \
+#define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, dres, dlink)
 		if (iv.dense && tent) RB3_LAUNCH_FAST(true, true);
 		else if (iv.dense) RB3_LAUNCH_FAST(true, false);

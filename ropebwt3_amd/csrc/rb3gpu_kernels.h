@@ -21,6 +21,11 @@
 #include "rb3gpu_layout.h"
 
 #define RB3_UNSET (-1LL)
+/* One 8-byte word per row of the batch, as in the reference's rb[] (fm-index.c:166-168): until the row
+ * is visited it holds LF_B2(row) << 3 | B2[row] with bit 63 set; a walker replaces it by the row's merged
+ * position (bit 63 clear), so the record lands in the line the walker has just read. */
+#define RB3_ROW_LF   0x8000000000000000ull
+#define RB3_ROW_NEXT(x) ((int64_t)(((x) & ~RB3_ROW_LF) >> 3))
 
 struct IdxView {
 	const uint64_t *grp64;   // rb3_grp_t viewed as 8 x u64
@@ -363,7 +368,7 @@ __global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, cons
 		const uint64_t word = a < 3 ? p0 : p1;
 		const uint32_t sh = 16 * (a < 3 ? a : a - 3);
 		const uint64_t in_tile = (word >> sh) & 0xFFFFull;
-		out[i] = (shbase[a] + in_tile) << 3 | a;
+		out[i] = RB3_ROW_LF | (shbase[a] + in_tile) << 3 | a;
 		if (a < 3) p0 += 1ull << sh; else p1 += 1ull << sh;
 	}
 	if (nv == 16) {
@@ -512,14 +517,15 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 #define RB3_TENT_MIN_AGE 64u
 #endif
 
-template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t v)
+template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t v, bool vis)
 {
-	if (TENT) atomicMin((unsigned long long*)p, (unsigned long long)v); // final < tentative < unset (0xFFFF...)
-	else st_pos(p, v);
+	if (TENT) atomicMin((unsigned long long*)p, (unsigned long long)v); // final < tentative < unvisited (bit 63)
+	else if (vis) st_pos(p, v);  // written through: other walkers may be waiting to see it
+	else *p = v;                 // one walker per string, nobody ever looks: let the L2 keep the line it just read
 }
 
 template<bool LIST, bool DENSE, bool TENT>
-__global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, int64_t *pos, int64_t n2, int64_t m2,
+__global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
 		int32_t *dres, int32_t *dlink)
 {
@@ -529,14 +535,15 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 	if ((lane >> 3) >= octs) return;
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
 	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
-	bool active = false, check = false;
+	const bool vis = LIST || M != 0; // records must become visible to other walkers only if strings are split
+	bool active = false;
 	int gap = 0;            // 0: exact (lo == hi), 1: hi == lo + 1, 2: wider
-	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, seen = RB3_UNSET, myid = 0;
-	uint64_t x = 0;
+	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, myid = 0;
+	uint64_t x = 0;         // row word of the current row (requested one step ahead)
 	uint32_t steps = 0;
-	// Recorded rows are written through to memory (agent scope) so that walkers on other XCDs can see
-	// them.  Each octet parks up to 8 records in its lanes (lane it&7 takes iteration it) and the whole
-	// wave flushes them with ONE store instruction every 8 iterations.
+	// Records are written through to memory (agent scope) so that walkers on other XCDs can see them.
+	// Each octet parks up to 8 records in its lanes (lane it&7 takes iteration it) and the whole wave
+	// flushes them with ONE store instruction every 8 iterations.
 	int64_t bkb = -1, bval = 0;
 	uint32_t it = 0, age = 0;
 #ifdef RB3_PROF
@@ -553,62 +560,56 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			w0 = oct_bcast0(w0, j), w1 = oct_bcast0(w1, j);
 			const int64_t wid = (int64_t)((uint64_t)w1 << 32 | w0);
 			if (wid >= nwalk) {
-				if (bkb >= 0) rec_pos<TENT && !LIST>(&pos[bkb], bval);
+				if (bkb >= 0) rec_pos<TENT && !LIST>(&row[bkb], bval, vis);
 				break;
 			}
 			if (LIST) {
 				const Walker w = wl[wid];
-				kb = w.row, remaining = w.nsteps, check = (w.flags & RB3_WK_CHECK) != 0;
+				kb = w.row, remaining = w.nsteps;
 				if (w.ka0 >= 0) lo = hi = w.ka0;
 				else if (w.ka0 == -2) lo = hi = b1.m; // RB3GPU_KA_SENTINEL: a sentinel row, ka = acc[1] of the index (fm-index.c:164)
 				else lo = 0, hi = b1.n;
 				myid = wid;
 			} else {
-				check = false, remaining = INT64_MAX;
+				remaining = INT64_MAX;
 				if (wid < m2) kb = wid, lo = hi = b1.m;
 				else kb = first_marked + ((wid - m2) << logM), lo = 0, hi = b1.n;
 				myid = wid - m2;
 			}
 			gap = hi - lo > 1 ? 2 : (int)(hi - lo);
-			seen = RB3_UNSET, age = 0;
-			if (gap || check) {
-				seen = ld_pos(&pos[kb]);
-				if (gap && seen != RB3_UNSET) continue; // somebody already came through
-			}
-			x = lf2[kb];
+			age = 0;
+			x = (uint64_t)ld_pos(&row[kb]);
+			if (gap && (int64_t)x >= 0) continue; // an inexact walker whose start row somebody has already recorded
 			active = true;
 		}
 		// ---- steps: run until some octet of this wave needs a refill.  Two independent dependency
-		// chains meet in a step: kb -> lf2[kb] -> next row, and ka -> directory entry -> slot -> next ka.
-		// The next row's lf2 word (and its recorded-row check) are requested one step ahead, so the
-		// symbol c is known before anything is issued and only the ka chain is on the critical path.
-		// The body is branch-free (selects) except for the second bound of wide walkers and the rare
-		// settle events: a lone wave runs at instruction-issue speed, so instruction count is the cost.
+		// chains meet in a step: kb -> row[kb] -> next row, and ka -> directory entry -> slot -> next ka.
+		// The next row's word is requested one step ahead, so the symbol c is known before anything is
+		// issued and only the ka chain is on the critical path.  The body is branch-free (selects) except
+		// for the second bound of wide walkers and the rare settle events: a lone wave runs at
+		// instruction-issue speed, so instruction count is the cost.
 		do {
-			if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&pos[bkb], bval); bkb = -1; }
+			if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
+			const bool met = (int64_t)x >= 0;  // this row already carries a record
 			const int c = (int)(x & 7u);
-			const int64_t kbn = (int64_t)(x >> 3);
+			const int64_t kbn = met ? kb : RB3_ROW_NEXT(x);
 			const bool wide = TENT ? gap == 2 : gap != 0;
 			const bool tentok = TENT && gap == 1 && age >= RB3_TENT_MIN_AGE; // may record tentatively
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
 			if (wide) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
-			const uint64_t xn = lf2[kbn];
+			const uint64_t xn = (uint64_t)ld_pos(&row[kbn]);
 			bool end_next;
 			if (LIST) end_next = remaining == 1;
 			else end_next = M && kbn >= m2 && (kbn & (M - 1)) == 0;
-			// recorded-row check of the next row: only walkers beyond their own segment need it (a dummy
-			// load from one fixed word here would make every wave of the chip hit the same L2 channel)
-			int64_t seen_n = RB3_UNSET;
-			if (check || end_next) seen_n = ld_pos(&pos[kbn]);
 			octc_issue_slot<DENSE>(b1, j, rl);
 			if (wide) octc_issue_slot<DENSE>(b1, j, rh);
 			// this row: record it unless somebody already has
 			++steps;
-			const bool met = check && seen != RB3_UNSET;
-			const bool fin = (c == 0) || met;
+			const bool fin = met || c == 0;
 			const int64_t myval = lo + kb;
 			if (TENT && met) { // settle one bit (rare)
+				const int64_t seen = (int64_t)x;
 				if (!(seen & RB3_TENT)) { // a final value: my own bit, if I am tentative
 					if (gap == 1 && j == 0) dres[myid] = 1 + (int)(seen - myval);
 				} else {
@@ -634,9 +635,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, const uint64_t *lf2, 
 			const bool at_stop = LIST && kbn == stop_row; // the rest of this string is recorded on another GPU
 			if (at_stop && gap_n == 0 && !fin && j == 0) st_pos(arrive, lo_n);
 			active = !(fin || at_stop || (end_next && stop_wide));
-			check = check || end_next;
 			remaining = end_next ? INT64_MAX : remaining - 1;
-			kb = kbn, x = xn, seen = seen_n, lo = lo_n, hi = hi_n, gap = gap_n;
+			kb = kbn, x = xn, lo = lo_n, hi = hi_n, gap = gap_n;
 		} while (__all(active));
 	}
 	if (j == 0) atomicAdd(nsteps, (unsigned long long)steps);
@@ -670,7 +670,8 @@ __global__ void __launch_bounds__(256) k_resolve(int32_t *dres, const int32_t *d
  * bad[0] += #unset, bad[1] += #order violations, bad[2] += #unsettled tentative records */
 __device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *dres, unsigned long long *bad)
 {
-	if (v < 0 || !(v & RB3_TENT)) return v;
+	if (v < 0) return RB3_UNSET; // never visited (still an LF word)
+	if (!(v & RB3_TENT)) return v;
 	const int r = dres[(int)(v >> 40) & (RB3_TENT_IDS - 1)];
 	if (r != 1 && r != 2) { if (bad) atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
 	return (v & RB3_TENT_MASK) + (r - 1);
@@ -693,8 +694,8 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check(int64_t *pos, int64_
 	const int64_t p = pos_final(raw, dres, bad);
 	const int64_t q = i > 0 ? pos_final(pos[i - 1], dres, nullptr) : RB3_UNSET; // the neighbour's own thread reports its problems
 	if (p != raw) pos[i] = p;
-	if (p == RB3_UNSET) atomicAdd(&bad[0], 1ull);
-	else if (p < 0 || p >= ntot || (i > 0 && q != RB3_UNSET && q >= p)) atomicAdd(&bad[1], 1ull);
+	if (p < 0) atomicAdd(&bad[0], 1ull);
+	else if (p >= ntot || (i > 0 && q >= 0 && q >= p)) atomicAdd(&bad[1], 1ull);
 }
 
 __global__ void __launch_bounds__(256) k_pos_check(const int64_t *pos, int64_t n2, int64_t ntot, unsigned long long *bad)
@@ -702,8 +703,8 @@ __global__ void __launch_bounds__(256) k_pos_check(const int64_t *pos, int64_t n
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n2) return;
 	const int64_t p = pos[i];
-	if (p == RB3_UNSET) atomicAdd(&bad[0], 1ull);
-	else if (p < 0 || p >= ntot || (i > 0 && pos[i - 1] != RB3_UNSET && pos[i - 1] >= p)) atomicAdd(&bad[1], 1ull);
+	if (p < 0) atomicAdd(&bad[0], 1ull); // never visited
+	else if (p >= ntot || (i > 0 && pos[i - 1] >= 0 && pos[i - 1] >= p)) atomicAdd(&bad[1], 1ull);
 }
 
 /* ----------------------------------------------------------------------------------------- */
@@ -742,9 +743,11 @@ __global__ void __launch_bounds__(256) k_group_rows(const int64_t *pos, int64_t 
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n2) return;
-	const int64_t a = i == 0 ? -1 : pos[i - 1] >> RB3_GRP_BITS; // group of the previous row
-	const int64_t b = i == n2 ? ngrp : pos[i] >> RB3_GRP_BITS;   // group of this row
-	for (int64_t g = a + 1; g <= b && g <= ngrp; ++g) jg[g] = i;
+	int64_t a = i == 0 ? -1 : pos[i - 1] >> RB3_GRP_BITS; // group of the previous row
+	int64_t b = i == n2 ? ngrp : pos[i] >> RB3_GRP_BITS;   // group of this row
+	if (a < -1) a = -1;       // (only an invalid pos[] has negative entries; the result is discarded then,
+	if (b > ngrp) b = ngrp;   //  but the loop must stay bounded)
+	for (int64_t g = a + 1; g <= b; ++g) jg[g] = i;
 }
 
 /* The 256 symbols of window [p0, p0+256) of the merged BWT.  Lane t gets positions

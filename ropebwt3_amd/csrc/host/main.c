@@ -414,6 +414,94 @@ int main_build(int argc, char *argv[])
 	return 0;
 }
 
+/* merge, main.c:84-133 (rb3_fmi_merge, fm-index.c:251-277): merge whole indexes into the first one.
+ * The plain BWT of an index is itself a valid partial BWT whose sentinels all sort after those of
+ * the base (fm-index.c:147), so every further index is decoded to plain symbols on the host and goes
+ * through the same rb3gpu_merge_plain path as a batch. */
+typedef struct { uint8_t *s; int64_t l, m; } plainvec_t;
+
+static int sink_plainvec(void *data, int c, int64_t l)
+{
+	plainvec_t *v = (plainvec_t*)data;
+	if (v->l + l > v->m) {
+		v->m = (v->l + l) + ((v->l + l) >> 1) + 1024;
+		v->s = (uint8_t*)realloc(v->s, (size_t)v->m);
+		if (v->s == 0) return -1;
+	}
+	memset(v->s + v->l, c, (size_t)l);
+	v->l += l;
+	return 0;
+}
+
+int main_merge(int argc, char *argv[])
+{
+	int c, i, ret = 0, fmt = FMT_FMR, device = 0;
+	char *fn_tmp = 0;
+	rb3gpu_t *h;
+	rb3gpu_opt_t gopt;
+	bopt_t opt;
+	runvec_t rv = {0, 0, 0};
+	bopt_init(&opt);
+	optind = 1;
+	while ((c = getopt_long(argc, argv, "t:o:S:db", long_opts, 0)) >= 0) {
+		if (c == 't') opt.n_threads = atoi(optarg);
+		else if (c == 'o') { if (freopen(optarg, "wb", stdout) == 0) return 1; }
+		else if (c == 'S') fn_tmp = optarg;
+		else if (c == 'd') fmt = FMT_FMD;
+		else if (c == 'b') fmt = FMT_FMR;
+		else if (c == 301) device = atoi(optarg);
+		else if (c == '?') return 1;
+	}
+	if (argc - optind < 2) {
+		fprintf(stdout, "Usage: ropebwt3-amd merge [options] <base.fmr|fmd> <other1.fmr|fmd> [...]\n");
+		fprintf(stdout, "Options:\n");
+		fprintf(stdout, "  -o FILE    output to FILE [stdout]\n");
+		fprintf(stdout, "  -b / -d    output FMR (default, as the reference) / FMD\n");
+		fprintf(stdout, "  -S FILE    save the current index to FILE after each input file []\n");
+		fprintf(stdout, "  --gpu INT  HIP device ordinal [0]\n");
+		return 1;
+	}
+	rb3gpu_opt_init(&gopt);
+	gopt.device = device, gopt.verbose = rb3h_verbose;
+	h = rb3gpu_create(&gopt);
+	if (h == 0) { fprintf(stderr, "ERROR: no usable MI355X/HIP device; the merge path has no CPU fallback\n"); return 1; }
+	if (rb3h_index_read_runs(argv[optind], sink_runvec, &rv) < 0 || rv.n == 0 || rb3gpu_from_runs(h, rv.n, rv.a) < 0) {
+		fprintf(stderr, "ERROR: failed to load FMR/FMD file '%s'\n", argv[optind]);
+		free(rv.a); rb3gpu_destroy(h);
+		return 1;
+	}
+	free(rv.a);
+	for (i = optind + 1; i < argc && ret == 0; ++i) {
+		plainvec_t pv = {0, 0, 0};
+		if (rb3h_index_read_runs(argv[i], sink_plainvec, &pv) < 0 || pv.l == 0) {
+			fprintf(stderr, "ERROR: failed to load FMR/FMD file '%s'\n", argv[i]);
+			free(pv.s); ret = 1;
+			break;
+		}
+		ret = rb3gpu_merge_plain(h, pv.l, pv.s);
+		free(pv.s);
+		if (ret < 0) { fprintf(stderr, "ERROR: the GPU engine failed to merge '%s': %s\n", argv[i], rb3gpu_strerror(ret)); break; }
+		if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] merged '%s'\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), argv[i]);
+		if (fn_tmp) {
+			FILE *fp = fopen(fn_tmp, "wb");
+			if (fp) { dump_fmr(h, &opt, fp); fclose(fp); }
+		}
+	}
+	if (ret == 0) {
+		if (fmt == FMT_FMR) ret = dump_fmr(h, &opt, stdout);
+		else {
+			rb3h_fmdw_t *w = rb3h_fmdw_init();
+			ret = w ? rb3gpu_export_runs(h, sink_fmd, w) : -1;
+			if (ret == 0) ret = rb3h_fmdw_finish(w);
+			if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
+			rb3h_fmdw_destroy(w);
+		}
+		fflush(stdout);
+	}
+	rb3gpu_destroy(h);
+	return ret == 0 ? 0 : 1;
+}
+
 /* plain2fmd, main.c:299-331: every byte of the input is one BWT symbol ('\n' and '$' are 0) */
 int main_plain2fmd(int argc, char *argv[])
 {
@@ -501,6 +589,7 @@ static int usage(FILE *fp)
 	fprintf(fp, "Usage: ropebwt3-amd <command> <arguments>\n");
 	fprintf(fp, "Commands:\n");
 	fprintf(fp, "    build      construct a BWT (merge path on an MI355X)\n");
+	fprintf(fp, "    merge      merge BWTs (on an MI355X)\n");
 	fprintf(fp, "    plain2fmd  convert BWT in plain text to FMD (host only)\n");
 	fprintf(fp, "    recode     convert an FMD/FMR file to plain text, FMD (-d) or FMR (-b) (host only)\n");
 	fprintf(fp, "    version    print the version number\n");
@@ -513,6 +602,7 @@ int main(int argc, char *argv[])
 	rb3h_init();
 	if (argc == 1) return usage(stdout);
 	else if (strcmp(argv[1], "build") == 0) ret = main_build(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "merge") == 0) ret = main_merge(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "plain2fmd") == 0) ret = main_plain2fmd(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "recode") == 0) ret = main_recode(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "version") == 0) { printf("%s\n", RB3H_VERSION); return 0; }

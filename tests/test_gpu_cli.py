@@ -84,3 +84,27 @@ def test_fmr_output_and_checkpoint(tmp_path):
 def test_unsupported_options_fail_cleanly():
     r = subprocess.run([CLI, "build", "-2", "-L", os.path.join(util.GOLDEN, "k2_fwd.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"ropebwt2" in r.stderr
+
+
+def test_merge_subcommand(tmp_path):
+    """`merge base other...` (main.c:84-133): indexes of adjacent input slices merged in order give the
+    index of the whole input; checked against the golden .fmd of the 12-genome set"""
+    ent = MAN["genomes12_files"]
+    parts = []
+    for i, p in enumerate(ent["inputs"]):
+        out, _ = run(["build", "-d", os.path.join(util.GOLDEN, p)])
+        f = tmp_path / ("part%d.fmd" % i)
+        f.write_bytes(out)
+        parts.append(str(f))
+    out, _ = run(["merge", "-d"] + parts)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+    fmr, _ = run(["merge"] + parts)   # default output is FMR like the reference
+    p = tmp_path / "m.fmr"
+    p.write_bytes(fmr)
+    got = subprocess.run([CLI, "recode", "-d", str(p)], stdout=subprocess.PIPE, check=True).stdout
+    assert hashlib.md5(got).hexdigest() == ent["fmd_md5"]
+    if os.path.exists(util.REF_BIN):  # the reference's own merge of the same three files
+        ref = subprocess.run([util.REF_BIN, "merge"] + parts, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        q = tmp_path / "r.fmr"
+        q.write_bytes(ref)
+        assert subprocess.run([CLI, "recode", "-d", str(q)], stdout=subprocess.PIPE, check=True).stdout == got

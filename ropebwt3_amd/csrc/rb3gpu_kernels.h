@@ -616,7 +616,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 					const int id2 = (int)(seen >> 40) & (RB3_TENT_IDS - 1);
 					if (j == 0) {
 						if (gap == 0) dres[id2] = 1 + (int)(myval - (seen & RB3_TENT_MASK));
-						else if (gap == 1) dlink[id2] = (int)myid + 1; // same unique suffix (equal lo), hence the same bit
+						else if (gap == 1) { // both track the same unique suffix: equal lo, hence the same bit
+							if ((seen & RB3_TENT_MASK) == myval) dlink[id2] = (int)myid + 1;
+							else dres[id2] = 99; // cannot happen; an invalid code makes the host redo the rank phase
+						}
 					}
 				}
 			}

@@ -48,7 +48,7 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	fprintf(fp, "  Algorithm:\n");
 	fprintf(fp, "    -m NUM      batch size [7G]\n");
 	fprintf(fp, "    -t INT      total number of threads [%d]\n", opt->n_threads);
-	fprintf(fp, "    -p INT      #threads for sais and run sais and merge together (more RAM) [%d]\n", opt->sais_threads);
+	fprintf(fp, "    -p INT      suffix-sort INT batches at once on host threads, ahead of the GPU merge (more RAM) [%d]\n", opt->sais_threads);
 	fprintf(fp, "    -l INT      leaf block size in B+-tree (FMR output only) [%d]\n", opt->block_len);
 	fprintf(fp, "    -n INT      max number children per internal node (FMR output only) [%d]\n", opt->max_nodes);
 	fprintf(fp, "    --gpu INT   HIP device ordinal [%d]\n", opt->device);
@@ -141,23 +141,27 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	return 0;
 }
 
-/* 2-stage pipeline (build.c:55-83, 186-201): a producer thread reads and suffix-sorts batch
- * i+1 while the calling thread merges batch i on the GPU. */
+/* Pipeline (build.c:55-83, 186-201, generalised).  The reference overlaps the suffix sorting of batch
+ * i+1 with the merge of batch i.  Here the merge takes milliseconds and the suffix sorter is the slow
+ * stage, so `-p N` runs N sorter threads: one reader thread cuts the batches in input order, the
+ * sorters work on N batches at once, and the calling thread feeds the GPU strictly in input order. */
+typedef struct {
+	rb3h_buf_t seq;      /* raw text of the batch */
+	int64_t n_seq;
+	batch_t *out;        /* sorted batch */
+	int state;           /* 0 free, 1 raw, 2 being sorted, 3 ready (or an end-of-file marker), */
+	int end_of_file, err;
+} job_t;
+
 typedef struct {
 	pthread_mutex_t mtx;
 	pthread_cond_t cv;
-	batch_t *slot;       /* one batch in flight */
-	int done;
-} pipe_t;
-
-typedef struct {
+	job_t *ring;
+	int cap;
+	int64_t head, tail, next_sort; /* next to consume / to fill / to sort */
+	int reader_done;
 	const bopt_t *opt;
-	int n_files;
-	char **files;
-	pipe_t *q;
-	int64_t n_empty;
-	int err;
-} producer_t;
+} pool_t;
 
 static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_threads, batch_t **out)
 {
@@ -179,12 +183,14 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s, b->n_walkers = n_walkers, b->walkers = walkers;
 	seq->s = 0, seq->l = seq->m = 0; /* ownership moves to the batch */
 	*out = b;
-	(void)opt;
 	return 0;
 }
 
-/* read every input file, cutting batches as io.c:104-125 does; emit(b) is called per batch */
-static int for_each_batch(const bopt_t *opt, int n_files, char **files, int n_threads, int (*emit)(void*, batch_t*, const char*, int), void *data, int64_t *n_empty)
+/* what to do with a freshly cut batch (raw text in *seq, ownership passes) or an end-of-file event */
+typedef int (*submit_f)(void *data, rb3h_buf_t *seq, int64_t n_seq, int end_of_file);
+
+/* read every input file, cutting batches as io.c:104-125 does */
+static int for_each_batch(const bopt_t *opt, int n_files, char **files, submit_f submit, void *data, int64_t *n_empty)
 {
 	rb3h_buf_t seq = {0, 0, 0};
 	int64_t n_seq_acc = 0;
@@ -208,20 +214,14 @@ static int for_each_batch(const bopt_t *opt, int n_files, char **files, int n_th
 			if (rb3h_verbose >= 3)
 				fprintf(stderr, "[M::%s::%.3f*%.2f] read %ld symbols from file '%s'\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)(seq.l - l0), files[i]);
 			if (opt->rebatch && !(opt->batch_size > 0 && seq.l > opt->batch_size)) break; /* keep filling from the next file */
-			{
-				batch_t *b;
-				if (sort_batch(opt, &seq, n_seq_acc, n_threads, &b) < 0) { ret = -1; break; }
-				n_seq_acc = 0;
-				if ((ret = emit(data, b, files[i], 0)) != 0) break;
-			}
+			if ((ret = submit(data, &seq, n_seq_acc, 0)) != 0) break;
+			n_seq_acc = 0;
 		}
 		rb3h_seq_close(fp);
-		if (ret == 0 && !(opt->rebatch && seq.l > 0)) ret = emit(data, 0, files[i], 1); /* end of file i */
+		if (ret == 0 && !(opt->rebatch && seq.l > 0)) ret = submit(data, 0, 0, 1); /* end of file i */
 	}
 	if (ret == 0 && seq.l > 0) { /* the last, partly filled re-batched batch */
-		batch_t *b;
-		if (sort_batch(opt, &seq, n_seq_acc, n_threads, &b) < 0) ret = -1;
-		else if ((ret = emit(data, b, files[n_files - 1], 0)) == 0) ret = emit(data, 0, files[n_files - 1], 1);
+		if ((ret = submit(data, &seq, n_seq_acc, 0)) == 0) ret = submit(data, 0, 0, 1);
 	}
 	free(seq.s);
 	return ret;
@@ -234,9 +234,8 @@ typedef struct {
 	const char *fn_tmp;
 } consumer_t;
 
-static int consume(void *data, batch_t *b, const char *fn, int end_of_file)
+static int consume(consumer_t *c, batch_t *b, int end_of_file)
 {
-	consumer_t *c = (consumer_t*)data;
 	if (b) {
 		int r = process_batch(c->h, b, &c->has_index);
 		free(b->bwt); free(b->walkers); free(b);
@@ -250,33 +249,72 @@ static int consume(void *data, batch_t *b, const char *fn, int end_of_file)
 			if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] saved the current index to '%s'\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), c->fn_tmp);
 		}
 	}
-	(void)fn;
 	return 0;
 }
 
-static int produce(void *data, batch_t *b, const char *fn, int end_of_file)
+/* serial mode: sort and merge on the calling thread */
+static int submit_serial(void *data, rb3h_buf_t *seq, int64_t n_seq, int end_of_file)
 {
-	producer_t *p = (producer_t*)data;
-	(void)fn;
-	if (b == 0) return 0; /* -S is not combined with -p (as in the reference, build.c:186) */
-	pthread_mutex_lock(&p->q->mtx);
-	while (p->q->slot != 0) pthread_cond_wait(&p->q->cv, &p->q->mtx);
-	p->q->slot = b;
-	pthread_cond_broadcast(&p->q->cv);
-	pthread_mutex_unlock(&p->q->mtx);
+	consumer_t *c = (consumer_t*)data;
+	batch_t *b = 0;
+	if (seq && sort_batch(c->opt, seq, n_seq, c->opt->n_threads, &b) < 0) return -1;
+	return consume(c, b, end_of_file);
+}
+
+/* pipelined mode: the reader thread queues raw batches */
+static int submit_pool(void *data, rb3h_buf_t *seq, int64_t n_seq, int end_of_file)
+{
+	pool_t *q = (pool_t*)data;
+	job_t *j;
+	pthread_mutex_lock(&q->mtx);
+	while (q->tail - q->head >= q->cap) pthread_cond_wait(&q->cv, &q->mtx);
+	j = &q->ring[q->tail % q->cap];
+	memset(j, 0, sizeof(*j));
+	if (seq) j->seq = *seq, j->n_seq = n_seq, j->state = 1, seq->s = 0, seq->l = seq->m = 0;
+	else j->state = 3, j->end_of_file = 1;
 	(void)end_of_file;
+	++q->tail;
+	pthread_cond_broadcast(&q->cv);
+	pthread_mutex_unlock(&q->mtx);
 	return 0;
 }
 
-static void *producer_main(void *arg)
+typedef struct { pool_t *q; int n_files; char **files; int64_t n_empty; int err; } reader_t;
+
+static void *reader_main(void *arg)
 {
-	producer_t *p = (producer_t*)arg;
-	p->err = for_each_batch(p->opt, p->n_files, p->files, p->opt->sais_threads, produce, p, &p->n_empty);
-	pthread_mutex_lock(&p->q->mtx);
-	p->q->done = 1;
-	pthread_cond_broadcast(&p->q->cv);
-	pthread_mutex_unlock(&p->q->mtx);
+	reader_t *r = (reader_t*)arg;
+	r->err = for_each_batch(r->q->opt, r->n_files, r->files, submit_pool, r->q, &r->n_empty);
+	pthread_mutex_lock(&r->q->mtx);
+	r->q->reader_done = 1;
+	pthread_cond_broadcast(&r->q->cv);
+	pthread_mutex_unlock(&r->q->mtx);
 	return 0;
+}
+
+static void *sorter_main(void *arg)
+{
+	pool_t *q = (pool_t*)arg;
+	for (;;) {
+		job_t *j = 0;
+		pthread_mutex_lock(&q->mtx);
+		for (;;) {
+			while (q->next_sort < q->tail && q->ring[q->next_sort % q->cap].state != 1) ++q->next_sort; /* markers */
+			if (q->next_sort < q->tail) { j = &q->ring[q->next_sort % q->cap]; j->state = 2; ++q->next_sort; break; }
+			if (q->reader_done) break;
+			pthread_cond_wait(&q->cv, &q->mtx);
+		}
+		pthread_mutex_unlock(&q->mtx);
+		if (j == 0) return 0;
+		{
+			batch_t *b = 0;
+			int err = sort_batch(q->opt, &j->seq, j->n_seq, 1, &b);
+			pthread_mutex_lock(&q->mtx);
+			j->out = b, j->err = err, j->state = 3;
+			pthread_cond_broadcast(&q->cv);
+			pthread_mutex_unlock(&q->mtx);
+		}
+	}
 }
 
 static const struct option long_opts[] = {
@@ -355,34 +393,44 @@ int main_build(int argc, char *argv[])
 		if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] loaded the index from file '%s'\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), fn_in);
 	}
 
-	if (opt.sais_threads > 0 && argc - optind >= 1) { /* suffix sorting overlapped with the GPU merge */
-		pipe_t q;
-		producer_t p;
-		pthread_t tid;
-		consumer_t cs = { h, &opt, has_index, 0 };
+	if (opt.sais_threads > 0 && argc - optind >= 1) { /* N suffix sorters ahead of the GPU merge */
+		pool_t q;
+		reader_t rd;
+		pthread_t rt, *st;
+		consumer_t cs = { h, &opt, has_index, fn_tmp };
+		int k, n_sort = opt.sais_threads;
+		memset(&q, 0, sizeof(q));
 		pthread_mutex_init(&q.mtx, 0);
 		pthread_cond_init(&q.cv, 0);
-		q.slot = 0, q.done = 0;
-		memset(&p, 0, sizeof(p));
-		p.opt = &opt, p.n_files = argc - optind, p.files = argv + optind, p.q = &q;
-		pthread_create(&tid, 0, producer_main, &p);
+		q.cap = n_sort + 2, q.ring = (job_t*)calloc((size_t)q.cap, sizeof(job_t)), q.opt = &opt;
+		memset(&rd, 0, sizeof(rd));
+		rd.q = &q, rd.n_files = argc - optind, rd.files = argv + optind;
+		st = (pthread_t*)calloc((size_t)n_sort, sizeof(pthread_t));
+		pthread_create(&rt, 0, reader_main, &rd);
+		for (k = 0; k < n_sort; ++k) pthread_create(&st[k], 0, sorter_main, &q);
 		for (;;) {
-			batch_t *b;
+			job_t j;
 			pthread_mutex_lock(&q.mtx);
-			while (q.slot == 0 && !q.done) pthread_cond_wait(&q.cv, &q.mtx);
-			b = q.slot, q.slot = 0;
+			while (!(q.head < q.tail && q.ring[q.head % q.cap].state == 3) && !(q.reader_done && q.head == q.tail))
+				pthread_cond_wait(&q.cv, &q.mtx);
+			if (q.head == q.tail) { pthread_mutex_unlock(&q.mtx); break; }
+			j = q.ring[q.head % q.cap];
+			q.ring[q.head % q.cap].state = 0;
+			++q.head;
 			pthread_cond_broadcast(&q.cv);
 			pthread_mutex_unlock(&q.mtx);
-			if (b == 0) break;
-			if (ret == 0) ret = consume(&cs, b, 0, 0);
-			else { free(b->bwt); free(b->walkers); free(b); }
+			if (j.err != 0) ret = -1;
+			if (ret == 0) ret = consume(&cs, j.out, j.end_of_file);
+			else if (j.out) { free(j.out->bwt); free(j.out->walkers); free(j.out); }
 		}
-		pthread_join(tid, 0);
-		if (p.err != 0) ret = -1;
-		n_empty = p.n_empty, has_index = cs.has_index;
+		pthread_join(rt, 0);
+		for (k = 0; k < n_sort; ++k) pthread_join(st[k], 0);
+		free(st); free(q.ring);
+		if (rd.err != 0) ret = -1;
+		n_empty = rd.n_empty, has_index = cs.has_index;
 	} else if (argc - optind >= 1) {
 		consumer_t cs = { h, &opt, has_index, fn_tmp };
-		ret = for_each_batch(&opt, argc - optind, argv + optind, opt.n_threads, consume, &cs, &n_empty);
+		ret = for_each_batch(&opt, argc - optind, argv + optind, submit_serial, &cs, &n_empty);
 		has_index = cs.has_index;
 	}
 	if (n_empty > 0 && rb3h_verbose >= 2)

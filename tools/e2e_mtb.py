@@ -45,8 +45,9 @@ def run(name, cmd):
 amd = os.path.join(ROOT, "ropebwt3_amd", "ropebwt3-amd")
 ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
 a, ea = run("amd one-file-per-batch", [amd, "build", "-d"] + files)
-b, eb = run("amd --rebatch -m80m -p1", [amd, "build", "-d", "--rebatch", "-m80m", "-p1"] + files)
-print("amd variants identical:", a == b)
+b, eb = run("amd -p16 (16 sorter threads)", [amd, "build", "-d", "-p16"] + files)
+c2, _ = run("amd --rebatch -m40m -p4", [amd, "build", "-d", "--rebatch", "-m40m", "-p4"] + files)
+print("amd variants identical:", a == b and a == c2)
 if os.path.exists(ref):
     c, ec = run("reference -t%d" % (os.cpu_count() or 8), [ref, "build", "-d", "-t%d" % min(64, os.cpu_count() or 8)] + files)
     print("IDENTICAL to reference:", a == c)

@@ -648,6 +648,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)hm[MISC_LF_TOT + a];
 	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
+	if (tent && getenv("RB3GPU_TEST_FORCE_FALLBACK")) hm[4] = 1; // test hook: exercise the redo path
 	if (tent && hm[4] != 0) { // some tentative record was left unsettled: nothing was installed, redo without them
 		h->stt.n_fallbacks += 1;
 		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled; redoing the merge without tentative records\n", hm[4]);

@@ -240,3 +240,26 @@ def test_stress_walker_modes_vs_oracle(oracle, seed):
     h.merge_plain_walkers(b2, w)
     assert np.array_equal(h.export_plain(), oracle.merge(b1, b2))
     h.close()
+
+
+def test_fallback_path_redoes_the_rank_phase(oracle):
+    """the optimistic tentative-record pass is verified on the device; when it reports unsettled records
+    the merge is redone without them (forced here through the test hook) and must give the same index"""
+    import os
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(41)
+    g0 = util.random_genome(rng, 50000)
+    b1 = host.build_bwt(util.make_text([g0]))
+    b2, w = host.build_bwt_walkers(util.make_text([util.mutate(rng, g0, 0.002)]), 256)
+    want = oracle.merge(b1, b2)
+    os.environ["RB3GPU_TEST_FORCE_FALLBACK"] = "1"
+    try:
+        h = Rb3Gpu(verbose=1)
+        h.from_plain(b1)
+        h.merge_plain_walkers(b2, w)
+        st = h.stats()
+        assert st["n_fallbacks"] == 1
+        assert np.array_equal(h.export_plain(), want)
+        h.close()
+    finally:
+        os.environ.pop("RB3GPU_TEST_FORCE_FALLBACK", None)

@@ -49,6 +49,7 @@ struct rb3gpu_s {
 	int64_t bytes_owned = 0;
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
+	int64_t sid_dirty = RB3_TENT_IDS; // entries of the stretch tables (dl) that may be non-zero
 };
 
 static double now_s(void)
@@ -99,6 +100,32 @@ static float ev_ms(hipEvent_t a, hipEvent_t b)
 	float ms = 0;
 	if (hipEventElapsedTime(&ms, a, b) != hipSuccess) ms = 0;
 	return ms;
+}
+
+/* tables of the tentative stretches (k_chain): dependency words, settled unknowns, dependents */
+struct TentTab { uint64_t *sdep; int32_t *sdel, *schild; };
+
+static int tent_prepare(rb3gpu_t *h, TentTab &t)
+{
+	const size_t bytes = (size_t)RB3_TENT_IDS * 16;
+	const bool fresh = !(h->dl.p && h->dl.cap >= bytes);
+	int r;
+	if ((r = buf_ensure(h, h->dl, bytes)) < 0) return r;
+	t.sdep = (uint64_t*)h->dl.p, t.sdel = (int32_t*)(t.sdep + RB3_TENT_IDS), t.schild = t.sdel + RB3_TENT_IDS;
+	const int64_t dirty = fresh ? RB3_TENT_IDS : h->sid_dirty;
+	if (dirty >= RB3_TENT_IDS / 2) HIPCHK(hipMemsetAsync(h->dl.p, 0, bytes, h->st));
+	else if (dirty > 0) {
+		HIPCHK(hipMemsetAsync(t.sdep, 0, (size_t)dirty * 8, h->st));
+		HIPCHK(hipMemsetAsync(t.sdel, 0, (size_t)dirty * 4, h->st));
+		HIPCHK(hipMemsetAsync(t.schild, 0, (size_t)dirty * 4, h->st));
+	}
+	h->sid_dirty = RB3_TENT_IDS; // until the number of stretches this merge opens has been read back
+	return 0;
+}
+
+static void tent_used(rb3gpu_t *h, unsigned long long sidctr)
+{
+	h->sid_dirty = sidctr < (unsigned long long)RB3_TENT_IDS ? (int64_t)sidctr : RB3_TENT_IDS;
 }
 
 static IdxView view_of(const rb3gpu_t *h)
@@ -232,6 +259,7 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
 
 /* layout of the 64 x u64 words of h->misc (zeroed per merge up to MISC_KEEP):
  *   [0] walker queue head  [1] LF steps  [2] rows unset  [3] rows out of order  [4] tentative unsettled
+ *   [5] tentative stretches opened (u32)
  *   [16..23] totals of the batch scan (symbol counts of B2, [22] = bad bytes)
  *   [24..31] totals of the rebuild scan (symbol counts of the merged BWT, [30] = slots) */
 #define MISC_WORDS   64
@@ -425,17 +453,14 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 			if (first < len) nwalk += (len - first + M - 1) >> logM;
 		}
 	}
-	// tentative records need ids < 2^22 and merged positions < 2^40
-	const int64_t nids = walkers ? n_walkers : nwalk - m2;
+	// tentative records need merged positions < 2^40
 	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
-	if (nids <= 0 || nids > RB3_TENT_IDS || h->n + len >= (1LL << 40) || stop_row >= 0) tent = 0;
-	int32_t *dres = nullptr, *dlink = nullptr;
-	if (tent) {
-		if ((r = buf_ensure(h, h->dl, (size_t)nids * 8)) < 0) return r;
-		dres = (int32_t*)h->dl.p, dlink = dres + nids;
-		HIPCHK(hipMemsetAsync(dres, 0, (size_t)nids * 8, h->st));
-	}
+	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= (1LL << 40) || stop_row >= 0) tent = 0;
+	TentTab tt = {nullptr, nullptr, nullptr};
+	uint32_t *sidctr = (uint32_t*)(qhead + 5);
+	if (tent && (r = tent_prepare(h, tt)) < 0) return r;
 	HIPCHK(hipMemsetAsync(qhead, 0, 8, h->st));
+	HIPCHK(hipMemsetAsync(sidctr, 0, 8, h->st));
 	// octets per wave: all 8 when there are enough walkers to fill the chip (256 CUs x 32 waves), fewer
 	// when the launch is latency-bound anyway
 	int octs = 8; // measured: fewer octets per wave (more waves) is slower even for few walkers
@@ -449,7 +474,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 		const int64_t sr = stop_row < 0 ? -1 : stop_row;
 		const dim3 grid((unsigned)nblk), blk(256);
 #define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
-			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, dres, dlink)
+			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tt.sdel, tt.sdep, tt.schild, sidctr)
 		const int sel = (walkers ? 4 : 0) | (iv.dense ? 2 : 0) | (tent ? 1 : 0);
 		switch (sel) {
 		case 0: RB3_LAUNCH_CHAIN(false, false, false); break;
@@ -464,13 +489,22 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 #undef RB3_LAUNCH_CHAIN
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
-			hipLaunchKernelGGL(k_resolve, dim3((unsigned)((nids + 255) / 256)), dim3(256), 0, h->st, dres, (const int32_t*)dlink, nids, qhead + 2);
-			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, h->mg_pos, len, (const int32_t*)dres, qhead + 2);
+			hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, h->st, tt.sdel, (const uint64_t*)tt.sdep, (const int32_t*)tt.schild, (const uint32_t*)sidctr);
+			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, h->mg_pos, len, (const int32_t*)tt.sdel, qhead + 2);
 		}
 	}
 	HIPCHK(hipEventRecord(h->ev[5], h->st));
 	if (walkers && arrive) HIPCHK(hipMemcpyAsync(arrive, darr, 8, hipMemcpyDeviceToHost, h->st));
+	unsigned long long nsid = 0;
+	if (tent) HIPCHK(hipMemcpyAsync(&nsid, sidctr, 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
+	if (tent) {
+		tent_used(h, nsid);
+		if (nsid >= (unsigned long long)RB3_TENT_IDS - 1) { // the stretch table overflowed: count it as unsettled (the caller redoes the phase)
+			const unsigned long long one = 1;
+			HIPCHK(hipMemcpy(qhead + 4, &one, 8, hipMemcpyHostToDevice));
+		}
+	}
 	h->stt.ms_chain += ev_ms(h->ev[6], h->ev[7]), h->stt.ms_rank += ev_ms(h->ev[6], h->ev[5]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	return 0;
@@ -567,7 +601,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int tent = 1;
 	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
 	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
-	if (!walkers || n_walkers > RB3_TENT_IDS || ntot >= (1LL << 40) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED"))
+	if (!walkers || n_walkers > (1 << 22) || ntot >= (1LL << 40) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED"))
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
 	int r;
 	for (int64_t i = 0; i < n_walkers; ++i)
@@ -576,18 +610,18 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const int64_t ngrp_new = (ntot >> RB3_GRP_BITS) + 1;
 	if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
 	if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
-	if ((r = buf_ensure(h, h->dl, (size_t)n_walkers * 8)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	TentTab tt = {nullptr, nullptr, nullptr};
+	if (tent && (r = tent_prepare(h, tt)) < 0) return r;
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, nwin)) < 0) return r;
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	Walker *dwl = (Walker*)h->wl.p;
-	int32_t *dres = (int32_t*)h->dl.p, *dlink = dres + n_walkers;
+	uint32_t *sidctr = (uint32_t*)(misc + 5);
 	h->mg_active = 0;
 	HIPCHK(hipEventRecord(h->ev[0], h->st));
 	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
-	HIPCHK(hipMemsetAsync(dres, 0, (size_t)n_walkers * 8, h->st));
 	{ // walker list: through the pinned staging buffer when it fits (a pageable source is staged by the runtime, slowly)
 		const size_t wb = (size_t)n_walkers * 32;
 		if (h->stage[0] == nullptr)
@@ -612,7 +646,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		const dim3 grid((unsigned)nblk), blk(256);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, dres, dlink)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tt.sdel, tt.sdep, tt.schild, sidctr)
 		if (iv.dense && tent) RB3_LAUNCH_FAST(true, true);
 		else if (iv.dense) RB3_LAUNCH_FAST(true, false);
 		else if (tent) RB3_LAUNCH_FAST(false, true);
@@ -620,8 +654,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #undef RB3_LAUNCH_FAST
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
-			hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n_walkers + 255) / 256)), dim3(256), 0, h->st, dres, (const int32_t*)dlink, n_walkers, misc + 2);
-			hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)dres, misc + 2);
+			hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, h->st, tt.sdel, (const uint64_t*)tt.sdep, (const int32_t*)tt.schild, (const uint32_t*)sidctr);
+			hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)tt.sdel, misc + 2);
 		} else
 			hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, len, ntot, misc + 2);
 	}
@@ -648,7 +682,11 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)hm[MISC_LF_TOT + a];
 	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
-	if (tent && getenv("RB3GPU_TEST_FORCE_FALLBACK")) hm[4] = 1; // test hook: exercise the redo path
+	if (tent) {
+		tent_used(h, hm[5]);
+		if (hm[5] >= (unsigned long long)RB3_TENT_IDS - 1) hm[4] |= 1; // the stretch table overflowed
+		if (getenv("RB3GPU_TEST_FORCE_FALLBACK")) hm[4] = 1; // test hook: exercise the redo path
+	}
 	if (tent && hm[4] != 0) { // some tentative record was left unsettled: nothing was installed, redo without them
 		h->stt.n_fallbacks += 1;
 		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled; redoing the merge without tentative records\n", hm[4]);

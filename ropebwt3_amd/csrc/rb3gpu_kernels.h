@@ -485,37 +485,50 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 	return (int64_t)(r.gc + (sum & (RB3_MATCH_BIT - 1u)));
 }
 
-/* Tentative records (TENT = true).  An inexact walker whose interval has shrunk to [lo, lo+1)
- * -- exactly one suffix of B1's text starts with what it has read -- knows ka up to one bit
- * d = ka - lo, and that bit does not change while the interval keeps size 1 (the unique suffix and
- * the new one extend by the same symbol, so their order is preserved).  Such a walker records
- * RB3_TENT | id << 40 | (lo + kb) and moves on with ONE rank per step (hi' = lo' + [B1[lo] == c]).
- * Whoever later walks into those rows knowing more settles the bit instead of redoing the rows:
- *   an exact walker      -> dres[id] = 1 + d                       and stops;
- *   a tentative walker   -> dlink[id] = its own id (same unique suffix, same bit) and stops;
- * a tentative walker that meets a final value learns its own bit the same way.  k_resolve then
- * follows the links and k_pos_finalize rewrites the tentative records.  The critical path of a merge
- * drops from the longest variant-free stretch of the batch to about one segment.
+/* Tentative records (TENT = true).  An inexact walker whose interval [lo, hi) has shrunk to a few
+ * rows -- k = hi - lo suffixes of B1's text start with what it has read -- knows ka up to a small
+ * number: ka = lo + d, where d counts how many of those k suffixes are smaller than the new one.
+ * The k suffixes and the new one are extended by the same symbols as the walk goes on, so their
+ * relative order never changes: d stays put while all k survive, and when the suffix with index e
+ * (in row order) drops out because B1 has another symbol there, d becomes d - [e < d].  Such a
+ * walker therefore records RB3_TENT | sid << 40 | (lo + kb), where sid names a STRETCH of rows that
+ * share one unknown d, opens a new stretch at every drop (sdep[new] = EVENT, old sid, e), and goes
+ * on.  k = 1 is the common case for a genome merged into an index holding one close relative and has
+ * a fast path with ONE rank per step (hi' = lo' + [B1[lo] == c]); k > 1 (several close relatives
+ * indexed) costs the two ranks a wide walker pays anyway.  Whoever later walks into those rows
+ * knowing more settles d instead of redoing the rows:
+ *   an exact walker      -> sdel[sid] = 1 + (its value - the recorded lo + kb)           and stops;
+ *   a tentative walker   -> sdep[sid] = LINK, its own sid, offset (both intervals contain ka, so the
+ *                           two unknowns differ by the difference of the two lo)          and stops;
+ * a tentative walker that meets a final value learns its own d the same way.  k_resolve follows the
+ * event/link chains, k_pos_finalize_check rewrites the tentative records.  The critical path of a
+ * merge drops from the longest variant-free stretch of the batch to about one segment.
  *
  * Concurrency.  Records become visible late (lane-parked, written through), so a follower only a
- * few rows behind a tentative walker would read "unset", record its own value and never notice
+ * few rows behind a tentative walker would read "unvisited", record its own value and never notice
  * the tags.  Three measures: (1) a walker records tentatively only once it is RB3_TENT_MIN_AGE
  * steps old, so whoever follows it into its segment is that many rows behind -- provided the
  * follower's own segment was at least that long, which the host guarantees for the walker lists it
  * generates (LIST) but not for the automatic split (segments are geometric there); (2) without that
  * guarantee every record is an unsigned 64-bit atomic MIN, and the encoding orders
- * final < tentative < unset, so the better-informed value survives whatever the arrival order
+ * final < tentative < unvisited, so the better-informed value survives whatever the arrival order
  * (atomics sustain ~25 G/s on this chip against ~70 G/s for plain stores, hence only there);
- * (3) the host counts
- * unsettled tentative records after the launch and, if there are any, redoes the rank phase without
- * tentative records (rb3gpu.hip).  Correctness therefore never depends on timing.
+ * (3) the host counts unsettled tentative records after the launch and, if there are any, redoes
+ * the rank phase without tentative records (rb3gpu.hip).  Correctness therefore never depends on
+ * timing.
  */
 #define RB3_TENT      (1LL << 62)
 #define RB3_TENT_MASK ((1LL << 40) - 1)
-#define RB3_TENT_IDS  (1 << 22)
+#define RB3_TENT_IDS  (1 << 22)       /* stretch ids per merge */
+#define RB3_TENT_KMAX 255             /* widest interval that is tracked tentatively */
 #ifndef RB3_TENT_MIN_AGE
 #define RB3_TENT_MIN_AGE 64u
 #endif
+/* sdep[sid]: how the unknown of a stretch follows from another one */
+#define RB3_DEP_EVENT 1ull            /* d = d(prev) - [arg < d(prev)] */
+#define RB3_DEP_LINK  2ull            /* d = d(prev) + (int32)arg */
+#define RB3_TENT_DERIVED 0x10000     /* sdel[]: value derived by k_resolve, not settled by a walker */
+#define RB3_DEP_MAKE(type, prev, arg) ((uint64_t)(type) << 62 | (uint64_t)(uint32_t)(prev) << 32 | (uint64_t)(uint32_t)(arg))
 
 template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t v, bool vis)
 {
@@ -524,10 +537,12 @@ template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t 
 	else *p = v;                 // one walker per string, nobody ever looks: let the L2 keep the line it just read
 }
 
+__device__ __forceinline__ uint32_t idx_sym(const IdxView &ix, int64_t i);
+
 template<bool LIST, bool DENSE, bool TENT>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		int32_t *dres, int32_t *dlink)
+		int32_t *sdel, uint64_t *sdep, int32_t *schild, uint32_t *sidctr)
 {
 	const int lane = threadIdx.x & 63, j = lane & 7;
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
@@ -538,7 +553,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	const bool vis = LIST || M != 0; // records must become visible to other walkers only if strings are split
 	bool active = false;
 	int gap = 0;            // 0: exact (lo == hi), 1: hi == lo + 1, 2: wider
-	int64_t kb = 0, lo = 0, hi = 0, remaining = 0, myid = 0;
+	int sid = -1;           // stretch id of the tentative records being written, -1: none yet
+	int64_t kb = 0, lo = 0, hi = 0, remaining = 0;
 	uint64_t x = 0;         // row word of the current row (requested one step ahead)
 	uint32_t steps = 0;
 	// Records are written through to memory (agent scope) so that walkers on other XCDs can see them.
@@ -569,15 +585,13 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				if (w.ka0 >= 0) lo = hi = w.ka0;
 				else if (w.ka0 == -2) lo = hi = b1.m; // RB3GPU_KA_SENTINEL: a sentinel row, ka = acc[1] of the index (fm-index.c:164)
 				else lo = 0, hi = b1.n;
-				myid = wid;
 			} else {
 				remaining = INT64_MAX;
 				if (wid < m2) kb = wid, lo = hi = b1.m;
 				else kb = first_marked + ((wid - m2) << logM), lo = 0, hi = b1.n;
-				myid = wid - m2;
 			}
 			gap = hi - lo > 1 ? 2 : (int)(hi - lo);
-			age = 0;
+			age = 0, sid = -1;
 			x = (uint64_t)ld_pos(&row[kb]);
 			if (gap && (int64_t)x >= 0) continue; // an inexact walker whose start row somebody has already recorded
 			active = true;
@@ -586,7 +600,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 		// chains meet in a step: kb -> row[kb] -> next row, and ka -> directory entry -> slot -> next ka.
 		// The next row's word is requested one step ahead, so the symbol c is known before anything is
 		// issued and only the ka chain is on the critical path.  The body is branch-free (selects) except
-		// for the second bound of wide walkers and the rare settle events: a lone wave runs at
+		// for the second bound of wide walkers and the rare stretch events: a lone wave runs at
 		// instruction-issue speed, so instruction count is the cost.
 		do {
 			if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
@@ -594,7 +608,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			const int c = (int)(x & 7u);
 			const int64_t kbn = met ? kb : RB3_ROW_NEXT(x);
 			const bool wide = TENT ? gap == 2 : gap != 0;
-			const bool tentok = TENT && gap == 1 && age >= RB3_TENT_MIN_AGE; // may record tentatively
+			// may this walker record tentatively?  (an interval of at most KMAX rows, and old enough)
+			const bool tentok = TENT && gap != 0 && age >= RB3_TENT_MIN_AGE && hi - lo <= RB3_TENT_KMAX;
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
 			if (wide) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
@@ -608,36 +623,61 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			++steps;
 			const bool fin = met || c == 0;
 			const int64_t myval = lo + kb;
-			if (TENT && met) { // settle one bit (rare)
+			if (TENT && tentok && !met && sid < 0) { // first tentative record of this walker: open a stretch (rare)
+				uint32_t s0 = 0;
+				if (j == 0) s0 = atomicAdd(sidctr, 1u);
+				sid = (int)oct_bcast0(s0, j);
+				if (sid >= RB3_TENT_IDS) sid = RB3_TENT_IDS - 1; // table full: that stretch is never settled -> the host redoes the phase
+			}
+			if (TENT && met) { // settle an unknown (rare)
 				const int64_t seen = (int64_t)x;
-				if (!(seen & RB3_TENT)) { // a final value: my own bit, if I am tentative
-					if (gap == 1 && j == 0) dres[myid] = 1 + (int)(seen - myval);
+				if (!(seen & RB3_TENT)) { // a final value: the unknown of my current stretch
+					if (gap != 0 && sid >= 0 && j == 0) sdel[sid] = 1 + (int)(seen - myval);
 				} else {
 					const int id2 = (int)(seen >> 40) & (RB3_TENT_IDS - 1);
+					const int64_t diff = myval - (seen & RB3_TENT_MASK); // both intervals contain ka
 					if (j == 0) {
-						if (gap == 0) dres[id2] = 1 + (int)(myval - (seen & RB3_TENT_MASK));
-						else if (gap == 1) { // both track the same unique suffix: equal lo, hence the same bit
-							if ((seen & RB3_TENT_MASK) == myval) dlink[id2] = (int)myid + 1;
-							else dres[id2] = 99; // cannot happen; an invalid code makes the host redo the rank phase
-						}
+						if (gap == 0) sdel[id2] = 1 + (int)diff;
+						else if (sid >= 0 && id2 != sid) sdep[id2] = RB3_DEP_MAKE(RB3_DEP_LINK, sid, (int32_t)diff), schild[sid] = id2 + 1;
 					}
 				}
 			}
-			if ((gap == 0 || tentok) && !met && j == (int)(it & 7u))
-				bkb = kb, bval = gap ? (RB3_TENT | (myid << 40) | myval) : myval;
+			if ((gap == 0 || (tentok && sid >= 0)) && !met && j == (int)(it & 7u))
+				bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << 40) | myval) : myval;
 			// next insertion point(s)
 			uint32_t match, mh;
 			const int64_t lo_n = octc_finish<DENSE>(rl, c, j, &match);
 			int64_t hi_n = lo_n;
 			if (TENT && gap == 1) hi_n = lo_n + match;
 			if (wide) hi_n = octc_finish<DENSE>(rh, c, j, &mh);
-			const int gap_n = hi_n - lo_n > 1 ? 2 : (int)(hi_n - lo_n);
+			const int64_t kn = hi_n - lo_n;
+			const int gap_n = kn > 1 ? 2 : (int)kn;
+			if (TENT && wide && sid >= 0 && !fin && kn >= 1 && kn < hi - lo) {
+				// some of the matching suffixes are not preceded by c: one new stretch per dropped suffix,
+				// highest index first (rare: once per variant among the indexed relatives)
+				const int kk = (int)(hi - lo);
+				for (int itb = (kk - 1) >> 3; itb >= 0; --itb) {
+					const int i = itb * 8 + j;
+					const bool drop = i < kk && idx_sym(b1, lo + i) != (uint32_t)c;
+					uint32_t m8 = (uint32_t)(__ballot(drop) >> (lane & ~7)) & 0xFFu;
+					while (m8) {
+						const int bpos = 31 - __clz((int)m8);
+						m8 &= ~(1u << bpos);
+						uint32_t s0 = 0;
+						if (j == 0) s0 = atomicAdd(sidctr, 1u);
+						int ns = (int)oct_bcast0(s0, j);
+						if (ns >= RB3_TENT_IDS) ns = RB3_TENT_IDS - 1;
+						else if (j == 0) sdep[ns] = RB3_DEP_MAKE(RB3_DEP_EVENT, sid, itb * 8 + bpos), schild[sid] = ns + 1;
+						sid = ns;
+					}
+				}
+			}
 			++age;
-			// at the end of its own segment a walker goes on only if it is exact or already recording tentatively
-			const bool stop_wide = !(gap_n == 0 || (TENT && gap_n == 1 && age >= RB3_TENT_MIN_AGE));
+			// at the end of its own segment a walker goes on only if it is exact or has tentative records out
+			const bool goes_on = gap_n == 0 || (TENT && sid >= 0);
 			const bool at_stop = LIST && kbn == stop_row; // the rest of this string is recorded on another GPU
 			if (at_stop && gap_n == 0 && !fin && j == 0) st_pos(arrive, lo_n);
-			active = !(fin || at_stop || (end_next && stop_wide));
+			active = !(fin || at_stop || (end_next && !goes_on));
 			remaining = end_next ? INT64_MAX : remaining - 1;
 			kb = kbn, x = xn, lo = lo_n, hi = hi_n, gap = gap_n;
 		} while (__all(active));
@@ -651,32 +691,42 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 #endif
 }
 
-/* settle the tentative bits: follow dlink until a stretch with a known bit; dres[i] becomes 1 + bit */
-__global__ void __launch_bounds__(256) k_resolve(int32_t *dres, const int32_t *dlink, int64_t n, unsigned long long *bad)
+/* settle the unknowns of all stretches.  A stretch has at most one dependent: the next stretch of
+ * the same walker (EVENT) or, for the walker's last one, the first stretch of the walker it ran
+ * into (LINK) -- the dependencies form simple paths.  One thread per stretch that a walker settled
+ * walks its path forwards until the next such stretch.  sdel[s] becomes (1 + d) | RB3_TENT_DERIVED. */
+__global__ void __launch_bounds__(256) k_resolve(int32_t *sdel, const uint64_t *sdep, const int32_t *schild, const uint32_t *sidctr)
 {
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	if (dres[i] != 0 || dlink[i] == 0) return; // known, or never recorded anything tentative
-	int64_t cur = i;
-	int r = 0;
-	for (int hop = 0; hop < 1 << 20; ++hop) {
-		r = __hip_atomic_load(&dres[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (r != 0 || dlink[cur] == 0) break;
-		cur = dlink[cur] - 1;
+	const int64_t n = *sidctr < (uint32_t)RB3_TENT_IDS ? *sidctr : RB3_TENT_IDS;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const int r = __hip_atomic_load(&sdel[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (r <= 0 || (r & RB3_TENT_DERIVED)) continue;
+		int d = r - 1, cur = (int)i;
+		for (;;) {
+			const int ch = schild[cur] - 1;
+			if (ch < 0 || ch >= n) break;
+			const uint64_t dep = sdep[ch];
+			if ((int)(dep >> 32 & (RB3_TENT_IDS - 1)) != cur) break; // another follower's link won
+			if (__hip_atomic_load(&sdel[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break; // settled by a walker: its own thread goes on
+			const int32_t arg = (int32_t)(uint32_t)dep;
+			if (dep >> 62 == RB3_DEP_EVENT) d -= (arg < d) ? 1 : 0;
+			else d += arg;
+			if (d < 0 || d > RB3_TENT_KMAX) break; // cannot be: leave it unsettled, the host redoes the phase
+			__hip_atomic_store(&sdel[ch], (d + 1) | RB3_TENT_DERIVED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			cur = ch;
+		}
 	}
-	if (r == 0) atomicAdd(&bad[2], 1ull); // a tentative stretch nobody settled
-	else __hip_atomic_store(&dres[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* after the chains: rewrite tentative records (pos = lo + bit + kb), then every row must be recorded
  * and pos must be strictly increasing (ka is non-decreasing in kb).
  * bad[0] += #unset, bad[1] += #order violations, bad[2] += #unsettled tentative records */
-__device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *dres, unsigned long long *bad)
+__device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *sdel, unsigned long long *bad)
 {
 	if (v < 0) return RB3_UNSET; // never visited (still an LF word)
 	if (!(v & RB3_TENT)) return v;
-	const int r = dres[(int)(v >> 40) & (RB3_TENT_IDS - 1)];
-	if (r != 1 && r != 2) { if (bad) atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
+	const int r = sdel[(int)(v >> 40) & (RB3_TENT_IDS - 1)] & (RB3_TENT_DERIVED - 1);
+	if (r < 1 || r > RB3_TENT_KMAX + 1) { if (bad) atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
 	return (v & RB3_TENT_MASK) + (r - 1);
 }
 

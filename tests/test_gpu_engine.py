@@ -242,6 +242,46 @@ def test_stress_walker_modes_vs_oracle(oracle, seed):
     h.close()
 
 
+@pytest.mark.parametrize("seed,nrel", [(51, 2), (52, 6), (53, 12)])
+def test_family_of_relatives_tentative_stretches(oracle, seed, nrel):
+    """a genome merged into an index that already holds several close relatives (some identical): the
+    new suffixes match k > 1 indexed suffixes for long stretches, and the walkers record tentatively
+    with one stretch id per drop-out.  Bit-exact against the oracle, and far fewer LF steps than
+    without tentative records (every walker stops about one segment after it started)."""
+    import os
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(seed)
+    g0 = util.random_genome(rng, 40000)
+    rel = [g0]
+    for i in range(nrel - 1):
+        src = rel[int(rng.integers(0, len(rel)))]          # a small phylogeny: mutate some earlier relative
+        rel.append(src.copy() if i % 4 == 3 else util.mutate(rng, src, float(rng.choice([0.0005, 0.002, 0.01]))))
+    new = [util.mutate(rng, rel[int(rng.integers(0, nrel))], 0.001), rel[-1].copy()]
+    b1 = host.build_bwt(util.make_text(rel))
+    t2 = util.make_text(new)
+    rb, _ = oracle.mg_rank(b1, host.build_bwt(t2), 8)
+    want = rb >> 6
+    steps = {}
+    for tent in ("1", "0"):
+        os.environ["RB3GPU_TENT"] = tent
+        try:
+            h = Rb3Gpu(verbose=1)
+            h.from_plain(b1)
+            for step in (128, 384):
+                b2, w = host.build_bwt_walkers(t2, step)
+                got, _ = h.mg_rank_plain_walkers(b2, w)
+                assert np.array_equal(got, want), (tent, step)
+            pos, _ = h.mg_rank_plain(host.build_bwt(t2))   # automatic split (atomic-min records)
+            assert np.array_equal(pos, want), (tent, "auto")
+            st = h.stats()
+            steps[tent] = st["n_lf_steps"] - 3 * want.size    # steps beyond one per row and pass
+            assert st["n_fallbacks"] == 0
+            h.close()
+        finally:
+            os.environ.pop("RB3GPU_TENT", None)
+    assert steps["1"] < 0.6 * steps["0"], steps
+
+
 def test_fallback_path_redoes_the_rank_phase(oracle):
     """the optimistic tentative-record pass is verified on the device; when it reports unsettled records
     the merge is redone without them (forced here through the test hook) and must give the same index"""

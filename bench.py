@@ -248,7 +248,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_chain", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": load_pmc_traffic(),
                          "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_chain, 4),
-                         "note": "8.8 M rows in ~17 k walkers: partly latency-bound; see aux_reads_regime for the bandwidth-bound regime of the same kernel"},
+                         "note": "random-request bound (~80 G requests/s: one 128-B line, two 8-B loads, one 8-B store per LF step; waves wait on memory 75% of their cycles, profiles/r1_pmc_sq.txt); aux_reads_regime is the same kernel on 200 k short strings"},
         }
         if tree_ms is not None:
             out["tree_merge_ms"] = round(tree_ms, 3)

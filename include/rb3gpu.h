@@ -54,6 +54,8 @@ typedef struct {
 	int64_t n_fallbacks;         /* merges whose optimistic (tentative-record) rank phase had to be redone */
 	int64_t bytes_index;         /* current size of the block array + group directory in HBM */
 	int64_t bytes_peak;          /* high-water mark of device memory owned by the handle */
+	double  ms_ssa;              /* rb3gpu_ssa_gen: kernels + copy-back */
+	double  ms_ssa_walk;         /* k_ssa_walk alone (one LF step per row of the index) */
 } rb3gpu_stats_t;
 
 void rb3gpu_opt_init(rb3gpu_opt_t *opt);
@@ -143,6 +145,15 @@ int rb3gpu_export_plain(rb3gpu_t *h, uint8_t *out);
  * is itself a valid partial BWT, so a whole index can be merged into another one with
  * rb3gpu_merge_plain_dev -- the tree-shaped multi-GPU build (rb3_fmi_merge, fm-index.c:251-277) */
 int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out);
+
+/* Sampled suffix array of the index, `ropebwt3 ssa` (rb3_ssa_gen ssa.c:54-81; the words are those of
+ * rb3_ssa_t fm-index.h:28-36 as written by rb3_ssa_dump ssa.c:198-213):
+ *   r2i[k], k in [0, m): the string whose first suffix is reached from sentinel row k (ssa.c:36);
+ *   ssa[x], x in [0, n_ssa): for row m + (x << ssa_shift), (offset of its suffix in its string) << ms | string.
+ * rb3gpu_ssa_dims gives the sizes (m = acc[1], n_ssa = ceil((n - m) / 2^ssa_shift), ms = bits of m as in
+ * ssa.c:62-64); rb3gpu_ssa_gen fills caller-owned host arrays of m and n_ssa words. */
+int rb3gpu_ssa_dims(const rb3gpu_t *h, int ssa_shift, int64_t *m, int64_t *n_ssa, int *ms);
+int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa);
 
 /* Import for `build -i` (rb3_enc_fmd2fmr fm-index.c:56-85, mr_restore mrope.c:161-177):
  * runs[i] = len<<3 | sym in BWT order (host memory). */

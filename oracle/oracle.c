@@ -238,6 +238,56 @@ int64_t orc_runs(int64_t n, const uint8_t *b, int64_t *runs)
 	return n > 0 ? k : 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* orc_ssa_gen: sampled suffix array, restates ssa.c:17-40 (ssa_gen1) and      */
+/* ssa.c:54-81 (rb3_ssa_gen) sequentially over a plain BWT                     */
+/* ------------------------------------------------------------------------- */
+
+/* sizes as rb3_ssa_gen computes them (ssa.c:62-64) */
+void orc_ssa_dims(int64_t n, const uint8_t *b, int ss, int64_t *m, int64_t *n_ssa, int *ms)
+{
+	int64_t i, c0 = 0;
+	int x;
+	for (i = 0; i < n; ++i) c0 += b[i] == 0;
+	for (x = 1; 1LL << x < c0; ++x) {}
+	*m = c0, *ms = x, *n_ssa = (n - c0 + (1LL << ss) - 1LL) >> ss;
+}
+
+/* r2i: m words, ssa: n_ssa words, both zero-filled here like RB3_CALLOC (ssa.c:65-66). Returns 0. */
+int orc_ssa_gen(int64_t n, const uint8_t *b, int ss, uint64_t *r2i, uint64_t *ssa)
+{
+	orc_fmi_t f;
+	int64_t m, n_ssa, k0, mask = (1LL << ss) - 1, nb = 0, mb = 0, *buf = 0, i;
+	int ms;
+	orc_ssa_dims(n, b, ss, &m, &n_ssa, &ms);
+	orc_fmi_init(&f, n, b);
+	memset(r2i, 0, m * 8);
+	memset(ssa, 0, n_ssa * 8);
+	for (k0 = 0; k0 < m; ++k0) { /* ssa_gen1 (ssa.c:17-40) for string k0 */
+		int64_t ok[ORC_ASIZE], k = k0, l = 0;
+		int c;
+		nb = 0;
+		do {
+			++l;
+			c = k < f.n ? f.b[k] : 0; /* what rb3_fmi_rank1a returns: the symbol at k */
+			orc_rank1a(&f, k, ok);
+			k = f.acc[c] + ok[c];
+			if (c) {
+				if (((k - f.acc[1]) & mask) == 0) {
+					int64_t x = (k - f.acc[1]) >> ss;
+					ssa[x] = l;
+					if (nb == mb) { mb = mb ? mb << 1 : 256; buf = (int64_t*)realloc(buf, mb * sizeof(int64_t)); }
+					buf[nb++] = x;
+				}
+			} else r2i[k] = k0;
+		} while (c);
+		for (i = 0; i < nb; ++i)
+			ssa[buf[i]] = (uint64_t)(l - 1 - (int64_t)ssa[buf[i]]) << ms | (uint64_t)k0;
+	}
+	free(buf); free(f.occ);
+	return 0;
+}
+
 /* nt6 encoding + both-strand text assembly: restates io.c:12-40, 84-102.
  * seqs are given as one buffer of ASCII sequences separated by '\n'.
  * out must hold 2*(in_len+1) bytes.  Returns the text length. */

@@ -550,6 +550,77 @@ int main_merge(int argc, char *argv[])
 	return ret == 0 ? 0 : 1;
 }
 
+/* `ssa`, ssa.c:246-279: sampled suffix array of an index, written as rb3_ssa_dump does (ssa.c:198-213) */
+int main_ssa(int argc, char *argv[])
+{
+	int c, ret, ssa_shift = 8, device = 0, ms = 0;
+	int64_t m = 0, n_ssa = 0;
+	uint64_t *r2i = 0, *ssa = 0;
+	char *fn = 0;
+	FILE *fp;
+	rb3gpu_t *h;
+	rb3gpu_opt_t gopt;
+	runvec_t rv = {0, 0, 0};
+	optind = 1;
+	while ((c = getopt_long(argc, argv, "t:s:o:", long_opts, 0)) >= 0) {
+		if (c == 't') {} /* threads of the reference's kt_for: nothing to size here */
+		else if (c == 's') ssa_shift = atoi(optarg);
+		else if (c == 'o') fn = optarg;
+		else if (c == 301) device = atoi(optarg);
+		else if (c == '?') return 1;
+	}
+	if (argc == optind) {
+		fprintf(stderr, "Usage: ropebwt3-amd ssa [options] <in.fmd|fmr>\n");
+		fprintf(stderr, "Options:\n");
+		fprintf(stderr, "  -s INT     sample rate one SA per 2**INT bases [%d]\n", ssa_shift);
+		fprintf(stderr, "  -o FILE    output to file [stdout]\n");
+		fprintf(stderr, "  --gpu INT  HIP device ordinal [0]\n");
+		return 1;
+	}
+	rb3gpu_opt_init(&gopt);
+	gopt.device = device, gopt.verbose = rb3h_verbose;
+	h = rb3gpu_create(&gopt);
+	if (h == 0) { fprintf(stderr, "ERROR: no usable MI355X/HIP device; there is no CPU fallback\n"); return 1; }
+	if (rb3h_index_read_runs(argv[optind], sink_runvec, &rv) < 0 || rv.n == 0 || rb3gpu_from_runs(h, rv.n, rv.a) < 0) {
+		fprintf(stderr, "[E::%s] failed to load the FM-index\n", __func__);
+		free(rv.a); rb3gpu_destroy(h);
+		return 1;
+	}
+	free(rv.a);
+	if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] loaded the index\n", __func__, rb3h_realtime(), rb3h_percent_cpu());
+	ret = rb3gpu_ssa_dims(h, ssa_shift, &m, &n_ssa, &ms);
+	if (ret == 0) {
+		r2i = (uint64_t*)calloc((size_t)(m > 0 ? m : 1), 8);
+		ssa = (uint64_t*)calloc((size_t)(n_ssa > 0 ? n_ssa : 1), 8);
+		ret = r2i && ssa ? rb3gpu_ssa_gen(h, ssa_shift, r2i, ssa) : -1;
+	}
+	if (ret < 0) fprintf(stderr, "ERROR: the GPU engine failed to generate the sampled suffix array: %s\n", rb3gpu_strerror(ret));
+	else {
+		if (rb3h_verbose >= 3) {
+			rb3gpu_stats_t st;
+			rb3gpu_stats(h, &st);
+			fprintf(stderr, "[M::%s::%.3f*%.2f] %lld samples of %lld strings in %.3f ms on the GPU (LF walk %.3f ms)\n", __func__, rb3h_realtime(), rb3h_percent_cpu(),
+					(long long)n_ssa, (long long)m, st.ms_ssa, st.ms_ssa_walk);
+		}
+		fp = fn && strcmp(fn, "-") ? fopen(fn, "wb") : stdout;
+		if (fp == 0) ret = -1;
+		else {
+			uint32_t y;
+			fwrite("SSA\1", 1, 4, fp);
+			y = (uint32_t)ssa_shift; fwrite(&y, 4, 1, fp);
+			y = (uint32_t)ms; fwrite(&y, 4, 1, fp);
+			fwrite(&m, 8, 1, fp);
+			fwrite(&n_ssa, 8, 1, fp);
+			fwrite(r2i, 8, (size_t)m, fp);
+			fwrite(ssa, 8, (size_t)n_ssa, fp);
+			if (fp != stdout) fclose(fp); else fflush(fp);
+		}
+	}
+	free(r2i); free(ssa);
+	rb3gpu_destroy(h);
+	return ret == 0 ? 0 : 1;
+}
+
 /* plain2fmd, main.c:299-331: every byte of the input is one BWT symbol ('\n' and '$' are 0) */
 int main_plain2fmd(int argc, char *argv[])
 {
@@ -638,6 +709,7 @@ static int usage(FILE *fp)
 	fprintf(fp, "Commands:\n");
 	fprintf(fp, "    build      construct a BWT (merge path on an MI355X)\n");
 	fprintf(fp, "    merge      merge BWTs (on an MI355X)\n");
+	fprintf(fp, "    ssa        generate sampled suffix array (on an MI355X)\n");
 	fprintf(fp, "    plain2fmd  convert BWT in plain text to FMD (host only)\n");
 	fprintf(fp, "    recode     convert an FMD/FMR file to plain text, FMD (-d) or FMR (-b) (host only)\n");
 	fprintf(fp, "    version    print the version number\n");
@@ -651,6 +723,7 @@ int main(int argc, char *argv[])
 	if (argc == 1) return usage(stdout);
 	else if (strcmp(argv[1], "build") == 0) ret = main_build(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "merge") == 0) ret = main_merge(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "ssa") == 0) ret = main_ssa(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "plain2fmd") == 0) ret = main_plain2fmd(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "recode") == 0) ret = main_recode(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "version") == 0) { printf("%s\n", RB3H_VERSION); return 0; }

@@ -908,6 +908,70 @@ int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out)
 	return 0;
 }
 
+int rb3gpu_ssa_dims(const rb3gpu_t *h, int ssa_shift, int64_t *m, int64_t *n_ssa, int *ms)
+{
+	if (!h || ssa_shift < 0 || ssa_shift > 40) return RB3GPU_EINVAL;
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	int b;
+	for (b = 1; (1LL << b) < h->acc[1]; ++b) {} // ssa.c:63
+	if (m) *m = h->acc[1];
+	if (n_ssa) *n_ssa = (h->n - h->acc[1] + (1LL << ssa_shift) - 1) >> ssa_shift; // ssa.c:64
+	if (ms) *ms = b;
+	return 0;
+}
+
+int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa)
+{
+	int64_t m, n_ssa;
+	int ms, r;
+	if (!h || !r2i || (r = rb3gpu_ssa_dims(h, ssa_shift, &m, &n_ssa, &ms)) < 0) return h && r2i ? r : RB3GPU_EINVAL;
+	if (n_ssa > 0 && !ssa) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	// splitter spacing: the link pass hops over n/2^S splitters per string one after the other, the walk's
+	// longest sublist is about 2^S ln(number of splitters) steps: 2^10 balances the two for Mbp-long strings
+	int S = 10;
+	if (getenv("RB3GPU_SSA_SPLIT")) S = atoi(getenv("RB3GPU_SSA_SPLIT"));
+	if (S < 4) S = 4;
+	if (S > 20) S = 20;
+	const int64_t nsp = m + ((h->n - m + (1LL << S) - 1) >> S);
+	if (nsp >= (1LL << (64 - RB3_SSA_LBITS)) || ms + 1 > 63) return RB3GPU_EINVAL;
+	// scratch: nxt (2 words per splitter), base, sidp, tot, r2i, ssa, all u64
+	const size_t words = (size_t)nsp * 4 + (size_t)m * 2 + (size_t)n_ssa + 8;
+	if ((r = buf_ensure(h, h->xbuf, words * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	uint64_t *nxt = (uint64_t*)h->xbuf.p, *base = nxt + 2 * nsp, *sidp = base + nsp, *tot = sidp + nsp, *d_r2i = tot + m, *d_ssa = d_r2i + m;
+	unsigned long long *misc = (unsigned long long*)h->misc.p;
+	const double t0 = now_s();
+	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
+	HIPCHK(hipMemsetAsync(d_r2i, 0, (size_t)(m + n_ssa) * 8, h->st)); // RB3_CALLOC in ssa.c:65-66
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	{
+		int64_t nblk = (nsp + 31) / 32;
+		nblk = nblk > 256 * 8 ? 256 * 8 : nblk < 1 ? 1 : nblk;
+		hipLaunchKernelGGL(k_ssa_walk, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), S, ssa_shift, nsp, nxt, d_ssa, misc, misc + 2);
+	}
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	hipLaunchKernelGGL(k_ssa_link, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->st, m, nsp, (const uint64_t*)nxt, base, sidp, tot, d_r2i, misc + 2);
+	if (n_ssa > 0)
+		hipLaunchKernelGGL(k_ssa_final, dim3((unsigned)((n_ssa + 255) / 256)), dim3(256), 0, h->st, n_ssa, ms, (const uint64_t*)base, (const uint64_t*)sidp, (const uint64_t*)tot, d_ssa);
+	HIPCHK(hipEventRecord(h->ev[2], h->st));
+	unsigned long long hm[4];
+	HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipMemcpyAsync(r2i, d_r2i, (size_t)m * 8, hipMemcpyDeviceToHost, h->st));
+	if (n_ssa > 0) HIPCHK(hipMemcpyAsync(ssa, d_ssa, (size_t)n_ssa * 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_ssa += (now_s() - t0) * 1e3;
+	h->stt.ms_ssa_walk += ev_ms(h->ev[0], h->ev[1]);
+	if (hm[2] != 0 || hm[3] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] ssa: %llu sublists too long, %llu broken links\n", hm[2], hm[3]);
+		return RB3GPU_EINTERNAL;
+	}
+	if (h->opt.verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f] sampled suffix array: %lld strings, %lld samples, walk %.3f ms, link+final %.3f ms\n", __func__, now_s() - h->t0,
+				(long long)m, (long long)n_ssa, ev_ms(h->ev[0], h->ev[1]), ev_ms(h->ev[1], h->ev[2]));
+	return 0;
+}
+
 int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
 {
 	if (!h || !emit) return RB3GPU_EINVAL;

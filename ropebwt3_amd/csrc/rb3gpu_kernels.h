@@ -10,6 +10,7 @@
  *                            and rb3_enc_plain2fmr (fm-index.c:114-137), as one streaming
  *                            interleave that rebuilds the block array
  *   k_export_plain           mr_print_bwt / leaf iteration (mrope.c:133-147, 201-214)
+ *   k_ssa_walk/link/final    rb3_ssa_gen (ssa.c:17-81): sampled suffix array of the index
  *
  * No MFMA anywhere: this is integer pointer chasing bound by HBM/L2 latency and bandwidth.
  */
@@ -1252,6 +1253,137 @@ __global__ void __launch_bounds__(256) k_fill_iota(int64_t *p, int64_t n)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) p[i] = i;
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* sampled suffix array (rb3_ssa_gen, ssa.c:17-81)                                             */
+/* ----------------------------------------------------------------------------------------- */
+
+/* The reference walks LF from every sentinel row k0 to the start of string k0, one thread per
+ * string (kt_for over sa->m, ssa.c:73), and notes text offset and string id at every row k with
+ * (k - m) a multiple of 2^ss.  Here the rows are cut into sublists by SPLITTERS -- the m sentinel
+ * rows (heads of the strings) and every row k >= m with (k - m) a multiple of 2^S -- and every
+ * splitter walks its sublist at the same time (k_ssa_walk), leaving for each sampled row the pair
+ * (splitter, steps from it).  One thread per string then hops from splitter to splitter
+ * (k_ssa_link: 2^-S of the steps) to find where each sublist starts in its string, and a streaming
+ * pass (k_ssa_final) turns the pairs into the reference's words.  Rows are in suffix order, so
+ * sublist lengths are geometric with mean 2^S whatever the text looks like. */
+
+#define RB3_SSA_LBITS 24              /* bits for the steps inside one sublist */
+#define RB3_SSA_END   (1ull << 63)    /* nxt word: the sublist ends at the start of its string */
+
+/* symbol at offset `off` of the slot, this lane's share: 8 | symbol in the lane that holds it, else 0 */
+__device__ __forceinline__ uint32_t slice_sym(const uint4 &sl, uint32_t hdr0, uint32_t off, int j)
+{
+	if (!(hdr0 & RB3_SLOT_RLE)) {
+		const int t = (int)off - 32 * j;
+		if (t < 0 || t >= 32) return 0u;
+		return 8u | ((sl.y >> t) & 1u) | ((sl.z >> t) & 1u) << 1 | ((sl.w >> t) & 1u) << 2;
+	} else {
+		const uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
+		uint32_t len[6], tot = 0;
+#pragma unroll
+		for (int i = 0; i < 6; ++i) {
+			len[i] = (e[i] & 7u) == 7u ? 0u : (e[i] >> 3) + 1u;
+			tot += len[i];
+		}
+		uint32_t pos = oct_exscan(tot, j), r = 0u;
+#pragma unroll
+		for (int i = 0; i < 6; ++i) {
+			if (off >= pos && off < pos + len[i]) r = 8u | (e[i] & 7u);
+			pos += len[i];
+		}
+		return r;
+	}
+}
+
+/* one LF step of the index on itself: *c = B[k], returns C[c] + rank(c, k) (fm-index.h:109-112 + ssa.c:26-27) */
+__device__ __forceinline__ int64_t oct_lf_self(const IdxView &ix, int64_t k, int j, int *c)
+{
+	RankLoad r;
+	oct_rank_issue(ix, k, j, r);
+	const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
+	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
+	const uint32_t sy = oct_sum(slice_sym(r.sl, hdr0, off, j)) & 7u;
+	*c = (int)sy;
+	return oct_rank_finish(r, (int)sy, j);
+}
+
+/* nxt[2p] = next splitter (or RB3_SSA_END | sentinel row reached), nxt[2p+1] = steps of the sublist;
+ * ssa[x] = p << 24 | steps for every sampled row on it; err[0] counts sublists too long to encode */
+__global__ void __launch_bounds__(256) k_ssa_walk(IdxView ix, int S, int ss, int64_t nsp, uint64_t *nxt, uint64_t *ssa, unsigned long long *qhead, unsigned long long *err)
+{
+	const int lane = threadIdx.x & 63, j = lane & 7;
+	const int64_t m = ix.m, maskS = (1LL << S) - 1, maskss = (1LL << ss) - 1;
+	bool active = false;
+	int64_t k = 0, p = 0;
+	uint32_t l = 0;
+	for (;;) {
+		if (!active) {
+			uint32_t w0 = 0, w1 = 0;
+			if (j == 0) {
+				unsigned long long w = atomicAdd(qhead, 1ull);
+				w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+			}
+			w0 = oct_bcast0(w0, j), w1 = oct_bcast0(w1, j);
+			p = (int64_t)((uint64_t)w1 << 32 | w0);
+			if (p >= nsp) break;
+			k = p < m ? p : m + ((p - m) << S);
+			l = 0, active = true;
+		}
+		do {
+			int c;
+			const int64_t k2 = oct_lf_self(ix, k, j, &c);
+			++l;
+			const int64_t km = k2 - m; // >= 0 whenever c != 0
+			if (c != 0 && (km & maskss) == 0 && j == 0) ssa[km >> ss] = (uint64_t)p << RB3_SSA_LBITS | l;
+			const bool at_split = c != 0 && (km & maskS) == 0;
+			const bool too_long = l >= (1u << RB3_SSA_LBITS) - 1u;
+			if (c == 0 || at_split || too_long) {
+				if (j == 0) {
+					nxt[2 * p] = c == 0 ? (RB3_SSA_END | (uint64_t)k2) : (uint64_t)(m + (km >> S));
+					nxt[2 * p + 1] = l;
+					if (too_long && c != 0 && !at_split) atomicAdd(err, 1ull);
+				}
+				active = false;
+			}
+			k = k2;
+		} while (__all(active));
+	}
+}
+
+/* one thread per string: base[p] = steps from the sentinel row of the string to splitter p, sidp[p] = string,
+ * tot[k0] = steps of the whole walk (the reference's l, ssa.c:23-37), r2i[row reached] = k0 (ssa.c:36) */
+__global__ void __launch_bounds__(256) k_ssa_link(int64_t m, int64_t nsp, const uint64_t *nxt, uint64_t *base, uint64_t *sidp, uint64_t *tot, uint64_t *r2i, unsigned long long *err)
+{
+	const int64_t k0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k0 >= m) return;
+	int64_t p = k0;
+	uint64_t d = 0;
+	for (int64_t hop = 0; hop <= nsp; ++hop) {
+		base[p] = d, sidp[p] = (uint64_t)k0;
+		const uint64_t e = nxt[2 * p];
+		d += nxt[2 * p + 1];
+		if (e & RB3_SSA_END) {
+			const uint64_t row = e & ~RB3_SSA_END;
+			if (row < (uint64_t)m) r2i[row] = (uint64_t)k0; else atomicAdd(err + 1, 1ull);
+			tot[k0] = d;
+			return;
+		}
+		if (e >= (uint64_t)nsp) break;
+		p = (int64_t)e;
+	}
+	atomicAdd(err + 1, 1ull); // a cycle or a broken link: cannot happen with a valid index
+}
+
+/* ssa[x] = (offset of the sampled row's suffix in its string) << ms | string  (ssa.c:38-39) */
+__global__ void __launch_bounds__(256) k_ssa_final(int64_t n_ssa, int ms, const uint64_t *base, const uint64_t *sidp, const uint64_t *tot, uint64_t *ssa)
+{
+	const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= n_ssa) return;
+	const uint64_t t = ssa[x], p = t >> RB3_SSA_LBITS, l = t & ((1ull << RB3_SSA_LBITS) - 1);
+	const uint64_t sid = sidp[p];
+	ssa[x] = (tot[sid] - 1 - (base[p] + l)) << ms | sid;
 }
 
 #endif

@@ -34,7 +34,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("ms_h2d", ctypes.c_double), ("ms_lf", ctypes.c_double), ("ms_rank", ctypes.c_double),
                 ("ms_build", ctypes.c_double), ("ms_export", ctypes.c_double), ("ms_chain", ctypes.c_double),
                 ("n_rank_launches", ctypes.c_int64), ("n_lf_steps", ctypes.c_int64), ("n_symbols_merged", ctypes.c_int64),
-                ("n_rounds", ctypes.c_int64), ("n_fallbacks", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64)]
+                ("n_rounds", ctypes.c_int64), ("n_fallbacks", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64),
+                ("ms_ssa", ctypes.c_double), ("ms_ssa_walk", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -66,6 +67,8 @@ SYMBOLS = {
     "rb3gpu_export_runs": (ctypes.c_int, [ctypes.c_void_p, EMIT_F, ctypes.c_void_p]),
     "rb3gpu_export_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_export_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_ssa_dims": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),
+    "rb3gpu_ssa_gen": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),
@@ -215,6 +218,15 @@ class Rb3Gpu:
 
     def export_plain_dev(self, d_out):
         self._chk(self._lib.rb3gpu_export_plain_dev(self._h, d_out), "rb3gpu_export_plain_dev")
+
+    def ssa_gen(self, ssa_shift):
+        """sampled suffix array of the index (rb3_ssa_gen, ssa.c:54-81): (ms, r2i[m], ssa[n_ssa]) as uint64"""
+        m, n_ssa, ms = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        self._chk(self._lib.rb3gpu_ssa_dims(self._h, ssa_shift, ctypes.byref(m), ctypes.byref(n_ssa), ctypes.byref(ms)), "rb3gpu_ssa_dims")
+        r2i = np.empty(m.value, dtype=np.uint64)
+        ssa = np.empty(max(n_ssa.value, 1), dtype=np.uint64)
+        self._chk(self._lib.rb3gpu_ssa_gen(self._h, ssa_shift, r2i.ctypes.data, ssa.ctypes.data), "rb3gpu_ssa_gen")
+        return ms.value, r2i, ssa[:n_ssa.value]
 
     def export_runs(self):
         runs = []

@@ -105,3 +105,19 @@ def test_against_reference_library_random(oracle):
         assert np.array_equal(b1, ref.bwt(t1)) and np.array_equal(b2, ref.bwt(t2))
         # reference merge: plain2fmr + merge_plain, then print
         assert np.array_equal(oracle.merge(b1, b2), ref.bwt(np.concatenate([t1, t2])))
+
+
+@pytest.mark.parametrize("name", ["k2_fwd", "k3_both", "k4_readme", "edge_dups", "edge_chars", "genomes12", "reads_fq", "reads_fwd"])
+def test_ssa_matches_reference_files(oracle, name):
+    """sampled suffix array: the oracle's restatement of rb3_ssa_gen reproduces the .ssa
+    files the reference's `ssa` wrote for the fixtures' indexes, byte for byte"""
+    import hashlib
+    b = golden_plain(name)
+    for ss, md5 in MAN[name]["ssa_md5"].items():
+        ms, r2i, ssa = oracle.ssa_gen(b, int(ss))
+        out = util.ssa_bytes(int(ss), ms, r2i, ssa)
+        assert hashlib.md5(out).hexdigest() == md5, (name, ss)
+    if "ssa_file" in MAN[name]:
+        f = MAN[name]["ssa_file"]
+        ms, r2i, ssa = oracle.ssa_gen(b, f["shift"])
+        assert util.ssa_bytes(f["shift"], ms, r2i, ssa) == open(os.path.join(util.GOLDEN, f["file"]), "rb").read()

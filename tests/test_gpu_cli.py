@@ -108,3 +108,25 @@ def test_merge_subcommand(tmp_path):
         q = tmp_path / "r.fmr"
         q.write_bytes(ref)
         assert subprocess.run([CLI, "recode", "-d", str(q)], stdout=subprocess.PIPE, check=True).stdout == got
+
+
+@pytest.mark.parametrize("name", [k for k in CASES if "ssa_md5" in MAN[k]])
+def test_ssa_subcommand_identical(name, tmp_path):
+    """`ssa` (ssa.c:246-279): the .ssa written for the golden index is byte-identical to the reference's,
+    for every sample rate; from the FMD and, for one case, from the FMR form of the same index"""
+    ent = MAN[name]
+    fmd = os.path.join(util.GOLDEN, ent["fmd"])
+    for ss, md5 in ent["ssa_md5"].items():
+        out, _ = run(["ssa", "-s" + ss, fmd])
+        assert hashlib.md5(out).hexdigest() == md5, (name, ss)
+    if "ssa_file" in ent:
+        f = ent["ssa_file"]
+        o = tmp_path / "x.ssa"
+        run(["ssa", "-s%d" % f["shift"], "-o", str(o), fmd])
+        assert o.read_bytes() == open(os.path.join(util.GOLDEN, f["file"]), "rb").read()
+    if name == "genomes12":
+        fmr = subprocess.run([CLI, "recode", "-b", fmd], stdout=subprocess.PIPE, check=True).stdout
+        q = tmp_path / "g.fmr"
+        q.write_bytes(fmr)
+        out, _ = run(["ssa", "-s8", str(q)])
+        assert hashlib.md5(out).hexdigest() == ent["ssa_md5"]["8"]

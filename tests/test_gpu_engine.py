@@ -303,3 +303,45 @@ def test_fallback_path_redoes_the_rank_phase(oracle):
         h.close()
     finally:
         os.environ.pop("RB3GPU_TEST_FORCE_FALLBACK", None)
+
+
+@pytest.mark.parametrize("seed,kind", [(61, "genomes"), (62, "reads"), (63, "runs"), (64, "tiny")])
+def test_ssa_gen_vs_oracle(oracle, seed, kind):
+    """sampled suffix array of the resident index (rb3gpu_ssa_gen) against the oracle's restatement of
+    rb3_ssa_gen (ssa.c:17-81), for several sample rates and splitter spacings, on bit-plane and run slots"""
+    import os
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(seed)
+    if kind == "genomes":
+        g0 = util.random_genome(rng, 60000)
+        seqs = [g0] + [util.mutate(rng, g0, 0.003) for _ in range(3)]
+    elif kind == "reads":
+        seqs = util.reads_from(rng, util.random_genome(rng, 20000), 3000, 80, err=0.01)
+    elif kind == "runs":
+        seqs = [np.full(50000, 1, dtype=np.uint8), np.tile(np.array([1, 2, 3, 4], dtype=np.uint8), 3000), np.full(9000, 5, dtype=np.uint8)]
+        seqs += [seqs[1].copy() for _ in range(40)]
+    else:
+        seqs = [np.array([1, 3, 3], dtype=np.uint8), np.array([1, 3, 2], dtype=np.uint8)]
+    b = host.build_bwt(util.make_text(seqs))
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_plain(b)
+        if kind == "runs":   # through the run import too: that is how `ssa` loads an index
+            runs = h.export_runs()
+            h.close()
+            h = Rb3Gpu(verbose=1)
+            h.from_runs(runs)
+        for ss in (0, 2, 5, 8, 13):
+            want = oracle.ssa_gen(b, ss)
+            for S in (None, 4, 7, 20):
+                if S is None:
+                    os.environ.pop("RB3GPU_SSA_SPLIT", None)
+                else:
+                    os.environ["RB3GPU_SSA_SPLIT"] = str(S)
+                ms, r2i, ssa = h.ssa_gen(ss)
+                assert ms == want[0]
+                assert np.array_equal(r2i, want[1]), (ss, S)
+                assert np.array_equal(ssa, want[2]), (ss, S)
+    finally:
+        os.environ.pop("RB3GPU_SSA_SPLIT", None)
+        h.close()

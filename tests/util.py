@@ -37,7 +37,21 @@ class Oracle:
         L.orc_mg_rank_plain.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.orc_runs.restype = ctypes.c_int64
         L.orc_runs.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_ssa_dims.restype = None
+        L.orc_ssa_dims.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+        L.orc_ssa_gen.restype = ctypes.c_int
+        L.orc_ssa_gen.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         self.L = L
+
+    def ssa_gen(self, b, ss):
+        """(ms, r2i, ssa) of the index whose plain BWT is b (ssa.c:54-81)"""
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        m, n_ssa, ms = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        self.L.orc_ssa_dims(b.size, b.ctypes.data, ss, ctypes.byref(m), ctypes.byref(n_ssa), ctypes.byref(ms))
+        r2i = np.zeros(max(m.value, 1), dtype=np.uint64)
+        ssa = np.zeros(max(n_ssa.value, 1), dtype=np.uint64)
+        self.L.orc_ssa_gen(b.size, b.ctypes.data, ss, r2i.ctypes.data, ssa.ctypes.data)
+        return ms.value, r2i[:m.value], ssa[:n_ssa.value]
 
     def text(self, lines, fwd=True, rev=True):
         s = ("\n".join(lines) + "\n").encode()
@@ -107,6 +121,12 @@ class Reference:
         n_seq = int((t == 0).sum())
         self.L.rb3_build_sais(n_seq, t.size, t.ctypes.data, threads)
         return t
+
+
+def ssa_bytes(ss, ms, r2i, ssa):
+    """the bytes rb3_ssa_dump writes (ssa.c:198-213)"""
+    import struct
+    return b"SSA\1" + struct.pack("<IIqq", ss, ms, len(r2i), len(ssa)) + np.asarray(r2i, dtype="<u8").tobytes() + np.asarray(ssa, dtype="<u8").tobytes()
 
 
 def random_genome(rng, n):

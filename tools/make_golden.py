@@ -159,6 +159,20 @@ def main():
     man["resume"]["first"] += ".gz"
     man["resume"]["rest"] += ".gz"
 
+    # sampled suffix arrays of the fixtures' indexes (`ropebwt3 ssa`, ssa.c): md5 of the .ssa file for
+    # several sample rates; the file itself for two of them
+    for name, ent in sorted(man.items()):
+        if "fmd" not in ent or name == "resume":
+            continue
+        ent["ssa_md5"] = {}
+        for ss in (0, 3, 8):
+            out = ref(["ssa", "-t4", "-s%d" % ss, os.path.join(OUT, ent["fmd"])])
+            ent["ssa_md5"][str(ss)] = hashlib.md5(out).hexdigest()
+            if (name, ss) in (("k3_both", 0), ("genomes12", 8), ("reads_fwd", 3)):
+                fn = "%s.s%d.ssa" % (name, ss)
+                open(os.path.join(OUT, fn), "wb").write(out)
+                ent["ssa_file"] = {"shift": ss, "file": fn}
+
     json.dump(man, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("total fixture bytes:", tot)

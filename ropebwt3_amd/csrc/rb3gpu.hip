@@ -39,7 +39,7 @@ struct rb3gpu_s {
 	struct { rb3_grp_t *grp; size_t grp_cap; rb3_slot_t *slots; size_t slots_cap; } ib[2] = {{nullptr, 0, nullptr, 0}, {nullptr, 0, nullptr, 0}};
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane;
+	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane, wruns;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -231,7 +231,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	(void)hipStreamSynchronize(h->st);
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane };
+	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane, &h->wruns };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	for (int i = 0; i < 2; ++i) if (h->stage[i]) (void)hipHostFree(h->stage[i]);
@@ -288,11 +288,12 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		jg = (int64_t*)h->jg.p;
 	}
 	// window-parallel kernels (one wave per 256-symbol window, planes cached between the passes) unless
-	// their scratch (120 B per window) would be unreasonably large; then one wave per 8192-symbol group
-	const bool winpar = (size_t)nwin * 120 <= ((size_t)6 << 30) && !getenv("RB3GPU_GROUP_REBUILD");
+	// their scratch (216 B per window) would be unreasonably large; then one wave per 8192-symbol group
+	const bool winpar = (size_t)nwin * 216 <= ((size_t)8 << 30) && !getenv("RB3GPU_GROUP_REBUILD");
 	if (winpar) {
 		if ((r = buf_ensure(h, h->wstat, (size_t)nwin * 16)) < 0) return r;
 		if ((r = buf_ensure(h, h->wplane, (size_t)nwin * 96)) < 0) return r;
+		if ((r = buf_ensure(h, h->wruns, (size_t)nwin * RB3_RLE_CODES * 2)) < 0) return r;
 		if (!FROM_PLAIN && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
 		jg = (int64_t*)h->jg.p;
 	}
@@ -306,8 +307,8 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			HIPCHK(hipMemsetAsync(jg, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
 			hipLaunchKernelGGL(k_win_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, nwin);
 		}
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN>), dim3((unsigned)nwin), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-				(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, nwin);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN>), dim3((unsigned)((nwin + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
+				(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin);
 		hipLaunchKernelGGL(k_decide, dim3((unsigned)ngrp), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp);
 	} else {
 		if (!FROM_PLAIN) {
@@ -330,7 +331,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		if ((r = ib_ensure(h, dst, ngrp, *onslots)) < 0) return r;
 	}
 	if (winpar)
-		hipLaunchKernelGGL(k_pass2w, dim3((unsigned)nwin), dim3(64), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, ntot,
+		hipLaunchKernelGGL(k_pass2w, dim3((unsigned)ngrp), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
 				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin);
 	else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
@@ -498,13 +499,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 	unsigned long long nsid = 0;
 	if (tent) HIPCHK(hipMemcpyAsync(&nsid, sidctr, 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
-	if (tent) {
-		tent_used(h, nsid);
-		if (nsid >= (unsigned long long)RB3_TENT_IDS - 1) { // the stretch table overflowed: count it as unsettled (the caller redoes the phase)
-			const unsigned long long one = 1;
-			HIPCHK(hipMemcpy(qhead + 4, &one, 8, hipMemcpyHostToDevice));
-		}
-	}
+	if (tent) tent_used(h, nsid); // (a full table poisons the records it could not serve: they count as unsettled)
 	h->stt.ms_chain += ev_ms(h->ev[6], h->ev[7]), h->stt.ms_rank += ev_ms(h->ev[6], h->ev[5]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	return 0;
@@ -684,7 +679,6 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
 	if (tent) {
 		tent_used(h, hm[5]);
-		if (hm[5] >= (unsigned long long)RB3_TENT_IDS - 1) hm[4] |= 1; // the stretch table overflowed
 		if (getenv("RB3GPU_TEST_FORCE_FALLBACK")) hm[4] = 1; // test hook: exercise the redo path
 	}
 	if (tent && hm[4] != 0) { // some tentative record was left unsettled: nothing was installed, redo without them

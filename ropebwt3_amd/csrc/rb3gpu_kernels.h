@@ -491,9 +491,10 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
  * number: ka = lo + d, where d counts how many of those k suffixes are smaller than the new one.
  * The k suffixes and the new one are extended by the same symbols as the walk goes on, so their
  * relative order never changes: d stays put while all k survive, and when the suffix with index e
- * (in row order) drops out because B1 has another symbol there, d becomes d - [e < d].  Such a
+ * (in row order) drops out because B1 has another symbol there, d becomes d - [e < d] (a whole range
+ * [i0, i0 + len) dropping at once clamps: d, i0 or d - len).  Such a
  * walker therefore records RB3_TENT | sid << 40 | (lo + kb), where sid names a STRETCH of rows that
- * share one unknown d, opens a new stretch at every drop (sdep[new] = EVENT, old sid, e), and goes
+ * share one unknown d, opens a new stretch at every drop (sdep[new] = EVENT, old sid, range), and goes
  * on.  k = 1 is the common case for a genome merged into an index holding one close relative and has
  * a fast path with ONE rank per step (hi' = lo' + [B1[lo] == c]); k > 1 (several close relatives
  * indexed) costs the two ranks a wide walker pays anyway.  Whoever later walks into those rows
@@ -521,12 +522,14 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 #define RB3_TENT      (1LL << 62)
 #define RB3_TENT_MASK ((1LL << 40) - 1)
 #define RB3_TENT_IDS  (1 << 22)       /* stretch ids per merge */
+#define RB3_TENT_POISON (RB3_TENT_IDS - 1) /* the id of records whose stretch could not be allocated: never settled */
 #define RB3_TENT_KMAX 255             /* widest interval that is tracked tentatively */
 #ifndef RB3_TENT_MIN_AGE
 #define RB3_TENT_MIN_AGE 64u
 #endif
 /* sdep[sid]: how the unknown of a stretch follows from another one */
-#define RB3_DEP_EVENT 1ull            /* d = d(prev) - [arg < d(prev)] */
+#define RB3_DEP_EVENT 1ull            /* rows [i0, i0 + len) of the interval dropped out, arg = i0 | len << 8:
+                                         d = d(prev) if d(prev) <= i0, i0 if d(prev) < i0 + len, else d(prev) - len */
 #define RB3_DEP_LINK  2ull            /* d = d(prev) + (int32)arg */
 #define RB3_TENT_DERIVED 0x10000     /* sdel[]: value derived by k_resolve, not settled by a walker */
 #define RB3_DEP_MAKE(type, prev, arg) ((uint64_t)(type) << 62 | (uint64_t)(uint32_t)(prev) << 32 | (uint64_t)(uint32_t)(arg))
@@ -538,13 +541,104 @@ template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t 
 	else *p = v;                 // one walker per string, nobody ever looks: let the L2 keep the line it just read
 }
 
-__device__ __forceinline__ uint32_t idx_sym(const IdxView &ix, int64_t i);
+/* Rows of [lo, lo + kk) that do NOT hold c, from the slice of a slot this lane already has in registers:
+ * OR them into the octet's 256-bit mask D[8] (LDS; bit i <=> row lo + i).  Index i sits at slot offset
+ * off0 + i (off0 may be negative: the rows before the slot are somebody else's).  Called for the slot of
+ * lo and for the slot of hi, which together hold all of [lo, hi) when hi - lo < 256. */
+__device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, int off0, int kk, int c, int j, uint32_t *D)
+{
+	if (!(hdr0 & RB3_SLOT_RLE)) { // bit planes: this lane holds slot offsets [32j, 32j + 32)
+		const uint32_t m0 = (c & 1) ? sl.y : ~sl.y, m1 = (c & 2) ? sl.z : ~sl.z, m2 = (c & 4) ? sl.w : ~sl.w;
+		uint32_t nm = ~(m0 & m1 & m2);
+		const int ib = 32 * j - off0; // index of bit 0 of this word
+		const int t0 = ib < 0 ? -ib : 0, t1 = kk - ib < 32 ? kk - ib : 32;
+		if (t0 < t1) {
+			nm &= (t1 >= 32 ? 0xFFFFFFFFu : (1u << t1) - 1u) & ~((1u << t0) - 1u);
+			if (nm) {
+				const int wi = ib >> 5, sh = ib & 31; // arithmetic shift: wi may be -1
+				if (wi >= 0 && wi < 8 && (nm << sh)) atomicOr(&D[wi], nm << sh);
+				if (sh && wi + 1 >= 0 && wi + 1 < 8 && (nm >> (32 - sh))) atomicOr(&D[wi + 1], nm >> (32 - sh));
+			}
+		}
+	} else { // six run codes per lane (rolled loops: this is a cold path and must stay light on registers)
+		uint32_t tot = 0;
+#pragma unroll 1
+		for (int i = 0; i < 6; ++i) {
+			const uint32_t word = i < 2 ? sl.y : i < 4 ? sl.z : sl.w, e = (i & 1) ? word >> 16 : word & 0xFFFFu;
+			tot += (e & 7u) == 7u ? 0u : (e >> 3) + 1u;
+		}
+		int pos = (int)oct_exscan(tot, j);
+#pragma unroll 1
+		for (int i = 0; i < 6; ++i) {
+			const uint32_t word = i < 2 ? sl.y : i < 4 ? sl.z : sl.w, e = (i & 1) ? word >> 16 : word & 0xFFFFu;
+			const int len = (e & 7u) == 7u ? 0 : (int)(e >> 3) + 1;
+			if ((int)(e & 7u) != c && len != 0) {
+				int a = pos - off0, b = pos + len - off0; // index range of this run
+				a = a < 0 ? 0 : a, b = b > kk ? kk : b;
+#pragma unroll 1
+				for (int w = a >> 5; a < b && w <= (b - 1) >> 5; ++w) {
+					const int x0 = a > w * 32 ? a - w * 32 : 0, x1 = b < w * 32 + 32 ? b - w * 32 : 32;
+					atomicOr(&D[w], (x1 >= 32 ? 0xFFFFFFFFu : (1u << x1) - 1u) & ~((1u << x0) - 1u));
+				}
+			}
+			pos += len;
+		}
+	}
+}
+
+template<bool DENSE>
+__device__ __forceinline__ int open_drop_stretches(const IdxView &ix, int64_t lo, int64_t hi, int c, int j, int sid,
+		uint32_t *D, uint64_t *sdep, int32_t *schild, uint32_t *sidctr)
+{
+	const int kk = (int)(hi - lo);
+	D[j] = 0u;
+	__builtin_amdgcn_wave_barrier();
+	// the two slots were in registers a moment ago (the ranks of lo and hi); they are fetched again here
+	// (cache hits) so that the hot loop does not have to keep them alive for this rare case
+#pragma unroll 1
+	for (int which = 0; which < 2; ++which) {
+		const int64_t k = which ? hi : lo;
+		const uint32_t koff = (uint32_t)k & (RB3_GRP - 1);
+		int64_t s;
+		if (DENSE) s = k >> RB3_WIN_BITS;
+		else {
+			const uint64_t sm = ix.grp64[(k >> RB3_GRP_BITS) * 8 + 6];
+			s = (int64_t)((uint32_t)sm + __popc((uint32_t)(sm >> 32) & ((2u << (koff >> RB3_WIN_BITS)) - 1u)) - 1u);
+		}
+		const uint4 sl = ix.slot16[s * 8 + j];
+		const uint32_t hdr0 = oct_bcast0(sl.x, j);
+		drops_from_slot(sl, hdr0, (int)koff - (int)(hdr0 & 0xFFFFu) - (which ? kk : 0), kk, c, j, D);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t mine = D[j];
+	const uint32_t nrange = oct_sum(__popc(mine & ~(mine << 1)));
+	uint32_t s0 = 0;
+	if (j == 0) s0 = atomicAdd(sidctr, nrange);
+	const uint32_t base = oct_bcast0(s0, j);
+	if (base + nrange > (uint32_t)RB3_TENT_POISON || base + nrange < base) return RB3_TENT_POISON; // table full: records from here on stay unsettled, the host redoes the phase
+	uint32_t idx = 0;
+	for (int itb = 7; itb >= 0; --itb) {
+		uint32_t w = D[itb];
+		while (w) {
+			const int bpos = 31 - __clz((int)w);
+			const int len = __clz((int)~(w << (31 - bpos)));
+			const int i0 = itb * 32 + bpos - len + 1;
+			const int ns = (int)(base + idx);
+			if (j == 0) sdep[ns] = RB3_DEP_MAKE(RB3_DEP_EVENT, sid, i0 | len << 8), schild[sid] = ns + 1;
+			sid = ns, ++idx;
+			w &= ~((len >= 32 ? 0xFFFFFFFFu : (1u << len) - 1u) << (bpos - len + 1));
+		}
+	}
+	return sid;
+}
 
 template<bool LIST, bool DENSE, bool TENT>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
 		int32_t *sdel, uint64_t *sdep, int32_t *schild, uint32_t *sidctr)
 {
+	__shared__ uint32_t evmask[TENT ? 32 * 8 : 1]; // per octet: the rows of [lo, hi) that drop out at a step
 	const int lane = threadIdx.x & 63, j = lane & 7;
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
 	// it hosts: the host may enable only the first `octs` octets of each wave and launch more waves.
@@ -554,7 +648,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	const bool vis = LIST || M != 0; // records must become visible to other walkers only if strings are split
 	bool active = false;
 	int gap = 0;            // 0: exact (lo == hi), 1: hi == lo + 1, 2: wider
-	int sid = -1;           // stretch id of the tentative records being written, -1: none yet
+	int sid = -1;           // stretch id of the tentative records being written, -1: none yet, -2: none to be had
 	int64_t kb = 0, lo = 0, hi = 0, remaining = 0;
 	uint64_t x = 0;         // row word of the current row (requested one step ahead)
 	uint32_t steps = 0;
@@ -610,7 +704,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			const int64_t kbn = met ? kb : RB3_ROW_NEXT(x);
 			const bool wide = TENT ? gap == 2 : gap != 0;
 			// may this walker record tentatively?  (an interval of at most KMAX rows, and old enough)
-			const bool tentok = TENT && gap != 0 && age >= RB3_TENT_MIN_AGE && hi - lo <= RB3_TENT_KMAX;
+			const bool tentok = TENT && gap != 0 && age >= RB3_TENT_MIN_AGE && hi - lo <= RB3_TENT_KMAX && sid != -2;
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
 			if (wide) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
@@ -628,16 +722,16 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				uint32_t s0 = 0;
 				if (j == 0) s0 = atomicAdd(sidctr, 1u);
 				sid = (int)oct_bcast0(s0, j);
-				if (sid >= RB3_TENT_IDS) sid = RB3_TENT_IDS - 1; // table full: that stretch is never settled -> the host redoes the phase
+				if (sid < 0 || sid >= RB3_TENT_POISON) sid = -2; // table full: this walker stays a plain inexact one
 			}
 			if (TENT && met) { // settle an unknown (rare)
 				const int64_t seen = (int64_t)x;
 				if (!(seen & RB3_TENT)) { // a final value: the unknown of my current stretch
-					if (gap != 0 && sid >= 0 && j == 0) sdel[sid] = 1 + (int)(seen - myval);
+					if (gap != 0 && sid >= 0 && sid != RB3_TENT_POISON && j == 0) sdel[sid] = 1 + (int)(seen - myval);
 				} else {
 					const int id2 = (int)(seen >> 40) & (RB3_TENT_IDS - 1);
 					const int64_t diff = myval - (seen & RB3_TENT_MASK); // both intervals contain ka
-					if (j == 0) {
+					if (j == 0 && id2 != RB3_TENT_POISON) {
 						if (gap == 0) sdel[id2] = 1 + (int)diff;
 						else if (sid >= 0 && id2 != sid) sdep[id2] = RB3_DEP_MAKE(RB3_DEP_LINK, sid, (int32_t)diff), schild[sid] = id2 + 1;
 					}
@@ -654,24 +748,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			const int64_t kn = hi_n - lo_n;
 			const int gap_n = kn > 1 ? 2 : (int)kn;
 			if (TENT && wide && sid >= 0 && !fin && kn >= 1 && kn < hi - lo) {
-				// some of the matching suffixes are not preceded by c: one new stretch per dropped suffix,
-				// highest index first (rare: once per variant among the indexed relatives)
-				const int kk = (int)(hi - lo);
-				for (int itb = (kk - 1) >> 3; itb >= 0; --itb) {
-					const int i = itb * 8 + j;
-					const bool drop = i < kk && idx_sym(b1, lo + i) != (uint32_t)c;
-					uint32_t m8 = (uint32_t)(__ballot(drop) >> (lane & ~7)) & 0xFFu;
-					while (m8) {
-						const int bpos = 31 - __clz((int)m8);
-						m8 &= ~(1u << bpos);
-						uint32_t s0 = 0;
-						if (j == 0) s0 = atomicAdd(sidctr, 1u);
-						int ns = (int)oct_bcast0(s0, j);
-						if (ns >= RB3_TENT_IDS) ns = RB3_TENT_IDS - 1;
-						else if (j == 0) sdep[ns] = RB3_DEP_MAKE(RB3_DEP_EVENT, sid, itb * 8 + bpos), schild[sid] = ns + 1;
-						sid = ns;
-					}
-				}
+				// some of the matching suffixes are not preceded by c (rare: once per variant among the indexed
+				// relatives).  Which ones is in the two slots just used for the ranks: build the mask of dropped
+				// rows, then open one stretch per maximal range of them, highest first.
+				sid = open_drop_stretches<DENSE>(b1, lo, hi, c, j, sid, &evmask[(threadIdx.x >> 3) * 8], sdep, schild, sidctr);
 			}
 			++age;
 			// at the end of its own segment a walker goes on only if it is exact or has tentative records out
@@ -710,8 +790,10 @@ __global__ void __launch_bounds__(256) k_resolve(int32_t *sdel, const uint64_t *
 			if ((int)(dep >> 32 & (RB3_TENT_IDS - 1)) != cur) break; // another follower's link won
 			if (__hip_atomic_load(&sdel[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break; // settled by a walker: its own thread goes on
 			const int32_t arg = (int32_t)(uint32_t)dep;
-			if (dep >> 62 == RB3_DEP_EVENT) d -= (arg < d) ? 1 : 0;
-			else d += arg;
+			if (dep >> 62 == RB3_DEP_EVENT) {
+				const int i0 = arg & 0xFF, len = arg >> 8 & 0x1FF;
+				d = d <= i0 ? d : d < i0 + len ? i0 : d - len;
+			} else d += arg;
 			if (d < 0 || d > RB3_TENT_KMAX) break; // cannot be: leave it unsettled, the host redoes the phase
 			__hip_atomic_store(&sdel[ch], (d + 1) | RB3_TENT_DERIVED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			cur = ch;
@@ -807,6 +889,19 @@ __global__ void __launch_bounds__(256) k_group_rows(const int64_t *pos, int64_t 
 /* The 256 symbols of window [p0, p0+256) of the merged BWT.  Lane t gets positions
  * p0 + 64u + t, u = 0..3, in sym[u]; 7 marks positions past the end.  `j` is the number of
  * B2 rows placed before p0 and is advanced past this window.  One wave per workgroup. */
+#define RB3_REB_WAVES 4   /* waves per block of the window-parallel rebuild kernels */
+#define RB3_REB_WPW   1   /* consecutive windows each of those waves handles (blocks are dispatched at ~2 G/s:
+                             one 64-thread block per window would be bound by that) */
+/* the waves of a rebuild block work independently: LDS traffic between its lanes only needs program order
+ * (the LDS executes a wave's instructions in order), not a workgroup barrier -- and no wait for global
+ * loads in flight, which is what makes the loads of the next stage overlap */
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template<bool FROM_PLAIN>
 __device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
 		int64_t p0, int64_t &j, uint8_t *symbuf, uint32_t sym[4], int lane)
@@ -819,20 +914,75 @@ __device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *po
 		}
 		return;
 	}
+	// the old symbols of the window are consecutive positions of the old index, at most 256 of them: they
+	// lie in at most two of its windows, i.e. two slots, which the wave copies to LDS once (run slots:
+	// plus the start offset of every run) instead of walking directory and slot once per symbol
+	__shared__ uint32_t oslot_[RB3_REB_WAVES][2][32];
+	__shared__ uint16_t ostart_[RB3_REB_WAVES][2][64];
+	__shared__ uint8_t orsym_[RB3_REB_WAVES][2][64];
+	uint32_t (*oslot)[32] = oslot_[threadIdx.x >> 6];
+	uint16_t (*ostart)[64] = ostart_[threadIdx.x >> 6];
+	uint8_t (*orsym)[64] = orsym_[threadIdx.x >> 6];
+	const int64_t a1 = p0 - j;
+	const int64_t w0 = (a1 < 0 ? 0 : a1) >> RB3_WIN_BITS;
+	// round trip 1: the rows that land in this window (pos[]) and the directory entries of the two old windows
+	uint64_t sm[2] = {0, 0};
+	int64_t og[2] = {0, 0};
+	uint32_t olw[2] = {0, 0};
+	bool ohave[2];
+#pragma unroll
+	for (int X = 0; X < 2; ++X) {
+		const int64_t wv = w0 + X;
+		ohave[X] = (wv << RB3_WIN_BITS) < old.n;
+		if (ohave[X]) {
+			og[X] = wv >> (RB3_GRP_BITS - RB3_WIN_BITS), olw[X] = (uint32_t)wv & (RB3_GRP_WINS - 1);
+			sm[X] = old.grp64[og[X] * 8 + 6];
+		}
+	}
+	const int64_t r0 = j + lane < n2 ? pos[j + lane] : INT64_MAX;
 	((uint32_t*)symbuf)[lane] = 0xFFFFFFFFu;
-	__syncthreads();
+	wave_sync();
+	// round trip 2: the two slots and the symbols of those rows
+	const uint32_t *sp[2] = {nullptr, nullptr};
+	uint32_t sw[2] = {0, 0}, ohdr[2] = {0, 0};
+#pragma unroll
+	for (int X = 0; X < 2; ++X)
+		if (ohave[X]) {
+			const uint32_t sidx = (uint32_t)sm[X] + __popc((uint32_t)(sm[X] >> 32) & ((2u << olw[X]) - 1u)) - 1u;
+			sp[X] = (const uint32_t*)(old.slot16 + (int64_t)sidx * 8);
+			sw[X] = sp[X][lane & 31];
+			ohdr[X] = sp[X][0];
+		}
 	int nb2 = 0;
 	for (int u = 0; u < 4; ++u) {
 		const int64_t jj = j + 64 * u + lane;
-		const int64_t r = jj < n2 ? pos[jj] : INT64_MAX;
+		const int64_t r = u == 0 ? r0 : (jj < n2 ? pos[jj] : INT64_MAX);
 		const bool in = r < p0 + RB3_WIN;
 		if (in && r >= p0) symbuf[r - p0] = b2[jj]; // r >= p0 always holds for a valid pos[]; never write outside the window
 		const uint64_t m = __ballot(in);
 		nb2 += __popcll(m);
 		if (m != ~0ull) break;
 	}
-	__syncthreads();
-	const int64_t a1 = p0 - j;
+	int64_t obase[2] = {0, 0};
+#pragma unroll
+	for (int X = 0; X < 2; ++X)
+		if (ohave[X]) {
+			if (lane < 32) oslot[X][lane] = sw[X];
+			obase[X] = (og[X] << RB3_GRP_BITS) + (ohdr[X] & 0xFFFFu);
+			if (ohdr[X] & RB3_SLOT_RLE) { // start offset of every run: prefix sum over the 48 codes
+				uint32_t len = 0, sy = 7;
+				const uint32_t word = __shfl(sw[X], lane < RB3_RLE_CODES ? (lane / 6) * 4 + 1 + (lane % 6) / 2 : 0);
+				if (lane < RB3_RLE_CODES) {
+					const uint32_t code = (lane & 1) ? word >> 16 : word & 0xFFFFu; // lane % 6 and lane have the same parity
+					sy = code & 7u, len = sy == 7u ? 0u : (code >> 3) + 1u;
+				}
+				uint32_t inc = len;
+				for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+				ostart[X][lane] = (uint16_t)((lane < RB3_RLE_CODES && len != 0) ? inc - len : 0xFFFFu); // unused codes start at the end
+				orsym[X][lane] = (uint8_t)sy;
+			}
+		}
+	wave_sync();
 	int before = 0;
 #pragma unroll
 	for (int u = 0; u < 4; ++u) {
@@ -844,12 +994,26 @@ __device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *po
 		if (!isb2) {
 			const int64_t p = p0 + 64 * u + lane;
 			const int64_t i1 = a1 + 64 * u + lane - mine;
-			s = (p < ntot && i1 >= 0 && i1 < old.n) ? idx_sym(old, i1) : 7u; // the range check only matters if pos[] is invalid
+			s = 7u;
+			if (p < ntot && i1 >= 0 && i1 < old.n) { // the range check only matters if pos[] is invalid
+				const int X = (int)((i1 >> RB3_WIN_BITS) - w0) & 1;
+				const uint32_t off = (uint32_t)(i1 - obase[X]);
+				if (!(ohdr[X] & RB3_SLOT_RLE)) {
+					const uint32_t jj = (off >> 5) & 7u, bit = off & 31u;
+					s = ((oslot[X][jj * 4 + 1] >> bit) & 1u) | ((oslot[X][jj * 4 + 2] >> bit) & 1u) << 1 | ((oslot[X][jj * 4 + 3] >> bit) & 1u) << 2;
+				} else { // the last run that starts at or before off
+					int q = 0;
+#pragma unroll
+					for (int d = 32; d >= 1; d >>= 1)
+						if (q + d < RB3_RLE_CODES && ostart[X][q + d] <= off) q += d;
+					s = orsym[X][q];
+				}
+			}
 		}
 		sym[u] = s;
 	}
 	j += nb2;
-	__syncthreads();
+	wave_sync();
 }
 
 /* run heads of a window: H[u] bit t set <=> position 64u+t starts a run */
@@ -1056,13 +1220,17 @@ __global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2
 /* per window: symbols -> statistics (wstat: 6 x u16 counts, first, last, u16 runs = 16 B) and the
  * three bit planes (wplane: 24 dwords, the payload of a bit-plane slot) */
 template<bool FROM_PLAIN>
-__global__ void __launch_bounds__(64) k_pass1w(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
-		const int64_t *jw, uint4 *wstat, uint32_t *wplane, int64_t nwin)
+__global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
+		const int64_t *jw, uint4 *wstat, uint32_t *wplane, uint16_t *wruns, int64_t nwin)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t symbuf[RB3_WIN];
-	__shared__ uint64_t ball[12];
-	const int lane = threadIdx.x;
-	const int64_t w = blockIdx.x;
+	__shared__ __attribute__((aligned(16))) uint8_t symbuf_[RB3_REB_WAVES][RB3_WIN];
+	__shared__ uint64_t ball_[RB3_REB_WAVES][12];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint8_t *symbuf = symbuf_[wave];
+	uint64_t *ball = ball_[wave];
+	for (int t = 0; t < RB3_REB_WPW; ++t) {
+	const int64_t w = ((int64_t)blockIdx.x * RB3_REB_WAVES + wave) * RB3_REB_WPW + t;
+	if (w >= nwin) break;
 	const int64_t p0 = w << RB3_WIN_BITS;
 	int64_t j = FROM_PLAIN ? 0 : jw[w];
 	uint32_t sym[4];
@@ -1090,7 +1258,7 @@ __global__ void __launch_bounds__(64) k_pass1w(IdxView old, const int64_t *pos, 
 		const uint32_t v = lu == 0 ? sym[0] : lu == 1 ? sym[1] : lu == 2 ? sym[2] : sym[3];
 		last = __shfl(v, ll);
 	}
-	__syncthreads();
+	wave_sync();
 	if (lane < 24) wplane[w * 24 + lane] = ((const uint32_t*)ball)[lane];
 	if (lane == 0) {
 		uint4 v;
@@ -1098,6 +1266,29 @@ __global__ void __launch_bounds__(64) k_pass1w(IdxView old, const int64_t *pos, 
 		v.w = nruns | first << 16 | last << 24;
 		wstat[w] = v;
 	}
+	// the first 48 runs as codes (len-1) << 3 | sym: what a run slot is assembled from (a window with more
+	// runs can only become a bit-plane slot)
+	int hb = 0;
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		if (H[u] >> lane & 1ull) {
+			const int r = hb + __popcll(H[u] & ((1ull << lane) - 1ull));
+			if (r < RB3_RLE_CODES) {
+				const uint64_t up = lane == 63 ? 0ull : H[u] >> (lane + 1) << (lane + 1);
+				int nxt = nv;
+				if (up) nxt = 64 * u + (__ffsll((unsigned long long)up) - 1);
+				else {
+					for (int v = u + 1; v < 4; ++v)
+						if (H[v]) { nxt = 64 * v + (__ffsll((unsigned long long)H[v]) - 1); break; }
+				}
+				const int len = nxt - (64 * u + lane);
+				wruns[w * RB3_RLE_CODES + r] = (uint16_t)((uint32_t)(len - 1) << 3 | sym[u]);
+			}
+		}
+		hb += __popcll(H[u]);
+	}
+	wave_sync();
+	} // windows of this wave
 }
 
 /* per group of 32 windows: the slot partition (largest aligned power-of-two window groups with
@@ -1139,102 +1330,98 @@ __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot,
 }
 
 /* per window: emit its slot (bit-plane slots straight from the cached planes; the wave of the first
- * window of a run slot walks the slot's windows and run-length encodes them); window 0 of a group
- * also writes the directory entry */
-__global__ void __launch_bounds__(64) k_pass2w(const uint4 *wstat, const uint32_t *wplane, int64_t ntot, const uint32_t *gstat,
+ * window of a run slot gathers the slot's <= 48 codes from the run lists of its windows, one lane per
+ * code, merging runs that continue across window boundaries); window 0 of a group also writes the
+ * directory entry */
+__global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wstat, const uint32_t *wplane, const uint16_t *wruns, int64_t ntot, const uint32_t *gstat,
 		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin)
 {
-	__shared__ uint32_t csym[RB3_RLE_CODES + 16], clen[RB3_RLE_CODES + 16];
-	__shared__ uint32_t code16[RB3_RLE_CODES / 2];
-	const int lane = threadIdx.x;
-	const int64_t w = blockIdx.x, g = w >> 5;
-	const int lw = (int)(w & 31);
+	__shared__ uint32_t sP_[RB3_REB_WAVES][RB3_GRP_WINS + 1], sB_[RB3_REB_WAVES][RB3_GRP_WINS], sNr_[RB3_REB_WAVES][RB3_GRP_WINS];
+	__shared__ uint32_t code16_[RB3_REB_WAVES][RB3_RLE_CODES / 2];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t *sP = sP_[wave], *sB = sB_[wave], *sNr = sNr_[wave], *code16 = code16_[wave];
+	const int64_t g = blockIdx.x; // one block per group, each wave takes a quarter of its windows
 	const int nvw = (int)(nwin - g * RB3_GRP_WINS < RB3_GRP_WINS ? nwin - g * RB3_GRP_WINS : RB3_GRP_WINS);
 	const uint32_t mask = gstat[g * 8 + 7];
 	const uint64_t slot0 = gpre[g * 8 + 6];
-	if (lw == 0 && lane == 0) {
+	if (threadIdx.x == 0) {
 		rb3_grp_t e;
 		uint64_t c = 0;
 		for (int a = 0; a < 6; ++a) { e.cnt[a] = c + gpre[g * 8 + a]; c += tot[a]; }
 		e.slot0 = (uint32_t)slot0, e.mask = mask, e.spare = 0;
 		grp[g] = e;
 	}
-	if (!(mask >> lw & 1u)) return; // not the first window of a slot
-	const int64_t sidx = (int64_t)slot0 + __popc(mask & ((2u << lw) - 1u)) - 1;
-	const uint32_t above = lw == 31 ? 0u : mask >> (lw + 1);
-	const int slot_sz = (above ? lw + 1 + (__ffs(above) - 1) : nvw) - lw;
-	// symbol counts of the group's windows before this slot
-	uint4 st = make_uint4(0, 0, 0, 0);
-	if (lane < lw) st = wstat[g * RB3_GRP_WINS + lane];
-	uint64_t s0 = (uint64_t)(st.x & 0xFFFFu) | (uint64_t)(st.x >> 16) << 20 | (uint64_t)(st.y & 0xFFFFu) << 40;
-	uint64_t s1 = (uint64_t)(st.y >> 16) | (uint64_t)(st.z & 0xFFFFu) << 20 | (uint64_t)(st.z >> 16) << 40;
-	for (int d = 16; d >= 1; d >>= 1) s0 += __shfl_xor(s0, d), s1 += __shfl_xor(s1, d);
-	const uint32_t rel[6] = { (uint32_t)(s0 & 0xFFFFF), (uint32_t)(s0 >> 20 & 0xFFFFF), (uint32_t)(s0 >> 40),
-	                          (uint32_t)(s1 & 0xFFFFF), (uint32_t)(s1 >> 20 & 0xFFFFF), (uint32_t)(s1 >> 40) };
-	const int64_t srem = ntot - (w << RB3_WIN_BITS);
-	const uint32_t nsym = srem <= 0 ? 0u : srem < (int64_t)slot_sz * RB3_WIN ? (uint32_t)srem : (uint32_t)(slot_sz * RB3_WIN);
-	const uint32_t hq = lane == 0 ? (uint32_t)(lw * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
-		lane == 1 ? rel[0] : lane == 2 ? rel[1] : lane == 3 ? rel[2] : lane == 4 ? rel[3] : lane == 5 ? rel[4] :
-		lane == 6 ? rel[5] : nsym;
-	if (slot_sz == 1) { // bit-plane slot: header + the cached planes
+	for (int lw = wave * (RB3_GRP_WINS / RB3_REB_WAVES); lw < (wave + 1) * (RB3_GRP_WINS / RB3_REB_WAVES) && lw < nvw; ++lw) {
+		if (!(mask >> lw & 1u)) continue; // not the first window of a slot
+		const int64_t w = g * RB3_GRP_WINS + lw;
+		const int64_t sidx = (int64_t)slot0 + __popc(mask & ((2u << lw) - 1u)) - 1;
+		const uint32_t above = lw == 31 ? 0u : mask >> (lw + 1);
+		const int slot_sz = (above ? lw + 1 + (__ffs(above) - 1) : nvw) - lw;
+		// symbol counts of the group's windows before this slot
+		uint4 st = make_uint4(0, 0, 0, 0);
+		if (lane < lw) st = wstat[g * RB3_GRP_WINS + lane];
+		uint64_t s0 = (uint64_t)(st.x & 0xFFFFu) | (uint64_t)(st.x >> 16) << 20 | (uint64_t)(st.y & 0xFFFFu) << 40;
+		uint64_t s1 = (uint64_t)(st.y >> 16) | (uint64_t)(st.z & 0xFFFFu) << 20 | (uint64_t)(st.z >> 16) << 40;
+		for (int d = 16; d >= 1; d >>= 1) s0 += __shfl_xor(s0, d), s1 += __shfl_xor(s1, d);
+		const uint32_t rel[6] = { (uint32_t)(s0 & 0xFFFFF), (uint32_t)(s0 >> 20 & 0xFFFFF), (uint32_t)(s0 >> 40),
+		                          (uint32_t)(s1 & 0xFFFFF), (uint32_t)(s1 >> 20 & 0xFFFFF), (uint32_t)(s1 >> 40) };
+		const int64_t srem = ntot - (w << RB3_WIN_BITS);
+		const uint32_t nsym = srem <= 0 ? 0u : srem < (int64_t)slot_sz * RB3_WIN ? (uint32_t)srem : (uint32_t)(slot_sz * RB3_WIN);
+		const uint32_t hq = lane == 0 ? (uint32_t)(lw * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
+			lane == 1 ? rel[0] : lane == 2 ? rel[1] : lane == 3 ? rel[2] : lane == 4 ? rel[3] : lane == 5 ? rel[4] :
+			lane == 6 ? rel[5] : nsym;
+		if (slot_sz == 1) { // bit-plane slot: header + the cached planes
+			if (lane < 8) {
+				const uint32_t *pl = wplane + w * 24;
+				uint4 v;
+				v.x = hq;
+				v.y = pl[(lane >> 1) * 6 + 0 + (lane & 1)];
+				v.z = pl[(lane >> 1) * 6 + 2 + (lane & 1)];
+				v.w = pl[(lane >> 1) * 6 + 4 + (lane & 1)];
+				slot16[sidx * 8 + lane] = v;
+			}
+			continue;
+		}
+		// run slot.  Lane k < slot_sz looks at window k: it contributes its runs minus the first one if that
+		// continues the last run of the window before (same test as k_decide).
+		uint4 sw = make_uint4(0, 0, 0, 7u << 16 | 7u << 24);
+		if (lane < slot_sz) sw = wstat[w + lane];
+		const uint32_t nr = sw.w & 0xFFFFu, wfirst = sw.w >> 16 & 0xFFu, wlast = sw.w >> 24;
+		const uint32_t prev_last = __shfl_up(wlast, 1);
+		const uint32_t bm = (lane > 0 && lane < slot_sz && nr > 0 && prev_last == wfirst) ? 1u : 0u;
+		const uint32_t e = lane < slot_sz ? nr - bm : 0u;
+		uint32_t inc = e;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+		const int nc = (int)__shfl(inc, 63);
+		if (lane < RB3_GRP_WINS) sP[lane] = lane < slot_sz ? inc - e : 0xFFFFu, sB[lane] = bm, sNr[lane] = nr;
+		if (lane == 0) sP[RB3_GRP_WINS] = 0xFFFFu;
+		wave_sync();
+		if (lane < RB3_RLE_CODES) {
+			uint32_t code = 7u;
+			if (lane < nc) {
+				int k = 0; // the last window whose first code is at or before this lane's
+#pragma unroll
+				for (int d = 16; d >= 1; d >>= 1)
+					if (k + d < slot_sz && sP[k + d] <= (uint32_t)lane) k += d;
+				const uint32_t r = (uint32_t)lane - sP[k] + sB[k];
+				const uint32_t c0 = wruns[(w + k) * RB3_RLE_CODES + r];
+				uint32_t len = (c0 >> 3) + 1u;
+				if (r == sNr[k] - 1u) // the window's last run may go on through the following windows
+					for (int kk = k + 1; kk < slot_sz && sB[kk]; ++kk) {
+						len += ((uint32_t)wruns[(w + kk) * RB3_RLE_CODES] >> 3) + 1u;
+						if (sNr[kk] > 1u) break;
+					}
+				code = (len - 1u) << 3 | (c0 & 7u);
+			}
+			((uint16_t*)code16)[lane] = (uint16_t)code;
+		}
+		wave_sync();
 		if (lane < 8) {
-			const uint32_t *pl = wplane + w * 24;
 			uint4 v;
-			v.x = hq;
-			v.y = pl[(lane >> 1) * 6 + 0 + (lane & 1)];
-			v.z = pl[(lane >> 1) * 6 + 2 + (lane & 1)];
-			v.w = pl[(lane >> 1) * 6 + 4 + (lane & 1)];
+			v.x = hq, v.y = code16[lane * 3], v.z = code16[lane * 3 + 1], v.w = code16[lane * 3 + 2];
 			slot16[sidx * 8 + lane] = v;
 		}
-		return;
-	}
-	int nc = 0;
-	for (int k = 0; k < slot_sz; ++k) { // run slot: append the runs of each window, merging across window boundaries
-		const uint32_t *pl = wplane + (w + k) * 24;
-		uint32_t sym[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const int wi = u * 6 + (lane >> 5), bit = lane & 31;
-			sym[u] = (pl[wi] >> bit & 1u) | (pl[wi + 2] >> bit & 1u) << 1 | (pl[wi + 4] >> bit & 1u) << 2;
-		}
-		uint64_t H[4];
-		window_heads(sym, lane, H);
-		const int64_t rem = ntot - ((w + k) << RB3_WIN_BITS);
-		const int nv = rem >= RB3_WIN ? RB3_WIN : rem > 0 ? (int)rem : 0;
-		const int nr = __popcll(H[0]) + __popcll(H[1]) + __popcll(H[2]) + __popcll(H[3]);
-		const uint32_t fs = __shfl(sym[0], 0);
-		const int mg = (nc > 0 && nr > 0 && csym[nc - 1] == fs) ? 1 : 0;
-		int hb = 0;
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			if (H[u] >> lane & 1ull) {
-				const int r = hb + __popcll(H[u] & ((1ull << lane) - 1ull));
-				const uint64_t up = lane == 63 ? 0ull : H[u] >> (lane + 1) << (lane + 1);
-				int nxt = nv;
-				if (up) nxt = 64 * u + (__ffsll((unsigned long long)up) - 1);
-				else {
-					for (int v = u + 1; v < 4; ++v)
-						if (H[v]) { nxt = 64 * v + (__ffsll((unsigned long long)H[v]) - 1); break; }
-				}
-				const int len = nxt - (64 * u + lane);
-				const int idx = nc + r - mg;
-				if (r == 0 && mg) clen[idx] += (uint32_t)len;
-				else csym[idx] = sym[u], clen[idx] = (uint32_t)len;
-			}
-			hb += __popcll(H[u]);
-		}
-		nc += nr - mg;
-		__syncthreads();
-	}
-	if (lane < RB3_RLE_CODES) {
-		const uint32_t code = lane < nc ? ((clen[lane] - 1u) << 3 | csym[lane]) : 7u;
-		((uint16_t*)code16)[lane] = (uint16_t)code;
-	}
-	__syncthreads();
-	if (lane < 8) {
-		uint4 v;
-		v.x = hq, v.y = code16[lane * 3], v.z = code16[lane * 3 + 1], v.w = code16[lane * 3 + 2];
-		slot16[sidx * 8 + lane] = v;
+		wave_sync();
 	}
 }
 

@@ -8,6 +8,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 4400000
+NOREF = "--no-ref" in sys.argv
+if NOREF: sys.argv.remove("--no-ref")
 out = sys.argv[3] if len(sys.argv) > 3 else "/tmp/e2e_mtb"
 os.makedirs(out, exist_ok=True)
 ALPH = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -44,11 +46,12 @@ def run(name, cmd):
     return r.stdout, err
 amd = os.path.join(ROOT, "ropebwt3_amd", "ropebwt3-amd")
 ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
-a, ea = run("amd one-file-per-batch", [amd, "build", "-d"] + files)
+a, ea = (run("amd one-file-per-batch", [amd, "build", "-d"] + files) if not NOREF else (None, None))
 b, eb = run("amd -p16 (16 sorter threads)", [amd, "build", "-d", "-p16"] + files)
 c2, _ = run("amd --rebatch -m40m -p4", [amd, "build", "-d", "--rebatch", "-m40m", "-p4"] + files)
+if NOREF: a = b
 print("amd variants identical:", a == b and a == c2)
-if os.path.exists(ref):
+if os.path.exists(ref) and not NOREF:
     c, ec = run("reference -t%d" % (os.cpu_count() or 8), [ref, "build", "-d", "-t%d" % min(64, os.cpu_count() or 8)] + files)
     print("IDENTICAL to reference:", a == c)
     # reference merge-only seconds: t("inserted") - t(preceding "constructed partial BWT")

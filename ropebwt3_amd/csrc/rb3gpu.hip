@@ -49,7 +49,7 @@ struct rb3gpu_s {
 	int64_t bytes_owned = 0;
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
-	int64_t sid_dirty = RB3_TENT_IDS; // entries of the stretch tables (dl) that may be non-zero
+	int64_t sid_dirty[2] = {RB3_TENT_HALF, RB3_TENT_HALF}; // entries of the two halves of the stretch tables (dl) that may be non-zero
 };
 
 static double now_s(void)
@@ -102,30 +102,31 @@ static float ev_ms(hipEvent_t a, hipEvent_t b)
 	return ms;
 }
 
-/* tables of the tentative stretches (k_chain): dependency words, settled unknowns, dependents */
-struct TentTab { uint64_t *sdep; int32_t *sdel, *schild; };
-
-static int tent_prepare(rb3gpu_t *h, TentTab &t)
+/* table of the tentative stretches (k_chain): one 64-byte record each, followed by the compact array
+ * of settled unknowns (sfin, int32 per stretch) that k_resolve fills for k_pos_finalize_check */
+static int tent_prepare(rb3gpu_t *h, rb3_stretch_t **tab, int32_t **sfin)
 {
-	const size_t bytes = (size_t)RB3_TENT_IDS * 16;
+	const size_t bytes = (size_t)RB3_TENT_IDS * (sizeof(rb3_stretch_t) + 4);
 	const bool fresh = !(h->dl.p && h->dl.cap >= bytes);
 	int r;
 	if ((r = buf_ensure(h, h->dl, bytes)) < 0) return r;
-	t.sdep = (uint64_t*)h->dl.p, t.sdel = (int32_t*)(t.sdep + RB3_TENT_IDS), t.schild = t.sdel + RB3_TENT_IDS;
-	const int64_t dirty = fresh ? RB3_TENT_IDS : h->sid_dirty;
-	if (dirty >= RB3_TENT_IDS / 2) HIPCHK(hipMemsetAsync(h->dl.p, 0, bytes, h->st));
-	else if (dirty > 0) {
-		HIPCHK(hipMemsetAsync(t.sdep, 0, (size_t)dirty * 8, h->st));
-		HIPCHK(hipMemsetAsync(t.sdel, 0, (size_t)dirty * 4, h->st));
-		HIPCHK(hipMemsetAsync(t.schild, 0, (size_t)dirty * 4, h->st));
-	}
-	h->sid_dirty = RB3_TENT_IDS; // until the number of stretches this merge opens has been read back
+	rb3_stretch_t *t = *tab = (rb3_stretch_t*)h->dl.p;
+	int32_t *f = *sfin = (int32_t*)(t + RB3_TENT_IDS);
+	// zero what the previous merge used: the blocks at the bottom of the table, the single ids from the middle up
+	const int64_t da = fresh ? RB3_TENT_HALF : h->sid_dirty[0], db = fresh ? RB3_TENT_HALF : h->sid_dirty[1];
+	if (da > 0) HIPCHK(hipMemsetAsync(t, 0, (size_t)da * sizeof(rb3_stretch_t), h->st));
+	if (da > 0) HIPCHK(hipMemsetAsync(f, 0, (size_t)da * 4, h->st));
+	if (db > 0) HIPCHK(hipMemsetAsync(t + RB3_TENT_HALF, 0, (size_t)db * sizeof(rb3_stretch_t), h->st));
+	if (db > 0) HIPCHK(hipMemsetAsync(f + RB3_TENT_HALF, 0, (size_t)db * 4, h->st));
+	h->sid_dirty[0] = h->sid_dirty[1] = RB3_TENT_HALF; // until the number of stretches this merge opens has been read back
 	return 0;
 }
 
-static void tent_used(rb3gpu_t *h, unsigned long long sidctr)
+static void tent_used(rb3gpu_t *h, unsigned long long sidctr) // the two 32-bit counters of misc[5]
 {
-	h->sid_dirty = sidctr < (unsigned long long)RB3_TENT_IDS ? (int64_t)sidctr : RB3_TENT_IDS;
+	const unsigned long long a = sidctr & 0xFFFFFFFFull, b = sidctr >> 32;
+	h->sid_dirty[0] = a < (unsigned long long)RB3_TENT_HALF ? (int64_t)a : RB3_TENT_HALF;
+	h->sid_dirty[1] = b < (unsigned long long)RB3_TENT_HALF ? (int64_t)b : RB3_TENT_HALF;
 }
 
 static IdxView view_of(const rb3gpu_t *h)
@@ -457,9 +458,10 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 	// tentative records need merged positions < 2^40
 	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
 	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= (1LL << 40) || stop_row >= 0) tent = 0;
-	TentTab tt = {nullptr, nullptr, nullptr};
+	rb3_stretch_t *tab = nullptr;
+	int32_t *sfin = nullptr;
 	uint32_t *sidctr = (uint32_t*)(qhead + 5);
-	if (tent && (r = tent_prepare(h, tt)) < 0) return r;
+	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
 	HIPCHK(hipMemsetAsync(qhead, 0, 8, h->st));
 	HIPCHK(hipMemsetAsync(sidctr, 0, 8, h->st));
 	// octets per wave: all 8 when there are enough walkers to fill the chip (256 CUs x 32 waves), fewer
@@ -475,7 +477,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 		const int64_t sr = stop_row < 0 ? -1 : stop_row;
 		const dim3 grid((unsigned)nblk), blk(256);
 #define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
-			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tt.sdel, tt.sdep, tt.schild, sidctr)
+			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tab, sidctr)
 		const int sel = (walkers ? 4 : 0) | (iv.dense ? 2 : 0) | (tent ? 1 : 0);
 		switch (sel) {
 		case 0: RB3_LAUNCH_CHAIN(false, false, false); break;
@@ -490,8 +492,9 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 #undef RB3_LAUNCH_CHAIN
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
-			hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, h->st, tt.sdel, (const uint64_t*)tt.sdep, (const int32_t*)tt.schild, (const uint32_t*)sidctr);
-			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, h->mg_pos, len, (const int32_t*)tt.sdel, qhead + 2);
+			hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, (const uint32_t*)sidctr);
+			hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, h->mg_pos, len, (const int32_t*)sfin, qhead + 2);
 		}
 	}
 	HIPCHK(hipEventRecord(h->ev[5], h->st));
@@ -606,8 +609,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
 	if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
-	TentTab tt = {nullptr, nullptr, nullptr};
-	if (tent && (r = tent_prepare(h, tt)) < 0) return r;
+	rb3_stretch_t *tab = nullptr;
+	int32_t *sfin = nullptr;
+	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, nwin)) < 0) return r;
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	Walker *dwl = (Walker*)h->wl.p;
@@ -641,7 +645,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		const dim3 grid((unsigned)nblk), blk(256);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tt.sdel, tt.sdep, tt.schild, sidctr)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr)
 		if (iv.dense && tent) RB3_LAUNCH_FAST(true, true);
 		else if (iv.dense) RB3_LAUNCH_FAST(true, false);
 		else if (tent) RB3_LAUNCH_FAST(false, true);
@@ -649,8 +653,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #undef RB3_LAUNCH_FAST
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
-			hipLaunchKernelGGL(k_resolve, dim3(1024), dim3(256), 0, h->st, tt.sdel, (const uint64_t*)tt.sdep, (const int32_t*)tt.schild, (const uint32_t*)sidctr);
-			hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)tt.sdel, misc + 2);
+			hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, (const uint32_t*)sidctr);
+			hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+			hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2);
 		} else
 			hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, len, ntot, misc + 2);
 	}

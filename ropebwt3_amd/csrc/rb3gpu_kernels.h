@@ -527,12 +527,31 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 #ifndef RB3_TENT_MIN_AGE
 #define RB3_TENT_MIN_AGE 64u
 #endif
-/* sdep[sid]: how the unknown of a stretch follows from another one */
-#define RB3_DEP_EVENT 1ull            /* rows [i0, i0 + len) of the interval dropped out, arg = i0 | len << 8:
-                                         d = d(prev) if d(prev) <= i0, i0 if d(prev) < i0 + len, else d(prev) - len */
-#define RB3_DEP_LINK  2ull            /* d = d(prev) + (int32)arg */
-#define RB3_TENT_DERIVED 0x10000     /* sdel[]: value derived by k_resolve, not settled by a walker */
-#define RB3_DEP_MAKE(type, prev, arg) ((uint64_t)(type) << 62 | (uint64_t)(uint32_t)(prev) << 32 | (uint64_t)(uint32_t)(arg))
+/* One 64-byte record per stretch, so that following a dependency path costs one memory round trip per
+ * stretch (k_resolve).  w0, w1: how the unknown of the stretch follows from another one.
+ *   w0 = type << 62 | previous stretch << 40 | lo (EVENT only)
+ *   EVENT: some rows of the previous stretch's interval [lo, lo + kk) do not hold c and dropped out;
+ *          w1 = kk | c << 8.  k_events turns that into the 256-bit mask of the dropped
+ *          rows (the walker itself only notes the event: three stores, no loads), and
+ *          d = d(prev) - #{dropped rows with index < d(prev)}
+ *   LINK:  d = d(prev) + (int32)w1
+ * del: 0 = unknown, else 1 + d as settled by a walker; child: 1 + the stretch that depends on this one
+ * (there is at most one), 0 = none. */
+typedef struct {
+	uint64_t w0, w1;
+	int32_t del, child;
+	uint32_t mask[8];
+	uint32_t pad[2];
+} rb3_stretch_t; /* 64 bytes; the first 24 must be zero before a merge */
+#define RB3_DEP_EVENT 1ull
+#define RB3_DEP_LINK  2ull
+#define RB3_DEP_W0(type, prev, lo) ((uint64_t)(type) << 62 | (uint64_t)(uint32_t)(prev) << 40 | (uint64_t)(lo))
+#define RB3_DEP_PREV(w0) ((int)((w0) >> 40) & (RB3_TENT_IDS - 1))
+#define RB3_TENT_BLOCK 16            /* walkers with several matching suffixes get their stretch ids in aligned blocks of
+                                        this many, from the lower half of the table (counter sidctr[0]); walkers with a
+                                        unique match never see a drop-out and take single ids from the upper half
+                                        (counter sidctr[1]) */
+#define RB3_TENT_HALF (RB3_TENT_IDS / 2)
 
 template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t v, bool vis)
 {
@@ -586,59 +605,45 @@ __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, 
 	}
 }
 
-template<bool DENSE>
-__device__ __forceinline__ int open_drop_stretches(const IdxView &ix, int64_t lo, int64_t hi, int c, int j, int sid,
-		uint32_t *D, uint64_t *sdep, int32_t *schild, uint32_t *sidctr)
+/* mask[j] of every EVENT stretch: the rows of [lo, lo + kk) that do not hold c (one octet per stretch).
+ * The two slots that hold the rows are those of lo and of lo + kk. */
+__global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, const uint32_t *sidctr)
 {
-	const int kk = (int)(hi - lo);
-	D[j] = 0u;
-	__builtin_amdgcn_wave_barrier();
-	// the two slots were in registers a moment ago (the ranks of lo and hi); they are fetched again here
-	// (cache hits) so that the hot loop does not have to keep them alive for this rare case
+	__shared__ uint32_t dmask[32 * 8];
+	const int j = threadIdx.x & 7;
+	uint32_t *D = &dmask[(threadIdx.x >> 3) * 8];
+	const int64_t n = *sidctr < (uint32_t)RB3_TENT_HALF ? *sidctr : RB3_TENT_HALF; // events only happen to ids from blocks
+	for (int64_t sid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; sid < n; sid += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+		const uint64_t w0 = tab[sid].w0;
+		if (w0 >> 62 != RB3_DEP_EVENT) continue;
+		const uint64_t w1 = tab[sid].w1;
+		const int64_t lo = (int64_t)(w0 & (uint64_t)RB3_TENT_MASK);
+		const int kk = (int)(w1 & 0xFF), c = (int)(w1 >> 8 & 7);
+		D[j] = 0u;
+		__builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-	for (int which = 0; which < 2; ++which) {
-		const int64_t k = which ? hi : lo;
-		const uint32_t koff = (uint32_t)k & (RB3_GRP - 1);
-		int64_t s;
-		if (DENSE) s = k >> RB3_WIN_BITS;
-		else {
+		for (int which = 0; which < 2; ++which) {
+			const int64_t k = which ? lo + kk : lo;
+			if (k > ix.n) continue;
+			const uint32_t koff = (uint32_t)k & (RB3_GRP - 1);
 			const uint64_t sm = ix.grp64[(k >> RB3_GRP_BITS) * 8 + 6];
-			s = (int64_t)((uint32_t)sm + __popc((uint32_t)(sm >> 32) & ((2u << (koff >> RB3_WIN_BITS)) - 1u)) - 1u);
+			const int64_t s = (int64_t)((uint32_t)sm + __popc((uint32_t)(sm >> 32) & ((2u << (koff >> RB3_WIN_BITS)) - 1u)) - 1u);
+			const uint4 sl = ix.slot16[s * 8 + j];
+			const uint32_t hdr0 = oct_bcast0(sl.x, j);
+			drops_from_slot(sl, hdr0, (int)koff - (int)(hdr0 & 0xFFFFu) - (which ? kk : 0), kk, c, j, D);
 		}
-		const uint4 sl = ix.slot16[s * 8 + j];
-		const uint32_t hdr0 = oct_bcast0(sl.x, j);
-		drops_from_slot(sl, hdr0, (int)koff - (int)(hdr0 & 0xFFFFu) - (which ? kk : 0), kk, c, j, D);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		tab[sid].mask[j] = D[j];
+		__builtin_amdgcn_wave_barrier();
 	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	const uint32_t mine = D[j];
-	const uint32_t nrange = oct_sum(__popc(mine & ~(mine << 1)));
-	uint32_t s0 = 0;
-	if (j == 0) s0 = atomicAdd(sidctr, nrange);
-	const uint32_t base = oct_bcast0(s0, j);
-	if (base + nrange > (uint32_t)RB3_TENT_POISON || base + nrange < base) return RB3_TENT_POISON; // table full: records from here on stay unsettled, the host redoes the phase
-	uint32_t idx = 0;
-	for (int itb = 7; itb >= 0; --itb) {
-		uint32_t w = D[itb];
-		while (w) {
-			const int bpos = 31 - __clz((int)w);
-			const int len = __clz((int)~(w << (31 - bpos)));
-			const int i0 = itb * 32 + bpos - len + 1;
-			const int ns = (int)(base + idx);
-			if (j == 0) sdep[ns] = RB3_DEP_MAKE(RB3_DEP_EVENT, sid, i0 | len << 8), schild[sid] = ns + 1;
-			sid = ns, ++idx;
-			w &= ~((len >= 32 ? 0xFFFFFFFFu : (1u << len) - 1u) << (bpos - len + 1));
-		}
-	}
-	return sid;
 }
 
 template<bool LIST, bool DENSE, bool TENT>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		int32_t *sdel, uint64_t *sdep, int32_t *schild, uint32_t *sidctr)
+		rb3_stretch_t *tab, uint32_t *sidctr)
 {
-	__shared__ uint32_t evmask[TENT ? 32 * 8 : 1]; // per octet: the rows of [lo, hi) that drop out at a step
 	const int lane = threadIdx.x & 63, j = lane & 7;
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
 	// it hosts: the host may enable only the first `octs` octets of each wave and launch more waves.
@@ -720,20 +725,21 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			const int64_t myval = lo + kb;
 			if (TENT && tentok && !met && sid < 0) { // first tentative record of this walker: open a stretch (rare)
 				uint32_t s0 = 0;
-				if (j == 0) s0 = atomicAdd(sidctr, 1u);
-				sid = (int)oct_bcast0(s0, j);
-				if (sid < 0 || sid >= RB3_TENT_POISON) sid = -2; // table full: this walker stays a plain inexact one
+				if (j == 0) s0 = gap == 1 ? atomicAdd(sidctr + 1, 1u) : atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
+				s0 = oct_bcast0(s0, j);
+				if (gap == 1) sid = s0 < (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF) ? (int)(RB3_TENT_HALF + s0) : -2; // table full: this walker stays a plain inexact one
+				else sid = s0 <= (uint32_t)(RB3_TENT_HALF - RB3_TENT_BLOCK) ? (int)s0 : -2;
 			}
 			if (TENT && met) { // settle an unknown (rare)
 				const int64_t seen = (int64_t)x;
 				if (!(seen & RB3_TENT)) { // a final value: the unknown of my current stretch
-					if (gap != 0 && sid >= 0 && sid != RB3_TENT_POISON && j == 0) sdel[sid] = 1 + (int)(seen - myval);
+					if (gap != 0 && sid >= 0 && sid != RB3_TENT_POISON && j == 0) tab[sid].del = 1 + (int)(seen - myval);
 				} else {
 					const int id2 = (int)(seen >> 40) & (RB3_TENT_IDS - 1);
 					const int64_t diff = myval - (seen & RB3_TENT_MASK); // both intervals contain ka
 					if (j == 0 && id2 != RB3_TENT_POISON) {
-						if (gap == 0) sdel[id2] = 1 + (int)diff;
-						else if (sid >= 0 && id2 != sid) sdep[id2] = RB3_DEP_MAKE(RB3_DEP_LINK, sid, (int32_t)diff), schild[sid] = id2 + 1;
+						if (gap == 0) tab[id2].del = 1 + (int)diff;
+						else if (sid >= 0 && id2 != sid) tab[id2].w0 = RB3_DEP_W0(RB3_DEP_LINK, sid, 0), tab[id2].w1 = (uint64_t)(uint32_t)(int32_t)diff, tab[sid].child = id2 + 1;
 					}
 				}
 			}
@@ -748,10 +754,23 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			const int64_t kn = hi_n - lo_n;
 			const int gap_n = kn > 1 ? 2 : (int)kn;
 			if (TENT && wide && sid >= 0 && !fin && kn >= 1 && kn < hi - lo) {
-				// some of the matching suffixes are not preceded by c (rare: once per variant among the indexed
-				// relatives).  Which ones is in the two slots just used for the ranks: build the mask of dropped
-				// rows, then open one stretch per maximal range of them, highest first.
-				sid = open_drop_stretches<DENSE>(b1, lo, hi, c, j, sid, &evmask[(threadIdx.x >> 3) * 8], sdep, schild, sidctr);
+				// some of the matching suffixes are not preceded by c (once per variant among the indexed relatives):
+				// the rows to come belong to a new stretch.  Only note what happened -- which rows dropped out is
+				// worked out by k_events afterwards, for all events of the launch at once.
+				int ns = sid + 1;
+				if (sid == RB3_TENT_POISON) ns = RB3_TENT_POISON;
+				else if ((ns & (RB3_TENT_BLOCK - 1)) == 0) { // this walker's block of ids is used up (rare)
+					uint32_t s0 = 0;
+					if (j == 0) s0 = atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
+					s0 = oct_bcast0(s0, j);
+					// table full: the records from here on stay unsettled and the host redoes the phase
+					ns = s0 <= (uint32_t)(RB3_TENT_HALF - RB3_TENT_BLOCK) ? (int)s0 : RB3_TENT_POISON;
+				}
+				if (j == 0 && ns != RB3_TENT_POISON) {
+					tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = (uint64_t)(hi - lo) | (uint64_t)c << 8;
+					tab[sid].child = ns + 1;
+				}
+				sid = ns;
 			}
 			++age;
 			// at the end of its own segment a walker goes on only if it is exact or has tentative records out
@@ -774,29 +793,49 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 
 /* settle the unknowns of all stretches.  A stretch has at most one dependent: the next stretch of
  * the same walker (EVENT) or, for the walker's last one, the first stretch of the walker it ran
- * into (LINK) -- the dependencies form simple paths.  One thread per stretch that a walker settled
- * walks its path forwards until the next such stretch.  sdel[s] becomes (1 + d) | RB3_TENT_DERIVED. */
-__global__ void __launch_bounds__(256) k_resolve(int32_t *sdel, const uint64_t *sdep, const int32_t *schild, const uint32_t *sidctr)
+ * into (LINK) -- the dependencies form simple paths.  One group of 16 lanes per stretch that a walker
+ * settled follows its path forwards until the next such stretch.  The stretches of one walker are
+ * consecutive ids inside aligned blocks of 16, so the group fetches a block at a time (one record per
+ * lane) and steps through it with shuffles: one memory round trip per block instead of one per stretch.
+ * sfin[s] = 1 + d for every stretch that got settled, walker-settled ones included (a compact copy for
+ * k_pos_finalize_check; the records are 64 bytes apart). */
+__global__ void __launch_bounds__(256) k_resolve(rb3_stretch_t *tab, const uint32_t *sidctr, int32_t *sfin)
 {
-	const int64_t n = *sidctr < (uint32_t)RB3_TENT_IDS ? *sidctr : RB3_TENT_IDS;
-	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-		const int r = __hip_atomic_load(&sdel[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (r <= 0 || (r & RB3_TENT_DERIVED)) continue;
-		int d = r - 1, cur = (int)i;
-		for (;;) {
-			const int ch = schild[cur] - 1;
-			if (ch < 0 || ch >= n) break;
-			const uint64_t dep = sdep[ch];
-			if ((int)(dep >> 32 & (RB3_TENT_IDS - 1)) != cur) break; // another follower's link won
-			if (__hip_atomic_load(&sdel[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break; // settled by a walker: its own thread goes on
-			const int32_t arg = (int32_t)(uint32_t)dep;
-			if (dep >> 62 == RB3_DEP_EVENT) {
-				const int i0 = arg & 0xFF, len = arg >> 8 & 0x1FF;
-				d = d <= i0 ? d : d < i0 + len ? i0 : d - len;
-			} else d += arg;
-			if (d < 0 || d > RB3_TENT_KMAX) break; // cannot be: leave it unsettled, the host redoes the phase
-			__hip_atomic_store(&sdel[ch], (d + 1) | RB3_TENT_DERIVED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			cur = ch;
+	const int gl = threadIdx.x & 15;
+	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF, nb = sidctr[1] < (uint32_t)RB3_TENT_HALF ? sidctr[1] : RB3_TENT_HALF;
+	for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; t < na + nb; t += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+		const int64_t i = t < na ? t : RB3_TENT_HALF + (t - na);
+		const int r = tab[i].del;
+		if (r <= 0) continue; // only stretches a walker settled start a path
+		if (gl == 0) sfin[i] = r;
+		int d = r - 1, cur = (int)i, ch = tab[i].child - 1, hops = 0;
+		bool go = true;
+		while (go && ch >= 0 && ch < RB3_TENT_IDS && ++hops <= RB3_TENT_IDS) { // (the hop limit only guards against a corrupt table)
+			const int base = ch & ~(RB3_TENT_BLOCK - 1);
+			const uint4 *rp = (const uint4*)&tab[base + gl]; // lane gl: record base + gl
+			const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+			const uint32_t mw[8] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y };
+			for (int o = ch & (RB3_TENT_BLOCK - 1); ; ) {
+				const uint32_t w0hi = __shfl(q0.y, o, 16);
+				const int del = (int)__shfl(q1.x, o, 16), next = (int)__shfl(q1.y, o, 16) - 1;
+				if ((int)(w0hi >> 8 & (RB3_TENT_IDS - 1)) != cur || del != 0) { go = false; break; } // another follower's link won / settled by a walker
+				// every lane applies ITS record to d; the one of lane o counts
+				int nd;
+				if (w0hi >> 30 == RB3_DEP_EVENT) { // the dropped rows below d no longer count
+					int below = 0;
+#pragma unroll
+					for (int q = 0; q < 8; ++q) {
+						const int tt = d - 32 * q;
+						below += tt >= 32 ? __popc(mw[q]) : tt > 0 ? __popc(mw[q] & ((1u << tt) - 1u)) : 0;
+					}
+					nd = d - below;
+				} else nd = d + (int32_t)q0.z;
+				d = __shfl(nd, o, 16);
+				if (d < 0 || d > RB3_TENT_KMAX) { go = false; break; } // cannot be: leave it unsettled, the host redoes the phase
+				if (gl == o) sfin[base + o] = d + 1;
+				cur = base + o, ch = next;
+				if (ch != cur + 1 || ++o == RB3_TENT_BLOCK) break; // the path leaves this block
+			}
 		}
 	}
 }
@@ -804,11 +843,11 @@ __global__ void __launch_bounds__(256) k_resolve(int32_t *sdel, const uint64_t *
 /* after the chains: rewrite tentative records (pos = lo + bit + kb), then every row must be recorded
  * and pos must be strictly increasing (ka is non-decreasing in kb).
  * bad[0] += #unset, bad[1] += #order violations, bad[2] += #unsettled tentative records */
-__device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *sdel, unsigned long long *bad)
+__device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *sfin, unsigned long long *bad)
 {
 	if (v < 0) return RB3_UNSET; // never visited (still an LF word)
 	if (!(v & RB3_TENT)) return v;
-	const int r = sdel[(int)(v >> 40) & (RB3_TENT_IDS - 1)] & (RB3_TENT_DERIVED - 1);
+	const int r = sfin[(int)(v >> 40) & (RB3_TENT_IDS - 1)];
 	if (r < 1 || r > RB3_TENT_KMAX + 1) { if (bad) atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
 	return (v & RB3_TENT_MASK) + (r - 1);
 }

@@ -168,8 +168,9 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	batch_t *b;
 	int64_t n_walkers = 0;
 	rb3h_walker_t *walkers = 0;
-	const int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : 384;
+	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : 384;
 	int r;
+	if (step < (seq->l >> 20)) step = seq->l >> 20; /* at most ~2^20 walkers per batch: the engine's stretch table is finite */
 	if (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22))
 		r = rb3h_build_bwt_walkers(n_seq, seq->l, seq->s, n_threads, step, &n_walkers, &walkers);
 	else r = rb3h_build_bwt(n_seq, seq->l, seq->s, n_threads);

@@ -280,6 +280,8 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	const int dst = 1 - h->cur;
 	int r;
 	if (ngrp > 0x7fffffffLL) return RB3GPU_EINVAL;
+	// single-sync merge: the rank phase's validation counters (misc[2..4]) are still on the device; the kernels look
+	const unsigned long long *skip = (nosync && !FROM_PLAIN && h->misc.p) ? (const unsigned long long*)h->misc.p + 2 : nullptr;
 	if ((r = buf_ensure(h, h->gstat, (size_t)ngrp * 32)) < 0) return r;
 	if ((r = buf_ensure(h, h->gpre, (size_t)ngrp * 64)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
@@ -306,18 +308,18 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		if (!FROM_PLAIN) {
 			const int64_t nt = n2 + 1;
 			HIPCHK(hipMemsetAsync(jg, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
-			hipLaunchKernelGGL(k_win_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, nwin);
+			hipLaunchKernelGGL(k_win_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, nwin, skip);
 		}
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN>), dim3((unsigned)((nwin + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-				(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin);
-		hipLaunchKernelGGL(k_decide, dim3((unsigned)ngrp), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp);
+				(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip);
+		hipLaunchKernelGGL(k_decide, dim3((unsigned)ngrp), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip);
 	} else {
 		if (!FROM_PLAIN) {
 			const int64_t nt = n2 + 1;
 			HIPCHK(hipMemsetAsync(jg, 0, (size_t)(ngrp + 1) * 8, h->st)); // defined even if pos[] turns out invalid
-			hipLaunchKernelGGL(k_group_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, ngrp);
+			hipLaunchKernelGGL(k_group_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, ngrp, skip);
 		}
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, gstat, ngrp);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, gstat, ngrp, skip);
 	}
 	uint64_t total[8];
 	if ((r = scan_records(h, gstat, ngrp, gpre, dtot, nosync ? nullptr : total)) < 0) return r;
@@ -333,10 +335,10 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	}
 	if (winpar)
 		hipLaunchKernelGGL(k_pass2w, dim3((unsigned)ngrp), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
-				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin);
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip);
 	else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp);
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, skip);
 	*ongrp = ngrp;
 	return 0;
 }
@@ -457,7 +459,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 	}
 	// tentative records need merged positions < 2^40
 	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
-	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= (1LL << 40) || stop_row >= 0) tent = 0;
+	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= (1LL << RB3_TENT_PBITS) || stop_row >= 0) tent = 0;
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
 	uint32_t *sidctr = (uint32_t*)(qhead + 5);
@@ -599,7 +601,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int tent = 1;
 	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
 	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
-	if (!walkers || n_walkers > (1 << 22) || ntot >= (1LL << 40) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED"))
+	if (!walkers || n_walkers > (1 << 24) || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED"))
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
 	int r;
 	for (int64_t i = 0; i < n_walkers; ++i)

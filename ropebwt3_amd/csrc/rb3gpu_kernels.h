@@ -493,7 +493,7 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
  * relative order never changes: d stays put while all k survive, and when the suffix with index e
  * (in row order) drops out because B1 has another symbol there, d becomes d - [e < d] (a whole range
  * [i0, i0 + len) dropping at once clamps: d, i0 or d - len).  Such a
- * walker therefore records RB3_TENT | sid << 40 | (lo + kb), where sid names a STRETCH of rows that
+ * walker therefore records RB3_TENT | sid << 38 | (lo + kb), where sid names a STRETCH of rows that
  * share one unknown d, opens a new stretch at every drop (sdep[new] = EVENT, old sid, range), and goes
  * on.  k = 1 is the common case for a genome merged into an index holding one close relative and has
  * a fast path with ONE rank per step (hi' = lo' + [B1[lo] == c]); k > 1 (several close relatives
@@ -520,8 +520,9 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
  * timing.
  */
 #define RB3_TENT      (1LL << 62)
-#define RB3_TENT_MASK ((1LL << 40) - 1)
-#define RB3_TENT_IDS  (1 << 22)       /* stretch ids per merge */
+#define RB3_TENT_PBITS 38             /* bits of a merged position in a tentative record: merges up to 2^38 symbols */
+#define RB3_TENT_MASK ((1LL << RB3_TENT_PBITS) - 1)
+#define RB3_TENT_IDS  (1 << 24)       /* stretch ids per merge */
 #define RB3_TENT_POISON (RB3_TENT_IDS - 1) /* the id of records whose stretch could not be allocated: never settled */
 #define RB3_TENT_KMAX 255             /* widest interval that is tracked tentatively */
 #ifndef RB3_TENT_MIN_AGE
@@ -529,7 +530,7 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 #endif
 /* One 64-byte record per stretch, so that following a dependency path costs one memory round trip per
  * stretch (k_resolve).  w0, w1: how the unknown of the stretch follows from another one.
- *   w0 = type << 62 | previous stretch << 40 | lo (EVENT only)
+ *   w0 = type << 62 | previous stretch << 38 | lo (EVENT only)
  *   EVENT: some rows of the previous stretch's interval [lo, lo + kk) do not hold c and dropped out;
  *          w1 = kk | c << 8.  k_events turns that into the 256-bit mask of the dropped
  *          rows (the walker itself only notes the event: three stores, no loads), and
@@ -545,9 +546,9 @@ typedef struct {
 } rb3_stretch_t; /* 64 bytes; the first 24 must be zero before a merge */
 #define RB3_DEP_EVENT 1ull
 #define RB3_DEP_LINK  2ull
-#define RB3_DEP_W0(type, prev, lo) ((uint64_t)(type) << 62 | (uint64_t)(uint32_t)(prev) << 40 | (uint64_t)(lo))
-#define RB3_DEP_PREV(w0) ((int)((w0) >> 40) & (RB3_TENT_IDS - 1))
-#define RB3_TENT_BLOCK 16            /* walkers with several matching suffixes get their stretch ids in aligned blocks of
+#define RB3_DEP_W0(type, prev, lo) ((uint64_t)(type) << 62 | (uint64_t)(uint32_t)(prev) << RB3_TENT_PBITS | (uint64_t)(lo))
+#define RB3_DEP_PREV(w0) ((int)((w0) >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1))
+#define RB3_TENT_BLOCK 8             /* walkers with several matching suffixes get their stretch ids in aligned blocks of
                                         this many, from the lower half of the table (counter sidctr[0]); walkers with a
                                         unique match never see a drop-out and take single ids from the upper half
                                         (counter sidctr[1]) */
@@ -735,7 +736,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				if (!(seen & RB3_TENT)) { // a final value: the unknown of my current stretch
 					if (gap != 0 && sid >= 0 && sid != RB3_TENT_POISON && j == 0) tab[sid].del = 1 + (int)(seen - myval);
 				} else {
-					const int id2 = (int)(seen >> 40) & (RB3_TENT_IDS - 1);
+					const int id2 = (int)(seen >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1);
 					const int64_t diff = myval - (seen & RB3_TENT_MASK); // both intervals contain ka
 					if (j == 0 && id2 != RB3_TENT_POISON) {
 						if (gap == 0) tab[id2].del = 1 + (int)diff;
@@ -744,7 +745,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				}
 			}
 			if ((gap == 0 || (tentok && sid >= 0)) && !met && j == (int)(it & 7u))
-				bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << 40) | myval) : myval;
+				bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 			// next insertion point(s)
 			uint32_t match, mh;
 			const int64_t lo_n = octc_finish<DENSE>(rl, c, j, &match);
@@ -793,17 +794,17 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 
 /* settle the unknowns of all stretches.  A stretch has at most one dependent: the next stretch of
  * the same walker (EVENT) or, for the walker's last one, the first stretch of the walker it ran
- * into (LINK) -- the dependencies form simple paths.  One group of 16 lanes per stretch that a walker
+ * into (LINK) -- the dependencies form simple paths.  One group of 8 lanes per stretch that a walker
  * settled follows its path forwards until the next such stretch.  The stretches of one walker are
- * consecutive ids inside aligned blocks of 16, so the group fetches a block at a time (one record per
+ * consecutive ids inside aligned blocks of 8, so the group fetches a block at a time (one record per
  * lane) and steps through it with shuffles: one memory round trip per block instead of one per stretch.
  * sfin[s] = 1 + d for every stretch that got settled, walker-settled ones included (a compact copy for
  * k_pos_finalize_check; the records are 64 bytes apart). */
 __global__ void __launch_bounds__(256) k_resolve(rb3_stretch_t *tab, const uint32_t *sidctr, int32_t *sfin)
 {
-	const int gl = threadIdx.x & 15;
+	const int gl = threadIdx.x & (RB3_TENT_BLOCK - 1);
 	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF, nb = sidctr[1] < (uint32_t)RB3_TENT_HALF ? sidctr[1] : RB3_TENT_HALF;
-	for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; t < na + nb; t += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+	for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / RB3_TENT_BLOCK; t < na + nb; t += ((int64_t)gridDim.x * blockDim.x) / RB3_TENT_BLOCK) {
 		const int64_t i = t < na ? t : RB3_TENT_HALF + (t - na);
 		const int r = tab[i].del;
 		if (r <= 0) continue; // only stretches a walker settled start a path
@@ -816,9 +817,9 @@ __global__ void __launch_bounds__(256) k_resolve(rb3_stretch_t *tab, const uint3
 			const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
 			const uint32_t mw[8] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y };
 			for (int o = ch & (RB3_TENT_BLOCK - 1); ; ) {
-				const uint32_t w0hi = __shfl(q0.y, o, 16);
-				const int del = (int)__shfl(q1.x, o, 16), next = (int)__shfl(q1.y, o, 16) - 1;
-				if ((int)(w0hi >> 8 & (RB3_TENT_IDS - 1)) != cur || del != 0) { go = false; break; } // another follower's link won / settled by a walker
+				const uint32_t w0hi = __shfl(q0.y, o, RB3_TENT_BLOCK);
+				const int del = (int)__shfl(q1.x, o, RB3_TENT_BLOCK), next = (int)__shfl(q1.y, o, RB3_TENT_BLOCK) - 1;
+				if ((int)(w0hi >> (RB3_TENT_PBITS - 32) & (RB3_TENT_IDS - 1)) != cur || del != 0) { go = false; break; } // another follower's link won / settled by a walker
 				// every lane applies ITS record to d; the one of lane o counts
 				int nd;
 				if (w0hi >> 30 == RB3_DEP_EVENT) { // the dropped rows below d no longer count
@@ -830,7 +831,7 @@ __global__ void __launch_bounds__(256) k_resolve(rb3_stretch_t *tab, const uint3
 					}
 					nd = d - below;
 				} else nd = d + (int32_t)q0.z;
-				d = __shfl(nd, o, 16);
+				d = __shfl(nd, o, RB3_TENT_BLOCK);
 				if (d < 0 || d > RB3_TENT_KMAX) { go = false; break; } // cannot be: leave it unsettled, the host redoes the phase
 				if (gl == o) sfin[base + o] = d + 1;
 				cur = base + o, ch = next;
@@ -847,7 +848,7 @@ __device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *sfin, uns
 {
 	if (v < 0) return RB3_UNSET; // never visited (still an LF word)
 	if (!(v & RB3_TENT)) return v;
-	const int r = sfin[(int)(v >> 40) & (RB3_TENT_IDS - 1)];
+	const int r = sfin[(int)(v >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1)];
 	if (r < 1 || r > RB3_TENT_KMAX + 1) { if (bad) atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
 	return (v & RB3_TENT_MASK) + (r - 1);
 }
@@ -913,9 +914,15 @@ __device__ __forceinline__ uint32_t idx_sym(const IdxView &ix, int64_t i)
 	}
 }
 
+/* `skip`, in all rebuild kernels: the validation counters of the rank phase.  The single-sync
+ * merge launches the rebuild before the host has seen them; if the rank phase failed (it will be redone) pos[]
+ * is not a valid interleave and the rebuild must neither take long nor write out of bounds: it does nothing. */
+#define RB3_REB_SKIP(skip) ((skip) != nullptr && ((skip)[0] | (skip)[1] | (skip)[2]) != 0)
+
 /* jg[g] = #{rows kb : pos[kb] < g * 8192}, g = 0..ngrp  (pos is strictly increasing) */
-__global__ void __launch_bounds__(256) k_group_rows(const int64_t *pos, int64_t n2, int64_t *jg, int64_t ngrp)
+__global__ void __launch_bounds__(256) k_group_rows(const int64_t *pos, int64_t n2, int64_t *jg, int64_t ngrp, const unsigned long long *skip)
 {
+	if (RB3_REB_SKIP(skip)) return;
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n2) return;
 	int64_t a = i == 0 ? -1 : pos[i - 1] >> RB3_GRP_BITS; // group of the previous row
@@ -1071,8 +1078,9 @@ __device__ __forceinline__ void window_heads(const uint32_t sym[4], int lane, ui
  * gstat[g*8 + 0..5] = symbol counts, [6] = #slots, [7] = slot-start mask. */
 template<bool FROM_PLAIN>
 __global__ void __launch_bounds__(64) k_pass1(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
-		const int64_t *jg, uint32_t *gstat, int64_t ngrp)
+		const int64_t *jg, uint32_t *gstat, int64_t ngrp, const unsigned long long *skip)
 {
+	if (RB3_REB_SKIP(skip)) return;
 	__shared__ __attribute__((aligned(16))) uint8_t symbuf[RB3_WIN];
 	const int lane = threadIdx.x;
 	const int64_t g = blockIdx.x;
@@ -1131,8 +1139,9 @@ __global__ void __launch_bounds__(64) k_pass1(IdxView old, const int64_t *pos, c
  * gpre[g*8 + 0..5] = symbol counts before the group, [6] = slots before the group. */
 template<bool FROM_PLAIN>
 __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
-		const int64_t *jg, const uint32_t *gstat, const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t ngrp)
+		const int64_t *jg, const uint32_t *gstat, const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t ngrp, const unsigned long long *skip)
 {
+	if (RB3_REB_SKIP(skip)) return;
 	__shared__ __attribute__((aligned(16))) uint8_t symbuf[RB3_WIN];
 	__shared__ uint64_t ball[12];
 	__shared__ uint32_t csym[RB3_RLE_CODES + 16], clen[RB3_RLE_CODES + 16];
@@ -1245,8 +1254,9 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 /* ----------------------------------------------------------------------------------------- */
 
 /* jw[w] = #{rows kb : pos[kb] < w * 256}, w = 0..nwin */
-__global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2, int64_t *jw, int64_t nwin)
+__global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2, int64_t *jw, int64_t nwin, const unsigned long long *skip)
 {
+	if (RB3_REB_SKIP(skip)) return;
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n2) return;
 	int64_t a = i == 0 ? -1 : pos[i - 1] >> RB3_WIN_BITS;
@@ -1260,9 +1270,10 @@ __global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2
  * three bit planes (wplane: 24 dwords, the payload of a bit-plane slot) */
 template<bool FROM_PLAIN>
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
-		const int64_t *jw, uint4 *wstat, uint32_t *wplane, uint16_t *wruns, int64_t nwin)
+		const int64_t *jw, uint4 *wstat, uint32_t *wplane, uint16_t *wruns, int64_t nwin, const unsigned long long *skip)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t symbuf_[RB3_REB_WAVES][RB3_WIN];
+	if (RB3_REB_SKIP(skip)) return;
 	__shared__ uint64_t ball_[RB3_REB_WAVES][12];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint8_t *symbuf = symbuf_[wave];
@@ -1332,8 +1343,9 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 
 /* per group of 32 windows: the slot partition (largest aligned power-of-two window groups with
  * <= 48 runs) and the group's symbol counts; same output as k_pass1 */
-__global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot, uint32_t *gstat, int64_t ngrp)
+__global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot, uint32_t *gstat, int64_t ngrp, const unsigned long long *skip)
 {
+	if (RB3_REB_SKIP(skip)) return;
 	const int lane = threadIdx.x;
 	const int64_t g = blockIdx.x;
 	const int64_t W = (ntot >> RB3_WIN_BITS) + 1;
@@ -1373,8 +1385,9 @@ __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot,
  * code, merging runs that continue across window boundaries); window 0 of a group also writes the
  * directory entry */
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wstat, const uint32_t *wplane, const uint16_t *wruns, int64_t ntot, const uint32_t *gstat,
-		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin)
+		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin, const unsigned long long *skip)
 {
+	if (RB3_REB_SKIP(skip)) return;
 	__shared__ uint32_t sP_[RB3_REB_WAVES][RB3_GRP_WINS + 1], sB_[RB3_REB_WAVES][RB3_GRP_WINS], sNr_[RB3_REB_WAVES][RB3_GRP_WINS];
 	__shared__ uint32_t code16_[RB3_REB_WAVES][RB3_RLE_CODES / 2];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

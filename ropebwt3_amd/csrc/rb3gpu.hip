@@ -973,30 +973,50 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa)
 	return 0;
 }
 
+/* Runs are found on the device (k_export_runs: count, scan, emit), chunk by chunk; only start << 3 | sym of
+ * every run crosses PCIe, and the host turns consecutive starts into lengths. */
+#define RB3_RCHUNK_WINS (1LL << 16) /* windows (16 M symbols) per chunk: at most 128 MB of run words */
 int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
 {
 	if (!h || !emit) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->grp == nullptr) return RB3GPU_ESTATE;
 	double t = now_s();
-	const int64_t cap = RB3_XCHUNK < h->n ? RB3_XCHUNK : h->n;
-	uint8_t *buf = (uint8_t*)malloc((size_t)(cap > 0 ? cap : 1));
-	if (!buf) return RB3GPU_ENOMEM;
-	int c = -1, ret = 0;
-	int64_t l = 0;
-	for (int64_t beg = 0; beg < h->n && ret == 0; beg += RB3_XCHUNK) {
-		int64_t end = beg + RB3_XCHUNK < h->n ? beg + RB3_XCHUNK : h->n;
-		if ((ret = export_chunk(h, beg, end, buf)) < 0) break;
-		for (int64_t i = 0; i < end - beg; ++i) {
-			if (buf[i] == c) ++l;
-			else {
-				if (l > 0 && emit(data, c, l) != 0) { ret = RB3GPU_EINVAL; break; }
-				c = buf[i], l = 1;
-			}
+	const int64_t nwin = (h->n + RB3_WIN - 1) >> RB3_WIN_BITS;
+	const IdxView iv = view_of(h);
+	int ret = 0, c = -1;
+	int64_t start = 0;
+	uint64_t *host = nullptr;
+	size_t host_cap = 0;
+	if ((ret = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return ret;
+	for (int64_t w0 = 0; w0 < nwin && ret == 0; w0 += RB3_RCHUNK_WINS) {
+		const int64_t nw = w0 + RB3_RCHUNK_WINS < nwin ? RB3_RCHUNK_WINS : nwin - w0;
+		if ((ret = buf_ensure(h, h->gstat, (size_t)nw * 32)) < 0) break;
+		if ((ret = buf_ensure(h, h->gpre, (size_t)nw * 64)) < 0) break;
+		uint32_t *cnt8 = (uint32_t*)h->gstat.p;
+		uint64_t *off8 = (uint64_t*)h->gpre.p, total[8];
+		const dim3 grid((unsigned)((nw + 3) / 4)), blk(256);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<false>), grid, blk, 0, h->st, iv, w0, nw, cnt8, (const uint64_t*)nullptr, (uint64_t*)nullptr);
+		if ((ret = scan_records(h, cnt8, nw, off8, (uint64_t*)h->misc.p + MISC_IX_TOT, total)) < 0) break;
+		const int64_t nr = (int64_t)total[0];
+		if (nr == 0) continue;
+		if ((ret = buf_ensure(h, h->xbuf, (size_t)nr * 8)) < 0) break;
+		if ((size_t)nr > host_cap) {
+			free(host);
+			host_cap = (size_t)nr + ((size_t)nr >> 2) + 1024;
+			if ((host = (uint64_t*)malloc(host_cap * 8)) == nullptr) { ret = RB3GPU_ENOMEM; break; }
+		}
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<true>), grid, blk, 0, h->st, iv, w0, nw, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
+		HIPCHK(hipMemcpyAsync(host, h->xbuf.p, (size_t)nr * 8, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+		for (int64_t i = 0; i < nr; ++i) {
+			const int64_t s = (int64_t)(host[i] >> 3);
+			if (c >= 0 && emit(data, c, s - start) != 0) { ret = RB3GPU_EINVAL; break; }
+			c = (int)(host[i] & 7), start = s;
 		}
 	}
-	if (ret == 0 && l > 0 && emit(data, c, l) != 0) ret = RB3GPU_EINVAL;
-	free(buf);
+	if (ret == 0 && c >= 0 && emit(data, c, h->n - start) != 0) ret = RB3GPU_EINVAL;
+	free(host);
 	h->stt.ms_export += (now_s() - t) * 1e3;
 	return ret;
 }

@@ -1488,6 +1488,46 @@ __global__ void __launch_bounds__(256) k_export_plain(IdxView ix, int64_t beg, i
 	for (; i < end; i += stride) out[i - beg] = (uint8_t)idx_sym(ix, i);
 }
 
+/* run export (rb3_enc_fmr2fmd's leaf iteration, fm-index.c:31-52): the maximal runs of windows [w0, w0 + nw)
+ * as start << 3 | sym, in BWT order.  A position starts a run iff its symbol differs from the one before it
+ * (read from the index, so runs continue across windows and chunks).  Pass 1 (EMIT = false) counts the run
+ * starts per window into column 0 of an 8 x u32 record (the engine's scan works on those), pass 2 writes
+ * them at the scanned offsets.  One wave per window. */
+template<bool EMIT>
+__global__ void __launch_bounds__(256) k_export_runs(IdxView ix, int64_t w0, int64_t nw, uint32_t *cnt8, const uint64_t *off8, uint64_t *runs)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t wi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (wi >= nw) return;
+	const int64_t p0 = (w0 + wi) << RB3_WIN_BITS;
+	uint32_t sym[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		const int64_t p = p0 + 64 * u + lane;
+		sym[u] = p < ix.n ? idx_sym(ix, p) : 7u;
+	}
+	const uint32_t before = p0 > 0 ? idx_sym(ix, p0 - 1) : 8u;
+	uint64_t H[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		uint32_t prev = __shfl_up(sym[u], 1);
+		const uint32_t pl = u > 0 ? __shfl(sym[u > 0 ? u - 1 : 0], 63) : before;
+		if (lane == 0) prev = pl;
+		H[u] = __ballot(sym[u] != 7u && sym[u] != prev);
+	}
+	if (!EMIT) {
+		if (lane < 8) cnt8[wi * 8 + lane] = lane == 0 ? (uint32_t)(__popcll(H[0]) + __popcll(H[1]) + __popcll(H[2]) + __popcll(H[3])) : 0u;
+		return;
+	}
+	uint64_t o = off8[wi * 8];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) {
+		if (H[u] >> lane & 1ull)
+			runs[o + __popcll(H[u] & ((1ull << lane) - 1ull))] = (uint64_t)(p0 + 64 * u + lane) << 3 | sym[u];
+		o += __popcll(H[u]);
+	}
+}
+
 __global__ void __launch_bounds__(256) k_fill_iota(int64_t *p, int64_t n)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

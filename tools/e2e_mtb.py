@@ -10,6 +10,8 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 4400000
 NOREF = "--no-ref" in sys.argv
 if NOREF: sys.argv.remove("--no-ref")
+SSA = "--ssa" in sys.argv
+if SSA: sys.argv.remove("--ssa")
 out = sys.argv[3] if len(sys.argv) > 3 else "/tmp/e2e_mtb"
 os.makedirs(out, exist_ok=True)
 ALPH = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -63,3 +65,18 @@ if os.path.exists(ref) and not NOREF:
         if "constructed partial BWT" in l: last = float(m.group(1))
         elif "inserted" in l and last is not None: tot += float(m.group(1)) - last; last = None
     print("reference merge-only seconds (sum over rounds): %.2f" % tot)
+
+if SSA:  # sampled suffix array of the index just built: GPU vs the reference's kt_for over strings
+    fmd = os.path.join(out, "all.fmd")
+    open(fmd, "wb").write(b)
+    def runssa(name, cmd):
+        t = time.time()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        print("%-28s %7.2f s  rc=%d  md5=%s  bytes=%d" % (name, time.time() - t, r.returncode, hashlib.md5(r.stdout).hexdigest(), len(r.stdout)), flush=True)
+        for l in r.stderr.decode().splitlines():
+            if "samples of" in l or "sampled suffix array" in l: print("    " + l)
+        return r.stdout
+    x = runssa("amd ssa -s8", [amd, "ssa", "-s8", fmd])
+    if os.path.exists(ref):
+        y = runssa("reference ssa -s8 -t%d" % min(64, os.cpu_count() or 8), [ref, "ssa", "-s8", "-t%d" % min(64, os.cpu_count() or 8), fmd])
+        print("SSA IDENTICAL to reference:", x == y)

@@ -345,3 +345,12 @@ def test_ssa_gen_vs_oracle(oracle, seed, kind):
     finally:
         os.environ.pop("RB3GPU_SSA_SPLIT", None)
         h.close()
+
+
+def test_soak_few_cases():
+    """tools/soak.py: random families (substitutions, indels, duplicates, tandem repeats, homopolymers, several
+    genomes per batch, both walker modes) -- merged BWT, run export and sampled suffix array against the oracle"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "8", "5000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]

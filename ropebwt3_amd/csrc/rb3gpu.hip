@@ -271,10 +271,16 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
  * otherwise the interleave of the current index with d_b2 at merged positions pos[].
  * nosync: size the slot array by its upper bound (one slot per window) and do not wait for the
  * scan totals; the caller reads them from misc[MISC_IX_TOT..] after its own sync. */
+static bool use_winpar(int64_t nwin)
+{
+	return (size_t)nwin * 216 <= ((size_t)8 << 30) && !getenv("RB3GPU_GROUP_REBUILD");
+}
+
 extern "C++" {
+/* rows_done: jg[] (rows before every window) has been filled by k_pos_finalize_check_rows already */
 template<bool FROM_PLAIN>
 static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64_t *d_pos, int64_t ntot, bool nosync,
-		int64_t *ongrp, int64_t *onslots, int64_t oacc[7])
+		int64_t *ongrp, int64_t *onslots, int64_t oacc[7], bool rows_done = false)
 {
 	const int64_t ngrp = (ntot >> RB3_GRP_BITS) + 1, nwin = (ntot >> RB3_WIN_BITS) + 1;
 	const int dst = 1 - h->cur;
@@ -292,7 +298,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	}
 	// window-parallel kernels (one wave per 256-symbol window, planes cached between the passes) unless
 	// their scratch (216 B per window) would be unreasonably large; then one wave per 8192-symbol group
-	const bool winpar = (size_t)nwin * 216 <= ((size_t)8 << 30) && !getenv("RB3GPU_GROUP_REBUILD");
+	const bool winpar = use_winpar(nwin);
 	if (winpar) {
 		if ((r = buf_ensure(h, h->wstat, (size_t)nwin * 16)) < 0) return r;
 		if ((r = buf_ensure(h, h->wplane, (size_t)nwin * 96)) < 0) return r;
@@ -305,7 +311,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	uint32_t *gstat = (uint32_t*)h->gstat.p;
 	uint64_t *gpre = (uint64_t*)h->gpre.p, *dtot = (uint64_t*)h->misc.p + MISC_IX_TOT;
 	if (winpar) {
-		if (!FROM_PLAIN) {
+		if (!FROM_PLAIN && !rows_done) {
 			const int64_t nt = n2 + 1;
 			HIPCHK(hipMemsetAsync(jg, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
 			hipLaunchKernelGGL(k_win_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, nwin, skip);
@@ -615,6 +621,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int32_t *sfin = nullptr;
 	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, nwin)) < 0) return r;
+	const bool rows_fused = !rank_only && use_winpar(nwin);
+	if (rows_fused && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	Walker *dwl = (Walker*)h->wl.p;
 	uint32_t *sidctr = (uint32_t*)(misc + 5);
@@ -623,6 +631,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
+	if (rows_fused) HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
 	{ // walker list: through the pinned staging buffer when it fits (a pageable source is staged by the runtime, slowly)
 		const size_t wb = (size_t)n_walkers * 32;
 		if (h->stage[0] == nullptr)
@@ -657,13 +666,19 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		if (tent) {
 			hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, (const uint32_t*)sidctr);
 			hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+		}
+		if (rows_fused) { // validation and the rows-per-window table of the rebuild in one pass over pos[]
+			const dim3 g1((unsigned)((len + 1 + 255) / 256));
+			if (tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<false>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)nullptr, misc + 2, (int64_t*)h->jg.p, nwin);
+		} else if (tent)
 			hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2);
-		} else
+		else
 			hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, len, ntot, misc + 2);
 	}
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	int64_t ngrp = 0, nslots = 0, acc[7];
-	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc)) < 0) return r;
+	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[3], h->st));
 	unsigned long long hm[32];
 	HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));

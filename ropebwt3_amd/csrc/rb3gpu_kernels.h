@@ -874,6 +874,38 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check(int64_t *pos, int64_
 	else if (p >= ntot || (i > 0 && q >= 0 && q >= p)) atomicAdd(&bad[1], 1ull);
 }
 
+/* the same plus k_win_rows in the same pass (single-sync merge with the window-parallel rebuild): thread i also
+ * writes jw[w] = i for every output window w that begins between row i-1 and row i (thread n2: the windows
+ * after the last row).  Rows that failed validation write nothing -- the rebuild is skipped then anyway. */
+template<bool TENT>
+__global__ void __launch_bounds__(256) k_pos_finalize_check_rows(int64_t *pos, int64_t n2, int64_t ntot, const int32_t *sfin, unsigned long long *bad,
+		int64_t *jw, int64_t nwin)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n2) return;
+	int64_t p = INT64_MAX, q = RB3_UNSET;
+	if (i < n2) {
+		const int64_t raw = pos[i];
+		p = TENT ? pos_final(raw, sfin, bad) : (raw < 0 ? RB3_UNSET : raw);
+		if (TENT && p != raw) pos[i] = p;
+	}
+	if (i > 0) {
+		const int64_t rq = pos[i - 1];
+		q = TENT ? pos_final(rq, sfin, nullptr) : (rq < 0 ? RB3_UNSET : rq); // the neighbour's own thread reports its problems
+	}
+	bool ok = true;
+	if (i < n2) {
+		if (p < 0) { atomicAdd(&bad[0], 1ull); ok = false; }
+		else if (p >= ntot || (i > 0 && q >= 0 && q >= p)) { atomicAdd(&bad[1], 1ull); ok = false; }
+	}
+	if (i > 0 && q < 0) ok = false;
+	if (!ok) return;
+	const int64_t a = i == 0 ? -1 : q >> RB3_WIN_BITS;
+	int64_t b = i == n2 ? nwin : p >> RB3_WIN_BITS;
+	if (b > nwin) b = nwin;
+	for (int64_t w = a + 1; w <= b; ++w) jw[w] = i;
+}
+
 __global__ void __launch_bounds__(256) k_pos_check(const int64_t *pos, int64_t n2, int64_t ntot, unsigned long long *bad)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -17,6 +17,13 @@ def short(name):
             f = [x.strip() in ("true", "(bool)1") for x in m.group(1).split(",")]
             return "k_chain<%s,%s,%s>" % ("list" if f[0] else "auto", "dense" if f[1] else "mixed", "tent" if len(f) > 2 and f[2] else "plain")
         return "k_chain"
+    if "k_pos_finalize_check_rows" in name:
+        return "k_pos_finalize_check_rows"
+    if "k_export_runs" in name:
+        return "k_export_runs"
+    for k in ("k_events", "k_ssa_walk", "k_ssa_link", "k_ssa_final"):
+        if k in name:
+            return k
     for k in ("k_pos_finalize_check", "k_pass1w", "k_pass2w", "k_win_rows", "k_decide"):
         if k in name:
             return k + ("<plain>" if "<true>" in name else "<merge>" if "<false>" in name else "")

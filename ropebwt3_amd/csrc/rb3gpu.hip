@@ -944,8 +944,9 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa)
 	if (n_ssa > 0 && !ssa) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	// splitter spacing: the link pass hops over n/2^S splitters per string one after the other, the walk's
-	// longest sublist is about 2^S ln(number of splitters) steps: 2^10 balances the two for Mbp-long strings
-	int S = 10;
+	// longest sublist is about 2^S ln(number of splitters) steps: 2^9 balances the two for Mbp-long strings
+	// (141 M rows, 32 strings: walk 9.6 / 11.7 / 18.6 ms and link 7.2 / 3.6 / 1.7 ms for S = 8 / 9 / 10)
+	int S = 9;
 	if (getenv("RB3GPU_SSA_SPLIT")) S = atoi(getenv("RB3GPU_SSA_SPLIT"));
 	if (S < 4) S = 4;
 	if (S > 20) S = 20;

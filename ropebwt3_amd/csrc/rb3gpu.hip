@@ -463,7 +463,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 			if (first < len) nwalk += (len - first + M - 1) >> logM;
 		}
 	}
-	// tentative records need merged positions < 2^40
+	// tentative records need merged positions < 2^38
 	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
 	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= (1LL << RB3_TENT_PBITS) || stop_row >= 0) tent = 0;
 	rb3_stretch_t *tab = nullptr;

@@ -490,21 +490,21 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
  * rows -- k = hi - lo suffixes of B1's text start with what it has read -- knows ka up to a small
  * number: ka = lo + d, where d counts how many of those k suffixes are smaller than the new one.
  * The k suffixes and the new one are extended by the same symbols as the walk goes on, so their
- * relative order never changes: d stays put while all k survive, and when the suffix with index e
- * (in row order) drops out because B1 has another symbol there, d becomes d - [e < d] (a whole range
- * [i0, i0 + len) dropping at once clamps: d, i0 or d - len).  Such a
- * walker therefore records RB3_TENT | sid << 38 | (lo + kb), where sid names a STRETCH of rows that
- * share one unknown d, opens a new stretch at every drop (sdep[new] = EVENT, old sid, range), and goes
- * on.  k = 1 is the common case for a genome merged into an index holding one close relative and has
- * a fast path with ONE rank per step (hi' = lo' + [B1[lo] == c]); k > 1 (several close relatives
- * indexed) costs the two ranks a wide walker pays anyway.  Whoever later walks into those rows
- * knowing more settles d instead of redoing the rows:
- *   an exact walker      -> sdel[sid] = 1 + (its value - the recorded lo + kb)           and stops;
- *   a tentative walker   -> sdep[sid] = LINK, its own sid, offset (both intervals contain ka, so the
+ * relative order never changes: d stays put while all k survive, and when some of them drop out
+ * because B1 has another symbol there, d loses the dropped ones that were below it.  Such a walker
+ * therefore records RB3_TENT | sid << 38 | (lo + kb), where sid names a STRETCH of rows that share
+ * one unknown d, opens a new stretch at every drop-out (an EVENT record: previous stretch, lo, k, c --
+ * three stores; WHICH rows dropped is worked out afterwards by k_events), and goes on.  k = 1 is the
+ * common case for a genome merged into an index holding one close relative and has a fast path with
+ * ONE rank per step (hi' = lo' + [B1[lo] == c]); k > 1 (several close relatives indexed) costs the two
+ * ranks a wide walker pays anyway.  Whoever later walks into those rows knowing more settles d instead
+ * of redoing the rows:
+ *   an exact walker      -> del of that stretch = 1 + (its value - the recorded lo + kb)  and stops;
+ *   a tentative walker   -> a LINK record: its own stretch, offset (both intervals contain ka, so the
  *                           two unknowns differ by the difference of the two lo)          and stops;
  * a tentative walker that meets a final value learns its own d the same way.  k_resolve follows the
- * event/link chains, k_pos_finalize_check rewrites the tentative records.  The critical path of a
- * merge drops from the longest variant-free stretch of the batch to about one segment.
+ * event/link chains, k_pos_finalize_check[_rows] rewrites the tentative records.  The critical path
+ * of a merge drops from the longest variant-free stretch of the batch to about one segment.
  *
  * Concurrency.  Records become visible late (lane-parked, written through), so a follower only a
  * few rows behind a tentative walker would read "unvisited", record its own value and never notice
@@ -853,22 +853,22 @@ __device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *sfin, uns
 	return (v & RB3_TENT_MASK) + (r - 1);
 }
 
-__global__ void __launch_bounds__(256) k_pos_finalize(int64_t *pos, int64_t n2, const int32_t *dres, unsigned long long *bad)
+__global__ void __launch_bounds__(256) k_pos_finalize(int64_t *pos, int64_t n2, const int32_t *sfin, unsigned long long *bad)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n2) return;
 	const int64_t v = pos[i];
-	if (v >= 0 && (v & RB3_TENT)) pos[i] = pos_final(v, dres, bad);
+	if (v >= 0 && (v & RB3_TENT)) pos[i] = pos_final(v, sfin, bad);
 }
 
 /* both in one pass over pos[] (each thread finalises its own row and re-derives its left neighbour) */
-__global__ void __launch_bounds__(256) k_pos_finalize_check(int64_t *pos, int64_t n2, int64_t ntot, const int32_t *dres, unsigned long long *bad)
+__global__ void __launch_bounds__(256) k_pos_finalize_check(int64_t *pos, int64_t n2, int64_t ntot, const int32_t *sfin, unsigned long long *bad)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n2) return;
 	const int64_t raw = pos[i];
-	const int64_t p = pos_final(raw, dres, bad);
-	const int64_t q = i > 0 ? pos_final(pos[i - 1], dres, nullptr) : RB3_UNSET; // the neighbour's own thread reports its problems
+	const int64_t p = pos_final(raw, sfin, bad);
+	const int64_t q = i > 0 ? pos_final(pos[i - 1], sfin, nullptr) : RB3_UNSET; // the neighbour's own thread reports its problems
 	if (p != raw) pos[i] = p;
 	if (p < 0) atomicAdd(&bad[0], 1ull);
 	else if (p >= ntot || (i > 0 && q >= 0 && q >= p)) atomicAdd(&bad[1], 1ull);

@@ -468,6 +468,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= (1LL << RB3_TENT_PBITS) || stop_row >= 0) tent = 0;
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
+	const uint32_t sid_limit = getenv("RB3GPU_TEST_TENT_LIMIT") ? (uint32_t)atoi(getenv("RB3GPU_TEST_TENT_LIMIT")) : 0xFFFFFFFFu; // test hook: a tiny stretch table
 	uint32_t *sidctr = (uint32_t*)(qhead + 5);
 	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
 	HIPCHK(hipMemsetAsync(qhead, 0, 8, h->st));
@@ -485,7 +486,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 		const int64_t sr = stop_row < 0 ? -1 : stop_row;
 		const dim3 grid((unsigned)nblk), blk(256);
 #define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
-			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tab, sidctr)
+			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tab, sidctr, sid_limit)
 		const int sel = (walkers ? 4 : 0) | (iv.dense ? 2 : 0) | (tent ? 1 : 0);
 		switch (sel) {
 		case 0: RB3_LAUNCH_CHAIN(false, false, false); break;
@@ -619,6 +620,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
+	const uint32_t sid_limit = getenv("RB3GPU_TEST_TENT_LIMIT") ? (uint32_t)atoi(getenv("RB3GPU_TEST_TENT_LIMIT")) : 0xFFFFFFFFu; // test hook: a tiny stretch table
 	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, nwin)) < 0) return r;
 	const bool rows_fused = !rank_only && use_winpar(nwin);
@@ -656,7 +658,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		const dim3 grid((unsigned)nblk), blk(256);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit)
 		if (iv.dense && tent) RB3_LAUNCH_FAST(true, true);
 		else if (iv.dense) RB3_LAUNCH_FAST(true, false);
 		else if (tent) RB3_LAUNCH_FAST(false, true);

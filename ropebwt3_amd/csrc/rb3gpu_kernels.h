@@ -643,8 +643,11 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 template<bool LIST, bool DENSE, bool TENT>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		rb3_stretch_t *tab, uint32_t *sidctr)
+		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit)
 {
+	// ids a walker may take from each half of the stretch table (the whole half unless a test narrows it)
+	const uint32_t lim_blocks = sid_limit < (uint32_t)RB3_TENT_HALF ? sid_limit : (uint32_t)RB3_TENT_HALF;
+	const uint32_t lim_singles = sid_limit < (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF) ? sid_limit : (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF);
 	const int lane = threadIdx.x & 63, j = lane & 7;
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
 	// it hosts: the host may enable only the first `octs` octets of each wave and launch more waves.
@@ -728,8 +731,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				uint32_t s0 = 0;
 				if (j == 0) s0 = gap == 1 ? atomicAdd(sidctr + 1, 1u) : atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
 				s0 = oct_bcast0(s0, j);
-				if (gap == 1) sid = s0 < (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF) ? (int)(RB3_TENT_HALF + s0) : -2; // table full: this walker stays a plain inexact one
-				else sid = s0 <= (uint32_t)(RB3_TENT_HALF - RB3_TENT_BLOCK) ? (int)s0 : -2;
+				if (gap == 1) sid = s0 < lim_singles ? (int)(RB3_TENT_HALF + s0) : -2; // table full: this walker stays a plain inexact one
+				else sid = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : -2;
 			}
 			if (TENT && met) { // settle an unknown (rare)
 				const int64_t seen = (int64_t)x;
@@ -765,7 +768,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 					if (j == 0) s0 = atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
 					s0 = oct_bcast0(s0, j);
 					// table full: the records from here on stay unsettled and the host redoes the phase
-					ns = s0 <= (uint32_t)(RB3_TENT_HALF - RB3_TENT_BLOCK) ? (int)s0 : RB3_TENT_POISON;
+					ns = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 				}
 				if (j == 0 && ns != RB3_TENT_POISON) {
 					tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = (uint64_t)(hi - lo) | (uint64_t)c << 8;

@@ -282,6 +282,34 @@ def test_family_of_relatives_tentative_stretches(oracle, seed, nrel):
     assert steps["1"] < 0.6 * steps["0"], steps
 
 
+@pytest.mark.parametrize("limit", [0, 40, 400, 4000])
+def test_stretch_table_exhaustion(oracle, limit):
+    """a stretch table that is (artificially) too small: walkers that cannot get their first id stay plain
+    inexact walkers, walkers that run out in mid-walk poison their records; the device-side validation then
+    makes the rebuild of that attempt do nothing and the host redoes the rank phase -- same index either way"""
+    import os
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(71)
+    g0 = util.random_genome(rng, 60000)
+    rel = [g0] + [util.mutate(rng, g0, 0.003) for _ in range(9)]
+    b1 = host.build_bwt(util.make_text(rel))
+    b2, w = host.build_bwt_walkers(util.make_text([util.mutate(rng, g0, 0.002), rel[3].copy()]), 200)
+    want = oracle.merge(b1, b2)
+    os.environ["RB3GPU_TEST_TENT_LIMIT"] = str(limit)
+    try:
+        h = Rb3Gpu(verbose=1)
+        h.from_plain(b1)
+        h.merge_plain_walkers(b2, w)
+        st = h.stats()
+        assert np.array_equal(h.export_plain(), want)
+        h.merge_plain_walkers(b2, w)                       # and the handle is still fine afterwards
+        assert h.get_tot() == b1.size + 2 * b2.size
+        h.close()
+    finally:
+        os.environ.pop("RB3GPU_TEST_TENT_LIMIT", None)
+    print("limit", limit, "fallbacks", st["n_fallbacks"], "steps", st["n_lf_steps"])
+
+
 def test_fallback_path_redoes_the_rank_phase(oracle):
     """the optimistic tentative-record pass is verified on the device; when it reports unsettled records
     the merge is redone without them (forced here through the test hook) and must give the same index"""

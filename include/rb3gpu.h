@@ -56,6 +56,8 @@ typedef struct {
 	int64_t bytes_peak;          /* high-water mark of device memory owned by the handle */
 	double  ms_ssa;              /* rb3gpu_ssa_gen: kernels + copy-back */
 	double  ms_ssa_walk;         /* k_ssa_walk alone (one LF step per row of the index) */
+	double  ms_sort;             /* rb3gpu_bwt_from_text: upload + suffix sorting + BWT */
+	int64_t n_sort_rounds;       /* prefix-doubling rounds of those calls */
 } rb3gpu_stats_t;
 
 void rb3gpu_opt_init(rb3gpu_opt_t *opt);
@@ -154,6 +156,15 @@ int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out);
  * ssa.c:62-64); rb3gpu_ssa_gen fills caller-owned host arrays of m and n_ssa words. */
 int rb3gpu_ssa_dims(const rb3gpu_t *h, int ssa_shift, int64_t *m, int64_t *n_ssa, int *ms);
 int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa);
+
+/* Partial BWT of one batch on the GPU, instead of rb3_build_sais on the host (sais-ss.c:10-56; libsais in GSA
+ * mode: the i-th sentinel sorts before the (i+1)-th, sais-ss.c:16-21).  text: len symbols 0..5 in host memory,
+ * every string terminated by 0 (so text[len-1] == 0), exactly what rb3_seq_read leaves in seq->s (io.c:104-125);
+ * it is not modified.  d_bwt: len bytes of device memory (rb3gpu_dev_alloc) that receive the BWT, ready for
+ * rb3gpu_from_plain_dev / rb3gpu_merge_plain_dev[_walkers].  If step > 0 and ckrow != NULL, ckrow[i] (host,
+ * ceil(len / step) entries) receives the row of the suffix that starts at text position i * step -- the sampled
+ * inverse suffix array a walker list is made from.  len < 2^31. */
+int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow);
 
 /* Import for `build -i` (rb3_enc_fmd2fmr fm-index.c:56-85, mr_restore mrope.c:161-177):
  * runs[i] = len<<3 | sym in BWT order (host memory). */

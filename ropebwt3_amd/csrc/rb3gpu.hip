@@ -21,6 +21,13 @@
 
 #define RB3_STAGE_BYTES ((size_t)32 << 20) // pinned host staging buffers
 
+/* the suffix sorter lives in rb3gpu_sort.hip (it pulls in rocPRIM; kept out of this translation unit) */
+struct rb3sort_ws;
+rb3sort_ws *rb3sort_create(void);
+void rb3sort_destroy(rb3sort_ws *ws);
+int64_t rb3sort_bytes(const rb3sort_ws *ws);
+int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds);
+
 struct Buf {
 	void *p = nullptr;
 	size_t cap = 0;
@@ -49,6 +56,7 @@ struct rb3gpu_s {
 	int64_t bytes_owned = 0;
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
+	rb3sort_ws *sorter = nullptr;           // scratch of rb3gpu_bwt_from_text, created on first use
 	int64_t sid_dirty[2] = {RB3_TENT_HALF, RB3_TENT_HALF}; // entries of the two halves of the stretch tables (dl) that may be non-zero
 };
 
@@ -236,6 +244,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	for (int i = 0; i < 2; ++i) if (h->stage[i]) (void)hipHostFree(h->stage[i]);
+	rb3sort_destroy(h->sorter);
 	(void)hipStreamDestroy(h->st);
 	delete h;
 }
@@ -923,6 +932,30 @@ int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out)
 	if (nblk > 65536) nblk = 65536;
 	hipLaunchKernelGGL(k_export_plain, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (int64_t)0, h->n, d_out);
 	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
+int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow)
+{
+	if (!h || !text || !d_bwt || len <= 0 || len >= (1LL << 31) || step < 0) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	const double t0 = now_s();
+	int r, rounds = 0;
+	if (h->sorter == nullptr && (h->sorter = rb3sort_create()) == nullptr) return RB3GPU_ENOMEM;
+	if ((r = upload_b2(h, len, text)) < 0) return r; // the text, into the batch buffer
+	int64_t *d_ck = nullptr;
+	const int64_t nck = step > 0 && ckrow ? (len + step - 1) / step : 0;
+	if (nck > 0) {
+		if ((r = buf_ensure(h, h->xbuf, (size_t)nck * 8)) < 0) return r;
+		d_ck = (int64_t*)h->xbuf.p;
+	}
+	r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds);
+	if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -3 ? RB3GPU_ESYMBOL : RB3GPU_ENODEV;
+	if (nck > 0) HIPCHK(hipMemcpy(ckrow, d_ck, (size_t)nck * 8, hipMemcpyDeviceToHost));
+	h->stt.ms_sort += (now_s() - t0) * 1e3, h->stt.n_sort_rounds += rounds;
+	if (h->bytes_owned + rb3sort_bytes(h->sorter) > h->stt.bytes_peak) h->stt.bytes_peak = h->bytes_owned + rb3sort_bytes(h->sorter);
+	if (h->opt.verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f] suffix-sorted %lld symbols on the GPU in %.3f ms (%d doubling rounds)\n", __func__, now_s() - h->t0, (long long)len, (now_s() - t0) * 1e3, rounds);
 	return 0;
 }
 

@@ -35,7 +35,7 @@ class Stats(ctypes.Structure):
                 ("ms_build", ctypes.c_double), ("ms_export", ctypes.c_double), ("ms_chain", ctypes.c_double),
                 ("n_rank_launches", ctypes.c_int64), ("n_lf_steps", ctypes.c_int64), ("n_symbols_merged", ctypes.c_int64),
                 ("n_rounds", ctypes.c_int64), ("n_fallbacks", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64),
-                ("ms_ssa", ctypes.c_double), ("ms_ssa_walk", ctypes.c_double)]
+                ("ms_ssa", ctypes.c_double), ("ms_ssa_walk", ctypes.c_double), ("ms_sort", ctypes.c_double), ("n_sort_rounds", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -69,6 +69,7 @@ SYMBOLS = {
     "rb3gpu_export_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_ssa_dims": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),
     "rb3gpu_ssa_gen": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_bwt_from_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),
@@ -218,6 +219,21 @@ class Rb3Gpu:
 
     def export_plain_dev(self, d_out):
         self._chk(self._lib.rb3gpu_export_plain_dev(self._h, d_out), "rb3gpu_export_plain_dev")
+
+    def bwt_from_text(self, text, step=0):
+        """suffix-sort a batch text on the GPU (rb3_build_sais, sais-ss.c:10-56): returns (device pointer of the
+        BWT -- free it with dev_free --, ckrow or None)"""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        p = ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_dev_alloc(self._h, text.size + 16, ctypes.byref(p)), "rb3gpu_dev_alloc")
+        ck = np.empty((text.size + step - 1) // step, dtype=np.int64) if step > 0 else None
+        self._chk(self._lib.rb3gpu_bwt_from_text(self._h, text.size, text.ctypes.data, p, step, ck.ctypes.data if ck is not None else None), "rb3gpu_bwt_from_text")
+        return p, ck
+
+    def dev_download(self, p, nbytes):
+        out = np.empty(nbytes, dtype=np.uint8)
+        self._chk(self._lib.rb3gpu_dev_download(self._h, out.ctypes.data, p, nbytes), "rb3gpu_dev_download")
+        return out
 
     def ssa_gen(self, ssa_shift):
         """sampled suffix array of the index (rb3_ssa_gen, ssa.c:54-81): (ms, r2i[m], ssa[n_ssa]) as uint64"""

@@ -382,3 +382,45 @@ def test_soak_few_cases():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "8", "5000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+@pytest.mark.parametrize("seed,kind", [(81, "genomes"), (82, "reads"), (83, "copies"), (84, "tiny"), (85, "runs"), (86, "family")])
+def test_bwt_from_text_vs_host_sorter(oracle, seed, kind):
+    """partial BWT of a batch on the GPU (rb3gpu_bwt_from_text, prefix doubling) against the host suffix sorter
+    (itself pinned to the reference's libsais output): BWT bytes and the sampled inverse suffix array"""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(seed)
+    if kind == "genomes":
+        g0 = util.random_genome(rng, 150000)
+        seqs = [g0, util.mutate(rng, g0, 0.01)]
+    elif kind == "reads":
+        g0 = util.random_genome(rng, 5000)
+        seqs = util.reads_from(rng, g0, 4000, 60, err=0.01) + [g0[100:160].copy() for _ in range(30)]   # exact duplicates: sentinel order decides
+    elif kind == "copies":
+        g0 = util.random_genome(rng, 30000)
+        seqs = [g0.copy() for _ in range(5)] + [g0[:777].copy(), g0[29000:].copy()]                       # identical strings: every doubling round is needed
+    elif kind == "tiny":
+        seqs = [np.array([1, 3, 3], dtype=np.uint8), np.array([1, 3, 2], dtype=np.uint8)]
+    elif kind == "runs":
+        seqs = [np.full(70000, 1, dtype=np.uint8), np.tile(np.array([1, 2], dtype=np.uint8), 20000), np.full(100, 5, dtype=np.uint8), np.full(70001, 1, dtype=np.uint8)]
+    else:
+        g0 = util.random_genome(rng, 40000)
+        seqs = [util.mutate(rng, g0, 0.002) for _ in range(8)]
+    for both in (True, False):
+        text = util.make_text(seqs, True, both)
+        want = host.build_bwt(text.copy())
+        h = Rb3Gpu(verbose=1)
+        try:
+            for step in (0, 100):
+                p, ck = h.bwt_from_text(text, step)
+                got = h.dev_download(p, text.size)
+                h.dev_free(p)
+                assert np.array_equal(got, want), (kind, both, step)
+                if step:
+                    _, w = host.build_bwt_walkers(text.copy(), step)
+                    inner = w[w[:, 1] == -1]                # walkers strictly inside strings: their rows are ISA samples
+                    assert set(inner[:, 0].tolist()) <= set(ck.tolist())
+                    assert len(set(ck.tolist())) == ck.size and ck.min() >= 0 and ck.max() < text.size
+            assert h.stats()["n_sort_rounds"] >= 0
+        finally:
+            h.close()

@@ -30,7 +30,7 @@ enum { FMT_PLAIN = 0, FMT_FMD, FMT_FMR };
 typedef struct {
 	int64_t flag, batch_size;
 	int fmt, n_threads, sais_threads, block_len, max_nodes;
-	int device, split_log2, rebatch;
+	int device, split_log2, rebatch, gpu_sort;
 } bopt_t;
 
 static void bopt_init(bopt_t *o) /* build.c:31-41 */
@@ -38,7 +38,7 @@ static void bopt_init(bopt_t *o) /* build.c:31-41 */
 	memset(o, 0, sizeof(*o));
 	o->n_threads = 4, o->sais_threads = 0, o->fmt = FMT_PLAIN;
 	o->block_len = 512, o->max_nodes = 64, o->batch_size = 7000000000LL;
-	o->device = 0, o->split_log2 = 0, o->rebatch = 0;
+	o->device = 0, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 0;
 }
 
 static int usage_build(FILE *fp, const bopt_t *opt)
@@ -54,6 +54,7 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	fprintf(fp, "    --gpu INT   HIP device ordinal [%d]\n", opt->device);
 	fprintf(fp, "    --split INT start extra LF walkers every 2^INT rows (0=auto, -1=never) [%d]\n", opt->split_log2);
 	fprintf(fp, "    --rebatch   let a batch span input files (same output, fewer merge rounds)\n");
+	fprintf(fp, "    --gpu-sort  suffix-sort the batches on the GPU as well (batches below 2^31 symbols; same output)\n");
 	fprintf(fp, "  Input:\n");
 	fprintf(fp, "    -i FILE     read existing index from FILE []\n");
 	fprintf(fp, "    -L          one sequence per line in the input\n");
@@ -116,12 +117,39 @@ static int dump_fmr(rb3gpu_t *h, const bopt_t *opt, FILE *fp)
 
 /* ---- batches ----------------------------------------------------------------------------- */
 
-typedef struct { int64_t n_seq, len, n_walkers; uint8_t *bwt; rb3h_walker_t *walkers; int ret; } batch_t;
+typedef struct { int64_t n_seq, len, n_walkers, step; uint8_t *bwt; rb3h_walker_t *walkers; int ret, raw; } batch_t;
+
+/* --gpu-sort: the batch arrives as text; suffix sorting, BWT and sampled inverse suffix array on the GPU
+ * (rb3gpu_bwt_from_text instead of rb3_build_sais, build.c:220), the BWT never leaves HBM */
+static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
+{
+	void *d_bwt = 0;
+	int64_t *ckrow = 0, nck = b->step > 0 ? (b->len + b->step - 1) / b->step : 0;
+	int ret;
+	if ((ret = rb3gpu_dev_alloc(h, b->len + 16, &d_bwt)) < 0) return ret;
+	if (nck > 0 && *has_index && (ckrow = (int64_t*)malloc((size_t)nck * 8)) == 0) { rb3gpu_dev_free(h, d_bwt); return RB3GPU_ENOMEM; }
+	ret = rb3gpu_bwt_from_text(h, b->len, b->bwt, (uint8_t*)d_bwt, ckrow ? b->step : 0, ckrow);
+	if (ret == 0 && rb3h_verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
+	if (ret == 0 && !*has_index) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)d_bwt);
+	else if (ret == 0 && ckrow) {
+		if (rb3h_walkers_from_ckrow(b->len, b->bwt, b->step, ckrow, &b->n_walkers, &b->walkers) < 0) ret = RB3GPU_ENOMEM;
+		else ret = rb3gpu_merge_plain_dev_walkers(h, b->len, (const uint8_t*)d_bwt, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+	} else if (ret == 0) ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)d_bwt, 1);
+	free(ckrow);
+	rb3gpu_dev_free(h, d_bwt);
+	return ret;
+}
 
 static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 {
 	int ret;
-	if (!*has_index) {
+	if (b->raw) {
+		const int first = !*has_index;
+		ret = process_raw_batch(h, b, has_index);
+		if (ret == 0 && rb3h_verbose >= 3)
+			fprintf(stderr, "[M::%s::%.3f*%.2f] %s the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), first ? "encoded" : "merged", (long)b->len);
+	} else if (!*has_index) {
 		ret = rb3gpu_from_plain(h, b->len, b->bwt);
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] encoded the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
@@ -171,6 +199,14 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : 384;
 	int r;
 	if (step < (seq->l >> 20)) step = seq->l >> 20; /* at most ~2^20 walkers per batch: the engine's stretch table is finite */
+	if (opt->gpu_sort && seq->l < INT32_MAX - 16) { /* the GPU sorts: pass the text through (the sorter handles < 2^31 symbols) */
+		b = (batch_t*)calloc(1, sizeof(batch_t));
+		b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s, b->raw = 1;
+		b->step = (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22)) ? step : 0;
+		seq->s = 0, seq->l = seq->m = 0;
+		*out = b;
+		return 0;
+	}
 	if (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22))
 		r = rb3h_build_bwt_walkers(n_seq, seq->l, seq->s, n_threads, step, &n_walkers, &walkers);
 	else r = rb3h_build_bwt(n_seq, seq->l, seq->s, n_threads);
@@ -322,6 +358,7 @@ static const struct option long_opts[] = {
 	{ "gpu", required_argument, 0, 301 },
 	{ "split", required_argument, 0, 302 },
 	{ "rebatch", no_argument, 0, 303 },
+	{ "gpu-sort", no_argument, 0, 304 },
 	{ 0, 0, 0, 0 }
 };
 
@@ -359,6 +396,7 @@ int main_build(int argc, char *argv[])
 		else if (c == 301) opt.device = atoi(optarg);
 		else if (c == 302) opt.split_log2 = atoi(optarg);
 		else if (c == 303) opt.rebatch = 1;
+		else if (c == 304) opt.gpu_sort = 1;
 		else if (c == '?') return 1;
 	}
 	if (argc == optind && fn_in == 0) return usage_build(stderr, &opt);
@@ -457,6 +495,8 @@ int main_build(int argc, char *argv[])
 		rb3gpu_stats(h, &st);
 		fprintf(stderr, "[M::%s] GPU merge path: %ld symbols merged in %.3f ms (H2D %.3f + LF %.3f + rank %.3f + rebuild %.3f); index %.1f MB in HBM\n", __func__,
 				(long)st.n_symbols_merged, st.ms_h2d + st.ms_lf + st.ms_rank + st.ms_build, st.ms_h2d, st.ms_lf, st.ms_rank, st.ms_build, st.bytes_index / 1e6);
+		if (st.ms_sort > 0)
+			fprintf(stderr, "[M::%s] GPU suffix sorting: %.3f ms in all (%ld doubling rounds), text upload included\n", __func__, st.ms_sort, (long)st.n_sort_rounds);
 	}
 	rb3gpu_destroy(h);
 	if (ret != 0) { fprintf(stderr, "ERROR: failed to write the index (code %d)\n", ret); return 1; }

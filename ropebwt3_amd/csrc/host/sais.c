@@ -51,6 +51,37 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
 
 #define RB3H_MIN_SEG 128
 
+/* The walker list of a batch from its sampled inverse suffix array: ckrow[i] = row of the suffix starting at text
+ * position i * step (from the host sorter below, or from rb3gpu_bwt_from_text).  text is the batch BEFORE it is
+ * turned into a BWT.  Same list as rb3h_build_bwt_walkers. */
+int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, const int64_t *ckrow, int64_t *n_walkers, rb3h_walker_t **walkers)
+{
+	int64_t i, b, j, nw = 0, n_seq = 0;
+	rb3h_walker_t *w;
+	*n_walkers = 0, *walkers = 0;
+	if (step < 2 || len <= 0 || text[len - 1] != 0) return -3;
+	for (i = 0; i < len; ++i) n_seq += text[i] == 0;
+	w = (rb3h_walker_t*)malloc((size_t)(n_seq + len / step + 2) * sizeof(rb3h_walker_t));
+	if (!w) return -1;
+	for (j = 0, b = 0, i = 0; i < len; ++i) {
+		int64_t e, prev = -1, p;
+		if (text[i] != 0) continue;
+		e = i; /* string j occupies [b, e), sentinel at e */
+		for (p = (b / step + 1) * step; p < e; p += step) { /* multiples of step strictly inside the string */
+			if (text[p - 1] == 0) continue;
+			if (e - p < RB3H_MIN_SEG && e - p < step) continue; /* keep the sentinel walker's own segment long (see k_chain) */
+			w[nw].row = ckrow[p / step], w[nw].ka0 = -1, w[nw].flags = 0;
+			w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : p - prev;
+			prev = p, ++nw;
+		}
+		w[nw].row = j, w[nw].ka0 = -2 /* sentinel row: exact, = acc[1] of the index */, w[nw].flags = 0;
+		w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : e - prev;
+		++nw, ++j, b = e + 1;
+	}
+	*n_walkers = nw, *walkers = w;
+	return 0;
+}
+
 /* BWT plus the list of LF walkers for the GPU merge: one per string (its sentinel row) and one
  * at every text position that is a multiple of `step` strictly inside a string, in text order. */
 int rb3h_build_bwt_walkers(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads, int64_t step, int64_t *n_walkers, rb3h_walker_t **walkers)

@@ -130,3 +130,16 @@ def test_ssa_subcommand_identical(name, tmp_path):
         q.write_bytes(fmr)
         out, _ = run(["ssa", "-s8", str(q)])
         assert hashlib.md5(out).hexdigest() == ent["ssa_md5"]["8"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_build_gpu_sort_identical(name):
+    """--gpu-sort: the batches are suffix-sorted on the GPU too (rb3gpu_bwt_from_text); same .fmd for every batching"""
+    ent = MAN[name]
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    for m in ent["m_variants"]:
+        out, err = run(["build", "--gpu-sort"] + ent["flags"] + ["-m" + m, "-d"] + inputs)
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (name, m)
+    out, err = run(["build", "--gpu-sort", "-p3"] + ent["flags"] + ["-m" + ent["m_variants"][-1], "-d"] + inputs)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+    assert "on the GPU" in err

@@ -51,6 +51,10 @@ ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
 a, ea = (run("amd one-file-per-batch", [amd, "build", "-d"] + files) if not NOREF else (None, None))
 b, eb = run("amd -p16 (16 sorter threads)", [amd, "build", "-d", "-p16"] + files)
 c2, _ = run("amd --rebatch -m40m -p4", [amd, "build", "-d", "--rebatch", "-m40m", "-p4"] + files)
+c3, e3 = run("amd --gpu-sort -p2", [amd, "build", "-d", "--gpu-sort", "-p2"] + files)
+for l in e3.splitlines():
+    if "GPU suffix sorting" in l: print("    " + l)
+print("gpu-sort identical:", c3 == b)
 if NOREF: a = b
 print("amd variants identical:", a == b and a == c2)
 if os.path.exists(ref) and not NOREF:

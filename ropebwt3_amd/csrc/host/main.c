@@ -38,7 +38,7 @@ static void bopt_init(bopt_t *o) /* build.c:31-41 */
 	memset(o, 0, sizeof(*o));
 	o->n_threads = 4, o->sais_threads = 0, o->fmt = FMT_PLAIN;
 	o->block_len = 512, o->max_nodes = 64, o->batch_size = 7000000000LL;
-	o->device = 0, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 0;
+	o->device = 0, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 1;
 }
 
 static int usage_build(FILE *fp, const bopt_t *opt)
@@ -54,7 +54,8 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	fprintf(fp, "    --gpu INT   HIP device ordinal [%d]\n", opt->device);
 	fprintf(fp, "    --split INT start extra LF walkers every 2^INT rows (0=auto, -1=never) [%d]\n", opt->split_log2);
 	fprintf(fp, "    --rebatch   let a batch span input files (same output, fewer merge rounds)\n");
-	fprintf(fp, "    --gpu-sort  suffix-sort the batches on the GPU as well (batches below 2^31 symbols; same output)\n");
+	fprintf(fp, "    --host-sort suffix-sort the batches on the host (default: on the GPU for batches below 2^31 symbols;\n");
+	fprintf(fp, "                same output; -p then sets the number of host sorter threads)\n");
 	fprintf(fp, "  Input:\n");
 	fprintf(fp, "    -i FILE     read existing index from FILE []\n");
 	fprintf(fp, "    -L          one sequence per line in the input\n");
@@ -129,6 +130,11 @@ static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	if ((ret = rb3gpu_dev_alloc(h, b->len + 16, &d_bwt)) < 0) return ret;
 	if (nck > 0 && *has_index && (ckrow = (int64_t*)malloc((size_t)nck * 8)) == 0) { rb3gpu_dev_free(h, d_bwt); return RB3GPU_ENOMEM; }
 	ret = rb3gpu_bwt_from_text(h, b->len, b->bwt, (uint8_t*)d_bwt, ckrow ? b->step : 0, ckrow);
+	if (ret < 0 && ret != RB3GPU_ESYMBOL) { /* the sorter could not run (memory): the caller sorts this batch on the host */
+		free(ckrow);
+		rb3gpu_dev_free(h, d_bwt);
+		return 1;
+	}
 	if (ret == 0 && rb3h_verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 	if (ret == 0 && !*has_index) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)d_bwt);
@@ -147,6 +153,13 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	if (b->raw) {
 		const int first = !*has_index;
 		ret = process_raw_batch(h, b, has_index);
+		if (ret == 1) { /* host sorter instead */
+			if (rb3h_verbose >= 2) fprintf(stderr, "[W::%s] the GPU suffix sorter could not take a batch of %ld symbols; sorting it on the host\n", "main_build", (long)b->len);
+			ret = b->step > 0 ? rb3h_build_bwt_walkers(b->n_seq, b->len, b->bwt, 1, b->step, &b->n_walkers, &b->walkers) : rb3h_build_bwt(b->n_seq, b->len, b->bwt, 1);
+			if (ret < 0) { fprintf(stderr, "ERROR: failed to construct the partial BWT (code %d)\n", ret); return -1; }
+			b->raw = 0;
+			return process_batch(h, b, has_index);
+		}
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] %s the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), first ? "encoded" : "merged", (long)b->len);
 	} else if (!*has_index) {
@@ -359,6 +372,7 @@ static const struct option long_opts[] = {
 	{ "split", required_argument, 0, 302 },
 	{ "rebatch", no_argument, 0, 303 },
 	{ "gpu-sort", no_argument, 0, 304 },
+	{ "host-sort", no_argument, 0, 305 },
 	{ 0, 0, 0, 0 }
 };
 
@@ -397,6 +411,7 @@ int main_build(int argc, char *argv[])
 		else if (c == 302) opt.split_log2 = atoi(optarg);
 		else if (c == 303) opt.rebatch = 1;
 		else if (c == 304) opt.gpu_sort = 1;
+		else if (c == 305) opt.gpu_sort = 0;
 		else if (c == '?') return 1;
 	}
 	if (argc == optind && fn_in == 0) return usage_build(stderr, &opt);

@@ -74,6 +74,25 @@ def build_bwt_walkers(text, step=1024, n_threads=1):
     return t, w
 
 
+def walkers_from_ckrow(text, step, ckrow):
+    """the same walker list from a sampled inverse suffix array (ckrow[i] = row of text position i * step),
+    e.g. the one Rb3Gpu.bwt_from_text returns; `text` is the batch text (not its BWT)"""
+    L = load_library()
+    L.rb3h_walkers_from_ckrow.restype = ctypes.c_int
+    L.rb3h_walkers_from_ckrow.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_void_p)]
+    t = np.ascontiguousarray(text, dtype=np.uint8)
+    ck = np.ascontiguousarray(ckrow, dtype=np.int64)
+    nw, pw = ctypes.c_int64(0), ctypes.c_void_p()
+    r = L.rb3h_walkers_from_ckrow(t.size, t.ctypes.data, step, ck.ctypes.data, ctypes.byref(nw), ctypes.byref(pw))
+    if r < 0:
+        raise ValueError("rb3h_walkers_from_ckrow failed with code %d" % r)
+    w = np.ctypeslib.as_array(ctypes.cast(pw, ctypes.POINTER(ctypes.c_int64)), shape=(nw.value, 4)).copy()
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    libc.free(pw)
+    return w
+
+
 def read_batches(path, is_line, max_len, fwd=True, rev=True):
     """Iterate the batches `build` would cut from one file (rb3_seq_read, io.c:104-125):
     yields (n_strings, text) with text a uint8 array."""

@@ -120,3 +120,26 @@ def test_no_cpu_fallback_without_device():
         gpu.Rb3Gpu()
     r = subprocess.run([CLI, "build", "-L", os.path.join(util.GOLDEN, "k2_fwd.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"no CPU fallback" in r.stderr
+
+
+def test_walkers_from_sampled_isa_equal_the_sorter_walkers():
+    """rb3h_walkers_from_ckrow (walker list from a sampled inverse suffix array, as the GPU sorter returns it)
+    gives the list rb3h_build_bwt_walkers derives from its own suffix array"""
+    from ropebwt3_amd import host
+    rng = np.random.default_rng(5)
+    seqs = [util.random_genome(rng, 5000), util.random_genome(rng, 130), util.random_genome(rng, 900)]
+    t = util.make_text(seqs)
+    n = t.size
+    sid = np.cumsum(t == 0) - (t == 0)
+
+    def key(p):
+        e = p
+        while t[e] != 0:
+            e += 1
+        return (bytes(t[p:e]), sid[p])
+    sa = sorted(range(n), key=key)
+    isa = np.empty(n, dtype=np.int64)
+    isa[sa] = np.arange(n)
+    for step in (64, 100, 384):
+        _, w = host.build_bwt_walkers(t, step)
+        assert np.array_equal(w, host.walkers_from_ckrow(t, step, isa[::step].copy()))

@@ -133,13 +133,17 @@ def test_ssa_subcommand_identical(name, tmp_path):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_build_gpu_sort_identical(name):
-    """--gpu-sort: the batches are suffix-sorted on the GPU too (rb3gpu_bwt_from_text); same .fmd for every batching"""
+def test_build_host_sort_identical(name):
+    """by default the batches are suffix-sorted on the GPU too (rb3gpu_bwt_from_text); --host-sort uses the host
+    sorter (with -p sorter threads): same .fmd for every batching either way"""
     ent = MAN[name]
     inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
     for m in ent["m_variants"]:
-        out, err = run(["build", "--gpu-sort"] + ent["flags"] + ["-m" + m, "-d"] + inputs)
+        out, err = run(["build", "--host-sort"] + ent["flags"] + ["-m" + m, "-d"] + inputs)
         assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (name, m)
-    out, err = run(["build", "--gpu-sort", "-p3"] + ent["flags"] + ["-m" + ent["m_variants"][-1], "-d"] + inputs)
+        assert "on the GPU" not in err
+    out, err = run(["build", "--host-sort", "-p3"] + ent["flags"] + ["-m" + ent["m_variants"][-1], "-d"] + inputs)
     assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
-    assert "on the GPU" in err
+    out, err = run(["build", "-p2"] + ent["flags"] + ["-m" + ent["m_variants"][-1], "-d"] + inputs)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+    assert "partial BWT for" in err and "on the GPU" in err

@@ -48,10 +48,10 @@ def run(name, cmd):
     return r.stdout, err
 amd = os.path.join(ROOT, "ropebwt3_amd", "ropebwt3-amd")
 ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
-a, ea = (run("amd one-file-per-batch", [amd, "build", "-d"] + files) if not NOREF else (None, None))
-b, eb = run("amd -p16 (16 sorter threads)", [amd, "build", "-d", "-p16"] + files)
-c2, _ = run("amd --rebatch -m40m -p4", [amd, "build", "-d", "--rebatch", "-m40m", "-p4"] + files)
-c3, e3 = run("amd --gpu-sort -p2", [amd, "build", "-d", "--gpu-sort", "-p2"] + files)
+a, ea = (run("amd --host-sort, serial", [amd, "build", "-d", "--host-sort"] + files) if not NOREF else (None, None))
+b, eb = run("amd --host-sort -p16", [amd, "build", "-d", "--host-sort", "-p16"] + files)
+c2, _ = run("amd --host-sort --rebatch -m40m -p4", [amd, "build", "-d", "--host-sort", "--rebatch", "-m40m", "-p4"] + files)
+c3, e3 = run("amd (GPU suffix sorting) -p2", [amd, "build", "-d", "-p2"] + files)
 for l in e3.splitlines():
     if "GPU suffix sorting" in l: print("    " + l)
 print("gpu-sort identical:", c3 == b)

@@ -40,8 +40,12 @@ def run(name, cmd):
     return r.stdout, err
 amd = os.path.join(ROOT, "ropebwt3_amd", "ropebwt3-amd")
 ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
-a, ea = run("amd build -m%s -p8" % M, [amd, "build", "-d", "-m" + M, "-p8", fn])
+a, ea = run("amd build -m%s -p2" % M, [amd, "build", "-d", "-m" + M, "-p2", fn])
+for l in ea.splitlines():
+    if "GPU suffix sorting" in l: print("    " + l)
 print("    merge rounds:", ea.count("merged the partial BWT"))
+a2, _ = run("amd build --host-sort -m%s -p8" % M, [amd, "build", "-d", "--host-sort", "-m" + M, "-p8", fn])
+print("host-sort identical:", a == a2)
 if os.path.exists(ref) and not NOREF:
     import re
     b, eb = run("reference build -m%s -t64" % M, [ref, "build", "-d", "-m" + M, "-t%d" % min(64, os.cpu_count() or 8), fn])

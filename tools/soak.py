@@ -41,6 +41,16 @@ for case in range(ncase):
             b = host.build_bwt(t)
             if cur is None: h.from_plain(b)
             else: h.merge_plain(b)
+        elif case % 4 == 2:   # the batch is suffix-sorted on the GPU as well; the BWT never leaves the device
+            d, ck = h.bwt_from_text(t, step)
+            b = h.dev_download(d, t.size)
+            if not np.array_equal(b, host.build_bwt(t.copy())):
+                print("case %d: GPU suffix sorter MISMATCH" % case); sys.exit(1)
+            if cur is None: h._chk(h._lib.rb3gpu_from_plain_dev(h._h, t.size, d), "from_plain_dev")
+            else:
+                w = host.walkers_from_ckrow(t, step, ck)
+                h.merge_plain_dev_walkers(d, t.size, w, commit=True)
+            h.dev_free(d)
         else:
             b, w = host.build_bwt_walkers(t, step)
             if cur is None: h.from_plain(b)

@@ -147,3 +147,13 @@ def test_build_host_sort_identical(name):
     out, err = run(["build", "-p2"] + ent["flags"] + ["-m" + ent["m_variants"][-1], "-d"] + inputs)
     assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
     assert "partial BWT for" in err and "on the GPU" in err
+
+
+def test_differential_fuzz_against_the_reference_binary():
+    """tools/fuzz_cli.py: random FASTA/FASTQ/line inputs and options, `.fmd` byte-identical to the unmodified
+    reference's (needs oracle/_ref/ropebwt3, which travels with the repository when it was built)"""
+    import sys
+    if not os.path.exists(util.REF_BIN):
+        pytest.skip("no reference binary")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(util.GOLDEN), "..", "tools", "fuzz_cli.py"), "12", "4000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]

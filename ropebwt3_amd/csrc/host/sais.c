@@ -56,19 +56,18 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
  * turned into a BWT.  Same list as rb3h_build_bwt_walkers. */
 int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, const int64_t *ckrow, int64_t *n_walkers, rb3h_walker_t **walkers)
 {
-	int64_t i, b, j, nw = 0, n_seq = 0;
+	int64_t b, j, nw = 0, n_seq = 0;
+	const uint8_t *q;
 	rb3h_walker_t *w;
 	*n_walkers = 0, *walkers = 0;
 	if (step < 2 || len <= 0 || text[len - 1] != 0) return -3;
-	for (i = 0; i < len; ++i) n_seq += text[i] == 0;
+	for (q = text; (q = (const uint8_t*)memchr(q, 0, (size_t)(text + len - q))) != 0; ++q) ++n_seq; /* sentinels, at memchr speed */
 	w = (rb3h_walker_t*)malloc((size_t)(n_seq + len / step + 2) * sizeof(rb3h_walker_t));
 	if (!w) return -1;
-	for (j = 0, b = 0, i = 0; i < len; ++i) {
-		int64_t e, prev = -1, p;
-		if (text[i] != 0) continue;
-		e = i; /* string j occupies [b, e), sentinel at e */
+	for (j = 0, b = 0; b < len; ++j) {
+		const int64_t e = (const uint8_t*)memchr(text + b, 0, (size_t)(len - b)) - text; /* string j occupies [b, e), sentinel at e */
+		int64_t prev = -1, p;
 		for (p = (b / step + 1) * step; p < e; p += step) { /* multiples of step strictly inside the string */
-			if (text[p - 1] == 0) continue;
 			if (e - p < RB3H_MIN_SEG && e - p < step) continue; /* keep the sentinel walker's own segment long (see k_chain) */
 			w[nw].row = ckrow[p / step], w[nw].ka0 = -1, w[nw].flags = 0;
 			w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : p - prev;
@@ -76,7 +75,7 @@ int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, cons
 		}
 		w[nw].row = j, w[nw].ka0 = -2 /* sentinel row: exact, = acc[1] of the index */, w[nw].flags = 0;
 		w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : e - prev;
-		++nw, ++j, b = e + 1;
+		++nw, b = e + 1;
 	}
 	*n_walkers = nw, *walkers = w;
 	return 0;

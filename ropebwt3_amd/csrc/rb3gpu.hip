@@ -141,7 +141,8 @@ static IdxView view_of(const rb3gpu_t *h)
 {
 	IdxView v;
 	v.grp64 = (const uint64_t*)h->grp, v.slot16 = (const uint4*)h->slots, v.n = h->n, v.m = h->acc[1];
-	v.dense = (h->nslots == (h->n >> RB3_WIN_BITS) + 1);
+	const int64_t nwin = (h->n >> RB3_WIN_BITS) + 1;
+	v.dense = h->nslots == nwin ? (RB3_ABS_HEADERS(h->nslots, nwin, h->n) ? 2 : 1) : 0;
 	return v;
 }
 
@@ -496,7 +497,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 		const dim3 grid((unsigned)nblk), blk(256);
 #define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
 			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tab, sidctr, sid_limit)
-		const int sel = (walkers ? 4 : 0) | (iv.dense ? 2 : 0) | (tent ? 1 : 0);
+		const int sel = (walkers ? 4 : 0) | (iv.dense == 2 ? 2 : 0) | (tent ? 1 : 0);
 		switch (sel) {
 		case 0: RB3_LAUNCH_CHAIN(false, false, false); break;
 		case 1: RB3_LAUNCH_CHAIN(false, false, true); break;
@@ -668,8 +669,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit)
-		if (iv.dense && tent) RB3_LAUNCH_FAST(true, true);
-		else if (iv.dense) RB3_LAUNCH_FAST(true, false);
+		if (iv.dense == 2 && tent) RB3_LAUNCH_FAST(true, true);
+		else if (iv.dense == 2) RB3_LAUNCH_FAST(true, false);
 		else if (tent) RB3_LAUNCH_FAST(false, true);
 		else RB3_LAUNCH_FAST(false, false);
 #undef RB3_LAUNCH_FAST

@@ -33,8 +33,16 @@ struct IdxView {
 	const uint4 *slot16;     // rb3_slot_t viewed as 8 x uint4
 	int64_t n;               // number of symbols
 	int64_t m;               // number of sentinels (= acc[1])
-	int dense;               // every slot is a bit-plane slot: slot index = position >> 8
+	int dense;               // 0: mixed slots.  1: every slot is a bit-plane slot (slot index = position >> 8).
+	                         // 2: as 1 and the slot headers carry ABSOLUTE counts (RB3_ABS_HEADERS): rank needs no directory
 };
+
+/* A block array whose slots are all bit planes and that holds fewer than 2^32 symbols is written with
+ * hdr[1..6] = C[a] + #{i < slot start : B[i] = a}, the full LF base, instead of the count relative to the
+ * group start: rank(c, k) is then ONE memory request (the slot), which is worth ~16 % of k_chain on such
+ * an index (measured: one more directory request per rank costs 19 %).  The group directory is written
+ * as always.  Both the builder (device, from the scan totals) and the host (view_of) apply this rule. */
+#define RB3_ABS_HEADERS(nslots, nwin, ntot) ((nslots) == (nwin) && (ntot) < (1LL << 32))
 
 struct Acc7 { int64_t a[7]; };
 
@@ -147,11 +155,12 @@ __device__ __forceinline__ uint32_t slice_count(const uint4 &sl, uint32_t hdr0, 
 	return cnt;
 }
 
-__device__ __forceinline__ int64_t oct_rank_finish(const RankLoad &r, int c, int j)
+__device__ __forceinline__ int64_t oct_rank_finish(const RankLoad &r, int c, int j, bool abs_hdr)
 {
 	const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
 	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
 	uint32_t part = slice_count(r.sl, hdr0, off, c, j) & (RB3_MATCH_BIT - 1u);
+	if (abs_hdr) return (int64_t)oct_sum(j == c + 1 ? r.sl.x : 0u) + (int64_t)oct_sum(part); // hdr[c+1] is the whole LF base
 	if (j == c + 1) part += r.sl.x; // hdr[c+1] = count of c between group start and slot start
 	const uint32_t sum = oct_sum(part);
 	const uint32_t lo = oct_sum(j == c ? (uint32_t)r.gw : 0u);
@@ -174,7 +183,7 @@ __global__ void __launch_bounds__(256) k_rank_batch(IdxView ix, Acc7 acc, int64_
 		RankLoad r;
 		oct_rank_issue(ix, kk, j, r);
 		for (int c = 0; c < 6; ++c) {
-			int64_t v = oct_rank_finish(r, c, j) - acc.a[c];
+			int64_t v = oct_rank_finish(r, c, j, ix.dense == 2) - acc.a[c];
 			if (j == 0) ok[q * 6 + c] = v;
 		}
 	}
@@ -448,9 +457,8 @@ __device__ __forceinline__ void octc_issue_grp(const IdxView &ix, int64_t k, int
 {
 	const int64_t g = k >> RB3_GRP_BITS;
 	r.koff = (uint32_t)k & (RB3_GRP - 1);
-	r.gc = ix.grp64[g * 8 + c];
-	if (DENSE) r.sl = ix.slot16[(k >> RB3_WIN_BITS) * 8 + j]; // every window is its own slot: no directory lookup needed
-	else r.sm = ix.grp64[g * 8 + 6];
+	if (DENSE) r.sl = ix.slot16[(k >> RB3_WIN_BITS) * 8 + j]; // every window is its own slot and carries the LF base: no directory lookup
+	else r.gc = ix.grp64[g * 8 + c], r.sm = ix.grp64[g * 8 + 6];
 }
 
 template<bool DENSE>
@@ -468,7 +476,7 @@ template<bool DENSE>
 __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j, uint32_t *match)
 {
 	uint32_t part;
-	if (DENSE) { // bit planes, slot start = window start
+	if (DENSE) { // bit planes, slot start = window start, absolute header (RB3_ABS_HEADERS)
 		int t = (int)(r.koff & (RB3_WIN - 1)) - 32 * j;
 		const uint32_t m0 = (c & 1) ? r.sl.y : ~r.sl.y, m1 = (c & 2) ? r.sl.z : ~r.sl.z, m2 = (c & 4) ? r.sl.w : ~r.sl.w;
 		const uint32_t m = m0 & m1 & m2;
@@ -476,6 +484,9 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 		t = t < 0 ? 0 : t > 32 ? 32 : t;
 		const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
 		part = __popc(m & lim) | (at ? RB3_MATCH_BIT : 0u);
+		const uint32_t base = oct_sum(j == c + 1 ? r.sl.x : 0u), sum = oct_sum(part);
+		*match = sum >> 20;
+		return (int64_t)base + (int64_t)(sum & (RB3_MATCH_BIT - 1u));
 	} else {
 		const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
 		part = slice_count(r.sl, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
@@ -1212,9 +1223,14 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 		}
 		const int64_t srem = ntot - ((g * RB3_GRP_WINS + slot_w0) << RB3_WIN_BITS);
 		const uint32_t nsym = srem <= 0 ? 0u : srem < (int64_t)slot_sz * RB3_WIN ? (uint32_t)srem : (uint32_t)(slot_sz * RB3_WIN);
-		const uint32_t hq = lane == 0 ? (uint32_t)(slot_w0 * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
+		uint32_t hq = lane == 0 ? (uint32_t)(slot_w0 * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
 			lane == 1 ? rel[0] : lane == 2 ? rel[1] : lane == 3 ? rel[2] : lane == 4 ? rel[3] : lane == 5 ? rel[4] :
 			lane == 6 ? rel[5] : nsym;
+		if (RB3_ABS_HEADERS((int64_t)tot[6], W, ntot) && lane >= 1 && lane <= 6) { // the whole LF base (see RB3_ABS_HEADERS)
+			uint64_t cb = gpre[g * 8 + lane - 1];
+			for (int a = 0; a < lane - 1; ++a) cb += tot[a];
+			hq += (uint32_t)cb;
+		}
 		if (slot_sz == 1) { // bit-plane slot
 #pragma unroll
 			for (int u = 0; u < 4; ++u)
@@ -1454,9 +1470,14 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		                          (uint32_t)(s1 & 0xFFFFF), (uint32_t)(s1 >> 20 & 0xFFFFF), (uint32_t)(s1 >> 40) };
 		const int64_t srem = ntot - (w << RB3_WIN_BITS);
 		const uint32_t nsym = srem <= 0 ? 0u : srem < (int64_t)slot_sz * RB3_WIN ? (uint32_t)srem : (uint32_t)(slot_sz * RB3_WIN);
-		const uint32_t hq = lane == 0 ? (uint32_t)(lw * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
+		uint32_t hq = lane == 0 ? (uint32_t)(lw * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
 			lane == 1 ? rel[0] : lane == 2 ? rel[1] : lane == 3 ? rel[2] : lane == 4 ? rel[3] : lane == 5 ? rel[4] :
 			lane == 6 ? rel[5] : nsym;
+		if (RB3_ABS_HEADERS((int64_t)tot[6], nwin, ntot) && lane >= 1 && lane <= 6) { // the whole LF base (see RB3_ABS_HEADERS)
+			uint64_t cb = gpre[g * 8 + lane - 1];
+			for (int a = 0; a < lane - 1; ++a) cb += tot[a];
+			hq += (uint32_t)cb;
+		}
 		if (slot_sz == 1) { // bit-plane slot: header + the cached planes
 			if (lane < 8) {
 				const uint32_t *pl = wplane + w * 24;
@@ -1620,7 +1641,7 @@ __device__ __forceinline__ int64_t oct_lf_self(const IdxView &ix, int64_t k, int
 	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
 	const uint32_t sy = oct_sum(slice_sym(r.sl, hdr0, off, j)) & 7u;
 	*c = (int)sy;
-	return oct_rank_finish(r, (int)sy, j);
+	return oct_rank_finish(r, (int)sy, j, ix.dense == 2);
 }
 
 /* nxt[2p] = next splitter (or RB3_SSA_END | sentinel row reached), nxt[2p+1] = steps of the sublist;

@@ -15,7 +15,10 @@
  *   Slot (128 B) = 8 lane slices of 16 B: { u32 hdr; u32 w[3] }
  *        hdr[0]       bit 31: 1 = run slot, 0 = bit-plane slot; bits 0..15: offset of the
  *                     slot's first symbol from the group start (a multiple of 256)
- *        hdr[1..6]    #{group start <= i < slot start : B[i] = a}, a = 0..5
+ *        hdr[1..6]    #{group start <= i < slot start : B[i] = a}, a = 0..5 -- or, in a block array that
+ *                     consists of bit-plane slots only and holds < 2^32 symbols (RB3_ABS_HEADERS in
+ *                     rb3gpu_kernels.h), the whole LF base C[a] + #{i < slot start : B[i] = a}, so that
+ *                     rank is a single memory request there
  *        hdr[7]       number of symbols covered by the slot
  *      bit-plane slot (exactly one window): slice j holds symbols [32j, 32j+32) as three
  *        32-bit planes; symbol = bit0 | bit1<<1 | bit2<<2; padding past the end = 7

@@ -979,20 +979,21 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa)
 	if (!h || !r2i || (r = rb3gpu_ssa_dims(h, ssa_shift, &m, &n_ssa, &ms)) < 0) return h && r2i ? r : RB3GPU_EINVAL;
 	if (n_ssa > 0 && !ssa) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
-	// splitter spacing: the link pass hops over n/2^S splitters per string one after the other, the walk's
-	// longest sublist is about 2^S ln(number of splitters) steps: 2^9 balances the two for Mbp-long strings
-	// (141 M rows, 32 strings: walk 9.6 / 11.7 / 18.6 ms and link 7.2 / 3.6 / 1.7 ms for S = 8 / 9 / 10)
-	int S = 9;
+	// splitter spacing: the walk's longest sublist is about 2^S ln(number of splitters) steps, and every splitter
+	// costs a queue pull; the linking is pointer jumping, whose cost hardly depends on S
+	// (141 M rows, 32 strings: walk 14.5 / 9.6 / 11.7 / 18.6 ms for S = 7 / 8 / 9 / 10)
+	int S = 8;
 	if (getenv("RB3GPU_SSA_SPLIT")) S = atoi(getenv("RB3GPU_SSA_SPLIT"));
 	if (S < 4) S = 4;
 	if (S > 20) S = 20;
 	const int64_t nsp = m + ((h->n - m + (1LL << S) - 1) >> S);
 	if (nsp >= (1LL << (64 - RB3_SSA_LBITS)) || ms + 1 > 63) return RB3GPU_EINVAL;
-	// scratch: nxt (2 words per splitter), base, sidp, tot, r2i, ssa, all u64
-	const size_t words = (size_t)nsp * 4 + (size_t)m * 2 + (size_t)n_ssa + 8;
+	// scratch: two link tables (2 words per splitter), r2i, ssa, all u64
+	const size_t words = (size_t)nsp * 4 + (size_t)m + (size_t)n_ssa + 8;
 	if ((r = buf_ensure(h, h->xbuf, words * 8)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
-	uint64_t *nxt = (uint64_t*)h->xbuf.p, *base = nxt + 2 * nsp, *sidp = base + nsp, *tot = sidp + nsp, *d_r2i = tot + m, *d_ssa = d_r2i + m;
+	uint64_t *lnk[2] = { (uint64_t*)h->xbuf.p, (uint64_t*)h->xbuf.p + 2 * nsp };
+	uint64_t *d_r2i = lnk[1] + 2 * nsp, *d_ssa = d_r2i + m;
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	const double t0 = now_s();
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
@@ -1001,12 +1002,15 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa)
 	{
 		int64_t nblk = (nsp + 31) / 32;
 		nblk = nblk > 256 * 8 ? 256 * 8 : nblk < 1 ? 1 : nblk;
-		hipLaunchKernelGGL(k_ssa_walk, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), S, ssa_shift, nsp, nxt, d_ssa, misc, misc + 2);
+		hipLaunchKernelGGL(k_ssa_walk, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), S, ssa_shift, nsp, lnk[0], d_ssa, misc, misc + 2);
 	}
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
-	hipLaunchKernelGGL(k_ssa_link, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->st, m, nsp, (const uint64_t*)nxt, base, sidp, tot, d_r2i, misc + 2);
+	int cur = 0;
+	for (int64_t reach = 1; reach < nsp; reach <<= 1, cur ^= 1) // after this round every link spans 2 * reach splitters
+		hipLaunchKernelGGL(k_ssa_jump, dim3((unsigned)((nsp + 255) / 256)), dim3(256), 0, h->st, nsp, (const uint64_t*)lnk[cur], lnk[cur ^ 1]);
+	hipLaunchKernelGGL(k_ssa_heads, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->st, m, (const uint64_t*)lnk[cur], d_r2i, misc + 2);
 	if (n_ssa > 0)
-		hipLaunchKernelGGL(k_ssa_final, dim3((unsigned)((n_ssa + 255) / 256)), dim3(256), 0, h->st, n_ssa, ms, (const uint64_t*)base, (const uint64_t*)sidp, (const uint64_t*)tot, d_ssa);
+		hipLaunchKernelGGL(k_ssa_final, dim3((unsigned)((n_ssa + 255) / 256)), dim3(256), 0, h->st, n_ssa, ms, m, (const uint64_t*)lnk[cur], (const uint64_t*)d_r2i, d_ssa, misc + 2);
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	unsigned long long hm[4];
 	HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));

@@ -1687,38 +1687,45 @@ __global__ void __launch_bounds__(256) k_ssa_walk(IdxView ix, int S, int ss, int
 	}
 }
 
-/* one thread per string: base[p] = steps from the sentinel row of the string to splitter p, sidp[p] = string,
- * tot[k0] = steps of the whole walk (the reference's l, ssa.c:23-37), r2i[row reached] = k0 (ssa.c:36) */
-__global__ void __launch_bounds__(256) k_ssa_link(int64_t m, int64_t nsp, const uint64_t *nxt, uint64_t *base, uint64_t *sidp, uint64_t *tot, uint64_t *r2i, unsigned long long *err)
+/* Pointer jumping over the splitters: after round r, lnk[2p] points 2^r splitters ahead (or holds
+ * RB3_SSA_END | the sentinel row the string ends in) and lnk[2p+1] is the number of LF steps to get there;
+ * ceil(log2(#splitters)) + 1 rounds make every entry (END | row, steps to the start of the string).
+ * Double-buffered: reads `in`, writes `out`. */
+__global__ void __launch_bounds__(256) k_ssa_jump(int64_t nsp, const uint64_t *in, uint64_t *out)
+{
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= nsp) return;
+	const ulonglong2 a = ((const ulonglong2*)in)[p];
+	ulonglong2 r = a;
+	if (!(a.x & RB3_SSA_END) && a.x < (uint64_t)nsp) {
+		const ulonglong2 q = ((const ulonglong2*)in)[a.x];
+		r.x = q.x, r.y = a.y + q.y;
+	}
+	((ulonglong2*)out)[p] = r;
+}
+
+/* the heads of the strings (splitters 0..m-1 = the sentinel rows): r2i[row reached] = string (ssa.c:36) */
+__global__ void __launch_bounds__(256) k_ssa_heads(int64_t m, const uint64_t *lnk, uint64_t *r2i, unsigned long long *err)
 {
 	const int64_t k0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (k0 >= m) return;
-	int64_t p = k0;
-	uint64_t d = 0;
-	for (int64_t hop = 0; hop <= nsp; ++hop) {
-		base[p] = d, sidp[p] = (uint64_t)k0;
-		const uint64_t e = nxt[2 * p];
-		d += nxt[2 * p + 1];
-		if (e & RB3_SSA_END) {
-			const uint64_t row = e & ~RB3_SSA_END;
-			if (row < (uint64_t)m) r2i[row] = (uint64_t)k0; else atomicAdd(err + 1, 1ull);
-			tot[k0] = d;
-			return;
-		}
-		if (e >= (uint64_t)nsp) break;
-		p = (int64_t)e;
-	}
-	atomicAdd(err + 1, 1ull); // a cycle or a broken link: cannot happen with a valid index
+	const uint64_t e = lnk[2 * k0];
+	const uint64_t row = e & ~RB3_SSA_END;
+	if ((e & RB3_SSA_END) && row < (uint64_t)m) r2i[row] = (uint64_t)k0;
+	else atomicAdd(err + 1, 1ull); // a cycle or a broken link: cannot happen with a valid index
 }
 
-/* ssa[x] = (offset of the sampled row's suffix in its string) << ms | string  (ssa.c:38-39) */
-__global__ void __launch_bounds__(256) k_ssa_final(int64_t n_ssa, int ms, const uint64_t *base, const uint64_t *sidp, const uint64_t *tot, uint64_t *ssa)
+/* ssa[x] = (offset of the sampled row's suffix in its string) << ms | string  (ssa.c:38-39).  The row was
+ * reached l steps after splitter p, which is D = lnk[2p+1] steps from the start of the string: the offset is
+ * D - l - 1 (the walk's last step lands on the sentinel row of the previous string, not on a suffix) */
+__global__ void __launch_bounds__(256) k_ssa_final(int64_t n_ssa, int ms, int64_t m, const uint64_t *lnk, const uint64_t *r2i, uint64_t *ssa, unsigned long long *err)
 {
 	const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (x >= n_ssa) return;
 	const uint64_t t = ssa[x], p = t >> RB3_SSA_LBITS, l = t & ((1ull << RB3_SSA_LBITS) - 1);
-	const uint64_t sid = sidp[p];
-	ssa[x] = (tot[sid] - 1 - (base[p] + l)) << ms | sid;
+	const uint64_t e = lnk[2 * p], row = e & ~RB3_SSA_END;
+	if (!(e & RB3_SSA_END) || row >= (uint64_t)m) { atomicAdd(err + 1, 1ull); return; }
+	ssa[x] = (lnk[2 * p + 1] - l - 1) << ms | r2i[row];
 }
 
 #endif

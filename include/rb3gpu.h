@@ -139,6 +139,13 @@ int64_t rb3gpu_get_tot(const rb3gpu_t *h);          /* mr_get_tot, mrope.h:122-1
 typedef int (*rb3gpu_emit_f)(void *data, int c, int64_t l);
 int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data);
 
+/* The same runs in bulk, for writers that want a tight loop instead of a call per run: emit receives arrays of
+ * words start << 3 | sym, one per MAXIMAL run in BWT order (adjacent runs differ in symbol); run i ends where
+ * run i+1 starts -- possibly in the next call -- and the last call is (n = 0, words = NULL, end = total length),
+ * which closes the last run.  In the other calls end is -1. */
+typedef int (*rb3gpu_emit_words_f)(void *data, int64_t n, const uint64_t *words, int64_t end);
+int rb3gpu_export_run_words(rb3gpu_t *h, rb3gpu_emit_words_f emit, void *data);
+
 /* The whole BWT as one symbol per byte (0..5) into host memory of rb3gpu_get_tot() bytes;
  * small indexes / tests only. */
 int rb3gpu_export_plain(rb3gpu_t *h, uint8_t *out);

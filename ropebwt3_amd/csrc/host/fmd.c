@@ -140,6 +140,28 @@ int rb3h_fmdw_enc(rb3h_fmdw_t *w, int64_t l, int c)
 	return 0;
 }
 
+/* bulk form: words[i] = start << 3 | sym of maximal runs in order (rb3gpu_export_run_words); end >= 0 closes the
+ * last run.  Not to be mixed with rb3h_fmdw_enc on the same writer. */
+int rb3h_fmdw_enc_words(rb3h_fmdw_t *w, int64_t n, const uint64_t *words, int64_t end)
+{
+	int64_t i;
+	if (w->finished) return -1;
+	for (i = 0; i < n; ++i) {
+		const int64_t s = (int64_t)(words[i] >> 3);
+		const int c = (int)(words[i] & 7);
+		if (c >= FMD_ASIZE) return -1;
+		if (w->pc >= 0) { /* pl holds the START of the pending run here */
+			if (s <= w->pl || fmdw_enc1(w, s - w->pl, w->pc) < 0) return -1;
+		}
+		w->pl = s, w->pc = c;
+	}
+	if (end >= 0 && w->pc >= 0) {
+		if (end <= w->pl || fmdw_enc1(w, end - w->pl, w->pc) < 0) return -1;
+		w->pc = -1, w->pl = 0;
+	}
+	return 0;
+}
+
 static int fmdw_rank_index(rb3h_fmdw_t *w)
 {
 	const uint64_t n_blks = w->n_bytes * 8 / 64 / FMD_SSIZE + 1;

@@ -86,7 +86,7 @@ static int sink_runvec(void *data, int c, int64_t l)
 	return 0;
 }
 
-static int sink_fmd(void *data, int c, int64_t l) { return rb3h_fmdw_enc((rb3h_fmdw_t*)data, l, c); }
+static int sink_fmd_words(void *data, int64_t n, const uint64_t *words, int64_t end) { return rb3h_fmdw_enc_words((rb3h_fmdw_t*)data, n, words, end); }
 static int sink_fmr(void *data, int c, int64_t l) { return rb3h_fmrw_enc((rb3h_fmrw_t*)data, l, c); }
 
 static int sink_plain(void *data, int c, int64_t l) /* mr_print_bwt, mrope.c:201-214 */
@@ -496,7 +496,7 @@ int main_build(int argc, char *argv[])
 		ret = dump_fmr(h, &opt, stdout);
 	} else if (opt.fmt == FMT_FMD) {
 		rb3h_fmdw_t *w = rb3h_fmdw_init();
-		ret = w ? rb3gpu_export_runs(h, sink_fmd, w) : -1;
+		ret = w ? rb3gpu_export_run_words(h, sink_fmd_words, w) : -1;
 		if (ret == 0) ret = rb3h_fmdw_finish(w);
 		if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
 		rb3h_fmdw_destroy(w);
@@ -595,7 +595,7 @@ int main_merge(int argc, char *argv[])
 		if (fmt == FMT_FMR) ret = dump_fmr(h, &opt, stdout);
 		else {
 			rb3h_fmdw_t *w = rb3h_fmdw_init();
-			ret = w ? rb3gpu_export_runs(h, sink_fmd, w) : -1;
+			ret = w ? rb3gpu_export_run_words(h, sink_fmd_words, w) : -1;
 			if (ret == 0) ret = rb3h_fmdw_finish(w);
 			if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
 			rb3h_fmdw_destroy(w);

@@ -1032,19 +1032,18 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa)
 /* Runs are found on the device (k_export_runs: count, scan, emit), chunk by chunk; only start << 3 | sym of
  * every run crosses PCIe, and the host turns consecutive starts into lengths. */
 #define RB3_RCHUNK_WINS (1LL << 16) /* windows (16 M symbols) per chunk: at most 128 MB of run words */
-int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
+/* chunk by chunk: run starts on the device, copied through the pinned staging buffers when they fit */
+static int export_run_words(rb3gpu_t *h, rb3gpu_emit_words_f emit, void *data)
 {
-	if (!h || !emit) return RB3GPU_EINVAL;
-	HIPCHK(hipSetDevice(h->dev));
-	if (h->grp == nullptr) return RB3GPU_ESTATE;
-	double t = now_s();
 	const int64_t nwin = (h->n + RB3_WIN - 1) >> RB3_WIN_BITS;
 	const IdxView iv = view_of(h);
-	int ret = 0, c = -1;
-	int64_t start = 0;
+	int ret = 0;
 	uint64_t *host = nullptr;
 	size_t host_cap = 0;
 	if ((ret = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return ret;
+	if (h->stage[0] == nullptr)
+		for (int i = 0; i < 2; ++i)
+			if (hipHostMalloc((void**)&h->stage[i], RB3_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { h->stage[i] = nullptr; break; }
 	for (int64_t w0 = 0; w0 < nwin && ret == 0; w0 += RB3_RCHUNK_WINS) {
 		const int64_t nw = w0 + RB3_RCHUNK_WINS < nwin ? RB3_RCHUNK_WINS : nwin - w0;
 		if ((ret = buf_ensure(h, h->gstat, (size_t)nw * 32)) < 0) break;
@@ -1057,24 +1056,57 @@ int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
 		const int64_t nr = (int64_t)total[0];
 		if (nr == 0) continue;
 		if ((ret = buf_ensure(h, h->xbuf, (size_t)nr * 8)) < 0) break;
-		if ((size_t)nr > host_cap) {
-			free(host);
-			host_cap = (size_t)nr + ((size_t)nr >> 2) + 1024;
-			if ((host = (uint64_t*)malloc(host_cap * 8)) == nullptr) { ret = RB3GPU_ENOMEM; break; }
-		}
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<true>), grid, blk, 0, h->st, iv, w0, nw, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
-		HIPCHK(hipMemcpyAsync(host, h->xbuf.p, (size_t)nr * 8, hipMemcpyDeviceToHost, h->st));
-		HIPCHK(hipStreamSynchronize(h->st));
-		for (int64_t i = 0; i < nr; ++i) {
-			const int64_t s = (int64_t)(host[i] >> 3);
-			if (c >= 0 && emit(data, c, s - start) != 0) { ret = RB3GPU_EINVAL; break; }
-			c = (int)(host[i] & 7), start = s;
+		uint64_t *dst;
+		if (h->stage[0] && (size_t)nr * 8 <= RB3_STAGE_BYTES) dst = (uint64_t*)h->stage[0];
+		else {
+			if ((size_t)nr > host_cap) {
+				free(host);
+				host_cap = (size_t)nr + ((size_t)nr >> 2) + 1024;
+				if ((host = (uint64_t*)malloc(host_cap * 8)) == nullptr) { ret = RB3GPU_ENOMEM; break; }
+			}
+			dst = host;
 		}
+		HIPCHK(hipMemcpyAsync(dst, h->xbuf.p, (size_t)nr * 8, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+		if (emit(data, nr, dst, -1) != 0) ret = RB3GPU_EINVAL;
 	}
-	if (ret == 0 && c >= 0 && emit(data, c, h->n - start) != 0) ret = RB3GPU_EINVAL;
+	if (ret == 0 && emit(data, 0, nullptr, h->n) != 0) ret = RB3GPU_EINVAL;
 	free(host);
+	return ret;
+}
+
+int rb3gpu_export_run_words(rb3gpu_t *h, rb3gpu_emit_words_f emit, void *data)
+{
+	if (!h || !emit) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	const double t = now_s();
+	const int ret = export_run_words(h, emit, data);
 	h->stt.ms_export += (now_s() - t) * 1e3;
 	return ret;
+}
+
+/* one call per run on top of the bulk export (the host turns consecutive starts into lengths) */
+struct RunAdapter { rb3gpu_emit_f emit; void *data; int c; int64_t start; };
+
+static int run_adapter(void *data, int64_t n, const uint64_t *words, int64_t end)
+{
+	RunAdapter *a = (RunAdapter*)data;
+	for (int64_t i = 0; i < n; ++i) {
+		const int64_t s = (int64_t)(words[i] >> 3);
+		if (a->c >= 0 && a->emit(a->data, a->c, s - a->start) != 0) return -1;
+		a->c = (int)(words[i] & 7), a->start = s;
+	}
+	if (end >= 0 && a->c >= 0 && a->emit(a->data, a->c, end - a->start) != 0) return -1;
+	return 0;
+}
+
+int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
+{
+	if (!h || !emit) return RB3GPU_EINVAL;
+	RunAdapter a = { emit, data, -1, 0 };
+	return rb3gpu_export_run_words(h, run_adapter, &a);
 }
 
 int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs)

@@ -42,6 +42,7 @@ class Stats(ctypes.Structure):
 
 
 EMIT_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64)
+EMIT_WORDS_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64)
 
 # name -> (restype, argtypes); every symbol declared in include/rb3gpu.h
 SYMBOLS = {
@@ -65,6 +66,7 @@ SYMBOLS = {
     "rb3gpu_get_acc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_get_tot": (ctypes.c_int64, [ctypes.c_void_p]),
     "rb3gpu_export_runs": (ctypes.c_int, [ctypes.c_void_p, EMIT_F, ctypes.c_void_p]),
+    "rb3gpu_export_run_words": (ctypes.c_int, [ctypes.c_void_p, EMIT_WORDS_F, ctypes.c_void_p]),
     "rb3gpu_export_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_export_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_ssa_dims": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),

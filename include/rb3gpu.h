@@ -28,6 +28,7 @@ extern "C" {
 #define RB3GPU_ESYMBOL   -4      /* a BWT byte is outside 0..5 (fm-index.c:124-125) */
 #define RB3GPU_ESTATE    -5      /* call not valid in this state (e.g. merge into an empty index) */
 #define RB3GPU_EINTERNAL -6      /* invariant violated on the device (fm-index.c:246 analogue) */
+#define RB3GPU_EUNSUP    -7      /* this call cannot serve this index; use the alternative named in its description */
 
 typedef struct rb3gpu_s rb3gpu_t;
 
@@ -145,6 +146,15 @@ int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data);
  * which closes the last run.  In the other calls end is -1. */
 typedef int (*rb3gpu_emit_words_f)(void *data, int64_t n, const uint64_t *words, int64_t end);
 int rb3gpu_export_run_words(rb3gpu_t *h, rb3gpu_emit_words_f emit, void *data);
+
+/* The data section of the .fmd packed on the GPU (rb3_enc_fmr2fmd + rld_enc + rld_enc_finish, fm-index.c:31-52,
+ * rld0.c:107-216): *words receives a malloc'ed array (free it with rb3gpu_host_free) of *n_words 64-bit words, the
+ * blocks incl. the trailing header-only block, exactly what rld_dump writes between the file header and the rank
+ * index (rld0.c:237-239; n_bytes = 8 * *n_words).  Serves indexes whose FMD blocks all have 16-bit headers (every
+ * block holds fewer than 0x4000 symbols -- short-read data); otherwise returns RB3GPU_EUNSUP and the caller packs
+ * the runs of rb3gpu_export_run_words on the host. */
+int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words);
+void rb3gpu_host_free(void *p);
 
 /* The whole BWT as one symbol per byte (0..5) into host memory of rb3gpu_get_tot() bytes;
  * small indexes / tests only. */

@@ -40,11 +40,11 @@ def hipcc_path():
 
 def build_gpu(force=False):
     """librb3gpu.so: the HIP engine + C ABI (include/rb3gpu.h), gfx950 only."""
-    srcs = [os.path.join(CSRC, f) for f in ("rb3gpu.hip", "rb3gpu_sort.hip", "rb3gpu_kernels.h", "rb3gpu_layout.h")] + [os.path.join(INCLUDE, "rb3gpu.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("rb3gpu.hip", "rb3gpu_sort.hip", "rb3gpu_fmdenc.hip", "rb3gpu_kernels.h", "rb3gpu_layout.h")] + [os.path.join(INCLUDE, "rb3gpu.h")]
     if not force and _newer(LIB_GPU, srcs):
         return LIB_GPU
     _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-          "-I" + INCLUDE, "-I" + CSRC, "-o", LIB_GPU, os.path.join(CSRC, "rb3gpu.hip"), os.path.join(CSRC, "rb3gpu_sort.hip")])
+          "-I" + INCLUDE, "-I" + CSRC, "-o", LIB_GPU, os.path.join(CSRC, "rb3gpu.hip"), os.path.join(CSRC, "rb3gpu_sort.hip"), os.path.join(CSRC, "rb3gpu_fmdenc.hip")])
     return LIB_GPU
 
 

@@ -216,6 +216,25 @@ int rb3h_fmdw_finish(rb3h_fmdw_t *w)
 	return 0;
 }
 
+/* take over a data section that was packed elsewhere (rb3gpu_export_fmd_words): `words` is malloc'ed, n_words words incl.
+ * the trailing header-only block; acc[] is the C array of the BWT (acc[6] = its length).  Builds the rank index; the
+ * writer is finished afterwards. */
+int rb3h_fmdw_adopt(rb3h_fmdw_t *w, uint64_t *words, int64_t n_words, const int64_t acc[7])
+{
+	int i;
+	if (w->finished || words == 0 || n_words < 2) return -1;
+	free(w->z);
+	w->z = words, w->m = n_words;
+	w->n_bytes = (uint64_t)n_words * 8;
+	w->mcnt[0] = (uint64_t)acc[6];
+	for (i = 1; i <= FMD_ASIZE; ++i) w->mcnt[i] = (uint64_t)(acc[i] - acc[i - 1]);
+	memcpy(w->cnt, w->mcnt, sizeof(w->cnt));
+	for (w->cnt[0] = 0, i = 1; i <= FMD_ASIZE; ++i) w->cnt[i] += w->cnt[i - 1];
+	if (fmdw_rank_index(w) < 0) return -1;
+	w->finished = 1;
+	return 0;
+}
+
 int64_t rb3h_fmdw_nbytes(const rb3h_fmdw_t *w) { return (int64_t)w->n_bytes; }
 
 int rb3h_fmdw_dump(const rb3h_fmdw_t *w, FILE *fp)

@@ -87,6 +87,30 @@ static int sink_runvec(void *data, int c, int64_t l)
 }
 
 static int sink_fmd_words(void *data, int64_t n, const uint64_t *words, int64_t end) { return rb3h_fmdw_enc_words((rb3h_fmdw_t*)data, n, words, end); }
+
+/* the .fmd of the index (rb3_enc_fmr2fmd + rld_dump, build.c:248-252): the data section is packed on the GPU when all
+ * its blocks have 16-bit headers, else the GPU finds the runs and the host packs them; the rank index is built here */
+static int write_fmd(rb3gpu_t *h, FILE *fp)
+{
+	rb3h_fmdw_t *w = rb3h_fmdw_init();
+	uint64_t *words = 0;
+	int64_t n_words = 0, acc[7];
+	int ret;
+	if (w == 0) return -1;
+	ret = getenv("RB3_HOST_FMD") ? RB3GPU_EUNSUP : rb3gpu_export_fmd_words(h, &words, &n_words);
+	if (ret == 0) {
+		rb3gpu_get_acc(h, acc);
+		ret = rb3h_fmdw_adopt(w, words, n_words, acc); /* takes the array over */
+		if (ret < 0) rb3gpu_host_free(words);
+		else if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] packed the FMD on the GPU\n", __func__, rb3h_realtime(), rb3h_percent_cpu());
+	} else if (ret == RB3GPU_EUNSUP) {
+		ret = rb3gpu_export_run_words(h, sink_fmd_words, w);
+		if (ret == 0) ret = rb3h_fmdw_finish(w);
+	}
+	if (ret == 0) ret = rb3h_fmdw_dump(w, fp);
+	rb3h_fmdw_destroy(w);
+	return ret;
+}
 static int sink_fmr(void *data, int c, int64_t l) { return rb3h_fmrw_enc((rb3h_fmrw_t*)data, l, c); }
 
 static int sink_plain(void *data, int c, int64_t l) /* mr_print_bwt, mrope.c:201-214 */
@@ -495,11 +519,7 @@ int main_build(int argc, char *argv[])
 	if (opt.fmt == FMT_FMR) { /* build.c:245-260 */
 		ret = dump_fmr(h, &opt, stdout);
 	} else if (opt.fmt == FMT_FMD) {
-		rb3h_fmdw_t *w = rb3h_fmdw_init();
-		ret = w ? rb3gpu_export_run_words(h, sink_fmd_words, w) : -1;
-		if (ret == 0) ret = rb3h_fmdw_finish(w);
-		if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
-		rb3h_fmdw_destroy(w);
+		ret = write_fmd(h, stdout);
 	} else {
 		ret = rb3gpu_export_runs(h, sink_plain, stdout);
 		fputc('\n', stdout);
@@ -594,11 +614,7 @@ int main_merge(int argc, char *argv[])
 	if (ret == 0) {
 		if (fmt == FMT_FMR) ret = dump_fmr(h, &opt, stdout);
 		else {
-			rb3h_fmdw_t *w = rb3h_fmdw_init();
-			ret = w ? rb3gpu_export_run_words(h, sink_fmd_words, w) : -1;
-			if (ret == 0) ret = rb3h_fmdw_finish(w);
-			if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
-			rb3h_fmdw_destroy(w);
+			ret = write_fmd(h, stdout);
 		}
 		fflush(stdout);
 	}

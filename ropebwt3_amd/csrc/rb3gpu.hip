@@ -27,6 +27,8 @@ rb3sort_ws *rb3sort_create(void);
 void rb3sort_destroy(rb3sort_ws *ws);
 int64_t rb3sort_bytes(const rb3sort_ws *ws);
 int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds);
+/* the FMD packer lives in rb3gpu_fmdenc.hip */
+int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words);
 
 struct Buf {
 	void *p = nullptr;
@@ -164,6 +166,7 @@ const char *rb3gpu_strerror(int err)
 	case RB3GPU_ESYMBOL: return "BWT symbol outside 0..5";
 	case RB3GPU_ESTATE: return "operation not valid in this state";
 	case RB3GPU_EINTERNAL: return "device-side invariant violated";
+	case RB3GPU_EUNSUP: return "not supported for this index by this call";
 	default: return "unknown error";
 	}
 }
@@ -1086,6 +1089,40 @@ int rb3gpu_export_run_words(rb3gpu_t *h, rb3gpu_emit_words_f emit, void *data)
 	h->stt.ms_export += (now_s() - t) * 1e3;
 	return ret;
 }
+
+int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
+{
+	if (!h || !words || !n_words) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	const double t = now_s();
+	const int64_t nwin = (h->n + RB3_WIN - 1) >> RB3_WIN_BITS;
+	const IdxView iv = view_of(h);
+	int r;
+	*words = nullptr, *n_words = 0;
+	// the run starts of the whole index, resident: count per window, scan, emit
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->gstat, (size_t)nwin * 32)) < 0) return r;
+	if ((r = buf_ensure(h, h->gpre, (size_t)nwin * 64)) < 0) return r;
+	uint32_t *cnt8 = (uint32_t*)h->gstat.p;
+	uint64_t *off8 = (uint64_t*)h->gpre.p, total[8];
+	const dim3 grid((unsigned)((nwin + 3) / 4)), blk(256);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<false>), grid, blk, 0, h->st, iv, (int64_t)0, nwin, cnt8, (const uint64_t*)nullptr, (uint64_t*)nullptr);
+	if ((r = scan_records(h, cnt8, nwin, off8, (uint64_t*)h->misc.p + MISC_IX_TOT, total)) < 0) return r;
+	const int64_t nr = (int64_t)total[0];
+	if (nr <= 0) return RB3GPU_EINTERNAL;
+	if ((r = buf_ensure(h, h->xbuf, (size_t)nr * 8)) < 0) return r;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<true>), grid, blk, 0, h->st, iv, (int64_t)0, nwin, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
+	r = rb3fmd_encode(h->st, h->n, nr, (const uint64_t*)h->xbuf.p, words, n_words);
+	h->stt.ms_export += (now_s() - t) * 1e3;
+	if (r == 1) return RB3GPU_EUNSUP;
+	if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -2 ? RB3GPU_ENODEV : RB3GPU_EINTERNAL;
+	if (h->opt.verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f] packed %lld runs into %lld FMD words on the GPU in %.3f ms\n", __func__, now_s() - h->t0, (long long)nr, (long long)*n_words, (now_s() - t) * 1e3);
+	return 0;
+}
+
+void rb3gpu_host_free(void *p) { free(p); }
 
 /* one call per run on top of the bulk export (the host turns consecutive starts into lengths) */
 struct RunAdapter { rb3gpu_emit_f emit; void *data; int c; int64_t start; };

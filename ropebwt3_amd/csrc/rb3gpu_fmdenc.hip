@@ -1,0 +1,237 @@
+/*
+ * rb3gpu_fmdenc.hip -- the FMD word stream (rld0.c:107-216) packed on the GPU.  gfx950 only.
+ *
+ * Input: the maximal runs of the BWT as start << 3 | sym, resident in HBM (k_export_runs).  Output: the
+ * 64-bit words rld_enc/rld_enc_finish would have produced (blocks of 8 words: a header with the symbol
+ * counts of the block before, then Elias-delta codes, rld0.c:45-51, 137-151), ready for the rank index and
+ * rld_dump on the host.
+ *
+ * The reference packs greedily and sequentially: a code goes into the current block unless it would reach
+ * the end of the block's last usable word (rld0.c:142).  In terms of the prefix sums P of the code widths
+ * that is: the block starting at run i holds the runs j with P[j+1] - P[i] < C (C = payload bits of the
+ * block), so where a block ends only depends on where it starts -- a chain i -> next(i), at most 97 runs
+ * ahead.  Chains started at different runs do NOT fall into step quickly (their offset in bits only drifts
+ * by a few bits per block), so the chain is found exactly: the runs are cut into chunks of 4096; the first
+ * block start in a chunk is one of its first 128 runs, and for each of those 128 possible entries a thread
+ * follows the chain through the chunk and notes where it leaves (offset into the next chunk) and how many
+ * blocks it passed.  The host then walks these small tables chunk by chunk -- one lookup each -- to get
+ * every chunk's true entry and first block index, and a second kernel writes the block starts.  The last
+ * block of a 2^20-block superblock has one payload word less (rld0.h:81): the walk stops there, that one
+ * block is ended on the device, and the walk resumes behind it (the tables do not depend on it).
+ * Then one thread per block packs its runs.
+ *
+ * Only blocks with 16-bit headers (fewer than 0x4000 symbols in the block before, rld0.c:116-128) are
+ * produced here -- every block of a low-compressibility index such as short reads, which is where packing
+ * is worth moving; anything else returns 1 and the caller packs on the host as before.
+ */
+#include <cstring>
+#include <cstdlib>
+#include <algorithm>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <stdint.h>
+#include <stdio.h>
+
+#define FE_C0        384          /* payload bits of a block with a 16-bit header: 6 words */
+#define FE_SB_BLOCKS (1LL << 20)  /* blocks per superblock (2^23 words) */
+#define FE_CHUNK     4096         /* runs per speculation chunk */
+
+#define FE_HIP(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); ret = -2; goto done; } } while (0)
+#define FE_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, st
+
+__device__ __forceinline__ int fe_ilog2(uint64_t v) { return 63 - __clzll((long long)v); }
+
+struct fe_widen { __device__ __host__ uint64_t operator()(uint8_t v) const { return (uint64_t)v; } }; // the scan accumulates in 64 bits
+
+/* width of the code of every run (rld0.c:45-51, 140-141); flag[0] |= 1 if a code would not fit 63 bits */
+__global__ void __launch_bounds__(256) k_fe_width(const uint64_t *words, int64_t nr, int64_t n_sym, uint8_t *width, unsigned int *flag)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > nr) return;
+	if (i == nr) { width[i] = 0; return; }
+	const int64_t s = (int64_t)(words[i] >> 3), e = i + 1 < nr ? (int64_t)(words[i + 1] >> 3) : n_sym;
+	const uint64_t l = (uint64_t)(e - s);
+	const int y = fe_ilog2(l), zz = fe_ilog2((uint64_t)y + 1);
+	const int w = (zz << 1) + 1 + y + 3;
+	if (w >= 64 || e <= s) atomicOr(flag, 1u);
+	width[i] = (uint8_t)w;
+}
+
+/* first run of the block after the one that starts at run i (payload of C bits) */
+__device__ __forceinline__ int64_t fe_next(const uint64_t *P, int64_t nr, int64_t i, int C)
+{
+	const uint64_t lim = P[i] + (uint64_t)C;
+	int64_t lo = i + 1, hi = i + 1 + C / 4 < nr ? i + 1 + C / 4 : nr; // a code has at least 4 bits
+	if (P[hi] < lim) return nr; // everything that is left fits
+	while (lo < hi) { // smallest t in (i, nr] with P[t] >= lim
+		const int64_t mid = (lo + hi) >> 1;
+		if (P[mid] >= lim) hi = mid; else lo = mid + 1;
+	}
+	return lo - 1;
+}
+
+#define FE_ENTRIES 128            /* possible entry offsets into a chunk (a block spans at most 97 runs) */
+
+/* for chunk k and entry offset d: follow the chain from run k R + d to the first block start at or behind the end of
+ * the chunk; E = that start's offset into the next chunk, Cn = blocks passed */
+__global__ void __launch_bounds__(256) k_fe_table(int64_t K, int64_t nr, const uint64_t *P, uint8_t *E, uint16_t *Cn)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= K * FE_ENTRIES) return;
+	const int64_t k = t / FE_ENTRIES, end = (k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr;
+	int64_t i = k * FE_CHUNK + (t % FE_ENTRIES), c = 0;
+	while (i < end) i = fe_next(P, nr, i, FE_C0), ++c;
+	E[t] = (uint8_t)(i - end), Cn[t] = (uint16_t)c;
+}
+
+/* the same from one given run (the first chunk of a superblock is entered anywhere): out = { exit, blocks } */
+__global__ void k_fe_chain1(int64_t i, int64_t end, int64_t nr, const uint64_t *P, int64_t *out)
+{
+	int64_t c = 0;
+	while (i < end) i = fe_next(P, nr, i, FE_C0), ++c;
+	out[0] = i, out[1] = c;
+}
+
+/* block starts of the listed chunks: chunk ids[j] is entered at run entry[j], whose block has the global index base[j];
+ * only indices up to `last` are written */
+__global__ void __launch_bounds__(256) k_fe_emit(int64_t nlist, const int64_t *ids, const int64_t *entry, const int64_t *base, int64_t nr, const uint64_t *P, int64_t last, int64_t *bs)
+{
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nlist) return;
+	const int64_t k = ids[j], end = (k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr;
+	int64_t i = entry[j], b = base[j];
+	while (i < end && b <= last) bs[b] = i, i = fe_next(P, nr, i, FE_C0), ++b;
+}
+
+/* the superblock's last block: it starts at bs[gb] and has one payload word less; out[0] = first run behind it */
+__global__ void k_fe_special(const uint64_t *P, int64_t nr, const int64_t *bs, int64_t gb, int64_t *out)
+{
+	out[0] = fe_next(P, nr, bs[gb], FE_C0 - 64);
+}
+
+/* one thread per block (and one more for the trailing header-only block, rld0.c:206-216) */
+__global__ void __launch_bounds__(256) k_fe_pack(const uint64_t *words, int64_t nr, int64_t n_sym, const int64_t *bs, int64_t B, uint64_t *out, unsigned int *flag)
+{
+	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > B) return;
+	uint64_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	if (b > 0) { // header: what the block before contained (rld0.c:116-128), 7 x uint16
+		uint32_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+		for (int64_t i = bs[b - 1]; i < bs[b]; ++i) {
+			const int64_t s = (int64_t)(words[i] >> 3), e = i + 1 < nr ? (int64_t)(words[i + 1] >> 3) : n_sym;
+			const uint64_t l = (uint64_t)(e - s);
+			if (l >= 0x4000) { atomicOr(flag, 2u); break; }
+			c[0] += (uint32_t)l, c[1 + (int)(words[i] & 7)] += (uint32_t)l;
+			if (c[0] >= 0x4000) { atomicOr(flag, 2u); break; } // needs a 32-bit header: not produced here
+		}
+		z[0] = (uint64_t)c[0] | (uint64_t)c[1] << 16 | (uint64_t)c[2] << 32 | (uint64_t)c[3] << 48;
+		z[1] = (uint64_t)c[4] | (uint64_t)c[5] << 16 | (uint64_t)c[6] << 32;
+	}
+	if (b == B) { out[8 * b] = z[0], out[8 * b + 1] = z[1]; return; }
+	int p = 2, r = 64;
+	for (int64_t i = bs[b]; i < bs[b + 1]; ++i) { // rld_enc1, rld0.c:137-151, without the block switch
+		const int64_t s = (int64_t)(words[i] >> 3), e = i + 1 < nr ? (int64_t)(words[i + 1] >> 3) : n_sym;
+		const uint64_t l = (uint64_t)(e - s);
+		const int y = fe_ilog2(l), zz = fe_ilog2((uint64_t)y + 1);
+		int w = (zz << 1) + 1 + y + 3;
+		const uint64_t delta = (l ^ (uint64_t)1 << y) | (uint64_t)(y + 1) << y;
+		const uint64_t x = delta << 3 | (words[i] & 7);
+		if (w > r) { // straddles two words of the block
+			w -= r;
+			if (p >= 7) { atomicOr(flag, 4u); break; } // cannot happen if the chain is right
+			z[p++] |= x >> w;
+			r = 64 - w;
+			z[p] = x << r;
+		} else {
+			r -= w;
+			z[p] |= x << r;
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < 8; ++q) out[8 * b + q] = z[q];
+}
+
+/* d_words: nr words start << 3 | sym of the maximal runs of a BWT of n_sym symbols (device).  On success (0) *z_out is
+ * a malloc'ed host array of *n_words words: the FMD data section incl. the trailing header.  1: this index needs block
+ * headers wider than 16 bits somewhere (pack on the host); < 0: -1 out of memory, -2 HIP error, -3 internal. */
+int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words)
+{
+	int ret = 0;
+	uint8_t *width = nullptr, *E = nullptr, *hE = nullptr;
+	uint16_t *Cn = nullptr, *hCn = nullptr;
+	uint64_t *P = nullptr, *out = nullptr, *host = nullptr;
+	int64_t *lists = nullptr, *hlists = nullptr, *bs = nullptr, *scal = nullptr;
+	unsigned int *flag = nullptr, hflag[2];
+	void *tmp = nullptr;
+	size_t tb = 0;
+	const int64_t K = (nr + FE_CHUNK - 1) / FE_CHUNK;
+	int64_t o = 0, gb0 = 0, B = 0;
+	*z_out = nullptr, *n_words = 0;
+	if (nr <= 0 || n_sym <= 0) return -3;
+	if (hipMalloc(&width, (size_t)nr + 16) != hipSuccess || hipMalloc(&P, (size_t)(nr + 1) * 8) != hipSuccess || hipMalloc(&bs, (size_t)(nr + 2) * 8) != hipSuccess ||
+		hipMalloc(&E, (size_t)K * FE_ENTRIES) != hipSuccess || hipMalloc(&Cn, (size_t)K * FE_ENTRIES * 2) != hipSuccess || hipMalloc(&lists, (size_t)(K + 1) * 24) != hipSuccess ||
+		hipMalloc(&scal, 64) != hipSuccess || hipMalloc(&flag, 16) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
+	hE = (uint8_t*)malloc((size_t)K * FE_ENTRIES), hCn = (uint16_t*)malloc((size_t)K * FE_ENTRIES * 2), hlists = (int64_t*)malloc((size_t)(K + 1) * 24);
+	if (!hE || !hCn || !hlists) { ret = -1; goto done; }
+	FE_HIP(rocprim::exclusive_scan(nullptr, tb, rocprim::make_transform_iterator(width, fe_widen()), P, (uint64_t)0, (size_t)(nr + 1), rocprim::plus<uint64_t>(), st));
+	tb += 256;
+	if (hipMalloc(&tmp, tb) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
+	FE_HIP(hipMemsetAsync(flag, 0, 16, st));
+	hipLaunchKernelGGL(k_fe_width, FE_GRID(nr + 1), d_words, nr, n_sym, width, flag);
+	{ size_t b = tb; FE_HIP(rocprim::exclusive_scan(tmp, b, rocprim::make_transform_iterator(width, fe_widen()), P, (uint64_t)0, (size_t)(nr + 1), rocprim::plus<uint64_t>(), st)); }
+	hipLaunchKernelGGL(k_fe_table, FE_GRID(K * FE_ENTRIES), K, nr, (const uint64_t*)P, E, Cn);
+	FE_HIP(hipMemcpyAsync(hE, E, (size_t)K * FE_ENTRIES, hipMemcpyDeviceToHost, st));
+	FE_HIP(hipMemcpyAsync(hCn, Cn, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
+	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
+	FE_HIP(hipStreamSynchronize(st));
+	if (hflag[0] & 1u) { if (getenv("RB3_FMD_DEBUG")) fprintf(stderr, "[fmdenc] a code of 64 bits or more\n"); ret = 1; goto done; }
+	// the chain, one superblock at a time: the host walks the chunk tables
+	for (;;) {
+		const int64_t s = gb0 | (FE_SB_BLOCKS - 1); // global index of this superblock's last block
+		const int64_t k0 = o / FE_CHUNK;
+		int64_t *ids = hlists, *ent = hlists + (K + 1), *bas = hlists + 2 * (K + 1), nl = 0, c1[2];
+		hipLaunchKernelGGL(k_fe_chain1, dim3(1), dim3(1), 0, st, o, (k0 + 1) * FE_CHUNK < nr ? (k0 + 1) * FE_CHUNK : nr, nr, (const uint64_t*)P, scal);
+		FE_HIP(hipMemcpyAsync(c1, scal, 16, hipMemcpyDeviceToHost, st));
+		FE_HIP(hipStreamSynchronize(st));
+		ids[nl] = k0, ent[nl] = o, bas[nl] = gb0, ++nl;
+		int64_t cur = c1[0], gb = gb0 + c1[1]; // the block that starts at run cur has global index gb
+		for (int64_t k = k0 + 1; cur < nr && gb <= s; ++k) {
+			const int64_t d = cur - k * FE_CHUNK;
+			if (d < 0 || d >= FE_ENTRIES) { ret = -3; goto done; }
+			ids[nl] = k, ent[nl] = cur, bas[nl] = gb, ++nl;
+			gb += hCn[k * FE_ENTRIES + d];
+			cur = ((k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr) + hE[k * FE_ENTRIES + d];
+		}
+		FE_HIP(hipMemcpyAsync(lists, ids, (size_t)nl * 8, hipMemcpyHostToDevice, st));
+		FE_HIP(hipMemcpyAsync(lists + (K + 1), ent, (size_t)nl * 8, hipMemcpyHostToDevice, st));
+		FE_HIP(hipMemcpyAsync(lists + 2 * (K + 1), bas, (size_t)nl * 8, hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_fe_emit, FE_GRID(nl), nl, (const int64_t*)lists, (const int64_t*)(lists + (K + 1)), (const int64_t*)(lists + 2 * (K + 1)), nr, (const uint64_t*)P, s, bs);
+		if (gb <= s) { B = gb; FE_HIP(hipStreamSynchronize(st)); break; } // the data end before this superblock does
+		hipLaunchKernelGGL(k_fe_special, dim3(1), dim3(1), 0, st, (const uint64_t*)P, nr, (const int64_t*)bs, s, scal);
+		FE_HIP(hipMemcpyAsync(&o, scal, 8, hipMemcpyDeviceToHost, st));
+		FE_HIP(hipStreamSynchronize(st));
+		gb0 = s + 1;
+		if (o >= nr) { B = gb0; break; }
+	}
+	{
+		const int64_t nrv = nr;
+		FE_HIP(hipMemcpyAsync(bs + B, &nrv, 8, hipMemcpyHostToDevice, st));
+		FE_HIP(hipStreamSynchronize(st));
+	}
+	if (hipMalloc(&out, (size_t)(8 * B + 8) * 8) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
+	hipLaunchKernelGGL(k_fe_pack, FE_GRID(B + 1), d_words, nr, n_sym, (const int64_t*)bs, B, out, flag);
+	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
+	FE_HIP(hipStreamSynchronize(st));
+	if (hflag[0] & 4u) { ret = -3; goto done; }
+	if (hflag[0] & 3u) { if (getenv("RB3_FMD_DEBUG")) fprintf(stderr, "[fmdenc] flags %u: a block needs a wider header\n", hflag[0]); ret = 1; goto done; }
+	if ((host = (uint64_t*)malloc((size_t)(8 * B + 8) * 8)) == nullptr) { ret = -1; goto done; }
+	FE_HIP(hipMemcpy(host, out, (size_t)(8 * B + 2) * 8, hipMemcpyDeviceToHost));
+	*z_out = host, *n_words = 8 * B + 2, host = nullptr;
+done:
+	free(host); free(hE); free(hCn); free(hlists);
+	{
+		void *all[] = { width, P, out, E, Cn, lists, bs, scal, flag, tmp };
+		for (void *p : all) if (p) (void)hipFree(p);
+	}
+	return ret;
+}

@@ -67,6 +67,8 @@ SYMBOLS = {
     "rb3gpu_get_tot": (ctypes.c_int64, [ctypes.c_void_p]),
     "rb3gpu_export_runs": (ctypes.c_int, [ctypes.c_void_p, EMIT_F, ctypes.c_void_p]),
     "rb3gpu_export_run_words": (ctypes.c_int, [ctypes.c_void_p, EMIT_WORDS_F, ctypes.c_void_p]),
+    "rb3gpu_export_fmd_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
+    "rb3gpu_host_free": (None, [ctypes.c_void_p]),
     "rb3gpu_export_plain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_export_plain_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_ssa_dims": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),

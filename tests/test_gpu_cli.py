@@ -141,12 +141,12 @@ def test_build_host_sort_identical(name):
     for m in ent["m_variants"]:
         out, err = run(["build", "--host-sort"] + ent["flags"] + ["-m" + m, "-d"] + inputs)
         assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (name, m)
-        assert "on the GPU" not in err
+        assert "symbols on the GPU" not in err
     out, err = run(["build", "--host-sort", "-p3"] + ent["flags"] + ["-m" + ent["m_variants"][-1], "-d"] + inputs)
     assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
     out, err = run(["build", "-p2"] + ent["flags"] + ["-m" + ent["m_variants"][-1], "-d"] + inputs)
     assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
-    assert "partial BWT for" in err and "on the GPU" in err
+    assert "symbols on the GPU" in err
 
 
 def test_differential_fuzz_against_the_reference_binary():
@@ -157,3 +157,20 @@ def test_differential_fuzz_against_the_reference_binary():
         pytest.skip("no reference binary")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(util.GOLDEN), "..", "tools", "fuzz_cli.py"), "12", "4000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+def test_fmd_packed_on_gpu_and_on_host_agree(tmp_path):
+    """the .fmd data section is packed on the GPU when every block has a 16-bit header (read-like data) and on the
+    host otherwise (RB3_HOST_FMD=1 forces the host packer): both paths give the golden bytes, and the GPU packer
+    really ran for the read fixtures"""
+    for name in ("reads_fq", "reads_fwd", "genomes12", "copies3000", "longruns", "k3_both"):
+        ent = MAN[name]
+        inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+        out, err = run(["build"] + ent["flags"] + ["-d"] + inputs)
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], name
+        if name.startswith("reads"):
+            assert "packed the FMD on the GPU" in err
+        env = dict(os.environ, RB3_HOST_FMD="1")
+        r = subprocess.run([CLI, "build"] + ent["flags"] + ["-d"] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], name
+        assert b"packed the FMD on the GPU" not in r.stderr

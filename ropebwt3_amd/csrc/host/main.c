@@ -97,7 +97,7 @@ static int write_fmd(rb3gpu_t *h, FILE *fp)
 	int64_t n_words = 0, acc[7];
 	int ret;
 	if (w == 0) return -1;
-	ret = getenv("RB3_HOST_FMD") ? RB3GPU_EUNSUP : rb3gpu_export_fmd_words(h, &words, &n_words);
+	ret = getenv("RB3GPU_HOST_FMD") ? RB3GPU_EUNSUP : rb3gpu_export_fmd_words(h, &words, &n_words);
 	if (ret == 0) {
 		rb3gpu_get_acc(h, acc);
 		ret = rb3h_fmdw_adopt(w, words, n_words, acc); /* takes the array over */

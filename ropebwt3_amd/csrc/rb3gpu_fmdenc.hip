@@ -184,7 +184,7 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	FE_HIP(hipMemcpyAsync(hCn, Cn, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
-	if (hflag[0] & 1u) { if (getenv("RB3_FMD_DEBUG")) fprintf(stderr, "[fmdenc] a code of 64 bits or more\n"); ret = 1; goto done; }
+	if (hflag[0] & 1u) { if (getenv("RB3GPU_FMD_DEBUG")) fprintf(stderr, "[fmdenc] a code of 64 bits or more\n"); ret = 1; goto done; }
 	// the chain, one superblock at a time: the host walks the chunk tables
 	for (;;) {
 		const int64_t s = gb0 | (FE_SB_BLOCKS - 1); // global index of this superblock's last block
@@ -223,7 +223,7 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
 	if (hflag[0] & 4u) { ret = -3; goto done; }
-	if (hflag[0] & 3u) { if (getenv("RB3_FMD_DEBUG")) fprintf(stderr, "[fmdenc] flags %u: a block needs a wider header\n", hflag[0]); ret = 1; goto done; }
+	if (hflag[0] & 3u) { if (getenv("RB3GPU_FMD_DEBUG")) fprintf(stderr, "[fmdenc] flags %u: a block needs a wider header\n", hflag[0]); ret = 1; goto done; }
 	if ((host = (uint64_t*)malloc((size_t)(8 * B + 8) * 8)) == nullptr) { ret = -1; goto done; }
 	FE_HIP(hipMemcpy(host, out, (size_t)(8 * B + 2) * 8, hipMemcpyDeviceToHost));
 	*z_out = host, *n_words = 8 * B + 2, host = nullptr;

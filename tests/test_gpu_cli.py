@@ -161,7 +161,7 @@ def test_differential_fuzz_against_the_reference_binary():
 
 def test_fmd_packed_on_gpu_and_on_host_agree(tmp_path):
     """the .fmd data section is packed on the GPU when every block has a 16-bit header (read-like data) and on the
-    host otherwise (RB3_HOST_FMD=1 forces the host packer): both paths give the golden bytes, and the GPU packer
+    host otherwise (RB3GPU_HOST_FMD=1 forces the host packer): both paths give the golden bytes, and the GPU packer
     really ran for the read fixtures"""
     for name in ("reads_fq", "reads_fwd", "genomes12", "copies3000", "longruns", "k3_both"):
         ent = MAN[name]
@@ -170,7 +170,7 @@ def test_fmd_packed_on_gpu_and_on_host_agree(tmp_path):
         assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], name
         if name.startswith("reads"):
             assert "packed the FMD on the GPU" in err
-        env = dict(os.environ, RB3_HOST_FMD="1")
+        env = dict(os.environ, RB3GPU_HOST_FMD="1")
         r = subprocess.run([CLI, "build"] + ent["flags"] + ["-d"] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], name
         assert b"packed the FMD on the GPU" not in r.stderr

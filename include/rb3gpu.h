@@ -183,6 +183,17 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa);
  * inverse suffix array a walker list is made from.  len < 2^31. */
 int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow);
 
+/* The same sorter as an object of its own (own HIP stream and scratch, independent of any index handle), so that a
+ * host thread can sort batch i+1 while another merges batch i -- the pipeline of build.c:55-83, 186-201 with both
+ * stages on the GPU.  rb3gpu_sorter_bwt blocks until the BWT is complete and returns it in one of the sorter's two
+ * output buffers (*d_bwt, device memory, len bytes, valid until rb3gpu_sorter_release; it waits while both are out).
+ * A sorter is used by one thread at a time; release may come from any thread. */
+typedef struct rb3gpu_sorter_s rb3gpu_sorter_t;
+rb3gpu_sorter_t *rb3gpu_sorter_create(int device);
+void rb3gpu_sorter_destroy(rb3gpu_sorter_t *s);
+int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow);
+int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt);
+
 /* Import for `build -i` (rb3_enc_fmd2fmr fm-index.c:56-85, mr_restore mrope.c:161-177):
  * runs[i] = len<<3 | sym in BWT order (host memory). */
 int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs);

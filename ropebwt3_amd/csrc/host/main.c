@@ -36,7 +36,7 @@ typedef struct {
 static void bopt_init(bopt_t *o) /* build.c:31-41 */
 {
 	memset(o, 0, sizeof(*o));
-	o->n_threads = 4, o->sais_threads = 0, o->fmt = FMT_PLAIN;
+	o->n_threads = 4, o->sais_threads = -1, o->fmt = FMT_PLAIN;
 	o->block_len = 512, o->max_nodes = 64, o->batch_size = 7000000000LL;
 	o->device = 0, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 1;
 }
@@ -48,7 +48,8 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	fprintf(fp, "  Algorithm:\n");
 	fprintf(fp, "    -m NUM      batch size [7G]\n");
 	fprintf(fp, "    -t INT      total number of threads [%d]\n", opt->n_threads);
-	fprintf(fp, "    -p INT      suffix-sort INT batches at once on host threads, ahead of the GPU merge (more RAM) [%d]\n", opt->sais_threads);
+	fprintf(fp, "    -p INT      sort INT batches at once ahead of the GPU merge: sorter threads with a GPU sorter each (at most 3;\n");
+	fprintf(fp, "                default 1) or, with --host-sort, host sorter threads (default 0: sort and merge in turn)\n");
 	fprintf(fp, "    -l INT      leaf block size in B+-tree (FMR output only) [%d]\n", opt->block_len);
 	fprintf(fp, "    -n INT      max number children per internal node (FMR output only) [%d]\n", opt->max_nodes);
 	fprintf(fp, "    --gpu INT   HIP device ordinal [%d]\n", opt->device);
@@ -142,7 +143,14 @@ static int dump_fmr(rb3gpu_t *h, const bopt_t *opt, FILE *fp)
 
 /* ---- batches ----------------------------------------------------------------------------- */
 
-typedef struct { int64_t n_seq, len, n_walkers, step; uint8_t *bwt; rb3h_walker_t *walkers; int ret, raw; } batch_t;
+typedef struct {
+	int64_t n_seq, len, n_walkers, step;
+	uint8_t *bwt;             /* host: the BWT, or the text if raw */
+	rb3h_walker_t *walkers;
+	int ret, raw;             /* raw: not sorted yet, the consumer's GPU handle sorts it */
+	void *d_bwt;              /* device: the BWT from a sorter thread's own GPU sorter (gs), to be released after the merge */
+	rb3gpu_sorter_t *gs;
+} batch_t;
 
 /* --gpu-sort: the batch arrives as text; suffix sorting, BWT and sampled inverse suffix array on the GPU
  * (rb3gpu_bwt_from_text instead of rb3_build_sais, build.c:220), the BWT never leaves HBM */
@@ -174,7 +182,16 @@ static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 {
 	int ret;
-	if (b->raw) {
+	if (b->d_bwt) { /* sorted on the GPU by a sorter thread while the batch before was being merged */
+		const int first = !*has_index;
+		if (first) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)b->d_bwt);
+		else if (b->walkers) ret = rb3gpu_merge_plain_dev_walkers(h, b->len, (const uint8_t*)b->d_bwt, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+		else ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)b->d_bwt, 1);
+		rb3gpu_sorter_release(b->gs, b->d_bwt);
+		b->d_bwt = 0;
+		if (ret == 0 && rb3h_verbose >= 3)
+			fprintf(stderr, "[M::%s::%.3f*%.2f] %s the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), first ? "encoded" : "merged", (long)b->len);
+	} else if (b->raw) {
 		const int first = !*has_index;
 		ret = process_raw_batch(h, b, has_index);
 		if (ret == 1) { /* host sorter instead */
@@ -228,7 +245,7 @@ typedef struct {
 	const bopt_t *opt;
 } pool_t;
 
-static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_threads, batch_t **out)
+static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_threads, batch_t **out, rb3gpu_sorter_t *gs)
 {
 	batch_t *b;
 	int64_t n_walkers = 0;
@@ -236,11 +253,22 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : 384;
 	int r;
 	if (step < (seq->l >> 20)) step = seq->l >> 20; /* at most ~2^20 walkers per batch: the engine's stretch table is finite */
-	if (opt->gpu_sort && seq->l < INT32_MAX - 16) { /* the GPU sorts: pass the text through (the sorter handles < 2^31 symbols) */
+	if (opt->gpu_sort && seq->l < INT32_MAX - 16) { /* the GPU sorts (the sorter handles < 2^31 symbols) */
 		b = (batch_t*)calloc(1, sizeof(batch_t));
 		b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s, b->raw = 1;
 		b->step = (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22)) ? step : 0;
 		seq->s = 0, seq->l = seq->m = 0;
+		if (gs) { /* this thread has a GPU sorter of its own: sort now, while the consumer merges the batch before */
+			int64_t *ckrow = b->step > 0 ? (int64_t*)malloc((size_t)((b->len + b->step - 1) / b->step) * 8) : 0;
+			if (rb3gpu_sorter_bwt(gs, b->len, b->bwt, &b->d_bwt, ckrow ? b->step : 0, ckrow) == 0) {
+				if (rb3h_verbose >= 3)
+					fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
+				if (ckrow && rb3h_walkers_from_ckrow(b->len, b->bwt, b->step, ckrow, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0;
+				b->gs = gs, b->raw = 0;
+				free(b->bwt); b->bwt = 0; /* the text is not needed any more */
+			} else b->d_bwt = 0; /* leave it to the consumer (its handle's sorter, then the host sorter) */
+			free(ckrow);
+		}
 		*out = b;
 		return 0;
 	}
@@ -331,7 +359,7 @@ static int submit_serial(void *data, rb3h_buf_t *seq, int64_t n_seq, int end_of_
 {
 	consumer_t *c = (consumer_t*)data;
 	batch_t *b = 0;
-	if (seq && sort_batch(c->opt, seq, n_seq, c->opt->n_threads, &b) < 0) return -1;
+	if (seq && sort_batch(c->opt, seq, n_seq, c->opt->n_threads, &b, 0) < 0) return -1;
 	return consume(c, b, end_of_file);
 }
 
@@ -366,9 +394,12 @@ static void *reader_main(void *arg)
 	return 0;
 }
 
+typedef struct { pool_t *q; rb3gpu_sorter_t *gs; } sorter_arg_t;
+
 static void *sorter_main(void *arg)
 {
-	pool_t *q = (pool_t*)arg;
+	pool_t *q = ((sorter_arg_t*)arg)->q;
+	rb3gpu_sorter_t *gs = ((sorter_arg_t*)arg)->gs;
 	for (;;) {
 		job_t *j = 0;
 		pthread_mutex_lock(&q->mtx);
@@ -382,7 +413,7 @@ static void *sorter_main(void *arg)
 		if (j == 0) return 0;
 		{
 			batch_t *b = 0;
-			int err = sort_batch(q->opt, &j->seq, j->n_seq, 1, &b);
+			int err = sort_batch(q->opt, &j->seq, j->n_seq, 1, &b, gs);
 			pthread_mutex_lock(&q->mtx);
 			j->out = b, j->err = err, j->state = 3;
 			pthread_cond_broadcast(&q->cv);
@@ -471,12 +502,15 @@ int main_build(int argc, char *argv[])
 		if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] loaded the index from file '%s'\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), fn_in);
 	}
 
+	if (opt.sais_threads < 0) opt.sais_threads = opt.gpu_sort ? 1 : 0; /* one batch sorted on the GPU while the one before is merged */
 	if (opt.sais_threads > 0 && argc - optind >= 1) { /* N suffix sorters ahead of the GPU merge */
 		pool_t q;
 		reader_t rd;
 		pthread_t rt, *st;
 		consumer_t cs = { h, &opt, has_index, fn_tmp };
 		int k, n_sort = opt.sais_threads;
+		sorter_arg_t *sa;
+		if (opt.gpu_sort && n_sort > 3) n_sort = 3; /* GPU sorters: more than a few at once only compete for the same GPU */
 		memset(&q, 0, sizeof(q));
 		pthread_mutex_init(&q.mtx, 0);
 		pthread_cond_init(&q.cv, 0);
@@ -484,8 +518,12 @@ int main_build(int argc, char *argv[])
 		memset(&rd, 0, sizeof(rd));
 		rd.q = &q, rd.n_files = argc - optind, rd.files = argv + optind;
 		st = (pthread_t*)calloc((size_t)n_sort, sizeof(pthread_t));
+		sa = (sorter_arg_t*)calloc((size_t)n_sort, sizeof(sorter_arg_t));
 		pthread_create(&rt, 0, reader_main, &rd);
-		for (k = 0; k < n_sort; ++k) pthread_create(&st[k], 0, sorter_main, &q);
+		for (k = 0; k < n_sort; ++k) {
+			sa[k].q = &q, sa[k].gs = opt.gpu_sort ? rb3gpu_sorter_create(opt.device) : 0; /* NULL: the consumer's handle sorts */
+			pthread_create(&st[k], 0, sorter_main, &sa[k]);
+		}
 		for (;;) {
 			job_t j;
 			pthread_mutex_lock(&q.mtx);
@@ -499,11 +537,15 @@ int main_build(int argc, char *argv[])
 			pthread_mutex_unlock(&q.mtx);
 			if (j.err != 0) ret = -1;
 			if (ret == 0) ret = consume(&cs, j.out, j.end_of_file);
-			else if (j.out) { free(j.out->bwt); free(j.out->walkers); free(j.out); }
+			else if (j.out) {
+				if (j.out->d_bwt) rb3gpu_sorter_release(j.out->gs, j.out->d_bwt);
+				free(j.out->bwt); free(j.out->walkers); free(j.out);
+			}
 		}
 		pthread_join(rt, 0);
 		for (k = 0; k < n_sort; ++k) pthread_join(st[k], 0);
-		free(st); free(q.ring);
+		for (k = 0; k < n_sort; ++k) rb3gpu_sorter_destroy(sa[k].gs);
+		free(st); free(sa); free(q.ring);
 		if (rd.err != 0) ret = -1;
 		n_empty = rd.n_empty, has_index = cs.has_index;
 	} else if (argc - optind >= 1) {

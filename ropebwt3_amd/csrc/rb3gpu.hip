@@ -91,7 +91,7 @@ static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes)
 	if (b.cap >= bytes && b.p) return 0;
 	if (b.p) dev_free(h, b.p, b.cap);
 	b.p = nullptr, b.cap = 0;
-	size_t want = bytes + (bytes >> 3) + 256; // a little slack so that growing batches do not realloc every time
+	size_t want = bytes + (bytes >> 1) + 256; // geometric growth: an index that grows round by round must not realloc (hipFree synchronises) every round
 	int r = dev_malloc(h, &b.p, want);
 	if (r == RB3GPU_ENOMEM && want != bytes) r = dev_malloc(h, &b.p, want = bytes);
 	if (r < 0) return r;
@@ -220,14 +220,17 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots)
 	if (h->ib[i].grp_cap < (size_t)ngrp) {
 		dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * sizeof(rb3_grp_t));
 		h->ib[i].grp = nullptr, h->ib[i].grp_cap = 0;
-		const size_t want = (size_t)ngrp + (size_t)(ngrp >> 3) + 16;
-		if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * sizeof(rb3_grp_t))) < 0) return r;
+		size_t want = (size_t)ngrp + (size_t)(ngrp >> 1) + 16;
+		if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * sizeof(rb3_grp_t))) < 0) {
+			want = (size_t)ngrp;
+			if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * sizeof(rb3_grp_t))) < 0) return r;
+		}
 		h->ib[i].grp_cap = want;
 	}
 	if (h->ib[i].slots_cap < (size_t)nslots) {
 		dev_free(h, h->ib[i].slots, h->ib[i].slots_cap * sizeof(rb3_slot_t));
 		h->ib[i].slots = nullptr, h->ib[i].slots_cap = 0;
-		size_t want = (size_t)nslots + (size_t)(nslots >> 3) + 64;
+		size_t want = (size_t)nslots + (size_t)(nslots >> 1) + 64;
 		if ((r = dev_malloc(h, (void**)&h->ib[i].slots, want * sizeof(rb3_slot_t))) < 0) {
 			want = (size_t)nslots;
 			if ((r = dev_malloc(h, (void**)&h->ib[i].slots, want * sizeof(rb3_slot_t))) < 0) return r;
@@ -961,6 +964,118 @@ int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t 
 	if (h->opt.verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f] suffix-sorted %lld symbols on the GPU in %.3f ms (%d doubling rounds)\n", __func__, now_s() - h->t0, (long long)len, (now_s() - t0) * 1e3, rounds);
 	return 0;
+}
+
+/* ---- a sorter of its own: stream, scratch, two output buffers handed out in turn ---- */
+
+#include <pthread.h>
+#define SCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; } } while (0)
+
+struct rb3gpu_sorter_s {
+	int dev = 0;
+	hipStream_t st = nullptr;
+	rb3sort_ws *ws = nullptr;
+	void *text = nullptr, *ck = nullptr, *out[2] = {nullptr, nullptr};
+	size_t text_cap = 0, ck_cap = 0, out_cap[2] = {0, 0};
+	int busy[2] = {0, 0};
+	uint8_t *stage = nullptr; // pinned, for the text upload
+	pthread_mutex_t mtx;
+	pthread_cond_t cv;
+};
+
+static int sorter_grow(void **p, size_t *cap, size_t bytes)
+{
+	if (*p && *cap >= bytes) return 0;
+	if (*p) (void)hipFree(*p);
+	*p = nullptr, *cap = 0;
+	const size_t want = bytes + (bytes >> 3) + 256;
+	if (hipMalloc(p, want) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENOMEM; }
+	*cap = want;
+	return 0;
+}
+
+rb3gpu_sorter_t *rb3gpu_sorter_create(int device)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n || hipSetDevice(device) != hipSuccess) return nullptr;
+	rb3gpu_sorter_t *s = new rb3gpu_sorter_s;
+	s->dev = device;
+	if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess || (s->ws = rb3sort_create()) == nullptr) { delete s; return nullptr; }
+	if (hipHostMalloc((void**)&s->stage, RB3_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) s->stage = nullptr;
+	pthread_mutex_init(&s->mtx, nullptr);
+	pthread_cond_init(&s->cv, nullptr);
+	return s;
+}
+
+void rb3gpu_sorter_destroy(rb3gpu_sorter_t *s)
+{
+	if (!s) return;
+	(void)hipSetDevice(s->dev);
+	(void)hipStreamSynchronize(s->st);
+	rb3sort_destroy(s->ws);
+	void *all[] = { s->text, s->ck, s->out[0], s->out[1] };
+	for (void *p : all) if (p) (void)hipFree(p);
+	if (s->stage) (void)hipHostFree(s->stage);
+	(void)hipStreamDestroy(s->st);
+	pthread_mutex_destroy(&s->mtx);
+	pthread_cond_destroy(&s->cv);
+	delete s;
+}
+
+int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow)
+{
+	if (!s || !text || !d_bwt || len <= 0 || len >= (1LL << 31) || step < 0) return RB3GPU_EINVAL;
+	SCHK(hipSetDevice(s->dev));
+	int r, slot, rounds = 0;
+	*d_bwt = nullptr;
+	pthread_mutex_lock(&s->mtx); // an output buffer that is not with the merger
+	while (s->busy[0] && s->busy[1]) pthread_cond_wait(&s->cv, &s->mtx);
+	slot = s->busy[0] ? 1 : 0;
+	s->busy[slot] = 1;
+	pthread_mutex_unlock(&s->mtx);
+	const int64_t nck = step > 0 && ckrow ? (len + step - 1) / step : 0;
+	if ((r = sorter_grow(&s->text, &s->text_cap, (size_t)len + 16)) < 0 || (r = sorter_grow(&s->out[slot], &s->out_cap[slot], (size_t)len + 16)) < 0 ||
+		(nck > 0 && (r = sorter_grow(&s->ck, &s->ck_cap, (size_t)nck * 8)) < 0)) {
+		pthread_mutex_lock(&s->mtx);
+		s->busy[slot] = 0;
+		pthread_cond_broadcast(&s->cv);
+		pthread_mutex_unlock(&s->mtx);
+		return r;
+	}
+	if (s->stage) { // pageable -> pinned -> device, chunk by chunk
+		for (int64_t off = 0; off < len; off += (int64_t)RB3_STAGE_BYTES) {
+			const size_t n = (size_t)(len - off) < RB3_STAGE_BYTES ? (size_t)(len - off) : RB3_STAGE_BYTES;
+			memcpy(s->stage, text + off, n);
+			SCHK(hipMemcpyAsync((uint8_t*)s->text + off, s->stage, n, hipMemcpyHostToDevice, s->st));
+			SCHK(hipStreamSynchronize(s->st));
+		}
+	} else {
+		SCHK(hipMemcpyAsync(s->text, text, (size_t)len, hipMemcpyHostToDevice, s->st));
+		SCHK(hipStreamSynchronize(s->st));
+	}
+	r = rb3sort_bwt(s->ws, s->st, len, (const uint8_t*)s->text, (uint8_t*)s->out[slot], step, nck > 0 ? (int64_t*)s->ck : nullptr, &rounds);
+	if (r == 0 && nck > 0 && (hipMemcpyAsync(ckrow, s->ck, (size_t)nck * 8, hipMemcpyDeviceToHost, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess)) r = -2;
+	if (r < 0) {
+		pthread_mutex_lock(&s->mtx);
+		s->busy[slot] = 0;
+		pthread_cond_broadcast(&s->cv);
+		pthread_mutex_unlock(&s->mtx);
+		return r == -1 ? RB3GPU_ENOMEM : r == -3 ? RB3GPU_ESYMBOL : RB3GPU_ENODEV;
+	}
+	*d_bwt = s->out[slot];
+	return 0;
+}
+
+int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt)
+{
+	if (!s || !d_bwt) return RB3GPU_EINVAL;
+	int found = 0;
+	pthread_mutex_lock(&s->mtx);
+	for (int i = 0; i < 2; ++i)
+		if (s->out[i] == d_bwt && s->busy[i]) s->busy[i] = 0, found = 1;
+	pthread_cond_broadcast(&s->cv);
+	pthread_mutex_unlock(&s->mtx);
+	return found ? 0 : RB3GPU_EINVAL;
 }
 
 int rb3gpu_ssa_dims(const rb3gpu_t *h, int ssa_shift, int64_t *m, int64_t *n_ssa, int *ms)

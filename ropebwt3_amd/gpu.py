@@ -74,6 +74,10 @@ SYMBOLS = {
     "rb3gpu_ssa_dims": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),
     "rb3gpu_ssa_gen": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_bwt_from_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_sorter_create": (ctypes.c_void_p, [ctypes.c_int]),
+    "rb3gpu_sorter_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_sorter_bwt": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_sorter_release": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),

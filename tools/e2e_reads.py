@@ -40,7 +40,7 @@ def run(name, cmd):
     return r.stdout, err
 amd = os.path.join(ROOT, "ropebwt3_amd", "ropebwt3-amd")
 ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
-a, ea = run("amd build -m%s -p2" % M, [amd, "build", "-d", "-m" + M, "-p2", fn])
+a, ea = run("amd build -m%s" % M, [amd, "build", "-d", "-m" + M, fn])
 for l in ea.splitlines():
     if "GPU suffix sorting" in l: print("    " + l)
 print("    merge rounds:", ea.count("merged the partial BWT"))

@@ -1209,6 +1209,12 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 	uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, rel[6] = {0, 0, 0, 0, 0, 0};
 	int64_t sidx = (int64_t)slot0 - 1;
 	int slot_w0 = 0, slot_sz = 1, nc = 0;
+	uint32_t abs_base = 0; // lanes 1..6: the LF base of the group start if the headers are absolute (RB3_ABS_HEADERS)
+	if (RB3_ABS_HEADERS((int64_t)tot[6], W, ntot) && lane >= 1 && lane <= 6) {
+		uint64_t cb = gpre[g * 8 + lane - 1];
+		for (int a = 0; a < lane - 1; ++a) cb += tot[a];
+		abs_base = (uint32_t)cb;
+	}
 	for (int lw = 0; lw < nvw; ++lw) {
 		const int64_t p0 = (g * RB3_GRP_WINS + lw) << RB3_WIN_BITS;
 		uint32_t sym[4];
@@ -1226,11 +1232,7 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 		uint32_t hq = lane == 0 ? (uint32_t)(slot_w0 * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
 			lane == 1 ? rel[0] : lane == 2 ? rel[1] : lane == 3 ? rel[2] : lane == 4 ? rel[3] : lane == 5 ? rel[4] :
 			lane == 6 ? rel[5] : nsym;
-		if (RB3_ABS_HEADERS((int64_t)tot[6], W, ntot) && lane >= 1 && lane <= 6) { // the whole LF base (see RB3_ABS_HEADERS)
-			uint64_t cb = gpre[g * 8 + lane - 1];
-			for (int a = 0; a < lane - 1; ++a) cb += tot[a];
-			hq += (uint32_t)cb;
-		}
+		hq += abs_base;
 		if (slot_sz == 1) { // bit-plane slot
 #pragma unroll
 			for (int u = 0; u < 4; ++u)
@@ -1454,6 +1456,12 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		e.slot0 = (uint32_t)slot0, e.mask = mask, e.spare = 0;
 		grp[g] = e;
 	}
+	uint32_t abs_base = 0; // lanes 1..6: the LF base of the group start if the headers are absolute (RB3_ABS_HEADERS)
+	if (RB3_ABS_HEADERS((int64_t)tot[6], nwin, ntot) && lane >= 1 && lane <= 6) {
+		uint64_t cb = gpre[g * 8 + lane - 1];
+		for (int a = 0; a < lane - 1; ++a) cb += tot[a];
+		abs_base = (uint32_t)cb;
+	}
 	for (int lw = wave * (RB3_GRP_WINS / RB3_REB_WAVES); lw < (wave + 1) * (RB3_GRP_WINS / RB3_REB_WAVES) && lw < nvw; ++lw) {
 		if (!(mask >> lw & 1u)) continue; // not the first window of a slot
 		const int64_t w = g * RB3_GRP_WINS + lw;
@@ -1473,11 +1481,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		uint32_t hq = lane == 0 ? (uint32_t)(lw * RB3_WIN) | (slot_sz > 1 ? RB3_SLOT_RLE : 0u) :
 			lane == 1 ? rel[0] : lane == 2 ? rel[1] : lane == 3 ? rel[2] : lane == 4 ? rel[3] : lane == 5 ? rel[4] :
 			lane == 6 ? rel[5] : nsym;
-		if (RB3_ABS_HEADERS((int64_t)tot[6], nwin, ntot) && lane >= 1 && lane <= 6) { // the whole LF base (see RB3_ABS_HEADERS)
-			uint64_t cb = gpre[g * 8 + lane - 1];
-			for (int a = 0; a < lane - 1; ++a) cb += tot[a];
-			hq += (uint32_t)cb;
-		}
+		hq += abs_base;
 		if (slot_sz == 1) { // bit-plane slot: header + the cached planes
 			if (lane < 8) {
 				const uint32_t *pl = wplane + w * 24;

@@ -422,25 +422,15 @@ __global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, cons
 struct Walker { int64_t row, ka0, nsteps, flags; };
 #define RB3_WK_CHECK 2
 
+/* row words are read and written with agent-scope relaxed atomics: a record must reach the L2 where walkers
+ * on other compute units (and XCDs) look for it, and must not be torn */
 __device__ __forceinline__ int64_t ld_pos(const int64_t *p)
 {
-#ifdef RB3_EXP_LD_PLAIN
-	return *(const volatile int64_t*)p;
-#else
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 __device__ __forceinline__ void st_pos(int64_t *p, int64_t v)
 {
-#if defined(RB3_EXP_ST_NONE)
-	(void)p; (void)v;
-#elif defined(RB3_EXP_ST_PLAIN)
-	*p = v;
-#elif defined(RB3_EXP_ST_NT)
-	__builtin_nontemporal_store(v, p);
-#else
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 
 /* rank with the symbol known before the loads are issued: every lane of the octet fetches the one
@@ -1586,12 +1576,6 @@ __global__ void __launch_bounds__(256) k_export_runs(IdxView ix, int64_t w0, int
 			runs[o + __popcll(H[u] & ((1ull << lane) - 1ull))] = (uint64_t)(p0 + 64 * u + lane) << 3 | sym[u];
 		o += __popcll(H[u]);
 	}
-}
-
-__global__ void __launch_bounds__(256) k_fill_iota(int64_t *p, int64_t n)
-{
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) p[i] = i;
 }
 
 /* ----------------------------------------------------------------------------------------- */

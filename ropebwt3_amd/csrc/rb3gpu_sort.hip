@@ -10,7 +10,8 @@
  *   round 0   key = the first 20 symbols (3 bits each), cut after the first sentinel; sort (key, position);
  *             rank[p] = index of the first element of p's group of equal keys
  *   round r   depth h = 20 * 2^(r-1).  Only positions whose group still has several members take part
- *             (compacted list): key = rank[p] << 32 | sec, where sec = rank[p + h], or the number of the
+ *             (compacted list): key = rank[p] << nb | sec (nb = bits of n, so that the radix sort only has to
+ *             look at 2 nb bits), where sec = rank[p + h], or the number of the
  *             string if p's sentinel lies within the first h symbols (then all members of the group are
  *             identical up to their sentinels and the sentinel order decides -- never look past it).
  *             After the sort an element's final slot is its old rank + its index inside its old group;
@@ -93,12 +94,12 @@ __global__ void __launch_bounds__(256) k_s_key0(const uint8_t *text, int64_t n, 
 /* head[i] = i if element i starts a group of equal keys, else 0 (an inclusive max-scan makes it the index
  * of the group's first element); HI: compare the upper 32 bits only */
 template<bool HI>
-__global__ void __launch_bounds__(256) k_s_heads(const uint64_t *keys, int64_t n, uint32_t *head)
+__global__ void __launch_bounds__(256) k_s_heads(const uint64_t *keys, int64_t n, int nb, uint32_t *head)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	bool h = i == 0;
-	if (!h) h = HI ? (keys[i] >> 32) != (keys[i - 1] >> 32) : keys[i] != keys[i - 1];
+	if (!h) h = HI ? (keys[i] >> nb) != (keys[i - 1] >> nb) : keys[i] != keys[i - 1];
 	head[i] = h ? (uint32_t)i : 0u;
 }
 
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(256) k_s_rank0(const uint32_t *vals, const uin
 	unres[i] = single ? 0 : 1;
 }
 
-__global__ void __launch_bounds__(256) k_s_key(const uint32_t *list, int64_t nu, const uint32_t *rank, const uint32_t *sid, const uint32_t *sentpos, int64_t h,
+__global__ void __launch_bounds__(256) k_s_key(const uint32_t *list, int64_t nu, const uint32_t *rank, const uint32_t *sid, const uint32_t *sentpos, int64_t h, int nb,
 		uint64_t *keys, uint32_t *vals)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,16 +122,16 @@ __global__ void __launch_bounds__(256) k_s_key(const uint32_t *list, int64_t nu,
 	const uint32_t s = sid[p];
 	const int64_t d = (int64_t)sentpos[s] - (int64_t)p;
 	const uint32_t sec = d < h ? s : rank[p + h];
-	keys[i] = (uint64_t)rank[p] << 32 | sec, vals[i] = p;
+	keys[i] = (uint64_t)rank[p] << nb | sec, vals[i] = p;
 }
 
 /* gh / sh: index (in the sorted list) of the first element of the old group / of the new sub-group */
-__global__ void __launch_bounds__(256) k_s_update(const uint64_t *keys, const uint32_t *vals, const uint32_t *gh, const uint32_t *sh, int64_t nu,
+__global__ void __launch_bounds__(256) k_s_update(const uint64_t *keys, const uint32_t *vals, const uint32_t *gh, const uint32_t *sh, int64_t nu, int nb,
 		uint32_t *rank, uint32_t *sa, uint8_t *unres)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nu) return;
-	const uint32_t r0 = (uint32_t)(keys[i] >> 32), p = vals[i];
+	const uint32_t r0 = (uint32_t)(keys[i] >> nb), p = vals[i];
 	sa[r0 + ((uint32_t)i - gh[i])] = p;
 	rank[p] = r0 + (sh[i] - gh[i]);
 	const bool single = sh[i] == (uint32_t)i && (i + 1 == nu || sh[i + 1] == (uint32_t)(i + 1));
@@ -197,26 +198,27 @@ int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text
 	// round 0
 	hipLaunchKernelGGL(k_s_key0, S_GRID(n), d_text, n, (const uint32_t*)sid, (const uint32_t*)sentpos, keyA, valA);
 	b = tmp_bytes; S_HIP(rocprim::radix_sort_pairs(tmp, b, keyA, keyB, valA, valB, (size_t)n, 0, 3 * RB3S_H0, st));
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s_heads<false>), S_GRID(n), (const uint64_t*)keyB, n, t0);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s_heads<false>), S_GRID(n), (const uint64_t*)keyB, n, 0, t0);
 	b = tmp_bytes; S_HIP(rocprim::inclusive_scan(tmp, b, t0, t1, (size_t)n, rocprim::maximum<uint32_t>(), st));
 	hipLaunchKernelGGL(k_s_rank0, S_GRID(n), (const uint32_t*)valB, (const uint32_t*)t1, n, rank, sa, unres);
 	b = tmp_bytes; S_HIP(rocprim::select(tmp, b, valB, unres, valA, (size_t*)dcnt, (size_t)n, st));
 	size_t nu = 0;
 	S_HIP(hipMemcpyAsync(&nu, dcnt, 8, hipMemcpyDeviceToHost, st));
 	S_HIP(hipStreamSynchronize(st));
-	int nr = 0;
+	int nr = 0, nb = 1;
+	while ((1LL << nb) < n) ++nb; // ranks and string numbers are below n: 2 nb key bits
 	uint32_t *list = valA, *other = valB; // the compacted positions live in one of the two value buffers
 	for (int64_t h = RB3S_H0; nu > 0; h <<= 1) {
 		if (++nr > 40) return -3; // depth 20 * 2^40: cannot happen for a text that ends with a sentinel
-		hipLaunchKernelGGL(k_s_key, S_GRID(nu), (const uint32_t*)list, (int64_t)nu, (const uint32_t*)rank, (const uint32_t*)sid, (const uint32_t*)sentpos, h, keyA, other);
+		hipLaunchKernelGGL(k_s_key, S_GRID(nu), (const uint32_t*)list, (int64_t)nu, (const uint32_t*)rank, (const uint32_t*)sid, (const uint32_t*)sentpos, h, nb, keyA, other);
 		// sorted (keys, positions) -> keyB, list (the old list is free now: its positions were copied into `other`)
-		b = tmp_bytes; S_HIP(rocprim::radix_sort_pairs(tmp, b, keyA, keyB, other, list, nu, 0, 64, st));
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s_heads<true>), S_GRID(nu), (const uint64_t*)keyB, (int64_t)nu, t0);
+		b = tmp_bytes; S_HIP(rocprim::radix_sort_pairs(tmp, b, keyA, keyB, other, list, nu, 0, 2 * nb, st));
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s_heads<true>), S_GRID(nu), (const uint64_t*)keyB, (int64_t)nu, nb, t0);
 		b = tmp_bytes; S_HIP(rocprim::inclusive_scan(tmp, b, t0, t1, nu, rocprim::maximum<uint32_t>(), st));
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s_heads<false>), S_GRID(nu), (const uint64_t*)keyB, (int64_t)nu, t0);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s_heads<false>), S_GRID(nu), (const uint64_t*)keyB, (int64_t)nu, nb, t0);
 		uint32_t *sh = (uint32_t*)keyA; // the unsorted keys are not needed any more: sub-group heads go there
 		b = tmp_bytes; S_HIP(rocprim::inclusive_scan(tmp, b, t0, sh, nu, rocprim::maximum<uint32_t>(), st));
-		hipLaunchKernelGGL(k_s_update, S_GRID(nu), (const uint64_t*)keyB, (const uint32_t*)list, (const uint32_t*)t1, (const uint32_t*)sh, (int64_t)nu, rank, sa, unres);
+		hipLaunchKernelGGL(k_s_update, S_GRID(nu), (const uint64_t*)keyB, (const uint32_t*)list, (const uint32_t*)t1, (const uint32_t*)sh, (int64_t)nu, nb, rank, sa, unres);
 		b = tmp_bytes; S_HIP(rocprim::select(tmp, b, list, unres, other, (size_t*)dcnt, nu, st));
 		S_HIP(hipMemcpyAsync(&nu, dcnt, 8, hipMemcpyDeviceToHost, st));
 		S_HIP(hipStreamSynchronize(st));

@@ -106,9 +106,10 @@ static int64_t sio_getline(rb3h_seqio_t *fp, rb3h_buf_t *b, int append)
 	if (fp->beg >= fp->end && fp->is_eof) return -1;
 	for (;;) {
 		int i;
+		const uint8_t *nl;
 		if (fp->beg >= fp->end && !sio_fill(fp)) break;
-		for (i = fp->beg; i < fp->end; ++i)
-			if (fp->buf[i] == '\n') break;
+		nl = (const uint8_t*)memchr(fp->buf + fp->beg, '\n', (size_t)(fp->end - fp->beg));
+		i = nl ? (int)(nl - fp->buf) : fp->end;
 		if (buf_grow(b, b->l + (i - fp->beg) + 2) < 0) return -2;
 		memcpy(b->s + b->l, fp->buf + fp->beg, i - fp->beg);
 		b->l += i - fp->beg;
@@ -166,10 +167,12 @@ static int64_t sio_add(rb3h_buf_t *seq, int is_for, int is_rev, int64_t l, uint8
 		seq->s[seq->l + l] = 0;
 		seq->l += l + 1, ++n;
 	}
-	if (is_rev) {
-		rb3h_revcomp6(l, s);
-		memcpy(seq->s + seq->l, s, l);
-		seq->s[seq->l + l] = 0;
+	if (is_rev) { /* reverse complement straight into the batch: 1<->4, 2<->3, 0 and 5 unchanged (io.c:30-40) */
+		static const uint8_t comp[8] = { 0, 4, 3, 2, 1, 5, 6, 7 };
+		uint8_t *d = seq->s + seq->l;
+		int64_t i;
+		for (i = 0; i < l; ++i) d[i] = comp[s[l - 1 - i] & 7];
+		d[l] = 0;
 		seq->l += l + 1, ++n;
 	}
 	return n;

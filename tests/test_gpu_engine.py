@@ -424,3 +424,40 @@ def test_bwt_from_text_vs_host_sorter(oracle, seed, kind):
             assert h.stats()["n_sort_rounds"] >= 0
         finally:
             h.close()
+
+
+def test_sorter_object_matches_handle_sorter():
+    """rb3gpu_sorter_* (a sorter with its own stream and output buffers, used by the CLI's sorter thread): same BWT
+    and sampled inverse suffix array as rb3gpu_bwt_from_text; the two output buffers are handed out in turn"""
+    import ctypes
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(91)
+    h = Rb3Gpu(verbose=1)
+    L = h._lib
+    s = L.rb3gpu_sorter_create(0)
+    assert s
+    try:
+        held = []
+        for rep in range(3):
+            g = util.random_genome(rng, int(rng.integers(20000, 90000)))
+            text = util.make_text([g, util.mutate(rng, g, 0.01)])
+            want = host.build_bwt(text.copy())
+            step = 128
+            ck = np.empty((text.size + step - 1) // step, dtype=np.int64)
+            p = ctypes.c_void_p()
+            assert L.rb3gpu_sorter_bwt(s, text.size, text.ctypes.data, ctypes.byref(p), step, ck.ctypes.data) == 0
+            got = h.dev_download(p, text.size)
+            assert np.array_equal(got, want)
+            d2, ck2 = h.bwt_from_text(text, step)
+            assert np.array_equal(ck, ck2)
+            h.dev_free(d2)
+            held.append(p)
+            if len(held) == 2:            # both buffers out: give the older one back before the next sort
+                assert held[0].value != held[1].value
+                assert L.rb3gpu_sorter_release(s, held.pop(0)) == 0
+        for p in held:
+            assert L.rb3gpu_sorter_release(s, p) == 0
+        assert L.rb3gpu_sorter_release(s, held[-1]) != 0   # not out any more
+    finally:
+        L.rb3gpu_sorter_destroy(s)
+        h.close()

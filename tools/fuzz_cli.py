@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of `ropebwt3-amd build` against the unmodified reference binary (oracle/_ref/ropebwt3, GPU box):
+"""Differential fuzz of `ropebwt3-amd build` (and, for every third case, `ssa`) against the unmodified reference binary (oracle/_ref/ropebwt3, GPU box):
 random FASTA / FASTQ / one-per-line inputs (N, lower case, IUPAC, CRLF, duplicates, homopolymers, short and long
 records, several files), random -m / -R / -F / -p / sorter; the .fmd must be byte-identical.
     python tools/fuzz_cli.py [n_cases] [seed0]"""
@@ -78,6 +78,16 @@ for case in range(ncase):
     if not ok:
         bad += 1
         print("   ref stderr:", want.stderr.decode()[-300:]); print("   amd stderr:", got.stderr.decode()[-300:])
+    if ok and case % 3 == 0:   # and the sampled suffix array of that index, both programs reading the same .fmd
+        fmd = os.path.join(tmp, "c%d.fmd" % case)
+        open(fmd, "wb").write(got.stdout)
+        ss = str(rng.integers(0, 9))
+        a = subprocess.run([ref, "ssa", "-t4", "-s" + ss, fmd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        b = subprocess.run([amd, "ssa", "-s" + ss, fmd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if not (a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout):
+            bad += 1
+            print("   ssa -s%s MISMATCH rc=%d/%d %s" % (ss, a.returncode, b.returncode, b.stderr.decode()[-200:]))
+        os.remove(fmd)
     for f in files: os.remove(f)
 print("%d cases, %d mismatches" % (ncase, bad))
 sys.exit(1 if bad else 0)

@@ -104,7 +104,7 @@ static int write_fmd(rb3gpu_t *h, FILE *fp)
 		ret = rb3h_fmdw_adopt(w, words, n_words, acc); /* takes the array over */
 		if (ret < 0) rb3gpu_host_free(words);
 		else if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] packed the FMD on the GPU\n", __func__, rb3h_realtime(), rb3h_percent_cpu());
-	} else if (ret == RB3GPU_EUNSUP) {
+	} else if (ret == RB3GPU_EUNSUP || ret == RB3GPU_ENOMEM) { /* wider block headers needed, or no room to pack the whole index at once */
 		ret = rb3gpu_export_run_words(h, sink_fmd_words, w);
 		if (ret == 0) ret = rb3h_fmdw_finish(w);
 	}

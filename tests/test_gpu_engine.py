@@ -461,3 +461,31 @@ def test_sorter_object_matches_handle_sorter():
     finally:
         L.rb3gpu_sorter_destroy(s)
         h.close()
+
+
+def test_whole_index_merge_on_device(oracle):
+    """the closing step of the partitioned multi-GPU build (multi.tree_merge) on one GPU: index B is exported as a
+    plain BWT into device memory and merged into index A with rb3gpu_merge_plain_dev (the reference's signature, no
+    walker list: SA-regular walkers, atomic-min records).  Result = the BWT of all strings in input order."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(97)
+    g0 = util.random_genome(rng, 50000)
+    gs = [util.mutate(rng, g0, 0.003) for _ in range(8)]
+    a, b = Rb3Gpu(verbose=1), Rb3Gpu(verbose=1)
+    try:
+        for h, part in ((a, gs[:4]), (b, gs[4:])):
+            for i, g in enumerate(part):
+                bw, w = host.build_bwt_walkers(util.make_text([g]), 256)
+                if i == 0: h.from_plain(bw)
+                else: h.merge_plain_walkers(bw, w)
+        tot = b.get_tot()
+        plain_b = b.export_plain()
+        d = a.dev_upload(np.zeros(tot + 16, dtype=np.uint8))
+        # (two handles on one device: B's export goes through the host here; on two GPUs it is sent over RCCL)
+        a._chk(a._lib.rb3gpu_dev_upload(a._h, d, plain_b.ctypes.data, tot), "upload")
+        a.merge_plain_dev(d, tot, True)
+        a.dev_free(d)
+        want = host.build_bwt(util.make_text(gs))
+        assert np.array_equal(a.export_plain(), want)
+    finally:
+        a.close(); b.close()

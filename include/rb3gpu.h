@@ -2,8 +2,10 @@
  * rb3gpu.h -- C ABI of the MI355X-native BWT-merge engine (librb3gpu.so).
  *
  * This is the drop-in boundary for the hot path of `ropebwt3 build`: every entry
- * point replaces one call the reference's build.c makes on an `mrope_t*`
- * (citations are file:line in the reference tree).  The opaque `rb3gpu_t`
+ * point replaces one call the reference's build.c makes on an `mrope_t*` -- and,
+ * further down, the calls on either side of it: the suffix sorting of a batch, the
+ * run export / FMD packing, the sampled suffix array (citations are file:line in
+ * the reference tree).  The opaque `rb3gpu_t`
  * stands where `mrope_t*` stood; it owns a flat run/bit-plane block array in
  * HBM instead of the reference's B+-tree of RLE leaves.  Plain C types only:
  * no HIP, torch or C++ types cross this boundary.  All functions return 0 on

@@ -5,7 +5,10 @@
  * The call sequence of a merge mirrors rb3_fmi_merge_plain (fm-index.c:279-303):
  *   C array of B1 (286-287)            -> kept in the handle / folded into the group directory
  *   rb3_mg_rank_plain (288-289)        -> k_tile_hist + scan + k_lf2, then k_chain
- *   kt_for(worker_mgins) (294-299)     -> k_group_rows + k_pass1 + scan + k_pass2
+ *   kt_for(worker_mgins) (294-299)     -> k_pos_finalize_check_rows + k_pass1w + k_decide + scan + k_pass2w
+ *                                         (k_group_rows + k_pass1 + scan + k_pass2 when the window scratch would be too big)
+ * Suffix sorting of a batch (rb3gpu_sort.hip) and FMD packing (rb3gpu_fmdenc.hip) are separate translation units
+ * because they use rocPRIM's sorts and scans; nothing on the merge path depends on them.
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -489,3 +489,13 @@ def test_whole_index_merge_on_device(oracle):
         assert np.array_equal(a.export_plain(), want)
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("env", [{"RB3GPU_GROUP_REBUILD": "1"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_GROUP_REBUILD": "1", "RB3GPU_STAGED": "1"}])
+def test_fallback_code_paths_via_soak(env):
+    """the group-sequential rebuild kernels (taken when the window scratch would exceed 8 GB) and the staged merge
+    (taken for walker-less or oversized merges) forced through the randomised soak"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "10", "61000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout.decode()[-2000:]

@@ -253,7 +253,7 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : 384;
 	int r;
 	if (step < (seq->l >> 20)) step = seq->l >> 20; /* at most ~2^20 walkers per batch: the engine's stretch table is finite */
-	if (opt->gpu_sort && seq->l < INT32_MAX - 16) { /* the GPU sorts (the sorter handles < 2^31 symbols) */
+	if (opt->gpu_sort && seq->l < (getenv("RB3GPU_TEST_SORT_MAX") ? atoll(getenv("RB3GPU_TEST_SORT_MAX")) : (long long)INT32_MAX - 16)) { /* the GPU sorts (the sorter handles < 2^31 symbols; the variable is a test hook) */
 		b = (batch_t*)calloc(1, sizeof(batch_t));
 		b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s, b->raw = 1;
 		b->step = (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22)) ? step : 0;

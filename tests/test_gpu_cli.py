@@ -174,3 +174,15 @@ def test_fmd_packed_on_gpu_and_on_host_agree(tmp_path):
         r = subprocess.run([CLI, "build"] + ent["flags"] + ["-d"] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], name
         assert b"packed the FMD on the GPU" not in r.stderr
+
+
+def test_oversized_batches_go_to_the_host_sorter():
+    """batches the GPU sorter does not take (2^31 symbols or more; here the limit is lowered through the test hook)
+    are sorted on the host in the same run: same .fmd, serial and pipelined"""
+    ent = MAN["genomes12"]
+    for limit, on_gpu in (("1000", False), ("100000", True)):
+        env = dict(os.environ, RB3GPU_TEST_SORT_MAX=limit)
+        for extra in ([], ["-p2"], ["-p0"]):
+            r = subprocess.run([CLI, "build", "-d", "-m45k"] + extra + [os.path.join(util.GOLDEN, ent["inputs"][0])], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], (limit, extra)
+            assert ("symbols on the GPU" in r.stderr.decode()) == on_gpu

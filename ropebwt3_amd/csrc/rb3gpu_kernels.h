@@ -1309,6 +1309,130 @@ __global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2
 	for (int64_t w = a + 1; w <= b; ++w) jw[w] = i;
 }
 
+/* Run-space short cut of k_pass1w for the common window of a compressible index: its old symbols lie inside ONE
+ * run slot and at most three batch rows land in it.  Then the window is (at most 48 clipped runs) + (<= 3 single
+ * symbols), and its statistics and run list follow from those ~50 items without ever touching 256 symbols:
+ * lane q clips run q to the window, splits it at the rows that fall inside, the items are compacted in order,
+ * adjacent items with equal symbols are merged.  Returns false (nothing written) if the window does not qualify;
+ * the caller then takes the symbol path.  The planes are NOT produced (wstat gets RB3_WSTAT_NOPLANES): a window
+ * like this almost always ends up in a run slot, and k_pass2w rebuilds the planes from the run list otherwise. */
+#define RB3_WSTAT_NOPLANES 0x8000u
+#define RB3_FAST_MAXROWS 3
+
+__device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot, int64_t w, int64_t j,
+		int lane, uint32_t *sh /* >= 160 words of LDS of this wave */, uint4 *wstat, uint16_t *wruns)
+{
+	const int64_t p0 = w << RB3_WIN_BITS;
+	if (ntot - p0 < RB3_WIN) return false; // the last window
+	// the rows that land in this window (at most RB3_FAST_MAXROWS, else the symbol path)
+	int64_t r = INT64_MAX;
+	uint32_t rs = 7;
+	if (lane <= RB3_FAST_MAXROWS && j + lane < n2) r = pos[j + lane];
+	const bool in = r < p0 + RB3_WIN;
+	const uint32_t inm = (uint32_t)__ballot(in);
+	if (inm >> RB3_FAST_MAXROWS) return false;
+	const int nb2 = __popc(inm);
+	if (in) { if (r < p0) r = p0; rs = b2[j + lane]; }
+	const int64_t a1 = p0 - j;
+	const int nold = RB3_WIN - nb2;
+	if (a1 < 0 || a1 + nold > old.n) return false;
+	// one run slot must hold the whole old range
+	const int64_t wa = a1 >> RB3_WIN_BITS, wb = (a1 + nold - 1) >> RB3_WIN_BITS;
+	const int64_t ga = wa >> (RB3_GRP_BITS - RB3_WIN_BITS), gb = wb >> (RB3_GRP_BITS - RB3_WIN_BITS);
+	if (ga != gb) return false;
+	const uint64_t sm = old.grp64[ga * 8 + 6];
+	const uint32_t sa = (uint32_t)sm + __popc((uint32_t)(sm >> 32) & ((2u << ((uint32_t)wa & (RB3_GRP_WINS - 1))) - 1u)) - 1u;
+	const uint32_t sb = (uint32_t)sm + __popc((uint32_t)(sm >> 32) & ((2u << ((uint32_t)wb & (RB3_GRP_WINS - 1))) - 1u)) - 1u;
+	if (sa != sb) return false;
+	const uint32_t *sp = (const uint32_t*)(old.slot16 + (int64_t)sa * 8);
+	const uint32_t hdr0 = sp[0];
+	if (!(hdr0 & RB3_SLOT_RLE)) return false;
+	const int A = (int)(a1 - ((ga << RB3_GRP_BITS) + (hdr0 & 0xFFFFu))); // the window's old range starts at offset A of the slot
+	// the rows: old-local offset o_i = (new-local position) - i and symbol, in every lane
+	int o[RB3_FAST_MAXROWS];
+	uint32_t sy[RB3_FAST_MAXROWS];
+#pragma unroll
+	for (int i = 0; i < RB3_FAST_MAXROWS; ++i) {
+		o[i] = i < nb2 ? (int)(__shfl(r, i) - p0) - i : 0x7fffffff;
+		sy[i] = __shfl(rs, i);
+	}
+	// lane q: run q of the slot, clipped to the window, in old-local coordinates
+	uint32_t len = 0, rsym = 7;
+	if (lane < RB3_RLE_CODES) {
+		const uint32_t word = sp[(lane / 6) * 4 + 1 + (lane % 6) / 2];
+		const uint32_t code = (lane & 1) ? word >> 16 : word & 0xFFFFu;
+		rsym = code & 7u, len = rsym == 7u ? 0u : (code >> 3) + 1u;
+	}
+	uint32_t inc = len;
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+	int cs = (int)(inc - len) - A, ce = (int)inc - A;
+	cs = cs < 0 ? 0 : cs, ce = ce > nold ? nold : ce;
+	const bool valid = ce > cs;
+	const uint64_t vm = __ballot(valid);
+	if (vm == 0) return false;
+	const bool lastp = valid && (vm >> lane) == 1ull; // the last piece also takes the rows behind the last old symbol
+	// items of this lane, in order: [part of the run] row [part] row ... [rest]; parts may be empty.  Item slot 2i is the
+	// part before row i, slot 2i+1 row i, the last slot the rest; `present` says which exist.
+	uint32_t present = 0, plen[RB3_FAST_MAXROWS + 1];
+	bool mine[RB3_FAST_MAXROWS];
+	{
+		int at = cs;
+#pragma unroll
+		for (int i = 0; i < RB3_FAST_MAXROWS; ++i) {
+			mine[i] = valid && i < nb2 && o[i] >= cs && (o[i] < ce || (lastp && o[i] <= ce));
+			plen[i] = mine[i] && o[i] > at ? (uint32_t)(o[i] - at) : 0u;
+			if (plen[i]) present |= 1u << (2 * i);
+			if (mine[i]) present |= 1u << (2 * i + 1), at = o[i];
+		}
+		plen[RB3_FAST_MAXROWS] = valid && ce > at ? (uint32_t)(ce - at) : 0u;
+		if (plen[RB3_FAST_MAXROWS]) present |= 1u << (2 * RB3_FAST_MAXROWS);
+	}
+	uint32_t ic = __popc(present), ioff = ic;
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(ioff, d); if (lane >= d) ioff += t; }
+	const int nitems = (int)__shfl(ioff, 63);
+	if (nitems > 64) return false;
+	ioff -= ic;
+	uint32_t *it = sh; // items: sym | len << 8
+#pragma unroll
+	for (int i = 0; i <= RB3_FAST_MAXROWS; ++i) {
+		if (present >> (2 * i) & 1u) it[ioff + __popc(present & ((1u << (2 * i)) - 1u))] = rsym | plen[i] << 8;
+		if (i < RB3_FAST_MAXROWS && (present >> (2 * i + 1) & 1u)) it[ioff + __popc(present & ((1u << (2 * i + 1)) - 1u))] = sy[i] | 1u << 8;
+	}
+	if (lane < 8) sh[128 + lane] = 0u; // symbol counts
+	wave_sync();
+	// merge equal neighbours: one lane per item
+	uint32_t me = lane < nitems ? it[lane] : 7u;
+	const uint32_t msym = me & 0xFFu, mlen = lane < nitems ? me >> 8 : 0u;
+	uint32_t prev = __shfl_up(msym, 1);
+	if (lane == 0) prev = 8u;
+	const bool head = lane < nitems && msym != prev;
+	const uint64_t H = __ballot(head);
+	const int nruns = __popcll(H);
+	if (nruns > RB3_RLE_CODES) return false;
+	uint32_t pinc = mlen;
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(pinc, d); if (lane >= d) pinc += t; }
+	const uint32_t mypos = pinc - mlen; // new-local position of this item
+	const uint64_t above = lane == 63 ? 0ull : H >> (lane + 1);
+	const int nh = above ? lane + 1 + (__ffsll((unsigned long long)above) - 1) : 64;
+	uint32_t npos = __shfl(mypos, nh & 63);
+	if (nh >= nitems) npos = RB3_WIN;
+	if (head) {
+		const uint32_t rl = npos - mypos;
+		wruns[w * RB3_RLE_CODES + __popcll(H & ((1ull << lane) - 1ull))] = (uint16_t)((rl - 1u) << 3 | msym);
+		atomicAdd(&sh[128 + msym], rl);
+	}
+	wave_sync();
+	if (lane == 0) {
+		const uint32_t first = it[0] & 0xFFu, last = it[nitems - 1] & 0xFFu;
+		uint4 v;
+		v.x = sh[128] | sh[129] << 16, v.y = sh[130] | sh[131] << 16, v.z = sh[132] | sh[133] << 16;
+		v.w = (uint32_t)nruns | RB3_WSTAT_NOPLANES | first << 16 | last << 24;
+		wstat[w] = v;
+	}
+	wave_sync();
+	return true;
+}
+
 /* per window: symbols -> statistics (wstat: 6 x u16 counts, first, last, u16 runs = 16 B) and the
  * three bit planes (wplane: 24 dwords, the payload of a bit-plane slot) */
 template<bool FROM_PLAIN>
@@ -1318,6 +1442,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 	__shared__ __attribute__((aligned(16))) uint8_t symbuf_[RB3_REB_WAVES][RB3_WIN];
 	if (RB3_REB_SKIP(skip)) return;
 	__shared__ uint64_t ball_[RB3_REB_WAVES][12];
+	__shared__ uint32_t fast_[RB3_REB_WAVES][160];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint8_t *symbuf = symbuf_[wave];
 	uint64_t *ball = ball_[wave];
@@ -1326,6 +1451,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 	if (w >= nwin) break;
 	const int64_t p0 = w << RB3_WIN_BITS;
 	int64_t j = FROM_PLAIN ? 0 : jw[w];
+	if (!FROM_PLAIN && window_runs_fast(old, pos, b2, n2, ntot, w, j, lane, fast_[wave], wstat, wruns)) continue;
 	uint32_t sym[4];
 	gen_window<FROM_PLAIN>(old, pos, b2, n2, ntot, p0, j, symbuf, sym, lane);
 	uint64_t H[4];
@@ -1395,7 +1521,7 @@ __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot,
 	const int nvw = (int)(W - g * RB3_GRP_WINS < RB3_GRP_WINS ? W - g * RB3_GRP_WINS : RB3_GRP_WINS);
 	uint4 st = make_uint4(0, 0, 0, 7u << 16 | 7u << 24);
 	if (lane < nvw) st = wstat[g * RB3_GRP_WINS + lane];
-	const int my_nruns = (int)(st.w & 0xFFFFu);
+	const int my_nruns = (int)(st.w & 0x7FFFu); // (bit 15: RB3_WSTAT_NOPLANES)
 	const uint32_t my_first = st.w >> 16 & 0xFFu, my_last = st.w >> 24;
 	uint32_t cnt[6] = { st.x & 0xFFFFu, st.x >> 16, st.y & 0xFFFFu, st.y >> 16, st.z & 0xFFFFu, st.z >> 16 };
 #pragma unroll
@@ -1473,6 +1599,43 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 			lane == 6 ? rel[5] : nsym;
 		hq += abs_base;
 		if (slot_sz == 1) { // bit-plane slot: header + the cached planes
+			const uint32_t wflags = wstat[w].w;
+			if (wflags & RB3_WSTAT_NOPLANES) { // k_pass1w took the run-space short cut: make the planes from the run list (<= 48 runs)
+				uint32_t len = 0, sy = 7;
+				if (lane < (int)(wflags & 0x7FFFu)) { const uint32_t c = wruns[w * RB3_RLE_CODES + lane]; sy = c & 7u, len = (c >> 3) + 1u; }
+				uint32_t inc = len;
+				for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+				uint16_t *rst = (uint16_t*)code16; // 48 run starts
+				uint8_t *rsy = (uint8_t*)sB;       // 48 run symbols
+				uint32_t *pw = sNr;                // 24 plane words
+				if (lane < RB3_RLE_CODES) rst[lane] = (uint16_t)(len ? inc - len : 0xFFFFu), rsy[lane] = (uint8_t)sy;
+				wave_sync();
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t off = 64 * u + lane;
+					int q = 0;
+#pragma unroll
+					for (int d = 32; d >= 1; d >>= 1)
+						if (q + d < RB3_RLE_CODES && rst[q + d] <= off) q += d;
+					const uint32_t s1 = off < nsym ? rsy[q] : 7u;
+#pragma unroll
+					for (int p = 0; p < 3; ++p) {
+						const uint64_t m = __ballot((s1 >> p) & 1u);
+						if (lane == u * 3 + p) pw[(u * 3 + p) * 2] = (uint32_t)m, pw[(u * 3 + p) * 2 + 1] = (uint32_t)(m >> 32);
+					}
+				}
+				wave_sync();
+				if (lane < 8) { // same word order as wplane
+					uint4 v;
+					v.x = hq;
+					v.y = pw[(lane >> 1) * 6 + 0 + (lane & 1)];
+					v.z = pw[(lane >> 1) * 6 + 2 + (lane & 1)];
+					v.w = pw[(lane >> 1) * 6 + 4 + (lane & 1)];
+					slot16[sidx * 8 + lane] = v;
+				}
+				wave_sync();
+				continue;
+			}
 			if (lane < 8) {
 				const uint32_t *pl = wplane + w * 24;
 				uint4 v;
@@ -1488,7 +1651,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		// continues the last run of the window before (same test as k_decide).
 		uint4 sw = make_uint4(0, 0, 0, 7u << 16 | 7u << 24);
 		if (lane < slot_sz) sw = wstat[w + lane];
-		const uint32_t nr = sw.w & 0xFFFFu, wfirst = sw.w >> 16 & 0xFFu, wlast = sw.w >> 24;
+		const uint32_t nr = sw.w & 0x7FFFu, wfirst = sw.w >> 16 & 0xFFu, wlast = sw.w >> 24;
 		const uint32_t prev_last = __shfl_up(wlast, 1);
 		const uint32_t bm = (lane > 0 && lane < slot_sz && nr > 0 && prev_last == wfirst) ? 1u : 0u;
 		const uint32_t e = lane < slot_sz ? nr - bm : 0u;

@@ -1451,7 +1451,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 	if (w >= nwin) break;
 	const int64_t p0 = w << RB3_WIN_BITS;
 	int64_t j = FROM_PLAIN ? 0 : jw[w];
-	if (!FROM_PLAIN && window_runs_fast(old, pos, b2, n2, ntot, w, j, lane, fast_[wave], wstat, wruns)) continue;
+	if (!FROM_PLAIN && old.dense == 0 && window_runs_fast(old, pos, b2, n2, ntot, w, j, lane, fast_[wave], wstat, wruns)) continue;
 	uint32_t sym[4];
 	gen_window<FROM_PLAIN>(old, pos, b2, n2, ntot, p0, j, symbuf, sym, lane);
 	uint64_t H[4];

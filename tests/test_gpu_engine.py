@@ -499,3 +499,34 @@ def test_fallback_code_paths_via_soak(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "10", "61000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+def test_hundreds_of_relatives(oracle):
+    """more matching suffixes (420 near-identical short genomes indexed) than the 255 a tentative walker tracks: the
+    walkers stay plain inexact ones until enough relatives have dropped out; same result, no redo"""
+    import os
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(101)
+    g0 = util.random_genome(rng, 3000)
+    rel = [util.mutate(rng, g0, 0.004) for _ in range(420)]
+    b1 = host.build_bwt(util.make_text(rel, True, False))
+    t2 = util.make_text([util.mutate(rng, g0, 0.004), rel[7].copy(), util.mutate(rng, rel[100], 0.01)], True, False)
+    rb, _ = oracle.mg_rank(b1, host.build_bwt(t2.copy()), 8)
+    want = rb >> 6
+    steps = {}
+    for tent in ("1", "0"):
+        os.environ["RB3GPU_TENT"] = tent
+        try:
+            h = Rb3Gpu(verbose=1)
+            h.from_plain(b1)
+            for step in (128, 300):
+                b2, w = host.build_bwt_walkers(t2, step)
+                got, _ = h.mg_rank_plain_walkers(b2, w)
+                assert np.array_equal(got, want), (tent, step)
+            st = h.stats()
+            steps[tent] = st["n_lf_steps"] - 2 * want.size
+            assert st["n_fallbacks"] == 0
+            h.close()
+        finally:
+            os.environ.pop("RB3GPU_TENT", None)
+    assert steps["1"] <= steps["0"], steps

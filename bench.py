@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--walker-step", type=int, default=384, help="text distance between LF walkers handed to the engine")
     ap.add_argument("--plain-abi", action="store_true", help="use rb3gpu_merge_plain_dev (the reference's signature, no walker list)")
     ap.add_argument("--sharded", action="store_true", help="N>1: one batch of N genomes, walkers sharded by text range + all-reduce")
+    ap.add_argument("--row-words", action="store_true", help="walk row words (BWT + sampled inverse suffix array from the host sorter) instead of text-order words")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary reads-regime measurement")
     ap.add_argument("--aux-reads", type=int, default=100000)
@@ -161,15 +162,25 @@ def main():
     g0, gs = gen_genomes(args.genome_len, args.div, 1, seeds)
     b1 = host.build_bwt(util.make_text([g0]))
     walkers = None
+    text2 = util.make_text(gs)
+    text_words = not (args.plain_abi or args.row_words or sharded)  # default: BWT + text-order words from the GPU suffix sorter
     if args.plain_abi and not sharded:
-        b2 = host.build_bwt(util.make_text(gs))
+        b2 = host.build_bwt(text2.copy())
+    elif text_words:
+        b2 = host.build_bwt(text2.copy())
+        walkers = host.walkers_text(text2, args.walker_step)
     else:
-        b2, walkers = host.build_bwt_walkers(util.make_text(gs), args.walker_step)
+        b2, walkers = host.build_bwt_walkers(text2.copy(), args.walker_step)
     log("inputs: B1 %d symbols, B2 %d symbols on each GPU; host suffix sorting %.1f s (not timed)" % (b1.size, b2.size, time.time() - t0))
 
     h = Rb3Gpu(device=local_rank, verbose=1)
     h.from_plain(b1)
-    d_b2 = h.dev_upload(b2)
+    d_tw = None
+    if text_words:  # the batch as the GPU suffix sorter leaves it in HBM (sorting is outside the metric)
+        d_b2, d_tw = h.sort_text(text2)
+        assert np.array_equal(h.dev_download(d_b2, b2.size), b2), "GPU and host suffix sorters disagree"
+    else:
+        d_b2 = h.dev_upload(b2)
 
     def barrier():
         h.sync()
@@ -182,6 +193,9 @@ def main():
 
         def step(commit=False):
             multi.merge_sharded(h, d_b2, b2.size, walkers, args.walker_step, dist, rank, world, pos, commit=commit, sync=torch.cuda.synchronize)
+    elif text_words:
+        def step(commit=False):
+            h.merge_text_dev(d_b2, d_tw, b2.size, walkers, commit=commit)
     elif walkers is not None:
         def step(commit=False):
             h.merge_plain_dev_walkers(d_b2, b2.size, walkers, commit=commit)
@@ -241,6 +255,7 @@ def main():
             "config": {"workload": "cfg2-synthetic-mtb1: per GPU, merge G_i = G0 + 0.1%% substitutions (%d bp, both strands, %d symbols, 2 strings) into the index of G0 (%d symbols)" % (args.genome_len, rows_per_launch, b1.size),
                        "symbols_per_step_per_gpu": int(rows_per_launch), "index_symbols": int(b1.size), "parallelism": par,
                        "entry_point": "rb3gpu_merge_plain_dev (reference signature, SA-order walkers)" if walkers is None else
+                                      "rb3gpu_merge_text_dev (BWT + text-order words = inverse suffix array, both from the GPU suffix sorter; walkers by text position, step %d, %d walkers)" % (args.walker_step, len(walkers)) if text_words else
                                       "rb3gpu_merge_plain_dev_walkers (BWT + sampled inverse suffix array from the host suffix sorter, text step %d, %d walkers)" % (args.walker_step, len(walkers)),
                        "lf_steps_per_step": int(st["n_lf_steps"] // max(1, args.steps)), "rank_phase_fallbacks": int(st["n_fallbacks"])},
             "phases_ms_per_step": {"lf": round(st["ms_lf"] / args.steps, 4), "rank": round(st["ms_rank"] / args.steps, 4),
@@ -248,7 +263,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_chain", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": load_pmc_traffic(),
                          "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": round(ms_chain, 4),
-                         "note": "random-request bound (~80 G requests/s: one 128-B line, two 8-B loads, one 8-B store per LF step; waves wait on memory 75% of their cycles, profiles/r1_pmc_sq.txt); aux_reads_regime is the same kernel on 200 k short strings"},
+                         "note": "random-access bound (per LF step one 128-B block line read and one 8-B record written at random rows, ~4.6 TB/s of 64-B sectors; the batch side is streamed; waves wait on memory 75% of their cycles, profiles/r1_pmc_sq.txt); aux_reads_regime is the same kernel on 200 k short strings"},
         }
         if tree_ms is not None:
             out["tree_merge_ms"] = round(tree_ms, 3)
@@ -258,6 +273,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(b1, b2)
         print(json.dumps(out), flush=True)
     h.dev_free(d_b2)
+    if d_tw is not None:
+        h.dev_free(d_tw)
     h.close()
     if use_dist:
         dist.destroy_process_group()

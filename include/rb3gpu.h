@@ -176,6 +176,17 @@ int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out);
 int rb3gpu_ssa_dims(const rb3gpu_t *h, int ssa_shift, int64_t *m, int64_t *n_ssa, int *ms);
 int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa);
 
+/* The merge of a batch that comes with its TEXT-ORDER WORDS: d_tw[t] = row of the suffix at text position t << 3 |
+ * the symbol before it (0 at the start of a string), i.e. the inverse suffix array of the batch next to its BWT
+ * (rb3gpu_sort_text / rb3gpu_sorter_sort produce both; a host sorter has the suffix array and inverts it).
+ * walkers[i].row is then the TEXT POSITION a walker starts at (a sentinel's walker: the position of the sentinel),
+ * everything else as in rb3gpu_merge_plain_dev_walkers.  Same result as rb3_fmi_merge_plain (fm-index.c:279-303);
+ * the LF walkers read their batch-side state as a stream instead of one random row word per step.
+ * d_bwt: len bytes, d_tw: len 64-bit words, both device memory.  rb3gpu_mg_rank_text_dev: the rank phase alone
+ * (pos[] as in rb3gpu_mg_rank_plain), for parity tests. */
+int rb3gpu_merge_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit);
+int rb3gpu_mg_rank_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1]);
+
 /* Partial BWT of one batch on the GPU, instead of rb3_build_sais on the host (sais-ss.c:10-56; libsais in GSA
  * mode: the i-th sentinel sorts before the (i+1)-th, sais-ss.c:16-21).  text: len symbols 0..5 in host memory,
  * every string terminated by 0 (so text[len-1] == 0), exactly what rb3_seq_read leaves in seq->s (io.c:104-125);
@@ -184,6 +195,8 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa);
  * ceil(len / step) entries) receives the row of the suffix that starts at text position i * step -- the sampled
  * inverse suffix array a walker list is made from.  len < 2^31. */
 int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow);
+/* the same, with the text-order words of the batch (len 64-bit words of device memory) for rb3gpu_merge_text_dev */
+int rb3gpu_sort_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, uint64_t *d_tw);
 
 /* The same sorter as an object of its own (own HIP stream and scratch, independent of any index handle), so that a
  * host thread can sort batch i+1 while another merges batch i -- the pipeline of build.c:55-83, 186-201 with both
@@ -194,6 +207,8 @@ typedef struct rb3gpu_sorter_s rb3gpu_sorter_t;
 rb3gpu_sorter_t *rb3gpu_sorter_create(int device);
 void rb3gpu_sorter_destroy(rb3gpu_sorter_t *s);
 int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow);
+/* BWT + text-order words (*d_tw: len 64-bit words in the same output buffer; released together with *d_bwt) */
+int rb3gpu_sorter_sort(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, void **d_tw);
 int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt);
 
 /* Import for `build -i` (rb3_enc_fmd2fmr fm-index.c:56-85, mr_restore mrope.c:161-177):

@@ -149,32 +149,34 @@ typedef struct {
 	rb3h_walker_t *walkers;
 	int ret, raw;             /* raw: not sorted yet, the consumer's GPU handle sorts it */
 	void *d_bwt;              /* device: the BWT from a sorter thread's own GPU sorter (gs), to be released after the merge */
+	void *d_tw;               /* device: its text-order words (long strings: the walkers are then given by text position) */
 	rb3gpu_sorter_t *gs;
 } batch_t;
 
-/* --gpu-sort: the batch arrives as text; suffix sorting, BWT and sampled inverse suffix array on the GPU
- * (rb3gpu_bwt_from_text instead of rb3_build_sais, build.c:220), the BWT never leaves HBM */
+/* --gpu-sort: the batch arrives as text; suffix sorting, BWT and inverse suffix array on the GPU
+ * (rb3gpu_sort_text / rb3gpu_bwt_from_text instead of rb3_build_sais, build.c:220), the BWT never leaves HBM */
 static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 {
-	void *d_bwt = 0;
-	int64_t *ckrow = 0, nck = b->step > 0 ? (b->len + b->step - 1) / b->step : 0;
+	void *d_bwt = 0, *d_tw = 0;
+	const int text_walk = b->step > 0 && *has_index; /* long strings: text-order words + walkers by text position */
 	int ret;
 	if ((ret = rb3gpu_dev_alloc(h, b->len + 16, &d_bwt)) < 0) return ret;
-	if (nck > 0 && *has_index && (ckrow = (int64_t*)malloc((size_t)nck * 8)) == 0) { rb3gpu_dev_free(h, d_bwt); return RB3GPU_ENOMEM; }
-	ret = rb3gpu_bwt_from_text(h, b->len, b->bwt, (uint8_t*)d_bwt, ckrow ? b->step : 0, ckrow);
+	if (text_walk && rb3gpu_dev_alloc(h, b->len * 8, &d_tw) < 0) { rb3gpu_dev_free(h, d_bwt); return 1; }
+	if (text_walk) ret = rb3gpu_sort_text(h, b->len, b->bwt, (uint8_t*)d_bwt, (uint64_t*)d_tw);
+	else ret = rb3gpu_bwt_from_text(h, b->len, b->bwt, (uint8_t*)d_bwt, 0, 0);
 	if (ret < 0 && ret != RB3GPU_ESYMBOL) { /* the sorter could not run (memory): the caller sorts this batch on the host */
-		free(ckrow);
+		if (d_tw) rb3gpu_dev_free(h, d_tw);
 		rb3gpu_dev_free(h, d_bwt);
 		return 1;
 	}
 	if (ret == 0 && rb3h_verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 	if (ret == 0 && !*has_index) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)d_bwt);
-	else if (ret == 0 && ckrow) {
-		if (rb3h_walkers_from_ckrow(b->len, b->bwt, b->step, ckrow, &b->n_walkers, &b->walkers) < 0) ret = RB3GPU_ENOMEM;
-		else ret = rb3gpu_merge_plain_dev_walkers(h, b->len, (const uint8_t*)d_bwt, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+	else if (ret == 0 && text_walk) {
+		if (rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) ret = RB3GPU_ENOMEM;
+		else ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
 	} else if (ret == 0) ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)d_bwt, 1);
-	free(ckrow);
+	if (d_tw) rb3gpu_dev_free(h, d_tw);
 	rb3gpu_dev_free(h, d_bwt);
 	return ret;
 }
@@ -185,10 +187,10 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	if (b->d_bwt) { /* sorted on the GPU by a sorter thread while the batch before was being merged */
 		const int first = !*has_index;
 		if (first) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)b->d_bwt);
-		else if (b->walkers) ret = rb3gpu_merge_plain_dev_walkers(h, b->len, (const uint8_t*)b->d_bwt, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+		else if (b->walkers && b->d_tw) ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
 		else ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)b->d_bwt, 1);
 		rb3gpu_sorter_release(b->gs, b->d_bwt);
-		b->d_bwt = 0;
+		b->d_bwt = b->d_tw = 0;
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] %s the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), first ? "encoded" : "merged", (long)b->len);
 	} else if (b->raw) {
@@ -259,15 +261,16 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 		b->step = (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22)) ? step : 0;
 		seq->s = 0, seq->l = seq->m = 0;
 		if (gs) { /* this thread has a GPU sorter of its own: sort now, while the consumer merges the batch before */
-			int64_t *ckrow = b->step > 0 ? (int64_t*)malloc((size_t)((b->len + b->step - 1) / b->step) * 8) : 0;
-			if (rb3gpu_sorter_bwt(gs, b->len, b->bwt, &b->d_bwt, ckrow ? b->step : 0, ckrow) == 0) {
+			/* long strings: also the text-order words, and LF walkers by text position (same result, text-regular parallelism);
+			 * short strings (reads): one walker per string is what the engine does by itself */
+			const int r2 = b->step > 0 ? rb3gpu_sorter_sort(gs, b->len, b->bwt, &b->d_bwt, &b->d_tw) : rb3gpu_sorter_bwt(gs, b->len, b->bwt, &b->d_bwt, 0, 0);
+			if (r2 == 0) {
 				if (rb3h_verbose >= 3)
 					fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
-				if (ckrow && rb3h_walkers_from_ckrow(b->len, b->bwt, b->step, ckrow, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0;
+				if (b->d_tw && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0;
 				b->gs = gs, b->raw = 0;
 				free(b->bwt); b->bwt = 0; /* the text is not needed any more */
-			} else b->d_bwt = 0; /* leave it to the consumer (its handle's sorter, then the host sorter) */
-			free(ckrow);
+			} else b->d_bwt = b->d_tw = 0; /* leave it to the consumer (its handle's sorter, then the host sorter) */
 		}
 		*out = b;
 		return 0;

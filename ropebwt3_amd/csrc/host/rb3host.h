@@ -32,6 +32,7 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads);
 typedef struct { int64_t row, ka0, nsteps, flags; } rb3h_walker_t;
 int rb3h_build_bwt_walkers(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads, int64_t step, int64_t *n_walkers, rb3h_walker_t **walkers);
 int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, const int64_t *ckrow, int64_t *n_walkers, rb3h_walker_t **walkers);
+int rb3h_walkers_text(int64_t len, const uint8_t *text, int64_t step, int64_t *n_walkers, rb3h_walker_t **walkers); /* by text position (rb3gpu_merge_text_dev) */
 
 /* ---- sequence input (io.c) ---- */
 typedef struct { int64_t l, m; uint8_t *s; } rb3h_buf_t;

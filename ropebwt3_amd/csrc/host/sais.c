@@ -53,7 +53,8 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
 
 /* The walker list of a batch from its sampled inverse suffix array: ckrow[i] = row of the suffix starting at text
  * position i * step (from the host sorter below, or from rb3gpu_bwt_from_text).  text is the batch BEFORE it is
- * turned into a BWT.  Same list as rb3h_build_bwt_walkers. */
+ * turned into a BWT.  Same list as rb3h_build_bwt_walkers.  ckrow == NULL: the walkers are given by TEXT POSITION instead of
+ * row (a sentinel's walker: the position of the sentinel), for rb3gpu_merge_text_dev. */
 int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, const int64_t *ckrow, int64_t *n_walkers, rb3h_walker_t **walkers)
 {
 	int64_t b, j, nw = 0, n_seq = 0;
@@ -69,16 +70,21 @@ int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, cons
 		int64_t prev = -1, p;
 		for (p = (b / step + 1) * step; p < e; p += step) { /* multiples of step strictly inside the string */
 			if (e - p < RB3H_MIN_SEG && e - p < step) continue; /* keep the sentinel walker's own segment long (see k_chain) */
-			w[nw].row = ckrow[p / step], w[nw].ka0 = -1, w[nw].flags = 0;
+			w[nw].row = ckrow ? ckrow[p / step] : p, w[nw].ka0 = -1, w[nw].flags = 0;
 			w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : p - prev;
 			prev = p, ++nw;
 		}
-		w[nw].row = j, w[nw].ka0 = -2 /* sentinel row: exact, = acc[1] of the index */, w[nw].flags = 0;
+		w[nw].row = ckrow ? j : e, w[nw].ka0 = -2 /* sentinel row: exact, = acc[1] of the index */, w[nw].flags = 0;
 		w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : e - prev;
 		++nw, b = e + 1;
 	}
 	*n_walkers = nw, *walkers = w;
 	return 0;
+}
+
+int rb3h_walkers_text(int64_t len, const uint8_t *text, int64_t step, int64_t *n_walkers, rb3h_walker_t **walkers)
+{
+	return rb3h_walkers_from_ckrow(len, text, step, 0, n_walkers, walkers);
 }
 
 /* BWT plus the list of LF walkers for the GPU merge: one per string (its sentinel row) and one

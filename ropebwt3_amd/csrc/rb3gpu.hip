@@ -29,7 +29,7 @@ struct rb3sort_ws;
 rb3sort_ws *rb3sort_create(void);
 void rb3sort_destroy(rb3sort_ws *ws);
 int64_t rb3sort_bytes(const rb3sort_ws *ws);
-int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds);
+int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds, uint64_t *d_tw);
 /* the FMD packer lives in rb3gpu_fmdenc.hip */
 int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words);
 
@@ -383,7 +383,7 @@ static void index_install(rb3gpu_t *h, int64_t ngrp, int64_t nslots, int64_t nto
 
 /* histogram + row words of B2 (LF word of every row, fm-index.c:206-216) into d_row.  Totals stay on the device (misc[MISC_LF_TOT..]); acc2 != NULL also
  * brings the C array of B2 to the host (one sync) and checks the symbols (fm-index.c:124-125). */
-static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_row, int64_t *acc2)
+static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_row, int64_t *acc2, bool words = true)
 {
 	const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
 	int r;
@@ -399,7 +399,8 @@ static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_ro
 		acc2[0] = 0;
 		for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)total[a];
 	}
-	hipLaunchKernelGGL(k_lf2, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (const uint64_t*)h->tpre.p, (const uint64_t*)dtot, (uint64_t*)d_row);
+	if (words) hipLaunchKernelGGL(k_lf2, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (const uint64_t*)h->tpre.p, (const uint64_t*)dtot, (uint64_t*)d_row);
+	else HIPCHK(hipMemsetAsync(d_row, 0xff, (size_t)len * 8, h->st)); // text-order walk: the rows only hold records, all unvisited
 	return 0;
 }
 
@@ -504,8 +505,8 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 		const IdxView iv = view_of(h);
 		const int64_t sr = stop_row < 0 ? -1 : stop_row;
 		const dim3 grid((unsigned)nblk), blk(256);
-#define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
-			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tab, sidctr, sid_limit)
+#define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T, false>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
+			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tab, sidctr, sid_limit, (const uint64_t*)nullptr)
 		const int sel = (walkers ? 4 : 0) | (iv.dense == 2 ? 2 : 0) | (tent ? 1 : 0);
 		switch (sel) {
 		case 0: RB3_LAUNCH_CHAIN(false, false, false); break;
@@ -620,18 +621,61 @@ static int merge_staged(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commi
  * made after the final copy-back.  Needs an explicit walker list (the automatic SA-order split needs
  * the number of strings on the host to size its launch) and an index small enough for the upper
  * bound to be affordable; anything else goes through merge_staged. */
+/* walkers given by text position (text-order walk) -> the same list by row, for the paths that walk row words */
+__global__ void __launch_bounds__(256) k_walker_rows(Walker *wl, int64_t n, const uint64_t *tw)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) wl[i].row = (int64_t)(tw[wl[i].row] >> 3);
+}
+
+static int walkers_text_to_rows(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw, rb3gpu_walker_t **out)
+{
+	int r;
+	*out = nullptr;
+	if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
+	rb3gpu_walker_t *w = (rb3gpu_walker_t*)malloc((size_t)n_walkers * sizeof(rb3gpu_walker_t));
+	if (!w) return RB3GPU_ENOMEM;
+	hipError_t e = hipMemcpyAsync(h->wl.p, walkers, (size_t)n_walkers * 32, hipMemcpyHostToDevice, h->st);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_walker_rows, dim3((unsigned)((n_walkers + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw);
+		e = hipMemcpyAsync(w, h->wl.p, (size_t)n_walkers * 32, hipMemcpyDeviceToHost, h->st);
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+	if (e != hipSuccess) { (void)hipGetLastError(); free(w); return RB3GPU_ENODEV; }
+	*out = w;
+	return 0;
+}
+
 static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
-		int64_t n_walkers, const rb3gpu_walker_t *walkers)
+		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw = nullptr);
+
+/* the paths that walk row words, for a batch that came with text-order words */
+static int merge_staged_text(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
+		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw, int tent)
+{
+	rb3gpu_walker_t *wr = nullptr;
+	int r;
+	if ((r = walkers_text_to_rows(h, n_walkers, walkers, d_tw, &wr)) < 0) return r;
+	r = merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, wr, tent);
+	free(wr);
+	return r;
+}
+
+static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
+		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw)
 {
 	const int64_t ntot = h->n + len, nwin = (ntot >> RB3_WIN_BITS) + 1;
 	int tent = 1;
 	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
 	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
-	if (!walkers || n_walkers > (1 << 24) || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED"))
-		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
-	int r;
-	for (int64_t i = 0; i < n_walkers; ++i)
+	if (d_tw && !walkers) return RB3GPU_EINVAL;
+	for (int64_t i = 0; walkers && i < n_walkers; ++i)
 		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) return RB3GPU_EINVAL;
+	if (!walkers || n_walkers > (1 << 24) || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED")) {
+		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, tent);
+		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
+	}
+	int r;
 	// every allocation first: hipMalloc may synchronise
 	const int64_t ngrp_new = (ntot >> RB3_GRP_BITS) + 1;
 	if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
@@ -649,7 +693,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	uint32_t *sidctr = (uint32_t*)(misc + 5);
 	h->mg_active = 0;
 	HIPCHK(hipEventRecord(h->ev[0], h->st));
-	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr)) < 0) return r;
+	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
 	if (rows_fused) HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
@@ -676,12 +720,18 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #endif
 		const dim3 grid((unsigned)nblk), blk(256);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
-#define RB3_LAUNCH_FAST(D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit)
-		if (iv.dense == 2 && tent) RB3_LAUNCH_FAST(true, true);
-		else if (iv.dense == 2) RB3_LAUNCH_FAST(true, false);
-		else if (tent) RB3_LAUNCH_FAST(false, true);
-		else RB3_LAUNCH_FAST(false, false);
+#define RB3_LAUNCH_FAST(D, T, X) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, 0, \
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw)
+		switch ((iv.dense == 2 ? 4 : 0) | (tent ? 2 : 0) | (d_tw ? 1 : 0)) {
+		case 7: RB3_LAUNCH_FAST(true, true, true); break;
+		case 6: RB3_LAUNCH_FAST(true, true, false); break;
+		case 5: RB3_LAUNCH_FAST(true, false, true); break;
+		case 4: RB3_LAUNCH_FAST(true, false, false); break;
+		case 3: RB3_LAUNCH_FAST(false, true, true); break;
+		case 2: RB3_LAUNCH_FAST(false, true, false); break;
+		case 1: RB3_LAUNCH_FAST(false, false, true); break;
+		default: RB3_LAUNCH_FAST(false, false, false); break;
+		}
 #undef RB3_LAUNCH_FAST
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
@@ -727,6 +777,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (tent && hm[4] != 0) { // some tentative record was left unsettled: nothing was installed, redo without them
 		h->stt.n_fallbacks += 1;
 		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled; redoing the merge without tentative records\n", hm[4]);
+		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, 0);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, 0);
 	}
 	if (hm[2] != 0 || hm[3] != 0) {
@@ -852,6 +903,21 @@ int rb3gpu_merge_plain_dev_walkers(rb3gpu_t *h, int64_t len, const uint8_t *d_bw
 	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_walkers, walkers);
 }
 
+int rb3gpu_merge_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit)
+{
+	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0 || !walkers) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_walkers, walkers, d_tw);
+}
+
+int rb3gpu_mg_rank_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1])
+{
+	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0 || !walkers || !pos) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->n <= 0) return RB3GPU_ESTATE;
+	return merge_core(h, len, d_bwt, 0, pos, acc2, 1, n_walkers, walkers, d_tw);
+}
+
 int rb3gpu_mg_rank_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1])
 {
 	if (!h || len <= 0 || !bwt || !pos) return RB3GPU_EINVAL;
@@ -945,7 +1011,7 @@ int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out)
 	return 0;
 }
 
-int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow)
+static int sort_text_impl(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow, uint64_t *d_tw)
 {
 	if (!h || !text || !d_bwt || len <= 0 || len >= (1LL << 31) || step < 0) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
@@ -959,7 +1025,7 @@ int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t 
 		if ((r = buf_ensure(h, h->xbuf, (size_t)nck * 8)) < 0) return r;
 		d_ck = (int64_t*)h->xbuf.p;
 	}
-	r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds);
+	r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds, d_tw);
 	if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -3 ? RB3GPU_ESYMBOL : RB3GPU_ENODEV;
 	if (nck > 0) HIPCHK(hipMemcpy(ckrow, d_ck, (size_t)nck * 8, hipMemcpyDeviceToHost));
 	h->stt.ms_sort += (now_s() - t0) * 1e3, h->stt.n_sort_rounds += rounds;
@@ -967,6 +1033,17 @@ int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t 
 	if (h->opt.verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f] suffix-sorted %lld symbols on the GPU in %.3f ms (%d doubling rounds)\n", __func__, now_s() - h->t0, (long long)len, (now_s() - t0) * 1e3, rounds);
 	return 0;
+}
+
+int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow)
+{
+	return sort_text_impl(h, len, text, d_bwt, step, ckrow, nullptr);
+}
+
+int rb3gpu_sort_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, uint64_t *d_tw)
+{
+	if (!d_tw) return RB3GPU_EINVAL;
+	return sort_text_impl(h, len, text, d_bwt, 0, nullptr, d_tw);
 }
 
 /* ---- a sorter of its own: stream, scratch, two output buffers handed out in turn ---- */
@@ -1025,7 +1102,7 @@ void rb3gpu_sorter_destroy(rb3gpu_sorter_t *s)
 	delete s;
 }
 
-int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow)
+static int sorter_impl(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow, void **d_tw)
 {
 	if (!s || !text || !d_bwt || len <= 0 || len >= (1LL << 31) || step < 0) return RB3GPU_EINVAL;
 	SCHK(hipSetDevice(s->dev));
@@ -1037,7 +1114,9 @@ int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void
 	s->busy[slot] = 1;
 	pthread_mutex_unlock(&s->mtx);
 	const int64_t nck = step > 0 && ckrow ? (len + step - 1) / step : 0;
-	if ((r = sorter_grow(&s->text, &s->text_cap, (size_t)len + 16)) < 0 || (r = sorter_grow(&s->out[slot], &s->out_cap[slot], (size_t)len + 16)) < 0 ||
+	const size_t tw_off = ((size_t)len + 16 + 255) & ~(size_t)255; // the text-order words sit behind the BWT in the same buffer
+	if (d_tw) *d_tw = nullptr;
+	if ((r = sorter_grow(&s->text, &s->text_cap, (size_t)len + 16)) < 0 || (r = sorter_grow(&s->out[slot], &s->out_cap[slot], d_tw ? tw_off + (size_t)len * 8 : (size_t)len + 16)) < 0 ||
 		(nck > 0 && (r = sorter_grow(&s->ck, &s->ck_cap, (size_t)nck * 8)) < 0)) {
 		pthread_mutex_lock(&s->mtx);
 		s->busy[slot] = 0;
@@ -1056,7 +1135,8 @@ int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void
 		SCHK(hipMemcpyAsync(s->text, text, (size_t)len, hipMemcpyHostToDevice, s->st));
 		SCHK(hipStreamSynchronize(s->st));
 	}
-	r = rb3sort_bwt(s->ws, s->st, len, (const uint8_t*)s->text, (uint8_t*)s->out[slot], step, nck > 0 ? (int64_t*)s->ck : nullptr, &rounds);
+	r = rb3sort_bwt(s->ws, s->st, len, (const uint8_t*)s->text, (uint8_t*)s->out[slot], step, nck > 0 ? (int64_t*)s->ck : nullptr, &rounds,
+			d_tw ? (uint64_t*)((uint8_t*)s->out[slot] + tw_off) : nullptr);
 	if (r == 0 && nck > 0 && (hipMemcpyAsync(ckrow, s->ck, (size_t)nck * 8, hipMemcpyDeviceToHost, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess)) r = -2;
 	if (r < 0) {
 		pthread_mutex_lock(&s->mtx);
@@ -1066,7 +1146,19 @@ int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void
 		return r == -1 ? RB3GPU_ENOMEM : r == -3 ? RB3GPU_ESYMBOL : RB3GPU_ENODEV;
 	}
 	*d_bwt = s->out[slot];
+	if (d_tw) *d_tw = (uint8_t*)s->out[slot] + tw_off;
 	return 0;
+}
+
+int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow)
+{
+	return sorter_impl(s, len, text, d_bwt, step, ckrow, nullptr);
+}
+
+int rb3gpu_sorter_sort(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, void **d_tw)
+{
+	if (!d_tw) return RB3GPU_EINVAL;
+	return sorter_impl(s, len, text, d_bwt, 0, nullptr, d_tw);
 }
 
 int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt)

@@ -641,11 +641,20 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 	}
 }
 
-template<bool LIST, bool DENSE, bool TENT>
+/* TEXT = true (with LIST): the batch comes as TEXT-ORDER words tw[t] = row of the suffix at text position t << 3 |
+ * the symbol before it (0 at the start of a string) -- the inverse suffix array, which a suffix sorter has at
+ * hand -- and Walker.row is the text position a walker starts at.  A walker then streams its words (8 bytes
+ * per step out of lines it shares with its next steps) instead of fetching a row word from a random row, and
+ * row[] only holds records (all "unvisited" to begin with).  Inside its own segment a walker cannot meet a
+ * record (others enter a segment through its start row, which is checked when the walker starts), so the
+ * record of the next row is only looked up once the walker has left its segment. */
+#define RB3_BEYOND (INT64_MAX / 4 * 3) /* remaining > this: the walker has left its own segment */
+template<bool LIST, bool DENSE, bool TENT, bool TEXT>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit)
+		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw)
 {
+	static_assert(LIST || !TEXT, "text-order words need a walker list");
 	// ids a walker may take from each half of the stretch table (the whole half unless a test narrows it)
 	const uint32_t lim_blocks = sid_limit < (uint32_t)RB3_TENT_HALF ? sid_limit : (uint32_t)RB3_TENT_HALF;
 	const uint32_t lim_singles = sid_limit < (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF) ? sid_limit : (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF);
@@ -661,6 +670,9 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	int sid = -1;           // stretch id of the tentative records being written, -1: none yet, -2: none to be had
 	int64_t kb = 0, lo = 0, hi = 0, remaining = 0;
 	uint64_t x = 0;         // row word of the current row (requested one step ahead)
+	int64_t tp = 0;         // TEXT: text position of the current row
+	uint64_t x1 = 0;        // TEXT: word of the next row (requested two steps ahead)
+	uint64_t rc = ~0ull;    // TEXT: record word of the current row (unvisited unless looked up)
 	uint32_t steps = 0;
 	// Records are written through to memory (agent scope) so that walkers on other XCDs can see them.
 	// Each octet parks up to 8 records in its lanes (lane it&7 takes iteration it) and the whole wave
@@ -687,6 +699,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			if (LIST) {
 				const Walker w = wl[wid];
 				kb = w.row, remaining = w.nsteps;
+				if (TEXT) tp = w.row;
 				if (w.ka0 >= 0) lo = hi = w.ka0;
 				else if (w.ka0 == -2) lo = hi = b1.m; // RB3GPU_KA_SENTINEL: a sentinel row, ka = acc[1] of the index (fm-index.c:164)
 				else lo = 0, hi = b1.n;
@@ -697,8 +710,15 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			}
 			gap = hi - lo > 1 ? 2 : (int)(hi - lo);
 			age = 0, sid = -1;
-			x = (uint64_t)ld_pos(&row[kb]);
-			if (gap && (int64_t)x >= 0) continue; // an inexact walker whose start row somebody has already recorded
+			if (TEXT) {
+				x = tw[tp], x1 = tw[tp > 0 ? tp - 1 : 0];
+				kb = (int64_t)(x >> 3);
+				rc = (uint64_t)ld_pos(&row[kb]);
+				if (gap && (int64_t)rc >= 0) continue;
+			} else {
+				x = (uint64_t)ld_pos(&row[kb]);
+				if (gap && (int64_t)x >= 0) continue; // an inexact walker whose start row somebody has already recorded
+			}
 			active = true;
 		}
 		// ---- steps: run until some octet of this wave needs a refill.  Two independent dependency
@@ -709,16 +729,21 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 		// instruction-issue speed, so instruction count is the cost.
 		do {
 			if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
-			const bool met = (int64_t)x >= 0;  // this row already carries a record
+			const bool met = TEXT ? (int64_t)rc >= 0 : (int64_t)x >= 0;  // this row already carries a record
 			const int c = (int)(x & 7u);
-			const int64_t kbn = met ? kb : RB3_ROW_NEXT(x);
+			const int64_t kbn = TEXT ? (int64_t)(x1 >> 3) : met ? kb : RB3_ROW_NEXT(x);
+			const int64_t tpn = tp > 0 ? tp - 1 : 0;
 			const bool wide = TENT ? gap == 2 : gap != 0;
 			// may this walker record tentatively?  (an interval of at most KMAX rows, and old enough)
 			const bool tentok = TENT && gap != 0 && age >= RB3_TENT_MIN_AGE && hi - lo <= RB3_TENT_KMAX && sid != -2;
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
 			if (wide) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
-			const uint64_t xn = (uint64_t)ld_pos(&row[kbn]);
+			uint64_t xn, rcn = ~0ull;
+			if (TEXT) {
+				xn = tw[tpn > 0 ? tpn - 1 : 0]; // the word after next
+				if (remaining == 1 || remaining > RB3_BEYOND) rcn = (uint64_t)ld_pos(&row[kbn]);
+			} else xn = (uint64_t)ld_pos(&row[kbn]);
 			bool end_next;
 			if (LIST) end_next = remaining == 1;
 			else end_next = M && kbn >= m2 && (kbn & (M - 1)) == 0;
@@ -736,7 +761,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				else sid = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : -2;
 			}
 			if (TENT && met) { // settle an unknown (rare)
-				const int64_t seen = (int64_t)x;
+				const int64_t seen = TEXT ? (int64_t)rc : (int64_t)x;
 				if (!(seen & RB3_TENT)) { // a final value: the unknown of my current stretch
 					if (gap != 0 && sid >= 0 && sid != RB3_TENT_POISON && j == 0) tab[sid].del = 1 + (int)(seen - myval);
 				} else {
@@ -780,11 +805,13 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			++age;
 			// at the end of its own segment a walker goes on only if it is exact or has tentative records out
 			const bool goes_on = gap_n == 0 || (TENT && sid >= 0);
-			const bool at_stop = LIST && kbn == stop_row; // the rest of this string is recorded on another GPU
+			const bool at_stop = LIST && !TEXT && kbn == stop_row; // the rest of this string is recorded on another GPU
 			if (at_stop && gap_n == 0 && !fin && j == 0) st_pos(arrive, lo_n);
 			active = !(fin || at_stop || (end_next && !goes_on));
 			remaining = end_next ? INT64_MAX : remaining - 1;
-			kb = kbn, x = xn, lo = lo_n, hi = hi_n, gap = gap_n;
+			if (TEXT) tp = tpn, x = x1, x1 = xn, rc = rcn;
+			else x = xn;
+			kb = kbn, lo = lo_n, hi = hi_n, gap = gap_n;
 		} while (__all(active));
 	}
 	if (j == 0) atomicAdd(nsteps, (unsigned long long)steps);

@@ -152,6 +152,13 @@ __global__ void __launch_bounds__(256) k_s_ckrow(const uint32_t *rank, int64_t n
 	if (i < nck) ckrow[i] = rank[i * step];
 }
 
+/* text-order words for the merge's walkers (k_chain, TEXT): row of the suffix at p << 3 | the symbol before it */
+__global__ void __launch_bounds__(256) k_s_tw(const uint32_t *rank, const uint8_t *text, int64_t n, uint64_t *tw)
+{
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p < n) tw[p] = (uint64_t)rank[p] << 3 | (p ? text[p - 1] : 0);
+}
+
 /* ---- driver ---- */
 
 #define S_HIP(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return -2; } } while (0)
@@ -159,9 +166,10 @@ __global__ void __launch_bounds__(256) k_s_ckrow(const uint32_t *rank, int64_t n
 
 enum { W_KEYA, W_KEYB, W_VALA, W_VALB, W_RANK, W_SID, W_SA, W_SENT, W_T0, W_T1, W_FLAG, W_TMP };
 
-/* d_text: n symbols (0..5, last one 0) in device memory; d_bwt: n bytes out; d_ckrow: ceil(n/step) rows out or NULL.
+/* d_text: n symbols (0..5, last one 0) in device memory; d_bwt: n bytes out; d_ckrow: ceil(n/step) rows out or NULL;
+ * d_tw: n text-order words out or NULL.
  * Returns 0, -1 (out of memory), -2 (HIP error), -3 (bad text), and the number of doubling rounds in *rounds. */
-int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds)
+int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds, uint64_t *d_tw)
 {
 	if (!ws || n <= 0 || n >= (1LL << 31)) return -3;
 	if (ws_ensure(ws, W_KEYA, (size_t)n * 8) || ws_ensure(ws, W_KEYB, (size_t)n * 8) || ws_ensure(ws, W_VALA, (size_t)n * 4) || ws_ensure(ws, W_VALB, (size_t)n * 4) ||
@@ -229,6 +237,7 @@ int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text
 		const int64_t nck = (n + step - 1) / step;
 		hipLaunchKernelGGL(k_s_ckrow, S_GRID(nck), (const uint32_t*)rank, n, step, nck, d_ckrow);
 	}
+	if (d_tw) hipLaunchKernelGGL(k_s_tw, S_GRID(n), (const uint32_t*)rank, d_text, n, d_tw);
 	S_HIP(hipStreamSynchronize(st));
 	if (rounds) *rounds = nr;
 	return 0;

@@ -74,6 +74,10 @@ SYMBOLS = {
     "rb3gpu_ssa_dims": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]),
     "rb3gpu_ssa_gen": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_bwt_from_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_sort_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_merge_text_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]),
+    "rb3gpu_mg_rank_text_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_sorter_sort": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     "rb3gpu_sorter_create": (ctypes.c_void_p, [ctypes.c_int]),
     "rb3gpu_sorter_destroy": (None, [ctypes.c_void_p]),
     "rb3gpu_sorter_bwt": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_void_p]),
@@ -237,6 +241,28 @@ class Rb3Gpu:
         ck = np.empty((text.size + step - 1) // step, dtype=np.int64) if step > 0 else None
         self._chk(self._lib.rb3gpu_bwt_from_text(self._h, text.size, text.ctypes.data, p, step, ck.ctypes.data if ck is not None else None), "rb3gpu_bwt_from_text")
         return p, ck
+
+    def sort_text(self, text):
+        """suffix-sort a batch text on the GPU: returns device pointers (BWT, text-order words) for merge_text_dev;
+        free both with dev_free"""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        p, q = ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_dev_alloc(self._h, text.size + 16, ctypes.byref(p)), "rb3gpu_dev_alloc")
+        self._chk(self._lib.rb3gpu_dev_alloc(self._h, text.size * 8, ctypes.byref(q)), "rb3gpu_dev_alloc")
+        self._chk(self._lib.rb3gpu_sort_text(self._h, text.size, text.ctypes.data, p, q), "rb3gpu_sort_text")
+        return p, q
+
+    def merge_text_dev(self, d_bwt, d_tw, length, walkers, commit=True):
+        """merge a batch given by its BWT and text-order words (walkers by text position: host.walkers_text)"""
+        w = self._walkers(walkers)
+        self._chk(self._lib.rb3gpu_merge_text_dev(self._h, length, d_bwt, d_tw, w.shape[0], w.ctypes.data, 1 if commit else 0), "rb3gpu_merge_text_dev")
+
+    def mg_rank_text_dev(self, d_bwt, d_tw, length, walkers):
+        w = self._walkers(walkers)
+        pos = np.empty(length, dtype=np.int64)
+        acc2 = np.zeros(7, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_mg_rank_text_dev(self._h, length, d_bwt, d_tw, w.shape[0], w.ctypes.data, pos.ctypes.data, acc2.ctypes.data), "rb3gpu_mg_rank_text_dev")
+        return pos, acc2
 
     def dev_download(self, p, nbytes):
         out = np.empty(nbytes, dtype=np.uint8)

@@ -93,6 +93,24 @@ def walkers_from_ckrow(text, step, ckrow):
     return w
 
 
+def walkers_text(text, step):
+    """the walker list of a batch by TEXT POSITION (Rb3Gpu.merge_text_dev): one walker per string, at its sentinel,
+    and one per `step` text positions; `text` is the batch text (not its BWT)"""
+    L = load_library()
+    L.rb3h_walkers_text.restype = ctypes.c_int
+    L.rb3h_walkers_text.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_void_p)]
+    t = np.ascontiguousarray(text, dtype=np.uint8)
+    nw, pw = ctypes.c_int64(0), ctypes.c_void_p()
+    r = L.rb3h_walkers_text(t.size, t.ctypes.data, step, ctypes.byref(nw), ctypes.byref(pw))
+    if r < 0:
+        raise ValueError("rb3h_walkers_text failed with code %d" % r)
+    w = np.ctypeslib.as_array(ctypes.cast(pw, ctypes.POINTER(ctypes.c_int64)), shape=(nw.value, 4)).copy()
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    libc.free(pw)
+    return w
+
+
 def read_batches(path, is_line, max_len, fwd=True, rev=True):
     """Iterate the batches `build` would cut from one file (rb3_seq_read, io.c:104-125):
     yields (n_strings, text) with text a uint8 array."""

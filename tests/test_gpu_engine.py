@@ -530,3 +530,80 @@ def test_hundreds_of_relatives(oracle):
         finally:
             os.environ.pop("RB3GPU_TENT", None)
     assert steps["1"] <= steps["0"], steps
+
+
+@pytest.mark.parametrize("seed,kind", [(91, "genome"), (92, "two_strands"), (93, "family"), (94, "copies"), (95, "short")])
+def test_merge_text_order_words_vs_oracle(oracle, seed, kind):
+    """rb3gpu_merge_text_dev: the batch comes as BWT + text-order words (inverse suffix array) from the GPU sorter and
+    the walkers are given by text position; rank phase and merged index bit-exact against the oracle, and the same
+    pos[] as the row-word walkers"""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(seed)
+    g0 = util.random_genome(rng, 60000)
+    both = kind != "genome"
+    if kind == "family":
+        rel = [g0] + [util.mutate(rng, g0, 0.002) for _ in range(11)]
+        new = [util.mutate(rng, rel[4], 0.001), rel[7].copy()]
+    elif kind == "copies":
+        rel = [g0, g0.copy(), util.mutate(rng, g0, 0.01)]
+        new = [g0.copy(), g0[:5000].copy(), g0[20000:].copy()]
+    elif kind == "short":
+        rel = [g0]
+        new = [g0[i * 700:i * 700 + 650].copy() for i in range(40)] + [np.array([2], dtype=np.uint8), util.random_genome(rng, 3000)]
+    else:
+        rel = [g0]
+        new = [util.mutate(rng, g0, 0.001)]
+    b1 = host.build_bwt(util.make_text(rel, True, both))
+    t2 = util.make_text(new, True, both)
+    b2 = host.build_bwt(t2.copy())
+    rb, _ = oracle.mg_rank(b1, b2, 8)
+    want_pos, want = rb >> 6, oracle.merge(b1, b2)
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_plain(b1)
+        d_bwt, d_tw = h.sort_text(t2)
+        assert np.array_equal(h.dev_download(d_bwt, t2.size), b2)
+        tw = h.dev_download(d_tw, t2.size * 8).view(np.uint64)
+        isa = (tw >> np.uint64(3)).astype(np.int64)
+        assert np.array_equal(np.sort(isa), np.arange(t2.size))                     # a permutation: the inverse suffix array
+        prev = np.concatenate([[0], t2[:-1]]).astype(np.uint64)
+        assert np.array_equal(tw & np.uint64(7), prev) and np.array_equal(b2[isa], prev.astype(np.uint8))
+        for step in (100, 384):
+            wt = host.walkers_text(t2, step)
+            got, acc2 = h.mg_rank_text_dev(d_bwt, d_tw, t2.size, wt)
+            assert np.array_equal(got, want_pos), (kind, step)
+            assert acc2[6] == t2.size
+        assert h.stats()["n_fallbacks"] == 0
+        h.merge_text_dev(d_bwt, d_tw, t2.size, wt, commit=True)
+        assert np.array_equal(h.export_plain(), want)
+        h.dev_free(d_bwt); h.dev_free(d_tw)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("env", [{"RB3GPU_TEST_FORCE_FALLBACK": "1"}, {"RB3GPU_TEST_TENT_LIMIT": "40"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_TENT": "0"}])
+def test_merge_text_order_fallback_paths(oracle, env):
+    """the redo path, a stretch table that runs out, the staged path and the walk without tentative records, all
+    entered from rb3gpu_merge_text_dev (the walkers are converted to rows on the device where row words are walked)"""
+    import os
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(97)
+    g0 = util.random_genome(rng, 50000)
+    rel = [g0] + [util.mutate(rng, g0, 0.003) for _ in range(7)]
+    b1 = host.build_bwt(util.make_text(rel))
+    t2 = util.make_text([util.mutate(rng, g0, 0.002), rel[3].copy()])
+    want = oracle.merge(b1, host.build_bwt(t2.copy()))
+    os.environ.update(env)
+    try:
+        h = Rb3Gpu(verbose=1)
+        h.from_plain(b1)
+        d_bwt, d_tw = h.sort_text(t2)
+        h.merge_text_dev(d_bwt, d_tw, t2.size, host.walkers_text(t2, 200), commit=True)
+        st = h.stats()
+        assert np.array_equal(h.export_plain(), want)
+        if "RB3GPU_TEST_FORCE_FALLBACK" in env:
+            assert st["n_fallbacks"] == 1
+        h.close()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)

@@ -41,6 +41,14 @@ for case in range(ncase):
             b = host.build_bwt(t)
             if cur is None: h.from_plain(b)
             else: h.merge_plain(b)
+        elif case % 4 == 2 and case % 8 != 6:   # suffix-sorted on the GPU, merged through its text-order words (the CLI's default path)
+            d, dtw = h.sort_text(t)
+            b = h.dev_download(d, t.size)
+            if not np.array_equal(b, host.build_bwt(t.copy())):
+                print("case %d: GPU suffix sorter MISMATCH" % case); sys.exit(1)
+            if cur is None: h._chk(h._lib.rb3gpu_from_plain_dev(h._h, t.size, d), "from_plain_dev")
+            else: h.merge_text_dev(d, dtw, t.size, host.walkers_text(t, step), commit=True)
+            h.dev_free(d); h.dev_free(dtw)
         elif case % 4 == 2:   # the batch is suffix-sorted on the GPU as well; the BWT never leaves the device
             d, ck = h.bwt_from_text(t, step)
             b = h.dev_download(d, t.size)

@@ -95,20 +95,22 @@ def reads_regime(h_factory, n_reads, seed=11):
         r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
         return list(r)
     b1 = host.build_bwt(util.make_text(reads(st[:n_reads])))
-    b2 = host.build_bwt(util.make_text(reads(st[n_reads:])))
+    t2 = util.make_text(reads(st[n_reads:]))
     h = h_factory()
     h.from_plain(b1)
-    d = h.dev_upload(b2)
-    h.merge_plain_dev(d, b2.size, commit=False)
+    d, d_tw = h.sort_text(t2)   # BWT + text-order words; one walker per string, made on the device
+    b2 = t2
+    h.merge_text_dev(d, d_tw, b2.size, 2 * n_reads, commit=False)
     h.stats_reset()
     reps = 5
     t = time.perf_counter()
     for _ in range(reps):
-        h.merge_plain_dev(d, b2.size, commit=False)
+        h.merge_text_dev(d, d_tw, b2.size, 2 * n_reads, commit=False)
     dt = (time.perf_counter() - t) / reps
     st_ = h.stats()
     ms_chain = st_["ms_chain"] / reps
     h.dev_free(d)
+    h.dev_free(d_tw)
     h.close()
     ach = ALGO_BYTES_PER_STEP * b2.size / (ms_chain * 1e-3) / 1e9
     return {"workload": "reads regime: merge %d x 150 bp reads (both strands, %d symbols, %d strings) into an index of %d symbols" % (n_reads, b2.size, 2 * n_reads, b1.size),

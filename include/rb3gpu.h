@@ -103,6 +103,7 @@ typedef struct {
 /* rb3gpu_merge_plain with an explicit walker list (host memory); same result, more parallelism
  * and no dependence on how the suffix array scatters the strings */
 int rb3gpu_merge_plain_walkers(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers);
+/* (device BWT) walkers == NULL: one walker per string, made on the device; n_walkers = the number of strings of the batch */
 int rb3gpu_merge_plain_dev_walkers(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit);
 
 /* The same merge in three stages, for a multi-GPU build with the index replicated and the batch's
@@ -180,7 +181,8 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa);
  * the symbol before it (0 at the start of a string), i.e. the inverse suffix array of the batch next to its BWT
  * (rb3gpu_sort_text / rb3gpu_sorter_sort produce both; a host sorter has the suffix array and inverts it).
  * walkers[i].row is then the TEXT POSITION a walker starts at (a sentinel's walker: the position of the sentinel),
- * everything else as in rb3gpu_merge_plain_dev_walkers.  Same result as rb3_fmi_merge_plain (fm-index.c:279-303);
+ * everything else as in rb3gpu_merge_plain_dev_walkers.  walkers == NULL: one walker per string, made on the device
+ * (n_walkers = the number of strings of the batch; short strings, i.e. reads).  Same result as rb3_fmi_merge_plain (fm-index.c:279-303);
  * the LF walkers read their batch-side state as a stream instead of one random row word per step.
  * d_bwt: len bytes, d_tw: len 64-bit words, both device memory.  rb3gpu_mg_rank_text_dev: the rank phase alone
  * (pos[] as in rb3gpu_mg_rank_plain), for parity tests. */

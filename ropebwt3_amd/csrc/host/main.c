@@ -158,7 +158,7 @@ typedef struct {
 static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 {
 	void *d_bwt = 0, *d_tw = 0;
-	const int text_walk = b->step > 0 && *has_index; /* long strings: text-order words + walkers by text position */
+	const int text_walk = *has_index; /* text-order words; long strings: walkers by text position, short ones: one walker per string */
 	int ret;
 	if ((ret = rb3gpu_dev_alloc(h, b->len + 16, &d_bwt)) < 0) return ret;
 	if (text_walk && rb3gpu_dev_alloc(h, b->len * 8, &d_tw) < 0) { rb3gpu_dev_free(h, d_bwt); return 1; }
@@ -173,8 +173,9 @@ static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 		fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 	if (ret == 0 && !*has_index) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)d_bwt);
 	else if (ret == 0 && text_walk) {
-		if (rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) ret = RB3GPU_ENOMEM;
-		else ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+		if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) ret = RB3GPU_ENOMEM;
+		else if (b->step > 0) ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+		else ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, b->n_seq, 0, 1); /* short strings: one walker per string */
 	} else if (ret == 0) ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)d_bwt, 1);
 	if (d_tw) rb3gpu_dev_free(h, d_tw);
 	rb3gpu_dev_free(h, d_bwt);
@@ -188,6 +189,7 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 		const int first = !*has_index;
 		if (first) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)b->d_bwt);
 		else if (b->walkers && b->d_tw) ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+		else if (b->d_tw && b->step == 0 && b->n_seq > 0) ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, b->n_seq, 0, 1); /* short strings: one walker per string */
 		else ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)b->d_bwt, 1);
 		rb3gpu_sorter_release(b->gs, b->d_bwt);
 		b->d_bwt = b->d_tw = 0;
@@ -263,11 +265,11 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 		if (gs) { /* this thread has a GPU sorter of its own: sort now, while the consumer merges the batch before */
 			/* long strings: also the text-order words, and LF walkers by text position (same result, text-regular parallelism);
 			 * short strings (reads): one walker per string is what the engine does by itself */
-			const int r2 = b->step > 0 ? rb3gpu_sorter_sort(gs, b->len, b->bwt, &b->d_bwt, &b->d_tw) : rb3gpu_sorter_bwt(gs, b->len, b->bwt, &b->d_bwt, 0, 0);
+			const int r2 = rb3gpu_sorter_sort(gs, b->len, b->bwt, &b->d_bwt, &b->d_tw);
 			if (r2 == 0) {
 				if (rb3h_verbose >= 3)
 					fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
-				if (b->d_tw && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0;
+				if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0, b->d_tw = 0;
 				b->gs = gs, b->raw = 0;
 				free(b->bwt); b->bwt = 0; /* the text is not needed any more */
 			} else b->d_bwt = b->d_tw = 0; /* leave it to the consumer (its handle's sorter, then the host sorter) */

@@ -505,7 +505,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 		const IdxView iv = view_of(h);
 		const int64_t sr = stop_row < 0 ? -1 : stop_row;
 		const dim3 grid((unsigned)nblk), blk(256);
-#define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T, false>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
+#define RB3_LAUNCH_CHAIN(L, D, T) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<L, D, T, 0>), grid, blk, 0, h->st, iv, h->mg_pos, len, m2, \
 			walkers ? 0 : logM, (const Walker*)dwl, nwalk, walkers ? sr : (int64_t)-1, darr, qhead, nsteps, octs, tab, sidctr, sid_limit, (const uint64_t*)nullptr)
 		const int sel = (walkers ? 4 : 0) | (iv.dense == 2 ? 2 : 0) | (tent ? 1 : 0);
 		switch (sel) {
@@ -628,6 +628,22 @@ __global__ void __launch_bounds__(256) k_walker_rows(Walker *wl, int64_t n, cons
 	if (i < n) wl[i].row = (int64_t)(tw[wl[i].row] >> 3);
 }
 
+/* one walker per string, made on the device: the suffixes with rows 0..m2-1 are the sentinels */
+__global__ void __launch_bounds__(256) k_walkers_per_string(Walker *wl, int64_t m2, const uint64_t *tw, int64_t n)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	const int64_t r = (int64_t)(tw[t] >> 3);
+	const bool sentinel = t + 1 == n || (tw[t + 1] & 7u) == 0; // the word after it says which symbol sits at t
+	if (r < m2 && sentinel) { Walker w; w.row = t, w.ka0 = -2, w.nsteps = INT64_MAX / 2, w.flags = 0; wl[r] = w; }
+}
+
+__global__ void __launch_bounds__(256) k_walkers_sentinel_rows(Walker *wl, int64_t m2)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r < m2) { Walker w; w.row = r, w.ka0 = -2, w.nsteps = INT64_MAX / 2, w.flags = 0; wl[r] = w; }
+}
+
 static int walkers_text_to_rows(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw, rb3gpu_walker_t **out)
 {
 	int r;
@@ -668,10 +684,15 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int tent = 1;
 	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
 	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
-	if (d_tw && !walkers) return RB3GPU_EINVAL;
+	// no list but a count: one walker per string (n_walkers = number of strings), made on the device
+	const bool per_string = !walkers && n_walkers > 0;
+	if (d_tw && !walkers && !per_string) return RB3GPU_EINVAL;
+	const int tent_auto = tent;
+	if (per_string) tent = 0; // every walker is exact
 	for (int64_t i = 0; walkers && i < n_walkers; ++i)
 		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) return RB3GPU_EINVAL;
-	if (!walkers || n_walkers > (1 << 24) || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED")) {
+	if ((!walkers && !per_string) || n_walkers > (1 << 24) || n_walkers > len || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED")) {
+		if (per_string) return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, tent_auto);
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, tent);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
 	}
@@ -697,7 +718,12 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
 	if (rows_fused) HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
-	{ // walker list: through the pinned staging buffer when it fits (a pageable source is staged by the runtime, slowly)
+	if (per_string && d_tw) {
+		HIPCHK(hipMemsetAsync(h->wl.p, 0xff, (size_t)n_walkers * 32, h->st)); // a walker that nobody fills in starts at row -1: caught below
+		hipLaunchKernelGGL(k_walkers_per_string, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw, len);
+	} else if (per_string) { // row words: the sentinels are rows 0 .. n_walkers-1 (the count is checked against the batch below)
+		hipLaunchKernelGGL(k_walkers_sentinel_rows, dim3((unsigned)((n_walkers + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers);
+	} else { // walker list: through the pinned staging buffer when it fits (a pageable source is staged by the runtime, slowly)
 		const size_t wb = (size_t)n_walkers * 32;
 		if (h->stage[0] == nullptr)
 			for (int i = 0; i < 2; ++i)
@@ -714,23 +740,30 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		if (getenv("RB3GPU_OCTS")) octs = atoi(getenv("RB3GPU_OCTS"));
 		int64_t nblk = (n_walkers + 4 * octs - 1) / (4 * octs);
 		if (getenv("RB3GPU_BLKMUL")) nblk *= atoi(getenv("RB3GPU_BLKMUL"));
-		nblk = nblk > 4096 ? 4096 : nblk < 1 ? 1 : nblk;
+		// persistent waves: 2048 blocks x 4 waves fill the chip once (256 CUs x 32); more blocks only queue behind them (measured: 10 % slower at 4096)
+		{ const int64_t cap = getenv("RB3GPU_BLKCAP") ? atoll(getenv("RB3GPU_BLKCAP")) : 2048; nblk = nblk > cap ? cap : nblk < 1 ? 1 : nblk; }
 #ifdef RB3_PROF
 		fprintf(stderr, "[prof] launching %lld blocks x 256 threads, %d octets per wave, %lld walkers\n", (long long)nblk, octs, (long long)n_walkers);
 #endif
 		const dim3 grid((unsigned)nblk), blk(256);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
-#define RB3_LAUNCH_FAST(D, T, X) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, 0, \
+#define RB3_LAUNCH_FAST(D, T, X) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw)
-		switch ((iv.dense == 2 ? 4 : 0) | (tent ? 2 : 0) | (d_tw ? 1 : 0)) {
-		case 7: RB3_LAUNCH_FAST(true, true, true); break;
-		case 6: RB3_LAUNCH_FAST(true, true, false); break;
-		case 5: RB3_LAUNCH_FAST(true, false, true); break;
-		case 4: RB3_LAUNCH_FAST(true, false, false); break;
-		case 3: RB3_LAUNCH_FAST(false, true, true); break;
-		case 2: RB3_LAUNCH_FAST(false, true, false); break;
-		case 1: RB3_LAUNCH_FAST(false, false, true); break;
-		default: RB3_LAUNCH_FAST(false, false, false); break;
+		// text-order words: per-lane loads while the L1 can hold a line per walker (256 CUs x 32 waves x 8 octets), else 64-byte fetches
+		const int text_mode = !d_tw ? 0 : n_walkers <= 65536 ? 1 : 2;
+		switch ((iv.dense == 2 ? 12 : 0) + (tent ? 6 : 0) + text_mode) {
+		case 14: RB3_LAUNCH_FAST(true, false, 2); break;
+		case 13: RB3_LAUNCH_FAST(true, false, 1); break;
+		case 12: RB3_LAUNCH_FAST(true, false, 0); break;
+		case 20: RB3_LAUNCH_FAST(true, true, 2); break;
+		case 19: RB3_LAUNCH_FAST(true, true, 1); break;
+		case 18: RB3_LAUNCH_FAST(true, true, 0); break;
+		case 2: RB3_LAUNCH_FAST(false, false, 2); break;
+		case 1: RB3_LAUNCH_FAST(false, false, 1); break;
+		case 0: RB3_LAUNCH_FAST(false, false, 0); break;
+		case 8: RB3_LAUNCH_FAST(false, true, 2); break;
+		case 7: RB3_LAUNCH_FAST(false, true, 1); break;
+		default: RB3_LAUNCH_FAST(false, true, 0); break;
 		}
 #undef RB3_LAUNCH_FAST
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
@@ -769,6 +802,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	acc2[0] = 0;
 	for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)hm[MISC_LF_TOT + a];
 	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
+	if (per_string && acc2[1] != n_walkers) return RB3GPU_EINVAL; // not the number of strings of this batch (nothing was installed)
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
 	if (tent) {
 		tent_used(h, hm[5]);
@@ -898,21 +932,21 @@ int rb3gpu_merge_plain_walkers(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int
 
 int rb3gpu_merge_plain_dev_walkers(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit)
 {
-	if (!h || len <= 0 || !d_bwt || n_walkers <= 0 || !walkers) return RB3GPU_EINVAL;
+	if (!h || len <= 0 || !d_bwt || n_walkers <= 0) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_walkers, walkers);
 }
 
 int rb3gpu_merge_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit)
 {
-	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0 || !walkers) return RB3GPU_EINVAL;
+	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_walkers, walkers, d_tw);
 }
 
 int rb3gpu_mg_rank_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1])
 {
-	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0 || !walkers || !pos) return RB3GPU_EINVAL;
+	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0 || !pos) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->n <= 0) return RB3GPU_ESTATE;
 	return merge_core(h, len, d_bwt, 0, pos, acc2, 1, n_walkers, walkers, d_tw);

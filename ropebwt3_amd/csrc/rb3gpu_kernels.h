@@ -527,7 +527,7 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 #define RB3_TENT_POISON (RB3_TENT_IDS - 1) /* the id of records whose stretch could not be allocated: never settled */
 #define RB3_TENT_KMAX 255             /* widest interval that is tracked tentatively */
 #ifndef RB3_TENT_MIN_AGE
-#define RB3_TENT_MIN_AGE 64u
+#define RB3_TENT_MIN_AGE 32u
 #endif
 /* One 64-byte record per stretch, so that following a dependency path costs one memory round trip per
  * stretch (k_resolve).  w0, w1: how the unknown of the stretch follows from another one.
@@ -649,7 +649,11 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
  * record (others enter a segment through its start row, which is checked when the walker starts), so the
  * record of the next row is only looked up once the walker has left its segment. */
 #define RB3_BEYOND (INT64_MAX / 4 * 3) /* remaining > this: the walker has left its own segment */
-template<bool LIST, bool DENSE, bool TENT, bool TEXT>
+/* TEXT = 1: every lane of the octet loads the word it needs (one address per octet; with few walkers per compute
+ * unit the lines stay in the L1 for the 16 steps they serve).  TEXT = 2: the octet fetches the words of 8 steps with
+ * one 64-byte request and hands them out with cross-lane reads (many walkers per compute unit, i.e. one per short
+ * string: the L1 cannot hold a line per walker). */
+template<bool LIST, bool DENSE, bool TENT, int TEXT>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
 		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw)
@@ -664,7 +668,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	if ((lane >> 3) >= octs) return;
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
 	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
-	const bool vis = LIST || M != 0; // records must become visible to other walkers only if strings are split
+	// records must become visible to other walkers only if strings are split (logM < 0 with a list: one walker per string)
+	const bool vis = (LIST && logM >= 0) || M != 0;
 	bool active = false;
 	int gap = 0;            // 0: exact (lo == hi), 1: hi == lo + 1, 2: wider
 	int sid = -1;           // stretch id of the tentative records being written, -1: none yet, -2: none to be had
@@ -673,6 +678,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	int64_t tp = 0;         // TEXT: text position of the current row
 	uint64_t x1 = 0;        // TEXT: word of the next row (requested two steps ahead)
 	uint64_t rc = ~0ull;    // TEXT: record word of the current row (unvisited unless looked up)
+	uint64_t blk8 = 0;      // TEXT: the words this octet fetches during the current window of 8 iterations (lane j: at iteration phase j),
+	                        // loaded with one 64-byte request per octet and window, whatever the L1 does with the lines
 	uint32_t steps = 0;
 	// Records are written through to memory (agent scope) so that walkers on other XCDs can see them.
 	// Each octet parks up to 8 records in its lanes (lane it&7 takes iteration it) and the whole wave
@@ -699,7 +706,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			if (LIST) {
 				const Walker w = wl[wid];
 				kb = w.row, remaining = w.nsteps;
-				if (TEXT) tp = w.row;
+				if (TEXT) {
+					tp = w.row;
+					if (tp < 0 || tp >= n2) continue; // (a per-string list whose string count was wrong: the rows stay unset)
+				}
 				if (w.ka0 >= 0) lo = hi = w.ka0;
 				else if (w.ka0 == -2) lo = hi = b1.m; // RB3GPU_KA_SENTINEL: a sentinel row, ka = acc[1] of the index (fm-index.c:164)
 				else lo = 0, hi = b1.n;
@@ -712,6 +722,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			age = 0, sid = -1;
 			if (TEXT) {
 				x = tw[tp], x1 = tw[tp > 0 ? tp - 1 : 0];
+				if (TEXT == 2) { // the rest of the current window: this walker's first step runs at phase (it + 1) & 7
+					const int64_t a = tp - 2 - (int64_t)((j - (int)(it + 1)) & 7);
+					blk8 = tw[a > 0 ? a : 0];
+				}
 				kb = (int64_t)(x >> 3);
 				rc = (uint64_t)ld_pos(&row[kb]);
 				if (gap && (int64_t)rc >= 0) continue;
@@ -739,9 +753,13 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
 			if (wide) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
-			uint64_t xn, rcn = ~0ull;
+			uint64_t xn = 0, rcn = ~0ull;
 			if (TEXT) {
-				xn = tw[tpn > 0 ? tpn - 1 : 0]; // the word after next
+				if (TEXT == 1) xn = tw[tpn > 0 ? tpn - 1 : 0]; // the word after next
+				else if ((it & 7u) == 0) { // a new window: lane j fetches the word after next of phase j
+					const int64_t a = tp - 2 - j;
+					blk8 = tw[a > 0 ? a : 0];
+				}
 				if (remaining == 1 || remaining > RB3_BEYOND) rcn = (uint64_t)ld_pos(&row[kbn]);
 			} else xn = (uint64_t)ld_pos(&row[kbn]);
 			bool end_next;
@@ -778,6 +796,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			// next insertion point(s)
 			uint32_t match, mh;
 			const int64_t lo_n = octc_finish<DENSE>(rl, c, j, &match);
+			if (TEXT == 2) { // the word after next, from the lane that fetched it (after the slot has arrived: no wait of its own)
+				const int src = ((lane & ~7) | (int)(it & 7u)) << 2;
+				xn = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)blk8) | (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(blk8 >> 32)) << 32;
+			}
 			int64_t hi_n = lo_n;
 			if (TENT && gap == 1) hi_n = lo_n + match;
 			if (wide) hi_n = octc_finish<DENSE>(rh, c, j, &mh);

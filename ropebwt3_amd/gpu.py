@@ -169,6 +169,9 @@ class Rb3Gpu:
         self._chk(self._lib.rb3gpu_merge_plain_walkers(self._h, bwt.size, bwt.ctypes.data, w.shape[0], w.ctypes.data), "rb3gpu_merge_plain_walkers")
 
     def merge_plain_dev_walkers(self, d_bwt, length, walkers, commit=True):
+        if isinstance(walkers, (int, np.integer)):  # the number of strings: one walker per string, made on the device
+            self._chk(self._lib.rb3gpu_merge_plain_dev_walkers(self._h, length, d_bwt, int(walkers), None, 1 if commit else 0), "rb3gpu_merge_plain_dev_walkers")
+            return
         w = self._walkers(walkers)
         self._chk(self._lib.rb3gpu_merge_plain_dev_walkers(self._h, length, d_bwt, w.shape[0], w.ctypes.data, 1 if commit else 0), "rb3gpu_merge_plain_dev_walkers")
 
@@ -254,13 +257,19 @@ class Rb3Gpu:
 
     def merge_text_dev(self, d_bwt, d_tw, length, walkers, commit=True):
         """merge a batch given by its BWT and text-order words (walkers by text position: host.walkers_text)"""
+        if isinstance(walkers, (int, np.integer)):  # the number of strings: one walker per string, made on the device
+            self._chk(self._lib.rb3gpu_merge_text_dev(self._h, length, d_bwt, d_tw, int(walkers), None, 1 if commit else 0), "rb3gpu_merge_text_dev")
+            return
         w = self._walkers(walkers)
         self._chk(self._lib.rb3gpu_merge_text_dev(self._h, length, d_bwt, d_tw, w.shape[0], w.ctypes.data, 1 if commit else 0), "rb3gpu_merge_text_dev")
 
     def mg_rank_text_dev(self, d_bwt, d_tw, length, walkers):
-        w = self._walkers(walkers)
         pos = np.empty(length, dtype=np.int64)
         acc2 = np.zeros(7, dtype=np.int64)
+        if isinstance(walkers, (int, np.integer)):
+            self._chk(self._lib.rb3gpu_mg_rank_text_dev(self._h, length, d_bwt, d_tw, int(walkers), None, pos.ctypes.data, acc2.ctypes.data), "rb3gpu_mg_rank_text_dev")
+            return pos, acc2
+        w = self._walkers(walkers)
         self._chk(self._lib.rb3gpu_mg_rank_text_dev(self._h, length, d_bwt, d_tw, w.shape[0], w.ctypes.data, pos.ctypes.data, acc2.ctypes.data), "rb3gpu_mg_rank_text_dev")
         return pos, acc2
 

@@ -574,8 +574,28 @@ def test_merge_text_order_words_vs_oracle(oracle, seed, kind):
             assert np.array_equal(got, want_pos), (kind, step)
             assert acc2[6] == t2.size
         assert h.stats()["n_fallbacks"] == 0
-        h.merge_text_dev(d_bwt, d_tw, t2.size, wt, commit=True)
+        nstr = int((t2 == 0).sum())
+        got, _ = h.mg_rank_text_dev(d_bwt, d_tw, t2.size, nstr)                      # one walker per string, made on the device
+        assert np.array_equal(got, want_pos), (kind, "per string")
+        with pytest.raises(Exception):
+            h.mg_rank_text_dev(d_bwt, d_tw, t2.size, nstr + 1)                       # a wrong string count is noticed
+        if nstr > 1:
+            with pytest.raises(Exception):
+                h.mg_rank_text_dev(d_bwt, d_tw, t2.size, nstr - 1)
+        if kind == "short":
+            h.merge_text_dev(d_bwt, d_tw, t2.size, nstr, commit=True)
+        else:
+            h.merge_text_dev(d_bwt, d_tw, t2.size, wt, commit=True)
         assert np.array_equal(h.export_plain(), want)
+        h2 = Rb3Gpu(verbose=1)                                                       # row words, one walker per string made on the device
+        h2.from_plain(b1)
+        d2 = h2.dev_upload(b2)
+        with pytest.raises(Exception):
+            h2.merge_plain_dev_walkers(d2, b2.size, nstr + 3, commit=True)
+        h2.merge_plain_dev_walkers(d2, b2.size, nstr, commit=True)
+        assert np.array_equal(h2.export_plain(), want)
+        h2.dev_free(d2)
+        h2.close()
         h.dev_free(d_bwt); h.dev_free(d_tw)
     finally:
         h.close()

@@ -77,7 +77,7 @@ if __name__ == "__main__":
         w, nw = avg(sys.argv[3], "WRITE_SIZE")
         d = {"kernel": sys.argv[4], "dispatches": nf, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
              "hbm_bytes_per_launch": int((2 * f + w) * 1024),
-             "correction": "MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 (upper bound: the 8-B row loads are not halved); WRITE_SIZE as reported. k_lf2 in the same passes calibrates both: 8.8 MB streamed in -> FETCH_SIZE 4.5 MB, 70.4 MB streamed out -> WRITE_SIZE 70.4 MB."}
+             "correction": "MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 (upper bound: smaller loads are not halved); WRITE_SIZE as reported. Calibrated earlier this round with k_lf2 in the same kind of passes: 8.8 MB streamed in -> FETCH_SIZE 4.5 MB, 70.4 MB streamed out -> WRITE_SIZE 70.4 MB."}
         json.dump(d, open(sys.argv[5], "w"), indent=1)
         print(d)
     elif sys.argv[1] == "cols":

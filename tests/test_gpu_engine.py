@@ -627,3 +627,47 @@ def test_merge_text_order_fallback_paths(oracle, env):
     finally:
         for k in env:
             os.environ.pop(k, None)
+
+
+def test_config2_full_size_properties_and_oracle(oracle):
+    """BASELINE configs[1] at full size (the bench workload: a 4.4 Mbp genome, both strands, merged into the index of a
+    0.1 %-divergent one; 8,800,002 symbols each).  Size-independent properties of the interleave -- pos[] strictly
+    increasing, ka = pos - row non-decreasing and <= n1, the merged BWT restricted to pos[] is B2 and the rest is B1
+    in order, symbol counts add up -- for the text-order walk, and the same pos[] from the row-word walkers and the
+    reference-signature entry point; then the merged BWT byte for byte against the oracle."""
+    from ropebwt3_amd import Rb3Gpu, host
+    g0 = util.random_genome(np.random.default_rng(1), 4400000)
+    g1 = util.mutate(np.random.default_rng(2), g0, 0.001)
+    b1 = host.build_bwt(util.make_text([g0]))
+    t2 = util.make_text([g1])
+    b2, w = host.build_bwt_walkers(t2.copy(), 384)
+    n1, n2 = b1.size, b2.size
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_plain(b1)
+        d_bwt, d_tw = h.sort_text(t2)
+        assert np.array_equal(h.dev_download(d_bwt, n2), b2)
+        pos, acc2 = h.mg_rank_text_dev(d_bwt, d_tw, n2, host.walkers_text(t2, 384))
+        assert h.stats()["n_fallbacks"] == 0
+        assert pos[0] >= 0 and pos[-1] < n1 + n2 and np.all(np.diff(pos) > 0)
+        ka = pos - np.arange(n2)
+        assert np.all(np.diff(ka) >= 0) and ka[0] >= 0 and ka[-1] <= n1
+        assert np.array_equal(np.diff(acc2), np.bincount(b2, minlength=6)[:6])
+        p_rows, _ = h.mg_rank_plain_walkers(b2, w)
+        assert np.array_equal(p_rows, pos)
+        p_abi, _ = h.mg_rank_plain(b2)
+        assert np.array_equal(p_abi, pos)
+        h.merge_text_dev(d_bwt, d_tw, n2, host.walkers_text(t2, 384), commit=True)
+        merged = h.export_plain()
+        assert merged.size == n1 + n2
+        assert np.array_equal(merged[pos], b2)
+        keep = np.ones(merged.size, dtype=bool)
+        keep[pos] = False
+        assert np.array_equal(merged[keep], b1)
+        assert np.array_equal(np.bincount(merged, minlength=6), np.bincount(b1, minlength=6) + np.bincount(b2, minlength=6))
+        acc = h.get_acc()
+        assert acc[6] == n1 + n2
+        h.dev_free(d_bwt); h.dev_free(d_tw)
+    finally:
+        h.close()
+    assert np.array_equal(merged, oracle.merge(b1, b2, 8))

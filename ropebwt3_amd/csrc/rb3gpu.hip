@@ -750,7 +750,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #define RB3_LAUNCH_FAST(D, T, X) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw)
 		// text-order words: per-lane loads while the L1 can hold a line per walker (256 CUs x 32 waves x 8 octets), else 64-byte fetches
-		const int text_mode = !d_tw ? 0 : n_walkers <= 65536 ? 1 : 2;
+		const int text_mode = !d_tw ? 0 : getenv("RB3GPU_TEST_TEXT_MODE") ? (atoi(getenv("RB3GPU_TEST_TEXT_MODE")) == 2 ? 2 : 1) : n_walkers <= 65536 ? 1 : 2; // (the variable is a test hook)
 		switch ((iv.dense == 2 ? 12 : 0) + (tent ? 6 : 0) + text_mode) {
 		case 14: RB3_LAUNCH_FAST(true, false, 2); break;
 		case 13: RB3_LAUNCH_FAST(true, false, 1); break;

@@ -491,7 +491,8 @@ def test_whole_index_merge_on_device(oracle):
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("env", [{"RB3GPU_GROUP_REBUILD": "1"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_GROUP_REBUILD": "1", "RB3GPU_STAGED": "1"}])
+@pytest.mark.parametrize("env", [{"RB3GPU_GROUP_REBUILD": "1"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_GROUP_REBUILD": "1", "RB3GPU_STAGED": "1"},
+                                 {"RB3GPU_TEST_TEXT_MODE": "2"}])
 def test_fallback_code_paths_via_soak(env):
     """the group-sequential rebuild kernels (taken when the window scratch would exceed 8 GB) and the staged merge
     (taken for walker-less or oversized merges) forced through the randomised soak"""
@@ -601,7 +602,8 @@ def test_merge_text_order_words_vs_oracle(oracle, seed, kind):
         h.close()
 
 
-@pytest.mark.parametrize("env", [{"RB3GPU_TEST_FORCE_FALLBACK": "1"}, {"RB3GPU_TEST_TENT_LIMIT": "40"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_TENT": "0"}])
+@pytest.mark.parametrize("env", [{"RB3GPU_TEST_FORCE_FALLBACK": "1"}, {"RB3GPU_TEST_TENT_LIMIT": "40"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_TENT": "0"},
+                                 {"RB3GPU_TEST_TEXT_MODE": "2"}, {"RB3GPU_TEST_TEXT_MODE": "2", "RB3GPU_TENT": "0"}, {"RB3GPU_TEST_TEXT_MODE": "1"}])
 def test_merge_text_order_fallback_paths(oracle, env):
     """the redo path, a stretch table that runs out, the staged path and the walk without tentative records, all
     entered from rb3gpu_merge_text_dev (the walkers are converted to rows on the device where row words are walked)"""

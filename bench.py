@@ -222,6 +222,24 @@ def main():
         dt = float(tt.item())
     st = h.stats()
 
+    aux_t = None
+    if rank == 0 and world == 1 and not args.no_aux and text_words:
+        # the same step (same index, nothing committed yet) through the other two entry points, for the record:
+        # what the batch has to come with matters
+        _, w_rows = host.build_bwt_walkers(text2.copy(), args.walker_step)
+        d_b2h = h.dev_upload(b2)
+
+        def timed(fn, reps=10):
+            fn()
+            h.sync()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            h.sync()
+            return (time.perf_counter() - t) / reps
+        aux_t = (timed(lambda: h.merge_plain_dev_walkers(d_b2h, b2.size, w_rows, commit=False)), timed(lambda: h.merge_plain_dev(d_b2h, b2.size, commit=False)))
+        h.dev_free(d_b2h)
+
     # one committed merge, to make sure the timed path produces a consistent index
     step(commit=True)
     acc = h.get_acc()
@@ -271,6 +289,13 @@ def main():
             out["tree_merge_ms"] = round(tree_ms, 3)
         if world == 1 and not args.no_aux:
             out["aux_reads_regime"] = reads_regime(lambda: Rb3Gpu(device=local_rank, verbose=1), args.aux_reads)
+        if aux_t is not None:
+            t_rows, t_abi = aux_t
+            out["aux_entry_points"] = {
+                "note": "same workload, same handle; `value` above is the first line of this table",
+                "rb3gpu_merge_text_dev (BWT + inverse suffix array of the batch, as the GPU sorter leaves them; producing the words costs the sorter one 19-us kernel)": {"ms_per_step": round(dt / args.steps * 1e3, 4), "Gbp/s": round(value, 3)},
+                "rb3gpu_merge_plain_dev_walkers (BWT + inverse suffix array sampled every %d positions, from the host sorter; the LF array of the batch is built inside the step)" % args.walker_step: {"ms_per_step": round(t_rows * 1e3, 4), "Gbp/s": round(b2.size / t_rows / 1e9, 3)},
+                "rb3gpu_merge_plain_dev (the reference's signature: len + BWT only)": {"ms_per_step": round(t_abi * 1e3, 4), "Gbp/s": round(b2.size / t_abi / 1e9, 3)}}
         if world == 1 and not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(b1, b2)
         print(json.dumps(out), flush=True)

@@ -82,6 +82,31 @@ __device__ __forceinline__ uint32_t oct_exscan(uint32_t v, int j)
 	return inc - v;
 }
 
+/* inclusive prefix sum over the 64 lanes of a wave with DPP adds (6 instructions, no LDS crossbar round trips; the
+ * shuffle formulation costs ~45 instructions and six dependent ds_bpermute latencies) */
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1 (lanes shifted in from outside the row of 16 add 0)
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+	return v;
+}
+
+/* the value of one given lane (the same for the whole wave) through a scalar register */
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int l)
+{
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+
+/* the value of the lane below (lane 0 gets 0): DPP wave_shr:1 */
+__device__ __forceinline__ uint32_t wave_up1(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+
 /* ----------------------------------------------------------------------------------------- */
 /* rank: #{i < k : B[i] = c} + C[c], eight lanes per query                                     */
 /* ----------------------------------------------------------------------------------------- */
@@ -1108,7 +1133,7 @@ __device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *po
 					sy = code & 7u, len = sy == 7u ? 0u : (code >> 3) + 1u;
 				}
 				uint32_t inc = len;
-				for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+				inc = wave_incl_scan((uint32_t)inc);
 				ostart[X][lane] = (uint16_t)((lane < RB3_RLE_CODES && len != 0) ? inc - len : 0xFFFFu); // unused codes start at the end
 				orsym[X][lane] = (uint8_t)sy;
 			}
@@ -1152,9 +1177,9 @@ __device__ __forceinline__ void window_heads(const uint32_t sym[4], int lane, ui
 {
 #pragma unroll
 	for (int u = 0; u < 4; ++u) {
-		uint32_t prev = __shfl_up(sym[u], 1);
+		uint32_t prev = wave_up1(sym[u]);
 		if (lane == 0) prev = 8u;
-		if (u > 0) { const uint32_t pl = __shfl(sym[u - 1], 63); if (lane == 0) prev = pl; }
+		if (u > 0) { const uint32_t pl = wave_read(sym[u - 1], 63); if (lane == 0) prev = pl; }
 		H[u] = __ballot(sym[u] != 7u && sym[u] != prev);
 	}
 }
@@ -1188,7 +1213,7 @@ __global__ void __launch_bounds__(64) k_pass1(IdxView old, const int64_t *pos, c
 			for (int a = 0; a < 6; ++a) cnt[a] += __popcll(__ballot(sym[u] == (uint32_t)a));
 		const int64_t rem = ntot - p0;
 		const int nv = rem >= RB3_WIN ? RB3_WIN : rem > 0 ? (int)rem : 0;
-		const uint32_t first = __shfl(sym[0], 0);
+		const uint32_t first = wave_read(sym[0], 0);
 		uint32_t last = 7;
 		if (nv > 0) {
 			const int lu = (nv - 1) >> 6, ll = (nv - 1) & 63;
@@ -1198,11 +1223,11 @@ __global__ void __launch_bounds__(64) k_pass1(IdxView old, const int64_t *pos, c
 		if (lane == lw) my_nruns = nruns, my_first = first, my_last = last;
 	}
 	// partition the windows into slots: the largest aligned power-of-two groups with <= 48 runs
-	const uint32_t prev_last = __shfl_up(my_last, 1);
+	const uint32_t prev_last = wave_up1(my_last);
 	const int b = (lane > 0 && lane < nvw && my_nruns > 0 && prev_last == my_first) ? 1 : 0;
 	const int e = lane < nvw ? my_nruns - b : 0;
 	int P = e;
-	for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(P, d); if (lane >= d) P += t; }
+	P = (int)wave_incl_scan((uint32_t)P);
 	int level = 0;
 #pragma unroll
 	for (int jl = 1; jl <= 5; ++jl) {
@@ -1297,7 +1322,7 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 			const int64_t rem = ntot - p0;
 			const int nv = rem >= RB3_WIN ? RB3_WIN : rem > 0 ? (int)rem : 0;
 			const int nr = __popcll(H[0]) + __popcll(H[1]) + __popcll(H[2]) + __popcll(H[3]);
-			const uint32_t fs = __shfl(sym[0], 0);
+			const uint32_t fs = wave_read(sym[0], 0);
 			const int mg = (nc > 0 && nr > 0 && csym[nc - 1] == fs) ? 1 : 0;
 			int hb = 0;
 #pragma unroll
@@ -1402,8 +1427,8 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 	uint32_t sy[RB3_FAST_MAXROWS];
 #pragma unroll
 	for (int i = 0; i < RB3_FAST_MAXROWS; ++i) {
-		o[i] = i < nb2 ? (int)(__shfl(r, i) - p0) - i : 0x7fffffff;
-		sy[i] = __shfl(rs, i);
+		o[i] = i < nb2 ? (int)((int64_t)((uint64_t)wave_read((uint32_t)r, i) | (uint64_t)wave_read((uint32_t)((uint64_t)r >> 32), i) << 32) - p0) - i : 0x7fffffff;
+		sy[i] = wave_read(rs, i);
 	}
 	// lane q: run q of the slot, clipped to the window, in old-local coordinates
 	uint32_t len = 0, rsym = 7;
@@ -1413,7 +1438,7 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 		rsym = code & 7u, len = rsym == 7u ? 0u : (code >> 3) + 1u;
 	}
 	uint32_t inc = len;
-	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+	inc = wave_incl_scan((uint32_t)inc);
 	int cs = (int)(inc - len) - A, ce = (int)inc - A;
 	cs = cs < 0 ? 0 : cs, ce = ce > nold ? nold : ce;
 	const bool valid = ce > cs;
@@ -1437,8 +1462,8 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 		if (plen[RB3_FAST_MAXROWS]) present |= 1u << (2 * RB3_FAST_MAXROWS);
 	}
 	uint32_t ic = __popc(present), ioff = ic;
-	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(ioff, d); if (lane >= d) ioff += t; }
-	const int nitems = (int)__shfl(ioff, 63);
+	ioff = wave_incl_scan((uint32_t)ioff);
+	const int nitems = (int)wave_read(ioff, 63);
 	if (nitems > 64) return false;
 	ioff -= ic;
 	uint32_t *it = sh; // items: sym | len << 8
@@ -1452,14 +1477,14 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 	// merge equal neighbours: one lane per item
 	uint32_t me = lane < nitems ? it[lane] : 7u;
 	const uint32_t msym = me & 0xFFu, mlen = lane < nitems ? me >> 8 : 0u;
-	uint32_t prev = __shfl_up(msym, 1);
+	uint32_t prev = wave_up1(msym);
 	if (lane == 0) prev = 8u;
 	const bool head = lane < nitems && msym != prev;
 	const uint64_t H = __ballot(head);
 	const int nruns = __popcll(H);
 	if (nruns > RB3_RLE_CODES) return false;
 	uint32_t pinc = mlen;
-	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(pinc, d); if (lane >= d) pinc += t; }
+	pinc = wave_incl_scan((uint32_t)pinc);
 	const uint32_t mypos = pinc - mlen; // new-local position of this item
 	const uint64_t above = lane == 63 ? 0ull : H >> (lane + 1);
 	const int nh = above ? lane + 1 + (__ffsll((unsigned long long)above) - 1) : 64;
@@ -1519,7 +1544,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 	}
 	const int64_t rem = ntot - p0;
 	const int nv = rem >= RB3_WIN ? RB3_WIN : rem > 0 ? (int)rem : 0;
-	const uint32_t first = __shfl(sym[0], 0);
+	const uint32_t first = wave_read(sym[0], 0);
 	uint32_t last = 7;
 	if (nv > 0) {
 		const int lu = (nv - 1) >> 6, ll = (nv - 1) & 63;
@@ -1575,12 +1600,12 @@ __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot,
 	uint32_t cnt[6] = { st.x & 0xFFFFu, st.x >> 16, st.y & 0xFFFFu, st.y >> 16, st.z & 0xFFFFu, st.z >> 16 };
 #pragma unroll
 	for (int a = 0; a < 6; ++a)
-		for (int d = 32; d >= 1; d >>= 1) cnt[a] += __shfl_xor(cnt[a], d);
-	const uint32_t prev_last = __shfl_up(my_last, 1);
+		cnt[a] = wave_read(wave_incl_scan(cnt[a]), 63);
+	const uint32_t prev_last = wave_up1(my_last);
 	const int b = (lane > 0 && lane < nvw && my_nruns > 0 && prev_last == my_first) ? 1 : 0;
 	const int e = lane < nvw ? my_nruns - b : 0;
 	int P = e;
-	for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(P, d); if (lane >= d) P += t; }
+	P = (int)wave_incl_scan((uint32_t)P);
 	int level = 0;
 #pragma unroll
 	for (int jl = 1; jl <= 5; ++jl) {
@@ -1653,7 +1678,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 				uint32_t len = 0, sy = 7;
 				if (lane < (int)(wflags & 0x7FFFu)) { const uint32_t c = wruns[w * RB3_RLE_CODES + lane]; sy = c & 7u, len = (c >> 3) + 1u; }
 				uint32_t inc = len;
-				for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+				inc = wave_incl_scan((uint32_t)inc);
 				uint16_t *rst = (uint16_t*)code16; // 48 run starts
 				uint8_t *rsy = (uint8_t*)sB;       // 48 run symbols
 				uint32_t *pw = sNr;                // 24 plane words
@@ -1701,12 +1726,12 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		uint4 sw = make_uint4(0, 0, 0, 7u << 16 | 7u << 24);
 		if (lane < slot_sz) sw = wstat[w + lane];
 		const uint32_t nr = sw.w & 0x7FFFu, wfirst = sw.w >> 16 & 0xFFu, wlast = sw.w >> 24;
-		const uint32_t prev_last = __shfl_up(wlast, 1);
+		const uint32_t prev_last = wave_up1(wlast);
 		const uint32_t bm = (lane > 0 && lane < slot_sz && nr > 0 && prev_last == wfirst) ? 1u : 0u;
 		const uint32_t e = lane < slot_sz ? nr - bm : 0u;
 		uint32_t inc = e;
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-		const int nc = (int)__shfl(inc, 63);
+		inc = wave_incl_scan((uint32_t)inc);
+		const int nc = (int)wave_read(inc, 63);
 		if (lane < RB3_GRP_WINS) sP[lane] = lane < slot_sz ? inc - e : 0xFFFFu, sB[lane] = bm, sNr[lane] = nr;
 		if (lane == 0) sP[RB3_GRP_WINS] = 0xFFFFu;
 		wave_sync();
@@ -1772,8 +1797,8 @@ __global__ void __launch_bounds__(256) k_export_runs(IdxView ix, int64_t w0, int
 	uint64_t H[4];
 #pragma unroll
 	for (int u = 0; u < 4; ++u) {
-		uint32_t prev = __shfl_up(sym[u], 1);
-		const uint32_t pl = u > 0 ? __shfl(sym[u > 0 ? u - 1 : 0], 63) : before;
+		uint32_t prev = wave_up1(sym[u]);
+		const uint32_t pl = u > 0 ? wave_read(sym[u > 0 ? u - 1 : 0], 63) : before;
 		if (lane == 0) prev = pl;
 		H[u] = __ballot(sym[u] != 7u && sym[u] != prev);
 	}

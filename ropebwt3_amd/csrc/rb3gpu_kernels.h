@@ -1391,7 +1391,9 @@ __global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2
  * the caller then takes the symbol path.  The planes are NOT produced (wstat gets RB3_WSTAT_NOPLANES): a window
  * like this almost always ends up in a run slot, and k_pass2w rebuilds the planes from the run list otherwise. */
 #define RB3_WSTAT_NOPLANES 0x8000u
+#ifndef RB3_FAST_MAXROWS
 #define RB3_FAST_MAXROWS 3
+#endif
 
 __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot, int64_t w, int64_t j,
 		int lane, uint32_t *sh /* >= 160 words of LDS of this wave */, uint4 *wstat, uint16_t *wruns)

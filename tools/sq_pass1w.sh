@@ -1,5 +1,5 @@
 export TMPDIR=/tmp; R=$PWD; mkdir -p $R/gpurun_out/prof
-python tools/probe_rebuild.py prep 40 > /dev/null 2>&1
+python tools/probe_rebuild.py prep ${1:-40} > /dev/null 2>&1
 cd /tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do

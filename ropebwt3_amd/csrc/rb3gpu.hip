@@ -335,8 +335,16 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			HIPCHK(hipMemsetAsync(jg, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
 			hipLaunchKernelGGL(k_win_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, nwin, skip);
 		}
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN>), dim3((unsigned)((nwin + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-				(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip);
+		{
+			const dim3 g1w((unsigned)((nwin + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), b1w(64 * RB3_REB_WAVES);
+			// the run-space short cut takes windows with up to 3 batch rows, or up to 7 where a window receives more than 3 on average
+			if (!FROM_PLAIN && n2 * RB3_WIN > 3 * ntot)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 7>), g1w, b1w, 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
+						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip);
+			else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 3>), g1w, b1w, 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
+						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip);
+		}
 		hipLaunchKernelGGL(k_decide, dim3((unsigned)ngrp), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip);
 	} else {
 		if (!FROM_PLAIN) {

@@ -1391,22 +1391,22 @@ __global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2
  * the caller then takes the symbol path.  The planes are NOT produced (wstat gets RB3_WSTAT_NOPLANES): a window
  * like this almost always ends up in a run slot, and k_pass2w rebuilds the planes from the run list otherwise. */
 #define RB3_WSTAT_NOPLANES 0x8000u
-#ifndef RB3_FAST_MAXROWS
-#define RB3_FAST_MAXROWS 3
-#endif
+/* MR = most batch rows per window the short cut takes: every lane walks all MR rows, so a larger MR costs every window
+ * (measured: 3 is best from ~85 indexed relatives up, 7 at 40, where a window receives 6 rows on average) */
 
+template<int MR>
 __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot, int64_t w, int64_t j,
 		int lane, uint32_t *sh /* >= 160 words of LDS of this wave */, uint4 *wstat, uint16_t *wruns)
 {
 	const int64_t p0 = w << RB3_WIN_BITS;
 	if (ntot - p0 < RB3_WIN) return false; // the last window
-	// the rows that land in this window (at most RB3_FAST_MAXROWS, else the symbol path)
+	// the rows that land in this window (at most MR, else the symbol path)
 	int64_t r = INT64_MAX;
 	uint32_t rs = 7;
-	if (lane <= RB3_FAST_MAXROWS && j + lane < n2) r = pos[j + lane];
+	if (lane <= MR && j + lane < n2) r = pos[j + lane];
 	const bool in = r < p0 + RB3_WIN;
 	const uint32_t inm = (uint32_t)__ballot(in);
-	if (inm >> RB3_FAST_MAXROWS) return false;
+	if (inm >> MR) return false;
 	const int nb2 = __popc(inm);
 	if (in) { if (r < p0) r = p0; rs = b2[j + lane]; }
 	const int64_t a1 = p0 - j;
@@ -1425,10 +1425,10 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 	if (!(hdr0 & RB3_SLOT_RLE)) return false;
 	const int A = (int)(a1 - ((ga << RB3_GRP_BITS) + (hdr0 & 0xFFFFu))); // the window's old range starts at offset A of the slot
 	// the rows: old-local offset o_i = (new-local position) - i and symbol, in every lane
-	int o[RB3_FAST_MAXROWS];
-	uint32_t sy[RB3_FAST_MAXROWS];
+	int o[MR];
+	uint32_t sy[MR];
 #pragma unroll
-	for (int i = 0; i < RB3_FAST_MAXROWS; ++i) {
+	for (int i = 0; i < MR; ++i) {
 		o[i] = i < nb2 ? (int)((int64_t)((uint64_t)wave_read((uint32_t)r, i) | (uint64_t)wave_read((uint32_t)((uint64_t)r >> 32), i) << 32) - p0) - i : 0x7fffffff;
 		sy[i] = wave_read(rs, i);
 	}
@@ -1449,19 +1449,19 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 	const bool lastp = valid && (vm >> lane) == 1ull; // the last piece also takes the rows behind the last old symbol
 	// items of this lane, in order: [part of the run] row [part] row ... [rest]; parts may be empty.  Item slot 2i is the
 	// part before row i, slot 2i+1 row i, the last slot the rest; `present` says which exist.
-	uint32_t present = 0, plen[RB3_FAST_MAXROWS + 1];
-	bool mine[RB3_FAST_MAXROWS];
+	uint32_t present = 0, plen[MR + 1];
+	bool mine[MR];
 	{
 		int at = cs;
 #pragma unroll
-		for (int i = 0; i < RB3_FAST_MAXROWS; ++i) {
+		for (int i = 0; i < MR; ++i) {
 			mine[i] = valid && i < nb2 && o[i] >= cs && (o[i] < ce || (lastp && o[i] <= ce));
 			plen[i] = mine[i] && o[i] > at ? (uint32_t)(o[i] - at) : 0u;
 			if (plen[i]) present |= 1u << (2 * i);
 			if (mine[i]) present |= 1u << (2 * i + 1), at = o[i];
 		}
-		plen[RB3_FAST_MAXROWS] = valid && ce > at ? (uint32_t)(ce - at) : 0u;
-		if (plen[RB3_FAST_MAXROWS]) present |= 1u << (2 * RB3_FAST_MAXROWS);
+		plen[MR] = valid && ce > at ? (uint32_t)(ce - at) : 0u;
+		if (plen[MR]) present |= 1u << (2 * MR);
 	}
 	uint32_t ic = __popc(present), ioff = ic;
 	ioff = wave_incl_scan((uint32_t)ioff);
@@ -1470,9 +1470,9 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 	ioff -= ic;
 	uint32_t *it = sh; // items: sym | len << 8
 #pragma unroll
-	for (int i = 0; i <= RB3_FAST_MAXROWS; ++i) {
+	for (int i = 0; i <= MR; ++i) {
 		if (present >> (2 * i) & 1u) it[ioff + __popc(present & ((1u << (2 * i)) - 1u))] = rsym | plen[i] << 8;
-		if (i < RB3_FAST_MAXROWS && (present >> (2 * i + 1) & 1u)) it[ioff + __popc(present & ((1u << (2 * i + 1)) - 1u))] = sy[i] | 1u << 8;
+		if (i < MR && (present >> (2 * i + 1) & 1u)) it[ioff + __popc(present & ((1u << (2 * i + 1)) - 1u))] = sy[i] | 1u << 8;
 	}
 	if (lane < 8) sh[128 + lane] = 0u; // symbol counts
 	wave_sync();
@@ -1511,7 +1511,7 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 
 /* per window: symbols -> statistics (wstat: 6 x u16 counts, first, last, u16 runs = 16 B) and the
  * three bit planes (wplane: 24 dwords, the payload of a bit-plane slot) */
-template<bool FROM_PLAIN>
+template<bool FROM_PLAIN, int MR = 3>
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
 		const int64_t *jw, uint4 *wstat, uint32_t *wplane, uint16_t *wruns, int64_t nwin, const unsigned long long *skip)
 {
@@ -1527,7 +1527,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 	if (w >= nwin) break;
 	const int64_t p0 = w << RB3_WIN_BITS;
 	int64_t j = FROM_PLAIN ? 0 : jw[w];
-	if (!FROM_PLAIN && old.dense == 0 && window_runs_fast(old, pos, b2, n2, ntot, w, j, lane, fast_[wave], wstat, wruns)) continue;
+	if (!FROM_PLAIN && old.dense == 0 && window_runs_fast<MR>(old, pos, b2, n2, ntot, w, j, lane, fast_[wave], wstat, wruns)) continue;
 	uint32_t sym[4];
 	gen_window<FROM_PLAIN>(old, pos, b2, n2, ntot, p0, j, symbuf, sym, lane);
 	uint64_t H[4];

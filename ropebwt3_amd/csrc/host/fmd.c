@@ -257,6 +257,30 @@ int rb3h_fmdw_dump(const rb3h_fmdw_t *w, FILE *fp)
 /* reader                                                                                */
 /* ------------------------------------------------------------------------------------- */
 
+/* the word stream of an FMD file, undecoded (for rb3gpu_from_fmd_words): 0 = ok (*z: malloc'ed, n_words words followed by two
+ * zero words), 1 = not an FMD file of the DNA flavour, < 0 = error */
+int rb3h_fmd_read_words(const char *fn, uint64_t **z_out, int64_t *n_words_out, int64_t mcnt_out[6])
+{
+	FILE *fp;
+	char magic[4];
+	uint32_t a;
+	uint64_t hdr[3], mc[FMD_ASIZE], *z;
+	int64_t n_words;
+	int i;
+	*z_out = 0, *n_words_out = 0;
+	if (strcmp(fn, "-") == 0 || (fp = fopen(fn, "rb")) == 0) return 1; /* (a stream cannot be read twice: leave it to the run reader) */
+	if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "RLD\3", 4) != 0 || fread(&a, 4, 1, fp) != 1 || (int)(a >> 16) != FMD_ASIZE || (int)(a & 0xffff) != FMD_SBITS) { fclose(fp); return 1; }
+	if (fread(hdr, 8, 3, fp) != 3 || fread(mc, 8, FMD_ASIZE, fp) != FMD_ASIZE) { fclose(fp); return -1; }
+	n_words = (int64_t)(hdr[1] / 8);
+	if (n_words < FMD_SSIZE || (z = (uint64_t*)malloc((size_t)(n_words + 2) * 8)) == 0) { fclose(fp); return -1; }
+	if (fread(z, 8, (size_t)n_words, fp) != (size_t)n_words) { free(z); fclose(fp); return -1; }
+	fclose(fp);
+	z[n_words] = z[n_words + 1] = 0;
+	for (i = 0; i < FMD_ASIZE; ++i) mcnt_out[i] = (int64_t)mc[i];
+	*z_out = z, *n_words_out = n_words;
+	return 0;
+}
+
 int rb3h_fmd_read_runs(FILE *fp, rb3h_run_f emit, void *data, int64_t mcnt_out[6])
 {
 	uint32_t a;

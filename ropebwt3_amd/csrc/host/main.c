@@ -141,6 +141,27 @@ static int dump_fmr(rb3gpu_t *h, const bopt_t *opt, FILE *fp)
 	return ret;
 }
 
+/* an existing index into HBM (build.c:172-184, rb3_fmi_restore): an FMD file is decoded on the device
+ * (rb3gpu_from_fmd_words); an FMR file, a stream, or an FMD the device declined goes through the host decoder */
+static int load_index(rb3gpu_t *h, const char *fn)
+{
+	runvec_t rv = {0, 0, 0};
+	uint64_t *z = 0;
+	int64_t nw = 0, mc[6];
+	int r = getenv("RB3GPU_HOST_FMD") ? 1 : rb3h_fmd_read_words(fn, &z, &nw, mc);
+	if (r < 0) return -1;
+	if (r == 0) {
+		r = rb3gpu_from_fmd_words(h, nw, z, mc);
+		free(z);
+		if (r == 0) return 0;
+		if (rb3h_verbose >= 2) fprintf(stderr, "[W::%s] the GPU did not decode '%s' (%s); decoding it on the host\n", __func__, fn, rb3gpu_strerror(r));
+	}
+	if (rb3h_index_read_runs(fn, sink_runvec, &rv) < 0 || rv.n == 0) { free(rv.a); return -1; }
+	r = rb3gpu_from_runs(h, rv.n, rv.a);
+	free(rv.a);
+	return r < 0 ? -2 : 0;
+}
+
 /* ---- batches ----------------------------------------------------------------------------- */
 
 typedef struct {
@@ -489,17 +510,14 @@ int main_build(int argc, char *argv[])
 	}
 
 	if (fn_in) { /* build.c:172-184 */
-		runvec_t rv = {0, 0, 0};
-		int r = rb3h_index_read_runs(fn_in, sink_runvec, &rv);
-		if (r < 0 || rv.n == 0) {
+		const int r = load_index(h, fn_in);
+		if (r == -1) {
 			if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: failed to open index file '%s'\n", fn_in);
-			free(rv.a); rb3gpu_destroy(h);
+			rb3gpu_destroy(h);
 			return 1;
 		}
-		r = rb3gpu_from_runs(h, rv.n, rv.a);
-		free(rv.a);
 		if (r < 0) {
-			fprintf(stderr, "ERROR: failed to load the index into HBM: %s\n", rb3gpu_strerror(r));
+			fprintf(stderr, "ERROR: failed to load the index into HBM\n");
 			rb3gpu_destroy(h);
 			return 1;
 		}
@@ -611,7 +629,6 @@ int main_merge(int argc, char *argv[])
 	rb3gpu_t *h;
 	rb3gpu_opt_t gopt;
 	bopt_t opt;
-	runvec_t rv = {0, 0, 0};
 	bopt_init(&opt);
 	optind = 1;
 	while ((c = getopt_long(argc, argv, "t:o:S:db", long_opts, 0)) >= 0) {
@@ -636,12 +653,11 @@ int main_merge(int argc, char *argv[])
 	gopt.device = device, gopt.verbose = rb3h_verbose;
 	h = rb3gpu_create(&gopt);
 	if (h == 0) { fprintf(stderr, "ERROR: no usable MI355X/HIP device; the merge path has no CPU fallback\n"); return 1; }
-	if (rb3h_index_read_runs(argv[optind], sink_runvec, &rv) < 0 || rv.n == 0 || rb3gpu_from_runs(h, rv.n, rv.a) < 0) {
+	if (load_index(h, argv[optind]) < 0) {
 		fprintf(stderr, "ERROR: failed to load FMR/FMD file '%s'\n", argv[optind]);
-		free(rv.a); rb3gpu_destroy(h);
+		rb3gpu_destroy(h);
 		return 1;
 	}
-	free(rv.a);
 	for (i = optind + 1; i < argc && ret == 0; ++i) {
 		plainvec_t pv = {0, 0, 0};
 		if (rb3h_index_read_runs(argv[i], sink_plainvec, &pv) < 0 || pv.l == 0) {
@@ -679,7 +695,6 @@ int main_ssa(int argc, char *argv[])
 	FILE *fp;
 	rb3gpu_t *h;
 	rb3gpu_opt_t gopt;
-	runvec_t rv = {0, 0, 0};
 	optind = 1;
 	while ((c = getopt_long(argc, argv, "t:s:o:", long_opts, 0)) >= 0) {
 		if (c == 't') {} /* threads of the reference's kt_for: nothing to size here */
@@ -700,12 +715,11 @@ int main_ssa(int argc, char *argv[])
 	gopt.device = device, gopt.verbose = rb3h_verbose;
 	h = rb3gpu_create(&gopt);
 	if (h == 0) { fprintf(stderr, "ERROR: no usable MI355X/HIP device; there is no CPU fallback\n"); return 1; }
-	if (rb3h_index_read_runs(argv[optind], sink_runvec, &rv) < 0 || rv.n == 0 || rb3gpu_from_runs(h, rv.n, rv.a) < 0) {
+	if (load_index(h, argv[optind]) < 0) {
 		fprintf(stderr, "[E::%s] failed to load the FM-index\n", __func__);
-		free(rv.a); rb3gpu_destroy(h);
+		rb3gpu_destroy(h);
 		return 1;
 	}
-	free(rv.a);
 	if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] loaded the index\n", __func__, rb3h_realtime(), rb3h_percent_cpu());
 	ret = rb3gpu_ssa_dims(h, ssa_shift, &m, &n_ssa, &ms);
 	if (ret == 0) {

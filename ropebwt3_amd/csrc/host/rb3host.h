@@ -62,6 +62,7 @@ int64_t rb3h_fmdw_nbytes(const rb3h_fmdw_t *w);
 typedef int (*rb3h_run_f)(void *data, int c, int64_t l);
 /* decode every run of an FMD file in order (rld_restore + rld_dec, rld0.c:267-320, rld0.h:85-122) */
 int rb3h_fmd_read_runs(FILE *fp, rb3h_run_f emit, void *data, int64_t mcnt[6]);
+int rb3h_fmd_read_words(const char *fn, uint64_t **z, int64_t *n_words, int64_t mcnt[6]); /* undecoded, for rb3gpu_from_fmd_words */
 
 /* ---- FMR (mrope) writer / reader ---- */
 struct rb3h_fmrw_s;

@@ -32,6 +32,9 @@ int64_t rb3sort_bytes(const rb3sort_ws *ws);
 int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds, uint64_t *d_tw);
 /* the FMD packer lives in rb3gpu_fmdenc.hip */
 int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words);
+struct rb3fmd_dec;
+int rb3fmd_decode_begin(hipStream_t st, int64_t n_words, const uint64_t *d_z, rb3fmd_dec **ctx, int64_t *n_sym);
+int rb3fmd_decode_fill(rb3fmd_dec *ctx, uint8_t *d_plain);
 
 struct Buf {
 	void *p = nullptr;
@@ -1396,6 +1399,38 @@ int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
 	if (!h || !emit) return RB3GPU_EINVAL;
 	RunAdapter a = { emit, data, -1, 0 };
 	return rb3gpu_export_run_words(h, run_adapter, &a);
+}
+
+/* fm-index.c:56-85 (rb3_enc_fmd2fmr) with the decoding on the device: the word stream of an FMD file -> symbols in HBM
+ * (one thread per 64-byte block) -> rb3gpu_from_plain_dev */
+int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE])
+{
+	if (!h || n_words < 8 || !words) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	const double t = now_s();
+	int r;
+	if ((r = buf_ensure(h, h->xbuf, (size_t)(n_words + 2) * 8)) < 0) return r;
+	HIPCHK(hipMemsetAsync((uint64_t*)h->xbuf.p + n_words, 0, 16, h->st));
+	HIPCHK(hipMemcpyAsync(h->xbuf.p, words, (size_t)n_words * 8, hipMemcpyHostToDevice, h->st));
+	rb3fmd_dec *ctx = nullptr;
+	int64_t n_sym = 0;
+	r = rb3fmd_decode_begin(h->st, n_words, (const uint64_t*)h->xbuf.p, &ctx, &n_sym);
+	if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -2 ? RB3GPU_ENODEV : RB3GPU_ESYMBOL;
+	if (mcnt) { // the header of the file says how many symbols there are
+		int64_t tot = 0;
+		for (int a = 0; a < RB3GPU_ASIZE; ++a) tot += mcnt[a];
+		if (tot != n_sym) { (void)rb3fmd_decode_fill(ctx, nullptr); return RB3GPU_ESYMBOL; }
+	}
+	if ((r = buf_ensure(h, h->b2, (size_t)n_sym + 16)) < 0) { (void)rb3fmd_decode_fill(ctx, nullptr); return r; }
+	r = rb3fmd_decode_fill(ctx, (uint8_t*)h->b2.p);
+	if (r < 0) return RB3GPU_ENODEV;
+	if (h->opt.verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f] decoded %lld FMD words into %lld symbols on the GPU in %.3f ms\n", __func__, now_s() - h->t0, (long long)n_words, (long long)n_sym, (now_s() - t) * 1e3);
+	if ((r = rb3gpu_from_plain_dev(h, n_sym, (const uint8_t*)h->b2.p)) < 0) return r;
+	if (mcnt)
+		for (int a = 0; a < RB3GPU_ASIZE; ++a)
+			if (h->acc[a + 1] - h->acc[a] != mcnt[a]) { index_drop(h); return RB3GPU_ESYMBOL; }
+	return 0;
 }
 
 int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs)

@@ -235,3 +235,157 @@ done:
 	}
 	return ret;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* FMD decoding on the device (rld_dec0 / rld_dec, rld0.h:85-122; fm-index.c:56-85)            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* A 64-byte block is self-contained: header (2, 4 or 7 words by type, rld0.c:71-73), then Elias-delta coded runs
+ * delta(len) << 3 | sym, MSB first, ended by six zero bits or the block's last usable word (the last word of a
+ * superblock of 2^23 words is never used).  One thread per block: a first pass adds up the symbols of every block,
+ * an exclusive scan places them, a second pass writes the symbols, one byte each, where rb3gpu_from_plain_dev wants
+ * them; runs of 64 k symbols and more are left to whole workgroups (k_fd_long). */
+#define FD_LBITS 23
+#define FD_LONG  65536
+#define FD_LONG_CAP (1 << 20)
+
+template<class F>
+__device__ __forceinline__ bool fd_block(const uint64_t *z, int64_t head, F f)
+{
+	const int type = (int)(z[head] >> 62);
+	if (type > 2) return false;
+	const int64_t stail = head + 8 - (((head + 8) & ((1LL << FD_LBITS) - 1)) == 0 ? 2 : 1);
+	int64_t p = head + (type == 0 ? 2 : type == 1 ? 4 : 7);
+	int r = 64;
+	while (p <= stail) {
+		uint64_t x = z[p] << (64 - r);
+		if (r != 64 && p != stail) x |= z[p + 1] >> r;
+		if (x == 0) break;
+		const int lz = __clzll((long long)x);
+		if (lz >= 6) break; // no delta code starts with six zeros: end of block
+		int wd = 2 * lz + 1;
+		const int y = (int)(x >> (64 - wd)) - 1;
+		int64_t l = (int64_t)1 << y;
+		if (y > 0) l |= (int64_t)(x << wd >> (64 - y));
+		wd += y;
+		const int c = (int)(x << wd >> 61);
+		wd += 3;
+		if (r > wd) r -= wd; else ++p, r = 64 + r - wd;
+		if (c > 5) return false;
+		f(c, l);
+	}
+	return true;
+}
+
+__global__ void __launch_bounds__(256) k_fd_count(const uint64_t *z, int64_t nblk, uint64_t *btot, unsigned int *flag)
+{
+	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nblk) return;
+	uint64_t tot = 0;
+	if (!fd_block(z, b * 8, [&](int, int64_t l) { tot += (uint64_t)l; })) atomicOr(flag, 1u);
+	btot[b] = tot;
+}
+
+__device__ __forceinline__ void fd_fill(uint8_t *q, int64_t l, int c)
+{
+	int64_t i = 0;
+	for (; i < l && ((uintptr_t)(q + i) & 7); ++i) q[i] = (uint8_t)c; // up to an 8-byte boundary
+	const uint64_t w = 0x0101010101010101ull * (uint64_t)c;
+	for (; i + 8 <= l; i += 8) *(uint64_t*)(q + i) = w;
+	for (; i < l; ++i) q[i] = (uint8_t)c;
+}
+
+struct fd_long_t { int64_t off, len; int64_t sym; };
+
+__global__ void __launch_bounds__(256) k_fd_fill(const uint64_t *z, int64_t nblk, const uint64_t *boff, uint8_t *out, fd_long_t *lng, unsigned int *nlong)
+{
+	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nblk) return;
+	int64_t off = (int64_t)boff[b];
+	fd_block(z, b * 8, [&](int c, int64_t l) {
+		bool done = false;
+		if (l >= FD_LONG) {
+			const unsigned int k = atomicAdd(nlong, 1u);
+			if (k < (unsigned int)FD_LONG_CAP) { fd_long_t e; e.off = off, e.len = l, e.sym = c; lng[k] = e; done = true; }
+		}
+		if (!done) fd_fill(out + off, l, c);
+		off += l;
+	});
+}
+
+__global__ void __launch_bounds__(256) k_fd_long(const fd_long_t *lng, const unsigned int *nlong, uint8_t *out)
+{
+	const unsigned int n = *nlong < (unsigned int)FD_LONG_CAP ? *nlong : (unsigned int)FD_LONG_CAP;
+	for (unsigned int k = blockIdx.y; k < n; k += gridDim.y) {
+		const fd_long_t e = lng[k];
+		// this workgroup's share of the run: 64 KB pieces, gridDim.x of them in flight per run
+		for (int64_t s = (int64_t)blockIdx.x * FD_LONG; s < e.len; s += (int64_t)gridDim.x * FD_LONG) {
+			const int64_t m = e.len - s < FD_LONG ? e.len - s : FD_LONG;
+			uint8_t *q = out + e.off + s;
+			for (int64_t i = threadIdx.x; i < m; i += blockDim.x) q[i] = (uint8_t)e.sym;
+		}
+	}
+}
+
+struct rb3fmd_dec {
+	hipStream_t st;
+	int64_t nblk;
+	const uint64_t *z;
+	uint64_t *btot, *boff; // nblk + 1 each: symbols per block, their exclusive prefix sum
+	void *tmp;
+	fd_long_t *lng;
+	unsigned int *flag;  // [0] bad block, [1] number of long runs
+};
+
+/* d_z: the word stream in device memory, followed by two zero words.  Returns 0 and the number of symbols, -1 (out of
+ * memory), -2 (HIP error), -3 (not a valid stream). */
+int rb3fmd_decode_begin(hipStream_t st, int64_t n_words, const uint64_t *d_z, rb3fmd_dec **ctx, int64_t *n_sym)
+{
+	int ret = 0;
+	*ctx = nullptr, *n_sym = 0;
+	const int64_t nblk = n_words >> 3; // (a trailing header-only block, if any, holds no runs: rld0.c:190-216)
+	if (nblk <= 0) return -3;
+	rb3fmd_dec *c = new rb3fmd_dec;
+	c->st = st, c->nblk = nblk, c->z = d_z, c->btot = nullptr, c->boff = nullptr, c->tmp = nullptr, c->lng = nullptr, c->flag = nullptr;
+	size_t tb = 0;
+	unsigned int hflag = 0;
+	uint64_t last[2] = {0, 0};
+	if (hipMalloc(&c->btot, (size_t)(nblk + 1) * 8) != hipSuccess || hipMalloc(&c->boff, (size_t)(nblk + 1) * 8) != hipSuccess || hipMalloc(&c->lng, (size_t)FD_LONG_CAP * sizeof(fd_long_t)) != hipSuccess ||
+		hipMalloc(&c->flag, 16) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
+	FE_HIP(rocprim::exclusive_scan(nullptr, tb, c->btot, c->boff, (uint64_t)0, (size_t)(nblk + 1), rocprim::plus<uint64_t>(), st));
+	if (hipMalloc(&c->tmp, tb + 256) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
+	FE_HIP(hipMemsetAsync(c->flag, 0, 16, st));
+	FE_HIP(hipMemsetAsync(c->btot + nblk, 0, 8, st));
+	hipLaunchKernelGGL(k_fd_count, FE_GRID(nblk), d_z, nblk, c->btot, c->flag);
+	{ size_t b = tb; FE_HIP(rocprim::exclusive_scan(c->tmp, b, c->btot, c->boff, (uint64_t)0, (size_t)(nblk + 1), rocprim::plus<uint64_t>(), st)); }
+	FE_HIP(hipMemcpyAsync(&hflag, c->flag, 4, hipMemcpyDeviceToHost, st));
+	FE_HIP(hipMemcpyAsync(last, c->boff + nblk, 8, hipMemcpyDeviceToHost, st));
+	FE_HIP(hipStreamSynchronize(st));
+	if (hflag != 0 || last[0] == 0 || last[0] >= (1ull << 62)) { ret = -3; goto done; }
+	*n_sym = (int64_t)last[0];
+	*ctx = c;
+	return 0;
+done:
+	if (c->btot) (void)hipFree(c->btot);
+	if (c->boff) (void)hipFree(c->boff);
+	if (c->tmp) (void)hipFree(c->tmp);
+	if (c->lng) (void)hipFree(c->lng);
+	if (c->flag) (void)hipFree(c->flag);
+	delete c;
+	return ret;
+}
+
+/* the symbols into d_plain (n_sym bytes); frees the context */
+int rb3fmd_decode_fill(rb3fmd_dec *c, uint8_t *d_plain)
+{
+	int ret = 0;
+	hipStream_t st = c->st;
+	if (d_plain == nullptr) goto done; // (the caller gives up: just free the context)
+	hipLaunchKernelGGL(k_fd_fill, FE_GRID(c->nblk), c->z, c->nblk, (const uint64_t*)c->boff, d_plain, c->lng, c->flag + 1);
+	hipLaunchKernelGGL(k_fd_long, dim3(64, 256), dim3(256), 0, st, (const fd_long_t*)c->lng, (const unsigned int*)(c->flag + 1), d_plain);
+	FE_HIP(hipStreamSynchronize(st));
+done:
+	(void)hipFree(c->btot); (void)hipFree(c->boff); (void)hipFree(c->tmp); (void)hipFree(c->lng); (void)hipFree(c->flag);
+	delete c;
+	return ret;
+}

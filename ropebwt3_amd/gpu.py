@@ -83,6 +83,7 @@ SYMBOLS = {
     "rb3gpu_sorter_bwt": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_sorter_release": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_from_fmd_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),
     "rb3gpu_dev_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
@@ -302,6 +303,16 @@ class Rb3Gpu:
         self._chk(self._lib.rb3gpu_from_runs(self._h, arr.size, arr.ctypes.data), "rb3gpu_from_runs")
 
     # -- device-resident variants ------------------------------------------------------------
+    def from_fmd_file(self, path):
+        """load an .fmd file, decoding it on the device (rb3gpu_from_fmd_words)"""
+        raw = np.fromfile(path, dtype=np.uint8)
+        assert raw[:4].tobytes() == b"RLD\x03", "not an FMD file"
+        hdr = raw[8:32].view(np.uint64)
+        mc = raw[32:80].view(np.uint64).astype(np.int64)
+        n_words = int(hdr[1]) // 8
+        words = np.ascontiguousarray(raw[80:80 + n_words * 8]).view(np.uint64)
+        self._chk(self._lib.rb3gpu_from_fmd_words(self._h, n_words, words.ctypes.data, mc.ctypes.data), "rb3gpu_from_fmd_words")
+
     def dev_upload(self, arr):
         arr = np.ascontiguousarray(arr)
         p = ctypes.c_void_p()

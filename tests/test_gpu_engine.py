@@ -1,5 +1,6 @@
 """Parity of the HIP engine (through the C ABI) against the CPU oracle.  Bit-exact: this is
 integer/byte work, so every comparison is array_equal."""
+import os
 import numpy as np
 import pytest
 
@@ -673,3 +674,58 @@ def test_config2_full_size_properties_and_oracle(oracle):
     finally:
         h.close()
     assert np.array_equal(merged, oracle.merge(b1, b2, 8))
+
+
+def _golden_fmd_names():
+    import json
+    man = json.load(open(os.path.join(util.GOLDEN, "MANIFEST.json")))
+    return sorted(k for k, v in man.items() if isinstance(v, dict) and "fmd" in v and "plain_md5" in v)
+
+
+@pytest.mark.parametrize("name", _golden_fmd_names())
+def test_fmd_decoded_on_the_device(name):
+    """rb3gpu_from_fmd_words: the reference's own .fmd files (tests/golden) decoded on the device, one thread per 64-byte
+    block: the plain BWT that comes out has the md5 the reference's decoder gives (MANIFEST plain_md5), and the
+    symbol counts of the file header"""
+    import json, hashlib
+    from ropebwt3_amd import Rb3Gpu
+    ent = json.load(open(os.path.join(util.GOLDEN, "MANIFEST.json")))[name]
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_fmd_file(os.path.join(util.GOLDEN, ent["fmd"]))
+        got = h.export_plain()
+        assert got.size == ent["n_symbols"]
+        text = np.frombuffer(b"$ACGTN", dtype=np.uint8)[got].tobytes() + b"\n"
+        assert hashlib.md5(text).hexdigest() == ent["plain_md5"]
+    finally:
+        h.close()
+
+
+def test_fmd_decode_long_runs_and_garbage():
+    """runs longer than 64 k symbols are written by whole workgroups; a stream that is not FMD is refused"""
+    from ropebwt3_amd import Rb3Gpu, host
+    import subprocess, tempfile
+    rng = np.random.default_rng(5)
+    seqs = [np.full(300000, 1, dtype=np.uint8), np.full(70000, 3, dtype=np.uint8), util.random_genome(rng, 5000), np.full(200001, 1, dtype=np.uint8)]
+    bwt = host.build_bwt(util.make_text(seqs, True, False))
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_plain(bwt)
+        with tempfile.TemporaryDirectory() as d:
+            fa = os.path.join(d, "x.txt")
+            with open(fa, "wb") as f:
+                for s in seqs:
+                    f.write(np.frombuffer(b"$ACGTN", dtype=np.uint8)[s].tobytes() + b"\n")
+            fmd = os.path.join(d, "x.fmd")
+            cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ropebwt3_amd", "ropebwt3-amd")
+            subprocess.check_call([cli, "build", "-LR", "-d", "-o", fmd, fa], stderr=subprocess.DEVNULL)
+            h2 = Rb3Gpu(verbose=1)
+            h2.from_fmd_file(fmd)
+            assert np.array_equal(h2.export_plain(), bwt)
+            junk = np.frombuffer(rng.integers(0, 256, size=4096, dtype=np.uint8).tobytes(), dtype=np.uint64).copy()
+            junk[0] |= np.uint64(3) << np.uint64(62)   # block type 3 does not exist
+            with pytest.raises(Exception):
+                h2._chk(h2._lib.rb3gpu_from_fmd_words(h2._h, junk.size, junk.ctypes.data, None), "rb3gpu_from_fmd_words")
+            h2.close()
+    finally:
+        h.close()

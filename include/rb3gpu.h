@@ -218,11 +218,14 @@ int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt);
 int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs);
 
 /* rb3_enc_fmd2fmr (fm-index.c:56-85: rld_dec over the whole file + rope inserts) with the decoding on the device:
- * `words` (host) is the word stream of an FMD file -- what follows the 60-byte header, n_words = n_bytes / 8
+ * `words` (host) is the word stream of an FMD file -- what follows the 80-byte header, n_words = n_bytes / 8
  * (rld0.c:218-243) --, mcnt[6] the symbol counts of the header (NULL: not checked).  One thread decodes one 64-byte
  * block (blocks are self-contained, rld0.h:85-122); the symbols are built into the block array as by
  * rb3gpu_from_plain_dev.  RB3GPU_ESYMBOL: not a valid stream. */
 int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE]);
+/* the same stream decoded on the device and merged into the index the handle holds as one batch, like rb3gpu_merge_plain
+ * (`ropebwt3 merge`, main.c:84-133, with the right-hand index taken as its BWT) */
+int rb3gpu_merge_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE]);
 
 int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st);
 void rb3gpu_stats_reset(rb3gpu_t *h);

@@ -660,6 +660,24 @@ int main_merge(int argc, char *argv[])
 	}
 	for (i = optind + 1; i < argc && ret == 0; ++i) {
 		plainvec_t pv = {0, 0, 0};
+		{ /* an FMD file: decoded on the device and merged as one batch */
+			uint64_t *z = 0;
+			int64_t nw = 0, mc[6];
+			if (!getenv("RB3GPU_HOST_FMD") && rb3h_fmd_read_words(argv[i], &z, &nw, mc) == 0) {
+				ret = rb3gpu_merge_fmd_words(h, nw, z, mc);
+				free(z);
+				if (ret == 0) {
+					if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] merged '%s'\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), argv[i]);
+					if (fn_tmp) {
+						FILE *fp = fopen(fn_tmp, "wb");
+						if (fp) { dump_fmr(h, &opt, fp); fclose(fp); }
+					}
+					continue;
+				}
+				if (ret != RB3GPU_ESYMBOL && ret != RB3GPU_ENOMEM) { fprintf(stderr, "ERROR: the GPU engine failed to merge '%s': %s\n", argv[i], rb3gpu_strerror(ret)); break; }
+				ret = 0; /* the device declined the stream: host decoder */
+			}
+		}
 		if (rb3h_index_read_runs(argv[i], sink_plainvec, &pv) < 0 || pv.l == 0) {
 			fprintf(stderr, "ERROR: failed to load FMR/FMD file '%s'\n", argv[i]);
 			free(pv.s); ret = 1;

@@ -1403,10 +1403,8 @@ int rb3gpu_export_runs(rb3gpu_t *h, rb3gpu_emit_f emit, void *data)
 
 /* fm-index.c:56-85 (rb3_enc_fmd2fmr) with the decoding on the device: the word stream of an FMD file -> symbols in HBM
  * (one thread per 64-byte block) -> rb3gpu_from_plain_dev */
-int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE])
+static int fmd_words_to_b2(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE], int64_t *n_sym_out)
 {
-	if (!h || n_words < 8 || !words) return RB3GPU_EINVAL;
-	HIPCHK(hipSetDevice(h->dev));
 	const double t = now_s();
 	int r;
 	if ((r = buf_ensure(h, h->xbuf, (size_t)(n_words + 2) * 8)) < 0) return r;
@@ -1426,11 +1424,33 @@ int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, c
 	if (r < 0) return RB3GPU_ENODEV;
 	if (h->opt.verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f] decoded %lld FMD words into %lld symbols on the GPU in %.3f ms\n", __func__, now_s() - h->t0, (long long)n_words, (long long)n_sym, (now_s() - t) * 1e3);
+	*n_sym_out = n_sym;
+	return 0;
+}
+
+int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE])
+{
+	if (!h || n_words < 8 || !words) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	int64_t n_sym = 0;
+	int r;
+	if ((r = fmd_words_to_b2(h, n_words, words, mcnt, &n_sym)) < 0) return r;
 	if ((r = rb3gpu_from_plain_dev(h, n_sym, (const uint8_t*)h->b2.p)) < 0) return r;
 	if (mcnt)
 		for (int a = 0; a < RB3GPU_ASIZE; ++a)
 			if (h->acc[a + 1] - h->acc[a] != mcnt[a]) { index_drop(h); return RB3GPU_ESYMBOL; }
 	return 0;
+}
+
+int rb3gpu_merge_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE])
+{
+	if (!h || n_words < 8 || !words) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->n <= 0) return RB3GPU_ESTATE;
+	int64_t n_sym = 0;
+	int r;
+	if ((r = fmd_words_to_b2(h, n_words, words, mcnt, &n_sym)) < 0) return r; // (checks the total against the header)
+	return merge_core(h, n_sym, (const uint8_t*)h->b2.p, 1, nullptr, nullptr, 0, 0, nullptr);
 }
 
 int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs)

@@ -96,8 +96,11 @@ def test_merge_subcommand(tmp_path):
         f = tmp_path / ("part%d.fmd" % i)
         f.write_bytes(out)
         parts.append(str(f))
-    out, _ = run(["merge", "-d"] + parts)
+    out, err = run(["merge", "-d"] + parts)
     assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+    assert err.count("FMD words into") == len(parts)      # every operand was decoded on the device
+    r = subprocess.run([CLI, "merge", "-d"] + parts, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, RB3GPU_HOST_FMD="1"))
+    assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"] and b"FMD words into" not in r.stderr   # and the host decoder agrees
     fmr, _ = run(["merge"] + parts)   # default output is FMR like the reference
     p = tmp_path / "m.fmr"
     p.write_bytes(fmr)

@@ -552,8 +552,10 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 #define RB3_TENT_POISON (RB3_TENT_IDS - 1) /* the id of records whose stretch could not be allocated: never settled */
 #define RB3_TENT_KMAX 255             /* widest interval that is tracked tentatively */
 #ifndef RB3_TENT_MIN_AGE
-#define RB3_TENT_MIN_AGE 32u
+#define RB3_TENT_MIN_AGE 32u      /* walker lists (segments of a guaranteed length) */
 #endif
+#define RB3_TENT_MIN_AGE_AUTO 64u /* automatic split: the segments are geometric, and with 32 one merge in a hundred of the
+                                     soak left records unsettled and was redone */
 /* One 64-byte record per stretch, so that following a dependency path costs one memory round trip per
  * stretch (k_resolve).  w0, w1: how the unknown of the stretch follows from another one.
  *   w0 = type << 62 | previous stretch << 38 | lo (EVENT only)
@@ -774,7 +776,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			const int64_t tpn = tp > 0 ? tp - 1 : 0;
 			const bool wide = TENT ? gap == 2 : gap != 0;
 			// may this walker record tentatively?  (an interval of at most KMAX rows, and old enough)
-			const bool tentok = TENT && gap != 0 && age >= RB3_TENT_MIN_AGE && hi - lo <= RB3_TENT_KMAX && sid != -2;
+			const bool tentok = TENT && gap != 0 && age >= (LIST ? RB3_TENT_MIN_AGE : RB3_TENT_MIN_AGE_AUTO) && hi - lo <= RB3_TENT_KMAX && sid != -2;
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
 			if (wide) octc_issue_grp<DENSE>(b1, hi, c, j, rh);

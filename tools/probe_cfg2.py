@@ -20,7 +20,7 @@ def run(name, h, fn, reps=5):
     dt = (time.time() - t) / reps
     st = h.stats()
     print("%-22s %.2f ms/merge (lf %.2f chain %.2f build %.2f) steps=%d fb=%d -> %.3f Gsym/s" % (name, dt*1e3, st['ms_lf']/reps, st['ms_chain']/reps, st['ms_build']/reps, st['n_lf_steps']//reps, st['n_fallbacks'], b2.size/dt/1e9))
-for sl in [8, 9]:
+for sl in [6, 7, 8, 9]:
     h = Rb3Gpu(split_log2=sl, verbose=1); h.from_plain(b1); d = h.dev_upload(b2)
     run("sa-order 2^%d" % sl, h, lambda: h.merge_plain_dev(d, b2.size, commit=False))
     h.dev_free(d); h.close()

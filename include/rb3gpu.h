@@ -227,6 +227,14 @@ int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, c
  * (`ropebwt3 merge`, main.c:84-133, with the right-hand index taken as its BWT) */
 int rb3gpu_merge_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE]);
 
+/* Diagnostic switches of a handle (no reference analogue; none is needed in normal use).  Each key is also read ONCE from
+ * the environment variable RB3GPU_<KEY> when the handle is created; the merge path itself never calls getenv().
+ *   "tent" 0/1, "staged" 0/1, "group_rebuild" 0/1, "window_rebuild" 0/1, "octs" 1..8, "blkmul", "blkcap", "ssa_split" 4..20,
+ *   "lf_check" n (verify the LF relation of every n-th batch row against the index after each merge; 0 = off)
+ * Test hooks "force_fallback", "tent_limit", "text_mode" exist only in the test build of the library (compiled with
+ * -DRB3GPU_TEST_HOOKS, librb3gpu_hooks.so); the release library answers RB3GPU_EUNSUP.  Unknown key: RB3GPU_EINVAL. */
+int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value);
+
 int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st);
 void rb3gpu_stats_reset(rb3gpu_t *h);
 

@@ -13,6 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 
 LIB_GPU = os.path.join(HERE, "librb3gpu.so")
+LIB_GPU_HOOKS = os.path.join(HERE, "librb3gpu_hooks.so")
 LIB_HOST = os.path.join(HERE, "librb3host.so")
 BIN_CLI = os.path.join(HERE, "ropebwt3-amd")
 
@@ -38,13 +39,37 @@ def hipcc_path():
     raise RuntimeError("hipcc not found; the HIP engine cannot be built (there is no CPU fallback)")
 
 
+GPU_UNITS = ("rb3gpu.hip", "rb3gpu_sort.hip", "rb3gpu_fmdenc.hip", "rb3gpu_multi.hip")
+
+
 def build_gpu(force=False):
-    """librb3gpu.so: the HIP engine + C ABI (include/rb3gpu.h), gfx950 only."""
-    srcs = [os.path.join(CSRC, f) for f in ("rb3gpu.hip", "rb3gpu_sort.hip", "rb3gpu_fmdenc.hip", "rb3gpu_kernels.h", "rb3gpu_layout.h")] + [os.path.join(INCLUDE, "rb3gpu.h")]
-    if not force and _newer(LIB_GPU, srcs):
-        return LIB_GPU
-    _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-          "-I" + INCLUDE, "-I" + CSRC, "-o", LIB_GPU, os.path.join(CSRC, "rb3gpu.hip"), os.path.join(CSRC, "rb3gpu_sort.hip"), os.path.join(CSRC, "rb3gpu_fmdenc.hip")])
+    """librb3gpu.so: the HIP engine + C ABI (include/rb3gpu.h), gfx950 only -- and librb3gpu_hooks.so, the same sources
+    with -DRB3GPU_TEST_HOOKS (the test hooks of rb3gpu_tune are compiled out of the release library).  Translation units
+    are compiled in parallel into build/ and linked; force=True recompiles everything (what the driver's build() does)."""
+    from concurrent.futures import ThreadPoolExecutor
+    units = [u for u in GPU_UNITS if os.path.exists(os.path.join(CSRC, u))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "rb3gpu.h")]
+    odir = os.path.join(HERE, "build")
+    os.makedirs(odir, exist_ok=True)
+    hipcc = hipcc_path()
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+    jobs = []
+    for u in units:
+        src = os.path.join(CSRC, u)
+        variants = [("", [])]
+        if u == "rb3gpu.hip":
+            variants.append(("_hooks", ["-DRB3GPU_TEST_HOOKS"]))
+        for tag, defs in variants:
+            obj = os.path.join(odir, u.replace(".hip", tag + ".o"))
+            if force or not _newer(obj, [src] + hdrs):
+                jobs.append(base + defs + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(_run, jobs))
+    for lib, tag in ((LIB_GPU, ""), (LIB_GPU_HOOKS, "_hooks")):
+        objs = [os.path.join(odir, u.replace(".hip", (tag if u == "rb3gpu.hip" else "") + ".o")) for u in units]
+        if force or jobs or not _newer(lib, objs):
+            _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return LIB_GPU
 
 

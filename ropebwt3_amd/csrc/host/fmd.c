@@ -211,14 +211,14 @@ int rb3h_fmdw_finish(rb3h_fmdw_t *w)
 	if (fmdw_next_block(w) < 0) return -1; /* trailing header-only block */
 	w->n_bytes = (uint64_t)w->p * 8;
 	for (w->cnt[0] = 0, i = 1; i <= FMD_ASIZE; ++i) w->cnt[i] += w->cnt[i - 1];
-	if (fmdw_rank_index(w) < 0) return -1;
+	if (fmdw_rank_index(w) < 0) { w->z = 0, w->m = 0; return -1; } /* not taken over: on failure `words` stays with the caller */
 	w->finished = 1;
 	return 0;
 }
 
 /* take over a data section that was packed elsewhere (rb3gpu_export_fmd_words): `words` is malloc'ed, n_words words incl.
  * the trailing header-only block; acc[] is the C array of the BWT (acc[6] = its length).  Builds the rank index; the
- * writer is finished afterwards. */
+ * writer is finished afterwards.  On failure the array still belongs to the caller. */
 int rb3h_fmdw_adopt(rb3h_fmdw_t *w, uint64_t *words, int64_t n_words, const int64_t acc[7])
 {
 	int i;

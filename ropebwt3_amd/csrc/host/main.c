@@ -30,15 +30,29 @@ enum { FMT_PLAIN = 0, FMT_FMD, FMT_FMR };
 typedef struct {
 	int64_t flag, batch_size;
 	int fmt, n_threads, sais_threads, block_len, max_nodes;
-	int device, split_log2, rebatch, gpu_sort;
+	int device, split_log2, rebatch, gpu_sort, host_fmd;
+	int64_t gpu_batch;      /* with GPU suffix sorting a batch (-m) is cut into sub-batches of at most this many symbols, at record
+	                           boundaries: the .fmd does not depend on the batching, and the GPU sorter takes < 2^31 */
+	int64_t gpu_sort_limit; /* batches of this many symbols or more go to the host sorter (one record longer than a sub-batch) */
 } bopt_t;
+
+/* how the batches of this run were sorted (for the closing statistics line) */
+static struct { int64_t n_gpu, n_host, sym_gpu, sym_host; } g_sorted;
 
 static void bopt_init(bopt_t *o) /* build.c:31-41 */
 {
 	memset(o, 0, sizeof(*o));
 	o->n_threads = 4, o->sais_threads = -1, o->fmt = FMT_PLAIN;
 	o->block_len = 512, o->max_nodes = 64, o->batch_size = 7000000000LL;
-	o->device = 0, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 1;
+	o->device = 0, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 1, o->host_fmd = 0;
+	o->gpu_batch = 1LL << 30, o->gpu_sort_limit = (int64_t)INT32_MAX - 16;
+}
+
+/* the size at which the reader cuts batches: -m, or the GPU sub-batch size if that is smaller */
+static int64_t batch_cut(const bopt_t *o)
+{
+	if (o->gpu_sort && o->gpu_batch > 0 && (o->batch_size <= 0 || o->gpu_batch < o->batch_size)) return o->gpu_batch;
+	return o->batch_size;
 }
 
 static int usage_build(FILE *fp, const bopt_t *opt)
@@ -55,8 +69,11 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	fprintf(fp, "    --gpu INT   HIP device ordinal [%d]\n", opt->device);
 	fprintf(fp, "    --split INT start extra LF walkers every 2^INT rows (0=auto, -1=never) [%d]\n", opt->split_log2);
 	fprintf(fp, "    --rebatch   let a batch span input files (same output, fewer merge rounds)\n");
-	fprintf(fp, "    --host-sort suffix-sort the batches on the host (default: on the GPU for batches below 2^31 symbols;\n");
-	fprintf(fp, "                same output; -p then sets the number of host sorter threads)\n");
+	fprintf(fp, "    --host-sort suffix-sort the batches on the host (default: on the GPU; same output; -p then sets the number\n");
+	fprintf(fp, "                of host sorter threads)\n");
+	fprintf(fp, "    --gpu-batch NUM  with GPU sorting, cut the batches of -m into sub-batches of at most NUM symbols at record\n");
+	fprintf(fp, "                boundaries (the output does not depend on the batching; the GPU sorter takes < 2^31) [1G]\n");
+	fprintf(fp, "    --host-fmd  pack/unpack FMD files on the host even where the GPU could\n");
 	fprintf(fp, "  Input:\n");
 	fprintf(fp, "    -i FILE     read existing index from FILE []\n");
 	fprintf(fp, "    -L          one sequence per line in the input\n");
@@ -91,6 +108,8 @@ static int sink_fmd_words(void *data, int64_t n, const uint64_t *words, int64_t 
 
 /* the .fmd of the index (rb3_enc_fmr2fmd + rld_dump, build.c:248-252): the data section is packed on the GPU when all
  * its blocks have 16-bit headers, else the GPU finds the runs and the host packs them; the rank index is built here */
+static int g_host_fmd = 0; /* --host-fmd */
+
 static int write_fmd(rb3gpu_t *h, FILE *fp)
 {
 	rb3h_fmdw_t *w = rb3h_fmdw_init();
@@ -98,7 +117,7 @@ static int write_fmd(rb3gpu_t *h, FILE *fp)
 	int64_t n_words = 0, acc[7];
 	int ret;
 	if (w == 0) return -1;
-	ret = getenv("RB3GPU_HOST_FMD") ? RB3GPU_EUNSUP : rb3gpu_export_fmd_words(h, &words, &n_words);
+	ret = g_host_fmd ? RB3GPU_EUNSUP : rb3gpu_export_fmd_words(h, &words, &n_words);
 	if (ret == 0) {
 		rb3gpu_get_acc(h, acc);
 		ret = rb3h_fmdw_adopt(w, words, n_words, acc); /* takes the array over */
@@ -148,7 +167,7 @@ static int load_index(rb3gpu_t *h, const char *fn)
 	runvec_t rv = {0, 0, 0};
 	uint64_t *z = 0;
 	int64_t nw = 0, mc[6];
-	int r = getenv("RB3GPU_HOST_FMD") ? 1 : rb3h_fmd_read_words(fn, &z, &nw, mc);
+	int r = g_host_fmd ? 1 : rb3h_fmd_read_words(fn, &z, &nw, mc);
 	if (r < 0) return -1;
 	if (r == 0) {
 		r = rb3gpu_from_fmd_words(h, nw, z, mc);
@@ -181,7 +200,7 @@ static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	void *d_bwt = 0, *d_tw = 0;
 	const int text_walk = *has_index; /* text-order words; long strings: walkers by text position, short ones: one walker per string */
 	int ret;
-	if ((ret = rb3gpu_dev_alloc(h, b->len + 16, &d_bwt)) < 0) return ret;
+	if (rb3gpu_dev_alloc(h, b->len + 16, &d_bwt) < 0) return 1; /* no room on the device: the caller sorts this batch on the host */
 	if (text_walk && rb3gpu_dev_alloc(h, b->len * 8, &d_tw) < 0) { rb3gpu_dev_free(h, d_bwt); return 1; }
 	if (text_walk) ret = rb3gpu_sort_text(h, b->len, b->bwt, (uint8_t*)d_bwt, (uint64_t*)d_tw);
 	else ret = rb3gpu_bwt_from_text(h, b->len, b->bwt, (uint8_t*)d_bwt, 0, 0);
@@ -278,7 +297,8 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : 384;
 	int r;
 	if (step < (seq->l >> 20)) step = seq->l >> 20; /* at most ~2^20 walkers per batch: the engine's stretch table is finite */
-	if (opt->gpu_sort && seq->l < (getenv("RB3GPU_TEST_SORT_MAX") ? atoll(getenv("RB3GPU_TEST_SORT_MAX")) : (long long)INT32_MAX - 16)) { /* the GPU sorts (the sorter handles < 2^31 symbols; the variable is a test hook) */
+	if (opt->gpu_sort && seq->l < opt->gpu_sort_limit) { /* the GPU sorts (its sorter handles < 2^31 symbols; batches are cut to fit, see batch_cut) */
+		__sync_fetch_and_add(&g_sorted.n_gpu, 1), __sync_fetch_and_add(&g_sorted.sym_gpu, seq->l);
 		b = (batch_t*)calloc(1, sizeof(batch_t));
 		b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s, b->raw = 1;
 		b->step = (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22)) ? step : 0;
@@ -298,6 +318,7 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 		*out = b;
 		return 0;
 	}
+	__sync_fetch_and_add(&g_sorted.n_host, 1), __sync_fetch_and_add(&g_sorted.sym_host, seq->l);
 	if (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22))
 		r = rb3h_build_bwt_walkers(n_seq, seq->l, seq->s, n_threads, step, &n_walkers, &walkers);
 	else r = rb3h_build_bwt(n_seq, seq->l, seq->s, n_threads);
@@ -332,16 +353,18 @@ static int for_each_batch(const bopt_t *opt, int n_files, char **files, submit_f
 		}
 		for (;;) {
 			const int64_t l0 = seq.l;
-			n_seq = rb3h_seq_read(fp, &seq, opt->batch_size, !(opt->flag & BF_NO_FOR), !(opt->flag & BF_NO_REV), n_empty);
+			n_seq = rb3h_seq_read(fp, &seq, batch_cut(opt), !(opt->flag & BF_NO_FOR), !(opt->flag & BF_NO_REV), n_empty);
 			if (n_seq < 0) {
-				if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: FASTX parsing error (code %ld)\n", (long)n_seq);
+				if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: failed to read sequences (code %ld)\n", (long)n_seq);
 				break;
 			}
+			if (rb3h_seq_error(fp) && seq.l != l0 && rb3h_verbose >= 1) /* the records before the error are indexed, as in io.c:121-124 */
+				fprintf(stderr, "ERROR: FASTX parsing error (code %d)\n", rb3h_seq_error(fp));
 			if (n_seq == 0 && seq.l == l0) break; /* EOF */
 			n_seq_acc += n_seq;
 			if (rb3h_verbose >= 3)
 				fprintf(stderr, "[M::%s::%.3f*%.2f] read %ld symbols from file '%s'\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)(seq.l - l0), files[i]);
-			if (opt->rebatch && !(opt->batch_size > 0 && seq.l > opt->batch_size)) break; /* keep filling from the next file */
+			if (opt->rebatch && !(batch_cut(opt) > 0 && seq.l > batch_cut(opt))) break; /* keep filling from the next file */
 			if ((ret = submit(data, &seq, n_seq_acc, 0)) != 0) break;
 			n_seq_acc = 0;
 		}
@@ -454,6 +477,9 @@ static const struct option long_opts[] = {
 	{ "rebatch", no_argument, 0, 303 },
 	{ "gpu-sort", no_argument, 0, 304 },
 	{ "host-sort", no_argument, 0, 305 },
+	{ "gpu-batch", required_argument, 0, 306 },
+	{ "gpu-sort-limit", required_argument, 0, 307 }, /* (tests: pretend the GPU sorter takes less than it does) */
+	{ "host-fmd", no_argument, 0, 308 },
 	{ 0, 0, 0, 0 }
 };
 
@@ -493,8 +519,13 @@ int main_build(int argc, char *argv[])
 		else if (c == 303) opt.rebatch = 1;
 		else if (c == 304) opt.gpu_sort = 1;
 		else if (c == 305) opt.gpu_sort = 0;
+		else if (c == 306) opt.gpu_batch = rb3h_parse_num(optarg);
+		else if (c == 307) opt.gpu_sort_limit = rb3h_parse_num(optarg);
+		else if (c == 308) opt.host_fmd = g_host_fmd = 1;
 		else if (c == '?') return 1;
 	}
+	if (opt.gpu_sort_limit > (int64_t)INT32_MAX - 16) opt.gpu_sort_limit = (int64_t)INT32_MAX - 16;
+	if (opt.gpu_batch <= 0 || opt.gpu_batch > opt.gpu_sort_limit - 1) opt.gpu_batch = opt.gpu_sort_limit - 1;
 	if (argc == optind && fn_in == 0) return usage_build(stderr, &opt);
 	if ((opt.flag & BF_NO_FOR) && (opt.flag & BF_NO_REV)) {
 		fprintf(stderr, "ERROR: -F and -R together leave nothing to index\n");
@@ -597,6 +628,9 @@ int main_build(int argc, char *argv[])
 				(long)st.n_symbols_merged, st.ms_h2d + st.ms_lf + st.ms_rank + st.ms_build, st.ms_h2d, st.ms_lf, st.ms_rank, st.ms_build, st.bytes_index / 1e6);
 		if (st.ms_sort > 0)
 			fprintf(stderr, "[M::%s] GPU suffix sorting: %.3f ms in all (%ld doubling rounds), text upload included\n", __func__, st.ms_sort, (long)st.n_sort_rounds);
+		fprintf(stderr, "[M::%s] batches: %ld (%ld symbols) suffix-sorted on the GPU, %ld (%ld symbols) on the host; -m %ld%s\n", __func__,
+				(long)g_sorted.n_gpu, (long)g_sorted.sym_gpu, (long)g_sorted.n_host, (long)g_sorted.sym_host, (long)opt.batch_size,
+				batch_cut(&opt) != opt.batch_size ? " cut into GPU sub-batches (--gpu-batch)" : "");
 	}
 	rb3gpu_destroy(h);
 	if (ret != 0) { fprintf(stderr, "ERROR: failed to write the index (code %d)\n", ret); return 1; }
@@ -638,6 +672,7 @@ int main_merge(int argc, char *argv[])
 		else if (c == 'd') fmt = FMT_FMD;
 		else if (c == 'b') fmt = FMT_FMR;
 		else if (c == 301) device = atoi(optarg);
+		else if (c == 308) g_host_fmd = 1;
 		else if (c == '?') return 1;
 	}
 	if (argc - optind < 2) {
@@ -663,7 +698,7 @@ int main_merge(int argc, char *argv[])
 		{ /* an FMD file: decoded on the device and merged as one batch */
 			uint64_t *z = 0;
 			int64_t nw = 0, mc[6];
-			if (!getenv("RB3GPU_HOST_FMD") && rb3h_fmd_read_words(argv[i], &z, &nw, mc) == 0) {
+			if (!g_host_fmd && rb3h_fmd_read_words(argv[i], &z, &nw, mc) == 0) {
 				ret = rb3gpu_merge_fmd_words(h, nw, z, mc);
 				free(z);
 				if (ret == 0) {
@@ -719,6 +754,7 @@ int main_ssa(int argc, char *argv[])
 		else if (c == 's') ssa_shift = atoi(optarg);
 		else if (c == 'o') fn = optarg;
 		else if (c == 301) device = atoi(optarg);
+		else if (c == 308) g_host_fmd = 1;
 		else if (c == '?') return 1;
 	}
 	if (argc == optind) {

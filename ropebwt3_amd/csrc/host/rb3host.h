@@ -13,7 +13,7 @@
 extern "C" {
 #endif
 
-#define RB3H_VERSION "3.10-r281-mi355x-r1"
+#define RB3H_VERSION "3.10-r281-mi355x-r2"
 
 extern int rb3h_verbose;
 
@@ -25,7 +25,9 @@ double rb3h_percent_cpu(void);
 long rb3h_peakrss(void);
 void rb3h_init(void);
 
-/* ---- suffix sorting of one batch (sais-ss.c:50-56) ---- */
+/* ---- suffix sorting of one batch (sais-ss.c:50-56) ----
+ * n_threads is there for signature parity with rb3_build_sais and is IGNORED: this from-scratch SA-IS is sequential
+ * (parallelism on the host side is `-p N`: N batches at once).  It is the fallback sorter only. */
 int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads);
 /* same, plus the LF-walker list for rb3gpu_merge_plain_walkers (layout = rb3gpu_walker_t): the
  * sampled inverse suffix array is free here because the suffix array is still in memory */
@@ -44,6 +46,7 @@ void rb3h_seq_close(rb3h_seqio_t *fp);                                     /* io
  * seq->l > max_len; returns the number of strings appended (0 at EOF) or <0 on a parse error;
  * *n_empty counts records of length 0, which are skipped (out of contract in the reference) */
 int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is_for, int is_rev, int64_t *n_empty);
+int rb3h_seq_error(const rb3h_seqio_t *fp); /* != 0: a FASTX parsing error ended the file early (code as in kseq: -2 truncated quality, ...) */
 void rb3h_char2nt6(int64_t l, uint8_t *s);                                 /* io.c:23-28 */
 void rb3h_revcomp6(int64_t l, uint8_t *s);                                 /* io.c:30-40 */
 

@@ -6,6 +6,10 @@
  * j+1 < A < C < G < T < N", so any correct suffix sorter yields the same bytes; this one is a
  * from-scratch SA-IS (see sais_core.h).  The partial BWT stays on the host by design
  * (north_star); it is not part of the timed merge path.
+ *
+ * The sorter is SEQUENTIAL.  `n_threads` is accepted so that the call reads like rb3_build_sais(n_seq, len, seq,
+ * n_threads) and is ignored: host-side parallelism comes from the CLI's `-p N` (N batches sorted at once, one
+ * thread each), and the default path does not come here at all (batches are cut to fit the GPU sorter, main.c).
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -14,6 +14,7 @@
 struct rb3h_seqio_s {
 	gzFile fp;
 	int is_line, is_eof, last_char;
+	int err;          /* FASTX parsing error met (code < -1); nothing more is read from the file */
 	int beg, end;
 	uint8_t *buf;
 	rb3h_buf_t rec, qual;
@@ -182,6 +183,7 @@ int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is
 {
 	int64_t n_seq = 0, ret;
 	if (!is_for && !is_rev) return -3;
+	if (fp->err) return 0; /* like the end of the file (the reference's loop ends there too, build.c:212) */
 	for (;;) {
 		ret = fp->is_line ? sio_getline(fp, &fp->rec, 0) : sio_read_fastx(fp);
 		if (ret < 0) break;
@@ -195,6 +197,8 @@ int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is
 		n_seq += ret;
 		if (max_len > 0 && seq->l > max_len) break; /* io.c:114,119 */
 	}
-	if (!fp->is_line && ret < -1) return ret; /* FASTX parsing error */
+	if (!fp->is_line && ret < -1) fp->err = (int)ret; /* FASTX parsing error: the records read before it still count (io.c:121-124) */
 	return n_seq;
 }
+
+int rb3h_seq_error(const rb3h_seqio_t *fp) { return fp->err; }

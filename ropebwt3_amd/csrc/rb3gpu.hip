@@ -41,8 +41,30 @@ struct Buf {
 	size_t cap = 0;
 };
 
+/* Diagnostic switches of a handle.  They are read from the environment ONCE, in rb3gpu_create (RB3GPU_<KEY>), and can be
+ * changed on a live handle with rb3gpu_tune(); nothing on the merge path calls getenv().  The keys under
+ * RB3GPU_TEST_HOOKS only exist in the test build of the library (librb3gpu_hooks.so): the release build has no code
+ * that pretends a failure. */
+struct Tune {
+	int tent = 1;            // tentative records (0: every inexact walker runs until it is exact)
+	int staged = 0;          // the three-stage merge (several host syncs) instead of the single-sync one
+	int group_rebuild = 0;   // group-sequential rebuild kernels instead of the window-parallel ones
+	int window_rebuild = 0;  // the per-window rebuild (k_pass1w) instead of the run-space rebuild per group
+	int octs = 8;            // octets per wave of k_chain
+	int blkmul = 1;          // launch width multiplier of k_chain
+	int64_t blkcap = 2048;   // block cap of k_chain
+	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
+	int lf_check = 0;        // sampled LF-consistency check of pos[] after every merge (0: off, n: every n-th row)
+#ifdef RB3GPU_TEST_HOOKS
+	int force_fallback = 0;  // pretend the tentative pass left unsettled records
+	int64_t tent_limit = -1; // shrink the stretch table
+	int text_mode = 0;       // force how the text-order words are fetched (1: per lane, 2: 64 bytes per octet)
+#endif
+};
+
 struct rb3gpu_s {
 	int dev = 0;
+	Tune tn;
 	hipStream_t st = nullptr;
 	rb3gpu_opt_t opt;
 	rb3gpu_stats_t stt;
@@ -184,6 +206,51 @@ int rb3gpu_device_count(void)
 	return n;
 }
 
+
+static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
+{
+	Tune &t = h->tn;
+	if (!strcmp(key, "tent")) t.tent = v != 0;
+	else if (!strcmp(key, "staged")) t.staged = v != 0;
+	else if (!strcmp(key, "group_rebuild")) t.group_rebuild = v != 0;
+	else if (!strcmp(key, "window_rebuild")) t.window_rebuild = v != 0;
+	else if (!strcmp(key, "octs")) t.octs = v < 1 ? 1 : v > 8 ? 8 : (int)v;
+	else if (!strcmp(key, "blkmul")) t.blkmul = v < 1 ? 1 : (int)v;
+	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
+	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
+	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
+	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode")) {
+#ifdef RB3GPU_TEST_HOOKS
+		if (!strcmp(key, "force_fallback")) t.force_fallback = v != 0;
+		else if (!strcmp(key, "tent_limit")) t.tent_limit = v;
+		else t.text_mode = v == 1 || v == 2 ? (int)v : 0;
+#else
+		return RB3GPU_EUNSUP; // test hooks are compiled out of the release library
+#endif
+	} else return RB3GPU_EINVAL;
+	return 0;
+}
+
+int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
+{
+	if (!h || !key) return RB3GPU_EINVAL;
+	return tune_set(h, key, value);
+}
+
+static void tune_from_env(rb3gpu_t *h) // once per handle
+{
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "octs", "blkmul", "blkcap", "ssa_split", "lf_check",
+		"force_fallback", "tent_limit", "text_mode", nullptr };
+	for (int i = 0; keys[i]; ++i) {
+		char name[64] = "RB3GPU_";
+		size_t l = strlen(name);
+		for (const char *p = keys[i]; *p && l + 1 < sizeof(name); ++p) name[l++] = (char)(*p >= 'a' && *p <= 'z' ? *p - 32 : *p);
+		name[l] = 0;
+		const char *v = getenv(name);
+		if (v && *v) (void)tune_set(h, keys[i], atoll(v));
+	}
+}
+
 rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
 {
 	rb3gpu_opt_t o;
@@ -197,6 +264,7 @@ rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
 	rb3gpu_t *h = new (std::nothrow) rb3gpu_s();
 	if (!h) return nullptr;
 	h->dev = o.device, h->opt = o;
+	tune_from_env(h);
 	memset(&h->stt, 0, sizeof(h->stt));
 	if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
 	for (int i = 0; i < 8; ++i)
@@ -293,9 +361,9 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
  * otherwise the interleave of the current index with d_b2 at merged positions pos[].
  * nosync: size the slot array by its upper bound (one slot per window) and do not wait for the
  * scan totals; the caller reads them from misc[MISC_IX_TOT..] after its own sync. */
-static bool use_winpar(int64_t nwin)
+static bool use_winpar(const rb3gpu_t *h, int64_t nwin)
 {
-	return (size_t)nwin * 216 <= ((size_t)8 << 30) && !getenv("RB3GPU_GROUP_REBUILD");
+	return (size_t)nwin * 216 <= ((size_t)8 << 30) && !h->tn.group_rebuild;
 }
 
 extern "C++" {
@@ -320,7 +388,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	}
 	// window-parallel kernels (one wave per 256-symbol window, planes cached between the passes) unless
 	// their scratch (216 B per window) would be unreasonably large; then one wave per 8192-symbol group
-	const bool winpar = use_winpar(nwin);
+	const bool winpar = use_winpar(h, nwin);
 	if (winpar) {
 		if ((r = buf_ensure(h, h->wstat, (size_t)nwin * 16)) < 0) return r;
 		if ((r = buf_ensure(h, h->wplane, (size_t)nwin * 96)) < 0) return r;
@@ -495,19 +563,22 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 		}
 	}
 	// tentative records need merged positions < 2^38
-	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
+	if (!h->tn.tent) tent = 0;
 	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= (1LL << RB3_TENT_PBITS) || stop_row >= 0) tent = 0;
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
-	const uint32_t sid_limit = getenv("RB3GPU_TEST_TENT_LIMIT") ? (uint32_t)atoi(getenv("RB3GPU_TEST_TENT_LIMIT")) : 0xFFFFFFFFu; // test hook: a tiny stretch table
+#ifdef RB3GPU_TEST_HOOKS
+	const uint32_t sid_limit = h->tn.tent_limit >= 0 ? (uint32_t)h->tn.tent_limit : 0xFFFFFFFFu; // test hook: a tiny stretch table
+#else
+	const uint32_t sid_limit = 0xFFFFFFFFu;
+#endif
 	uint32_t *sidctr = (uint32_t*)(qhead + 5);
 	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
 	HIPCHK(hipMemsetAsync(qhead, 0, 8, h->st));
 	HIPCHK(hipMemsetAsync(sidctr, 0, 8, h->st));
 	// octets per wave: all 8 when there are enough walkers to fill the chip (256 CUs x 32 waves), fewer
 	// when the launch is latency-bound anyway
-	int octs = 8; // measured: fewer octets per wave (more waves) is slower even for few walkers
-	if (getenv("RB3GPU_OCTS")) octs = atoi(getenv("RB3GPU_OCTS"));
+	const int octs = h->tn.octs; // 8 by default; measured: fewer octets per wave (more waves) is slower even for few walkers
 	int64_t nblk = (nwalk + 4 * octs - 1) / (4 * octs);
 	if (nblk > 256 * 8) nblk = 256 * 8;
 	if (nblk < 1) nblk = 1;
@@ -692,8 +763,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw)
 {
 	const int64_t ntot = h->n + len, nwin = (ntot >> RB3_WIN_BITS) + 1;
-	int tent = 1;
-	if (getenv("RB3GPU_TENT") && atoi(getenv("RB3GPU_TENT")) == 0) tent = 0;
+	int tent = h->tn.tent;
 	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
 	// no list but a count: one walker per string (n_walkers = number of strings), made on the device
 	const bool per_string = !walkers && n_walkers > 0;
@@ -702,7 +772,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (per_string) tent = 0; // every walker is exact
 	for (int64_t i = 0; walkers && i < n_walkers; ++i)
 		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) return RB3GPU_EINVAL;
-	if ((!walkers && !per_string) || n_walkers > (1 << 24) || n_walkers > len || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || getenv("RB3GPU_STAGED")) {
+	if ((!walkers && !per_string) || n_walkers > (1 << 24) || n_walkers > len || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || h->tn.staged) {
 		if (per_string) return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, tent_auto);
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, tent);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
@@ -715,10 +785,14 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
-	const uint32_t sid_limit = getenv("RB3GPU_TEST_TENT_LIMIT") ? (uint32_t)atoi(getenv("RB3GPU_TEST_TENT_LIMIT")) : 0xFFFFFFFFu; // test hook: a tiny stretch table
+#ifdef RB3GPU_TEST_HOOKS
+	const uint32_t sid_limit = h->tn.tent_limit >= 0 ? (uint32_t)h->tn.tent_limit : 0xFFFFFFFFu; // test hook: a tiny stretch table
+#else
+	const uint32_t sid_limit = 0xFFFFFFFFu;
+#endif
 	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, nwin)) < 0) return r;
-	const bool rows_fused = !rank_only && use_winpar(nwin);
+	const bool rows_fused = !rank_only && use_winpar(h, nwin);
 	if (rows_fused && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	Walker *dwl = (Walker*)h->wl.p;
@@ -747,12 +821,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int64_t *dpos = (int64_t*)h->pos.p;
 	{
 		const IdxView iv = view_of(h);
-		int octs = 8;
-		if (getenv("RB3GPU_OCTS")) octs = atoi(getenv("RB3GPU_OCTS"));
-		int64_t nblk = (n_walkers + 4 * octs - 1) / (4 * octs);
-		if (getenv("RB3GPU_BLKMUL")) nblk *= atoi(getenv("RB3GPU_BLKMUL"));
+		const int octs = h->tn.octs;
+		int64_t nblk = (n_walkers + 4 * octs - 1) / (4 * octs) * h->tn.blkmul;
 		// persistent waves: 2048 blocks x 4 waves fill the chip once (256 CUs x 32); more blocks only queue behind them (measured: 10 % slower at 4096)
-		{ const int64_t cap = getenv("RB3GPU_BLKCAP") ? atoll(getenv("RB3GPU_BLKCAP")) : 2048; nblk = nblk > cap ? cap : nblk < 1 ? 1 : nblk; }
+		{ const int64_t cap = h->tn.blkcap; nblk = nblk > cap ? cap : nblk < 1 ? 1 : nblk; }
 #ifdef RB3_PROF
 		fprintf(stderr, "[prof] launching %lld blocks x 256 threads, %d octets per wave, %lld walkers\n", (long long)nblk, octs, (long long)n_walkers);
 #endif
@@ -761,7 +833,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #define RB3_LAUNCH_FAST(D, T, X) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw)
 		// text-order words: per-lane loads while the L1 can hold a line per walker (256 CUs x 32 waves x 8 octets), else 64-byte fetches
-		const int text_mode = !d_tw ? 0 : getenv("RB3GPU_TEST_TEXT_MODE") ? (atoi(getenv("RB3GPU_TEST_TEXT_MODE")) == 2 ? 2 : 1) : n_walkers <= 65536 ? 1 : 2; // (the variable is a test hook)
+		int text_mode = !d_tw ? 0 : n_walkers <= 65536 ? 1 : 2;
+#ifdef RB3GPU_TEST_HOOKS
+		if (d_tw && h->tn.text_mode) text_mode = h->tn.text_mode;
+#endif
 		switch ((iv.dense == 2 ? 12 : 0) + (tent ? 6 : 0) + text_mode) {
 		case 14: RB3_LAUNCH_FAST(true, false, 2); break;
 		case 13: RB3_LAUNCH_FAST(true, false, 1); break;
@@ -817,7 +892,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
 	if (tent) {
 		tent_used(h, hm[5]);
-		if (getenv("RB3GPU_TEST_FORCE_FALLBACK")) hm[4] = 1; // test hook: exercise the redo path
+#ifdef RB3GPU_TEST_HOOKS
+		if (h->tn.force_fallback) hm[4] = 1; // test hook: exercise the redo path
+#endif
 	}
 	if (tent && hm[4] != 0) { // some tentative record was left unsettled: nothing was installed, redo without them
 		h->stt.n_fallbacks += 1;
@@ -1169,16 +1246,21 @@ static int sorter_impl(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, voi
 		pthread_mutex_unlock(&s->mtx);
 		return r;
 	}
+	r = 0;
 	if (s->stage) { // pageable -> pinned -> device, chunk by chunk
-		for (int64_t off = 0; off < len; off += (int64_t)RB3_STAGE_BYTES) {
+		for (int64_t off = 0; off < len && r == 0; off += (int64_t)RB3_STAGE_BYTES) {
 			const size_t n = (size_t)(len - off) < RB3_STAGE_BYTES ? (size_t)(len - off) : RB3_STAGE_BYTES;
 			memcpy(s->stage, text + off, n);
-			SCHK(hipMemcpyAsync((uint8_t*)s->text + off, s->stage, n, hipMemcpyHostToDevice, s->st));
-			SCHK(hipStreamSynchronize(s->st));
+			if (hipMemcpyAsync((uint8_t*)s->text + off, s->stage, n, hipMemcpyHostToDevice, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess) r = -2;
 		}
-	} else {
-		SCHK(hipMemcpyAsync(s->text, text, (size_t)len, hipMemcpyHostToDevice, s->st));
-		SCHK(hipStreamSynchronize(s->st));
+	} else if (hipMemcpyAsync(s->text, text, (size_t)len, hipMemcpyHostToDevice, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess) r = -2;
+	if (r < 0) { // the upload failed: give the output slot back, or the next two calls would wait for it for ever
+		(void)hipGetLastError();
+		pthread_mutex_lock(&s->mtx);
+		s->busy[slot] = 0;
+		pthread_cond_broadcast(&s->cv);
+		pthread_mutex_unlock(&s->mtx);
+		return RB3GPU_ENODEV;
 	}
 	r = rb3sort_bwt(s->ws, s->st, len, (const uint8_t*)s->text, (uint8_t*)s->out[slot], step, nck > 0 ? (int64_t*)s->ck : nullptr, &rounds,
 			d_tw ? (uint64_t*)((uint8_t*)s->out[slot] + tw_off) : nullptr);
@@ -1240,8 +1322,7 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa)
 	// splitter spacing: the walk's longest sublist is about 2^S ln(number of splitters) steps, and every splitter
 	// costs a queue pull; the linking is pointer jumping, whose cost hardly depends on S
 	// (141 M rows, 32 strings: walk 14.5 / 9.6 / 11.7 / 18.6 ms for S = 7 / 8 / 9 / 10)
-	int S = 8;
-	if (getenv("RB3GPU_SSA_SPLIT")) S = atoi(getenv("RB3GPU_SSA_SPLIT"));
+	int S = h->tn.ssa_split;
 	if (S < 4) S = 4;
 	if (S > 20) S = 20;
 	const int64_t nsp = m + ((h->n - m + (1LL << S) - 1) >> S);

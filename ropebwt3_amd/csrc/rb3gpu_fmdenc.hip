@@ -154,6 +154,13 @@ __global__ void __launch_bounds__(256) k_fe_pack(const uint64_t *words, int64_t 
 /* d_words: nr words start << 3 | sym of the maximal runs of a BWT of n_sym symbols (device).  On success (0) *z_out is
  * a malloc'ed host array of *n_words words: the FMD data section incl. the trailing header.  1: this index needs block
  * headers wider than 16 bits somewhere (pack on the host); < 0: -1 out of memory, -2 HIP error, -3 internal. */
+/* RB3GPU_FMD_DEBUG=1: say why the packer declined an index (read once) */
+static bool fmd_debug(void)
+{
+	static const bool on = getenv("RB3GPU_FMD_DEBUG") != nullptr;
+	return on;
+}
+
 int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words)
 {
 	int ret = 0;
@@ -184,7 +191,7 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	FE_HIP(hipMemcpyAsync(hCn, Cn, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
-	if (hflag[0] & 1u) { if (getenv("RB3GPU_FMD_DEBUG")) fprintf(stderr, "[fmdenc] a code of 64 bits or more\n"); ret = 1; goto done; }
+	if (hflag[0] & 1u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] a code of 64 bits or more\n"); ret = 1; goto done; }
 	// the chain, one superblock at a time: the host walks the chunk tables
 	for (;;) {
 		const int64_t s = gb0 | (FE_SB_BLOCKS - 1); // global index of this superblock's last block
@@ -223,7 +230,7 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
 	if (hflag[0] & 4u) { ret = -3; goto done; }
-	if (hflag[0] & 3u) { if (getenv("RB3GPU_FMD_DEBUG")) fprintf(stderr, "[fmdenc] flags %u: a block needs a wider header\n", hflag[0]); ret = 1; goto done; }
+	if (hflag[0] & 3u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a wider header\n", hflag[0]); ret = 1; goto done; }
 	if ((host = (uint64_t*)malloc((size_t)(8 * B + 8) * 8)) == nullptr) { ret = -1; goto done; }
 	FE_HIP(hipMemcpy(host, out, (size_t)(8 * B + 2) * 8, hipMemcpyDeviceToHost));
 	*z_out = host, *n_words = 8 * B + 2, host = nullptr;

@@ -17,7 +17,7 @@ from . import _build
 
 ASIZE = 6
 
-_ERR = {0: "OK", -1: "ENODEV", -2: "ENOMEM", -3: "EINVAL", -4: "ESYMBOL", -5: "ESTATE", -6: "EINTERNAL"}
+_ERR = {0: "OK", -1: "ENODEV", -2: "ENOMEM", -3: "EINVAL", -4: "ESYMBOL", -5: "ESTATE", -6: "EINTERNAL", -7: "EUNSUP"}
 
 
 class Rb3GpuError(RuntimeError):
@@ -85,6 +85,7 @@ SYMBOLS = {
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_from_fmd_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_merge_fmd_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_tune": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),
     "rb3gpu_dev_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
@@ -95,15 +96,16 @@ SYMBOLS = {
     "rb3gpu_device_count": (ctypes.c_int, []),
 }
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Load librb3gpu.so (the in-tree build) and declare every prototype.  Raises if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("RB3GPU_LIB", _build.LIB_GPU)  # override for kernel experiments only
+def load_library(hooks=False):
+    """Load librb3gpu.so (the in-tree build) and declare every prototype.  Raises if absent.
+    hooks=True: the test build (librb3gpu_hooks.so, -DRB3GPU_TEST_HOOKS), whose rb3gpu_tune also knows the keys that
+    make a merge pretend a failure; only tests load it."""
+    path = _build.LIB_GPU_HOOKS if hooks else os.environ.get("RB3GPU_LIB", _build.LIB_GPU)  # override for kernel experiments only
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the engine is HIP-only; there is no CPU fallback)" % path)
@@ -111,7 +113,7 @@ def load_library():
     for name, (res, args) in SYMBOLS.items():
         f = getattr(lib, name)  # AttributeError if the header and the library disagree
         f.restype, f.argtypes = res, args
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
@@ -123,8 +125,8 @@ def _u8(a):
 class Rb3Gpu:
     """One accumulated BWT resident in the HBM of one MI355X."""
 
-    def __init__(self, device=0, split_log2=0, verbose=1):
-        self._lib = load_library()
+    def __init__(self, device=0, split_log2=0, verbose=1, hooks=False):
+        self._lib = load_library(hooks)
         n = self._lib.rb3gpu_device_count()
         if n <= 0:
             raise RuntimeError("no HIP device visible (rb3gpu_device_count=%d); the engine has no CPU fallback" % n)
@@ -145,6 +147,10 @@ class Rb3Gpu:
             self.close()
         except Exception:
             pass
+
+    def tune(self, key, value):
+        """rb3gpu_tune: a diagnostic switch of this handle (see include/rb3gpu.h)"""
+        self._chk(self._lib.rb3gpu_tune(self._h, key.encode(), int(value)), "rb3gpu_tune(%s)" % key)
 
     def _chk(self, r, what):
         if r < 0:

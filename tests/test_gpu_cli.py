@@ -99,7 +99,7 @@ def test_merge_subcommand(tmp_path):
     out, err = run(["merge", "-d"] + parts)
     assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
     assert err.count("FMD words into") == len(parts)      # every operand was decoded on the device
-    r = subprocess.run([CLI, "merge", "-d"] + parts, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, RB3GPU_HOST_FMD="1"))
+    r = subprocess.run([CLI, "merge", "-d", "--host-fmd"] + parts, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"] and b"FMD words into" not in r.stderr   # and the host decoder agrees
     fmr, _ = run(["merge"] + parts)   # default output is FMR like the reference
     p = tmp_path / "m.fmr"
@@ -164,7 +164,7 @@ def test_differential_fuzz_against_the_reference_binary():
 
 def test_fmd_packed_on_gpu_and_on_host_agree(tmp_path):
     """the .fmd data section is packed on the GPU when every block has a 16-bit header (read-like data) and on the
-    host otherwise (RB3GPU_HOST_FMD=1 forces the host packer): both paths give the golden bytes, and the GPU packer
+    host otherwise (--host-fmd forces the host packer): both paths give the golden bytes, and the GPU packer
     really ran for the read fixtures"""
     for name in ("reads_fq", "reads_fwd", "genomes12", "copies3000", "longruns", "k3_both"):
         ent = MAN[name]
@@ -173,19 +173,17 @@ def test_fmd_packed_on_gpu_and_on_host_agree(tmp_path):
         assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], name
         if name.startswith("reads"):
             assert "packed the FMD on the GPU" in err
-        env = dict(os.environ, RB3GPU_HOST_FMD="1")
-        r = subprocess.run([CLI, "build"] + ent["flags"] + ["-d"] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        r = subprocess.run([CLI, "build", "--host-fmd"] + ent["flags"] + ["-d"] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], name
         assert b"packed the FMD on the GPU" not in r.stderr
 
 
 def test_oversized_batches_go_to_the_host_sorter():
-    """batches the GPU sorter does not take (2^31 symbols or more; here the limit is lowered through the test hook)
-    are sorted on the host in the same run: same .fmd, serial and pipelined"""
+    """batches the GPU sorter does not take (a single record of 2^31 symbols or more; here the limit is lowered with
+    --gpu-sort-limit) are sorted on the host in the same run: same .fmd, serial and pipelined"""
     ent = MAN["genomes12"]
     for limit, on_gpu in (("1000", False), ("100000", True)):
-        env = dict(os.environ, RB3GPU_TEST_SORT_MAX=limit)
         for extra in ([], ["-p2"], ["-p0"]):
-            r = subprocess.run([CLI, "build", "-d", "-m45k"] + extra + [os.path.join(util.GOLDEN, ent["inputs"][0])], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            r = subprocess.run([CLI, "build", "-d", "-m45k", "--gpu-sort-limit", limit] + extra + [os.path.join(util.GOLDEN, ent["inputs"][0])], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], (limit, extra)
             assert ("symbols on the GPU" in r.stderr.decode()) == on_gpu

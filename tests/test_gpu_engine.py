@@ -296,9 +296,9 @@ def test_stretch_table_exhaustion(oracle, limit):
     b1 = host.build_bwt(util.make_text(rel))
     b2, w = host.build_bwt_walkers(util.make_text([util.mutate(rng, g0, 0.002), rel[3].copy()]), 200)
     want = oracle.merge(b1, b2)
-    os.environ["RB3GPU_TEST_TENT_LIMIT"] = str(limit)
     try:
-        h = Rb3Gpu(verbose=1)
+        h = Rb3Gpu(verbose=1, hooks=True)
+        h.tune("tent_limit", limit)
         h.from_plain(b1)
         h.merge_plain_walkers(b2, w)
         st = h.stats()
@@ -307,7 +307,7 @@ def test_stretch_table_exhaustion(oracle, limit):
         assert h.get_tot() == b1.size + 2 * b2.size
         h.close()
     finally:
-        os.environ.pop("RB3GPU_TEST_TENT_LIMIT", None)
+        pass
     print("limit", limit, "fallbacks", st["n_fallbacks"], "steps", st["n_lf_steps"])
 
 
@@ -321,9 +321,9 @@ def test_fallback_path_redoes_the_rank_phase(oracle):
     b1 = host.build_bwt(util.make_text([g0]))
     b2, w = host.build_bwt_walkers(util.make_text([util.mutate(rng, g0, 0.002)]), 256)
     want = oracle.merge(b1, b2)
-    os.environ["RB3GPU_TEST_FORCE_FALLBACK"] = "1"
     try:
-        h = Rb3Gpu(verbose=1)
+        h = Rb3Gpu(verbose=1, hooks=True)
+        h.tune("force_fallback", 1)
         h.from_plain(b1)
         h.merge_plain_walkers(b2, w)
         st = h.stats()
@@ -331,7 +331,7 @@ def test_fallback_path_redoes_the_rank_phase(oracle):
         assert np.array_equal(h.export_plain(), want)
         h.close()
     finally:
-        os.environ.pop("RB3GPU_TEST_FORCE_FALLBACK", None)
+        pass
 
 
 @pytest.mark.parametrize("seed,kind", [(61, "genomes"), (62, "reads"), (63, "runs"), (64, "tiny")])
@@ -363,16 +363,12 @@ def test_ssa_gen_vs_oracle(oracle, seed, kind):
         for ss in (0, 2, 5, 8, 13):
             want = oracle.ssa_gen(b, ss)
             for S in (None, 4, 7, 20):
-                if S is None:
-                    os.environ.pop("RB3GPU_SSA_SPLIT", None)
-                else:
-                    os.environ["RB3GPU_SSA_SPLIT"] = str(S)
+                h.tune("ssa_split", 8 if S is None else S)
                 ms, r2i, ssa = h.ssa_gen(ss)
                 assert ms == want[0]
                 assert np.array_equal(r2i, want[1]), (ss, S)
                 assert np.array_equal(ssa, want[2]), (ss, S)
     finally:
-        os.environ.pop("RB3GPU_SSA_SPLIT", None)
         h.close()
 
 
@@ -493,7 +489,7 @@ def test_whole_index_merge_on_device(oracle):
 
 
 @pytest.mark.parametrize("env", [{"RB3GPU_GROUP_REBUILD": "1"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_GROUP_REBUILD": "1", "RB3GPU_STAGED": "1"},
-                                 {"RB3GPU_TEST_TEXT_MODE": "2"}])
+                                 {"RB3GPU_TEXT_MODE": "2"}, {"RB3GPU_WINDOW_REBUILD": "1"}])
 def test_fallback_code_paths_via_soak(env):
     """the group-sequential rebuild kernels (taken when the window scratch would exceed 8 GB) and the staged merge
     (taken for walker-less or oversized merges) forced through the randomised soak"""
@@ -603,8 +599,8 @@ def test_merge_text_order_words_vs_oracle(oracle, seed, kind):
         h.close()
 
 
-@pytest.mark.parametrize("env", [{"RB3GPU_TEST_FORCE_FALLBACK": "1"}, {"RB3GPU_TEST_TENT_LIMIT": "40"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_TENT": "0"},
-                                 {"RB3GPU_TEST_TEXT_MODE": "2"}, {"RB3GPU_TEST_TEXT_MODE": "2", "RB3GPU_TENT": "0"}, {"RB3GPU_TEST_TEXT_MODE": "1"}])
+@pytest.mark.parametrize("env", [{"force_fallback": 1}, {"tent_limit": 40}, {"staged": 1}, {"tent": 0},
+                                 {"text_mode": 2}, {"text_mode": 2, "tent": 0}, {"text_mode": 1}, {"window_rebuild": 1}])
 def test_merge_text_order_fallback_paths(oracle, env):
     """the redo path, a stretch table that runs out, the staged path and the walk without tentative records, all
     entered from rb3gpu_merge_text_dev (the walkers are converted to rows on the device where row words are walked)"""
@@ -616,20 +612,20 @@ def test_merge_text_order_fallback_paths(oracle, env):
     b1 = host.build_bwt(util.make_text(rel))
     t2 = util.make_text([util.mutate(rng, g0, 0.002), rel[3].copy()])
     want = oracle.merge(b1, host.build_bwt(t2.copy()))
-    os.environ.update(env)
     try:
-        h = Rb3Gpu(verbose=1)
+        h = Rb3Gpu(verbose=1, hooks=True)
+        for k, v in env.items():
+            h.tune(k, v)
         h.from_plain(b1)
         d_bwt, d_tw = h.sort_text(t2)
         h.merge_text_dev(d_bwt, d_tw, t2.size, host.walkers_text(t2, 200), commit=True)
         st = h.stats()
         assert np.array_equal(h.export_plain(), want)
-        if "RB3GPU_TEST_FORCE_FALLBACK" in env:
+        if "force_fallback" in env:
             assert st["n_fallbacks"] == 1
         h.close()
     finally:
-        for k in env:
-            os.environ.pop(k, None)
+        pass
 
 
 def test_config2_full_size_properties_and_oracle(oracle):

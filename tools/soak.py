@@ -33,7 +33,7 @@ for case in range(ncase):
     both = bool(rng.random() < 0.7)
     step = int(rng.choice([128, 200, 384, 1000]))
     per = int(rng.choice([1, 1, 2, 5]))          # genomes per batch
-    h = Rb3Gpu(verbose=1)
+    h = Rb3Gpu(verbose=1, hooks=bool(os.environ.get("RB3GPU_TEXT_MODE")))   # (test hooks need the test build of the library)
     cur = None
     for i in range(0, nrel, per):
         t = util.make_text(rel[i:i + per], True, both)

@@ -61,6 +61,8 @@ typedef struct {
 	double  ms_ssa_walk;         /* k_ssa_walk alone (one LF step per row of the index) */
 	double  ms_sort;             /* rb3gpu_bwt_from_text: upload + suffix sorting + BWT */
 	int64_t n_sort_rounds;       /* prefix-doubling rounds of those calls */
+	int64_t n_reb_groups;        /* groups (8192 symbols) of the merges whose rebuild went through the run-space kernel ... */
+	int64_t n_reb_groups_window; /* ... and how many of them it handed on to the per-window kernels (single-sync merges) */
 } rb3gpu_stats_t;
 
 void rb3gpu_opt_init(rb3gpu_opt_t *opt);
@@ -229,7 +231,7 @@ int rb3gpu_merge_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, 
 
 /* Diagnostic switches of a handle (no reference analogue; none is needed in normal use).  Each key is also read ONCE from
  * the environment variable RB3GPU_<KEY> when the handle is created; the merge path itself never calls getenv().
- *   "tent" 0/1, "staged" 0/1, "group_rebuild" 0/1, "window_rebuild" 0/1, "octs" 1..8, "blkmul", "blkcap", "ssa_split" 4..20,
+ *   "tent" 0/1, "staged" 0/1, "group_rebuild" 0/1, "window_rebuild" 0/1, "reb_force" 0/1, "octs" 1..8, "blkmul", "blkcap", "ssa_split" 4..20,
  *   "lf_check" n (verify the LF relation of every n-th batch row against the index after each merge; 0 = off)
  * Test hooks "force_fallback", "tent_limit", "text_mode" exist only in the test build of the library (compiled with
  * -DRB3GPU_TEST_HOOKS, librb3gpu_hooks.so); the release library answers RB3GPU_EUNSUP.  Unknown key: RB3GPU_EINVAL. */

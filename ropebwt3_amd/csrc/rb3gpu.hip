@@ -50,6 +50,7 @@ struct Tune {
 	int staged = 0;          // the three-stage merge (several host syncs) instead of the single-sync one
 	int group_rebuild = 0;   // group-sequential rebuild kernels instead of the window-parallel ones
 	int window_rebuild = 0;  // the per-window rebuild (k_pass1w) instead of the run-space rebuild per group
+	int reb_force = 0;       // the run-space rebuild whatever the row density and the old index look like (tests: the hand-over paths)
 	int octs = 8;            // octets per wave of k_chain
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
@@ -76,7 +77,7 @@ struct rb3gpu_s {
 	struct { rb3_grp_t *grp; size_t grp_cap; rb3_slot_t *slots; size_t slots_cap; } ib[2] = {{nullptr, 0, nullptr, 0}, {nullptr, 0, nullptr, 0}};
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane, wruns;
+	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane, wruns, gslots, glist;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -214,6 +215,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "staged")) t.staged = v != 0;
 	else if (!strcmp(key, "group_rebuild")) t.group_rebuild = v != 0;
 	else if (!strcmp(key, "window_rebuild")) t.window_rebuild = v != 0;
+	else if (!strcmp(key, "reb_force")) t.reb_force = v != 0;
 	else if (!strcmp(key, "octs")) t.octs = v < 1 ? 1 : v > 8 ? 8 : (int)v;
 	else if (!strcmp(key, "blkmul")) t.blkmul = v < 1 ? 1 : (int)v;
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
@@ -239,7 +241,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "octs", "blkmul", "blkcap", "ssa_split", "lf_check",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "octs", "blkmul", "blkcap", "ssa_split", "lf_check",
 		"force_fallback", "tent_limit", "text_mode", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -319,9 +321,17 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	if (!h) return;
 	(void)hipSetDevice(h->dev);
 	(void)hipStreamSynchronize(h->st);
+#ifdef RB3_PROF_REB
+	{
+		unsigned long long p[16];
+		if (hipMemcpyFromSymbol(p, HIP_SYMBOL(g_reb_prof), sizeof(p)) == hipSuccess && p[8])
+			fprintf(stderr, "[prof] k_reb_group: %llu groups done (rows %.1f, runs %.1f, slots %.2f per group); cycles per group: setup %.0f, runs %.0f, rows-load %.0f, rows %.0f, run items %.0f, heads %.0f, partition %.0f, slots %.0f\n",
+					p[8], (double)p[9] / p[8], (double)p[10] / p[8], (double)p[11] / p[8], (double)p[0] / p[8], (double)p[1] / p[8], (double)p[2] / p[8], (double)p[3] / p[8], (double)p[4] / p[8], (double)p[5] / p[8], (double)p[6] / p[8], (double)p[7] / p[8]);
+	}
+#endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane, &h->wruns };
+	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	for (int i = 0; i < 2; ++i) if (h->stage[i]) (void)hipHostFree(h->stage[i]);
@@ -352,15 +362,25 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
  *   [0] walker queue head  [1] LF steps  [2] rows unset  [3] rows out of order  [4] tentative unsettled
  *   [5] tentative stretches opened (u32)
  *   [16..23] totals of the batch scan (symbol counts of B2, [22] = bad bytes)
- *   [24..31] totals of the rebuild scan (symbol counts of the merged BWT, [30] = slots) */
+ *   [24..31] totals of the rebuild scan (symbol counts of the merged BWT, [30] = slots)
+ *   [14] (two u32) lengths of the two lists of groups the run-space rebuild hands on: after the small tier, after the large tier */
 #define MISC_WORDS   64
 #define MISC_LF_TOT  16
 #define MISC_IX_TOT  24
+#define MISC_RG_LISTS 14
 
 /* build a block array for ntot symbols into ib[1-cur]; FROM_PLAIN: symbols are d_b2[0..ntot);
  * otherwise the interleave of the current index with d_b2 at merged positions pos[].
  * nosync: size the slot array by its upper bound (one slot per window) and do not wait for the
  * scan totals; the caller reads them from misc[MISC_IX_TOT..] after its own sync. */
+/* does the run-space rebuild (k_reb_group) run for a merge of n2 rows into the current index?  (the statistics ask too) */
+static bool runspace_applies(const rb3gpu_t *h, int64_t n2, int64_t ntot)
+{
+	const int64_t nwin_old = (h->n >> RB3_WIN_BITS) + 1;
+	if (h->tn.window_rebuild || h->nslots == nwin_old) return false; // (a fully bit-plane index has no run slot to start from)
+	return h->tn.reb_force || (h->nslots * 2 < nwin_old && (double)n2 * RB3_GRP <= 260.0 * (double)ntot);
+}
+
 static bool use_winpar(const rb3gpu_t *h, int64_t nwin)
 {
 	return (size_t)nwin * 216 <= ((size_t)8 << 30) && !h->tn.group_rebuild;
@@ -396,6 +416,20 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		if (!FROM_PLAIN && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
 		jg = (int64_t*)h->jg.p;
 	}
+	// run-space rebuild per group (k_reb_group) wherever the old index is run-coded; what it leaves over goes through the
+	// window kernels.  A fully bit-plane index (old.dense) has nothing for it.
+	// (not where a group receives more rows than the tables of the run-space kernel take, and not where the old index is
+	// mostly bit planes -- few of its groups would qualify and every one that does not costs a hand-over)
+	const double rows_per_group = (double)n2 * RB3_GRP / (double)(ntot > 0 ? ntot : 1);
+	const bool runspace = runspace_applies(h, n2, ntot) && winpar && !FROM_PLAIN;
+	uint32_t *glist[2] = {nullptr, nullptr}, *nglist = nullptr;
+	uint8_t *gkind = nullptr;
+	if (runspace) {
+		if ((r = buf_ensure(h, h->gslots, (size_t)ngrp * RB3_RG_MAXSLOTS * sizeof(rb3_slot_t))) < 0) return r;
+		if ((r = buf_ensure(h, h->glist, (size_t)ngrp * 9 + 64)) < 0) return r;
+		glist[0] = (uint32_t*)h->glist.p, glist[1] = glist[0] + ngrp, gkind = (uint8_t*)(glist[1] + ngrp);
+		nglist = (uint32_t*)((uint64_t*)h->misc.p + MISC_RG_LISTS);
+	}
 	if (nosync && (r = ib_ensure(h, dst, ngrp, nwin)) < 0) return r; // before any launch: hipMalloc may synchronise
 	IdxView old = view_of(h);
 	uint32_t *gstat = (uint32_t*)h->gstat.p;
@@ -406,17 +440,42 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			HIPCHK(hipMemsetAsync(jg, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
 			hipLaunchKernelGGL(k_win_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, nwin, skip);
 		}
-		{
+		if (runspace) {
+			// Tiers by the average number of batch rows per group: the small-table kernel where most groups have few rows, then the
+			// medium one on what it left (or on all groups where the small one would mostly fail), then the window kernels on the
+			// list the last tier leaves (its length stays on the device: fixed grids, grid-stride loops).
+			HIPCHK(hipMemsetAsync(nglist, 0, 8, h->st));
+			const int64_t gw4 = (ngrp + RB3_RG_WAVES - 1) / RB3_RG_WAVES;
+			const unsigned grs = (unsigned)(gw4 < 3072 ? gw4 : 3072), grm = (unsigned)(gw4 < 2048 ? gw4 : 2048);
+			if (rows_per_group <= 96.0) {
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<384, 128, false, false>), dim3(grs), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
+						gstat, (uint4*)h->gslots.p, gkind, glist[1], nglist + 1, skip);
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<624, 320, true, true>), dim3(grm), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
+						gstat, (uint4*)h->gslots.p, gkind, glist[1], nglist + 1, skip);
+			} else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<624, 320, false, true>), dim3(grm), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
+						gstat, (uint4*)h->gslots.p, gkind, glist[1], nglist + 1, skip);
+			const unsigned gw = (unsigned)(nwin / RB3_REB_WAVES + 1 < 8192 ? nwin / RB3_REB_WAVES + 1 : 8192);
+			if (n2 * RB3_WIN > 3 * ntot)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 7, true>), dim3(gw), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
+						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1));
+			else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 3, true>), dim3(gw), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
+						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1));
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_decide<true>), dim3(ngrp < 4096 ? (unsigned)ngrp : 4096u), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip,
+					(const uint32_t*)glist[1], (const uint32_t*)(nglist + 1));
+		} else {
 			const dim3 g1w((unsigned)((nwin + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), b1w(64 * RB3_REB_WAVES);
 			// the run-space short cut takes windows with up to 3 batch rows, or up to 7 where a window receives more than 3 on average
 			if (!FROM_PLAIN && n2 * RB3_WIN > 3 * ntot)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 7>), g1w, b1w, 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip);
+						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 			else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 3>), g1w, b1w, 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip);
+						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_decide<false>), dim3((unsigned)ngrp), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip,
+					(const uint32_t*)nullptr, (const uint32_t*)nullptr);
 		}
-		hipLaunchKernelGGL(k_decide, dim3((unsigned)ngrp), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip);
 	} else {
 		if (!FROM_PLAIN) {
 			const int64_t nt = n2 + 1;
@@ -437,9 +496,14 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		*onslots = (int64_t)total[6];
 		if ((r = ib_ensure(h, dst, ngrp, *onslots)) < 0) return r;
 	}
-	if (winpar)
-		hipLaunchKernelGGL(k_pass2w, dim3((unsigned)ngrp), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
-				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip);
+	if (winpar && runspace) {
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<true>), dim3(ngrp < 4096 ? (unsigned)ngrp : 4096u), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1));
+		hipLaunchKernelGGL(k_place, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, h->st, (const uint8_t*)gkind, (const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot,
+				(const uint4*)h->gslots.p, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, nwin, ntot, skip);
+	} else if (winpar)
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<false>), dim3((unsigned)ngrp), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 	else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
 				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, skip);
@@ -911,6 +975,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		acc[0] = 0;
 		for (int a = 0; a < 6; ++a) acc[a + 1] = acc[a] + (int64_t)hm[MISC_IX_TOT + a];
 		nslots = (int64_t)hm[MISC_IX_TOT + 6];
+		if (runspace_applies(h, len, ntot) && use_winpar(h, nwin)) // the run-space rebuild ran: how many groups it handed to the window kernels
+			h->stt.n_reb_groups += ngrp, h->stt.n_reb_groups_window += (int64_t)(hm[MISC_RG_LISTS] >> 32);
 		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + acc2[a]) return RB3GPU_EINTERNAL;
 		if (nslots > nwin) return RB3GPU_EINTERNAL;
 		if (commit) index_install(h, ngrp, nslots, ntot, acc);

@@ -1513,9 +1513,12 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 
 /* per window: symbols -> statistics (wstat: 6 x u16 counts, first, last, u16 runs = 16 B) and the
  * three bit planes (wplane: 24 dwords, the payload of a bit-plane slot) */
-template<bool FROM_PLAIN, int MR = 3>
+/* LISTED: only the windows of the groups glist[0 .. *nglist) (the groups the run-space rebuild k_reb_group left over),
+ * with a grid-stride loop: the length of the list is only known on the device */
+template<bool FROM_PLAIN, int MR = 3, bool LISTED = false>
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
-		const int64_t *jw, uint4 *wstat, uint32_t *wplane, uint16_t *wruns, int64_t nwin, const unsigned long long *skip)
+		const int64_t *jw, uint4 *wstat, uint32_t *wplane, uint16_t *wruns, int64_t nwin, const unsigned long long *skip,
+		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t symbuf_[RB3_REB_WAVES][RB3_WIN];
 	if (RB3_REB_SKIP(skip)) return;
@@ -1524,9 +1527,10 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint8_t *symbuf = symbuf_[wave];
 	uint64_t *ball = ball_[wave];
-	for (int t = 0; t < RB3_REB_WPW; ++t) {
-	const int64_t w = ((int64_t)blockIdx.x * RB3_REB_WAVES + wave) * RB3_REB_WPW + t;
-	if (w >= nwin) break;
+	const int64_t nunits = LISTED ? (int64_t)*nglist * RB3_GRP_WINS : nwin;
+	for (int64_t v = (int64_t)blockIdx.x * RB3_REB_WAVES + wave; v < nunits; v += LISTED ? (int64_t)gridDim.x * RB3_REB_WAVES : nunits) {
+	const int64_t w = LISTED ? (int64_t)glist[v >> 5] * RB3_GRP_WINS + (v & (RB3_GRP_WINS - 1)) : v;
+	if (w >= nwin) continue;
 	const int64_t p0 = w << RB3_WIN_BITS;
 	int64_t j = FROM_PLAIN ? 0 : jw[w];
 	if (!FROM_PLAIN && old.dense == 0 && window_runs_fast<MR>(old, pos, b2, n2, ntot, w, j, lane, fast_[wave], wstat, wruns)) continue;
@@ -1590,11 +1594,15 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 
 /* per group of 32 windows: the slot partition (largest aligned power-of-two window groups with
  * <= 48 runs) and the group's symbol counts; same output as k_pass1 */
-__global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot, uint32_t *gstat, int64_t ngrp, const unsigned long long *skip)
+template<bool LISTED = false>
+__global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot, uint32_t *gstat, int64_t ngrp, const unsigned long long *skip,
+		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr)
 {
 	if (RB3_REB_SKIP(skip)) return;
 	const int lane = threadIdx.x;
-	const int64_t g = blockIdx.x;
+	const int64_t nunits = LISTED ? (int64_t)*nglist : ngrp;
+	for (int64_t gu = blockIdx.x; gu < nunits; gu += LISTED ? (int64_t)gridDim.x : nunits) {
+	const int64_t g = LISTED ? (int64_t)glist[gu] : gu;
 	const int64_t W = (ntot >> RB3_WIN_BITS) + 1;
 	const int nvw = (int)(W - g * RB3_GRP_WINS < RB3_GRP_WINS ? W - g * RB3_GRP_WINS : RB3_GRP_WINS);
 	uint4 st = make_uint4(0, 0, 0, 7u << 16 | 7u << 24);
@@ -1625,21 +1633,30 @@ __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot,
 			lane == 5 ? cnt[5] : lane == 6 ? (uint32_t)__popc(mask) : mask;
 		gstat[g * 8 + lane] = v;
 	}
+	} // groups of this block
 }
 
 /* per window: emit its slot (bit-plane slots straight from the cached planes; the wave of the first
  * window of a run slot gathers the slot's <= 48 codes from the run lists of its windows, one lane per
  * code, merging runs that continue across window boundaries); window 0 of a group also writes the
  * directory entry */
+template<bool LISTED = false>
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wstat, const uint32_t *wplane, const uint16_t *wruns, int64_t ntot, const uint32_t *gstat,
-		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin, const unsigned long long *skip)
+		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin, const unsigned long long *skip,
+		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr)
 {
 	if (RB3_REB_SKIP(skip)) return;
+#ifdef RB3_ABL
+	if (LISTED) return;
+#endif
 	__shared__ uint32_t sP_[RB3_REB_WAVES][RB3_GRP_WINS + 1], sB_[RB3_REB_WAVES][RB3_GRP_WINS], sNr_[RB3_REB_WAVES][RB3_GRP_WINS];
 	__shared__ uint32_t code16_[RB3_REB_WAVES][RB3_RLE_CODES / 2];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t *sP = sP_[wave], *sB = sB_[wave], *sNr = sNr_[wave], *code16 = code16_[wave];
-	const int64_t g = blockIdx.x; // one block per group, each wave takes a quarter of its windows
+	const int64_t ngrp_all = (nwin + RB3_GRP_WINS - 1) / RB3_GRP_WINS;
+	const int64_t nunits = LISTED ? (int64_t)*nglist : ngrp_all;
+	for (int64_t gu = blockIdx.x; gu < nunits; gu += LISTED ? (int64_t)gridDim.x : nunits) {
+	const int64_t g = LISTED ? (int64_t)glist[gu] : gu; // one block per group at a time, each wave takes a quarter of its windows
 	const int nvw = (int)(nwin - g * RB3_GRP_WINS < RB3_GRP_WINS ? nwin - g * RB3_GRP_WINS : RB3_GRP_WINS);
 	const uint32_t mask = gstat[g * 8 + 7];
 	const uint64_t slot0 = gpre[g * 8 + 6];
@@ -1765,6 +1782,471 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 			slot16[sidx * 8 + lane] = v;
 		}
 		wave_sync();
+	}
+	} // groups of this block
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* run-space rebuild: one wave per 8192-symbol GROUP of the new index                          */
+/* ----------------------------------------------------------------------------------------- */
+
+/* The per-window kernels above regenerate 256 symbols per window whatever the index looks like.  In a compressible index
+ * (the target workload: many genomes of one species; runs of ~100 symbols) a group of 8192 output symbols is a few dozen
+ * old runs plus the batch rows that land in it, and the whole rebuild of the group -- interleave (worker_mgins +
+ * rope_insert_run, fm-index.c:237-249, rope.c:114-148), slot partition, run codes, header counts -- can be done on those
+ * items without ever expanding a symbol.  One wave per group:
+ *
+ *   rows     r = 0..nb-1: batch rows j0+r with new offset q_r = pos - P0 and old offset k_r = q_r - r (non-decreasing)
+ *   runs     i = 0..nR-1: the old runs that intersect the group's old range [A0, A0 + 8192 - nb), clipped, start S_i
+ *   items    sorted by new offset; three kinds, and each knows its own index without a search through the other list:
+ *            B_r (batch row r)           offset q_r,       index r + lb_r + C(r),  lb_r = #{i : S_i < k_r}: rank in a bitmap
+ *                                                                                  of the run starts (one LDS round trip)
+ *            C_r (the old run resumes)   offset q_r + 1,   index of B_r + 1        iff r is the last row with its k_r and
+ *                                                                                  k_r lies strictly inside an old run
+ *            A_i (start of old run i)    offset S_i + ub,  index i + ub + C',      ub = #{r : k_r <= S_i} = #{r : lb_r <= i},
+ *                                                                                  C' = #{C_r : lb_r <= i}: prefix sums of a
+ *                                                                                  histogram the rows fill by lb_r
+ *   heads    items whose symbol differs from the item before: the maximal runs of the group
+ *   slots    the same rule as k_decide (largest aligned power-of-two window blocks with <= 48 runs), evaluated from the
+ *            number of heads before every window boundary (a histogram of the heads by window); all run slots of the group
+ *            are cut out of the head list in one pass (one lane per code), single windows are expanded to bit planes.
+ *
+ * The slots go to a scratch array (at most RB3_RG_MAXSLOTS per group; final places need the scan over all groups) and
+ * k_place copies them once the offsets are known.  A group that does not qualify -- a bit-plane slot in its old range,
+ * too many rows / runs / slots for the tier, the last group -- is left to the next tier: k_reb_group with larger tables
+ * (gkind[g] says which groups are still to do), then the per-window kernels (LISTED variants, from a list the last tier
+ * appends to), so every index goes through; the host only starts the tiers that the average number of rows per group
+ * makes worthwhile, and a fully bit-plane index (old.dense) never comes here at all.
+ *
+ * The global loads of a group form a chain jw -> (directory entries of the old range, batch rows) -> old slots; every
+ * link is issued as one burst and jw one group ahead.  What is left is LDS latency: the kernel runs at ~2000 wave
+ * instructions per group, waiting most of the time (profiles/r2_*). */
+#define RB3_RG_MAXSLOTS 8
+#define RB3_RG_WAVES 4
+#define RB3_RG_FAILBUF 16
+
+#ifdef RB3_PROF_REB
+/* cycles per phase of reb_group_one, summed over groups (lane 0 of every wave): a kernel experiment, not in the release build */
+__device__ unsigned long long g_reb_prof[16];
+#define RB3_REB_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_reb_prof[i], t_ - tprof); tprof = t_; } while (0)
+#else
+#define RB3_REB_T(i) do {} while (0)
+#endif
+
+template<int RMAX, int NBMAX>
+struct RebLds {
+	__attribute__((aligned(16))) uint32_t bits[260]; // bit s set <=> an old run starts at old-range offset s
+	uint32_t it[RMAX + 2 * NBMAX + 2]; // items, then (in place) heads: offset << 3 | sym
+	uint32_t PHC[RMAX + 2];        // histogram by lb_r: rows (low half), C items (high half)
+	uint16_t cum[260];             // set bits before word w of bits[]
+	uint16_t S[RMAX + 2];          // old run starts (old-range offsets)
+	uint16_t K[NBMAX + 2];         // k_r, K[nb] = 0xFFFF
+	uint8_t Ssym[RMAX + 2];
+	uint8_t Ksym[NBMAX + 2];
+	uint32_t stage[RB3_RG_MAXSLOTS * 24]; // payload of the group's slots: 48 run codes, or the 24 plane words
+	uint32_t scnt[RB3_RG_MAXSLOTS * 8];   // symbol counts per slot
+	uint32_t wh[34];               // heads per window
+	uint32_t wexact;               // bit w: a head sits exactly on the start of window w
+	uint16_t cH[34], hB[34];       // heads before / at-or-before every window boundary
+	uint32_t slotA[RB3_RG_MAXSLOTS + 2];  // start window of every slot, slotA[nslots] = 32
+	uint32_t sbase[RB3_RG_MAXSLOTS + 2];  // first code of every run slot in the group's code sequence
+	uint32_t fail[RB3_RG_FAILBUF]; // groups this wave hands on to the window kernels, flushed with one atomic
+};
+
+/* number of heads h[0..n) whose offset (h >> 3) is < key */
+__device__ __forceinline__ int lb_head(const uint32_t *h, int n, uint32_t key)
+{
+	int lo = 0;
+	for (int step = n > 0 ? 1 << (31 - __clz(n)) : 0; step; step >>= 1)
+		if (lo + step <= n && (h[lo + step - 1] >> 3) < key) lo += step;
+	return lo;
+}
+
+/* one group; returns false (nothing of consequence written) if the group does not qualify for this tier.
+ * j0, j1: jw[32 g], jw[32 g + 32], loaded by the caller one group ahead. */
+template<int RMAX, int NBMAX>
+__device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t ntot, int64_t j0, int64_t j1,
+		int64_t g, int lane, RebLds<RMAX, NBMAX> &L, uint32_t *gstat, uint4 *gslots)
+{
+	const int64_t P0 = g << RB3_GRP_BITS;
+#ifdef RB3_PROF_REB
+	unsigned long long tprof = __builtin_readcyclecounter();
+#endif
+	if (ntot - P0 < RB3_GRP) return false; // the last (partial) group goes through the window kernels
+	const int64_t nb64 = j1 - j0;
+	if (nb64 < 0 || nb64 > NBMAX) return false;
+	const int nb = (int)nb64, nold = RB3_GRP - nb;
+	const int64_t A0 = P0 - j0, A1 = A0 + nold;
+	if (A0 < 0 || A1 > old.n) return false; // (only with an invalid pos[])
+	RB3_REB_T(0);
+#if defined(RB3_ABL) && RB3_ABL == 1
+	return true;
+#endif
+	// the batch rows of the group, requested now (registers), used after the old runs
+	constexpr int NCH = (NBMAX + 63) / 64;
+	int64_t rpos[NCH];
+	uint8_t rsym[NCH];
+#pragma unroll
+	for (int c = 0; c < NCH; ++c) {
+		const int r = c * 64 + lane;
+		rpos[c] = r < nb ? pos[j0 + r] : 0;
+		rsym[c] = r < nb ? b2[j0 + r] : (uint8_t)0;
+	}
+	{ // clear what the phases below accumulate into
+		uint4 *bz = (uint4*)L.bits;
+		bz[lane] = make_uint4(0, 0, 0, 0);
+		if (lane == 0) bz[64] = make_uint4(0, 0, 0, 0);
+		L.scnt[lane] = 0u;
+		if (lane < 34) L.wh[lane] = 0u;
+		if (lane == 0) L.wexact = 0u;
+#pragma unroll
+		for (int q = 0; q < 3; ++q) L.stage[q * 64 + lane] = 0x00070007u; // unused run codes
+	}
+	wave_sync();
+	// ---- the old runs of [A0, A1) ----
+	int nR = 0;
+	if (nold > 0) {
+		const int64_t ga = A0 >> RB3_GRP_BITS, gb = (A1 - 1) >> RB3_GRP_BITS;
+		const uint64_t sma = old.grp64[ga * 8 + 6], smb = old.grp64[gb * 8 + 6];
+		const uint32_t wa = ((uint32_t)A0 & (RB3_GRP - 1)) >> RB3_WIN_BITS, wb = ((uint32_t)(A1 - 1) & (RB3_GRP - 1)) >> RB3_WIN_BITS;
+		const int64_t fa = (int64_t)((uint32_t)sma + __popc((uint32_t)(sma >> 32) & ((2u << wa) - 1u)) - 1u);
+		const int64_t la = (int64_t)((uint32_t)smb + __popc((uint32_t)(smb >> 32) & ((2u << wb) - 1u)) - 1u);
+		const int64_t slot0b = (int64_t)(uint32_t)smb;
+		const int ns = (int)(la - fa + 1);
+		if (ns <= 0 || ns * RB3_RLE_CODES > RMAX) return false;
+		const int j = lane & 7;
+		constexpr int NPASS = (RMAX / RB3_RLE_CODES + 7) / 8;
+		uint4 slv[NPASS];
+#pragma unroll
+		for (int p = 0; p < NPASS; ++p) { // all slots of the range in one burst
+			const int q = p * 8 + (lane >> 3);
+			slv[p] = make_uint4(RB3_SLOT_RLE, 0x00070007u, 0x00070007u, 0x00070007u);
+			if (q < ns) slv[p] = old.slot16[(fa + q) * 8 + j];
+		}
+#pragma unroll
+		for (int p = 0; p < NPASS; ++p) {
+			if (p * 8 >= ns) break;
+			const int q = p * 8 + (lane >> 3);
+			const bool valid = q < ns;
+			const uint4 sl = slv[p];
+			const uint32_t hdr0 = oct_bcast0(sl.x, j);
+			if (__any(valid && !(hdr0 & RB3_SLOT_RLE))) return false; // a bit-plane slot: this group is rebuilt from symbols
+			const int64_t sgrp = (gb != ga && fa + q >= slot0b) ? gb : ga;
+			const uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
+			uint32_t len[6], tot = 0;
+#pragma unroll
+			for (int i = 0; i < 6; ++i) {
+				len[i] = (e[i] & 7u) == 7u ? 0u : (e[i] >> 3) + 1u;
+				tot += len[i];
+			}
+			int rel = (int)(((sgrp << RB3_GRP_BITS) + (int64_t)(hdr0 & 0xFFFFu)) - A0) + (int)oct_exscan(tot, j); // may be negative
+			int cs[6];
+			uint32_t nv = 0, vm = 0;
+#pragma unroll
+			for (int i = 0; i < 6; ++i) {
+				const int st = rel < 0 ? 0 : rel, en = rel + (int)len[i] > nold ? nold : rel + (int)len[i];
+				cs[i] = st;
+				if (valid && len[i] != 0u && en > st) vm |= 1u << i, ++nv;
+				rel += (int)len[i];
+			}
+			const uint32_t inc = wave_incl_scan(nv);
+			int o = nR + (int)(inc - nv);
+#pragma unroll
+			for (int i = 0; i < 6; ++i)
+				if (vm >> i & 1u) {
+					L.S[o] = (uint16_t)cs[i], L.Ssym[o] = (uint8_t)(e[i] & 7u);
+					atomicOr(&L.bits[cs[i] >> 5], 1u << (cs[i] & 31));
+					++o;
+				}
+			nR += (int)wave_read(inc, 63);
+		}
+		if (nR <= 0 || nR > RMAX) return false;
+	}
+	RB3_REB_T(1);
+	// ---- the batch rows ----
+#pragma unroll
+	for (int c = 0; c < NCH; ++c) {
+		const int r = c * 64 + lane;
+		if (r < nb) {
+			const int64_t k = rpos[c] - P0 - r;
+			L.K[r] = (uint16_t)(k < 0 ? 0 : k > nold ? nold : k); // (clamped: only an invalid pos[] is outside)
+			L.Ksym[r] = rsym[c];
+		}
+	}
+	if (lane == 0) L.K[nb] = 0xFFFFu;
+	for (int c = 0; c * 64 <= nR; ++c)
+		if (c * 64 + lane <= nR) L.PHC[c * 64 + lane] = 0u;
+	wave_sync();
+	{ // cum[w] = set bits before word w
+		const uint4 bw = ((const uint4*)L.bits)[lane];
+		const uint32_t c0 = __popc(bw.x), c1 = __popc(bw.y), c2 = __popc(bw.z), c3 = __popc(bw.w), t4 = c0 + c1 + c2 + c3;
+		const uint32_t base = wave_incl_scan(t4) - t4;
+		ushort4 cv;
+		cv.x = (uint16_t)base, cv.y = (uint16_t)(base + c0), cv.z = (uint16_t)(base + c0 + c1), cv.w = (uint16_t)(base + c0 + c1 + c2);
+		((ushort4*)L.cum)[lane] = cv;
+		if (lane == 0) L.cum[256] = (uint16_t)nR;
+	}
+	wave_sync();
+	RB3_REB_T(2);
+#if defined(RB3_ABL) && RB3_ABL == 2
+	return true;
+#endif
+	int nC = 0;
+	for (int c = 0; c * 64 < nb; ++c) {
+		const int r = c * 64 + lane;
+		const bool valid = r < nb;
+		const uint32_t k = valid ? L.K[r] : 0u, kn = valid ? L.K[r + 1] : 0u;
+		const uint32_t bwd = L.bits[k >> 5];
+		const int lb = (int)L.cum[k >> 5] + __popc(bwd & ((1u << (k & 31)) - 1u)); // run starts before k
+		const bool exact = (bwd >> (k & 31)) & 1u;                                   // a run starts at k itself
+		const bool cf = valid && kn != k && (int)k < nold && lb >= 1 && !exact;
+		const uint64_t bal = __ballot(cf);
+		if (valid) {
+			const int idx = r + lb + nC + __popcll(bal & ((1ull << lane) - 1ull));
+			L.it[idx] = (k + (uint32_t)r) << 3 | (uint32_t)L.Ksym[r];
+			if (cf) L.it[idx + 1] = (k + (uint32_t)r + 1u) << 3 | (uint32_t)L.Ssym[lb - 1];
+			atomicAdd(&L.PHC[lb], cf ? 0x10001u : 1u);
+		}
+		nC += __popcll(bal);
+	}
+	wave_sync();
+	RB3_REB_T(3);
+	{
+		uint32_t carry = 0;
+		for (int c = 0; c * 64 < nR; ++c) {
+			const int i = c * 64 + lane;
+			const uint32_t v = i < nR ? L.PHC[i] : 0u;
+			const uint32_t inc = wave_incl_scan(v) + carry; // both halves: rows / C items with lb <= i
+			if (i < nR) {
+				const uint32_t ub = inc & 0xFFFFu;
+				L.it[i + (int)ub + (int)(inc >> 16)] = ((uint32_t)L.S[i] + ub) << 3 | (uint32_t)L.Ssym[i];
+			}
+			carry = wave_read(inc, 63);
+		}
+	}
+	const int nI = nR + nb + nC;
+	wave_sync();
+	RB3_REB_T(4);
+	// ---- heads (maximal runs), compacted in place; heads per window ----
+	int nH = 0;
+	{
+		uint32_t carry = 8u;
+		for (int c = 0; c * 64 < nI; ++c) {
+			const int i = c * 64 + lane;
+			const bool valid = i < nI;
+			const uint32_t x = valid ? L.it[i] : 7u, sy = x & 7u;
+			uint32_t up = wave_up1(sy);
+			if (lane == 0) up = carry;
+			const bool head = valid && sy != up;
+			const uint64_t bal = __ballot(head);
+			if (head) {
+				L.it[nH + __popcll(bal & ((1ull << lane) - 1ull))] = x; // never ahead of what has been read
+				atomicAdd(&L.wh[x >> (3 + RB3_WIN_BITS)], 1u);
+				if (((x >> 3) & (RB3_WIN - 1)) == 0u) atomicOr(&L.wexact, 1u << (x >> (3 + RB3_WIN_BITS)));
+			}
+			carry = wave_read(sy, 63);
+			nH += __popcll(bal);
+		}
+	}
+	if (lane == 0) L.it[nH] = (uint32_t)RB3_GRP << 3 | 7u;
+	wave_sync();
+	const uint32_t *H = L.it;
+	RB3_REB_T(5);
+#if defined(RB3_ABL) && RB3_ABL == 3
+	return true;
+#endif
+	// ---- slot partition: the rule of k_decide on the number of runs that intersect each aligned block of windows ----
+	{
+		const uint32_t v = lane < RB3_GRP_WINS ? L.wh[lane] : 0u;
+		const uint32_t c0 = wave_incl_scan(v) - v;
+		if (lane <= RB3_GRP_WINS) L.cH[lane] = (uint16_t)c0, L.hB[lane] = (uint16_t)(c0 + (lane < RB3_GRP_WINS ? (L.wexact >> lane) & 1u : 0u));
+	}
+	wave_sync();
+	int level = 0;
+	if (lane < RB3_GRP_WINS) {
+#pragma unroll
+		for (int jl = 1; jl <= 5; ++jl) {
+			const int sz = 1 << jl, a = lane & ~(sz - 1);
+			const int runs = (int)L.cH[a + sz] - (int)L.hB[a] + 1;
+			if (runs <= RB3_RLE_CODES && level == jl - 1) level = jl;
+		}
+	}
+	const bool sstart = lane < RB3_GRP_WINS && (lane & ((1 << level) - 1)) == 0;
+	const uint32_t mask = (uint32_t)__ballot(sstart);
+	const int nslots = __popc(mask);
+	if (nslots > RB3_RG_MAXSLOTS) return false;
+	if (sstart) L.slotA[__popc(mask & ((1u << lane) - 1u))] = (uint32_t)lane;
+	if (lane == 0) L.slotA[nslots] = RB3_GRP_WINS;
+	wave_sync();
+	RB3_REB_T(6);
+#if defined(RB3_ABL) && RB3_ABL == 4
+	return true;
+#endif
+	// ---- all slots of the group ----
+	int TC = 0; // run codes of the group
+	uint32_t bpm = 0; // slots that are single windows
+	{
+		uint32_t nc = 0;
+		bool single = false;
+		if (lane < nslots) {
+			const uint32_t a = L.slotA[lane], an = L.slotA[lane + 1];
+			single = an - a == 1u;
+			if (!single) nc = (uint32_t)L.cH[an] - ((uint32_t)L.hB[a] - 1u);
+		}
+		const uint32_t inc = wave_incl_scan(nc);
+		if (lane <= nslots && lane <= RB3_RG_MAXSLOTS) L.sbase[lane] = inc - nc;
+		TC = (int)wave_read(inc, 63);
+		bpm = (uint32_t)__ballot(single);
+	}
+	wave_sync();
+	for (uint32_t m = bpm; m; m &= m - 1u) { // a single window: its symbols from the (few) runs that intersect it, as bit planes
+		const int si = __ffs(m) - 1;
+		const uint32_t a = L.slotA[si], x0 = a << RB3_WIN_BITS;
+		const int t0 = (int)L.hB[a] - 1, nt = (int)L.cH[a + 1] - t0;
+		uint32_t *pw = &L.stage[si * 24];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t x = x0 + 64u * u + (uint32_t)lane;
+			const uint32_t sy = H[t0 + lb_head(H + t0 + 1, nt - 1, x + 1u)] & 7u; // the last head at or before x
+#pragma unroll
+			for (int p = 0; p < 3; ++p) {
+				const uint64_t bm = __ballot((sy >> p) & 1u);
+				if (lane == u * 3 + p) pw[(u * 3 + p) * 2] = (uint32_t)bm, pw[(u * 3 + p) * 2 + 1] = (uint32_t)(bm >> 32);
+			}
+#pragma unroll
+			for (int s6 = 0; s6 < 6; ++s6) {
+				const uint32_t pc = (uint32_t)__popcll(__ballot(sy == (uint32_t)s6));
+				if (lane == s6) atomicAdd(&L.scnt[si * 8 + s6], pc);
+			}
+		}
+	}
+	for (int c = 0; c * 64 < TC; ++c) { // one lane per run code
+		const int x = c * 64 + lane;
+		if (x < TC) {
+			int si = 0;
+#pragma unroll
+			for (int q = 1; q < RB3_RG_MAXSLOTS; ++q) si += (q < nslots && (int)L.sbase[q] <= x) ? 1 : 0; // (bit-plane slots have no codes: equal bases, the last one wins)
+			const uint32_t a = L.slotA[si], an = L.slotA[si + 1];
+			const uint32_t x0 = a << RB3_WIN_BITS, x1 = an << RB3_WIN_BITS;
+			const int ci = x - (int)L.sbase[si], t = (int)L.hB[a] - 1 + ci;
+			const uint32_t h = H[t], hn = H[t + 1];
+			const uint32_t st = (h >> 3) < x0 ? x0 : h >> 3, en = (hn >> 3) > x1 ? x1 : hn >> 3;
+			((uint16_t*)L.stage)[si * RB3_RLE_CODES + ci] = (uint16_t)((en - st - 1u) << 3 | (h & 7u));
+			atomicAdd(&L.scnt[si * 8 + (h & 7u)], en - st);
+		}
+	}
+	wave_sync();
+	{ // headers and payload: lane = slot * 8 + slice
+		const int si = lane >> 3, j = lane & 7;
+		if (si < nslots) {
+			const uint32_t a = L.slotA[si], an = L.slotA[si + 1];
+			uint32_t hq;
+			if (j == 0) hq = a << RB3_WIN_BITS | (an - a > 1u ? RB3_SLOT_RLE : 0u);
+			else if (j == 7) hq = (an - a) << RB3_WIN_BITS;
+			else {
+				hq = 0u;
+				for (int q = 0; q < si; ++q) hq += L.scnt[q * 8 + j - 1];
+			}
+			const uint32_t *pw = &L.stage[si * 24];
+			uint4 v;
+			v.x = hq;
+			if (an - a > 1u) v.y = pw[j * 3], v.z = pw[j * 3 + 1], v.w = pw[j * 3 + 2];
+			else v.y = pw[(j >> 1) * 6 + 0 + (j & 1)], v.z = pw[(j >> 1) * 6 + 2 + (j & 1)], v.w = pw[(j >> 1) * 6 + 4 + (j & 1)]; // same word order as wplane
+			gslots[((int64_t)g * RB3_RG_MAXSLOTS + si) * 8 + j] = v;
+		}
+	}
+	// ---- the group's record for the scan: symbol counts, slot count, slot-start mask (as k_decide) ----
+	if (lane < 8) {
+		uint32_t v = lane == 6 ? (uint32_t)nslots : mask;
+		if (lane < 6) {
+			v = 0u;
+			for (int q = 0; q < nslots; ++q) v += L.scnt[q * 8 + lane];
+		}
+		gstat[g * 8 + lane] = v;
+	}
+	wave_sync();
+	RB3_REB_T(7);
+#ifdef RB3_PROF_REB
+	if (lane == 0) atomicAdd(&g_reb_prof[8], 1ull), atomicAdd(&g_reb_prof[9], (unsigned long long)nb), atomicAdd(&g_reb_prof[10], (unsigned long long)nR), atomicAdd(&g_reb_prof[11], (unsigned long long)nslots);
+#endif
+	return true;
+}
+
+/* gkind[g]: 0 = rebuilt in run space (slots in the scratch, placed by k_place), 1 = not yet (the next tier, or the window
+ * kernels).  CHECK: a later tier: only the groups an earlier one left (gkind[g] == 1).  LAST: the groups this tier cannot
+ * do either are appended to lout (counter nlout) for the LISTED window kernels, a wave's failures with one atomic. */
+template<int RMAX, int NBMAX, bool CHECK, bool LAST>
+__global__ void __launch_bounds__(64 * RB3_RG_WAVES) k_reb_group(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t ntot, const int64_t *jw, int64_t ngrp,
+		uint32_t *gstat, uint4 *gslots, uint8_t *gkind, uint32_t *lout, uint32_t *nlout, const unsigned long long *skip)
+{
+	__shared__ RebLds<RMAX, NBMAX> lds_[RB3_RG_WAVES];
+	if (RB3_REB_SKIP(skip)) return;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	RebLds<RMAX, NBMAX> &L = lds_[wave];
+	const int64_t ustep = (int64_t)gridDim.x * RB3_RG_WAVES;
+	const int64_t full = ntot >> RB3_GRP_BITS; // groups 0 .. full-1 are whole
+	int64_t g = (int64_t)blockIdx.x * RB3_RG_WAVES + wave;
+	int64_t jn0 = 0, jn1 = 0; // the row range of the next group of this wave, requested one iteration ahead
+	uint32_t kn = 1;
+	if (g < full) jn0 = jw[g * RB3_GRP_WINS], jn1 = jw[(g + 1) * RB3_GRP_WINS];
+	if (CHECK && g < ngrp) kn = gkind[g];
+	int nfail = 0;
+	for (; g < ngrp; g += ustep) {
+		const int64_t j0 = jn0, j1 = jn1;
+		const uint32_t kind = kn;
+		if (g + ustep < full) jn0 = jw[(g + ustep) * RB3_GRP_WINS], jn1 = jw[(g + ustep + 1) * RB3_GRP_WINS];
+		if (CHECK && g + ustep < ngrp) kn = gkind[g + ustep];
+		if (CHECK && kind == 0) continue;
+		const bool ok = reb_group_one<RMAX, NBMAX>(old, pos, b2, ntot, j0, j1, g, lane, L, gstat, gslots);
+		if (!CHECK || ok) { if (lane == 0) gkind[g] = ok ? 0 : 1; }
+		if (LAST && !ok) {
+			if (lane == 0) L.fail[nfail] = (uint32_t)g;
+			if (++nfail == RB3_RG_FAILBUF) {
+				wave_sync();
+				uint32_t o = 0;
+				if (lane == 0) o = atomicAdd(nlout, (uint32_t)RB3_RG_FAILBUF);
+				o = wave_read(o, 0);
+				if (lane < RB3_RG_FAILBUF) lout[o + lane] = L.fail[lane];
+				nfail = 0;
+			}
+		}
+		wave_sync();
+	}
+	if (LAST && nfail > 0) {
+		wave_sync();
+		uint32_t o = 0;
+		if (lane == 0) o = atomicAdd(nlout, (uint32_t)nfail);
+		o = wave_read(o, 0);
+		if (lane < nfail) lout[o + lane] = L.fail[lane];
+	}
+}
+
+/* the groups rebuilt in run space: directory entry + slots from the scratch to their final places (the groups of the
+ * window kernels are written by k_pass2w).  Eight lanes per group. */
+__global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint32_t *gstat, const uint64_t *gpre, const uint64_t *tot, const uint4 *gslots,
+		rb3_grp_t *grp, uint4 *slot16, int64_t ngrp, int64_t nwin, int64_t ntot, const unsigned long long *skip)
+{
+	if (RB3_REB_SKIP(skip)) return;
+#ifdef RB3_ABL
+	return; // (kernel ablation builds leave the group records undefined)
+#endif
+	const int j = threadIdx.x & 7;
+	const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+	if (g >= ngrp || gkind[g] != 0) return;
+	const uint32_t gs = gstat[g * 8 + j];     // lane 6: slots, lane 7: mask
+	const uint64_t gp = gpre[g * 8 + j];      // lanes 0..5: symbols before the group, lane 6: slots before the group
+	uint64_t cb = 0;                          // C[j] of the merged BWT (lanes 0..5)
+	for (int a = 0; a < j && a < 6; ++a) cb += tot[a];
+	const uint32_t ns = (uint32_t)__shfl((int)gs, 6, 8), mask = (uint32_t)__shfl((int)gs, 7, 8);
+	const uint64_t slot0 = (uint64_t)(uint32_t)__shfl((int)(uint32_t)gp, 6, 8) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(gp >> 32), 6, 8) << 32;
+	((uint64_t*)grp)[g * 8 + j] = j < 6 ? cb + gp : j == 6 ? (uint64_t)(uint32_t)slot0 | (uint64_t)mask << 32 : 0ull;
+	// headers that carry the whole LF base (RB3_ABS_HEADERS): header lane j holds symbol j-1, whose base sits in lane j-1
+	const uint32_t below = (uint32_t)__shfl((int)(uint32_t)(cb + gp), (j + 7) & 7, 8);
+	const uint32_t add = (RB3_ABS_HEADERS((int64_t)tot[6], nwin, ntot) && j >= 1 && j <= 6) ? below : 0u;
+	for (uint32_t si = 0; si < ns && si < RB3_RG_MAXSLOTS; ++si) {
+		uint4 v = gslots[(g * RB3_RG_MAXSLOTS + si) * 8 + j];
+		v.x += add;
+		slot16[(slot0 + si) * 8 + j] = v;
 	}
 }
 

@@ -35,7 +35,8 @@ class Stats(ctypes.Structure):
                 ("ms_build", ctypes.c_double), ("ms_export", ctypes.c_double), ("ms_chain", ctypes.c_double),
                 ("n_rank_launches", ctypes.c_int64), ("n_lf_steps", ctypes.c_int64), ("n_symbols_merged", ctypes.c_int64),
                 ("n_rounds", ctypes.c_int64), ("n_fallbacks", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64),
-                ("ms_ssa", ctypes.c_double), ("ms_ssa_walk", ctypes.c_double), ("ms_sort", ctypes.c_double), ("n_sort_rounds", ctypes.c_int64)]
+                ("ms_ssa", ctypes.c_double), ("ms_ssa_walk", ctypes.c_double), ("ms_sort", ctypes.c_double), ("n_sort_rounds", ctypes.c_int64),
+                ("n_reb_groups", ctypes.c_int64), ("n_reb_groups_window", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -99,11 +100,12 @@ SYMBOLS = {
 _libs = {}
 
 
-def load_library(hooks=False):
+def load_library(hooks=False, path=None):
     """Load librb3gpu.so (the in-tree build) and declare every prototype.  Raises if absent.
     hooks=True: the test build (librb3gpu_hooks.so, -DRB3GPU_TEST_HOOKS), whose rb3gpu_tune also knows the keys that
     make a merge pretend a failure; only tests load it."""
-    path = _build.LIB_GPU_HOOKS if hooks else os.environ.get("RB3GPU_LIB", _build.LIB_GPU)  # override for kernel experiments only
+    if path is None:
+        path = _build.LIB_GPU_HOOKS if hooks else os.environ.get("RB3GPU_LIB", _build.LIB_GPU)  # override for kernel experiments only
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -125,8 +127,8 @@ def _u8(a):
 class Rb3Gpu:
     """One accumulated BWT resident in the HBM of one MI355X."""
 
-    def __init__(self, device=0, split_log2=0, verbose=1, hooks=False):
-        self._lib = load_library(hooks)
+    def __init__(self, device=0, split_log2=0, verbose=1, hooks=False, lib=None):
+        self._lib = load_library(hooks, lib)   # lib: another build of the library (kernel experiments, tools/probe_*.py)
         n = self._lib.rb3gpu_device_count()
         if n <= 0:
             raise RuntimeError("no HIP device visible (rb3gpu_device_count=%d); the engine has no CPU fallback" % n)

@@ -725,3 +725,68 @@ def test_fmd_decode_long_runs_and_garbage():
             h2.close()
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("seed,nrel,L,per,force", [(201, 24, 30000, 1, 1), (202, 40, 20000, 2, 1), (203, 12, 60000, 1, 1), (204, 64, 9000, 4, 1),
+                                                   (205, 130, 5000, 1, 0), (206, 60, 12000, 1, 0)])
+def test_run_space_rebuild_vs_oracle_and_window_rebuild(oracle, seed, nrel, L, per, force):
+    """the rebuild in run space (k_reb_group: one wave per 8192-symbol group works on the old runs and the batch rows,
+    no symbol is regenerated) against the oracle's merge (fm-index.c:237-249) round by round on a family of relatives --
+    the index turns from bit planes to run slots as relatives accumulate, so both tiers, the hand-over to the window
+    kernels and k_place are exercised -- and against the per-window rebuild (rb3gpu_tune window_rebuild=1): same slots
+    statistics, same BWT."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(seed)
+    g0 = util.random_genome(rng, L)
+    rel = []
+    for i in range(nrel):
+        g = util.mutate(rng, g0, float(rng.choice([0.0005, 0.001, 0.003])))
+        if i % 5 == 4:   # an indel, and a long homopolymer now and then
+            p = int(rng.integers(0, len(g) - 10))
+            g = np.concatenate([g[:p], util.random_genome(rng, int(rng.integers(1, 400))), g[p:]])
+        if i % 7 == 6:
+            p = int(rng.integers(0, len(g) - 10))
+            g = np.concatenate([g[:p], np.full(int(rng.integers(100, 20000)), int(rng.integers(1, 5)), dtype=np.uint8), g[p:]])
+        if i % 9 == 8:
+            g = rel[int(rng.integers(0, len(rel)))].copy()   # an exact duplicate
+        rel.append(g)
+    ha, hb = Rb3Gpu(verbose=1), Rb3Gpu(verbose=1)
+    hb.tune("window_rebuild", 1)
+    ha.tune("reb_force", force)   # 1: also where the host would not start it (many rows per group, index mostly bit planes): the hand-over paths
+    want = None
+    try:
+        for i in range(0, nrel, per):
+            t = util.make_text(rel[i:i + per])
+            b = host.build_bwt(t.copy())
+            if want is None:
+                ha.from_plain(b), hb.from_plain(b)
+                want = b
+                continue
+            want = oracle.merge(want, b)
+            for h in (ha, hb):
+                d, dtw = h.sort_text(t)
+                h.merge_text_dev(d, dtw, t.size, host.walkers_text(t, 256), commit=True)
+                h.dev_free(d), h.dev_free(dtw)
+            ga = ha.export_plain()
+            assert np.array_equal(ga, want), ("run-space rebuild", i)
+            if (i // per) % 4 == 0:
+                assert np.array_equal(hb.export_plain(), want), ("window rebuild", i)
+                assert ha.stats()["bytes_index"] == hb.stats()["bytes_index"], i   # the same slot partition
+        st = ha.stats()
+        assert st["n_fallbacks"] == 0
+        print("groups through the run-space rebuild: %d, handed on to the window kernels: %d" % (st["n_reb_groups"], st["n_reb_groups_window"]))
+        assert st["n_reb_groups"] > 0
+        if nrel >= 24:
+            assert st["n_reb_groups_window"] < st["n_reb_groups"], st   # the run-space kernel really did groups
+        if not force:
+            assert st["n_reb_groups_window"] * 4 < st["n_reb_groups"], st   # where the host starts it by itself, most groups qualify
+        assert hb.stats()["n_reb_groups"] == 0
+        # rank on the rebuilt index (headers, directory): every 997th offset and the ends
+        ks = np.concatenate([np.arange(0, want.size, 997), [want.size - 1, want.size]])
+        ok = ha.rank1a(ks)
+        cum = np.zeros((want.size + 1, 6), dtype=np.int64)
+        for c in range(6):
+            cum[1:, c] = np.cumsum(want == c)
+        assert np.array_equal(ok, cum[ks])
+    finally:
+        ha.close(), hb.close()

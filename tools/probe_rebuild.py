@@ -1,32 +1,43 @@
-"""Scratch probe for kernel ablations: time the rebuild of one merge into a K-genome index with whatever build of
-librb3gpu.so RB3GPU_LIB names (results are discarded; errors from deliberately wrong kernels are ignored).
-  python tools/probe_rebuild.py prep K   -> /tmp/probe_runs.npy, /tmp/probe_b2.npy, /tmp/probe_w.npy (normal library)
-  python tools/probe_rebuild.py time"""
+"""Scratch probe for kernel ablations: build the index of K genomes of the synthetic family with the normal library, then
+time the merge of one more genome (result discarded) with every variant build of librb3gpu.so named on the command line
+(tools/build_variant.sh; errors from deliberately wrong kernels are ignored).
+  python tools/probe_rebuild.py K [variant.so ...] [key=value ...]      (key=value: rb3gpu_tune switches for every handle)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tests import util
 from ropebwt3_amd import Rb3Gpu, host
-if sys.argv[1] == "prep":
-    K = int(sys.argv[2]); L = 4400000
-    g0 = util.random_genome(np.random.default_rng(1), L)
-    h = Rb3Gpu(verbose=1)
-    for k in range(K):
-        b, w = host.build_bwt_walkers(util.make_text([util.mutate(np.random.default_rng(100 + k), g0, 0.001)]), 384)
-        if k == 0: h.from_plain(b)
-        else: h.merge_plain_walkers(b, w)
-    runs = h.export_runs()
-    np.save("/tmp/probe_runs.npy", np.array([(l << 3) | c for c, l in runs], dtype=np.uint64))
-    b, w = host.build_bwt_walkers(util.make_text([util.mutate(np.random.default_rng(999), g0, 0.001)]), 384)
-    np.save("/tmp/probe_b2.npy", b); np.save("/tmp/probe_w.npy", w)
-else:
-    arr = np.load("/tmp/probe_runs.npy"); b = np.load("/tmp/probe_b2.npy"); w = np.load("/tmp/probe_w.npy")
-    h = Rb3Gpu(verbose=0)
-    h._chk(h._lib.rb3gpu_from_runs(h._h, arr.size, arr.ctypes.data), "from_runs")
-    d = h.dev_upload(b)
+K = int(sys.argv[1]); L = 4400000
+libs = [None] + [a for a in sys.argv[2:] if "=" not in a]
+tunes = [a.split("=") for a in sys.argv[2:] if "=" in a]
+g0 = util.random_genome(np.random.default_rng(1), L)
+h = Rb3Gpu(verbose=1)
+for k in range(K):
+    t = util.make_text([util.mutate(np.random.default_rng(100 + k), g0, 0.001)])
+    d, dtw = h.sort_text(t)
+    if k == 0: h.from_plain_dev(d, t.size)
+    else: h.merge_text_dev(d, dtw, t.size, host.walkers_text(t, 384), commit=True)
+    h.dev_free(d); h.dev_free(dtw)
+n = h.get_tot()
+d_plain = h._dev_alloc(n) if hasattr(h, "_dev_alloc") else None
+if d_plain is None:
+    import ctypes
+    p = ctypes.c_void_p()
+    h._chk(h._lib.rb3gpu_dev_alloc(h._h, n, ctypes.byref(p)), "alloc"); d_plain = p.value
+h.export_plain_dev(d_plain)
+t = util.make_text([util.mutate(np.random.default_rng(999), g0, 0.001)])
+w = host.walkers_text(t, 384)
+d, dtw = h.sort_text(t)
+print("index of %d genomes: %d symbols, %.1f MB" % (K, n, h.stats()["bytes_index"] / 1e6))
+for lib in libs:
+    h2 = Rb3Gpu(verbose=0, lib=lib)
+    for k, v in tunes: h2.tune(k, int(v))
+    h2.from_plain_dev(d_plain, n)
     for rep in range(6):
-        if rep == 1: h.stats_reset()
-        try: h.merge_plain_dev_walkers(d, b.size, w, commit=False)
+        if rep == 1: h2.stats_reset()
+        try: h2.merge_text_dev(d, dtw, t.size, w, commit=False)
         except Exception as e: pass
-    st = h.stats()
-    print("%s: rebuild %.3f ms, rank %.3f ms per merge" % (os.environ.get("RB3GPU_LIB", "default").split("/")[-1], st["ms_build"] / 5, st["ms_rank"] / 5))
+    st = h2.stats()
+    print("%-12s rebuild %.3f ms, rank %.3f ms (chain %.3f) per merge; groups to the window kernels %d of %d" % ((lib or "default").split("/")[-1], st["ms_build"] / 5, st["ms_rank"] / 5, st["ms_chain"] / 5,
+          st["n_reb_groups_window"] // 5, st["n_reb_groups"] // 5))
+    h2.close()

@@ -17,6 +17,10 @@ def short(name):
             f = [x.strip() in ("true", "(bool)1") for x in m.group(1).split(",")]
             return "k_chain<%s,%s,%s>" % ("list" if f[0] else "auto", "dense" if f[1] else "mixed", "tent" if len(f) > 2 and f[2] else "plain")
         return "k_chain"
+    if "k_reb_group" in name:
+        import re
+        m = re.search(r"k_reb_group<(\d+), *(\d+)", name) or re.search(r"k_reb_groupILi(\d+)ELi(\d+)", name)
+        return "k_reb_group<%s,%s>" % (m.group(1), m.group(2)) if m else "k_reb_group"
     if "k_pos_finalize_check_rows" in name:
         return "k_pos_finalize_check_rows"
     if "k_export_runs" in name:

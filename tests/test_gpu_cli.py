@@ -22,7 +22,7 @@ def run(args, inp=None):
     return r.stdout, r.stderr.decode()
 
 
-CASES = [k for k in MAN if k != "resume"]
+CASES = [k for k in MAN if k not in ("resume", "mtb_star")]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -187,3 +187,25 @@ def test_oversized_batches_go_to_the_host_sorter():
             r = subprocess.run([CLI, "build", "-d", "-m45k", "--gpu-sort-limit", limit] + extra + [os.path.join(util.GOLDEN, ent["inputs"][0])], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], (limit, extra)
             assert ("symbols on the GPU" in r.stderr.decode()) == on_gpu
+
+
+@pytest.mark.parametrize("K", [24, 152])
+def test_config3_mtb_star_full_length(tmp_path, K):
+    """BASELINE configs[2] (mtb152) at full genome length on the synthetic star of tools/gen_mtb.py: `ropebwt3-amd build`,
+    one file per batch as the reference is run, gives the .fmd of the unmodified reference byte for byte (md5 and size
+    recorded in tests/golden/MANIFEST.json by tools/make_golden_mtb.py from oracle/_ref/ropebwt3: 152 genomes of 4.4 Mbp,
+    1.34 G symbols, 151 merge rounds; the reference needs 826 s for it).  With --rebatch -m (fewer, larger rounds) and with
+    the host sorter on a prefix the bytes are the same."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(util.GOLDEN)))
+    from tools import gen_mtb
+    ent = MAN["mtb_star"]["prefixes"][str(K)]
+    files = gen_mtb.generate(K, MAN["mtb_star"]["genome_len"], str(tmp_path))
+    out, err = run(["build", "-d"] + files)
+    assert len(out) == ent["fmd_bytes"] and hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+    assert "0 (0 symbols) on the host" in err          # every batch was suffix-sorted on the GPU
+    if K == 24:
+        out2, _ = run(["build", "-d", "--rebatch", "-m60m"] + files)
+        assert hashlib.md5(out2).hexdigest() == ent["fmd_md5"]
+        out3, _ = run(["build", "-d", "--host-fmd"] + files)
+        assert hashlib.md5(out3).hexdigest() == ent["fmd_md5"]

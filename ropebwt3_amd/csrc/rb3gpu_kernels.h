@@ -142,6 +142,60 @@ __device__ __forceinline__ void oct_rank_issue(const IdxView &ix, int64_t k, int
 	oct_rank_issue_slot(ix, j, r);
 }
 
+/* The same count with packed 16-bit arithmetic (v_pk_*): run lengths (<= 8192) and offsets inside a slot fit 16 bits, so
+ * the six codes of a lane are three dwords processed two at a time -- about half the vector instructions of slice_count,
+ * and the second offset of an interval that lies in the same slot comes almost for free.  A lone wave issues one vector
+ * instruction every ~4 cycles, so on the LF chain instruction count IS latency.  Unused codes (sym 7, "length" 1) sit
+ * behind the last used one: their positions are past every valid offset and their symbol never equals c, so they need no
+ * special case here.  cnt = #{i < off : sym_i == c} for this lane's share of the slot; match_a != 0 in the lane that holds the
+ * symbol AT off_a if that symbol is c. */
+typedef short rb3_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short rb3_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ rb3_s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(rb3_s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(rb3_s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+template<bool TWO, bool MATCH>
+__device__ __forceinline__ void slice_count_pk(const uint4 &sl, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b, uint32_t *match_a)
+{
+	const uint32_t w[3] = { sl.y, sl.z, sl.w };
+	uint32_t lw[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) lw[k] = ((w[k] >> 3) & 0x1FFF1FFFu) + 0x00010001u; // run lengths of the two codes (no carry: <= 8192)
+	const uint32_t sum2 = lw[0] + lw[1] + lw[2];                                      // per half <= 3 * 8192: no carry either
+	const uint32_t tot = (sum2 & 0xFFFFu) + (sum2 >> 16);
+	uint32_t base = oct_exscan(tot, j);
+	const uint32_t csplat = (uint32_t)c * 0x00010001u;
+	const rb3_s16x2 oa = as_s16x2((uint32_t)off_a * 0x00010001u), ob = as_s16x2((uint32_t)off_b * 0x00010001u), zero = as_s16x2(0u);
+	rb3_s16x2 acc_a = zero, acc_b = zero;
+	uint32_t mt = 0;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const rb3_s16x2 P = as_s16x2(base * 0x00010001u + (lw[k] << 16)); // start offsets: (base, base + len of the first code)
+		const rb3_s16x2 Lk = as_s16x2(lw[k]);
+		// 0xFFFF in the halves whose symbol is c: x in 0..7 per half, x + 0x7FFF has bit 15 set iff x != 0
+		const uint32_t x = (w[k] & 0x00070007u) ^ csplat;
+		const uint32_t eq = ((((x + 0x7FFF7FFFu) >> 15) & 0x00010001u) ^ 0x00010001u) * 0xFFFFu;
+		const rb3_s16x2 ta = oa - P;
+		rb3_s16x2 d = __builtin_elementwise_min(__builtin_elementwise_max(ta, zero), Lk);
+		acc_a += as_s16x2(as_u32(d) & eq);
+		if (MATCH) { // the code that holds offset off_a itself: 0 <= off_a - start < length, i.e. clamping to [0, length - 1] changes nothing
+			const uint32_t y = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(ta, zero), Lk - as_s16x2(0x00010001u))) ^ as_u32(ta);
+			const uint32_t nz = ((y | ((y & 0x7FFF7FFFu) + 0x7FFF7FFFu)) >> 15) & 0x00010001u; // 1 in the halves where y != 0
+			mt |= (nz ^ 0x00010001u) & (eq & 0x00010001u);
+		}
+		if (TWO) {
+			d = __builtin_elementwise_min(__builtin_elementwise_max(ob - P, zero), Lk);
+			acc_b += as_s16x2(as_u32(d) & eq);
+		}
+		base += (lw[k] & 0xFFFFu) + (lw[k] >> 16);
+	}
+	const uint32_t ua = as_u32(acc_a);
+	*cnt_a = (ua & 0xFFFFu) + (ua >> 16);
+	if (TWO) { const uint32_t ub = as_u32(acc_b); *cnt_b = (ub & 0xFFFFu) + (ub >> 16); }
+	if (MATCH) *match_a = mt;
+}
+
 /* number of symbols equal to c among the first `off` symbols of the slot, this lane's share;
  * bit 20 of the result is set in the one lane that holds the symbol AT offset `off` if that symbol is c */
 #define RB3_MATCH_BIT 0x100000u
@@ -156,26 +210,10 @@ __device__ __forceinline__ uint32_t slice_count(const uint4 &sl, uint32_t hdr0, 
 		t = t < 0 ? 0 : t > 32 ? 32 : t;
 		const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
 		cnt = __popc(m & lim) | (at ? RB3_MATCH_BIT : 0u);
-	} else { // six run codes per lane
-		uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
-		uint32_t len[6], tot = 0;
-#pragma unroll
-		for (int i = 0; i < 6; ++i) {
-			len[i] = (e[i] & 7u) == 7u ? 0u : (e[i] >> 3) + 1u;
-			tot += len[i];
-		}
-		int pos = (int)oct_exscan(tot, j);
-		cnt = 0;
-#pragma unroll
-		for (int i = 0; i < 6; ++i) {
-			int d = (int)off - pos;
-			d = d < 0 ? 0 : d > (int)len[i] ? (int)len[i] : d;
-			if ((int)(e[i] & 7u) == c) {
-				cnt += (uint32_t)d;
-				if ((int)off >= pos && (int)off < pos + (int)len[i]) cnt |= RB3_MATCH_BIT;
-			}
-			pos += (int)len[i];
-		}
+	} else { // six run codes per lane, two at a time
+		uint32_t cb, mt;
+		slice_count_pk<false, true>(sl, (int)off, (int)off, c, j, &cnt, &cb, &mt);
+		if (mt) cnt |= RB3_MATCH_BIT;
 	}
 	return cnt;
 }
@@ -465,6 +503,7 @@ struct RankLoadC {
 	uint64_t sm;     // slot0 | mask << 32
 	uint4 sl;        // slice j of the slot
 	uint32_t koff;   // k & 8191
+	uint32_t sidx;   // index of the slot (mixed indexes)
 };
 
 template<bool DENSE>
@@ -482,7 +521,34 @@ __device__ __forceinline__ void octc_issue_slot(const IdxView &ix, int j, RankLo
 	if (DENSE) return;
 	const uint32_t lw = r.koff >> RB3_WIN_BITS;
 	const uint32_t s = (uint32_t)r.sm + __popc((uint32_t)(r.sm >> 32) & ((2u << lw) - 1u)) - 1u;
+	r.sidx = s;
 	r.sl = ix.slot16[(int64_t)s * 8 + j];
+}
+
+/* the upper bound of an interval whose lower bound is being fetched as `lo`: the two usually lie in the same slot
+ * (an interval of <= 255 rows against slots of >= 512 symbols), and then there is nothing to fetch */
+template<bool DENSE>
+__device__ __forceinline__ void octc_issue_slot_hi(const IdxView &ix, int j, RankLoadC &r, const RankLoadC &lo)
+{
+	if (DENSE) return;
+	const uint32_t lw = r.koff >> RB3_WIN_BITS;
+	const uint32_t s = (uint32_t)r.sm + __popc((uint32_t)(r.sm >> 32) & ((2u << lw) - 1u)) - 1u;
+	r.sidx = s;
+	if (s != lo.sidx) r.sl = ix.slot16[(int64_t)s * 8 + j];
+	else r.sl = lo.sl;
+}
+
+/* both ends of an interval that lies inside ONE run slot, from one decode */
+__device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, const RankLoadC &rh, uint32_t hdr0, int c, int j, int64_t *lo_n, int64_t *hi_n)
+{
+	const int base = (int)(hdr0 & 0xFFFFu);
+	uint32_t ca, cb;
+	uint32_t mt;
+	slice_count_pk<true, false>(rl.sl, (int)rl.koff - base, (int)rh.koff - base, c, j, &ca, &cb, &mt);
+	uint32_t v = ca | cb << 16; // both fit 16 bits (counts inside a group of 8192)
+	if (j == c + 1) v += rl.sl.x * 0x00010001u;
+	v = oct_sum(v);
+	*lo_n = (int64_t)(rl.gc + (v & 0xFFFFu)), *hi_n = (int64_t)(rl.gc + (v >> 16));
 }
 
 /* LF(c, k) for the octet's query; *match = 1 iff the symbol at offset k itself is c (then the suffix
@@ -793,7 +859,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			if (LIST) end_next = remaining == 1;
 			else end_next = M && kbn >= m2 && (kbn & (M - 1)) == 0;
 			octc_issue_slot<DENSE>(b1, j, rl);
-			if (wide) octc_issue_slot<DENSE>(b1, j, rh);
+			if (wide) octc_issue_slot_hi<DENSE>(b1, j, rh, rl);
 			// this row: record it unless somebody already has
 			++steps;
 			const bool fin = met || c == 0;
@@ -821,15 +887,22 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			if ((gap == 0 || (tentok && sid >= 0)) && !met && j == (int)(it & 7u))
 				bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 			// next insertion point(s)
-			uint32_t match, mh;
-			const int64_t lo_n = octc_finish<DENSE>(rl, c, j, &match);
+			uint32_t match = 0, mh;
+			int64_t lo_n, hi_n;
+			// an interval inside one run slot (the usual state of a walker in an index that holds many relatives): both bounds from
+			// one fetch and one packed decode.  A branch per octet: a wave whose octets are all in this state runs only this side.
+			const uint32_t hdr0q = DENSE ? 0u : oct_bcast0(rl.sl.x, j);
+			if (!DENSE && wide && rh.sidx == rl.sidx && (hdr0q & RB3_SLOT_RLE)) octc_finish_pair(rl, rh, hdr0q, c, j, &lo_n, &hi_n);
+			else {
+				lo_n = octc_finish<DENSE>(rl, c, j, &match);
+				hi_n = lo_n;
+				if (TENT && gap == 1) hi_n = lo_n + match;
+				if (wide) hi_n = octc_finish<DENSE>(rh, c, j, &mh);
+			}
 			if (TEXT == 2) { // the word after next, from the lane that fetched it (after the slot has arrived: no wait of its own)
 				const int src = ((lane & ~7) | (int)(it & 7u)) << 2;
 				xn = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)blk8) | (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(blk8 >> 32)) << 32;
 			}
-			int64_t hi_n = lo_n;
-			if (TENT && gap == 1) hi_n = lo_n + match;
-			if (wide) hi_n = octc_finish<DENSE>(rh, c, j, &mh);
 			const int64_t kn = hi_n - lo_n;
 			const int gap_n = kn > 1 ? 2 : (int)kn;
 			if (TENT && wide && sid >= 0 && !fin && kn >= 1 && kn < hi - lo) {

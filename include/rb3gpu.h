@@ -63,6 +63,7 @@ typedef struct {
 	int64_t n_sort_rounds;       /* prefix-doubling rounds of those calls */
 	int64_t n_reb_groups;        /* groups (8192 symbols) of the merges whose rebuild went through the run-space kernel ... */
 	int64_t n_reb_groups_window; /* ... and how many of them it handed on to the per-window kernels (single-sync merges) */
+	int64_t bytes_rebuild;       /* algorithmic bytes of the rebuilds: per merge 9 B x rows + old block array + new block array */
 } rb3gpu_stats_t;
 
 void rb3gpu_opt_init(rb3gpu_opt_t *opt);
@@ -214,6 +215,8 @@ int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void
 /* BWT + text-order words (*d_tw: len 64-bit words in the same output buffer; released together with *d_bwt) */
 int rb3gpu_sorter_sort(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, void **d_tw);
 int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt);
+/* cumulative times of a sorter: text upload (host -> HBM, through its pinned staging buffer) and suffix sorting proper */
+int rb3gpu_sorter_stats(const rb3gpu_sorter_t *s, double *ms_upload, double *ms_sort, int64_t *n_batches, int64_t *n_symbols);
 
 /* Import for `build -i` (rb3_enc_fmd2fmr fm-index.c:56-85, mr_restore mrope.c:161-177):
  * runs[i] = len<<3 | sym in BWT order (host memory). */

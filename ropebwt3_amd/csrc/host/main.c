@@ -37,7 +37,7 @@ typedef struct {
 } bopt_t;
 
 /* how the batches of this run were sorted (for the closing statistics line) */
-static struct { int64_t n_gpu, n_host, sym_gpu, sym_host; } g_sorted;
+static struct { int64_t n_gpu, n_host, sym_gpu, sym_host; double ms_upload, ms_sort; } g_sorted;
 
 static void bopt_init(bopt_t *o) /* build.c:31-41 */
 {
@@ -598,7 +598,11 @@ int main_build(int argc, char *argv[])
 		}
 		pthread_join(rt, 0);
 		for (k = 0; k < n_sort; ++k) pthread_join(st[k], 0);
-		for (k = 0; k < n_sort; ++k) rb3gpu_sorter_destroy(sa[k].gs);
+		for (k = 0; k < n_sort; ++k) {
+			double up = 0, so = 0;
+			if (sa[k].gs && rb3gpu_sorter_stats(sa[k].gs, &up, &so, 0, 0) == 0) g_sorted.ms_upload += up, g_sorted.ms_sort += so;
+			rb3gpu_sorter_destroy(sa[k].gs);
+		}
 		free(st); free(sa); free(q.ring);
 		if (rd.err != 0) ret = -1;
 		n_empty = rd.n_empty, has_index = cs.has_index;
@@ -628,6 +632,10 @@ int main_build(int argc, char *argv[])
 				(long)st.n_symbols_merged, st.ms_h2d + st.ms_lf + st.ms_rank + st.ms_build, st.ms_h2d, st.ms_lf, st.ms_rank, st.ms_build, st.bytes_index / 1e6);
 		if (st.ms_sort > 0)
 			fprintf(stderr, "[M::%s] GPU suffix sorting: %.3f ms in all (%ld doubling rounds), text upload included\n", __func__, st.ms_sort, (long)st.n_sort_rounds);
+		if (g_sorted.ms_sort > 0)
+			fprintf(stderr, "[M::%s] GPU sorter threads: text upload %.3f ms, suffix sorting %.3f ms (overlapped with the merges)\n", __func__, g_sorted.ms_upload, g_sorted.ms_sort);
+		fprintf(stderr, "[M::%s] rebuild: %.3f ms for %ld algorithmic bytes (9 B x rows + old + new block array per round) = %.1f GB/s; LF walkers: k_chain %.3f ms in %ld launches, %ld steps\n", __func__,
+				st.ms_build, (long)st.bytes_rebuild, st.ms_build > 0 ? st.bytes_rebuild / st.ms_build / 1e6 : 0.0, st.ms_chain, (long)st.n_rank_launches, (long)st.n_lf_steps);
 		fprintf(stderr, "[M::%s] batches: %ld (%ld symbols) suffix-sorted on the GPU, %ld (%ld symbols) on the host; -m %ld%s\n", __func__,
 				(long)g_sorted.n_gpu, (long)g_sorted.sym_gpu, (long)g_sorted.n_host, (long)g_sorted.sym_host, (long)opt.batch_size,
 				batch_cut(&opt) != opt.batch_size ? " cut into GPU sub-batches (--gpu-batch)" : "");

@@ -726,6 +726,7 @@ static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
 	h->stt.n_symbols_merged += len;
 	if (!rank_only) {
 		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + h->mg_acc2[a]) return RB3GPU_EINTERNAL;
+		h->stt.bytes_rebuild += 9 * len + h->stt.bytes_index + ngrp * (int64_t)sizeof(rb3_grp_t) + nslots * (int64_t)sizeof(rb3_slot_t);
 		if (commit) index_install(h, ngrp, nslots, ntot, acc);
 	}
 	if (h->opt.verbose >= 3)
@@ -979,6 +980,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			h->stt.n_reb_groups += ngrp, h->stt.n_reb_groups_window += (int64_t)(hm[MISC_RG_LISTS] >> 32);
 		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + acc2[a]) return RB3GPU_EINTERNAL;
 		if (nslots > nwin) return RB3GPU_EINTERNAL;
+		// algorithmic bytes of this rebuild: 9 B per batch row + the old block array read + the new one written
+		h->stt.bytes_rebuild += 9 * len + h->stt.bytes_index + ngrp * (int64_t)sizeof(rb3_grp_t) + nslots * (int64_t)sizeof(rb3_slot_t);
 		if (commit) index_install(h, ngrp, nslots, ntot, acc);
 	}
 	if (h->opt.verbose >= 3)
@@ -1247,6 +1250,8 @@ struct rb3gpu_sorter_s {
 	size_t text_cap = 0, ck_cap = 0, out_cap[2] = {0, 0};
 	int busy[2] = {0, 0};
 	uint8_t *stage = nullptr; // pinned, for the text upload
+	double ms_upload = 0, ms_sort = 0; // cumulative: text host -> HBM; suffix sorting + BWT + text-order words
+	int64_t n_sorted = 0, n_symbols = 0;
 	pthread_mutex_t mtx;
 	pthread_cond_t cv;
 };
@@ -1313,6 +1318,7 @@ static int sorter_impl(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, voi
 		return r;
 	}
 	r = 0;
+	const double t_up = now_s();
 	if (s->stage) { // pageable -> pinned -> device, chunk by chunk
 		for (int64_t off = 0; off < len && r == 0; off += (int64_t)RB3_STAGE_BYTES) {
 			const size_t n = (size_t)(len - off) < RB3_STAGE_BYTES ? (size_t)(len - off) : RB3_STAGE_BYTES;
@@ -1328,8 +1334,10 @@ static int sorter_impl(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, voi
 		pthread_mutex_unlock(&s->mtx);
 		return RB3GPU_ENODEV;
 	}
+	const double t_so = now_s();
 	r = rb3sort_bwt(s->ws, s->st, len, (const uint8_t*)s->text, (uint8_t*)s->out[slot], step, nck > 0 ? (int64_t*)s->ck : nullptr, &rounds,
 			d_tw ? (uint64_t*)((uint8_t*)s->out[slot] + tw_off) : nullptr);
+	s->ms_upload += (t_so - t_up) * 1e3, s->ms_sort += (now_s() - t_so) * 1e3, s->n_sorted += 1, s->n_symbols += len;
 	if (r == 0 && nck > 0 && (hipMemcpyAsync(ckrow, s->ck, (size_t)nck * 8, hipMemcpyDeviceToHost, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess)) r = -2;
 	if (r < 0) {
 		pthread_mutex_lock(&s->mtx);
@@ -1352,6 +1360,16 @@ int rb3gpu_sorter_sort(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, voi
 {
 	if (!d_tw) return RB3GPU_EINVAL;
 	return sorter_impl(s, len, text, d_bwt, 0, nullptr, d_tw);
+}
+
+int rb3gpu_sorter_stats(const rb3gpu_sorter_t *s, double *ms_upload, double *ms_sort, int64_t *n_batches, int64_t *n_symbols)
+{
+	if (!s) return RB3GPU_EINVAL;
+	if (ms_upload) *ms_upload = s->ms_upload;
+	if (ms_sort) *ms_sort = s->ms_sort;
+	if (n_batches) *n_batches = s->n_sorted;
+	if (n_symbols) *n_symbols = s->n_symbols;
+	return 0;
 }
 
 int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt)
@@ -1644,7 +1662,7 @@ int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st)
 void rb3gpu_stats_reset(rb3gpu_t *h)
 {
 	if (!h) return;
-	int64_t bi = h->stt.bytes_index;
+	const int64_t bi = h->stt.bytes_index;
 	memset(&h->stt, 0, sizeof(h->stt));
 	h->stt.bytes_index = bi, h->stt.bytes_peak = h->bytes_owned;
 }

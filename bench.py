@@ -301,7 +301,8 @@ def main():
                     help="plain: rb3gpu_merge_plain_dev, the reference's signature (default, = value); rows: + sampled inverse suffix array; text: + inverse suffix array (the CLI's path)")
     ap.add_argument("--plain-abi", action="store_true", help="same as --entry plain")
     ap.add_argument("--row-words", action="store_true", help="same as --entry rows")
-    ap.add_argument("--mode", choices=["interval", "partition", "replicated"], default="interval", help="N>1: how the work is split (ropebwt3_amd/multi.py)")
+    ap.add_argument("--mode", choices=["interval", "partition", "replicated"], default=None,
+                    help="how the work is split over the GPUs (ropebwt3_amd/multi.py); N>1 default: interval (north_star).  With N=1, --mode interval runs the same sharded step on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary measurements (entry points, reads regime, large index)")
     ap.add_argument("--no-target", action="store_true", help="skip the mtb152 end-to-end leg")
@@ -329,8 +330,9 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False and the engine has no CPU fallback")
-    if world > 1:
+    if world > 1 or args.mode is not None:
         from ropebwt3_amd import multi
+        args.mode = args.mode or "interval"
         return multi.bench_main(args, rank, local_rank, world)
     torch.cuda.set_device(local_rank)
 

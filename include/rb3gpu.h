@@ -232,6 +232,26 @@ int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, c
  * (`ropebwt3 merge`, main.c:84-133, with the right-hand index taken as its BWT) */
 int rb3gpu_merge_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE]);
 
+/* INTERVAL-SHARDED INDEX over several GPUs (one process and one handle per GPU; no reference analogue beyond the walk over
+ * the per-rope totals in mr_rank2a, mrope.c:76-88, and the kt_for over strings, fm-index.c:217-224).  The accumulated BWT is
+ * cut into n_iv contiguous intervals of positions, iv_bounds[i] .. iv_bounds[i+1]; the handle of rank i holds the block array
+ * of interval i only (build it with rb3gpu_from_plain[_dev] from that slice of the BWT).  A chain STATE is the text position
+ * of the current suffix of a string of the batch and its insertion point ka in the whole BWT; it lives on the rank whose
+ * interval contains ka.  The batch (its text-order words d_tw, rb3gpu_sort_text) is replicated on every rank.
+ *   rb3gpu_sh_step   one LF step (fm-index.c:166-173) for the n_states states resident here: ka is recorded for the suffix's
+ *                    row in d_ka (len of the batch int64, -1 = not recorded), the next states are written to d_send GROUPED
+ *                    BY THE INTERVAL THAT OWNS THEM, counts[d] of them for interval d (the split sizes of the all-to-all),
+ *                    counts[n_iv] = chains that reached the start of their string.  adj[c] = C[c] of the whole BWT + symbols c
+ *                    in the intervals before this one - C[c] of this interval (rb3gpu_get_acc of every rank, all-gathered).
+ *   rb3gpu_sh_finish the rows jlo .. jlo + n_rows - 1 of the batch are the ones whose insertion points lie in this interval
+ *                    (ka is monotone in the row number, so they are contiguous, and this rank recorded every one of them):
+ *                    interleave them into the interval (worker_mgins, fm-index.c:237-249) and rebuild its block array. */
+#define RB3GPU_SH_MAXIV 64
+typedef struct { int64_t tp, ka; } rb3gpu_state_t;
+int rb3gpu_sh_step(rb3gpu_t *h, int64_t n_states, const rb3gpu_state_t *d_in, const uint64_t *d_tw, int64_t *d_ka, const int64_t adj[RB3GPU_ASIZE],
+		int n_iv, const int64_t *iv_bounds, int my_iv, rb3gpu_state_t *d_send, int64_t *counts);
+int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_bwt, const int64_t *d_ka, int64_t iv_start, int commit);
+
 /* Diagnostic switches of a handle (no reference analogue; none is needed in normal use).  Each key is also read ONCE from
  * the environment variable RB3GPU_<KEY> when the handle is created; the merge path itself never calls getenv().
  *   "tent" 0/1, "staged" 0/1, "group_rebuild" 0/1, "window_rebuild" 0/1, "reb_force" 0/1, "octs" 1..8, "blkmul", "blkcap", "ssa_split" 4..20,
@@ -249,6 +269,8 @@ int rb3gpu_dev_alloc(rb3gpu_t *h, int64_t n_bytes, void **d_ptr);
 int rb3gpu_dev_upload(rb3gpu_t *h, void *d_dst, const void *src, int64_t n_bytes);
 int rb3gpu_dev_download(rb3gpu_t *h, void *dst, const void *d_src, int64_t n_bytes);
 int rb3gpu_dev_free(rb3gpu_t *h, void *d_ptr);
+int rb3gpu_dev_copy(rb3gpu_t *h, void *d_dst, const void *d_src, int64_t n_bytes);   /* device to device */
+int rb3gpu_dev_memset(rb3gpu_t *h, void *d_dst, int byte, int64_t n_bytes);
 int rb3gpu_sync(rb3gpu_t *h);
 
 /* number of HIP devices visible, or a negative error */

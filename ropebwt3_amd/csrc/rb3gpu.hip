@@ -1652,6 +1652,110 @@ int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs)
 	return rb3gpu_from_plain_dev(h, tot, (const uint8_t*)h->b2.p);
 }
 
+/* ---- interval-sharded index (north_star): see k_sh_step ---- */
+
+int rb3gpu_sh_step(rb3gpu_t *h, int64_t n_states, const rb3gpu_state_t *d_in, const uint64_t *d_tw, int64_t *d_ka, const int64_t adj[RB3GPU_ASIZE],
+		int n_iv, const int64_t *iv_bounds, int my_iv, rb3gpu_state_t *d_send, int64_t *counts)
+{
+	if (!h || n_states < 0 || !d_tw || !d_ka || !adj || !iv_bounds || !counts || n_iv < 1 || n_iv > RB3_SH_MAXIV || my_iv < 0 || my_iv >= n_iv) return RB3GPU_EINVAL;
+	if (n_states > 0 && (!d_in || !d_send)) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	for (int i = 0; i <= n_iv; ++i) counts[i] = 0;
+	if (n_states == 0) return 0;
+	int r;
+	// scratch: new states + destinations, counters (n_iv + 1), cursors (n_iv + 1), bad
+	const size_t cnt_off = ((size_t)n_states * 20 + 255) & ~(size_t)255;
+	if ((r = buf_ensure(h, h->xbuf, cnt_off + (size_t)(2 * RB3_SH_MAXIV + 4) * 8)) < 0) return r;
+	ShState *d_out = (ShState*)h->xbuf.p;
+	int32_t *d_dest = (int32_t*)(d_out + n_states);
+	unsigned long long *d_cnt = (unsigned long long*)((char*)h->xbuf.p + cnt_off), *d_cur = d_cnt + RB3_SH_MAXIV + 1, *d_bad = d_cur + RB3_SH_MAXIV + 1;
+	ShArgs a;
+	memset(&a, 0, sizeof(a));
+	for (int c = 0; c < 6; ++c) a.adj[c] = adj[c];
+	for (int i = 0; i <= n_iv; ++i) a.bounds[i] = iv_bounds[i];
+	a.iv_start = iv_bounds[my_iv], a.n_iv = n_iv;
+	HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(2 * RB3_SH_MAXIV + 4) * 8, h->st));
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	int64_t nblk = (n_states * 8 + 255) / 256;
+	if (nblk > 256 * 16) nblk = 256 * 16;
+	hipLaunchKernelGGL(k_sh_step, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), a, n_states, (const ShState*)d_in, d_tw, d_ka, d_out, d_dest, d_cnt, d_bad);
+	unsigned long long hc[RB3_SH_MAXIV + 1], hbad = 0;
+	HIPCHK(hipMemcpyAsync(hc, d_cnt, (size_t)(n_iv + 1) * 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipMemcpyAsync(&hbad, d_bad, 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	if (hbad != 0) return RB3GPU_EINTERNAL;
+	ShOffsets o;
+	memset(&o, 0, sizeof(o));
+	o.n_iv = n_iv;
+	int64_t tot = 0;
+	for (int i = 0; i <= n_iv; ++i) {
+		counts[i] = (int64_t)hc[i];
+		o.off[i] = tot;
+		if (i < n_iv) tot += counts[i];
+	}
+	if (tot + counts[n_iv] != n_states) return RB3GPU_EINTERNAL;
+	if (tot > 0)
+		hipLaunchKernelGGL(k_sh_scatter, dim3((unsigned)((n_states + 255) / 256)), dim3(256), 0, h->st, o, n_states, (const ShState*)d_out, (const int32_t*)d_dest, (ShState*)d_send, d_cur);
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_rank += ev_ms(h->ev[0], h->ev[1]);
+	h->stt.n_lf_steps += n_states, h->stt.n_rank_launches += 1;
+	return 0;
+}
+
+int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_bwt, const int64_t *d_ka, int64_t iv_start, int commit)
+{
+	if (!h || jlo < 0 || n_rows < 0 || !d_bwt || !d_ka) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	if (n_rows == 0) return 0; // nothing landed in this interval
+	const int64_t ntot = h->n + n_rows;
+	int r;
+	if ((r = buf_ensure(h, h->pos, (size_t)n_rows * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	unsigned long long *misc = (unsigned long long*)h->misc.p;
+	int64_t *dpos = (int64_t*)h->pos.p;
+	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
+	HIPCHK(hipEventRecord(h->ev[2], h->st));
+	hipLaunchKernelGGL(k_sh_localpos, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, h->st, jlo, n_rows, d_ka, iv_start, dpos, misc + 2);
+	hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, n_rows, ntot, misc + 2);
+	unsigned long long hm[5] = {0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(hm, misc, 40, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	if (hm[2] != 0 || hm[3] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] sharded merge: %llu rows of the interval unset or misrouted, %llu out of order\n", hm[2], hm[3]);
+		return RB3GPU_EINTERNAL;
+	}
+	int64_t ngrp = 0, nslots = 0, acc[7];
+	if ((r = build_index<false>(h, n_rows, d_bwt + jlo, (const int64_t*)dpos, ntot, false, &ngrp, &nslots, acc)) < 0) return r;
+	HIPCHK(hipEventRecord(h->ev[3], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
+	h->stt.n_symbols_merged += n_rows;
+	h->stt.bytes_rebuild += 9 * n_rows + h->stt.bytes_index + ngrp * (int64_t)sizeof(rb3_grp_t) + nslots * (int64_t)sizeof(rb3_slot_t);
+	if (commit) index_install(h, ngrp, nslots, ntot, acc);
+	return 0;
+}
+
+int rb3gpu_dev_copy(rb3gpu_t *h, void *d_dst, const void *d_src, int64_t n_bytes)
+{
+	if (!h || n_bytes < 0 || (n_bytes > 0 && (!d_dst || !d_src))) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (n_bytes > 0) HIPCHK(hipMemcpyAsync(d_dst, d_src, (size_t)n_bytes, hipMemcpyDeviceToDevice, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
+int rb3gpu_dev_memset(rb3gpu_t *h, void *d_dst, int byte, int64_t n_bytes)
+{
+	if (!h || n_bytes < 0 || (n_bytes > 0 && !d_dst)) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (n_bytes > 0) HIPCHK(hipMemsetAsync(d_dst, byte, (size_t)n_bytes, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
 int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st)
 {
 	if (!h || !st) return RB3GPU_EINVAL;

@@ -2324,6 +2324,97 @@ __global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint3
 }
 
 /* ----------------------------------------------------------------------------------------- */
+/* interval-sharded index: one LF step of many chains per launch (north_star)  */
+/* ----------------------------------------------------------------------------------------- */
+
+/* The accumulated BWT is cut into contiguous INTERVALS of positions, one per GPU; a handle holds the block array of its
+ * interval only.  rank over the whole BWT = rank inside the interval + the symbol totals of the intervals before it -- the
+ * analogue of the walk over the six ropes' totals in mr_rank2a (mrope.c:76-88) -- so with adj[c] = C[c] + (symbols c in the
+ * intervals before) - C_local[c] the LF step of rb3_mg_rank1_plain (fm-index.c:171-173) is LF_local(c, ka - start) + adj[c].
+ * A chain STATE (text position tp of the current suffix, its insertion point ka) lives on the GPU whose interval contains
+ * ka.  k_sh_step advances every state of this GPU by one symbol: record ka for the suffix's row, next ka, and the interval
+ * that owns it; k_sh_scatter groups the new states by destination for the all-to-all.  Chains advance in lock step, one
+ * collective per symbol: for batches of short strings (the kt_for over millions of reads, fm-index.c:217-224). */
+#define RB3_SH_MAXIV 64
+
+struct ShState { int64_t tp, ka; };
+struct ShArgs {
+	int64_t adj[6];
+	int64_t bounds[RB3_SH_MAXIV + 1]; // interval i = [bounds[i], bounds[i+1])
+	int64_t iv_start;
+	int n_iv;
+};
+
+/* counts[d], d = 0..n_iv-1: states that go to interval d; counts[n_iv]: chains that ended (the start of a string was reached) */
+__global__ void __launch_bounds__(256) k_sh_step(IdxView ix, ShArgs a, int64_t n, const ShState *in, const uint64_t *tw, int64_t *ka_rec,
+		ShState *out, int32_t *dest, unsigned long long *counts, unsigned long long *bad)
+{
+	__shared__ uint32_t lc[RB3_SH_MAXIV + 1];
+	const int lane = threadIdx.x & 63, j = lane & 7;
+	for (int i = threadIdx.x; i <= a.n_iv; i += blockDim.x) lc[i] = 0u;
+	__syncthreads();
+	const int64_t nq8 = (int64_t)gridDim.x * (blockDim.x >> 3);
+	for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; q < n; q += nq8) {
+		const ShState st = in[q];
+		const uint64_t x = tw[st.tp];
+		const int64_t kb = (int64_t)(x >> 3);
+		const int c = (int)(x & 7u);
+		int64_t k = st.ka - a.iv_start;
+		if (k < 0 || k > ix.n) { if (j == 0) atomicAdd(bad, 1ull); k = k < 0 ? 0 : ix.n; } // (a state routed to the wrong interval: cannot be)
+		if (j == 0) ka_rec[kb] = st.ka;
+		int d = a.n_iv;
+		ShState nx;
+		nx.tp = st.tp - 1, nx.ka = 0;
+		if (c != 0) { // (wave-uniform control flow is not required: the rank helpers only talk inside an octet)
+			RankLoad r;
+			oct_rank_issue(ix, k, j, r);
+			nx.ka = oct_rank_finish(r, c, j, ix.dense == 2) + a.adj[c];
+			d = 0;
+			for (int i = 1; i < a.n_iv; ++i) d += a.bounds[i] <= nx.ka ? 1 : 0;
+		}
+		if (j == 0) {
+			out[q] = nx, dest[q] = d;
+			atomicAdd(&lc[d], 1u);
+		}
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i <= a.n_iv; i += blockDim.x)
+		if (lc[i]) atomicAdd(&counts[i], (unsigned long long)lc[i]);
+}
+
+/* send[off[d] ...] = the states with dest d (any order inside a destination); cursor[] zeroed by the caller */
+struct ShOffsets { int64_t off[RB3_SH_MAXIV + 1]; int n_iv; };
+__global__ void __launch_bounds__(256) k_sh_scatter(ShOffsets o, int64_t n, const ShState *out, const int32_t *dest, ShState *send, unsigned long long *cursor)
+{
+	__shared__ uint32_t lc[RB3_SH_MAXIV + 1];
+	__shared__ unsigned long long lb[RB3_SH_MAXIV + 1];
+	for (int i = threadIdx.x; i <= o.n_iv; i += blockDim.x) lc[i] = 0u;
+	__syncthreads();
+	const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int d = -1;
+	uint32_t mine = 0;
+	if (q < n) {
+		d = dest[q];
+		if (d < o.n_iv) mine = atomicAdd(&lc[d], 1u); else d = -1; // ended chains are not sent anywhere
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < o.n_iv; i += blockDim.x)
+		lb[i] = lc[i] ? atomicAdd(&cursor[i], (unsigned long long)lc[i]) : 0ull;
+	__syncthreads();
+	if (d >= 0) send[o.off[d] + (int64_t)lb[d] + mine] = out[q];
+}
+
+/* merged position inside the interval of the rows [jlo, jlo + n) that landed in it: pos[r] = (ka - start) + r */
+__global__ void __launch_bounds__(256) k_sh_localpos(int64_t jlo, int64_t n, const int64_t *ka_rec, int64_t iv_start, int64_t *pos, unsigned long long *bad)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	const int64_t ka = ka_rec[jlo + r];
+	if (ka < iv_start) { atomicAdd(bad, 1ull); pos[r] = RB3_UNSET; return; } // unset (-1) or routed wrongly
+	pos[r] = ka - iv_start + r;
+}
+
+/* ----------------------------------------------------------------------------------------- */
 /* export                                                                                      */
 /* ----------------------------------------------------------------------------------------- */
 

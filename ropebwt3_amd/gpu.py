@@ -95,6 +95,10 @@ SYMBOLS = {
     "rb3gpu_dev_download": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     "rb3gpu_dev_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "rb3gpu_dev_copy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "rb3gpu_dev_memset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
+    "rb3gpu_sh_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_sh_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
     "rb3gpu_device_count": (ctypes.c_int, []),
 }
 
@@ -338,6 +342,33 @@ class Rb3Gpu:
 
     def merge_plain_dev(self, d_bwt, length, commit=True):
         self._chk(self._lib.rb3gpu_merge_plain_dev(self._h, length, d_bwt, 1 if commit else 0), "rb3gpu_merge_plain_dev")
+
+    # -- interval-sharded index (multi-GPU; ropebwt3_amd/multi.py) ------------------------------
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_dev_alloc(self._h, int(nbytes), ctypes.byref(p)), "rb3gpu_dev_alloc")
+        return p.value
+
+    def dev_copy(self, d_dst, d_src, nbytes):
+        self._chk(self._lib.rb3gpu_dev_copy(self._h, d_dst, d_src, int(nbytes)), "rb3gpu_dev_copy")
+
+    def dev_memset(self, d_dst, byte, nbytes):
+        self._chk(self._lib.rb3gpu_dev_memset(self._h, d_dst, int(byte), int(nbytes)), "rb3gpu_dev_memset")
+
+    def dev_upload_to(self, d_dst, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self._lib.rb3gpu_dev_upload(self._h, d_dst, arr.ctypes.data, arr.nbytes), "rb3gpu_dev_upload")
+
+    def sh_step(self, n_states, d_in, d_tw, d_ka, adj, bounds, my_iv, d_send):
+        """one LF step of the states resident on this rank; returns counts[n_iv + 1] (see include/rb3gpu.h)"""
+        adj = np.ascontiguousarray(adj, dtype=np.int64)
+        bounds = np.ascontiguousarray(bounds, dtype=np.int64)
+        counts = np.zeros(bounds.size, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_sh_step(self._h, int(n_states), d_in, d_tw, d_ka, adj.ctypes.data, bounds.size - 1, bounds.ctypes.data, int(my_iv), d_send, counts.ctypes.data), "rb3gpu_sh_step")
+        return counts
+
+    def sh_finish(self, jlo, n_rows, d_bwt, d_ka, iv_start, commit=True):
+        self._chk(self._lib.rb3gpu_sh_finish(self._h, int(jlo), int(n_rows), d_bwt, d_ka, int(iv_start), 1 if commit else 0), "rb3gpu_sh_finish")
 
     def sync(self):
         self._chk(self._lib.rb3gpu_sync(self._h), "rb3gpu_sync")

@@ -1,5 +1,12 @@
-"""Multi-GPU merge: index replicated on every GPU, the LF walkers of one batch sharded by text
-range, one RCCL all-reduce(MAX) of pos[] per merge (SURVEY 8(e) option 2).
+"""Multi-GPU merge.  Three decompositions:
+
+* merge_interval (north_star): the accumulated BWT is cut into contiguous INTERVALS of positions, one per
+  GPU; the chains of a batch of short strings advance in lock step, every chain state is processed on the GPU whose
+  interval contains its insertion point, and one all-to-all per symbol routes the new states to their owners
+  (rb3gpu_sh_step / rb3gpu_sh_finish); the rebuild of every interval is local.
+* merge_sharded (SURVEY 8(e) option 2, long strings): index replicated on every GPU, the LF walkers of one batch sharded
+  by text range, one RCCL all-reduce(MAX) of pos[] per merge.
+* tree_merge: partitioned input, one index per GPU, combined by a binary tree of whole-index merges.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 The reference has no distributed code; what is sharded here is the kt_for over strings of
@@ -123,3 +130,297 @@ def tree_merge(engine, dist, rank, world, device, sync=None):
             dist.send(buf, dst=rank - stride)
         stride *= 2
     return engine.get_tot()
+
+
+
+# ---------------------------------------------------------------------------------------------
+# interval-sharded index (north_star): lock-step chains, all-to-all per symbol
+# ---------------------------------------------------------------------------------------------
+
+class TorchComm:
+    """collectives of one rank over torch.distributed ("nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
+    Buffers are torch tensors; `as_numpy`: the engine is a CPU stand-in that takes numpy views instead of device pointers.
+    sync(): make the engine's stream and torch's stream see each other's work (torch.cuda.synchronize on GPUs)."""
+
+    def __init__(self, dist, rank, world, device, sync=None, as_numpy=False):
+        import torch
+        self.t, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
+        self.sync = sync or (lambda: None)
+        self.as_numpy = as_numpy
+
+    def new_states(self, n):
+        return self.t.empty((max(int(n), 1), 2), dtype=self.t.int64, device=self.device)
+
+    def new_i64(self, n, fill):
+        return self.t.full((max(int(n), 1),), fill, dtype=self.t.int64, device=self.device)
+
+    def ptr(self, buf):
+        return buf.numpy() if self.as_numpy else buf.data_ptr()
+
+    def upload_states(self, buf, arr):
+        if len(arr):
+            buf[:len(arr)].copy_(self.t.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)))
+        self.sync()
+
+    def free(self, buf):
+        pass
+
+    def all_gather(self, vec):
+        v = self.t.tensor(np.asarray(vec, dtype=np.int64), device=self.device)
+        out = [self.t.empty_like(v) for _ in range(self.world)]
+        self.dist.all_gather(out, v)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    def exchange(self, send, send_counts, recv_counts, recv):
+        """all-to-all(v) of states: send is grouped by destination; returns the number of states received into recv"""
+        n_in = int(np.sum(recv_counts))
+        self.sync()
+        if self.world == 1:
+            if n_in:
+                recv[:n_in].copy_(send[:n_in])
+        else:
+            self.dist.all_to_all_single(recv[:n_in], send[:int(np.sum(send_counts))], [int(x) for x in recv_counts], [int(x) for x in send_counts])
+        self.sync()
+        return n_in
+
+
+class ThreadComm:
+    """W ranks as W threads of ONE process on ONE GPU, each with its own engine handle (own HIP stream): the collectives are
+    barriers plus device-to-device copies.  Drives the real engine through the sharded protocol without a multi-GPU node."""
+
+    class Shared:
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank, engine):
+        self.sh, self.rank, self.world, self.engine = shared, rank, shared.world, engine
+
+    def new_states(self, n):
+        return self.engine.dev_alloc(max(int(n), 1) * 16)
+
+    def new_i64(self, n, fill):
+        p = self.engine.dev_alloc(max(int(n), 1) * 8)
+        self.engine.dev_memset(p, 0xff if fill == -1 else 0, max(int(n), 1) * 8)
+        return p
+
+    def ptr(self, buf):
+        return buf
+
+    def upload_states(self, buf, arr):
+        if len(arr):
+            self.engine.dev_upload_to(buf, np.ascontiguousarray(arr, dtype=np.int64))
+
+    def free(self, buf):
+        self.engine.dev_free(buf)
+
+    def all_gather(self, vec):
+        self.sh.slots[self.rank] = np.asarray(vec, dtype=np.int64).copy()
+        self.sh.barrier.wait()
+        out = np.stack(self.sh.slots)
+        self.sh.barrier.wait()
+        return out
+
+    def exchange(self, send, send_counts, recv_counts, recv):
+        off = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+        self.sh.slots[self.rank] = (send, off)
+        self.sh.barrier.wait()
+        n_in = int(np.sum(recv_counts))
+        at = 0
+        for src in range(self.world):
+            p, o = self.sh.slots[src]
+            n = int(o[self.rank + 1] - o[self.rank])
+            if n:
+                self.engine.dev_copy(recv + at * 16, p + int(o[self.rank]) * 16, n * 16)
+            at += n
+        self.sh.barrier.wait()
+        return n_in
+
+
+def interval_bounds(n, world):
+    """world contiguous intervals of about equal length over n positions"""
+    return np.array([n * r // world for r in range(world + 1)], dtype=np.int64)
+
+
+def merge_interval(engine, comm, bounds, d_bwt, d_tw, n2, sent_tp, commit=True, stats=None):
+    """One merge of a batch of (short) strings into the interval-sharded index (north_star).
+
+    engine:  this rank's handle; it holds the block array of interval comm.rank = [bounds[r], bounds[r+1]).
+    d_bwt, d_tw: the batch's BWT and text-order words, replicated on every rank (device pointers of this rank).
+    sent_tp: text positions of the sentinels of the batch (host int64 array, the same on every rank): where the chains start.
+    Returns the interval bounds after the merge (every rank computes the same array).
+    """
+    rank, world = comm.rank, comm.world
+    bounds = np.asarray(bounds, dtype=np.int64)
+    # symbol totals of every interval -> C array of the whole BWT and this interval's additive offsets (mrope.c:76-88)
+    acc = np.asarray(engine.get_acc(), dtype=np.int64)
+    allc = comm.all_gather(np.diff(acc)[:6])                       # world x 6
+    tot = allc.sum(axis=0)
+    C = np.concatenate([[0], np.cumsum(tot)])[:6]
+    pre = allc[:rank].sum(axis=0) if rank > 0 else np.zeros(6, dtype=np.int64)
+    adj = C + pre - acc[:6]
+    m1 = int(tot[0])                                               # every chain starts at ka = #sentinels of the index (fm-index.c:164)
+    owner0 = int(np.sum(bounds[1:world] <= m1))
+    d_ka = comm.new_i64(n2, -1)
+    # two state buffers for the whole merge: a rank never holds more states than there are strings
+    cap = len(sent_tp)
+    cur, nxt = comm.new_states(cap), comm.new_states(cap)
+    n_cur = cap if rank == owner0 else 0
+    if n_cur:
+        st = np.empty((n_cur, 2), dtype=np.int64)
+        st[:, 0], st[:, 1] = sent_tp, m1
+        comm.upload_states(cur, st)
+    rows_here, rounds = 0, 0
+    while True:
+        rows_here += n_cur
+        counts = engine.sh_step(n_cur, comm.ptr(cur), d_tw, comm.ptr(d_ka), adj, bounds, rank, comm.ptr(nxt))   # nxt: grouped by destination
+        M = comm.all_gather(counts[:world])                        # M[s][d]: states rank s sends to rank d
+        rounds += 1
+        if int(M.sum()) == 0:
+            break
+        n_cur = comm.exchange(nxt, M[rank], M[:, rank], cur)
+    comm.free(cur)
+    comm.free(nxt)
+    R = comm.all_gather([rows_here])[:, 0]
+    jlo = int(R[:rank].sum())
+    if int(R.sum()) != n2:
+        raise RuntimeError("sharded merge recorded %d of %d rows" % (int(R.sum()), n2))
+    engine.sh_finish(jlo, rows_here, d_bwt, comm.ptr(d_ka), int(bounds[rank]), commit)
+    comm.free(d_ka)
+    if stats is not None:
+        stats["rounds"] = rounds
+        stats["rows_per_rank"] = [int(x) for x in R]
+    grow = np.concatenate([[0], np.cumsum(R)])
+    return bounds + grow if commit else bounds
+
+
+def bench_main(args, rank, local_rank, world):
+    """bench.py --gpus N (N > 1), one process per GPU.  --mode interval (default): north_star -- the index of a random genome
+    is cut into N intervals, every step merges one batch of reads (N x 100 k reads of 150 bp, both strands: per-GPU work fixed)
+    with merge_interval; the timed step holds every all-gather, the all-to-all of every symbol and the local rebuilds.
+    --mode partition: every GPU merges its own genome into its own index, then the tree merge, all inside the timed region.
+    --mode replicated: one batch of N genomes, walkers sharded by text range, all-reduce of pos[]."""
+    import json
+    import os
+    import sys
+    import time
+    import torch
+    import torch.distributed as dist
+    from ropebwt3_amd import Rb3Gpu, host
+    from tests import util
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    h = Rb3Gpu(device=local_rank, verbose=1)
+
+    def barrier():
+        h.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    out = None
+    if args.mode == "interval":
+        n_index, reads_per_gpu = (1 << 26) * world, 100000
+        rng = np.random.default_rng(31)
+        g = util.random_genome(rng, n_index // 2 - 1)
+        t1 = util.make_text([g])
+        d1, d1tw = h.sort_text(t1)                                  # every rank sorts the (synthetic) index text itself: no broadcast needed
+        b1 = h.dev_download(d1, t1.size)
+        h.dev_free(d1), h.dev_free(d1tw)
+        bounds = interval_bounds(b1.size, world)
+        h.from_plain(b1[bounds[rank]:bounds[rank + 1]])
+        st = rng.integers(0, len(g) - 150, size=reads_per_gpu * world)
+        r = np.stack([g[s:s + 150] for s in st])
+        m = rng.random(r.shape) < 0.01
+        r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
+        t2 = util.make_text(list(r))
+        d2, d2tw = h.sort_text(t2)
+        sent = np.flatnonzero(t2 == 0).astype(np.int64)
+        comm = TorchComm(dist, rank, world, dev, sync=lambda: (h.sync(), torch.cuda.synchronize()))
+        stt = {}
+        for _ in range(args.warmup):
+            merge_interval(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
+        h.stats_reset()
+        barrier()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            merge_interval(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
+        barrier()
+        dt = time.perf_counter() - t
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        s = h.stats()
+        if rank == 0:
+            out = {"metric": "Gbp/s indexed (build merge)", "value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+                   "config": {"workload": "interval-sharded index (north_star): %d symbols in %d intervals, one per GPU; per step one batch of %d x 150 bp reads (both strands, %d symbols) merged with one all-to-all per symbol" % (b1.size, world, reads_per_gpu * world, t2.size),
+                              "symbols_per_step_per_gpu": int(t2.size // world), "index_symbols": int(b1.size), "parallelism": "interval%d: chain states routed to the owner of their insertion point by RCCL all-to-all(v), %d lock-step rounds per merge; local rebuild per interval" % (world, stt.get("rounds", 0)),
+                              "rows_per_rank": stt.get("rows_per_rank")},
+                   "phases_ms_per_step_rank0": {"step_kernels": round(s["ms_rank"] / args.steps, 3), "rebuild": round(s["ms_build"] / args.steps, 3)},
+                   "roofline": {"bound": "hbm", "kernel": "k_sh_step", "achieved": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                "frac": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6 / 8000.0, 5), "traffic": None,
+                                "note": "rank 0: 208 B x the LF steps it executed / the time of its step kernels; the collectives are outside this figure and inside `value`"}}
+    elif args.mode == "partition":
+        g0, gs = util.random_genome(np.random.default_rng(1), args.genome_len), None
+        g1 = util.mutate(np.random.default_rng(2 + rank), g0, args.div)
+        b1 = host.build_bwt(util.make_text([g0]))
+        t2 = util.make_text([g1])
+        w = host.walkers_text(t2, args.walker_step)
+        for _ in range(args.warmup):
+            h.from_plain(b1)
+            d2, d2tw = h.sort_text(t2)
+            h.merge_text_dev(d2, d2tw, t2.size, w, commit=True)
+            h.dev_free(d2), h.dev_free(d2tw)
+        barrier()
+        t = time.perf_counter()
+        for _ in range(args.steps):                                  # a whole partitioned build per step: leaf merges + tree merge
+            h.from_plain(b1)
+            d2, d2tw = h.sort_text(t2)
+            h.merge_text_dev(d2, d2tw, t2.size, w, commit=True)
+            h.dev_free(d2), h.dev_free(d2tw)
+            tot = tree_merge(h, dist, rank, world, dev, sync=torch.cuda.synchronize)
+        barrier()
+        dt = time.perf_counter() - t
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        if rank == 0:
+            assert tot == world * (b1.size + t2.size)
+            out = {"metric": "Gbp/s indexed (build merge)", "value": round(world * (b1.size + t2.size) * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+                   "config": {"workload": "partitioned build END TO END: every GPU indexes 2 genomes of %d bp (index of G0, merge of G_r), then the per-GPU indexes are combined by a binary tree of whole-index merges into rank 0; all of it inside the timed region" % args.genome_len,
+                              "parallelism": "partition%d + tree merge (plain BWTs over RCCL); note DESIGN.md section 6: merging B into A costs |B| LF steps however B was built, so the tree's critical path equals the sequential build" % world}}
+    else:
+        seeds = [2 + i for i in range(world)]
+        g0 = util.random_genome(np.random.default_rng(1), args.genome_len)
+        gs = [util.mutate(np.random.default_rng(sd), g0, args.div) for sd in seeds]
+        b1 = host.build_bwt(util.make_text([g0]))
+        b2, walkers = host.build_bwt_walkers(util.make_text(gs), args.walker_step)
+        h.from_plain(b1)
+        d2 = h.dev_upload(b2)
+        pos = torch.empty(b2.size, dtype=torch.int64, device=dev)
+        for _ in range(args.warmup):
+            merge_sharded(h, d2, b2.size, walkers, args.walker_step, dist, rank, world, pos, commit=False, sync=torch.cuda.synchronize)
+        barrier()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            merge_sharded(h, d2, b2.size, walkers, args.walker_step, dist, rank, world, pos, commit=False, sync=torch.cuda.synchronize)
+        barrier()
+        dt = time.perf_counter() - t
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        if rank == 0:
+            out = {"metric": "Gbp/s indexed (build merge)", "value": round(b2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+                   "config": {"workload": "one batch of %d genomes of %d bp merged into the index of G0, replicated on every GPU" % (world, args.genome_len),
+                              "parallelism": "replicated%d: walkers sharded by text range, all-reduce(MAX) of pos[] (8 B per batch row), every GPU rebuilds its replica" % world}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    h.close()
+    dist.destroy_process_group()

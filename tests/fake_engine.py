@@ -97,3 +97,52 @@ class FakePlainEngine:
         b2 = np.empty(n, dtype=np.uint8)
         ctypes.memmove(b2.ctypes.data, ptr, n)
         self.b = self.orc.merge(self.b, b2)
+
+
+class FakeShardEngine:
+    """numpy stand-in for the interval-sharded calls (rb3gpu_sh_step / rb3gpu_sh_finish / rb3gpu_get_acc) of ONE rank: it
+    holds the symbols of its interval of the accumulated BWT.  For the gloo tests of ropebwt3_amd.multi.merge_interval."""
+
+    def __init__(self, b1_slice):
+        self.b = np.asarray(b1_slice, dtype=np.uint8).copy()
+        self.steps = 0
+
+    def get_acc(self):
+        return np.concatenate([[0], np.cumsum(np.bincount(self.b, minlength=6)[:6])]).astype(np.int64)
+
+    def sh_step(self, n_states, d_in, d_tw, d_ka, adj, bounds, my_iv, d_send):
+        n_iv = len(bounds) - 1
+        counts = np.zeros(n_iv + 1, dtype=np.int64)
+        acc = self.get_acc()
+        start = int(bounds[my_iv])
+        out = [[] for _ in range(n_iv)]
+        for q in range(n_states):
+            tp, ka = int(d_in[q, 0]), int(d_in[q, 1])
+            x = int(d_tw[tp])
+            kb, c = x >> 3, x & 7
+            k = ka - start
+            assert 0 <= k <= self.b.size, "state routed to the wrong interval"
+            d_ka[kb] = ka
+            self.steps += 1
+            if c == 0:
+                counts[n_iv] += 1
+                continue
+            nka = int(acc[c] + np.count_nonzero(self.b[:k] == c) + adj[c])
+            d = int(np.sum(np.asarray(bounds[1:n_iv]) <= nka))
+            out[d].append((tp - 1, nka))
+            counts[d] += 1
+        at = 0
+        for d in range(n_iv):
+            for tp, ka in out[d]:
+                d_send[at, 0], d_send[at, 1] = tp, ka
+                at += 1
+        return counts
+
+    def sh_finish(self, jlo, n_rows, d_bwt, d_ka, iv_start, commit=True):
+        if n_rows == 0:
+            return
+        ka = np.asarray(d_ka[jlo:jlo + n_rows], dtype=np.int64)
+        assert (ka >= iv_start).all(), "rows of the interval unset or misrouted"
+        assert (np.diff(ka) >= 0).all(), "ka not monotone"
+        if commit:
+            self.b = np.insert(self.b, ka - iv_start, np.asarray(d_bwt[jlo:jlo + n_rows], dtype=np.uint8))

@@ -141,3 +141,77 @@ def test_tree_merge_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
+
+
+def _interval_worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ropebwt3_amd import host, multi
+    from tests import util
+    from tests.fake_engine import FakeShardEngine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(17)
+        g0 = util.random_genome(rng, 3000)
+        orc = util.Oracle()
+        cur = orc.bwt(util.make_text([g0] + util.reads_from(rng, g0, 10, 50)))
+        bounds = multi.interval_bounds(cur.size, world)
+        eng = FakeShardEngine(cur[bounds[rank]:bounds[rank + 1]])
+        comm = multi.TorchComm(dist, rank, world, torch.device("cpu"), as_numpy=True)
+        rounds = []
+        for b in range(3):     # three batches in a row: the interval bounds move with every merge
+            if case == "reads":
+                seqs = util.reads_from(rng, g0, 30, 40, err=0.02)
+            elif case == "dups":   # exact duplicates of indexed text and of each other: ties are broken by the sentinel order
+                seqs = [g0[100:160].copy(), g0[100:160].copy(), g0[:30].copy()] + util.reads_from(rng, g0, 5, 40)
+            else:                  # strings of very different lengths
+                seqs = [util.mutate(rng, g0, 0.01)[:400], g0[5:9].copy(), util.mutate(rng, g0, 0.02)[1000:1100]]
+            t2 = util.make_text(seqs, rev=(b != 1))
+            b2 = host.build_bwt(t2.copy())
+            # text-order words of the batch from its suffix array (what rb3gpu_sort_text leaves in HBM)
+            sa = np.array(sorted(range(t2.size), key=lambda i: _suffix_key(t2, i)), dtype=np.int64)
+            isa = np.empty(t2.size, dtype=np.int64)
+            isa[sa] = np.arange(t2.size)
+            prev = np.concatenate([[0], t2[:-1]]).astype(np.int64)
+            tw = (isa << 3) | prev
+            assert np.array_equal(b2, prev[sa].astype(np.uint8))
+            st = {}
+            bounds = multi.merge_interval(eng, comm, bounds, b2, tw, t2.size, np.flatnonzero(t2 == 0), commit=True, stats=st)
+            rounds.append(st["rounds"])
+            cur = orc.merge(cur, b2)
+            assert bounds[-1] == cur.size
+            assert np.array_equal(eng.b, cur[bounds[rank]:bounds[rank + 1]]), (case, b, rank)
+        q.put((rank, True, rounds))
+    finally:
+        dist.destroy_process_group()
+
+
+def _suffix_key(t, i):
+    """suffix of the multi-string text starting at i, cut after its sentinel, with the sentinel ranked by its position
+    (the i-th sentinel sorts before the (i+1)-th, sais-ss.c:16-21)"""
+    j = i
+    while t[j] != 0:
+        j += 1
+    return tuple(int(x) + 1 for x in t[i:j]) + (0, j)
+
+
+@pytest.mark.parametrize("world,case", [(2, "reads"), (3, "reads"), (2, "dups"), (2, "ragged"), (4, "ragged")])
+def test_interval_sharded_merge_gloo(world, case):
+    """merge_interval (north_star: index cut into intervals, one all-to-all per symbol) over gloo with a numpy stand-in per
+    rank: after every merge the concatenation of the intervals is the oracle's merged BWT"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_interval_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert all(r[2] == res[0][2] for r in res)      # every rank went through the same number of rounds
+    assert min(res[0][2]) >= 5                       # (longest string + 1)

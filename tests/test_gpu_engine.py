@@ -790,3 +790,67 @@ def test_run_space_rebuild_vs_oracle_and_window_rebuild(oracle, seed, nrel, L, p
         assert np.array_equal(ok, cum[ks])
     finally:
         ha.close(), hb.close()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "reads"), (3, "reads"), (2, "family"), (4, "dups")])
+def test_interval_sharded_merge_real_engine(oracle, world, kind):
+    """north_star multi-GPU split (ropebwt3_amd.multi.merge_interval) driven through the REAL engine: `world` ranks as
+    threads of this process, each with its own handle (own HIP stream) holding one interval of the accumulated BWT; the
+    collectives are barriers + device-to-device copies (multi.ThreadComm).  Batches of short strings are merged in lock
+    step (rb3gpu_sh_step per symbol, states routed to the owner of their insertion point, rb3gpu_sh_finish per interval);
+    after every merge the concatenation of the intervals is the oracle's merged BWT, and rank queries on the rebuilt
+    intervals agree with it."""
+    import threading
+    from ropebwt3_amd import Rb3Gpu, host, multi
+    rng = np.random.default_rng(300 + world)
+    g0 = util.random_genome(rng, 40000)
+    if kind == "family":   # a run-coded index: relatives of one genome
+        cur = host.build_bwt(util.make_text([util.mutate(rng, g0, 0.002) for _ in range(12)]))
+    else:
+        cur = host.build_bwt(util.make_text([g0] + util.reads_from(rng, g0, 200, 100)))
+    batches = []
+    for b in range(3):
+        if kind == "dups":
+            seqs = [g0[500:650].copy()] * 3 + util.reads_from(rng, g0, 300, 80)
+        else:
+            seqs = util.reads_from(rng, g0, 2000, int(rng.integers(40, 151)), err=0.01)
+        batches.append(util.make_text(seqs, rev=(b != 1)))
+    want = [cur]
+    for t2 in batches:
+        want.append(oracle.merge(want[-1], host.build_bwt(t2.copy())))
+    shared = multi.ThreadComm.Shared(world)
+    bounds0 = multi.interval_bounds(cur.size, world)
+    errs, rounds = [], [None] * world
+
+    def run(rank):
+        try:
+            h = Rb3Gpu(verbose=1)
+            comm = multi.ThreadComm(shared, rank, h)
+            bounds = bounds0
+            h.from_plain(cur[bounds[rank]:bounds[rank + 1]])
+            for b, t2 in enumerate(batches):
+                d_bwt, d_tw = h.sort_text(t2)
+                st = {}
+                bounds = multi.merge_interval(h, comm, bounds, d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0), commit=True, stats=st)
+                h.dev_free(d_bwt), h.dev_free(d_tw)
+                w = want[b + 1]
+                assert bounds[-1] == w.size
+                mine = w[bounds[rank]:bounds[rank + 1]]
+                assert h.get_tot() == mine.size
+                assert np.array_equal(h.export_plain(), mine), (rank, b)
+                ks = np.unique(np.concatenate([rng.integers(0, mine.size + 1, size=50), [0, mine.size]]))
+                cum = np.stack([np.concatenate([[0], np.cumsum(mine == c)]) for c in range(6)], axis=1)
+                assert np.array_equal(h.rank1a(ks), cum[ks])
+                rounds[rank] = st["rounds"]
+            h.close()
+        except BaseException as e:   # (a failed rank must not leave the others waiting at the barrier for ever)
+            errs.append((rank, repr(e)))
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs, errs
+    assert all(r == rounds[0] for r in rounds) and rounds[0] >= 40

@@ -63,6 +63,7 @@ typedef struct {
 	int64_t n_sort_rounds;       /* prefix-doubling rounds of those calls */
 	int64_t n_reb_groups;        /* groups (8192 symbols) of the merges whose rebuild went through the run-space kernel ... */
 	int64_t n_reb_groups_window; /* ... and how many of them it handed on to the per-window kernels (single-sync merges) */
+	int64_t n_lf_checked;        /* batch rows whose LF relation was verified against the index after the rank phase (approximate) */
 	int64_t bytes_rebuild;       /* algorithmic bytes of the rebuilds: per merge 9 B x rows + old block array + new block array */
 } rb3gpu_stats_t;
 
@@ -255,7 +256,7 @@ int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_
 /* Diagnostic switches of a handle (no reference analogue; none is needed in normal use).  Each key is also read ONCE from
  * the environment variable RB3GPU_<KEY> when the handle is created; the merge path itself never calls getenv().
  *   "tent" 0/1, "staged" 0/1, "group_rebuild" 0/1, "window_rebuild" 0/1, "reb_force" 0/1, "octs" 1..8, "blkmul", "blkcap", "ssa_split" 4..20,
- *   "lf_check" n (verify the LF relation of every n-th batch row against the index after each merge; 0 = off)
+ *   "lf_check" n (verify the LF relation of every n-th batch row against the index after each merge; default 4096, 0 = off)
  * Test hooks "force_fallback", "tent_limit", "text_mode" exist only in the test build of the library (compiled with
  * -DRB3GPU_TEST_HOOKS, librb3gpu_hooks.so); the release library answers RB3GPU_EUNSUP.  Unknown key: RB3GPU_EINVAL. */
 int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value);

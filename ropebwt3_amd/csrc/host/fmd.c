@@ -253,6 +253,16 @@ int rb3h_fmdw_dump(const rb3h_fmdw_t *w, FILE *fp)
 	return fflush(fp) == 0 ? 0 : -1;
 }
 
+int rb3h_fmdw_dump_file(const rb3h_fmdw_t *w, const char *fn) /* rld_dump(e, fn) */
+{
+	FILE *fp = fopen(fn, "wb");
+	int r;
+	if (fp == 0) return -1;
+	r = rb3h_fmdw_dump(w, fp);
+	if (fclose(fp) != 0) r = -1;
+	return r;
+}
+
 /* ------------------------------------------------------------------------------------- */
 /* reader                                                                                */
 /* ------------------------------------------------------------------------------------- */

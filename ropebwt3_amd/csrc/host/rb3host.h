@@ -58,6 +58,7 @@ int rb3h_fmdw_enc(rb3h_fmdw_t *w, int64_t l, int c);                        /* r
 int rb3h_fmdw_enc_words(rb3h_fmdw_t *w, int64_t n, const uint64_t *words, int64_t end); /* bulk: start << 3 | sym of maximal runs */
 int rb3h_fmdw_adopt(rb3h_fmdw_t *w, uint64_t *words, int64_t n_words, const int64_t acc[7]); /* data section packed elsewhere */
 int rb3h_fmdw_finish(rb3h_fmdw_t *w);                                      /* rld_enc_finish, rld0.c:206-216 */
+int rb3h_fmdw_dump_file(const rb3h_fmdw_t *w, const char *fn);
 int rb3h_fmdw_dump(const rb3h_fmdw_t *w, FILE *fp);                         /* rld_dump, rld0.c:222-243 */
 void rb3h_fmdw_destroy(rb3h_fmdw_t *w);
 int64_t rb3h_fmdw_nbytes(const rb3h_fmdw_t *w);

@@ -55,11 +55,12 @@ struct Tune {
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
 	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
-	int lf_check = 0;        // sampled LF-consistency check of pos[] after every merge (0: off, n: every n-th row)
+	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
 #ifdef RB3GPU_TEST_HOOKS
 	int force_fallback = 0;  // pretend the tentative pass left unsettled records
 	int64_t tent_limit = -1; // shrink the stretch table
 	int text_mode = 0;       // force how the text-order words are fetched (1: per lane, 2: 64 bytes per octet)
+	int corrupt_pos = 0;     // move a range of rows of pos[] by one after the walk (still monotone): the LF check must notice
 #endif
 };
 
@@ -67,6 +68,8 @@ struct rb3gpu_s {
 	int dev = 0;
 	Tune tn;
 	hipStream_t st = nullptr;
+	hipStream_t st2 = nullptr;  // side stream: the sampled LF check of pos[] runs beside the rebuild
+	hipEvent_t evx[2];
 	rb3gpu_opt_t opt;
 	rb3gpu_stats_t stt;
 	// the index: grp/slots point into ib[cur]; a merge builds into ib[1-cur] and swaps on commit
@@ -221,9 +224,10 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
-	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode")) {
+	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos")) {
 #ifdef RB3GPU_TEST_HOOKS
-		if (!strcmp(key, "force_fallback")) t.force_fallback = v != 0;
+		if (!strcmp(key, "corrupt_pos")) t.corrupt_pos = v != 0;
+		else if (!strcmp(key, "force_fallback")) t.force_fallback = v != 0;
 		else if (!strcmp(key, "tent_limit")) t.tent_limit = v;
 		else t.text_mode = v == 1 || v == 2 ? (int)v : 0;
 #else
@@ -242,7 +246,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
 	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "octs", "blkmul", "blkcap", "ssa_split", "lf_check",
-		"force_fallback", "tent_limit", "text_mode", nullptr };
+		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
 		size_t l = strlen(name);
@@ -269,8 +273,11 @@ rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
 	tune_from_env(h);
 	memset(&h->stt, 0, sizeof(h->stt));
 	if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
+	if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
 	for (int i = 0; i < 8; ++i)
 		if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return nullptr; }
+	for (int i = 0; i < 2; ++i)
+		if (hipEventCreateWithFlags(&h->evx[i], hipEventDisableTiming) != hipSuccess) { delete h; return nullptr; }
 	h->t0 = now_s();
 	return h;
 }
@@ -334,6 +341,8 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	for (Buf *b : all) buf_release(h, *b);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
+	for (int i = 0; i < 2; ++i) (void)hipEventDestroy(h->evx[i]);
+	(void)hipStreamDestroy(h->st2);
 	for (int i = 0; i < 2; ++i) if (h->stage[i]) (void)hipHostFree(h->stage[i]);
 	rb3sort_destroy(h->sorter);
 	(void)hipStreamDestroy(h->st);
@@ -547,6 +556,25 @@ static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_ro
 	return 0;
 }
 
+/* the sampled LF-consistency check of pos[] (k_lf_check), against the index as it is BEFORE the merge is installed; counts into
+ * misc[4] (with the unsettled tentative records: a failure first makes the merge redo its rank phase without speculation) */
+static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b2, int64_t len, bool side)
+{
+	const int64_t stride = h->tn.lf_check;
+	if (stride <= 0 || h->tpre.p == nullptr) return false;
+	unsigned long long *misc = (unsigned long long*)h->misc.p;
+	const int64_t ns = (len + stride - 1) / stride;
+	hipStream_t s = h->st;
+	if (side) { // beside the rebuild: pos[] is read-only from here on, and a rebuild from a wrong-but-monotone pos[] is harmless (never installed)
+		if (hipEventRecord(h->evx[0], h->st) != hipSuccess || hipStreamWaitEvent(h->st2, h->evx[0], 0) != hipSuccess) side = false;
+		else s = h->st2;
+	}
+	hipLaunchKernelGGL(k_lf_check, dim3((unsigned)((ns * 8 + 255) / 256)), dim3(256), 0, s, view_of(h), dpos, d_b2, len, (const uint64_t*)h->tpre.p,
+			(const uint64_t*)(misc + MISC_LF_TOT), stride, misc + 2, misc + 6);
+	if (side) (void)hipEventRecord(h->evx[1], h->st2);
+	return side; // true: the caller makes its stream wait for evx[1] before it reads the counters
+}
+
 static int pick_split(const rb3gpu_t *h, int64_t len, int64_t m2)
 {
 	if (h->opt.split_log2 < 0) return 0;
@@ -707,12 +735,14 @@ static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)h->mg_pos, len, ntot, misc + 2);
-	unsigned long long hm[5] = {0, 0, 0, 0, 0};
-	HIPCHK(hipMemcpyAsync(hm, misc, 40, hipMemcpyDeviceToHost, h->st));
+	(void)launch_lf_check(h, (const int64_t*)h->mg_pos, h->mg_b2, len, false);
+	unsigned long long hm[7] = {0, 0, 0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(hm, misc, 56, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	h->stt.n_lf_steps += (int64_t)hm[1];
+	h->stt.n_lf_checked += (int64_t)hm[6];
 	if (hm[2] != 0 || hm[3] != 0 || hm[4] != 0) {
-		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu tentative records unsettled\n", hm[2], hm[3], hm[4]);
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu tentative records unsettled or rows that fail the LF relation\n", hm[2], hm[3], hm[4]);
 		return RB3GPU_EINTERNAL;
 	}
 	int64_t ngrp = 0, nslots = 0, acc[7];
@@ -931,10 +961,15 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		else
 			hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, len, ntot, misc + 2);
 	}
+#ifdef RB3GPU_TEST_HOOKS
+	if (h->tn.corrupt_pos) hipLaunchKernelGGL(k_test_corrupt, dim3((unsigned)(len / 6 / 256 + 1)), dim3(256), 0, h->st, dpos, len);
+#endif
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
+	const bool lf_side = launch_lf_check(h, (const int64_t*)dpos, d_b2, len, true);
 	int64_t ngrp = 0, nslots = 0, acc[7];
 	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[3], h->st));
+	if (lf_side) HIPCHK(hipStreamWaitEvent(h->st, h->evx[1], 0));
 	unsigned long long hm[32];
 	HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));
 	if (host_pos) HIPCHK(hipMemcpyAsync(host_pos, dpos, (size_t)len * 8, hipMemcpyDeviceToHost, h->st));
@@ -945,6 +980,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	h->stt.n_lf_steps += (int64_t)hm[1];
+	h->stt.n_lf_checked += (int64_t)hm[6];
 #ifdef RB3_PROF
 	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, max iterations %llu -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], hm[12], (double)hm[9] / hm[10]);
 #endif
@@ -967,8 +1003,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, 0);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, 0);
 	}
-	if (hm[2] != 0 || hm[3] != 0) {
-		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order\n", hm[2], hm[3]);
+	if (hm[2] != 0 || hm[3] != 0 || hm[4] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu sampled rows that fail the LF relation\n", hm[2], hm[3], hm[4]);
 		return RB3GPU_EINTERNAL;
 	}
 	h->stt.n_symbols_merged += len;

@@ -1068,6 +1068,69 @@ __global__ void __launch_bounds__(256) k_pos_check(const int64_t *pos, int64_t n
 	else if (p >= ntot || (i > 0 && pos[i - 1] >= 0 && pos[i - 1] >= p)) atomicAdd(&bad[1], 1ull);
 }
 
+#ifdef RB3GPU_TEST_HOOKS
+/* test hook: a wrong-but-monotone pos[] -- every row in [n2/3, n2/2) whose successor leaves room moves one position up */
+__global__ void __launch_bounds__(256) k_test_corrupt(int64_t *pos, int64_t n2)
+{
+	const int64_t i = n2 / 3 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i + 1 >= n2 / 2) return;
+	const int64_t p = pos[i], q = pos[i + 1];
+	if (p >= 0 && q >= 0 && !(p & RB3_TENT) && !(q & RB3_TENT) && q - p >= 3) pos[i] = p + 1;
+}
+#endif
+
+/* Sampled check of pos[] against the index itself, independent of how the walkers got there: for a
+ * row kb of the batch with symbol c != $, the row of the suffix one symbol longer is kb' = C2[c] + rank_B2(c, kb) and its
+ * insertion point must be ka[kb'] = C1[c] + rank_B1(c, ka[kb]) (fm-index.c:171-173), where ka[r] = pos[r] - r; the sentinel
+ * rows have ka = m1 (fm-index.c:164).  If this holds for every row, pos[] is the reference's rb[] >> 6 by induction along
+ * every string; here it is verified for every `stride`-th row (one octet per sample: the count inside the 4096-byte tile of
+ * B2, then one rank on B1), which finds any systematic error of the speculative walkers at sizes no CPU oracle reaches.
+ * bad[4] (shared with "tentative records unsettled": the merge is redone without them, then fails) counts mismatches. */
+__global__ void __launch_bounds__(256) k_lf_check(IdxView b1, const int64_t *pos, const uint8_t *b2, int64_t n2, const uint64_t *tpre, const uint64_t *tot2,
+		int64_t stride, unsigned long long *bad, unsigned long long *nchecked)
+{
+	if ((bad[0] | bad[1] | bad[2]) != 0) return; // pos[] already failed validation
+	const int lane = threadIdx.x & 63, j = lane & 7;
+	const int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+	// spread the samples over the residues of the stride so that repeated merges look at different rows
+	const int64_t kb = s * stride + (int64_t)((uint64_t)(s * 0x9E3779B97F4A7C15ull) >> 40) % stride;
+	if (kb >= n2) return;
+	const int64_t m2 = (int64_t)tot2[0];
+	const int64_t ka = pos[kb] - kb;
+	const int c = (int)b2[kb];
+	bool ok = ka >= 0 && ka <= b1.n && c <= 5;
+	if (kb < m2 && ka != b1.m) ok = false; // a sentinel row
+	if (ok && c != 0) {
+		const int64_t tile = kb >> 12, base = tile << 12;
+		const int r = (int)(kb - base);
+		uint32_t cnt = 0;
+		if (((uintptr_t)b2 & 7) == 0) { // eight bytes at a time: bytes are 0..7, so (y + 0x7f) has bit 7 set exactly in the bytes that differ from c
+			const uint64_t *w8 = (const uint64_t*)(b2 + base);
+			const uint64_t pat = 0x0101010101010101ull * (uint64_t)c;
+			for (int w = j; w * 8 < r; w += 8) {
+				const uint64_t y = w8[w] ^ pat;
+				uint64_t ne = ((y & 0x0707070707070707ull) + 0x7F7F7F7F7F7F7F7Full) & 0x8080808080808080ull;
+				const int nbytes = r - w * 8 < 8 ? r - w * 8 : 8; // bytes of this word that lie before the row
+				if (nbytes < 8) ne |= ~0ull << (8 * nbytes);      // the others count as different
+				cnt += 8u - (uint32_t)__popcll(ne & 0x8080808080808080ull);
+			}
+		} else
+			for (int i = j; i < r; i += 8) cnt += b2[base + i] == (uint8_t)c ? 1u : 0u;
+		cnt = oct_sum(cnt);
+		int64_t c2 = 0;
+		for (int a = 0; a < c; ++a) c2 += (int64_t)tot2[a];
+		const int64_t kbn = c2 + (int64_t)tpre[tile * 8 + c] + cnt;
+		RankLoad rl;
+		oct_rank_issue(b1, ka, j, rl);
+		const int64_t want = oct_rank_finish(rl, c, j, b1.dense == 2);
+		if (kbn < 0 || kbn >= n2 || pos[kbn] - kbn != want) ok = false;
+	}
+	if (j == 0) {
+		if (!ok) atomicAdd(&bad[2], 1ull);
+		else if ((s & 63) == 0) atomicAdd(nchecked, 64ull); // (approximate count, kept off the hot address)
+	}
+}
+
 /* ----------------------------------------------------------------------------------------- */
 /* interleave + rebuild                                                                        */
 /* ----------------------------------------------------------------------------------------- */

@@ -143,3 +143,65 @@ def test_walkers_from_sampled_isa_equal_the_sorter_walkers():
     for step in (64, 100, 384):
         _, w = host.build_bwt_walkers(t, step)
         assert np.array_equal(w, host.walkers_from_ckrow(t, step, isa[::step].copy()))
+
+
+@pytest.mark.parametrize("case", ["w32", "w64", "mixed"])
+def test_fmd_writer_wide_block_headers_vs_reference_library(tmp_path, case):
+    """FMD blocks whose predecessor holds >= 2^14 symbols carry 32-bit headers and >= 2^30 symbols 64-bit headers
+    (rld0.c:116-128).  Runs that long are fed to the reference's own encoder (rld_init / rld_enc / rld_enc_finish / rld_dump
+    of oracle/_ref/librb3ref.so -- no text of that size is needed) and to the host writer (rb3h_fmdw_*): the files must be
+    byte-identical.  This is the only place 64-bit headers are exercised."""
+    import ctypes
+    from ropebwt3_amd import host
+    if not util.Reference.available():
+        pytest.skip("no reference library")
+    R = util.Reference().L
+    R.rld_init.restype = ctypes.c_void_p
+    R.rld_init.argtypes = [ctypes.c_int, ctypes.c_int]
+    R.rld_itr_init.restype = None
+    R.rld_itr_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+    R.rld_enc.restype = ctypes.c_int
+    R.rld_enc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint8]
+    R.rld_enc_finish.restype = ctypes.c_uint64
+    R.rld_enc_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    R.rld_dump.restype = ctypes.c_int
+    R.rld_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    R.rld_destroy.restype = None
+    R.rld_destroy.argtypes = [ctypes.c_void_p]
+    rng = np.random.default_rng({"w32": 1, "w64": 2, "mixed": 3}[case])
+    runs = []
+    for i in range(400):
+        if case == "w32":
+            l = int(rng.choice([1, 3, 17, 300, 20000, 70000, 1 << 20, (1 << 29) + 5]))
+        elif case == "w64":
+            l = int(rng.choice([1, 2, (1 << 30) + 3, (1 << 31) + 1, 1 << 33, (1 << 40) + 12345, 9]))
+        else:
+            l = int(rng.choice([1, 1, 2, 5, 40, 1000, 16384, 16383, (1 << 30) - 1, 1 << 30, (1 << 30) + 1, 1 << 36]))
+        c = int(rng.integers(0, 6))
+        if runs and runs[-1][1] == c:
+            c = (c + 1) % 6
+        runs.append((l, c))
+    e = R.rld_init(6, 3)
+    itr = ctypes.create_string_buffer(256)
+    R.rld_itr_init(e, itr, 0)
+    for l, c in runs:
+        R.rld_enc(e, itr, l, c)
+    R.rld_enc_finish(e, itr)
+    fn_ref = str(tmp_path / "ref.fmd")
+    assert R.rld_dump(e, fn_ref.encode()) == 0
+    R.rld_destroy(e)
+    H = host.load_library()
+    H.rb3h_fmdw_dump_file.restype = ctypes.c_int
+    H.rb3h_fmdw_dump_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    w = H.rb3h_fmdw_init()
+    for l, c in runs:
+        assert H.rb3h_fmdw_enc(w, l, c) == 0
+    assert H.rb3h_fmdw_finish(w) == 0
+    fn_own = str(tmp_path / "own.fmd")
+    assert H.rb3h_fmdw_dump_file(w, fn_own.encode()) == 0
+    H.rb3h_fmdw_destroy(w)
+    a, b = open(fn_ref, "rb").read(), open(fn_own, "rb").read()
+    assert len(a) == len(b) and a == b
+    # and the reader gets the runs back
+    out = subprocess.run([os.path.join(os.path.dirname(host.__file__), "ropebwt3-amd"), "recode", "-d", fn_own], stdout=subprocess.PIPE)
+    assert out.returncode == 0 and out.stdout == a

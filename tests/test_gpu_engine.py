@@ -854,3 +854,35 @@ def test_interval_sharded_merge_real_engine(oracle, world, kind):
         t.join(timeout=600)
     assert not errs, errs
     assert all(r == rounds[0] for r in rounds) and rounds[0] >= 40
+
+
+def test_lf_consistency_check_finds_a_wrong_but_monotone_pos(oracle):
+    """the device-side check of pos[] against the index (k_lf_check: ka[LF2(kb)] == C1[c] + rank_B1(c, ka[kb]), SURVEY
+    appendix A) on every row: a correct merge passes with all rows verified; a pos[] that was moved by one position for a
+    range of rows -- still strictly increasing, so the completeness/monotonicity check cannot see it (test hook) -- is
+    caught, nothing is installed from it, and the merge is redone without speculation: same index as the oracle's."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(88)
+    g0 = util.random_genome(rng, 60000)
+    b1 = host.build_bwt(util.make_text([g0, util.mutate(rng, g0, 0.01)]))
+    t2 = util.make_text([util.mutate(rng, g0, 0.002)] + util.reads_from(rng, g0, 100, 80))
+    want = oracle.merge(b1, host.build_bwt(t2.copy()))
+    for corrupt in (0, 1):
+        h = Rb3Gpu(verbose=1, hooks=True)
+        h.tune("lf_check", 1)
+        h.tune("corrupt_pos", corrupt)
+        h.from_plain(b1)
+        d, dtw = h.sort_text(t2)
+        h.merge_text_dev(d, dtw, t2.size, host.walkers_text(t2, 256), commit=True)
+        st = h.stats()
+        assert np.array_equal(h.export_plain(), want)
+        assert st["n_fallbacks"] == corrupt                      # the corrupted attempt was thrown away and redone
+        assert st["n_lf_checked"] >= (0.9 * t2.size if not corrupt else 0)
+        h.close()
+    # the default: every 4096-th row, on every merge
+    h = Rb3Gpu(verbose=1)
+    h.from_plain(b1)
+    d, dtw = h.sort_text(t2)
+    h.merge_text_dev(d, dtw, t2.size, host.walkers_text(t2, 256), commit=True)
+    assert h.stats()["n_lf_checked"] > 0
+    h.close()

@@ -211,7 +211,7 @@ int rb3h_fmdw_finish(rb3h_fmdw_t *w)
 	if (fmdw_next_block(w) < 0) return -1; /* trailing header-only block */
 	w->n_bytes = (uint64_t)w->p * 8;
 	for (w->cnt[0] = 0, i = 1; i <= FMD_ASIZE; ++i) w->cnt[i] += w->cnt[i - 1];
-	if (fmdw_rank_index(w) < 0) { w->z = 0, w->m = 0; return -1; } /* not taken over: on failure `words` stays with the caller */
+	if (fmdw_rank_index(w) < 0) return -1;
 	w->finished = 1;
 	return 0;
 }
@@ -230,7 +230,7 @@ int rb3h_fmdw_adopt(rb3h_fmdw_t *w, uint64_t *words, int64_t n_words, const int6
 	for (i = 1; i <= FMD_ASIZE; ++i) w->mcnt[i] = (uint64_t)(acc[i] - acc[i - 1]);
 	memcpy(w->cnt, w->mcnt, sizeof(w->cnt));
 	for (w->cnt[0] = 0, i = 1; i <= FMD_ASIZE; ++i) w->cnt[i] += w->cnt[i - 1];
-	if (fmdw_rank_index(w) < 0) return -1;
+	if (fmdw_rank_index(w) < 0) { w->z = 0, w->m = 0; return -1; } /* not taken over: on failure `words` stays with the caller */
 	w->finished = 1;
 	return 0;
 }

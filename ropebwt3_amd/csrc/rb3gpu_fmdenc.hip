@@ -20,9 +20,11 @@
  * block is ended on the device, and the walk resumes behind it (the tables do not depend on it).
  * Then one thread per block packs its runs.
  *
- * Only blocks with 16-bit headers (fewer than 0x4000 symbols in the block before, rld0.c:116-128) are
- * produced here -- every block of a low-compressibility index such as short reads, which is where packing
- * is worth moving; anything else returns 1 and the caller packs on the host as before.
+ * Block headers are 16-bit (fewer than 0x4000 symbols in the block before, rld0.c:116-128: 2 header words, 384 payload
+ * bits) or 32-bit (fewer than 2^30: 4 header words, 256 payload bits) -- the second kind is what a compressible index such
+ * as many genomes of one species consists of.  The width of a block's header follows from the symbols of the block before,
+ * so the state of the chain is (first run, header type) and the chunk tables have an entry per (offset, type).  A block
+ * whose predecessor holds 2^30 symbols or more (64-bit header, one payload word) returns 1 and the caller packs on the host.
  */
 #include <cstring>
 #include <cstdlib>
@@ -33,6 +35,9 @@
 #include <stdio.h>
 
 #define FE_C0        384          /* payload bits of a block with a 16-bit header: 6 words */
+#define FE_C1        256          /* ... with a 32-bit header: 4 words */
+#define FE_CBITS(t)  ((t) ? FE_C1 : FE_C0)
+#define FE_WIDE      0x40000000ull /* symbols in a block from which the next header would be 64-bit: not produced here */
 #define FE_SB_BLOCKS (1LL << 20)  /* blocks per superblock (2^23 words) */
 #define FE_CHUNK     4096         /* runs per speculation chunk */
 
@@ -72,63 +77,103 @@ __device__ __forceinline__ int64_t fe_next(const uint64_t *P, int64_t nr, int64_
 
 #define FE_ENTRIES 128            /* possible entry offsets into a chunk (a block spans at most 97 runs) */
 
-/* for chunk k and entry offset d: follow the chain from run k R + d to the first block start at or behind the end of
- * the chunk; E = that start's offset into the next chunk, Cn = blocks passed */
-__global__ void __launch_bounds__(256) k_fe_table(int64_t K, int64_t nr, const uint64_t *P, uint8_t *E, uint16_t *Cn)
+/* start of run i (S[nr] = n_sym) */
+__device__ __forceinline__ uint64_t fe_start(const uint64_t *words, int64_t nr, int64_t n_sym, int64_t i)
+{
+	return i < nr ? words[i] >> 3 : (uint64_t)n_sym;
+}
+
+/* one block of the chain: (i, t) -> (first run of the next block, its header type); flag |= 8 if that header would be 64-bit */
+__device__ __forceinline__ int64_t fe_step(const uint64_t *P, const uint64_t *words, int64_t nr, int64_t n_sym, int64_t i, int *t, int cut, unsigned int *flag)
+{
+	const int64_t nx = fe_next(P, nr, i, FE_CBITS(*t) - cut);
+	const uint64_t tot = fe_start(words, nr, n_sym, nx) - fe_start(words, nr, n_sym, i);
+	if (tot >= FE_WIDE) atomicOr(flag, 8u);
+	*t = tot >= 0x4000 ? 1 : 0;
+	return nx;
+}
+
+/* for chunk k, entry offset d and entry header type t: follow the chain from run k R + d to the first block start at or
+ * behind the end of the chunk; E = that start's offset into the next chunk | its type << 7, Cn = blocks passed */
+__global__ void __launch_bounds__(256) k_fe_table(int64_t K, int64_t nr, int64_t n_sym, const uint64_t *P, const uint64_t *words, uint8_t *E, uint16_t *Cn, unsigned int *flag)
 {
 	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= K * FE_ENTRIES) return;
-	const int64_t k = t / FE_ENTRIES, end = (k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr;
-	int64_t i = k * FE_CHUNK + (t % FE_ENTRIES), c = 0;
-	while (i < end) i = fe_next(P, nr, i, FE_C0), ++c;
-	E[t] = (uint8_t)(i - end), Cn[t] = (uint16_t)c;
+	if (t >= K * FE_ENTRIES * 2) return;
+	const int64_t k = (t >> 1) / FE_ENTRIES, end = (k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr;
+	int64_t i = k * FE_CHUNK + ((t >> 1) % FE_ENTRIES), c = 0;
+	int ty = (int)(t & 1);
+	unsigned int dummy = 0; // a speculative entry that is never taken must not raise the flag: the emit pass raises it for real
+	(void)flag;
+	while (i < end) i = fe_step(P, words, nr, n_sym, i, &ty, 0, &dummy), ++c;
+	E[t] = (uint8_t)((i - end) | ty << 7), Cn[t] = (uint16_t)c;
 }
 
-/* the same from one given run (the first chunk of a superblock is entered anywhere): out = { exit, blocks } */
-__global__ void k_fe_chain1(int64_t i, int64_t end, int64_t nr, const uint64_t *P, int64_t *out)
+/* the same from one given state (the first chunk of a superblock is entered anywhere): out = { exit, blocks, exit type } */
+__global__ void k_fe_chain1(int64_t i, int ty, int64_t end, int64_t nr, int64_t n_sym, const uint64_t *P, const uint64_t *words, int64_t *out)
 {
 	int64_t c = 0;
-	while (i < end) i = fe_next(P, nr, i, FE_C0), ++c;
-	out[0] = i, out[1] = c;
+	unsigned int dummy = 0;
+	while (i < end) i = fe_step(P, words, nr, n_sym, i, &ty, 0, &dummy), ++c;
+	out[0] = i, out[1] = c, out[2] = ty;
 }
 
-/* block starts of the listed chunks: chunk ids[j] is entered at run entry[j], whose block has the global index base[j];
- * only indices up to `last` are written */
-__global__ void __launch_bounds__(256) k_fe_emit(int64_t nlist, const int64_t *ids, const int64_t *entry, const int64_t *base, int64_t nr, const uint64_t *P, int64_t last, int64_t *bs)
+/* block starts of the listed chunks: chunk ids[j] is entered at run entry[j] >> 1 with header type entry[j] & 1, whose block
+ * has the global index base[j]; only indices up to `last` are written */
+__global__ void __launch_bounds__(256) k_fe_emit(int64_t nlist, const int64_t *ids, const int64_t *entry, const int64_t *base, int64_t nr, int64_t n_sym, const uint64_t *P, const uint64_t *words,
+		int64_t last, int64_t *bs, unsigned int *flag)
 {
 	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= nlist) return;
 	const int64_t k = ids[j], end = (k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr;
-	int64_t i = entry[j], b = base[j];
-	while (i < end && b <= last) bs[b] = i, i = fe_next(P, nr, i, FE_C0), ++b;
+	int64_t i = entry[j] >> 1, b = base[j];
+	int ty = (int)(entry[j] & 1);
+	while (i < end && b <= last) {
+		bs[b] = i, ++b;
+		if (b > last) break; // the superblock's last block is ended by k_fe_special (one payload word less)
+		i = fe_step(P, words, nr, n_sym, i, &ty, 0, flag);
+	}
 }
 
-/* the superblock's last block: it starts at bs[gb] and has one payload word less; out[0] = first run behind it */
-__global__ void k_fe_special(const uint64_t *P, int64_t nr, const int64_t *bs, int64_t gb, int64_t *out)
+/* the superblock's last block: it starts at bs[gb] and has one payload word less; out[0] = first run behind it, out[1] =
+ * the header type of the block that starts there */
+__global__ void k_fe_special(const uint64_t *P, const uint64_t *words, int64_t nr, int64_t n_sym, const int64_t *bs, int64_t gb, int64_t *out, unsigned int *flag)
 {
-	out[0] = fe_next(P, nr, bs[gb], FE_C0 - 64);
+	const uint64_t before = fe_start(words, nr, n_sym, bs[gb]) - fe_start(words, nr, n_sym, bs[gb - 1]); // gb >= 1: it is the LAST block of a superblock
+	int ty = before >= 0x4000 ? 1 : 0;
+	out[0] = fe_step(P, words, nr, n_sym, bs[gb], &ty, 64, flag);
+	out[1] = ty;
 }
 
 /* one thread per block (and one more for the trailing header-only block, rld0.c:206-216) */
-__global__ void __launch_bounds__(256) k_fe_pack(const uint64_t *words, int64_t nr, int64_t n_sym, const int64_t *bs, int64_t B, uint64_t *out, unsigned int *flag)
+__global__ void __launch_bounds__(256) k_fe_pack(const uint64_t *words, int64_t nr, int64_t n_sym, const int64_t *bs, int64_t B, uint64_t *out, unsigned int *flag, unsigned int *tail)
 {
 	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b > B) return;
 	uint64_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	if (b > 0) { // header: what the block before contained (rld0.c:116-128), 7 x uint16
-		uint32_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+	int type = 0;
+	if (b > 0) { // header: what the block before contained (rld0.c:116-128), 7 x uint16 or 7 x uint32
+		uint64_t c[7] = {0, 0, 0, 0, 0, 0, 0};
 		for (int64_t i = bs[b - 1]; i < bs[b]; ++i) {
 			const int64_t s = (int64_t)(words[i] >> 3), e = i + 1 < nr ? (int64_t)(words[i + 1] >> 3) : n_sym;
 			const uint64_t l = (uint64_t)(e - s);
-			if (l >= 0x4000) { atomicOr(flag, 2u); break; }
-			c[0] += (uint32_t)l, c[1 + (int)(words[i] & 7)] += (uint32_t)l;
-			if (c[0] >= 0x4000) { atomicOr(flag, 2u); break; } // needs a 32-bit header: not produced here
+			c[0] += l, c[1 + (int)(words[i] & 7)] += l;
 		}
-		z[0] = (uint64_t)c[0] | (uint64_t)c[1] << 16 | (uint64_t)c[2] << 32 | (uint64_t)c[3] << 48;
-		z[1] = (uint64_t)c[4] | (uint64_t)c[5] << 16 | (uint64_t)c[6] << 32;
+		if (c[0] >= FE_WIDE) { atomicOr(flag, 2u); return; } // needs a 64-bit header: not produced here
+		if (c[0] < 0x4000) {
+			z[0] = c[0] | c[1] << 16 | c[2] << 32 | c[3] << 48;
+			z[1] = c[4] | c[5] << 16 | c[6] << 32;
+		} else {
+			type = 1;
+			z[0] = c[0] | c[1] << 32, z[1] = c[2] | c[3] << 32, z[2] = c[4] | c[5] << 32, z[3] = c[6];
+			z[0] |= 1ull << 62;
+		}
 	}
-	if (b == B) { out[8 * b] = z[0], out[8 * b + 1] = z[1]; return; }
-	int p = 2, r = 64;
+	if (b == B) { // the trailing header-only block (rld0.c:206-216): its header words
+		for (int q = 0; q < (type ? 4 : 2); ++q) out[8 * b + q] = z[q];
+		if (type) tail[0] = 4;
+		return;
+	}
+	int p = type ? 4 : 2, r = 64;
 	for (int64_t i = bs[b]; i < bs[b + 1]; ++i) { // rld_enc1, rld0.c:137-151, without the block switch
 		const int64_t s = (int64_t)(words[i] >> 3), e = i + 1 < nr ? (int64_t)(words[i + 1] >> 3) : n_sym;
 		const uint64_t l = (uint64_t)(e - s);
@@ -168,17 +213,18 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	uint16_t *Cn = nullptr, *hCn = nullptr;
 	uint64_t *P = nullptr, *out = nullptr, *host = nullptr;
 	int64_t *lists = nullptr, *hlists = nullptr, *bs = nullptr, *scal = nullptr;
-	unsigned int *flag = nullptr, hflag[2];
+	unsigned int *flag = nullptr, hflag[4];
 	void *tmp = nullptr;
 	size_t tb = 0;
 	const int64_t K = (nr + FE_CHUNK - 1) / FE_CHUNK;
 	int64_t o = 0, gb0 = 0, B = 0;
+	int oty = 0; // header type of the block that starts at run o
 	*z_out = nullptr, *n_words = 0;
 	if (nr <= 0 || n_sym <= 0) return -3;
 	if (hipMalloc(&width, (size_t)nr + 16) != hipSuccess || hipMalloc(&P, (size_t)(nr + 1) * 8) != hipSuccess || hipMalloc(&bs, (size_t)(nr + 2) * 8) != hipSuccess ||
-		hipMalloc(&E, (size_t)K * FE_ENTRIES) != hipSuccess || hipMalloc(&Cn, (size_t)K * FE_ENTRIES * 2) != hipSuccess || hipMalloc(&lists, (size_t)(K + 1) * 24) != hipSuccess ||
+		hipMalloc(&E, (size_t)K * FE_ENTRIES * 2) != hipSuccess || hipMalloc(&Cn, (size_t)K * FE_ENTRIES * 4) != hipSuccess || hipMalloc(&lists, (size_t)(K + 1) * 24) != hipSuccess ||
 		hipMalloc(&scal, 64) != hipSuccess || hipMalloc(&flag, 16) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
-	hE = (uint8_t*)malloc((size_t)K * FE_ENTRIES), hCn = (uint16_t*)malloc((size_t)K * FE_ENTRIES * 2), hlists = (int64_t*)malloc((size_t)(K + 1) * 24);
+	hE = (uint8_t*)malloc((size_t)K * FE_ENTRIES * 2), hCn = (uint16_t*)malloc((size_t)K * FE_ENTRIES * 4), hlists = (int64_t*)malloc((size_t)(K + 1) * 24);
 	if (!hE || !hCn || !hlists) { ret = -1; goto done; }
 	FE_HIP(rocprim::exclusive_scan(nullptr, tb, rocprim::make_transform_iterator(width, fe_widen()), P, (uint64_t)0, (size_t)(nr + 1), rocprim::plus<uint64_t>(), st));
 	tb += 256;
@@ -186,9 +232,9 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	FE_HIP(hipMemsetAsync(flag, 0, 16, st));
 	hipLaunchKernelGGL(k_fe_width, FE_GRID(nr + 1), d_words, nr, n_sym, width, flag);
 	{ size_t b = tb; FE_HIP(rocprim::exclusive_scan(tmp, b, rocprim::make_transform_iterator(width, fe_widen()), P, (uint64_t)0, (size_t)(nr + 1), rocprim::plus<uint64_t>(), st)); }
-	hipLaunchKernelGGL(k_fe_table, FE_GRID(K * FE_ENTRIES), K, nr, (const uint64_t*)P, E, Cn);
-	FE_HIP(hipMemcpyAsync(hE, E, (size_t)K * FE_ENTRIES, hipMemcpyDeviceToHost, st));
-	FE_HIP(hipMemcpyAsync(hCn, Cn, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
+	hipLaunchKernelGGL(k_fe_table, FE_GRID(K * FE_ENTRIES * 2), K, nr, n_sym, (const uint64_t*)P, d_words, E, Cn, flag);
+	FE_HIP(hipMemcpyAsync(hE, E, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
+	FE_HIP(hipMemcpyAsync(hCn, Cn, (size_t)K * FE_ENTRIES * 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
 	if (hflag[0] & 1u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] a code of 64 bits or more\n"); ret = 1; goto done; }
@@ -196,27 +242,34 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	for (;;) {
 		const int64_t s = gb0 | (FE_SB_BLOCKS - 1); // global index of this superblock's last block
 		const int64_t k0 = o / FE_CHUNK;
-		int64_t *ids = hlists, *ent = hlists + (K + 1), *bas = hlists + 2 * (K + 1), nl = 0, c1[2];
-		hipLaunchKernelGGL(k_fe_chain1, dim3(1), dim3(1), 0, st, o, (k0 + 1) * FE_CHUNK < nr ? (k0 + 1) * FE_CHUNK : nr, nr, (const uint64_t*)P, scal);
-		FE_HIP(hipMemcpyAsync(c1, scal, 16, hipMemcpyDeviceToHost, st));
+		int64_t *ids = hlists, *ent = hlists + (K + 1), *bas = hlists + 2 * (K + 1), nl = 0, c1[3];
+		hipLaunchKernelGGL(k_fe_chain1, dim3(1), dim3(1), 0, st, o, oty, (k0 + 1) * FE_CHUNK < nr ? (k0 + 1) * FE_CHUNK : nr, nr, n_sym, (const uint64_t*)P, d_words, scal);
+		FE_HIP(hipMemcpyAsync(c1, scal, 24, hipMemcpyDeviceToHost, st));
 		FE_HIP(hipStreamSynchronize(st));
-		ids[nl] = k0, ent[nl] = o, bas[nl] = gb0, ++nl;
+		ids[nl] = k0, ent[nl] = o << 1 | oty, bas[nl] = gb0, ++nl;
 		int64_t cur = c1[0], gb = gb0 + c1[1]; // the block that starts at run cur has global index gb
+		int cty = (int)c1[2];
 		for (int64_t k = k0 + 1; cur < nr && gb <= s; ++k) {
 			const int64_t d = cur - k * FE_CHUNK;
 			if (d < 0 || d >= FE_ENTRIES) { ret = -3; goto done; }
-			ids[nl] = k, ent[nl] = cur, bas[nl] = gb, ++nl;
-			gb += hCn[k * FE_ENTRIES + d];
-			cur = ((k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr) + hE[k * FE_ENTRIES + d];
+			ids[nl] = k, ent[nl] = cur << 1 | cty, bas[nl] = gb, ++nl;
+			const int64_t te = (k * FE_ENTRIES + d) * 2 + cty;
+			gb += hCn[te];
+			cur = ((k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr) + (hE[te] & 0x7F);
+			cty = hE[te] >> 7;
 		}
 		FE_HIP(hipMemcpyAsync(lists, ids, (size_t)nl * 8, hipMemcpyHostToDevice, st));
 		FE_HIP(hipMemcpyAsync(lists + (K + 1), ent, (size_t)nl * 8, hipMemcpyHostToDevice, st));
 		FE_HIP(hipMemcpyAsync(lists + 2 * (K + 1), bas, (size_t)nl * 8, hipMemcpyHostToDevice, st));
-		hipLaunchKernelGGL(k_fe_emit, FE_GRID(nl), nl, (const int64_t*)lists, (const int64_t*)(lists + (K + 1)), (const int64_t*)(lists + 2 * (K + 1)), nr, (const uint64_t*)P, s, bs);
+		hipLaunchKernelGGL(k_fe_emit, FE_GRID(nl), nl, (const int64_t*)lists, (const int64_t*)(lists + (K + 1)), (const int64_t*)(lists + 2 * (K + 1)), nr, n_sym, (const uint64_t*)P, d_words, s, bs, flag);
 		if (gb <= s) { B = gb; FE_HIP(hipStreamSynchronize(st)); break; } // the data end before this superblock does
-		hipLaunchKernelGGL(k_fe_special, dim3(1), dim3(1), 0, st, (const uint64_t*)P, nr, (const int64_t*)bs, s, scal);
-		FE_HIP(hipMemcpyAsync(&o, scal, 8, hipMemcpyDeviceToHost, st));
-		FE_HIP(hipStreamSynchronize(st));
+		hipLaunchKernelGGL(k_fe_special, dim3(1), dim3(1), 0, st, (const uint64_t*)P, d_words, nr, n_sym, (const int64_t*)bs, s, scal, flag);
+		{
+			int64_t sp[2];
+			FE_HIP(hipMemcpyAsync(sp, scal, 16, hipMemcpyDeviceToHost, st));
+			FE_HIP(hipStreamSynchronize(st));
+			o = sp[0], oty = (int)sp[1];
+		}
 		gb0 = s + 1;
 		if (o >= nr) { B = gb0; break; }
 	}
@@ -226,14 +279,17 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 		FE_HIP(hipStreamSynchronize(st));
 	}
 	if (hipMalloc(&out, (size_t)(8 * B + 8) * 8) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
-	hipLaunchKernelGGL(k_fe_pack, FE_GRID(B + 1), d_words, nr, n_sym, (const int64_t*)bs, B, out, flag);
-	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
+	hipLaunchKernelGGL(k_fe_pack, FE_GRID(B + 1), d_words, nr, n_sym, (const int64_t*)bs, B, out, flag, flag + 1);
+	FE_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
 	if (hflag[0] & 4u) { ret = -3; goto done; }
-	if (hflag[0] & 3u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a wider header\n", hflag[0]); ret = 1; goto done; }
-	if ((host = (uint64_t*)malloc((size_t)(8 * B + 8) * 8)) == nullptr) { ret = -1; goto done; }
-	FE_HIP(hipMemcpy(host, out, (size_t)(8 * B + 2) * 8, hipMemcpyDeviceToHost));
-	*z_out = host, *n_words = 8 * B + 2, host = nullptr;
+	if (hflag[0] & 11u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a 64-bit header\n", hflag[0]); ret = 1; goto done; }
+	{
+		const int64_t tailw = hflag[1] == 4u ? 4 : 2; // header words of the trailing header-only block (rld0.c:211)
+		if ((host = (uint64_t*)malloc((size_t)(8 * B + 8) * 8)) == nullptr) { ret = -1; goto done; }
+		FE_HIP(hipMemcpy(host, out, (size_t)(8 * B + tailw) * 8, hipMemcpyDeviceToHost));
+		*z_out = host, *n_words = 8 * B + tailw, host = nullptr;
+	}
 done:
 	free(host); free(hE); free(hCn); free(hlists);
 	{

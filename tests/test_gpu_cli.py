@@ -163,16 +163,15 @@ def test_differential_fuzz_against_the_reference_binary():
 
 
 def test_fmd_packed_on_gpu_and_on_host_agree(tmp_path):
-    """the .fmd data section is packed on the GPU when every block has a 16-bit header (read-like data) and on the
-    host otherwise (--host-fmd forces the host packer): both paths give the golden bytes, and the GPU packer
-    really ran for the read fixtures"""
+    """the .fmd data section is packed on the GPU (blocks with 16-bit and 32-bit headers, rld0.c:116-128; only a block of
+    2^30 symbols or more falls back to the host) or, with --host-fmd, on the host: both paths give the golden bytes, and
+    the GPU packer really ran -- for the compressible fixtures (32-bit headers: copies3000, longruns) too"""
     for name in ("reads_fq", "reads_fwd", "genomes12", "copies3000", "longruns", "k3_both"):
         ent = MAN[name]
         inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
         out, err = run(["build"] + ent["flags"] + ["-d"] + inputs)
         assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], name
-        if name.startswith("reads"):
-            assert "packed the FMD on the GPU" in err
+        assert "packed the FMD on the GPU" in err, name
         r = subprocess.run([CLI, "build", "--host-fmd"] + ent["flags"] + ["-d"] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], name
         assert b"packed the FMD on the GPU" not in r.stderr

@@ -55,6 +55,7 @@ struct Tune {
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
 	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
+	int b2_split = 4;        // splitter spacing 2^S of the batch's own LF walk (walkers for the BWT-only entry point); 0: SA-regular walkers (staged path)
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
 #ifdef RB3GPU_TEST_HOOKS
 	int force_fallback = 0;  // pretend the tentative pass left unsettled records
@@ -223,6 +224,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "blkmul")) t.blkmul = v < 1 ? 1 : (int)v;
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
+	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? 0 : v > 12 ? 12 : (int)v;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
 	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos")) {
 #ifdef RB3GPU_TEST_HOOKS
@@ -245,7 +247,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "octs", "blkmul", "blkcap", "ssa_split", "lf_check",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "octs", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -863,11 +865,16 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	// no list but a count: one walker per string (n_walkers = number of strings), made on the device
 	const bool per_string = !walkers && n_walkers > 0;
 	if (d_tw && !walkers && !per_string) return RB3GPU_EINVAL;
+	// neither (the reference's signature: BWT only): the list is made on the device from a sparse LF walk of the batch itself
+	const bool auto_list = !walkers && !per_string && !d_tw && h->tn.b2_split > 0 && h->opt.split_log2 == 0 && len >= 4096;
+	const int b2S = h->tn.b2_split;
+	const int64_t b2_nbk = len / RB3_B2_W + 1, b2_m2cap = len / 64 + 1, b2_nspmax = (len >> b2S) + b2_m2cap + 2;
+	if (auto_list) n_walkers = b2_nbk + b2_m2cap; // capacity of the list; how many are in use stays on the device
 	const int tent_auto = tent;
 	if (per_string) tent = 0; // every walker is exact
 	for (int64_t i = 0; walkers && i < n_walkers; ++i)
 		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) return RB3GPU_EINVAL;
-	if ((!walkers && !per_string) || n_walkers > (1 << 24) || n_walkers > len || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || h->tn.staged) {
+	if ((!walkers && !per_string && !auto_list) || n_walkers > (1 << 24) || n_walkers > len || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || h->tn.staged) {
 		if (per_string) return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, tent_auto);
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, tent);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
@@ -878,6 +885,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = buf_ensure(h, h->pos, (size_t)len * 8)) < 0) return r;
 	if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	if (auto_list && (r = buf_ensure(h, h->xbuf, ((size_t)b2_nspmax * 4 + (size_t)b2_m2cap + 2 + (size_t)b2_nbk) * 8)) < 0) return r;
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
 #ifdef RB3GPU_TEST_HOOKS
@@ -898,7 +906,28 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
 	if (rows_fused) HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
-	if (per_string && d_tw) {
+	unsigned long long *b2_nwalk = nullptr; // device-side length of a device-made list
+	if (auto_list) {
+		// scratch: two link tables (2 words per splitter), string lengths / offsets, one word per window
+		uint64_t *lnk[2] = { (uint64_t*)h->xbuf.p, (uint64_t*)h->xbuf.p + 2 * b2_nspmax };
+		uint64_t *slen = lnk[1] + 2 * b2_nspmax;
+		unsigned long long *bucket = (unsigned long long*)(slen + b2_m2cap + 2);
+		const uint64_t *tot2 = (const uint64_t*)(misc + MISC_LF_TOT);
+		unsigned long long *mode = misc + 7;
+		b2_nwalk = misc + 13;
+		HIPCHK(hipMemsetAsync(bucket, 0xff, (size_t)b2_nbk * 8, h->st));
+		HIPCHK(hipMemsetAsync(slen, 0, (size_t)(b2_m2cap + 2) * 8, h->st));
+		hipLaunchKernelGGL(k_b2_mode, dim3(1), dim3(64), 0, h->st, tot2, len, b2_m2cap, mode);
+		hipLaunchKernelGGL(k_b2_walk, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)h->pos.p, len, tot2, b2S, (const unsigned long long*)mode, lnk[0]);
+		int cur = 0;
+		for (int64_t reach = 1; reach < b2_nspmax; reach <<= 2, cur ^= 1) // (on the upper bound of the splitter count; entries behind the real count are never read)
+			hipLaunchKernelGGL(k_b2_jump4, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, b2_nspmax, (const uint64_t*)lnk[cur], lnk[cur ^ 1]);
+		hipLaunchKernelGGL(k_b2_strings, dim3(64), dim3(256), 0, h->st, tot2, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], slen);
+		hipLaunchKernelGGL(k_b2_scan, dim3(1), dim3(1024), 0, h->st, tot2, (const unsigned long long*)mode, slen);
+		hipLaunchKernelGGL(k_b2_pick, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], (const uint64_t*)slen, bucket);
+		hipLaunchKernelGGL(k_b2_list, dim3((unsigned)((n_walkers + 255) / 256 < 2048 ? (n_walkers + 255) / 256 : 2048)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode,
+				(const uint64_t*)lnk[cur], (const uint64_t*)slen, (const unsigned long long*)bucket, b2_nbk, (Walker*)h->wl.p, b2_nwalk);
+	} else if (per_string && d_tw) {
 		HIPCHK(hipMemsetAsync(h->wl.p, 0xff, (size_t)n_walkers * 32, h->st)); // a walker that nobody fills in starts at row -1: caught below
 		hipLaunchKernelGGL(k_walkers_per_string, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw, len);
 	} else if (per_string) { // row words: the sentinels are rows 0 .. n_walkers-1 (the count is checked against the batch below)
@@ -917,7 +946,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	{
 		const IdxView iv = view_of(h);
 		const int octs = h->tn.octs;
-		int64_t nblk = (n_walkers + 4 * octs - 1) / (4 * octs) * h->tn.blkmul;
+		const int64_t n_expect = auto_list ? b2_nbk + 64 : n_walkers; // (a device-made list: capacity >> walkers; size the launch for the walkers)
+		int64_t nblk = (n_expect + 4 * octs - 1) / (4 * octs) * h->tn.blkmul;
 		// persistent waves: 2048 blocks x 4 waves fill the chip once (256 CUs x 32); more blocks only queue behind them (measured: 10 % slower at 4096)
 		{ const int64_t cap = h->tn.blkcap; nblk = nblk > cap ? cap : nblk < 1 ? 1 : nblk; }
 #ifdef RB3_PROF
@@ -926,7 +956,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		const dim3 grid((unsigned)nblk), blk(256);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST(D, T, X) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk)
 		// text-order words: per-lane loads while the L1 can hold a line per walker (256 CUs x 32 waves x 8 octets), else 64-byte fetches
 		int text_mode = !d_tw ? 0 : n_walkers <= 65536 ? 1 : 2;
 #ifdef RB3GPU_TEST_HOOKS
@@ -990,6 +1020,25 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)hm[MISC_LF_TOT + a];
 	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
 	if (per_string && acc2[1] != n_walkers) return RB3GPU_EINVAL; // not the number of strings of this batch (nothing was installed)
+#ifdef RB3_DEBUG_B2
+	if (auto_list) { // kernel experiment: what the device-made list looks like
+		const int64_t nw = (int64_t)hm[13];
+		rb3gpu_walker_t *w = (rb3gpu_walker_t*)malloc((size_t)nw * 32);
+		(void)hipMemcpy(w, h->wl.p, (size_t)nw * 32, hipMemcpyDeviceToHost);
+		int64_t nv = 0, ninf = 0, mx = 0, mn = INT64_MAX, sum = 0, nbig = 0;
+		for (int64_t i = 0; i < nw; ++i) {
+			if (w[i].row < 0) continue;
+			++nv;
+			if (w[i].nsteps > (1LL << 60)) { ++ninf; continue; }
+			sum += w[i].nsteps, mx = w[i].nsteps > mx ? w[i].nsteps : mx, mn = w[i].nsteps < mn ? w[i].nsteps : mn, nbig += w[i].nsteps > 600;
+		}
+		fprintf(stderr, "[debug] device-made list: %lld slots, %lld walkers, %lld with nsteps = inf, gaps min %lld mean %.1f max %lld, %lld above 600; mode %llu\n", (long long)nw, (long long)nv, (long long)ninf,
+				(long long)mn, (double)sum / (double)(nv - ninf > 0 ? nv - ninf : 1), (long long)mx, (long long)nbig, hm[7]);
+		free(w);
+	}
+#endif
+	if (auto_list && hm[7] == 2) // more strings than the device-made list takes (strings shorter than 64 symbols on average): nothing was walked
+		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, tent);
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
 	if (tent) {
 		tent_used(h, hm[5]);

@@ -748,9 +748,10 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
  * string: the L1 cannot hold a line per walker). */
 template<bool LIST, bool DENSE, bool TENT, int TEXT>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
-		int logM, const Walker *wl, int64_t nwalk, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw)
+		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
+		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr)
 {
+	const int64_t nwalk = nwalk_dev ? (int64_t)*nwalk_dev : nwalk_arg; // (a list made on the device: its length never went to the host)
 	static_assert(LIST || !TEXT, "text-order words need a walker list");
 	// ids a walker may take from each half of the stretch table (the whole half unless a test narrows it)
 	const uint32_t lim_blocks = sid_limit < (uint32_t)RB3_TENT_HALF ? sid_limit : (uint32_t)RB3_TENT_HALF;
@@ -799,6 +800,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			if (LIST) {
 				const Walker w = wl[wid];
 				kb = w.row, remaining = w.nsteps;
+				if (!TEXT && kb < 0) continue; // an empty slot of a device-made list
 				if (TEXT) {
 					tp = w.row;
 					if (tp < 0 || tp >= n2) continue; // (a per-string list whose string count was wrong: the rows stay unset)
@@ -2387,6 +2389,161 @@ __global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint3
 }
 
 /* ----------------------------------------------------------------------------------------- */
+/* text-regular walkers from the BWT alone (the reference's signature: no suffix array)         */
+/* ----------------------------------------------------------------------------------------- */
+
+/* rb3_fmi_merge_plain(r, len, seq) gets the partial BWT and nothing else, and a batch of two long strings is two chains.
+ * Walkers in the middle of the strings need rows at (roughly) regular TEXT distances, i.e. samples of the inverse suffix
+ * array, which the BWT only yields through its own LF walk.  That walk is done once, sparsely (sampled list ranking,
+ * Helman-JaJa): SPLITTERS -- the sentinel rows and every 2^S-th row, random text positions at mean distance 2^S -- walk
+ * the batch's LF words to the next splitter (k_b2_walk; ~2^S ln(#splitters) dependent 8-byte loads on the critical path,
+ * no rank on B1), pointer jumping gives every splitter its distance D from the start of its string (k_ssa_jump), and
+ * from each window of RB3_B2_W text positions the splitter closest to the window's start becomes a walker if it lies in
+ * the first two thirds (k_b2_pick / k_b2_list): gaps between walkers are then RB3_B2_W +- a few 2^S and never below 128, which is
+ * what k_chain's plain-store records need (see "Concurrency").  Everything stays on the device; the list is read by
+ * k_chain through its device-side length. */
+#define RB3_SSA_END  (1ull << 63)  /* link word: the sublist ends at the start of its string (shared with the sampled suffix array) */
+#define RB3_B2_W     384           /* text distance between walkers */
+#define RB3_B2_FIRST 256           /* a splitter qualifies if it lies this close behind the start of its window (gaps stay >= W - FIRST = 128) */
+#define RB3_B2_MINSEG 128          /* shortest segment of any walker (what plain-store records need, see k_chain) */
+#define RB3_B2_EMPTY (~0ull)
+
+__global__ void k_ssa_jump(int64_t nsp, const uint64_t *in, uint64_t *out); // (pointer jumping over splitters: defined with the sampled suffix array)
+
+/* pointer jumping, three hops per round (links of the OLD table only, so one round multiplies the reach of every link by
+ * four): half the launches of the doubling form, and a launch costs more here than two more dependent gathers */
+__global__ void __launch_bounds__(256) k_b2_jump4(int64_t nsp, const uint64_t *in, uint64_t *out)
+{
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= nsp) return;
+	ulonglong2 r = ((const ulonglong2*)in)[p];
+#pragma unroll
+	for (int hop = 0; hop < 3; ++hop) {
+		if ((r.x & RB3_SSA_END) || r.x >= (uint64_t)nsp) break;
+		const ulonglong2 q = ((const ulonglong2*)in)[r.x];
+		r.x = q.x, r.y += q.y;
+	}
+	((ulonglong2*)out)[p] = r;
+}
+
+/* mode[0]: 0 = splitters, 1 = strings are short (one walker per string), 2 = more strings than the list can take */
+__global__ void __launch_bounds__(256) k_b2_mode(const uint64_t *tot2, int64_t n2, int64_t m2cap, unsigned long long *mode)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	const int64_t m2 = (int64_t)tot2[0];
+	mode[0] = m2 <= 0 || m2 > m2cap ? 2ull : (n2 / m2 <= 4 * RB3_B2_W ? 1ull : 0ull);
+}
+
+__global__ void __launch_bounds__(256) k_b2_walk(const int64_t *roww, int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, uint64_t *lnk)
+{
+	if (mode[0] != 0) return;
+	const int64_t m2 = (int64_t)tot2[0], msk = (1LL << S) - 1;
+	const int64_t nsp = m2 + ((n2 - m2 + msk) >> S);
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= nsp) return;
+	int64_t r = p < m2 ? p : m2 + ((p - m2) << S);
+	uint64_t steps = 0, nxt;
+	for (;;) {
+		const uint64_t w = (uint64_t)roww[r];
+		if ((w & 7u) == 0u) { nxt = RB3_SSA_END | (uint64_t)RB3_ROW_NEXT(w); break; } // the first suffix of a string: its $ has a dense number
+		r = RB3_ROW_NEXT(w), ++steps;
+		if (r >= m2 && ((r - m2) & msk) == 0) { nxt = (uint64_t)(m2 + ((r - m2) >> S)); break; }
+	}
+	lnk[2 * p] = nxt, lnk[2 * p + 1] = steps;
+}
+
+/* slen[s] = rows of string s (the LF steps of its sentinel row's splitter to the start of the string, + 1) */
+__global__ void __launch_bounds__(256) k_b2_strings(const uint64_t *tot2, const unsigned long long *mode, const uint64_t *lnk, uint64_t *slen)
+{
+	if (mode[0] != 0) return;
+	const int64_t m2 = (int64_t)tot2[0];
+	for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m2; j += (int64_t)gridDim.x * blockDim.x) {
+		const uint64_t e = lnk[2 * j];
+		if (e & RB3_SSA_END) slen[e & ~RB3_SSA_END] = lnk[2 * j + 1] + 1;
+	}
+}
+
+/* slen[] -> its exclusive prefix in place, total behind the last entry (one workgroup; the strings are long, so there are few) */
+__global__ void __launch_bounds__(1024) k_b2_scan(const uint64_t *tot2, const unsigned long long *mode, uint64_t *slen)
+{
+	__shared__ uint64_t part[1024];
+	if (mode[0] != 0) return;
+	const int64_t m2 = (int64_t)tot2[0];
+	const int t = threadIdx.x;
+	const int64_t per = (m2 + 1023) / 1024, a = t * per, b = a + per < m2 ? a + per : m2;
+	uint64_t sum = 0;
+	for (int64_t i = a; i < b; ++i) sum += slen[i];
+	part[t] = sum;
+	__syncthreads();
+	if (t == 0) { uint64_t run = 0; for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; } slen[m2] = run; }
+	__syncthreads();
+	uint64_t run = part[t];
+	for (int64_t i = a; i < b; ++i) { const uint64_t v = slen[i]; slen[i] = run; run += v; }
+}
+
+/* per window of RB3_B2_W text positions (concatenated strings): the qualifying splitter closest to the window's start */
+__global__ void __launch_bounds__(256) k_b2_pick(int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, const uint64_t *lnk, const uint64_t *gbase, unsigned long long *bucket)
+{
+	if (mode[0] != 0) return;
+	const int64_t m2 = (int64_t)tot2[0], msk = (1LL << S) - 1;
+	const int64_t nsp = m2 + ((n2 - m2 + msk) >> S);
+	const int64_t p = m2 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= nsp) return;
+	const uint64_t e = lnk[2 * p], D = lnk[2 * p + 1];
+	if (!(e & RB3_SSA_END)) return; // (cannot be after the jumping rounds)
+	const uint64_t sid = e & ~RB3_SSA_END;
+	if (sid >= (uint64_t)m2) return;
+	const uint64_t g0 = gbase[sid], len = gbase[sid + 1] - g0, G = g0 + D;
+	if (D == 0 || D + 1 + RB3_B2_MINSEG > len) return; // the sentinel walker's own segment stays >= RB3_B2_MINSEG steps
+	const uint64_t off = G % RB3_B2_W;
+	if (off < RB3_B2_FIRST) atomicMin(&bucket[G / RB3_B2_W], (unsigned long long)(off << 48 | (uint64_t)p));
+}
+
+/* the walker list: slot b < nbk = the pick of window b (row -1: none), slot nbk + j = the sentinel row j; nsteps = text distance
+ * to the next walker on the left in the same string.  nwalk[0] = slots in use. */
+__global__ void __launch_bounds__(256) k_b2_list(int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, const uint64_t *lnk, const uint64_t *gbase,
+		const unsigned long long *bucket, int64_t nbk, Walker *wl, unsigned long long *nwalk)
+{
+	const int64_t m2 = (int64_t)tot2[0];
+	const unsigned long long md = mode[0];
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+	if (md == 2) { if (t == 0) nwalk[0] = 0; return; }
+	if (md == 1) { // short strings: one walker per string
+		if (t == 0) nwalk[0] = (unsigned long long)m2;
+		for (int64_t j = t; j < m2; j += nt) { Walker w; w.row = j, w.ka0 = -2, w.nsteps = INT64_MAX / 2, w.flags = 0; wl[j] = w; }
+		return;
+	}
+	if (t == 0) nwalk[0] = (unsigned long long)(nbk + m2);
+	for (int64_t u = t; u < nbk + m2; u += nt) {
+		Walker w;
+		w.row = -1, w.ka0 = -1, w.nsteps = INT64_MAX / 2, w.flags = 0;
+		uint64_t sid, D, G;
+		int64_t b;
+		if (u < nbk) {
+			const unsigned long long v = bucket[u];
+			if (v == RB3_B2_EMPTY) { wl[u] = w; continue; }
+			const int64_t p = (int64_t)(v & 0xFFFFFFFFFFFFull);
+			w.row = m2 + ((p - m2) << S);
+			sid = lnk[2 * p] & ~RB3_SSA_END, D = lnk[2 * p + 1], G = gbase[sid] + D, b = u - 1;
+		} else {
+			const int64_t j = u - nbk;
+			w.row = j, w.ka0 = -2;
+			sid = lnk[2 * j] & ~RB3_SSA_END, D = lnk[2 * j + 1], G = gbase[sid] + D, b = (int64_t)(G / RB3_B2_W);
+		}
+		// the next walker on the left: the pick of the nearest window below that lies in the same string
+		for (; b >= 0 && (uint64_t)(b + 1) * RB3_B2_W > gbase[sid]; --b) {
+			const unsigned long long v = bucket[b];
+			if (v == RB3_B2_EMPTY) continue;
+			const int64_t q = (int64_t)(v & 0xFFFFFFFFFFFFull);
+			if ((lnk[2 * q] & ~RB3_SSA_END) != sid) continue; // a window shared with the neighbouring string
+			const uint64_t Dq = lnk[2 * q + 1];
+			if (Dq < D) { w.nsteps = (int64_t)(D - Dq); break; }
+		}
+		wl[u] = w;
+	}
+}
+
+/* ----------------------------------------------------------------------------------------- */
 /* interval-sharded index: one LF step of many chains per launch (north_star)  */
 /* ----------------------------------------------------------------------------------------- */
 
@@ -2543,7 +2700,9 @@ __global__ void __launch_bounds__(256) k_export_runs(IdxView ix, int64_t w0, int
  * sublist lengths are geometric with mean 2^S whatever the text looks like. */
 
 #define RB3_SSA_LBITS 24              /* bits for the steps inside one sublist */
+#ifndef RB3_SSA_END
 #define RB3_SSA_END   (1ull << 63)    /* nxt word: the sublist ends at the start of its string */
+#endif
 
 /* symbol at offset `off` of the slot, this lane's share: 8 | symbol in the lane that holds it, else 0 */
 __device__ __forceinline__ uint32_t slice_sym(const uint4 &sl, uint32_t hdr0, uint32_t off, int j)

@@ -308,6 +308,7 @@ def main():
     ap.add_argument("--no-target", action="store_true", help="skip the mtb152 end-to-end leg")
     ap.add_argument("--aux-reads", type=int, default=100000)
     ap.add_argument("--large-index", type=int, default=1 << 30, help="symbols of the index of the large-index leg (0: skip)")
+    ap.add_argument("--only", choices=["large", "reads", "target"], default=None, help="run one auxiliary leg alone and print its JSON (profiling)")
     ap.add_argument("--mtb", type=int, default=152, help="genomes of the target-workload leg")
     ap.add_argument("--mtb-ref-prefix", type=int, default=6, help="files the reference binary is timed on (cpu_baseline of the target workload)")
     args = ap.parse_args()
@@ -335,6 +336,11 @@ def main():
         args.mode = args.mode or "interval"
         return multi.bench_main(args, rank, local_rank, world)
     torch.cuda.set_device(local_rank)
+    if args.only:
+        mk = lambda: Rb3Gpu(device=local_rank, verbose=1)
+        print(json.dumps(large_index_regime(mk, args.large_index, 1000000) if args.only == "large" else reads_regime(mk, args.aux_reads) if args.only == "reads" else
+                         target_workload(args.mtb, 4400000, 0 if args.no_cpu_baseline else args.mtb_ref_prefix)), flush=True)
+        return
 
     t0 = time.time()
     g0, gs = gen_genomes(args.genome_len, args.div, 1, [2])

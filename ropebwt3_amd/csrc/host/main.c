@@ -45,7 +45,7 @@ static void bopt_init(bopt_t *o) /* build.c:31-41 */
 	o->n_threads = 4, o->sais_threads = -1, o->fmt = FMT_PLAIN;
 	o->block_len = 512, o->max_nodes = 64, o->batch_size = 7000000000LL;
 	o->device = 0, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 1, o->host_fmd = 0;
-	o->gpu_batch = 1LL << 30, o->gpu_sort_limit = (int64_t)INT32_MAX - 16;
+	o->gpu_batch = 1LL << 29, o->gpu_sort_limit = (int64_t)INT32_MAX - 16;
 }
 
 /* the size at which the reader cuts batches: -m, or the GPU sub-batch size if that is smaller */
@@ -72,7 +72,7 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	fprintf(fp, "    --host-sort suffix-sort the batches on the host (default: on the GPU; same output; -p then sets the number\n");
 	fprintf(fp, "                of host sorter threads)\n");
 	fprintf(fp, "    --gpu-batch NUM  with GPU sorting, cut the batches of -m into sub-batches of at most NUM symbols at record\n");
-	fprintf(fp, "                boundaries (the output does not depend on the batching; the GPU sorter takes < 2^31) [1G]\n");
+	fprintf(fp, "                boundaries (the output does not depend on the batching; the GPU sorter takes < 2^31) [512M]\n");
 	fprintf(fp, "    --host-fmd  pack/unpack FMD files on the host even where the GPU could\n");
 	fprintf(fp, "  Input:\n");
 	fprintf(fp, "    -i FILE     read existing index from FILE []\n");

@@ -208,3 +208,23 @@ def test_config3_mtb_star_full_length(tmp_path, K):
         assert hashlib.md5(out2).hexdigest() == ent["fmd_md5"]
         out3, _ = run(["build", "-d", "--host-fmd"] + files)
         assert hashlib.md5(out3).hexdigest() == ent["fmd_md5"]
+
+
+@pytest.mark.parametrize("name", ["k2_fwd", "k3_both", "genomes12", "reads_fq", "copies3000", "edge_dups"])
+def test_reference_cli_bound_to_the_engine(name):
+    """INTEGRATION.md, compiled: the UNMODIFIED reference CLI (its own main.c, build.c, io.c, libsais, rld0.c ... objects)
+    with the mrope calls of build.c for the merge path redirected to librb3gpu.so at link time (oracle/bind/rb3_bind.c,
+    GNU ld --wrap: rb3_enc_plain2fmr, rb3_fmi_merge_plain, rb3_enc_fmr2fmd, mr_print_bwt, mr_destroy).  Its `build` must
+    write the golden bytes: the engine is a drop-in for exactly that seam."""
+    bound = os.path.join(os.path.dirname(util.REF_SO), "ropebwt3-bound")
+    if not os.path.exists(bound):
+        pytest.skip("oracle/_ref/ropebwt3-bound was not built")
+    ent = MAN[name]
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    for m in ent["m_variants"]:
+        r = subprocess.run([bound, "build"] + ent["flags"] + ["-m" + m, "-d", "-t4"] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-500:]
+        assert hashlib.md5(r.stdout).hexdigest() == ent["fmd_md5"], (name, m)
+    if "plain_text" in ent:
+        r = subprocess.run([bound, "build"] + ent["flags"] + ["-m" + ent["m_variants"][-1]] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout.decode().strip() == ent["plain_text"]

@@ -22,7 +22,7 @@ def run(args, inp=None):
     return r.stdout, r.stderr.decode()
 
 
-CASES = [k for k in MAN if k not in ("resume", "mtb_star")]
+CASES = [k for k in MAN if k not in ("resume", "mtb_star", "reads_m7g")]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -228,3 +228,29 @@ def test_reference_cli_bound_to_the_engine(name):
     if "plain_text" in ent:
         r = subprocess.run([bound, "build"] + ent["flags"] + ["-m" + ent["m_variants"][-1]] + inputs, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 0 and r.stdout.decode().strip() == ent["plain_text"]
+
+
+def test_config4_reads_m7g_stays_on_the_gpu(tmp_path):
+    """BASELINE configs[3] at 1/60 scale with the reference's default batch size: 10 M reads of 150 bp = 3.02 G symbols, more
+    than 2^31, so `-m7g` is ONE batch, which the GPU suffix sorter cannot take whole.  The CLI cuts it into sub-batches at
+    record boundaries (--gpu-batch; the .fmd does not depend on the batching): no batch goes to the host sorter,
+    and the .fmd is the reference's (md5 from oracle/_ref/ropebwt3 build -L -d -m7g, tests/golden/MANIFEST.json "reads_m7g";
+    the reference needs 512 s and 25 GB for it)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(util.GOLDEN)))
+    from tools import gen_reads
+    ent = MAN["reads_m7g"]
+    fn = gen_reads.generate(ent["n_reads"], str(tmp_path / "reads.txt"))
+    out = str(tmp_path / "out.fmd")
+    r = subprocess.run([CLI, "build", "-L", "-d", "-m7g", "-o", out, fn], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-500:]
+    assert "0 (0 symbols) on the host" in err and "cut into GPU sub-batches" in err
+    import re
+    m = re.search(r"batches: (\d+) \((\d+) symbols\) suffix-sorted on the GPU", err)
+    assert m and int(m.group(1)) >= 2 and int(m.group(2)) == ent["n_symbols"]
+    h = hashlib.md5()
+    with open(out, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    assert os.path.getsize(out) == ent["fmd_bytes"] and h.hexdigest() == ent["fmd_md5"]

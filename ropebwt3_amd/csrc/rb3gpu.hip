@@ -50,6 +50,7 @@ struct Tune {
 	int staged = 0;          // the three-stage merge (several host syncs) instead of the single-sync one
 	int group_rebuild = 0;   // group-sequential rebuild kernels instead of the window-parallel ones
 	int window_rebuild = 0;  // the per-window rebuild (k_pass1w) instead of the run-space rebuild per group
+	int resolve_v1 = 0;      // settle the tentative stretches with k_resolve (one hop per stretch) instead of k_cum / k_resolve_w / k_sfin
 	int reb_force = 0;       // the run-space rebuild whatever the row density and the old index look like (tests: the hand-over paths)
 	int octs = 8;            // octets per wave of k_chain
 	int blkmul = 1;          // launch width multiplier of k_chain
@@ -220,6 +221,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "group_rebuild")) t.group_rebuild = v != 0;
 	else if (!strcmp(key, "window_rebuild")) t.window_rebuild = v != 0;
 	else if (!strcmp(key, "reb_force")) t.reb_force = v != 0;
+	else if (!strcmp(key, "resolve_v1")) t.resolve_v1 = v != 0;
 	else if (!strcmp(key, "octs")) t.octs = v < 1 ? 1 : v > 8 ? 8 : (int)v;
 	else if (!strcmp(key, "blkmul")) t.blkmul = v < 1 ? 1 : (int)v;
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
@@ -247,7 +249,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "octs", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -698,7 +700,12 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
 			hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, (const uint32_t*)sidctr);
-			hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+			if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+			else {
+				hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr);
+				hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+				hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin);
+			}
 			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, h->mg_pos, len, (const int32_t*)sfin, qhead + 2);
 		}
 	}
@@ -980,7 +987,12 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
 			hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, (const uint32_t*)sidctr);
-			hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+			if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+			else {
+				hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr);
+				hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+				hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin);
+			}
 		}
 		if (rows_fused) { // validation and the rows-per-window table of the rebuild in one pass over pos[]
 			const dim3 g1((unsigned)((len + 1 + 255) / 256));

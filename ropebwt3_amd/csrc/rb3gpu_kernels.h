@@ -107,6 +107,16 @@ __device__ __forceinline__ uint32_t wave_up1(uint32_t v)
 	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+/* waves that work independently inside a block (rebuild, settle): LDS traffic between its lanes only needs program order
+ * (the LDS executes a wave's instructions in order), not a workgroup barrier -- and no wait for global
+ * loads in flight, which is what makes the loads of the next stage overlap */
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 /* ----------------------------------------------------------------------------------------- */
 /* rank: #{i < k : B[i] = c} + C[c], eight lanes per query                                     */
 /* ----------------------------------------------------------------------------------------- */
@@ -767,6 +777,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	bool active = false;
 	int gap = 0;            // 0: exact (lo == hi), 1: hi == lo + 1, 2: wider
 	int sid = -1;           // stretch id of the tentative records being written, -1: none yet, -2: none to be had
+	int sid0 = -1;          // the first stretch this walker opened (the unknown all its later stretches follow from)
 	int64_t kb = 0, lo = 0, hi = 0, remaining = 0;
 	uint64_t x = 0;         // row word of the current row (requested one step ahead)
 	int64_t tp = 0;         // TEXT: text position of the current row
@@ -872,6 +883,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				s0 = oct_bcast0(s0, j);
 				if (gap == 1) sid = s0 < lim_singles ? (int)(RB3_TENT_HALF + s0) : -2; // table full: this walker stays a plain inexact one
 				else sid = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : -2;
+				sid0 = sid;
 			}
 			if (TENT && met) { // settle an unknown (rare)
 				const int64_t seen = TEXT ? (int64_t)rc : (int64_t)x;
@@ -922,6 +934,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				}
 				if (j == 0 && ns != RB3_TENT_POISON) {
 					tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = (uint64_t)(hi - lo) | (uint64_t)c << 8;
+					tab[ns].pad[0] = (uint32_t)sid0 + 1u; // (same 64-byte record: the store rides along)
 					tab[sid].child = ns + 1;
 				}
 				sid = ns;
@@ -993,6 +1006,169 @@ __global__ void __launch_bounds__(256) k_resolve(rb3_stretch_t *tab, const uint3
 				if (ch != cur + 1 || ++o == RB3_TENT_BLOCK) break; // the path leaves this block
 			}
 		}
+	}
+}
+
+/* ---- settle, second form (round 2): one hop per WALKER instead of one per stretch -------------------------------------
+ * The stretches of one walker differ by the rows that dropped out of its interval since its first stretch.  k_events gives
+ * every event stretch the mask of the rows that dropped AT that event, in the coordinates of the interval as it was then
+ * (index among the survivors).  k_cum turns that, walker by walker, into the CUMULATIVE mask in the coordinates of the
+ * walker's first interval: the i-th survivor is the i-th zero of the cumulative mask so far.  With it every stretch follows
+ * from the walker's first unknown alone, d_t = d_0 - #{dropped rows with original index < d_0}, the dependency paths run over
+ * first stretches only (d_0 of the next walker = d_last of this one + the link's offset) -- 3 to 24 hops where k_resolve
+ * followed up to 1400 stretches one after the other --, and all other stretches are filled in parallel (k_sfin).
+ * Record fields used: pad[0] of an event stretch = 1 + the walker's first stretch (written by the walker); of a first stretch,
+ * after k_cum: RB3_FIRSTFLAG | 1 + the first stretch of the walker it links into; pad[1] = 1 + the walker's last stretch; mask[] of
+ * a first stretch = the cumulative mask of the last one. */
+#define RB3_FIRSTFLAG 0x80000000u
+
+/* position of the n-th (0-based) set bit of z */
+__device__ __forceinline__ int select32(uint32_t z, int n)
+{
+	int pos = 0;
+	uint32_t t;
+	t = __popc(z & 0xFFFFu); if (n >= (int)t) n -= (int)t, pos += 16, z >>= 16;
+	t = __popc(z & 0xFFu);   if (n >= (int)t) n -= (int)t, pos += 8, z >>= 8;
+	t = __popc(z & 0xFu);    if (n >= (int)t) n -= (int)t, pos += 4, z >>= 4;
+	t = __popc(z & 0x3u);    if (n >= (int)t) n -= (int)t, pos += 2, z >>= 2;
+	t = z & 1u;              if (n >= (int)t) pos += 1;
+	return pos;
+}
+
+__device__ __forceinline__ uint32_t oct_max(uint32_t v)
+{
+	uint32_t t;
+	t = dpp_mov<0x141>(v); v = v > t ? v : t;
+	t = dpp_mov<0xB1>(v);  v = v > t ? v : t;
+	t = dpp_mov<0x4E>(v);  v = v > t ? v : t;
+	return v;
+}
+
+/* one octet per first stretch of a walker that has stretch-id blocks (ids 0 .. na-1, multiples of 8 with pad[0] == 0) */
+__global__ void __launch_bounds__(256) k_cum(rb3_stretch_t *tab, const uint32_t *sidctr)
+{
+	__shared__ uint32_t cumL_[32][8];        // the cumulative mask of the octet's walker
+	__shared__ uint32_t blk_[32][8][8];      // the masks of the 8 records of the block being stepped through
+	const int j = threadIdx.x & 7, oi = threadIdx.x >> 3;
+	uint32_t *cumL = cumL_[oi];
+	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF;
+	for (int64_t F = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3) * RB3_TENT_BLOCK; F < na; F += (((int64_t)gridDim.x * blockDim.x) >> 3) * RB3_TENT_BLOCK) {
+		if (tab[F].pad[0] != 0u) continue;   // the block continues another walker's stretches
+		int next = tab[F].child - 1;
+		if (next < 0) continue;              // a walker without events that nobody links out of
+		cumL[j] = 0u;
+		int cur = (int)F;
+		bool go = true;
+		int hops = 0;
+		while (go && next >= 0 && next < RB3_TENT_HALF && ++hops <= RB3_TENT_IDS) {
+			const int base = next & ~(RB3_TENT_BLOCK - 1);
+			const uint4 *rp = (const uint4*)&tab[base + j]; // lane j: record base + j
+			const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+			{
+				uint32_t *bw = blk_[oi][j];
+				bw[0] = q1.z, bw[1] = q1.w, bw[2] = q2.x, bw[3] = q2.y, bw[4] = q2.z, bw[5] = q2.w, bw[6] = q3.x, bw[7] = q3.y;
+			}
+			wave_sync();
+			for (int o = next & (RB3_TENT_BLOCK - 1); ; ) {
+				const uint32_t w0hi = __shfl(q0.y, o, RB3_TENT_BLOCK);
+				const int nxt = (int)__shfl(q1.y, o, RB3_TENT_BLOCK) - 1;
+				if (w0hi >> 30 != RB3_DEP_EVENT || (int)(w0hi >> (RB3_TENT_PBITS - 32) & (RB3_TENT_IDS - 1)) != cur) { go = false; break; } // not this walker's next event
+				// the rows that dropped at this event, from survivor indices to the coordinates of the first interval
+				const uint32_t cw = cumL[j];
+				const uint32_t zc = 32u - __popc(cw), Z = oct_exscan(zc, j);
+				uint32_t m = blk_[oi][o][j];
+				const uint32_t most = oct_max((uint32_t)__popc(m));
+				for (uint32_t it = 0; it < most; ++it) { // (uniform over the octet: the shuffles below need every lane)
+					const bool act = m != 0u;
+					const int p = act ? __ffs(m) - 1 : 0;
+					m &= m - 1u;
+					const uint32_t i = 32u * (uint32_t)j + (uint32_t)p; // index among the survivors
+					int jj = 0;
+#pragma unroll
+					for (int l = 1; l < 8; ++l) jj += __shfl(Z, l, 8) <= i ? 1 : 0;
+					const uint32_t Zj = __shfl(Z, jj, 8), cj = __shfl(cw, jj, 8);
+					if (act) atomicOr(&cumL[jj], 1u << select32(~cj, (int)(i - Zj)));
+				}
+				wave_sync();
+				tab[base + o].mask[j] = cumL[j]; // cumulative, first-interval coordinates
+				cur = base + o, next = nxt;
+				if (next != cur + 1 || ++o == RB3_TENT_BLOCK) break; // the sequence leaves this block
+			}
+			wave_sync();
+		}
+		// summary in the first stretch: total drops, last stretch, and the first stretch of the walker this one linked into
+		tab[F].mask[j] = cumL[j];
+		if (j == 0) {
+			uint32_t nf = 0u;
+			if (next >= 0 && next < RB3_TENT_IDS) {
+				const uint64_t w0 = tab[next].w0;
+				if (w0 >> 62 == RB3_DEP_LINK && RB3_DEP_PREV(w0) == cur) nf = (uint32_t)next + 1u;
+			}
+			tab[F].pad[1] = (uint32_t)cur + 1u;
+			tab[F].pad[0] = RB3_FIRSTFLAG | nf;
+		}
+		wave_sync();
+	}
+}
+
+__device__ __forceinline__ int popc_below256(const uint32_t m[8], int d)
+{
+	int below = 0;
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		const int tt = d - 32 * q;
+		below += tt >= 32 ? __popc(m[q]) : tt > 0 ? __popc(m[q] & ((1u << tt) - 1u)) : 0;
+	}
+	return below;
+}
+
+/* paths over first stretches: one thread per first stretch a walker settled; one record per hop */
+__global__ void __launch_bounds__(256) k_resolve_w(rb3_stretch_t *tab, const uint32_t *sidctr, int32_t *sfin)
+{
+	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF, nb = sidctr[1] < (uint32_t)RB3_TENT_HALF ? sidctr[1] : RB3_TENT_HALF;
+	const int64_t nblk = (na + RB3_TENT_BLOCK - 1) / RB3_TENT_BLOCK;
+	for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk + nb; t += (int64_t)gridDim.x * blockDim.x) {
+		int F = (int)(t < nblk ? t * RB3_TENT_BLOCK : RB3_TENT_HALF + (t - nblk));
+		const uint4 *rp = (const uint4*)&tab[F];
+		uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+		int d0 = (int)q1.x - 1; // del
+		if (d0 < 0) continue;   // only first stretches a walker settled start a path
+		if (t < nblk && q3.z != 0u && !(q3.z & RB3_FIRSTFLAG)) continue; // (a continuation block: its first id is an event stretch)
+		for (int hops = 0; hops <= RB3_TENT_IDS; ++hops) {
+			if (d0 < 0 || d0 > RB3_TENT_KMAX) break; // cannot be: leave it unsettled, the host redoes the phase
+			sfin[F] = d0 + 1;
+			int last = F, next = (int)q1.y - 1, dl = d0;
+			if (q3.z & RB3_FIRSTFLAG) { // the walker had events: k_cum left the summary
+				const uint32_t mw[8] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y };
+				dl = d0 - popc_below256(mw, d0);
+				last = (int)q3.w - 1, next = (int)(q3.z & ~RB3_FIRSTFLAG) - 1;
+			}
+			if (next < 0 || next >= RB3_TENT_IDS) break;
+			rp = (const uint4*)&tab[next];
+			q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+			const uint64_t w0 = (uint64_t)q0.y << 32 | q0.x;
+			if (w0 >> 62 != RB3_DEP_LINK || RB3_DEP_PREV(w0) != last || q1.x != 0u) break; // another follower's link won / settled by a walker
+			d0 = dl + (int32_t)q0.z, F = next;
+		}
+	}
+}
+
+/* every event stretch from its walker's first unknown: sfin[s] = 1 + d_0 - #{dropped rows below d_0}; one octet per stretch */
+__global__ void __launch_bounds__(256) k_sfin(const rb3_stretch_t *tab, const uint32_t *sidctr, int32_t *sfin)
+{
+	const int j = threadIdx.x & 7;
+	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF;
+	for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; s < na; s += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+		const uint32_t head = tab[s].pad[0];
+		if (head == 0u || (head & RB3_FIRSTFLAG)) continue; // a first stretch: settled by a walker or by k_resolve_w
+		if (tab[s].w0 >> 62 != RB3_DEP_EVENT || tab[s].del != 0) continue;
+		const int r0 = sfin[head - 1u];
+		if (r0 < 1) continue; // the walker's first unknown is not settled: neither is this one
+		const int d0 = r0 - 1, tt = d0 - 32 * j;
+		const uint32_t mw = tab[s].mask[j];
+		const uint32_t below = oct_sum(tt >= 32 ? __popc(mw) : tt > 0 ? __popc(mw & ((1u << tt) - 1u)) : 0u);
+		const int d = d0 - (int)below;
+		if (j == 0 && d >= 0 && d <= RB3_TENT_KMAX) sfin[s] = d + 1;
 	}
 }
 
@@ -1188,15 +1364,6 @@ __global__ void __launch_bounds__(256) k_group_rows(const int64_t *pos, int64_t 
 #define RB3_REB_WAVES 4   /* waves per block of the window-parallel rebuild kernels */
 #define RB3_REB_WPW   1   /* consecutive windows each of those waves handles (blocks are dispatched at ~2 G/s:
                              one 64-thread block per window would be bound by that) */
-/* the waves of a rebuild block work independently: LDS traffic between its lanes only needs program order
- * (the LDS executes a wave's instructions in order), not a workgroup barrier -- and no wait for global
- * loads in flight, which is what makes the loads of the next stage overlap */
-__device__ __forceinline__ void wave_sync()
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template<bool FROM_PLAIN>
 __device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,

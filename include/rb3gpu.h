@@ -64,6 +64,7 @@ typedef struct {
 	int64_t n_reb_groups;        /* groups (8192 symbols) of the merges whose rebuild went through the run-space kernel ... */
 	int64_t n_reb_groups_window; /* ... and how many of them it handed on to the per-window kernels (single-sync merges) */
 	int64_t n_lf_checked;        /* batch rows whose LF relation was verified against the index after the rank phase (approximate) */
+	int64_t n_long_settles;      /* merges whose tentative records needed the pointer-jumping settle pass (paths over > 64 walkers) */
 	int64_t bytes_rebuild;       /* algorithmic bytes of the rebuilds: per merge 9 B x rows + old block array + new block array */
 } rb3gpu_stats_t;
 

@@ -381,6 +381,8 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
 #define MISC_LF_TOT  16
 #define MISC_IX_TOT  24
 #define MISC_RG_LISTS 14
+#define MISC_LF_CHK   6    /* [6] rows whose LF relation was verified, [7] rows that failed it */
+#define MISC_B2_MODE  15   /* what the device-made walker list is (k_b2_mode) */
 
 /* build a block array for ntot symbols into ib[1-cur]; FROM_PLAIN: symbols are d_b2[0..ntot);
  * otherwise the interleave of the current index with d_b2 at merged positions pos[].
@@ -574,7 +576,7 @@ static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b
 		else s = h->st2;
 	}
 	hipLaunchKernelGGL(k_lf_check, dim3((unsigned)((ns * 8 + 255) / 256)), dim3(256), 0, s, view_of(h), dpos, d_b2, len, (const uint64_t*)h->tpre.p,
-			(const uint64_t*)(misc + MISC_LF_TOT), stride, misc + 2, misc + 6);
+			(const uint64_t*)(misc + MISC_LF_TOT), stride, misc + 2, misc + MISC_LF_CHK);
 	if (side) (void)hipEventRecord(h->evx[1], h->st2);
 	return side; // true: the caller makes its stream wait for evx[1] before it reads the counters
 }
@@ -703,7 +705,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 			if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
 			else {
 				hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr);
-				hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+				hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin, qhead + 2, (int)RB3_TENT_IDS); // (no second chance on this path: follow every path to its end)
 				hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin);
 			}
 			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, h->mg_pos, len, (const int32_t*)sfin, qhead + 2);
@@ -745,13 +747,13 @@ static int mg_finish(rb3gpu_t *h, int commit, int64_t *host_pos, int rank_only)
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)h->mg_pos, len, ntot, misc + 2);
 	(void)launch_lf_check(h, (const int64_t*)h->mg_pos, h->mg_b2, len, false);
-	unsigned long long hm[7] = {0, 0, 0, 0, 0, 0, 0};
-	HIPCHK(hipMemcpyAsync(hm, misc, 56, hipMemcpyDeviceToHost, h->st));
+	unsigned long long hm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	h->stt.n_lf_steps += (int64_t)hm[1];
-	h->stt.n_lf_checked += (int64_t)hm[6];
-	if (hm[2] != 0 || hm[3] != 0 || hm[4] != 0) {
-		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu tentative records unsettled or rows that fail the LF relation\n", hm[2], hm[3], hm[4]);
+	h->stt.n_lf_checked += (int64_t)hm[MISC_LF_CHK];
+	if (hm[2] != 0 || hm[3] != 0 || hm[4] != 0 || hm[MISC_LF_CHK + 1] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu tentative records unsettled, %llu sampled rows that fail the LF relation\n", hm[2], hm[3], hm[4], hm[MISC_LF_CHK + 1]);
 		return RB3GPU_EINTERNAL;
 	}
 	int64_t ngrp = 0, nslots = 0, acc[7];
@@ -920,7 +922,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		uint64_t *slen = lnk[1] + 2 * b2_nspmax;
 		unsigned long long *bucket = (unsigned long long*)(slen + b2_m2cap + 2);
 		const uint64_t *tot2 = (const uint64_t*)(misc + MISC_LF_TOT);
-		unsigned long long *mode = misc + 7;
+		unsigned long long *mode = misc + MISC_B2_MODE;
 		b2_nwalk = misc + 13;
 		HIPCHK(hipMemsetAsync(bucket, 0xff, (size_t)b2_nbk * 8, h->st));
 		HIPCHK(hipMemsetAsync(slen, 0, (size_t)(b2_m2cap + 2) * 8, h->st));
@@ -990,7 +992,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
 			else {
 				hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr);
-				hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
+				hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS);
 				hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin);
 			}
 		}
@@ -1022,7 +1024,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	h->stt.n_lf_steps += (int64_t)hm[1];
-	h->stt.n_lf_checked += (int64_t)hm[6];
+	h->stt.n_lf_checked += (int64_t)hm[MISC_LF_CHK];
 #ifdef RB3_PROF
 	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, max iterations %llu -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], hm[12], (double)hm[9] / hm[10]);
 #endif
@@ -1045,11 +1047,11 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			sum += w[i].nsteps, mx = w[i].nsteps > mx ? w[i].nsteps : mx, mn = w[i].nsteps < mn ? w[i].nsteps : mn, nbig += w[i].nsteps > 600;
 		}
 		fprintf(stderr, "[debug] device-made list: %lld slots, %lld walkers, %lld with nsteps = inf, gaps min %lld mean %.1f max %lld, %lld above 600; mode %llu\n", (long long)nw, (long long)nv, (long long)ninf,
-				(long long)mn, (double)sum / (double)(nv - ninf > 0 ? nv - ninf : 1), (long long)mx, (long long)nbig, hm[7]);
+				(long long)mn, (double)sum / (double)(nv - ninf > 0 ? nv - ninf : 1), (long long)mx, (long long)nbig, hm[MISC_B2_MODE]);
 		free(w);
 	}
 #endif
-	if (auto_list && hm[7] == 2) // more strings than the device-made list takes (strings shorter than 64 symbols on average): nothing was walked
+	if (auto_list && hm[MISC_B2_MODE] == 2) // more strings than the device-made list takes (strings shorter than 64 symbols on average): nothing was walked
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, tent);
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
 	if (tent) {
@@ -1058,14 +1060,56 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		if (h->tn.force_fallback) hm[4] = 1; // test hook: exercise the redo path
 #endif
 	}
-	if (tent && hm[4] != 0) { // some tentative record was left unsettled: nothing was installed, redo without them
+	if (tent && hm[4] != 0 && hm[MISC_LF_CHK + 1] == 0 && !h->tn.resolve_v1
+#ifdef RB3GPU_TEST_HOOKS
+			&& !h->tn.force_fallback
+#endif
+			) {
+		// Second chance: dependency paths longer than k_resolve_w follows (a string that repeats indexed text).  Nothing was installed
+		// and the unsettled records are still in pos[]: settle them by pointer jumping over the walkers, then validate and rebuild again.
+		const int64_t na = h->sid_dirty[0], nb = h->sid_dirty[1], nblk = (na + RB3_TENT_BLOCK - 1) / RB3_TENT_BLOCK, nn = nblk + nb;
+		if (nn > 0 && (r = buf_ensure(h, h->xbuf, (size_t)nn * 2 * sizeof(WjNode))) < 0) return r;
+		if (nn > 0) {
+			WjNode *nd[2] = { (WjNode*)h->xbuf.p, (WjNode*)h->xbuf.p + nn };
+			HIPCHK(hipEventRecord(h->ev[4], h->st));
+			hipLaunchKernelGGL(k_wj_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const int32_t*)sfin, nblk, nb, nd[0]);
+			int cur = 0;
+			for (int64_t reach = 1; reach <= nn; reach <<= 1, cur ^= 1)
+				hipLaunchKernelGGL(k_wj_round, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->st, nn, (const WjNode*)nd[cur], nd[cur ^ 1]);
+			hipLaunchKernelGGL(k_wj_apply, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->st, nblk, nb, (const WjNode*)nd[cur], sfin);
+			hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin);
+			HIPCHK(hipMemsetAsync(misc + 2, 0, 24, h->st));
+			if (rows_fused) {
+				HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st));
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), dim3((unsigned)((len + 1 + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
+			} else
+				hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2);
+			HIPCHK(hipEventRecord(h->ev[5], h->st));
+			(void)launch_lf_check(h, (const int64_t*)dpos, d_b2, len, false);
+			if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) return r;
+			HIPCHK(hipEventRecord(h->ev[3], h->st));
+			HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));
+			if (host_pos) HIPCHK(hipMemcpyAsync(host_pos, dpos, (size_t)len * 8, hipMemcpyDeviceToHost, h->st));
+			HIPCHK(hipStreamSynchronize(h->st));
+			h->stt.ms_rank += ev_ms(h->ev[4], h->ev[5]);
+			h->stt.ms_build += ev_ms(h->ev[5], h->ev[3]);
+			h->stt.n_long_settles += 1;
+		}
+	}
+	if (tent && (hm[4] != 0 || hm[2] != 0 || hm[3] != 0)) { // the optimistic pass did not validate (records unsettled, or rows nobody reached): nothing was installed, redo without tentative records
 		h->stt.n_fallbacks += 1;
-		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled; redoing the merge without tentative records\n", hm[4]);
+		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled, %llu rows unset, %llu out of order; redoing the merge without tentative records\n", hm[4], hm[2], hm[3]);
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, 0);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, 0);
 	}
-	if (hm[2] != 0 || hm[3] != 0 || hm[4] != 0) {
-		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu sampled rows that fail the LF relation\n", hm[2], hm[3], hm[4]);
+	if (tent && hm[MISC_LF_CHK + 1] != 0) { // sampled rows fail the LF relation: nothing was installed; once more without speculative records
+		h->stt.n_fallbacks += 1;
+		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu sampled rows fail the LF relation; redoing the merge without tentative records\n", hm[MISC_LF_CHK + 1]);
+		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, 0);
+		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, 0);
+	}
+	if (hm[2] != 0 || hm[3] != 0 || hm[4] != 0 || hm[MISC_LF_CHK + 1] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] rank phase left %llu rows unset, %llu out of order, %llu sampled rows that fail the LF relation\n", hm[2], hm[3], hm[MISC_LF_CHK + 1]);
 		return RB3GPU_EINTERNAL;
 	}
 	h->stt.n_symbols_merged += len;

@@ -1021,6 +1021,7 @@ __global__ void __launch_bounds__(256) k_resolve(rb3_stretch_t *tab, const uint3
  * after k_cum: RB3_FIRSTFLAG | 1 + the first stretch of the walker it links into; pad[1] = 1 + the walker's last stretch; mask[] of
  * a first stretch = the cumulative mask of the last one. */
 #define RB3_FIRSTFLAG 0x80000000u
+#define RB3_RESW_MAXHOPS 64
 
 /* position of the n-th (0-based) set bit of z */
 __device__ __forceinline__ int select32(uint32_t z, int n)
@@ -1123,7 +1124,7 @@ __device__ __forceinline__ int popc_below256(const uint32_t m[8], int d)
 }
 
 /* paths over first stretches: one thread per first stretch a walker settled; one record per hop */
-__global__ void __launch_bounds__(256) k_resolve_w(rb3_stretch_t *tab, const uint32_t *sidctr, int32_t *sfin)
+__global__ void __launch_bounds__(256) k_resolve_w(rb3_stretch_t *tab, const uint32_t *sidctr, int32_t *sfin, unsigned long long *bad, int maxhops)
 {
 	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF, nb = sidctr[1] < (uint32_t)RB3_TENT_HALF ? sidctr[1] : RB3_TENT_HALF;
 	const int64_t nblk = (na + RB3_TENT_BLOCK - 1) / RB3_TENT_BLOCK;
@@ -1134,7 +1135,7 @@ __global__ void __launch_bounds__(256) k_resolve_w(rb3_stretch_t *tab, const uin
 		int d0 = (int)q1.x - 1; // del
 		if (d0 < 0) continue;   // only first stretches a walker settled start a path
 		if (t < nblk && q3.z != 0u && !(q3.z & RB3_FIRSTFLAG)) continue; // (a continuation block: its first id is an event stretch)
-		for (int hops = 0; hops <= RB3_TENT_IDS; ++hops) {
+		for (int hops = 0; hops <= maxhops; ++hops) { // longer paths (a string that repeats indexed text) are left to k_wj_*
 			if (d0 < 0 || d0 > RB3_TENT_KMAX) break; // cannot be: leave it unsettled, the host redoes the phase
 			sfin[F] = d0 + 1;
 			int last = F, next = (int)q1.y - 1, dl = d0;
@@ -1149,8 +1150,102 @@ __global__ void __launch_bounds__(256) k_resolve_w(rb3_stretch_t *tab, const uin
 			const uint64_t w0 = (uint64_t)q0.y << 32 | q0.x;
 			if (w0 >> 62 != RB3_DEP_LINK || RB3_DEP_PREV(w0) != last || q1.x != 0u) break; // another follower's link won / settled by a walker
 			d0 = dl + (int32_t)q0.z, F = next;
+			if (hops == maxhops) atomicAdd(&bad[2], 1ull); // the path goes on: tell the validation pass not to bother (the host starts k_wj_*)
 		}
 	}
+}
+
+/* ---- long dependency paths: pointer jumping over the walkers (second chance, after k_resolve_w gave up) ----------------
+ * A string that repeats indexed text end to end never makes a walker exact, so ALL its walkers hang on one path, which
+ * k_resolve_w would follow hop by hop (11.5 k hops for a 4.4 Mbp genome: 5-10 ms).  The step from the first unknown of one
+ * walker to the first unknown of the next is x -> x - #{dropped rows below x} + offset, and such maps compose into a map of the
+ * same form (the dropped rows of the second walker are pulled back to the coordinates of the first: a select per bit; rows
+ * that only the younger walker's wider interval holds lie below or above every possible x and change the offset or nothing).
+ * So the path is shortened by doubling: node = first stretch, (ptr, M, c) = "my unknown is M/c applied to the unknown of ptr". */
+struct WjNode {
+	uint32_t M[8];
+	int32_t c, ptr, val, pad; // val: >= 0 settled, -1 not yet, -2 not a node; ptr: node this one hangs on, -1 none
+};
+
+__device__ __forceinline__ int wj_id(int X, int64_t nblk) { return X < RB3_TENT_HALF ? X / RB3_TENT_BLOCK : (int)nblk + (X - RB3_TENT_HALF); }
+__device__ __forceinline__ int wj_stretch(int64_t t, int64_t nblk) { return t < nblk ? (int)t * RB3_TENT_BLOCK : RB3_TENT_HALF + (int)(t - nblk); }
+
+__global__ void __launch_bounds__(256) k_wj_init(const rb3_stretch_t *tab, const int32_t *sfin, int64_t nblk, int64_t nb, WjNode *nodes)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nblk + nb) return;
+	const int X = wj_stretch(t, nblk);
+	WjNode n;
+	for (int q = 0; q < 8; ++q) n.M[q] = 0u;
+	n.c = 0, n.ptr = -1, n.val = -1, n.pad = 0;
+	const uint32_t h0 = tab[X].pad[0];
+	if (t < nblk && h0 != 0u && !(h0 & RB3_FIRSTFLAG)) n.val = -2; // the block continues another walker's stretches
+	else {
+		const int s = sfin[X], del = tab[X].del;
+		if (s > 0) n.val = s - 1;
+		else if (del > 0 && del <= RB3_TENT_KMAX + 1) n.val = del - 1;
+		else {
+			const uint64_t w0 = tab[X].w0;
+			if (w0 >> 62 == RB3_DEP_LINK) {
+				const int pl = RB3_DEP_PREV(w0); // the LAST stretch of the walker that ran into this one
+				const uint32_t hp = tab[pl].pad[0];
+				const int pf = (hp == 0u || (hp & RB3_FIRSTFLAG)) ? pl : (int)hp - 1;
+				if (pf >= 0 && pf < RB3_TENT_IDS && (pf >= RB3_TENT_HALF || (pf & (RB3_TENT_BLOCK - 1)) == 0)) {
+					n.ptr = wj_id(pf, nblk), n.c = (int32_t)tab[X].w1;
+					if (pf != pl || (tab[pf].pad[0] & RB3_FIRSTFLAG)) // the cumulative mask of its last stretch (k_cum keeps a copy in the first)
+						for (int q = 0; q < 8; ++q) n.M[q] = tab[pl].mask[q];
+					if (pf == pl) for (int q = 0; q < 8; ++q) n.M[q] = 0u; // it linked from its first stretch: nothing had dropped
+				}
+			}
+		}
+	}
+	nodes[t] = n;
+}
+
+__device__ __forceinline__ int wj_apply(const uint32_t M[8], int c, int x) { return x - popc_below256(M, x) + c; }
+
+__global__ void __launch_bounds__(256) k_wj_round(int64_t n, const WjNode *in, WjNode *out)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	WjNode a = in[t];
+	if (a.val == -1 && a.ptr >= 0 && a.ptr < n) {
+		const WjNode p = in[a.ptr];
+		if (p.val >= 0) {
+			const int y = wj_apply(a.M, a.c, p.val);
+			a.val = y >= 0 && y <= RB3_TENT_KMAX ? y : -3; // (-3: cannot be; stays unsettled and the merge is redone)
+		} else if (p.val != -1 || p.ptr < 0) a.ptr = -1; // hangs on something that will never be settled
+		else { // compose: p's map first, then mine
+			uint32_t M[8];
+			int c = p.c + a.c, zeros = 0;
+			for (int q = 0; q < 8; ++q) M[q] = p.M[q], zeros += 32 - __popc(p.M[q]);
+			for (int q = 0; q < 8; ++q) {
+				uint32_t m = a.M[q];
+				while (m) {
+					const int i = 32 * q + __ffs(m) - 1; // a row that dropped on my side, index in the coordinates p's map produces
+					m &= m - 1u;
+					int sidx = i - p.c;               // its rank among the rows p's first interval keeps
+					if (sidx < 0) { c -= 1; continue; } // only in the wider interval, below every x: one less below the new suffix, always
+					if (sidx >= zeros) continue;        // above every x
+					for (int w = 0; w < 8; ++w) {       // the sidx-th zero of p.M
+						const int z = 32 - __popc(p.M[w]);
+						if (sidx < z) { M[w] |= 1u << select32(~p.M[w], sidx); break; }
+						sidx -= z;
+					}
+				}
+			}
+			for (int q = 0; q < 8; ++q) a.M[q] = M[q];
+			a.c = c, a.ptr = p.ptr;
+		}
+	}
+	out[t] = a;
+}
+
+__global__ void __launch_bounds__(256) k_wj_apply(int64_t nblk, int64_t nb, const WjNode *nodes, int32_t *sfin)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nblk + nb) return;
+	if (nodes[t].val >= 0) sfin[wj_stretch(t, nblk)] = nodes[t].val + 1;
 }
 
 /* every event stretch from its walker's first unknown: sfin[s] = 1 + d_0 - #{dropped rows below d_0}; one octet per stretch */
@@ -1197,10 +1292,11 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check(int64_t *pos, int64_
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n2) return;
+	if (*(volatile unsigned long long*)&bad[2] != 0) return; // the settle pass already knows it is incomplete: nothing to validate yet
 	const int64_t raw = pos[i];
 	const int64_t p = pos_final(raw, sfin, bad);
 	const int64_t q = i > 0 ? pos_final(pos[i - 1], sfin, nullptr) : RB3_UNSET; // the neighbour's own thread reports its problems
-	if (p != raw) pos[i] = p;
+	if (p != raw && p >= 0) pos[i] = p; // (an unsettled record stays as it is: a longer settle pass may still resolve it)
 	if (p < 0) atomicAdd(&bad[0], 1ull);
 	else if (p >= ntot || (i > 0 && q >= 0 && q >= p)) atomicAdd(&bad[1], 1ull);
 }
@@ -1214,11 +1310,12 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check_rows(int64_t *pos, i
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n2) return;
+	if (TENT && *(volatile unsigned long long*)&bad[2] != 0) return; // the settle pass already knows it is incomplete: nothing to validate yet
 	int64_t p = INT64_MAX, q = RB3_UNSET;
 	if (i < n2) {
 		const int64_t raw = pos[i];
 		p = TENT ? pos_final(raw, sfin, bad) : (raw < 0 ? RB3_UNSET : raw);
-		if (TENT && p != raw) pos[i] = p;
+		if (TENT && p != raw && p >= 0) pos[i] = p; // (an unsettled record stays as it is: a longer settle pass may still resolve it)
 	}
 	if (i > 0) {
 		const int64_t rq = pos[i - 1];
@@ -1263,7 +1360,7 @@ __global__ void __launch_bounds__(256) k_test_corrupt(int64_t *pos, int64_t n2)
  * rows have ka = m1 (fm-index.c:164).  If this holds for every row, pos[] is the reference's rb[] >> 6 by induction along
  * every string; here it is verified for every `stride`-th row (one octet per sample: the count inside the 4096-byte tile of
  * B2, then one rank on B1), which finds any systematic error of the speculative walkers at sizes no CPU oracle reaches.
- * bad[4] (shared with "tentative records unsettled": the merge is redone without them, then fails) counts mismatches. */
+ * nchecked[1] counts mismatches (a merge that fails here is redone without speculative records, then reported). */
 __global__ void __launch_bounds__(256) k_lf_check(IdxView b1, const int64_t *pos, const uint8_t *b2, int64_t n2, const uint64_t *tpre, const uint64_t *tot2,
 		int64_t stride, unsigned long long *bad, unsigned long long *nchecked)
 {
@@ -1304,7 +1401,7 @@ __global__ void __launch_bounds__(256) k_lf_check(IdxView b1, const int64_t *pos
 		if (kbn < 0 || kbn >= n2 || pos[kbn] - kbn != want) ok = false;
 	}
 	if (j == 0) {
-		if (!ok) atomicAdd(&bad[2], 1ull);
+		if (!ok) atomicAdd(nchecked + 1, 1ull); // (its own counter: not to be mistaken for unsettled tentative records)
 		else if ((s & 63) == 0) atomicAdd(nchecked, 64ull); // (approximate count, kept off the hot address)
 	}
 }

@@ -886,3 +886,29 @@ def test_lf_consistency_check_finds_a_wrong_but_monotone_pos(oracle):
     h.merge_text_dev(d, dtw, t2.size, host.walkers_text(t2, 256), commit=True)
     assert h.stats()["n_lf_checked"] > 0
     h.close()
+
+
+def test_duplicate_genome_long_settle_paths(oracle):
+    """a string that repeats indexed text end to end never makes a walker exact: all its walkers hang on ONE dependency path,
+    longer than k_resolve_w follows (64 hops).  The merge notices on the device, the host starts the pointer-jumping settle
+    (k_wj_*: maps x -> x - #dropped below x + offset composed by doubling), validates and rebuilds again -- no redo of the
+    rank phase, and the same index as the oracle's.  Single relative (pure links) and a family (drop-outs along the path)."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(404)
+    g0 = util.random_genome(rng, 120000)
+    for nrel in (1, 6):
+        rel = [g0] + [util.mutate(rng, g0, 0.002) for _ in range(nrel - 1)]
+        b1 = host.build_bwt(util.make_text(rel))
+        t2 = util.make_text([rel[-1].copy(), util.mutate(rng, g0, 0.001)])     # a duplicate and an ordinary relative in one batch
+        want = oracle.merge(b1, host.build_bwt(t2.copy()))
+        h = Rb3Gpu(verbose=1)
+        h.from_plain(b1)
+        d, dtw = h.sort_text(t2)
+        h.merge_text_dev(d, dtw, t2.size, host.walkers_text(t2, 128), commit=True)
+        st = h.stats()
+        assert np.array_equal(h.export_plain(), want), nrel
+        assert st["n_fallbacks"] == 0 and st["n_long_settles"] == 1, st
+        h.merge_plain(host.build_bwt(t2.copy()))                              # the BWT-only entry point, the same batch again: now both strings are duplicates
+        assert np.array_equal(h.export_plain(), oracle.merge(want, host.build_bwt(t2.copy()))), nrel
+        assert h.stats()["n_fallbacks"] == 0
+        h.close()

@@ -243,6 +243,16 @@ def target_workload(K, L, ref_prefix, keep=None):
                           "phases_ms": {"text_upload(H2D)": up, "lf": st.get("lf_ms"), "rank": st.get("rank_ms"), "rebuild": st.get("rebuild_ms")},
                           "definition": "SURVEY 8(d): H2D + rank + interleave + rebuild summed over the rounds, suffix sorting and file I/O excluded; with GPU suffix sorting the H2D of a batch is its text upload (the BWT never crosses PCIe)"},
            "suffix_sorting_ms_overlapped": st.get("sort_ms"), "index_mb": st.get("index_mb"), "batches_sorted_on_gpu": st.get("batches_gpu"), "batches_sorted_on_host": st.get("batches_host")}
+    # (b) of SURVEY 8(d) config 3: the same files re-batched (a batch spans input files: ~16 rounds instead of 151); same .fmd
+    t = time.time()
+    rb = subprocess.run([_build.BIN_CLI, "build", "-d", "--rebatch", "-m80m"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    wall_b = time.time() - t
+    if rb.returncode == 0:
+        sb = parse_cli_stats(rb.stderr.decode())
+        out["rebatched"] = {"command": "ropebwt3-amd build -d --rebatch -m80m (9-10 genomes per batch)", "build_wall_s": round(wall_b, 3), "merge_rounds": sb.get("chain_launches"),
+                            "merge_path_ms": sb.get("merge_path_ms"), "phases_ms": {"text_upload(H2D)": sb.get("text_upload_ms"), "lf": sb.get("lf_ms"), "rank": sb.get("rank_ms"), "rebuild": sb.get("rebuild_ms")},
+                            "Gbp/s_merge_path": round(sb.get("symbols_merged", 0) / sb["merge_path_ms"] / 1e6, 4) if sb.get("merge_path_ms") else None,
+                            "fmd_identical": hashlib.md5(rb.stdout).hexdigest() == md5}
     if st.get("chain_ms") and st.get("chain_launches"):
         rows = nsym / max(1, st["chain_launches"])
         ms = st["chain_ms"] / st["chain_launches"]

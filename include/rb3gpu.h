@@ -65,6 +65,9 @@ typedef struct {
 	int64_t n_reb_groups_window; /* ... and how many of them it handed on to the per-window kernels (single-sync merges) */
 	int64_t n_lf_checked;        /* batch rows whose LF relation was verified against the index after the rank phase (approximate) */
 	int64_t n_long_settles;      /* merges whose tentative records needed the pointer-jumping settle pass (paths over > 64 walkers) */
+	double  ms_alloc;            /* host time inside hipMalloc / hipFree for the handle's buffers (they grow with the index; replaced ones are freed in bulk) */
+	int64_t n_allocs;
+	int64_t n_reb_again;         /* rebuilds done twice because a buffer sized by an estimate did not take the result */
 	int64_t bytes_rebuild;       /* algorithmic bytes of the rebuilds: per merge 9 B x rows + old block array + new block array */
 } rb3gpu_stats_t;
 

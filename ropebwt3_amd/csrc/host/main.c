@@ -636,6 +636,8 @@ int main_build(int argc, char *argv[])
 			fprintf(stderr, "[M::%s] GPU sorter threads: text upload %.3f ms, suffix sorting %.3f ms (overlapped with the merges)\n", __func__, g_sorted.ms_upload, g_sorted.ms_sort);
 		fprintf(stderr, "[M::%s] rebuild: %.3f ms for %ld algorithmic bytes (9 B x rows + old + new block array per round) = %.1f GB/s; LF walkers: k_chain %.3f ms in %ld launches, %ld steps\n", __func__,
 				st.ms_build, (long)st.bytes_rebuild, st.ms_build > 0 ? st.bytes_rebuild / st.ms_build / 1e6 : 0.0, st.ms_chain, (long)st.n_rank_launches, (long)st.n_lf_steps);
+		fprintf(stderr, "[M::%s] run-space rebuild: %ld groups, %ld of them handed on to the window kernels; %ld merges redone without tentative records, %ld needed the long settle pass; %ld rows LF-checked; %.1f ms in %ld device allocations\n", __func__,
+				(long)st.n_reb_groups, (long)st.n_reb_groups_window, (long)st.n_fallbacks, (long)st.n_long_settles, (long)st.n_lf_checked, st.ms_alloc, (long)st.n_allocs);
 		fprintf(stderr, "[M::%s] batches: %ld (%ld symbols) suffix-sorted on the GPU, %ld (%ld symbols) on the host; -m %ld%s\n", __func__,
 				(long)g_sorted.n_gpu, (long)g_sorted.sym_gpu, (long)g_sorted.n_host, (long)g_sorted.sym_host, (long)opt.batch_size,
 				batch_cut(&opt) != opt.batch_size ? " cut into GPU sub-batches (--gpu-batch)" : "");

@@ -11,6 +11,8 @@
  * because they use rocPRIM's sorts and scans; nothing on the merge path depends on them.
  */
 #include <hip/hip_runtime.h>
+#include <vector>
+#include <utility>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -57,11 +59,17 @@ struct Tune {
 	int64_t blkcap = 2048;   // block cap of k_chain
 	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
 	int b2_split = 4;        // splitter spacing 2^S of the batch's own LF walk (walkers for the BWT-only entry point); 0: SA-regular walkers (staged path)
+	int log_alloc = 0;       // print every device allocation and the time it took
+	int poison = 0;          // fill every new device buffer with 0xA5 bytes (debugging: nothing may rely on what fresh memory holds)
+	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
+	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
 #ifdef RB3GPU_TEST_HOOKS
 	int force_fallback = 0;  // pretend the tentative pass left unsettled records
 	int64_t tent_limit = -1; // shrink the stretch table
 	int text_mode = 0;       // force how the text-order words are fetched (1: per lane, 2: 64 bytes per octet)
+	int64_t reb_lcap = 0;    // > 0: entries of the hand-over list the window scratch takes (a longer list: rebuild done again)
+	int64_t reb_slot_cap = 0;// > 0: pretend the slot array of a single-sync rebuild holds this many slots
 	int corrupt_pos = 0;     // move a range of rows of pos[] by one after the walk (still monotone): the LF check must notice
 #endif
 };
@@ -90,6 +98,9 @@ struct rb3gpu_s {
 	int64_t *mg_pos = nullptr;
 	hipEvent_t ev[8];
 	int64_t bytes_owned = 0;
+	std::vector<std::pair<void*, size_t> > garbage; // replaced buffers not yet given back (dev_free)
+	int64_t bytes_garbage = 0;
+	uint64_t reb_slot_cap = 0; // capacity of the slot array the last rebuild emitted into (build_index)
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
 	rb3sort_ws *sorter = nullptr;           // scratch of rb3gpu_bwt_from_text, created on first use
@@ -103,11 +114,46 @@ static double now_s(void)
 	return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
+#define RB3_GUARD 4096 /* tune "guard": bytes behind every buffer of the handle that must keep their fill pattern */
+
+#define RB3_GUARD 4096 /* tune "guard": bytes behind every buffer of the handle that must keep their fill pattern */
+
+/* give the replaced buffers back.  hipFree waits for EVERY stream of the device -- the sorter thread's kernels included, tens of
+ * milliseconds per call while a batch is being sorted -- and the buffers of an index that grows round by round are replaced all
+ * the time (408 of the 536 ms of the merge path of a 152-genome build were spent there).  So a replaced buffer only goes on a
+ * list, and the list is emptied when it has grown to half of what the handle holds (or 4 GB), when memory runs out, and when the
+ * handle is destroyed.  (The stream-ordered allocator, hipMallocAsync, was tried instead: on ROCm 7.2 freshly obtained pool
+ * memory was seen zeroed AFTER the first stream-ordered writes to it, which corrupted the index.) */
+static void garbage_collect(rb3gpu_t *h, bool force)
+{
+	if (h->garbage.empty()) return;
+	const int64_t live = h->bytes_owned - h->bytes_garbage, limit = live / 2 > ((int64_t)4 << 30) ? live / 2 : ((int64_t)4 << 30);
+	if (!force && h->bytes_garbage <= limit) return;
+	const double t0 = now_s();
+	for (auto &g : h->garbage) (void)hipFree(g.first);
+	h->stt.ms_alloc += (now_s() - t0) * 1e3;
+	h->bytes_owned -= h->bytes_garbage, h->bytes_garbage = 0;
+	h->garbage.clear();
+}
+
 static int dev_malloc(rb3gpu_t *h, void **p, size_t bytes)
 {
 	*p = nullptr;
 	if (bytes == 0) bytes = 256;
-	HIPCHK(hipMalloc(p, bytes));
+	const size_t payload = bytes;
+	if (h->tn.guard) bytes += RB3_GUARD;
+	const double t0 = now_s();
+	hipError_t e = hipMalloc(p, bytes);
+	if (e == hipErrorOutOfMemory && !h->garbage.empty()) {
+		(void)hipGetLastError();
+		garbage_collect(h, true);
+		e = hipMalloc(p, bytes);
+	}
+	h->stt.ms_alloc += (now_s() - t0) * 1e3, h->stt.n_allocs += 1;
+	if (h->tn.log_alloc) fprintf(stderr, "[M::rb3gpu] hipMalloc of %.1f MB took %.3f ms -> %p\n", (double)bytes / 1e6, (now_s() - t0) * 1e3, *p);
+	HIPCHK(e);
+	if (h->tn.poison) HIPCHK(hipMemsetAsync(*p, 0xA5, bytes, h->st));
+	if (h->tn.guard) HIPCHK(hipMemsetAsync((uint8_t*)*p + payload, 0xA5, RB3_GUARD, h->st));
 	h->bytes_owned += (int64_t)bytes;
 	if (h->bytes_owned > h->stt.bytes_peak) h->stt.bytes_peak = h->bytes_owned;
 	return 0;
@@ -116,8 +162,16 @@ static int dev_malloc(rb3gpu_t *h, void **p, size_t bytes)
 static void dev_free(rb3gpu_t *h, void *p, size_t bytes)
 {
 	if (p == nullptr) return;
+	if (bytes == 0) bytes = 256;
+	if (h->tn.guard) bytes += RB3_GUARD;
+	if (h->tn.defer_free) { // (every user of the buffer is on h->st or joined to it, and the list is only emptied by hipFree, which waits for the device)
+		h->garbage.push_back(std::make_pair(p, bytes)), h->bytes_garbage += (int64_t)bytes;
+		return;
+	}
+	const double t0 = now_s();
 	(void)hipFree(p);
-	h->bytes_owned -= (int64_t)(bytes ? bytes : 256);
+	h->stt.ms_alloc += (now_s() - t0) * 1e3;
+	h->bytes_owned -= (int64_t)bytes;
 }
 
 static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes)
@@ -125,7 +179,7 @@ static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes)
 	if (b.cap >= bytes && b.p) return 0;
 	if (b.p) dev_free(h, b.p, b.cap);
 	b.p = nullptr, b.cap = 0;
-	size_t want = bytes + (bytes >> 1) + 256; // geometric growth: an index that grows round by round must not realloc (hipFree synchronises) every round
+	size_t want = bytes + (bytes >> 1) + 256; // geometric growth: an index that grows round by round must not realloc every round
 	int r = dev_malloc(h, &b.p, want);
 	if (r == RB3GPU_ENOMEM && want != bytes) r = dev_malloc(h, &b.p, want = bytes);
 	if (r < 0) return r;
@@ -227,10 +281,16 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
 	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? 0 : v > 12 ? 12 : (int)v;
+	else if (!strcmp(key, "log_alloc")) t.log_alloc = v != 0;
+	else if (!strcmp(key, "defer_free")) t.defer_free = v != 0;
+	else if (!strcmp(key, "poison")) t.poison = v != 0;
+	else if (!strcmp(key, "guard")) t.guard = v != 0;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
-	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos")) {
+	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap")) {
 #ifdef RB3GPU_TEST_HOOKS
 		if (!strcmp(key, "corrupt_pos")) t.corrupt_pos = v != 0;
+		else if (!strcmp(key, "reb_lcap")) t.reb_lcap = v;
+		else if (!strcmp(key, "reb_slot_cap")) t.reb_slot_cap = v;
 		else if (!strcmp(key, "force_fallback")) t.force_fallback = v != 0;
 		else if (!strcmp(key, "tent_limit")) t.tent_limit = v;
 		else t.text_mode = v == 1 || v == 2 ? (int)v : 0;
@@ -249,8 +309,8 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check",
-		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", nullptr };
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check", "log_alloc", "defer_free", "poison", "guard",
+		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
 		size_t l = strlen(name);
@@ -327,6 +387,33 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots)
 	return 0;
 }
 
+/* tune "guard": have the kernels written behind any buffer of the handle?  (call with the stream idle) */
+static void guard_check(rb3gpu_t *h, const char *where)
+{
+	if (!h->tn.guard) return;
+	static const char *names[] = { "b2", "pos", "tcnt", "tpre", "ctot", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "wstat", "wplane", "wruns", "gslots", "glist" };
+	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	uint8_t g[RB3_GUARD];
+	for (int i = 0; i < 17 + 4; ++i) {
+		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
+		if (i < 17) p = (const uint8_t*)all[i]->p, cap = all[i]->cap, name = names[i];
+		else if (i < 19) p = (const uint8_t*)h->ib[i - 17].grp, cap = h->ib[i - 17].grp_cap * sizeof(rb3_grp_t), name = "index directory";
+		else p = (const uint8_t*)h->ib[i - 19].slots, cap = h->ib[i - 19].slots_cap * sizeof(rb3_slot_t), name = "index slots";
+		if (!p) continue;
+		if (cap == 0) cap = 256;
+		if (hipMemcpy(g, p + cap, RB3_GUARD, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); continue; }
+		for (int k = 0; k < RB3_GUARD; ++k)
+			if (g[k] != 0xA5) {
+				int nbad = 0, last = k;
+				for (int q = k; q < RB3_GUARD; ++q) if (g[q] != 0xA5) ++nbad, last = q;
+				fprintf(stderr, "[E::rb3gpu] %s: buffer '%s' (%zu bytes at %p) was written behind its end: %d bytes differ, offsets %d..%d:", where, name, cap, (const void*)p, nbad, k, last);
+				for (int q = k; q < k + 32 && q < RB3_GUARD; ++q) fprintf(stderr, " %02x", g[q]);
+				fprintf(stderr, "\n");
+				break;
+			}
+	}
+}
+
 void rb3gpu_destroy(rb3gpu_t *h)
 {
 	if (!h) return;
@@ -338,12 +425,16 @@ void rb3gpu_destroy(rb3gpu_t *h)
 		if (hipMemcpyFromSymbol(p, HIP_SYMBOL(g_reb_prof), sizeof(p)) == hipSuccess && p[8])
 			fprintf(stderr, "[prof] k_reb_group: %llu groups done (rows %.1f, runs %.1f, slots %.2f per group); cycles per group: setup %.0f, runs %.0f, rows-load %.0f, rows %.0f, run items %.0f, heads %.0f, partition %.0f, slots %.0f\n",
 					p[8], (double)p[9] / p[8], (double)p[10] / p[8], (double)p[11] / p[8], (double)p[0] / p[8], (double)p[1] / p[8], (double)p[2] / p[8], (double)p[3] / p[8], (double)p[4] / p[8], (double)p[5] / p[8], (double)p[6] / p[8], (double)p[7] / p[8]);
+		unsigned long long w[8];
+		if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_reb_why), sizeof(w)) == hipSuccess)
+			fprintf(stderr, "[prof] k_reb_group tiers handed on (counted per tier): too many rows %llu, old slots %llu, bit-plane slot %llu, old runs %llu, row runs %llu, new slots %llu, last group %llu\n", w[0], w[1], w[2], w[3], w[4], w[5], w[6]);
 	}
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
 	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	for (Buf *b : all) buf_release(h, *b);
+	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
 	for (int i = 0; i < 2; ++i) (void)hipEventDestroy(h->evx[i]);
 	(void)hipStreamDestroy(h->st2);
@@ -383,6 +474,7 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
 #define MISC_RG_LISTS 14
 #define MISC_LF_CHK   6    /* [6] rows whose LF relation was verified, [7] rows that failed it */
 #define MISC_B2_MODE  15   /* what the device-made walker list is (k_b2_mode) */
+#define MISC_RG_OVER  32   /* set by k_decide<LISTED>: the hand-over list of the run-space rebuild is longer than the window scratch */
 
 /* build a block array for ntot symbols into ib[1-cur]; FROM_PLAIN: symbols are d_b2[0..ntot);
  * otherwise the interleave of the current index with d_b2 at merged positions pos[].
@@ -393,7 +485,7 @@ static bool runspace_applies(const rb3gpu_t *h, int64_t n2, int64_t ntot)
 {
 	const int64_t nwin_old = (h->n >> RB3_WIN_BITS) + 1;
 	if (h->tn.window_rebuild || h->nslots == nwin_old) return false; // (a fully bit-plane index has no run slot to start from)
-	return h->tn.reb_force || (h->nslots * 2 < nwin_old && (double)n2 * RB3_GRP <= 260.0 * (double)ntot);
+	return h->tn.reb_force || (h->nslots * 2 < nwin_old && (double)n2 * RB3_GRP <= 4096.0 * (double)ntot); // (run-coded index; not where half of every group is new)
 }
 
 static bool use_winpar(const rb3gpu_t *h, int64_t nwin)
@@ -405,7 +497,7 @@ extern "C++" {
 /* rows_done: jg[] (rows before every window) has been filled by k_pos_finalize_check_rows already */
 template<bool FROM_PLAIN>
 static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64_t *d_pos, int64_t ntot, bool nosync,
-		int64_t *ongrp, int64_t *onslots, int64_t oacc[7], bool rows_done = false)
+		int64_t *ongrp, int64_t *onslots, int64_t oacc[7], bool rows_done = false, bool full = false)
 {
 	const int64_t ngrp = (ntot >> RB3_GRP_BITS) + 1, nwin = (ntot >> RB3_WIN_BITS) + 1;
 	const int dst = 1 - h->cur;
@@ -424,10 +516,25 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	// window-parallel kernels (one wave per 256-symbol window, planes cached between the passes) unless
 	// their scratch (216 B per window) would be unreasonably large; then one wave per 8192-symbol group
 	const bool winpar = use_winpar(h, nwin);
+	const double rows_per_group = (double)n2 * RB3_GRP / (double)(ntot > 0 ? ntot : 1);
+	const bool runspace = runspace_applies(h, n2, ntot) && winpar && !FROM_PLAIN;
+	// Scratch of the window kernels (208 B per window).  Behind the run-space rebuild they only see the groups it hands on, and
+	// index the scratch by the place in that list: room for an eighth of the groups (all of them while the index is small) --
+	// device memory costs ~37 us per MB to obtain, and the buffers of a growing index are obtained over and over.  A longer
+	// list is noticed on the device (k_decide) and the rebuild is done again with full = true.
+	int64_t lcap = ngrp;
+	if (runspace && nosync && !full) {
+		lcap = ngrp < 32768 ? ngrp : 32768;
+		if (lcap < ngrp / 8) lcap = ngrp / 8;
+#ifdef RB3GPU_TEST_HOOKS
+		if (h->tn.reb_lcap > 0 && h->tn.reb_lcap < lcap) lcap = h->tn.reb_lcap;
+#endif
+	}
 	if (winpar) {
-		if ((r = buf_ensure(h, h->wstat, (size_t)nwin * 16)) < 0) return r;
-		if ((r = buf_ensure(h, h->wplane, (size_t)nwin * 96)) < 0) return r;
-		if ((r = buf_ensure(h, h->wruns, (size_t)nwin * RB3_RLE_CODES * 2)) < 0) return r;
+		const int64_t nws = runspace ? lcap * RB3_GRP_WINS : nwin;
+		if ((r = buf_ensure(h, h->wstat, (size_t)nws * 16)) < 0) return r;
+		if ((r = buf_ensure(h, h->wplane, (size_t)nws * 96)) < 0) return r;
+		if ((r = buf_ensure(h, h->wruns, (size_t)nws * RB3_RLE_CODES * 2)) < 0) return r;
 		if (!FROM_PLAIN && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
 		jg = (int64_t*)h->jg.p;
 	}
@@ -435,8 +542,6 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	// window kernels.  A fully bit-plane index (old.dense) has nothing for it.
 	// (not where a group receives more rows than the tables of the run-space kernel take, and not where the old index is
 	// mostly bit planes -- few of its groups would qualify and every one that does not costs a hand-over)
-	const double rows_per_group = (double)n2 * RB3_GRP / (double)(ntot > 0 ? ntot : 1);
-	const bool runspace = runspace_applies(h, n2, ntot) && winpar && !FROM_PLAIN;
 	uint32_t *glist[2] = {nullptr, nullptr}, *nglist = nullptr;
 	uint8_t *gkind = nullptr;
 	if (runspace) {
@@ -445,7 +550,22 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		glist[0] = (uint32_t*)h->glist.p, glist[1] = glist[0] + ngrp, gkind = (uint8_t*)(glist[1] + ngrp);
 		nglist = (uint32_t*)((uint64_t*)h->misc.p + MISC_RG_LISTS);
 	}
-	if (nosync && (r = ib_ensure(h, dst, ngrp, nwin)) < 0) return r; // before any launch: hipMalloc may synchronise
+	if (nosync) { // before any launch: hipMalloc may synchronise
+		// the number of slots is only known after the scan: one per window is the upper bound; where the index is run-coded an
+		// estimate from the old count stands in (the emitting kernels compare the scan total with the capacity and leave the
+		// array alone if it does not fit; the caller then emits again after its sync)
+		int64_t est = nwin;
+		if (winpar && !FROM_PLAIN && !full && h->nslots * 2 < (h->n >> RB3_WIN_BITS) + 1) {
+			est = h->nslots + h->nslots / 4 + n2 / 16 + 4096;
+			if (est > nwin) est = nwin;
+		}
+		if ((r = ib_ensure(h, dst, ngrp, est)) < 0) return r;
+	}
+	uint64_t slot_cap = nosync ? (uint64_t)h->ib[dst].slots_cap : ~0ull;
+#ifdef RB3GPU_TEST_HOOKS
+	if (nosync && !full && h->tn.reb_slot_cap > 0 && (uint64_t)h->tn.reb_slot_cap < slot_cap) slot_cap = (uint64_t)h->tn.reb_slot_cap;
+#endif
+	h->reb_slot_cap = slot_cap;
 	IdxView old = view_of(h);
 	uint32_t *gstat = (uint32_t*)h->gstat.p;
 	uint64_t *gpre = (uint64_t*)h->gpre.p, *dtot = (uint64_t*)h->misc.p + MISC_IX_TOT;
@@ -460,6 +580,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			// medium one on what it left (or on all groups where the small one would mostly fail), then the window kernels on the
 			// list the last tier leaves (its length stays on the device: fixed grids, grid-stride loops).
 			HIPCHK(hipMemsetAsync(nglist, 0, 8, h->st));
+			HIPCHK(hipMemsetAsync((uint64_t*)h->misc.p + MISC_RG_OVER, 0, 8, h->st));
 			const int64_t gw4 = (ngrp + RB3_RG_WAVES - 1) / RB3_RG_WAVES;
 			const unsigned grs = (unsigned)(gw4 < 3072 ? gw4 : 3072), grm = (unsigned)(gw4 < 2048 ? gw4 : 2048);
 			if (rows_per_group <= 96.0) {
@@ -473,12 +594,12 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			const unsigned gw = (unsigned)(nwin / RB3_REB_WAVES + 1 < 8192 ? nwin / RB3_REB_WAVES + 1 : 8192);
 			if (n2 * RB3_WIN > 3 * ntot)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 7, true>), dim3(gw), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1));
+						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap);
 			else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 3, true>), dim3(gw), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1));
+						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap);
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_decide<true>), dim3(ngrp < 4096 ? (unsigned)ngrp : 4096u), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip,
-					(const uint32_t*)glist[1], (const uint32_t*)(nglist + 1));
+					(const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, (unsigned long long*)h->misc.p + MISC_RG_OVER);
 		} else {
 			const dim3 g1w((unsigned)((nwin + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), b1w(64 * RB3_REB_WAVES);
 			// the run-space short cut takes windows with up to 3 batch rows, or up to 7 where a window receives more than 3 on average
@@ -513,12 +634,12 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	}
 	if (winpar && runspace) {
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<true>), dim3(ngrp < 4096 ? (unsigned)ngrp : 4096u), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
-				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1));
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap);
 		hipLaunchKernelGGL(k_place, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, h->st, (const uint8_t*)gkind, (const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot,
-				(const uint4*)h->gslots.p, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, nwin, ntot, skip);
+				(const uint4*)h->gslots.p, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, nwin, ntot, skip, (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap);
 	} else if (winpar)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<false>), dim3((unsigned)ngrp), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
-				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, slot_cap);
 	else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
 				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, skip);
@@ -719,6 +840,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 	if (tent) tent_used(h, nsid); // (a full table poisons the records it could not serve: they count as unsettled)
 	h->stt.ms_chain += ev_ms(h->ev[6], h->ev[7]), h->stt.ms_rank += ev_ms(h->ev[6], h->ev[5]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
+	guard_check(h, __func__);
 	return 0;
 }
 
@@ -871,6 +993,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const int64_t ntot = h->n + len, nwin = (ntot >> RB3_WIN_BITS) + 1;
 	int tent = h->tn.tent;
 	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
+	garbage_collect(h, false); // (nothing of this merge is queued yet)
 	// no list but a count: one walker per string (n_walkers = number of strings), made on the device
 	const bool per_string = !walkers && n_walkers > 0;
 	if (d_tw && !walkers && !per_string) return RB3GPU_EINVAL;
@@ -1014,7 +1137,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[3], h->st));
 	if (lf_side) HIPCHK(hipStreamWaitEvent(h->st, h->evx[1], 0));
-	unsigned long long hm[32];
+	unsigned long long hm[40];
 	HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));
 	if (host_pos) HIPCHK(hipMemcpyAsync(host_pos, dpos, (size_t)len * 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st)); // the only synchronisation of the merge
@@ -1023,6 +1146,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	h->stt.ms_rank += ev_ms(h->ev[1], h->ev[2]);
 	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
+	guard_check(h, __func__);
 	h->stt.n_lf_steps += (int64_t)hm[1];
 	h->stt.n_lf_checked += (int64_t)hm[MISC_LF_CHK];
 #ifdef RB3_PROF
@@ -1114,13 +1238,34 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	}
 	h->stt.n_symbols_merged += len;
 	if (!rank_only) {
+		const bool ran_runspace = runspace_applies(h, len, ntot) && use_winpar(h, nwin);
 		acc[0] = 0;
 		for (int a = 0; a < 6; ++a) acc[a + 1] = acc[a] + (int64_t)hm[MISC_IX_TOT + a];
 		nslots = (int64_t)hm[MISC_IX_TOT + 6];
-		if (runspace_applies(h, len, ntot) && use_winpar(h, nwin)) // the run-space rebuild ran: how many groups it handed to the window kernels
+		if ((ran_runspace && hm[MISC_RG_OVER] != 0) || (uint64_t)nslots > h->reb_slot_cap) {
+			// the scratch of the window kernels or the slot array, both sized by estimates, did not take this rebuild: nothing was
+			// emitted.  Once more with full sizes (pos[] and the rows per window are still on the device).
+			if (h->opt.verbose >= 3) fprintf(stderr, "[M::%s] rebuild emitted again: %llu groups handed on, %lld slots vs a capacity of %llu\n", __func__,
+					hm[MISC_RG_LISTS] >> 32, (long long)nslots, (unsigned long long)h->reb_slot_cap);
+			HIPCHK(hipEventRecord(h->ev[4], h->st));
+			if ((r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, false, &ngrp, &nslots, acc, true, true)) < 0) return r;
+			HIPCHK(hipEventRecord(h->ev[5], h->st));
+			HIPCHK(hipMemcpyAsync(hm + MISC_RG_LISTS, misc + MISC_RG_LISTS, 8, hipMemcpyDeviceToHost, h->st));
+			HIPCHK(hipStreamSynchronize(h->st));
+			h->stt.ms_build += ev_ms(h->ev[4], h->ev[5]);
+			h->stt.n_reb_again += 1;
+		}
+		if (ran_runspace) // the run-space rebuild ran: how many groups it handed to the window kernels
 			h->stt.n_reb_groups += ngrp, h->stt.n_reb_groups_window += (int64_t)(hm[MISC_RG_LISTS] >> 32);
-		for (int a = 0; a <= 6; ++a) if (acc[a] != h->acc[a] + acc2[a]) return RB3GPU_EINTERNAL;
-		if (nslots > nwin) return RB3GPU_EINTERNAL;
+		for (int a = 0; a <= 6; ++a)
+			if (acc[a] != h->acc[a] + acc2[a]) {
+				if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] the rebuilt index counts %lld symbols below %d, expected %lld\n", (long long)acc[a], a, (long long)(h->acc[a] + acc2[a]));
+				return RB3GPU_EINTERNAL;
+			}
+		if (nslots > nwin) {
+			if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] the rebuilt index has %lld slots for %lld windows\n", (long long)nslots, (long long)nwin);
+			return RB3GPU_EINTERNAL;
+		}
 		// algorithmic bytes of this rebuild: 9 B per batch row + the old block array read + the new one written
 		h->stt.bytes_rebuild += 9 * len + h->stt.bytes_index + ngrp * (int64_t)sizeof(rb3_grp_t) + nslots * (int64_t)sizeof(rb3_slot_t);
 		if (commit) index_install(h, ngrp, nslots, ntot, acc);

@@ -117,6 +117,25 @@ __device__ __forceinline__ void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* the value of the lane above (lane 63 gets 0): DPP wave_shl:1 */
+__device__ __forceinline__ uint32_t wave_down1(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+/* inclusive prefix maximum over the 64 lanes (unsigned values; same DPP ladder as wave_incl_scan) */
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{
+	uint32_t t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = v > t ? v : t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = v > t ? v : t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = v > t ? v : t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = v > t ? v : t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;
+	t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;
+	return v;
+}
+
 /* ----------------------------------------------------------------------------------------- */
 /* rank: #{i < k : B[i] = c} + C[c], eight lanes per query                                     */
 /* ----------------------------------------------------------------------------------------- */
@@ -1800,7 +1819,7 @@ __global__ void __launch_bounds__(256) k_win_rows(const int64_t *pos, int64_t n2
 
 template<int MR>
 __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot, int64_t w, int64_t j,
-		int lane, uint32_t *sh /* >= 160 words of LDS of this wave */, uint4 *wstat, uint16_t *wruns)
+		int lane, uint32_t *sh /* >= 160 words of LDS of this wave */, uint4 *wstat, uint16_t *wruns, int64_t ws /* the window's place in the scratch arrays */)
 {
 	const int64_t p0 = w << RB3_WIN_BITS;
 	if (ntot - p0 < RB3_WIN) return false; // the last window
@@ -1898,7 +1917,7 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 	if (nh >= nitems) npos = RB3_WIN;
 	if (head) {
 		const uint32_t rl = npos - mypos;
-		wruns[w * RB3_RLE_CODES + __popcll(H & ((1ull << lane) - 1ull))] = (uint16_t)((rl - 1u) << 3 | msym);
+		wruns[ws * RB3_RLE_CODES + __popcll(H & ((1ull << lane) - 1ull))] = (uint16_t)((rl - 1u) << 3 | msym);
 		atomicAdd(&sh[128 + msym], rl);
 	}
 	wave_sync();
@@ -1907,7 +1926,7 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 		uint4 v;
 		v.x = sh[128] | sh[129] << 16, v.y = sh[130] | sh[131] << 16, v.z = sh[132] | sh[133] << 16;
 		v.w = (uint32_t)nruns | RB3_WSTAT_NOPLANES | first << 16 | last << 24;
-		wstat[w] = v;
+		wstat[ws] = v;
 	}
 	wave_sync();
 	return true;
@@ -1916,14 +1935,17 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 /* per window: symbols -> statistics (wstat: 6 x u16 counts, first, last, u16 runs = 16 B) and the
  * three bit planes (wplane: 24 dwords, the payload of a bit-plane slot) */
 /* LISTED: only the windows of the groups glist[0 .. *nglist) (the groups the run-space rebuild k_reb_group left over),
- * with a grid-stride loop: the length of the list is only known on the device */
+ * with a grid-stride loop: the length of the list is only known on the device.  The scratch arrays (wstat, wplane, wruns)
+ * are then indexed by the place in the list, 32 windows per entry, and hold lcap entries: a longer list raises *lover and
+ * nothing is written (the host redoes the rebuild with full-size scratch). */
 template<bool FROM_PLAIN, int MR = 3, bool LISTED = false>
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
 		const int64_t *jw, uint4 *wstat, uint32_t *wplane, uint16_t *wruns, int64_t nwin, const unsigned long long *skip,
-		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr)
+		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr, uint32_t lcap = 0)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t symbuf_[RB3_REB_WAVES][RB3_WIN];
 	if (RB3_REB_SKIP(skip)) return;
+	if (LISTED && *nglist > lcap) return;
 	__shared__ uint64_t ball_[RB3_REB_WAVES][12];
 	__shared__ uint32_t fast_[RB3_REB_WAVES][160];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1932,10 +1954,11 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 	const int64_t nunits = LISTED ? (int64_t)*nglist * RB3_GRP_WINS : nwin;
 	for (int64_t v = (int64_t)blockIdx.x * RB3_REB_WAVES + wave; v < nunits; v += LISTED ? (int64_t)gridDim.x * RB3_REB_WAVES : nunits) {
 	const int64_t w = LISTED ? (int64_t)glist[v >> 5] * RB3_GRP_WINS + (v & (RB3_GRP_WINS - 1)) : v;
+	const int64_t ws = v; // == w unless LISTED
 	if (w >= nwin) continue;
 	const int64_t p0 = w << RB3_WIN_BITS;
 	int64_t j = FROM_PLAIN ? 0 : jw[w];
-	if (!FROM_PLAIN && old.dense == 0 && window_runs_fast<MR>(old, pos, b2, n2, ntot, w, j, lane, fast_[wave], wstat, wruns)) continue;
+	if (!FROM_PLAIN && old.dense == 0 && window_runs_fast<MR>(old, pos, b2, n2, ntot, w, j, lane, fast_[wave], wstat, wruns, ws)) continue;
 	uint32_t sym[4];
 	gen_window<FROM_PLAIN>(old, pos, b2, n2, ntot, p0, j, symbuf, sym, lane);
 	uint64_t H[4];
@@ -1962,12 +1985,12 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 		last = __shfl(v, ll);
 	}
 	wave_sync();
-	if (lane < 24) wplane[w * 24 + lane] = ((const uint32_t*)ball)[lane];
+	if (lane < 24) wplane[ws * 24 + lane] = ((const uint32_t*)ball)[lane];
 	if (lane == 0) {
 		uint4 v;
 		v.x = cnt[0] | cnt[1] << 16, v.y = cnt[2] | cnt[3] << 16, v.z = cnt[4] | cnt[5] << 16;
 		v.w = nruns | first << 16 | last << 24;
-		wstat[w] = v;
+		wstat[ws] = v;
 	}
 	// the first 48 runs as codes (len-1) << 3 | sym: what a run slot is assembled from (a window with more
 	// runs can only become a bit-plane slot)
@@ -1985,7 +2008,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 						if (H[v]) { nxt = 64 * v + (__ffsll((unsigned long long)H[v]) - 1); break; }
 				}
 				const int len = nxt - (64 * u + lane);
-				wruns[w * RB3_RLE_CODES + r] = (uint16_t)((uint32_t)(len - 1) << 3 | sym[u]);
+				wruns[ws * RB3_RLE_CODES + r] = (uint16_t)((uint32_t)(len - 1) << 3 | sym[u]);
 			}
 		}
 		hb += __popcll(H[u]);
@@ -1998,9 +2021,13 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
  * <= 48 runs) and the group's symbol counts; same output as k_pass1 */
 template<bool LISTED = false>
 __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot, uint32_t *gstat, int64_t ngrp, const unsigned long long *skip,
-		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr)
+		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr, uint32_t lcap = 0, unsigned long long *lover = nullptr)
 {
 	if (RB3_REB_SKIP(skip)) return;
+	if (LISTED && *nglist > lcap) { // the list does not fit the scratch arrays: tell the host (the slot counts of these groups stay undefined)
+		if (blockIdx.x == 0 && threadIdx.x == 0) *lover = 1;
+		return;
+	}
 	const int lane = threadIdx.x;
 	const int64_t nunits = LISTED ? (int64_t)*nglist : ngrp;
 	for (int64_t gu = blockIdx.x; gu < nunits; gu += LISTED ? (int64_t)gridDim.x : nunits) {
@@ -2008,7 +2035,7 @@ __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot,
 	const int64_t W = (ntot >> RB3_WIN_BITS) + 1;
 	const int nvw = (int)(W - g * RB3_GRP_WINS < RB3_GRP_WINS ? W - g * RB3_GRP_WINS : RB3_GRP_WINS);
 	uint4 st = make_uint4(0, 0, 0, 7u << 16 | 7u << 24);
-	if (lane < nvw) st = wstat[g * RB3_GRP_WINS + lane];
+	if (lane < nvw) st = wstat[gu * RB3_GRP_WINS + lane]; // (gu == g unless LISTED)
 	const int my_nruns = (int)(st.w & 0x7FFFu); // (bit 15: RB3_WSTAT_NOPLANES)
 	const uint32_t my_first = st.w >> 16 & 0xFFu, my_last = st.w >> 24;
 	uint32_t cnt[6] = { st.x & 0xFFFFu, st.x >> 16, st.y & 0xFFFFu, st.y >> 16, st.z & 0xFFFFu, st.z >> 16 };
@@ -2045,9 +2072,11 @@ __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot,
 template<bool LISTED = false>
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wstat, const uint32_t *wplane, const uint16_t *wruns, int64_t ntot, const uint32_t *gstat,
 		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin, const unsigned long long *skip,
-		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr)
+		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr, uint32_t lcap = 0, uint64_t slot_cap = ~0ull)
 {
 	if (RB3_REB_SKIP(skip)) return;
+	if (LISTED && *nglist > lcap) return;
+	if (tot[6] > slot_cap) return; // the slot array was sized by an estimate: the host looks at the total and emits again
 #ifdef RB3_ABL
 	if (LISTED) return;
 #endif
@@ -2078,12 +2107,13 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 	for (int lw = wave * (RB3_GRP_WINS / RB3_REB_WAVES); lw < (wave + 1) * (RB3_GRP_WINS / RB3_REB_WAVES) && lw < nvw; ++lw) {
 		if (!(mask >> lw & 1u)) continue; // not the first window of a slot
 		const int64_t w = g * RB3_GRP_WINS + lw;
+		const int64_t ws = gu * RB3_GRP_WINS + lw; // the window in the scratch arrays (== w unless LISTED)
 		const int64_t sidx = (int64_t)slot0 + __popc(mask & ((2u << lw) - 1u)) - 1;
 		const uint32_t above = lw == 31 ? 0u : mask >> (lw + 1);
 		const int slot_sz = (above ? lw + 1 + (__ffs(above) - 1) : nvw) - lw;
 		// symbol counts of the group's windows before this slot
 		uint4 st = make_uint4(0, 0, 0, 0);
-		if (lane < lw) st = wstat[g * RB3_GRP_WINS + lane];
+		if (lane < lw) st = wstat[gu * RB3_GRP_WINS + lane];
 		uint64_t s0 = (uint64_t)(st.x & 0xFFFFu) | (uint64_t)(st.x >> 16) << 20 | (uint64_t)(st.y & 0xFFFFu) << 40;
 		uint64_t s1 = (uint64_t)(st.y >> 16) | (uint64_t)(st.z & 0xFFFFu) << 20 | (uint64_t)(st.z >> 16) << 40;
 		for (int d = 16; d >= 1; d >>= 1) s0 += __shfl_xor(s0, d), s1 += __shfl_xor(s1, d);
@@ -2096,10 +2126,10 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 			lane == 6 ? rel[5] : nsym;
 		hq += abs_base;
 		if (slot_sz == 1) { // bit-plane slot: header + the cached planes
-			const uint32_t wflags = wstat[w].w;
+			const uint32_t wflags = wstat[ws].w;
 			if (wflags & RB3_WSTAT_NOPLANES) { // k_pass1w took the run-space short cut: make the planes from the run list (<= 48 runs)
 				uint32_t len = 0, sy = 7;
-				if (lane < (int)(wflags & 0x7FFFu)) { const uint32_t c = wruns[w * RB3_RLE_CODES + lane]; sy = c & 7u, len = (c >> 3) + 1u; }
+				if (lane < (int)(wflags & 0x7FFFu)) { const uint32_t c = wruns[ws * RB3_RLE_CODES + lane]; sy = c & 7u, len = (c >> 3) + 1u; }
 				uint32_t inc = len;
 				inc = wave_incl_scan((uint32_t)inc);
 				uint16_t *rst = (uint16_t*)code16; // 48 run starts
@@ -2134,7 +2164,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 				continue;
 			}
 			if (lane < 8) {
-				const uint32_t *pl = wplane + w * 24;
+				const uint32_t *pl = wplane + ws * 24;
 				uint4 v;
 				v.x = hq;
 				v.y = pl[(lane >> 1) * 6 + 0 + (lane & 1)];
@@ -2147,7 +2177,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		// run slot.  Lane k < slot_sz looks at window k: it contributes its runs minus the first one if that
 		// continues the last run of the window before (same test as k_decide).
 		uint4 sw = make_uint4(0, 0, 0, 7u << 16 | 7u << 24);
-		if (lane < slot_sz) sw = wstat[w + lane];
+		if (lane < slot_sz) sw = wstat[ws + lane];
 		const uint32_t nr = sw.w & 0x7FFFu, wfirst = sw.w >> 16 & 0xFFu, wlast = sw.w >> 24;
 		const uint32_t prev_last = wave_up1(wlast);
 		const uint32_t bm = (lane > 0 && lane < slot_sz && nr > 0 && prev_last == wfirst) ? 1u : 0u;
@@ -2166,11 +2196,11 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 				for (int d = 16; d >= 1; d >>= 1)
 					if (k + d < slot_sz && sP[k + d] <= (uint32_t)lane) k += d;
 				const uint32_t r = (uint32_t)lane - sP[k] + sB[k];
-				const uint32_t c0 = wruns[(w + k) * RB3_RLE_CODES + r];
+				const uint32_t c0 = wruns[(ws + k) * RB3_RLE_CODES + r];
 				uint32_t len = (c0 >> 3) + 1u;
 				if (r == sNr[k] - 1u) // the window's last run may go on through the following windows
 					for (int kk = k + 1; kk < slot_sz && sB[kk]; ++kk) {
-						len += ((uint32_t)wruns[(w + kk) * RB3_RLE_CODES] >> 3) + 1u;
+						len += ((uint32_t)wruns[(ws + kk) * RB3_RLE_CODES] >> 3) + 1u;
 						if (sNr[kk] > 1u) break;
 					}
 				code = (len - 1u) << 3 | (c0 & 7u);
@@ -2198,7 +2228,9 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
  * rope_insert_run, fm-index.c:237-249, rope.c:114-148), slot partition, run codes, header counts -- can be done on those
  * items without ever expanding a symbol.  One wave per group:
  *
- *   rows     r = 0..nb-1: batch rows j0+r with new offset q_r = pos - P0 and old offset k_r = q_r - r (non-decreasing)
+ *   rows     the nb batch rows j0.. of the group as ROW RUNS r (consecutive rows with one symbol at one insertion point: the copies
+ *            of a context that several relatives of one batch bring): old offset k_r (non-decreasing), first row, length;
+ *            new offset q_r = k_r + rows before it
  *   runs     i = 0..nR-1: the old runs that intersect the group's old range [A0, A0 + 8192 - nb), clipped, start S_i
  *   items    sorted by new offset; three kinds, and each knows its own index without a search through the other list:
  *            B_r (batch row r)           offset q_r,       index r + lb_r + C(r),  lb_r = #{i : S_i < k_r}: rank in a bitmap
@@ -2231,20 +2263,21 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 /* cycles per phase of reb_group_one, summed over groups (lane 0 of every wave): a kernel experiment, not in the release build */
 __device__ unsigned long long g_reb_prof[16];
 #define RB3_REB_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_reb_prof[i], t_ - tprof); tprof = t_; } while (0)
+__device__ unsigned long long g_reb_why[8]; /* why groups were handed on: 0 rows, 1 slots of the old range, 2 bit-plane slot, 3 old runs, 4 row runs, 5 new slots, 6 last group */
+#define RB3_REB_WHY(i) do { if (lane == 0) atomicAdd(&g_reb_why[i], 1ull); } while (0)
 #else
 #define RB3_REB_T(i) do {} while (0)
+#define RB3_REB_WHY(i) do {} while (0)
 #endif
 
 template<int RMAX, int NBMAX>
 struct RebLds {
 	__attribute__((aligned(16))) uint32_t bits[260]; // bit s set <=> an old run starts at old-range offset s
 	uint32_t it[RMAX + 2 * NBMAX + 2]; // items, then (in place) heads: offset << 3 | sym
-	uint32_t PHC[RMAX + 2];        // histogram by lb_r: rows (low half), C items (high half)
+	uint32_t PHC[RMAX + 2];        // histogram of the batch rows by lb_r, three packed fields: rows (bits 0-13), rows that became items (14-22), C items (23-31)
 	uint16_t cum[260];             // set bits before word w of bits[]
 	uint16_t S[RMAX + 2];          // old run starts (old-range offsets)
-	uint16_t K[NBMAX + 2];         // k_r, K[nb] = 0xFFFF
 	uint8_t Ssym[RMAX + 2];
-	uint8_t Ksym[NBMAX + 2];
 	uint32_t stage[RB3_RG_MAXSLOTS * 24]; // payload of the group's slots: 48 run codes, or the 24 plane words
 	uint32_t scnt[RB3_RG_MAXSLOTS * 8];   // symbol counts per slot
 	uint32_t wh[34];               // heads per window
@@ -2274,9 +2307,9 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 #ifdef RB3_PROF_REB
 	unsigned long long tprof = __builtin_readcyclecounter();
 #endif
-	if (ntot - P0 < RB3_GRP) return false; // the last (partial) group goes through the window kernels
+	if (ntot - P0 < RB3_GRP) { RB3_REB_WHY(6); return false; } // the last (partial) group goes through the window kernels
 	const int64_t nb64 = j1 - j0;
-	if (nb64 < 0 || nb64 > NBMAX) return false;
+	if (nb64 < 0 || nb64 > RB3_GRP - 64) { RB3_REB_WHY(0); return false; } // (a group that is nearly all new rows: the window kernels)
 	const int nb = (int)nb64, nold = RB3_GRP - nb;
 	const int64_t A0 = P0 - j0, A1 = A0 + nold;
 	if (A0 < 0 || A1 > old.n) return false; // (only with an invalid pos[])
@@ -2284,8 +2317,8 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 #if defined(RB3_ABL) && RB3_ABL == 1
 	return true;
 #endif
-	// the batch rows of the group, requested now (registers), used after the old runs
-	constexpr int NCH = (NBMAX + 63) / 64;
+	// the first batch rows of the group, requested now (registers), used after the old runs; the rest in a loop behind them
+	constexpr int NCH = 2;
 	int64_t rpos[NCH];
 	uint8_t rsym[NCH];
 #pragma unroll
@@ -2315,7 +2348,7 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 		const int64_t la = (int64_t)((uint32_t)smb + __popc((uint32_t)(smb >> 32) & ((2u << wb) - 1u)) - 1u);
 		const int64_t slot0b = (int64_t)(uint32_t)smb;
 		const int ns = (int)(la - fa + 1);
-		if (ns <= 0 || ns * RB3_RLE_CODES > RMAX) return false;
+		if (ns <= 0 || ns * RB3_RLE_CODES > RMAX) { RB3_REB_WHY(1); return false; }
 		const int j = lane & 7;
 		constexpr int NPASS = (RMAX / RB3_RLE_CODES + 7) / 8;
 		uint4 slv[NPASS];
@@ -2332,7 +2365,7 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 			const bool valid = q < ns;
 			const uint4 sl = slv[p];
 			const uint32_t hdr0 = oct_bcast0(sl.x, j);
-			if (__any(valid && !(hdr0 & RB3_SLOT_RLE))) return false; // a bit-plane slot: this group is rebuilt from symbols
+			if (__any(valid && !(hdr0 & RB3_SLOT_RLE))) { RB3_REB_WHY(2); return false; } // a bit-plane slot: this group is rebuilt from symbols
 			const int64_t sgrp = (gb != ga && fa + q >= slot0b) ? gb : ga;
 			const uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
 			uint32_t len[6], tot = 0;
@@ -2362,20 +2395,10 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 				}
 			nR += (int)wave_read(inc, 63);
 		}
-		if (nR <= 0 || nR > RMAX) return false;
+		if (nR <= 0 || nR > RMAX) { RB3_REB_WHY(3); return false; }
 	}
 	RB3_REB_T(1);
 	// ---- the batch rows ----
-#pragma unroll
-	for (int c = 0; c < NCH; ++c) {
-		const int r = c * 64 + lane;
-		if (r < nb) {
-			const int64_t k = rpos[c] - P0 - r;
-			L.K[r] = (uint16_t)(k < 0 ? 0 : k > nold ? nold : k); // (clamped: only an invalid pos[] is outside)
-			L.Ksym[r] = rsym[c];
-		}
-	}
-	if (lane == 0) L.K[nb] = 0xFFFFu;
 	for (int c = 0; c * 64 <= nR; ++c)
 		if (c * 64 + lane <= nR) L.PHC[c * 64 + lane] = 0u;
 	wave_sync();
@@ -2393,23 +2416,51 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 #if defined(RB3_ABL) && RB3_ABL == 2
 	return true;
 #endif
-	int nC = 0;
-	for (int c = 0; c * 64 < nb; ++c) {
-		const int r = c * 64 + lane;
-		const bool valid = r < nb;
-		const uint32_t k = valid ? L.K[r] : 0u, kn = valid ? L.K[r + 1] : 0u;
-		const uint32_t bwd = L.bits[k >> 5];
-		const int lb = (int)L.cum[k >> 5] + __popc(bwd & ((1u << (k & 31)) - 1u)); // run starts before k
-		const bool exact = (bwd >> (k & 31)) & 1u;                                   // a run starts at k itself
-		const bool cf = valid && kn != k && (int)k < nold && lb >= 1 && !exact;
-		const uint64_t bal = __ballot(cf);
-		if (valid) {
-			const int idx = r + lb + nC + __popcll(bal & ((1ull << lane) - 1ull));
-			L.it[idx] = (k + (uint32_t)r) << 3 | (uint32_t)L.Ksym[r];
-			if (cf) L.it[idx + 1] = (k + (uint32_t)r + 1u) << 3 | (uint32_t)L.Ssym[lb - 1];
-			atomicAdd(&L.PHC[lb], cf ? 0x10001u : 1u);
+	// A row that falls strictly inside an old run of its own symbol changes nothing but the length of that run: it is ABSORBED
+	// (no item; it still counts for the offsets of everything behind it).  Only a row whose symbol differs from the run it
+	// splits, or that sits between two runs, becomes an item -- and so does every later row at the same insertion point, and
+	// the run resumes behind the last of them.  In an index of relatives nearly every row is absorbed, whatever the batch
+	// size: the work of a group is its old runs plus the variants.  The rows are streamed (64 per pass), nothing is stored.
+	int nB = 0, nC = 0;
+	{
+		uint32_t cbad = 0, cF = 0, pk = 0xFFFFFFFFu; // rows-with-an-item so far / that count at the start of the current insertion point / k of the row before
+		for (int c = 0; c * 64 < nb; ++c) {
+			const int r = c * 64 + lane;
+			const bool valid = r < nb;
+			int64_t pp = 0;
+			uint32_t sy = 0;
+			if (c < NCH) { pp = c == 0 ? rpos[0] : rpos[NCH - 1]; sy = c == 0 ? rsym[0] : rsym[NCH - 1]; }
+			else if (valid) pp = pos[j0 + r], sy = b2[j0 + r];
+			const int64_t pfirst_next = (c + 1) * 64 < nb ? pos[j0 + (c + 1) * 64] : 0; // (one address for the wave)
+			const int64_t k64 = pp - P0 - r;
+			const uint32_t k = valid ? (uint32_t)(k64 < 0 ? 0 : k64 > nold ? nold : k64) : 0xFFFFFFFEu; // (clamped: only an invalid pos[] is outside)
+			uint32_t kprev = wave_up1(k), kn = wave_down1(k);
+			if (lane == 0) kprev = pk;
+			if (lane == 63) kn = (c + 1) * 64 < nb ? (uint32_t)(pfirst_next - P0 - (c + 1) * 64) : 0xFFFFFFFEu;
+			const bool khead = valid && k != kprev, kend = valid && kn != k;
+			const uint32_t kk = valid ? k : 0u;
+			const uint32_t bwd = L.bits[kk >> 5];
+			const int lb = (int)L.cum[kk >> 5] + __popc(bwd & ((1u << (kk & 31)) - 1u)); // run starts before k
+			const bool inside = valid && !((bwd >> (kk & 31)) & 1u) && lb >= 1 && (int)kk < nold; // strictly inside old run lb - 1
+			const uint32_t ci = inside ? (uint32_t)L.Ssym[lb - 1] : 0xFFu;
+			const uint32_t bad = valid && sy != ci ? 1u : 0u;
+			const uint32_t bincl = wave_incl_scan(bad) + cbad, bexcl = bincl - bad;
+			uint32_t F = wave_incl_max(khead ? bexcl : 0u);
+			F = F > cF ? F : cF;
+			const bool item = valid && bincl > F;          // a differing row at this insertion point, at or before this one
+			const bool cf = kend && inside && item;        // ... and the old run goes on behind the last of them
+			const uint64_t balB = __ballot(item), balC = __ballot(cf);
+			const uint64_t lt = (1ull << lane) - 1ull;
+			if (item) {
+				const int idx = nB + __popcll(balB & lt) + lb + nC + __popcll(balC & lt);
+				L.it[idx] = (kk + (uint32_t)r) << 3 | sy;
+				if (cf) L.it[idx + 1] = (kk + (uint32_t)r + 1u) << 3 | ci;
+			}
+			if (valid) atomicAdd(&L.PHC[lb], 1u | (item ? 1u << 14 : 0u) | (cf ? 1u << 23 : 0u));
+			nB += __popcll(balB), nC += __popcll(balC);
+			if (nB > NBMAX) { RB3_REB_WHY(4); return false; } // too many rows that differ for this tier
+			cbad = wave_read(bincl, 63), cF = wave_read(F, 63), pk = wave_read(k, 63);
 		}
-		nC += __popcll(bal);
 	}
 	wave_sync();
 	RB3_REB_T(3);
@@ -2418,15 +2469,15 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 		for (int c = 0; c * 64 < nR; ++c) {
 			const int i = c * 64 + lane;
 			const uint32_t v = i < nR ? L.PHC[i] : 0u;
-			const uint32_t inc = wave_incl_scan(v) + carry; // both halves: rows / C items with lb <= i
+			const uint32_t inc = wave_incl_scan(v) + carry; // all three fields: rows / rows with an item / C items with lb <= i (no field overflows: <= 8192, 511, 511)
 			if (i < nR) {
-				const uint32_t ub = inc & 0xFFFFu;
-				L.it[i + (int)ub + (int)(inc >> 16)] = ((uint32_t)L.S[i] + ub) << 3 | (uint32_t)L.Ssym[i];
+				const uint32_t rows = inc & 0x3FFFu, runs = inc >> 14 & 0x1FFu, cs = inc >> 23;
+				L.it[i + (int)runs + (int)cs] = ((uint32_t)L.S[i] + rows) << 3 | (uint32_t)L.Ssym[i];
 			}
 			carry = wave_read(inc, 63);
 		}
 	}
-	const int nI = nR + nb + nC;
+	const int nI = nR + nB + nC;
 	wave_sync();
 	RB3_REB_T(4);
 	// ---- heads (maximal runs), compacted in place; heads per window ----
@@ -2476,7 +2527,7 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 	const bool sstart = lane < RB3_GRP_WINS && (lane & ((1 << level) - 1)) == 0;
 	const uint32_t mask = (uint32_t)__ballot(sstart);
 	const int nslots = __popc(mask);
-	if (nslots > RB3_RG_MAXSLOTS) return false;
+	if (nslots > RB3_RG_MAXSLOTS) { RB3_REB_WHY(5); return false; }
 	if (sstart) L.slotA[__popc(mask & ((1u << lane) - 1u))] = (uint32_t)lane;
 	if (lane == 0) L.slotA[nslots] = RB3_GRP_WINS;
 	wave_sync();
@@ -2626,9 +2677,11 @@ __global__ void __launch_bounds__(64 * RB3_RG_WAVES) k_reb_group(IdxView old, co
 /* the groups rebuilt in run space: directory entry + slots from the scratch to their final places (the groups of the
  * window kernels are written by k_pass2w).  Eight lanes per group. */
 __global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint32_t *gstat, const uint64_t *gpre, const uint64_t *tot, const uint4 *gslots,
-		rb3_grp_t *grp, uint4 *slot16, int64_t ngrp, int64_t nwin, int64_t ntot, const unsigned long long *skip)
+		rb3_grp_t *grp, uint4 *slot16, int64_t ngrp, int64_t nwin, int64_t ntot, const unsigned long long *skip,
+		const uint32_t *nglist, uint32_t lcap, uint64_t slot_cap)
 {
 	if (RB3_REB_SKIP(skip)) return;
+	if (*nglist > lcap || tot[6] > slot_cap) return; // see k_decide / k_pass2w: the host does the rebuild again
 #ifdef RB3_ABL
 	return; // (kernel ablation builds leave the group records undefined)
 #endif

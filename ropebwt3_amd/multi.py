@@ -324,7 +324,7 @@ def bench_main(args, rank, local_rank, world):
 
     out = None
     if args.mode == "interval":
-        n_index, reads_per_gpu = (1 << 26) * world, 100000
+        n_index, reads_per_gpu = (1 << 26) * world, (500000 if world > 1 else 100000)   # (large batches amortise the per-symbol collectives: config 4 has 46 M chains per batch)
         rng = np.random.default_rng(31)
         g = util.random_genome(rng, n_index // 2 - 1)
         t1 = util.make_text([g])

@@ -792,6 +792,41 @@ def test_run_space_rebuild_vs_oracle_and_window_rebuild(oracle, seed, nrel, L, p
         ha.close(), hb.close()
 
 
+@pytest.mark.parametrize("key,val", [("reb_lcap", 1), ("reb_slot_cap", 8)])
+def test_rebuild_buffers_sized_by_estimates_overflow(oracle, key, val):
+    """the single-sync merge sizes two buffers by estimates, because device memory is expensive to obtain and a growing index
+    obtains it again and again: the scratch of the window kernels behind the run-space rebuild (room for a fraction of the
+    groups) and the slot array (old slots + a margin).  When the device finds that either does not take the result, no
+    kernel emits anything and the host does the rebuild again with full sizes.  The test-hook library shrinks the two
+    capacities so that every merge goes that way; the result must still equal the oracle's merge (fm-index.c:237-249)."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(77)
+    g0 = util.random_genome(rng, 30000)
+    rel = [util.mutate(rng, g0, float(rng.choice([0.002, 0.01]))) for _ in range(16)]
+    h = Rb3Gpu(verbose=1, hooks=True)
+    h.tune("reb_force", 1)
+    h.tune(key, val)
+    try:
+        want = None
+        for g in rel:
+            t = util.make_text([g])
+            b = host.build_bwt(t.copy())
+            if want is None:
+                h.from_plain(b)
+                want = b
+                continue
+            want = oracle.merge(want, b)
+            d, dtw = h.sort_text(t)
+            h.merge_text_dev(d, dtw, t.size, host.walkers_text(t, 256), commit=True)
+            h.dev_free(d), h.dev_free(dtw)
+            assert np.array_equal(h.export_plain(), want)
+        st = h.stats()
+        assert st["n_reb_again"] >= 3, st
+        assert st["n_fallbacks"] == 0
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("world,kind", [(2, "reads"), (3, "reads"), (2, "family"), (4, "dups")])
 def test_interval_sharded_merge_real_engine(oracle, world, kind):
     """north_star multi-GPU split (ropebwt3_amd.multi.merge_interval) driven through the REAL engine: `world` ranks as

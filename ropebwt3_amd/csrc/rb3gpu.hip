@@ -55,6 +55,7 @@ struct Tune {
 	int resolve_v1 = 0;      // settle the tentative stretches with k_resolve (one hop per stretch) instead of k_cum / k_resolve_w / k_sfin
 	int reb_force = 0;       // the run-space rebuild whatever the row density and the old index look like (tests: the hand-over paths)
 	int octs = 8;            // octets per wave of k_chain
+	int lpw = 8;             // lanes per walker of k_chain in the single-sync merge: 8 (an octet) or 4 (a quad, 16 walkers per wave)
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
 	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
@@ -277,6 +278,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "reb_force")) t.reb_force = v != 0;
 	else if (!strcmp(key, "resolve_v1")) t.resolve_v1 = v != 0;
 	else if (!strcmp(key, "octs")) t.octs = v < 1 ? 1 : v > 8 ? 8 : (int)v;
+	else if (!strcmp(key, "lpw")) t.lpw = v == 4 ? 4 : 8;
 	else if (!strcmp(key, "blkmul")) t.blkmul = v < 1 ? 1 : (int)v;
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
@@ -309,7 +311,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -493,6 +495,17 @@ static bool use_winpar(const rb3gpu_t *h, int64_t nwin)
 	return (size_t)nwin * 216 <= ((size_t)8 << 30) && !h->tn.group_rebuild;
 }
 
+/* slots to make room for before a single-sync merge of n2 rows: one per window is the upper bound; where the index is
+ * run-coded (a fifth of that or less in a pangenome) the old count plus a margin stands in, and the rebuild is emitted again
+ * in the rare case that it does not fit (see build_index) */
+static int64_t slot_estimate(const rb3gpu_t *h, int64_t n2, int64_t ntot)
+{
+	const int64_t nwin = (ntot >> RB3_WIN_BITS) + 1;
+	if (!use_winpar(h, nwin) || h->nslots * 2 >= (h->n >> RB3_WIN_BITS) + 1) return nwin;
+	const int64_t est = h->nslots + h->nslots / 4 + n2 / 16 + 4096;
+	return est < nwin ? est : nwin;
+}
+
 extern "C++" {
 /* rows_done: jg[] (rows before every window) has been filled by k_pos_finalize_check_rows already */
 template<bool FROM_PLAIN>
@@ -554,11 +567,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		// the number of slots is only known after the scan: one per window is the upper bound; where the index is run-coded an
 		// estimate from the old count stands in (the emitting kernels compare the scan total with the capacity and leave the
 		// array alone if it does not fit; the caller then emits again after its sync)
-		int64_t est = nwin;
-		if (winpar && !FROM_PLAIN && !full && h->nslots * 2 < (h->n >> RB3_WIN_BITS) + 1) {
-			est = h->nslots + h->nslots / 4 + n2 / 16 + 4096;
-			if (est > nwin) est = nwin;
-		}
+		const int64_t est = (FROM_PLAIN || full) ? nwin : slot_estimate(h, n2, ntot);
 		if ((r = ib_ensure(h, dst, ngrp, est)) < 0) return r;
 	}
 	uint64_t slot_cap = nosync ? (uint64_t)h->ib[dst].slots_cap : ~0ull;
@@ -1026,7 +1035,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const uint32_t sid_limit = 0xFFFFFFFFu;
 #endif
 	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
-	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, nwin)) < 0) return r;
+	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, slot_estimate(h, len, ntot))) < 0) return r;
 	const bool rows_fused = !rank_only && use_winpar(h, nwin);
 	if (rows_fused && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
@@ -1077,7 +1086,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int64_t *dpos = (int64_t*)h->pos.p;
 	{
 		const IdxView iv = view_of(h);
-		const int octs = h->tn.octs;
+		const int lpw = h->tn.lpw;
+		const int octs = h->tn.octs * (8 / lpw); // groups of lpw lanes per wave
 		const int64_t n_expect = auto_list ? b2_nbk + 64 : n_walkers; // (a device-made list: capacity >> walkers; size the launch for the walkers)
 		int64_t nblk = (n_expect + 4 * octs - 1) / (4 * octs) * h->tn.blkmul;
 		// persistent waves: 2048 blocks x 4 waves fill the chip once (256 CUs x 32); more blocks only queue behind them (measured: 10 % slower at 4096)
@@ -1087,8 +1097,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #endif
 		const dim3 grid((unsigned)nblk), blk(256);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
-#define RB3_LAUNCH_FAST(D, T, X) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
+#define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk)
+#define RB3_LAUNCH_FAST(D, T, X) do { if (lpw == 4) RB3_LAUNCH_FAST1(D, T, X, 4); else RB3_LAUNCH_FAST1(D, T, X, 8); } while (0)
 		// text-order words: per-lane loads while the L1 can hold a line per walker (256 CUs x 32 waves x 8 octets), else 64-byte fetches
 		int text_mode = !d_tw ? 0 : n_walkers <= 65536 ? 1 : 2;
 #ifdef RB3GPU_TEST_HOOKS
@@ -1109,6 +1120,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		default: RB3_LAUNCH_FAST(false, true, 0); break;
 		}
 #undef RB3_LAUNCH_FAST
+#undef RB3_LAUNCH_FAST1
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
 			hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, (const uint32_t*)sidctr);

@@ -82,6 +82,31 @@ __device__ __forceinline__ uint32_t oct_exscan(uint32_t v, int j)
 	return inc - v;
 }
 
+/* the same three for a group of LPW lanes per query: an octet (8) or a QUAD (4 lanes, 16 queries per wave: k_chain's
+ * instruction stream is shared by twice as many walkers) */
+template<int LPW> __device__ __forceinline__ uint32_t grp_sum(uint32_t v)
+{
+	if (LPW == 8) return oct_sum(v);
+	v += dpp_mov<0xB1>(v); // quad_perm [1,0,3,2]
+	v += dpp_mov<0x4E>(v); // quad_perm [2,3,0,1]
+	return v;
+}
+
+template<int LPW> __device__ __forceinline__ uint32_t grp_bcast0(uint32_t v, int j)
+{
+	if (LPW == 8) return oct_bcast0(v, j);
+	return dpp_mov<0x00>(v); // quad_perm [0,0,0,0]
+}
+
+template<int LPW> __device__ __forceinline__ uint32_t grp_exscan(uint32_t v, int j)
+{
+	if (LPW == 8) return oct_exscan(v, j);
+	uint32_t inc = v, t;
+	t = dpp_mov<0x111>(inc); if (j >= 1) inc += t; // row_shr:1
+	t = dpp_mov<0x112>(inc); if (j >= 2) inc += t; // row_shr:2
+	return inc - v;
+}
+
 /* inclusive prefix sum over the 64 lanes of a wave with DPP adds (6 instructions, no LDS crossbar round trips; the
  * shuffle formulation costs ~45 instructions and six dependent ds_bpermute latencies) */
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
@@ -184,22 +209,25 @@ typedef unsigned short rb3_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ rb3_s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(rb3_s16x2, v); }
 __device__ __forceinline__ uint32_t as_u32(rb3_s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 
-template<bool TWO, bool MATCH>
-__device__ __forceinline__ void slice_count_pk(const uint4 &sl, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b, uint32_t *match_a)
+template<bool TWO, bool MATCH, int LPW = 8>
+__device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b, uint32_t *match_a)
 {
-	const uint32_t w[3] = { sl.y, sl.z, sl.w };
-	uint32_t lw[3];
+	// an octet lane holds slice j of the slot (6 codes), a quad lane slices 2j and 2j+1 (12 consecutive codes)
+	constexpr int NW = LPW == 4 ? 6 : 3;
+	const uint32_t w[6] = { sl.y, sl.z, sl.w, sl2.y, sl2.z, sl2.w };
+	uint32_t lw[NW];
 #pragma unroll
-	for (int k = 0; k < 3; ++k) lw[k] = ((w[k] >> 3) & 0x1FFF1FFFu) + 0x00010001u; // run lengths of the two codes (no carry: <= 8192)
-	const uint32_t sum2 = lw[0] + lw[1] + lw[2];                                      // per half <= 3 * 8192: no carry either
-	const uint32_t tot = (sum2 & 0xFFFFu) + (sum2 >> 16);
-	uint32_t base = oct_exscan(tot, j);
+	for (int k = 0; k < NW; ++k) lw[k] = ((w[k] >> 3) & 0x1FFF1FFFu) + 0x00010001u; // run lengths of the two codes (no carry: <= 8192)
+	uint32_t sum2 = lw[0] + lw[1] + lw[2];                                             // per half <= 3 * 8192: no carry either
+	uint32_t tot = (sum2 & 0xFFFFu) + (sum2 >> 16);
+	if (LPW == 4) { sum2 = lw[3] + lw[4] + lw[5]; tot += (sum2 & 0xFFFFu) + (sum2 >> 16); }
+	uint32_t base = grp_exscan<LPW>(tot, j);
 	const uint32_t csplat = (uint32_t)c * 0x00010001u;
 	const rb3_s16x2 oa = as_s16x2((uint32_t)off_a * 0x00010001u), ob = as_s16x2((uint32_t)off_b * 0x00010001u), zero = as_s16x2(0u);
 	rb3_s16x2 acc_a = zero, acc_b = zero;
 	uint32_t mt = 0;
 #pragma unroll
-	for (int k = 0; k < 3; ++k) {
+	for (int k = 0; k < NW; ++k) {
 		const rb3_s16x2 P = as_s16x2(base * 0x00010001u + (lw[k] << 16)); // start offsets: (base, base + len of the first code)
 		const rb3_s16x2 Lk = as_s16x2(lw[k]);
 		// 0xFFFF in the halves whose symbol is c: x in 0..7 per half, x + 0x7FFF has bit 15 set iff x != 0
@@ -228,20 +256,27 @@ __device__ __forceinline__ void slice_count_pk(const uint4 &sl, int off_a, int o
 /* number of symbols equal to c among the first `off` symbols of the slot, this lane's share;
  * bit 20 of the result is set in the one lane that holds the symbol AT offset `off` if that symbol is c */
 #define RB3_MATCH_BIT 0x100000u
-__device__ __forceinline__ uint32_t slice_count(const uint4 &sl, uint32_t hdr0, uint32_t off, int c, int j)
+/* bit planes of 32 symbols: #{i < t : sym_i == c} | RB3_MATCH_BIT if 0 <= t < 32 and the symbol at t is c */
+__device__ __forceinline__ uint32_t plane_count(const uint4 &sl, int t, int c)
+{
+	const uint32_t m0 = (c & 1) ? sl.y : ~sl.y, m1 = (c & 2) ? sl.z : ~sl.z, m2 = (c & 4) ? sl.w : ~sl.w;
+	const uint32_t m = m0 & m1 & m2;
+	const uint32_t at = (t >= 0 && t < 32) ? ((m >> t) & 1u) : 0u;
+	t = t < 0 ? 0 : t > 32 ? 32 : t;
+	const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
+	return __popc(m & lim) | (at ? RB3_MATCH_BIT : 0u);
+}
+
+template<int LPW = 8>
+__device__ __forceinline__ uint32_t slice_count(const uint4 &sl, const uint4 &sl2, uint32_t hdr0, uint32_t off, int c, int j)
 {
 	uint32_t cnt;
-	if (!(hdr0 & RB3_SLOT_RLE)) { // bit planes: symbols [32j, 32j+32)
-		int t = (int)off - 32 * j;
-		const uint32_t m0 = (c & 1) ? sl.y : ~sl.y, m1 = (c & 2) ? sl.z : ~sl.z, m2 = (c & 4) ? sl.w : ~sl.w;
-		const uint32_t m = m0 & m1 & m2;
-		const uint32_t at = (t >= 0 && t < 32) ? ((m >> t) & 1u) : 0u;
-		t = t < 0 ? 0 : t > 32 ? 32 : t;
-		const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
-		cnt = __popc(m & lim) | (at ? RB3_MATCH_BIT : 0u);
-	} else { // six run codes per lane, two at a time
+	if (!(hdr0 & RB3_SLOT_RLE)) { // bit planes: an octet lane has symbols [32j, 32j+32), a quad lane [64j, 64j+64)
+		if (LPW == 8) cnt = plane_count(sl, (int)off - 32 * j, c);
+		else cnt = plane_count(sl, (int)off - 64 * j, c) + plane_count(sl2, (int)off - 64 * j - 32, c); // (at most one of the two sets the match bit)
+	} else { // run codes, two at a time
 		uint32_t cb, mt;
-		slice_count_pk<false, true>(sl, (int)off, (int)off, c, j, &cnt, &cb, &mt);
+		slice_count_pk<false, true, LPW>(sl, sl2, (int)off, (int)off, c, j, &cnt, &cb, &mt);
 		if (mt) cnt |= RB3_MATCH_BIT;
 	}
 	return cnt;
@@ -251,7 +286,7 @@ __device__ __forceinline__ int64_t oct_rank_finish(const RankLoad &r, int c, int
 {
 	const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
 	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
-	uint32_t part = slice_count(r.sl, hdr0, off, c, j) & (RB3_MATCH_BIT - 1u);
+	uint32_t part = slice_count<8>(r.sl, r.sl, hdr0, off, c, j) & (RB3_MATCH_BIT - 1u);
 	if (abs_hdr) return (int64_t)oct_sum(j == c + 1 ? r.sl.x : 0u) + (int64_t)oct_sum(part); // hdr[c+1] is the whole LF base
 	if (j == c + 1) part += r.sl.x; // hdr[c+1] = count of c between group start and slot start
 	const uint32_t sum = oct_sum(part);
@@ -530,79 +565,92 @@ __device__ __forceinline__ void st_pos(int64_t *p, int64_t v)
 struct RankLoadC {
 	uint64_t gc;     // grp.cnt[c]
 	uint64_t sm;     // slot0 | mask << 32
-	uint4 sl;        // slice j of the slot
+	uint4 sl;        // slice j of the slot (quads: slice 2j)
+	uint4 sl2;       // quads: slice 2j + 1
 	uint32_t koff;   // k & 8191
 	uint32_t sidx;   // index of the slot (mixed indexes)
 };
 
-template<bool DENSE>
+template<int LPW>
+__device__ __forceinline__ void octc_load_slot(const IdxView &ix, int64_t s, int j, RankLoadC &r)
+{
+	if (LPW == 8) r.sl = ix.slot16[s * 8 + j];
+	else r.sl = ix.slot16[s * 8 + 2 * j], r.sl2 = ix.slot16[s * 8 + 2 * j + 1];
+}
+
+template<bool DENSE, int LPW = 8>
 __device__ __forceinline__ void octc_issue_grp(const IdxView &ix, int64_t k, int c, int j, RankLoadC &r)
 {
 	const int64_t g = k >> RB3_GRP_BITS;
 	r.koff = (uint32_t)k & (RB3_GRP - 1);
-	if (DENSE) r.sl = ix.slot16[(k >> RB3_WIN_BITS) * 8 + j]; // every window is its own slot and carries the LF base: no directory lookup
+	if (DENSE) octc_load_slot<LPW>(ix, k >> RB3_WIN_BITS, j, r); // every window is its own slot and carries the LF base: no directory lookup
 	else r.gc = ix.grp64[g * 8 + c], r.sm = ix.grp64[g * 8 + 6];
 }
 
-template<bool DENSE>
+template<bool DENSE, int LPW = 8>
 __device__ __forceinline__ void octc_issue_slot(const IdxView &ix, int j, RankLoadC &r)
 {
 	if (DENSE) return;
 	const uint32_t lw = r.koff >> RB3_WIN_BITS;
 	const uint32_t s = (uint32_t)r.sm + __popc((uint32_t)(r.sm >> 32) & ((2u << lw) - 1u)) - 1u;
 	r.sidx = s;
-	r.sl = ix.slot16[(int64_t)s * 8 + j];
+	octc_load_slot<LPW>(ix, (int64_t)s, j, r);
 }
 
 /* the upper bound of an interval whose lower bound is being fetched as `lo`: the two usually lie in the same slot
  * (an interval of <= 255 rows against slots of >= 512 symbols), and then there is nothing to fetch */
-template<bool DENSE>
+template<bool DENSE, int LPW = 8>
 __device__ __forceinline__ void octc_issue_slot_hi(const IdxView &ix, int j, RankLoadC &r, const RankLoadC &lo)
 {
 	if (DENSE) return;
 	const uint32_t lw = r.koff >> RB3_WIN_BITS;
 	const uint32_t s = (uint32_t)r.sm + __popc((uint32_t)(r.sm >> 32) & ((2u << lw) - 1u)) - 1u;
 	r.sidx = s;
-	if (s != lo.sidx) r.sl = ix.slot16[(int64_t)s * 8 + j];
-	else r.sl = lo.sl;
+	if (s != lo.sidx) octc_load_slot<LPW>(ix, (int64_t)s, j, r);
+	else { r.sl = lo.sl; if (LPW == 4) r.sl2 = lo.sl2; }
+}
+
+/* header word c + 1 of the slot (the count of c before the slot), in the lane that holds it: octet lane j has word j, quad lane j words 2j and 2j+1 */
+template<int LPW>
+__device__ __forceinline__ uint32_t octc_hdr_c(const RankLoadC &r, int c, int j)
+{
+	if (LPW == 8) return j == c + 1 ? r.sl.x : 0u;
+	return 2 * j == c + 1 ? r.sl.x : 2 * j + 1 == c + 1 ? r.sl2.x : 0u;
 }
 
 /* both ends of an interval that lies inside ONE run slot, from one decode */
+template<int LPW = 8>
 __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, const RankLoadC &rh, uint32_t hdr0, int c, int j, int64_t *lo_n, int64_t *hi_n)
 {
 	const int base = (int)(hdr0 & 0xFFFFu);
 	uint32_t ca, cb;
 	uint32_t mt;
-	slice_count_pk<true, false>(rl.sl, (int)rl.koff - base, (int)rh.koff - base, c, j, &ca, &cb, &mt);
+	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, (int)rl.koff - base, (int)rh.koff - base, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16; // both fit 16 bits (counts inside a group of 8192)
-	if (j == c + 1) v += rl.sl.x * 0x00010001u;
-	v = oct_sum(v);
+	v += octc_hdr_c<LPW>(rl, c, j) * 0x00010001u;
+	v = grp_sum<LPW>(v);
 	*lo_n = (int64_t)(rl.gc + (v & 0xFFFFu)), *hi_n = (int64_t)(rl.gc + (v >> 16));
 }
 
-/* LF(c, k) for the octet's query; *match = 1 iff the symbol at offset k itself is c (then the suffix
+/* LF(c, k) for the group's query; *match = 1 iff the symbol at offset k itself is c (then the suffix
  * at row k extends by c: used to advance an interval [k, k+1) with a single rank) */
-template<bool DENSE>
+template<bool DENSE, int LPW = 8>
 __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j, uint32_t *match)
 {
 	uint32_t part;
 	if (DENSE) { // bit planes, slot start = window start, absolute header (RB3_ABS_HEADERS)
-		int t = (int)(r.koff & (RB3_WIN - 1)) - 32 * j;
-		const uint32_t m0 = (c & 1) ? r.sl.y : ~r.sl.y, m1 = (c & 2) ? r.sl.z : ~r.sl.z, m2 = (c & 4) ? r.sl.w : ~r.sl.w;
-		const uint32_t m = m0 & m1 & m2;
-		const uint32_t at = (t >= 0 && t < 32) ? ((m >> t) & 1u) : 0u;
-		t = t < 0 ? 0 : t > 32 ? 32 : t;
-		const uint32_t lim = t >= 32 ? 0xFFFFFFFFu : ((1u << t) - 1u);
-		part = __popc(m & lim) | (at ? RB3_MATCH_BIT : 0u);
-		const uint32_t base = oct_sum(j == c + 1 ? r.sl.x : 0u), sum = oct_sum(part);
+		const int off = (int)(r.koff & (RB3_WIN - 1));
+		if (LPW == 8) part = plane_count(r.sl, off - 32 * j, c);
+		else part = plane_count(r.sl, off - 64 * j, c) + plane_count(r.sl2, off - 64 * j - 32, c);
+		const uint32_t base = grp_sum<LPW>(octc_hdr_c<LPW>(r, c, j)), sum = grp_sum<LPW>(part);
 		*match = sum >> 20;
 		return (int64_t)base + (int64_t)(sum & (RB3_MATCH_BIT - 1u));
 	} else {
-		const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
-		part = slice_count(r.sl, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
+		const uint32_t hdr0 = grp_bcast0<LPW>(r.sl.x, j);
+		part = slice_count<LPW>(r.sl, r.sl2, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
 	}
-	if (j == c + 1) part += r.sl.x;
-	const uint32_t sum = oct_sum(part);
+	part += octc_hdr_c<LPW>(r, c, j);
+	const uint32_t sum = grp_sum<LPW>(part);
 	*match = sum >> 20;
 	return (int64_t)(r.gc + (sum & (RB3_MATCH_BIT - 1u)));
 }
@@ -775,7 +823,9 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
  * unit the lines stay in the L1 for the 16 steps they serve).  TEXT = 2: the octet fetches the words of 8 steps with
  * one 64-byte request and hands them out with cross-lane reads (many walkers per compute unit, i.e. one per short
  * string: the L1 cannot hold a line per walker). */
-template<bool LIST, bool DENSE, bool TENT, int TEXT>
+/* LPW: lanes per walker, 8 (an octet) or 4 (a quad: every lane takes two slices of a slot, and the wave's instruction
+ * stream -- what a step costs where the index is run-coded -- serves 16 walkers instead of 8) */
+template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
 		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr)
@@ -785,10 +835,11 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	// ids a walker may take from each half of the stretch table (the whole half unless a test narrows it)
 	const uint32_t lim_blocks = sid_limit < (uint32_t)RB3_TENT_HALF ? sid_limit : (uint32_t)RB3_TENT_HALF;
 	const uint32_t lim_singles = sid_limit < (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF) ? sid_limit : (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF);
-	const int lane = threadIdx.x & 63, j = lane & 7;
+	static_assert(LPW == 8 || LPW == 4, "an octet or a quad per walker");
+	const int lane = threadIdx.x & 63, j = lane & (LPW - 1);
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
 	// it hosts: the host may enable only the first `octs` octets of each wave and launch more waves.
-	if ((lane >> 3) >= octs) return;
+	if (lane / LPW >= octs) return; // (octs counts groups of LPW lanes)
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
 	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
 	// records must become visible to other walkers only if strings are split (logM < 0 with a list: one walker per string)
@@ -821,7 +872,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				unsigned long long w = atomicAdd(qhead, 1ull);
 				w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
 			}
-			w0 = oct_bcast0(w0, j), w1 = oct_bcast0(w1, j);
+			w0 = grp_bcast0<LPW>(w0, j), w1 = grp_bcast0<LPW>(w1, j);
 			const int64_t wid = (int64_t)((uint64_t)w1 << 32 | w0);
 			if (wid >= nwalk) {
 				if (bkb >= 0) rec_pos<TENT && !LIST>(&row[bkb], bval, vis);
@@ -848,7 +899,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			if (TEXT) {
 				x = tw[tp], x1 = tw[tp > 0 ? tp - 1 : 0];
 				if (TEXT == 2) { // the rest of the current window: this walker's first step runs at phase (it + 1) & 7
-					const int64_t a = tp - 2 - (int64_t)((j - (int)(it + 1)) & 7);
+					const int64_t a = tp - 2 - (int64_t)((j - (int)(it + 1)) & (LPW - 1));
 					blk8 = tw[a > 0 ? a : 0];
 				}
 				kb = (int64_t)(x >> 3);
@@ -867,7 +918,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 		// for the second bound of wide walkers and the rare stretch events: a lone wave runs at
 		// instruction-issue speed, so instruction count is the cost.
 		do {
-			if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
+			if ((++it & (uint32_t)(LPW - 1)) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
 			const bool met = TEXT ? (int64_t)rc >= 0 : (int64_t)x >= 0;  // this row already carries a record
 			const int c = (int)(x & 7u);
 			const int64_t kbn = TEXT ? (int64_t)(x1 >> 3) : met ? kb : RB3_ROW_NEXT(x);
@@ -876,12 +927,12 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			// may this walker record tentatively?  (an interval of at most KMAX rows, and old enough)
 			const bool tentok = TENT && gap != 0 && age >= (LIST ? RB3_TENT_MIN_AGE : RB3_TENT_MIN_AGE_AUTO) && hi - lo <= RB3_TENT_KMAX && sid != -2;
 			RankLoadC rl, rh;
-			octc_issue_grp<DENSE>(b1, lo, c, j, rl);
-			if (wide) octc_issue_grp<DENSE>(b1, hi, c, j, rh);
+			octc_issue_grp<DENSE, LPW>(b1, lo, c, j, rl);
+			if (wide) octc_issue_grp<DENSE, LPW>(b1, hi, c, j, rh);
 			uint64_t xn = 0, rcn = ~0ull;
 			if (TEXT) {
 				if (TEXT == 1) xn = tw[tpn > 0 ? tpn - 1 : 0]; // the word after next
-				else if ((it & 7u) == 0) { // a new window: lane j fetches the word after next of phase j
+				else if ((it & (uint32_t)(LPW - 1)) == 0) { // a new window: lane j fetches the word after next of phase j
 					const int64_t a = tp - 2 - j;
 					blk8 = tw[a > 0 ? a : 0];
 				}
@@ -890,8 +941,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			bool end_next;
 			if (LIST) end_next = remaining == 1;
 			else end_next = M && kbn >= m2 && (kbn & (M - 1)) == 0;
-			octc_issue_slot<DENSE>(b1, j, rl);
-			if (wide) octc_issue_slot_hi<DENSE>(b1, j, rh, rl);
+			octc_issue_slot<DENSE, LPW>(b1, j, rl);
+			if (wide) octc_issue_slot_hi<DENSE, LPW>(b1, j, rh, rl);
 			// this row: record it unless somebody already has
 			++steps;
 			const bool fin = met || c == 0;
@@ -899,7 +950,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			if (TENT && tentok && !met && sid < 0) { // first tentative record of this walker: open a stretch (rare)
 				uint32_t s0 = 0;
 				if (j == 0) s0 = gap == 1 ? atomicAdd(sidctr + 1, 1u) : atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
-				s0 = oct_bcast0(s0, j);
+				s0 = grp_bcast0<LPW>(s0, j);
 				if (gap == 1) sid = s0 < lim_singles ? (int)(RB3_TENT_HALF + s0) : -2; // table full: this walker stays a plain inexact one
 				else sid = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : -2;
 				sid0 = sid;
@@ -917,23 +968,23 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 					}
 				}
 			}
-			if ((gap == 0 || (tentok && sid >= 0)) && !met && j == (int)(it & 7u))
+			if ((gap == 0 || (tentok && sid >= 0)) && !met && j == (int)(it & (uint32_t)(LPW - 1)))
 				bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 			// next insertion point(s)
 			uint32_t match = 0, mh;
 			int64_t lo_n, hi_n;
 			// an interval inside one run slot (the usual state of a walker in an index that holds many relatives): both bounds from
 			// one fetch and one packed decode.  A branch per octet: a wave whose octets are all in this state runs only this side.
-			const uint32_t hdr0q = DENSE ? 0u : oct_bcast0(rl.sl.x, j);
-			if (!DENSE && wide && rh.sidx == rl.sidx && (hdr0q & RB3_SLOT_RLE)) octc_finish_pair(rl, rh, hdr0q, c, j, &lo_n, &hi_n);
+			const uint32_t hdr0q = DENSE ? 0u : grp_bcast0<LPW>(rl.sl.x, j);
+			if (!DENSE && wide && rh.sidx == rl.sidx && (hdr0q & RB3_SLOT_RLE)) octc_finish_pair<LPW>(rl, rh, hdr0q, c, j, &lo_n, &hi_n);
 			else {
-				lo_n = octc_finish<DENSE>(rl, c, j, &match);
+				lo_n = octc_finish<DENSE, LPW>(rl, c, j, &match);
 				hi_n = lo_n;
 				if (TENT && gap == 1) hi_n = lo_n + match;
-				if (wide) hi_n = octc_finish<DENSE>(rh, c, j, &mh);
+				if (wide) hi_n = octc_finish<DENSE, LPW>(rh, c, j, &mh);
 			}
 			if (TEXT == 2) { // the word after next, from the lane that fetched it (after the slot has arrived: no wait of its own)
-				const int src = ((lane & ~7) | (int)(it & 7u)) << 2;
+				const int src = ((lane & ~(LPW - 1)) | (int)(it & (uint32_t)(LPW - 1))) << 2;
 				xn = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)blk8) | (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(blk8 >> 32)) << 32;
 			}
 			const int64_t kn = hi_n - lo_n;
@@ -947,7 +998,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				else if ((ns & (RB3_TENT_BLOCK - 1)) == 0) { // this walker's block of ids is used up (rare)
 					uint32_t s0 = 0;
 					if (j == 0) s0 = atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
-					s0 = oct_bcast0(s0, j);
+					s0 = grp_bcast0<LPW>(s0, j);
 					// table full: the records from here on stay unsettled and the host redoes the phase
 					ns = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 				}

@@ -9,7 +9,8 @@ from tests import util
 from ropebwt3_amd import Rb3Gpu, host
 K = int(sys.argv[1]); L = 4400000
 libs = [None] + [a for a in sys.argv[2:] if "=" not in a]
-tunes = [a.split("=") for a in sys.argv[2:] if "=" in a]
+tunes = [a.split("=") for a in sys.argv[2:] if "=" in a and not a.startswith("W=")]
+Ws = [int(a[2:]) for a in sys.argv[2:] if a.startswith("W=")] or [384]
 g0 = util.random_genome(np.random.default_rng(1), L)
 h = Rb3Gpu(verbose=1)
 for k in range(K):
@@ -26,10 +27,10 @@ if d_plain is None:
     h._chk(h._lib.rb3gpu_dev_alloc(h._h, n, ctypes.byref(p)), "alloc"); d_plain = p.value
 h.export_plain_dev(d_plain)
 t = util.make_text([util.mutate(np.random.default_rng(999), g0, 0.001)])
-w = host.walkers_text(t, 384)
 d, dtw = h.sort_text(t)
 print("index of %d genomes: %d symbols, %.1f MB" % (K, n, h.stats()["bytes_index"] / 1e6))
-for lib in libs:
+for lib, W in [(l, W) for l in libs for W in Ws]:
+    w = host.walkers_text(t, W)
     h2 = Rb3Gpu(verbose=0, lib=lib)
     for k, v in tunes: h2.tune(k, int(v))
     h2.from_plain_dev(d_plain, n)
@@ -38,6 +39,6 @@ for lib in libs:
         try: h2.merge_text_dev(d, dtw, t.size, w, commit=False)
         except Exception as e: pass
     st = h2.stats()
-    print("%-12s rebuild %.3f ms, rank %.3f ms (chain %.3f) per merge; groups to the window kernels %d of %d" % ((lib or "default").split("/")[-1], st["ms_build"] / 5, st["ms_rank"] / 5, st["ms_chain"] / 5,
-          st["n_reb_groups_window"] // 5, st["n_reb_groups"] // 5))
+    print("%-12s W=%d: rebuild %.3f ms, rank %.3f ms (chain %.3f, %.2f M steps) per merge; groups to the window kernels %d of %d" % ((lib or "default").split("/")[-1], W, st["ms_build"] / 5, st["ms_rank"] / 5, st["ms_chain"] / 5,
+          st["n_lf_steps"] / 5e6, st["n_reb_groups_window"] // 5, st["n_reb_groups"] // 5))
     h2.close()

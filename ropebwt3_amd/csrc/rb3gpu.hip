@@ -1750,7 +1750,7 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa)
 	return 0;
 }
 
-/* Runs are found on the device (k_export_runs: count, scan, emit), chunk by chunk; only start << 3 | sym of
+/* Runs are found on the device (k_export_runs_g: count, scan, emit), chunk by chunk; only start << 3 | sym of
  * every run crosses PCIe, and the host turns consecutive starts into lengths. */
 #define RB3_RCHUNK_WINS (1LL << 16) /* windows (16 M symbols) per chunk: at most 128 MB of run words */
 /* chunk by chunk: run starts on the device, copied through the pinned staging buffers when they fit */
@@ -1765,19 +1765,21 @@ static int export_run_words(rb3gpu_t *h, rb3gpu_emit_words_f emit, void *data)
 	if (h->stage[0] == nullptr)
 		for (int i = 0; i < 2; ++i)
 			if (hipHostMalloc((void**)&h->stage[i], RB3_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { h->stage[i] = nullptr; break; }
-	for (int64_t w0 = 0; w0 < nwin && ret == 0; w0 += RB3_RCHUNK_WINS) {
-		const int64_t nw = w0 + RB3_RCHUNK_WINS < nwin ? RB3_RCHUNK_WINS : nwin - w0;
-		if ((ret = buf_ensure(h, h->gstat, (size_t)nw * 32)) < 0) break;
-		if ((ret = buf_ensure(h, h->gpre, (size_t)nw * 64)) < 0) break;
+	const int64_t ngrp = (h->n + RB3_GRP - 1) >> RB3_GRP_BITS, gchunk = RB3_RCHUNK_WINS / RB3_GRP_WINS;
+	(void)nwin;
+	for (int64_t g0 = 0; g0 < ngrp && ret == 0; g0 += gchunk) {
+		const int64_t ng = g0 + gchunk < ngrp ? gchunk : ngrp - g0;
+		if ((ret = buf_ensure(h, h->gstat, (size_t)ng * 32)) < 0) break;
+		if ((ret = buf_ensure(h, h->gpre, (size_t)ng * 64)) < 0) break;
 		uint32_t *cnt8 = (uint32_t*)h->gstat.p;
 		uint64_t *off8 = (uint64_t*)h->gpre.p, total[8];
-		const dim3 grid((unsigned)((nw + 3) / 4)), blk(256);
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<false>), grid, blk, 0, h->st, iv, w0, nw, cnt8, (const uint64_t*)nullptr, (uint64_t*)nullptr);
-		if ((ret = scan_records(h, cnt8, nw, off8, (uint64_t*)h->misc.p + MISC_IX_TOT, total)) < 0) break;
+		const dim3 grid((unsigned)((ng + 3) / 4)), blk(256);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<false>), grid, blk, 0, h->st, iv, g0, ng, cnt8, (const uint64_t*)nullptr, (uint64_t*)nullptr);
+		if ((ret = scan_records(h, cnt8, ng, off8, (uint64_t*)h->misc.p + MISC_IX_TOT, total)) < 0) break;
 		const int64_t nr = (int64_t)total[0];
 		if (nr == 0) continue;
 		if ((ret = buf_ensure(h, h->xbuf, (size_t)nr * 8)) < 0) break;
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<true>), grid, blk, 0, h->st, iv, w0, nw, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<true>), grid, blk, 0, h->st, iv, g0, ng, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
 		uint64_t *dst;
 		if (h->stage[0] && (size_t)nr * 8 <= RB3_STAGE_BYTES) dst = (uint64_t*)h->stage[0];
 		else {
@@ -1820,17 +1822,19 @@ int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
 	*words = nullptr, *n_words = 0;
 	// the run starts of the whole index, resident: count per window, scan, emit
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
-	if ((r = buf_ensure(h, h->gstat, (size_t)nwin * 32)) < 0) return r;
-	if ((r = buf_ensure(h, h->gpre, (size_t)nwin * 64)) < 0) return r;
+	const int64_t ngrp = (h->n + RB3_GRP - 1) >> RB3_GRP_BITS;
+	(void)nwin;
+	if ((r = buf_ensure(h, h->gstat, (size_t)ngrp * 32)) < 0) return r;
+	if ((r = buf_ensure(h, h->gpre, (size_t)ngrp * 64)) < 0) return r;
 	uint32_t *cnt8 = (uint32_t*)h->gstat.p;
 	uint64_t *off8 = (uint64_t*)h->gpre.p, total[8];
-	const dim3 grid((unsigned)((nwin + 3) / 4)), blk(256);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<false>), grid, blk, 0, h->st, iv, (int64_t)0, nwin, cnt8, (const uint64_t*)nullptr, (uint64_t*)nullptr);
-	if ((r = scan_records(h, cnt8, nwin, off8, (uint64_t*)h->misc.p + MISC_IX_TOT, total)) < 0) return r;
+	const dim3 grid((unsigned)((ngrp + 3) / 4)), blk(256);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<false>), grid, blk, 0, h->st, iv, (int64_t)0, ngrp, cnt8, (const uint64_t*)nullptr, (uint64_t*)nullptr);
+	if ((r = scan_records(h, cnt8, ngrp, off8, (uint64_t*)h->misc.p + MISC_IX_TOT, total)) < 0) return r;
 	const int64_t nr = (int64_t)total[0];
 	if (nr <= 0) return RB3GPU_EINTERNAL;
 	if ((r = buf_ensure(h, h->xbuf, (size_t)nr * 8)) < 0) return r;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs<true>), grid, blk, 0, h->st, iv, (int64_t)0, nwin, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<true>), grid, blk, 0, h->st, iv, (int64_t)0, ngrp, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
 	r = rb3fmd_encode(h->st, h->n, nr, (const uint64_t*)h->xbuf.p, words, n_words);
 	h->stt.ms_export += (now_s() - t) * 1e3;
 	if (r == 1) return RB3GPU_EUNSUP;

@@ -3013,44 +3013,86 @@ __global__ void __launch_bounds__(256) k_export_plain(IdxView ix, int64_t beg, i
 	for (; i < end; i += stride) out[i - beg] = (uint8_t)idx_sym(ix, i);
 }
 
-/* run export (rb3_enc_fmr2fmd's leaf iteration, fm-index.c:31-52): the maximal runs of windows [w0, w0 + nw)
- * as start << 3 | sym, in BWT order.  A position starts a run iff its symbol differs from the one before it
- * (read from the index, so runs continue across windows and chunks).  Pass 1 (EMIT = false) counts the run
- * starts per window into column 0 of an 8 x u32 record (the engine's scan works on those), pass 2 writes
- * them at the scanned offsets.  One wave per window. */
+/* run export (rb3_enc_fmr2fmd's leaf iteration, fm-index.c:31-52): the maximal runs of groups [g0, g0 + ng) as
+ * start << 3 | sym, in BWT order.  A position starts a run iff its symbol differs from the one before it (runs continue
+ * across slots, groups and chunks).  Pass 1 (EMIT = false) counts the run starts per group into column 0 of an 8 x u32
+ * record (the engine's scan works on those), pass 2 writes them at the scanned offsets.
+ * One wave per GROUP walks the group's slots -- a run slot IS its runs (one lane per code,
+ * start = prefix sum of the lengths), a bit-plane slot is expanded as above -- so the cost follows the size of the block
+ * array, not the number of symbols (a pangenome index: ~100x fewer codes than symbols).  A run that continues from the
+ * slot (or group) before is recognised by the last symbol of that slot.  (Round 1 regenerated every symbol, one wave per
+ * window: 44 ms for the 1.33 G symbols of config 3.) */
+__device__ __forceinline__ uint32_t slot_code(const uint32_t *sp, int q) // code q of a run slot (q < 48)
+{
+	const uint32_t word = sp[(q / 6) * 4 + 1 + (q % 6) / 2];
+	return (q & 1) ? word >> 16 : word & 0xFFFFu;
+}
+
+__device__ __forceinline__ uint32_t slot_plane_sym(const uint32_t *sp, uint32_t off) // symbol at offset off (< 256) of a bit-plane slot
+{
+	const uint32_t *w = sp + (off >> 5) * 4, bit = off & 31;
+	return ((w[1] >> bit) & 1u) | ((w[2] >> bit) & 1u) << 1 | ((w[3] >> bit) & 1u) << 2;
+}
+
+/* last symbol of a slot (all lanes of the wave get it) */
+__device__ __forceinline__ uint32_t slot_last_sym(const uint32_t *sp, int lane)
+{
+	const uint32_t hdr0 = sp[0], nsym = sp[28] - 0u;
+	if (!(hdr0 & RB3_SLOT_RLE)) return slot_plane_sym(sp, (nsym & 0xFFFFu) - 1u);
+	const uint32_t code = lane < RB3_RLE_CODES ? slot_code(sp, lane) : 7u;
+	const int nc = __popcll(__ballot((code & 7u) != 7u));
+	return wave_read(code, nc > 0 ? nc - 1 : 0) & 7u;
+}
+
 template<bool EMIT>
-__global__ void __launch_bounds__(256) k_export_runs(IdxView ix, int64_t w0, int64_t nw, uint32_t *cnt8, const uint64_t *off8, uint64_t *runs)
+__global__ void __launch_bounds__(256) k_export_runs_g(IdxView ix, int64_t g0, int64_t ng, uint32_t *cnt8, const uint64_t *off8, uint64_t *runs)
 {
 	const int lane = threadIdx.x & 63;
-	const int64_t wi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (wi >= nw) return;
-	const int64_t p0 = (w0 + wi) << RB3_WIN_BITS;
-	uint32_t sym[4];
+	const int64_t gi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (gi >= ng) return;
+	const int64_t g = g0 + gi, P0 = g << RB3_GRP_BITS;
+	uint32_t total = 0;
+	if (P0 < ix.n) {
+		const uint64_t sm = ix.grp64[g * 8 + 6];
+		const uint32_t slot0 = (uint32_t)sm, nsl = (uint32_t)__popc((uint32_t)(sm >> 32));
+		// headers that carry the whole LF base (RB3_ABS_HEADERS) only differ in words 1..6; words 0 and 7 are what is read here
+		uint32_t prev = 8u;
+		if (g > 0) prev = slot_last_sym((const uint32_t*)(ix.slot16 + (int64_t)(slot0 - 1u) * 8), lane);
+		uint64_t o = EMIT ? off8[gi * 8] : 0;
+		for (uint32_t si = 0; si < nsl; ++si) {
+			const uint32_t *sp = (const uint32_t*)(ix.slot16 + (int64_t)(slot0 + si) * 8);
+			const uint32_t hdr0 = sp[0];
+			const int64_t start = P0 + (int64_t)(hdr0 & 0xFFFFu);
+			if (hdr0 & RB3_SLOT_RLE) {
+				const uint32_t code = lane < RB3_RLE_CODES ? slot_code(sp, lane) : 7u;
+				const uint32_t sym = code & 7u, len = sym == 7u ? 0u : (code >> 3) + 1u;
+				const uint32_t ex = wave_incl_scan(len) - len;
+				uint32_t before = wave_up1(sym);
+				if (lane == 0) before = prev;
+				const uint64_t H = __ballot(sym != 7u && sym != before);
+				if (EMIT && (H >> lane & 1ull)) runs[o + __popcll(H & ((1ull << lane) - 1ull))] = (uint64_t)(start + ex) << 3 | sym;
+				const int nh = __popcll(H), nc = __popcll(__ballot(sym != 7u));
+				o += nh, total += (uint32_t)nh;
+				if (nc > 0) prev = wave_read(sym, nc - 1);
+			} else {
+				const uint32_t nsym = sp[28] & 0xFFFFu; // (<= 256)
 #pragma unroll
-	for (int u = 0; u < 4; ++u) {
-		const int64_t p = p0 + 64 * u + lane;
-		sym[u] = p < ix.n ? idx_sym(ix, p) : 7u;
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t off = 64u * u + lane;
+					const uint32_t sym = off < nsym ? slot_plane_sym(sp, off) : 7u;
+					uint32_t before = wave_up1(sym);
+					if (lane == 0) before = prev;
+					const uint64_t H = __ballot(sym != 7u && sym != before);
+					if (EMIT && (H >> lane & 1ull)) runs[o + __popcll(H & ((1ull << lane) - 1ull))] = (uint64_t)(start + off) << 3 | sym;
+					const int nh = __popcll(H);
+					o += nh, total += (uint32_t)nh;
+					const int nv = (int)nsym - 64 * u;
+					if (nv > 0) prev = wave_read(sym, nv >= 64 ? 63 : nv - 1);
+				}
+			}
+		}
 	}
-	const uint32_t before = p0 > 0 ? idx_sym(ix, p0 - 1) : 8u;
-	uint64_t H[4];
-#pragma unroll
-	for (int u = 0; u < 4; ++u) {
-		uint32_t prev = wave_up1(sym[u]);
-		const uint32_t pl = u > 0 ? wave_read(sym[u > 0 ? u - 1 : 0], 63) : before;
-		if (lane == 0) prev = pl;
-		H[u] = __ballot(sym[u] != 7u && sym[u] != prev);
-	}
-	if (!EMIT) {
-		if (lane < 8) cnt8[wi * 8 + lane] = lane == 0 ? (uint32_t)(__popcll(H[0]) + __popcll(H[1]) + __popcll(H[2]) + __popcll(H[3])) : 0u;
-		return;
-	}
-	uint64_t o = off8[wi * 8];
-#pragma unroll
-	for (int u = 0; u < 4; ++u) {
-		if (H[u] >> lane & 1ull)
-			runs[o + __popcll(H[u] & ((1ull << lane) - 1ull))] = (uint64_t)(p0 + 64 * u + lane) << 3 | sym[u];
-		o += __popcll(H[u]);
-	}
+	if (!EMIT && lane < 8) cnt8[gi * 8 + lane] = lane == 0 ? total : 0u;
 }
 
 /* ----------------------------------------------------------------------------------------- */

@@ -369,7 +369,7 @@ def main():
     steps = {"plain": lambda commit=False: h.merge_plain_dev(d_b2, b2.size, commit=commit),
              "rows": lambda commit=False: h.merge_plain_dev_walkers(d_b2, b2.size, w_rows, commit=commit),
              "text": lambda commit=False: h.merge_text_dev(d_b2s, d_tw, b2.size, w_text, commit=commit)}
-    names = {"plain": "rb3gpu_merge_plain_dev (the reference's signature rb3_fmi_merge_plain(r, len, bwt): BWT only; walkers start at SA-regular rows)",
+    names = {"plain": "rb3gpu_merge_plain_dev (the reference's signature rb3_fmi_merge_plain(r, len, bwt): BWT only; the text-regular walker list is made on the device inside the step)",
              "rows": "rb3gpu_merge_plain_dev_walkers (BWT + inverse suffix array sampled every %d text positions, as a host suffix sorter has it; %d walkers)" % (args.walker_step, len(w_rows)),
              "text": "rb3gpu_merge_text_dev (BWT + inverse suffix array of the batch, both as the GPU suffix sorter leaves them in HBM: the CLI's path; %d walkers)" % len(w_text)}
     step = steps[args.entry]

@@ -2779,7 +2779,9 @@ __global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint3
 __global__ void k_ssa_jump(int64_t nsp, const uint64_t *in, uint64_t *out); // (pointer jumping over splitters: defined with the sampled suffix array)
 
 /* pointer jumping, three hops per round (links of the OLD table only, so one round multiplies the reach of every link by
- * four): half the launches of the doubling form, and a launch costs more here than two more dependent gathers */
+ * four): half the launches of the doubling form, and a launch costs more here than two more dependent gathers.  (All rounds
+ * in one launch with grid barriers -- 512 resident blocks, release/acquire fences at agent scope -- was measured: 0.6 ms
+ * instead of 0.2 ms for the ten rounds; the per-round L2 write-back and invalidate cost more than the launches.) */
 __global__ void __launch_bounds__(256) k_b2_jump4(int64_t nsp, const uint64_t *in, uint64_t *out)
 {
 	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2867,10 +2869,21 @@ __global__ void __launch_bounds__(256) k_b2_pick(int64_t n2, const uint64_t *tot
 	if (off < RB3_B2_FIRST) atomicMin(&bucket[G / RB3_B2_W], (unsigned long long)(off << 48 | (uint64_t)p));
 }
 
+/* A pick lies `off` text positions behind the start of its window (geometric, mean 2^S, the odd one beyond 100), and a
+ * wave of k_chain lasts as long as its longest walker while walkers of different lengths fall out of step (exact spacing 384:
+ * 0.46 ms, this jitter: 0.71 ms on the bench workload).  So the pick WALKS its `off` LF steps down to the window start (the
+ * batch's own LF words: dependent 8-byte loads, no rank) and the walker starts exactly there -- unless that would leave the
+ * pick's string (then it stays where it is).  b2_refined_D: the distance from the start of its string at which a pick ends up. */
+__device__ __forceinline__ uint64_t b2_refined_D(uint64_t D, uint64_t g0)
+{
+	const uint64_t off = (g0 + D) % RB3_B2_W;
+	return D > off ? D - off : D;
+}
+
 /* the walker list: slot b < nbk = the pick of window b (row -1: none), slot nbk + j = the sentinel row j; nsteps = text distance
  * to the next walker on the left in the same string.  nwalk[0] = slots in use. */
 __global__ void __launch_bounds__(256) k_b2_list(int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, const uint64_t *lnk, const uint64_t *gbase,
-		const unsigned long long *bucket, int64_t nbk, Walker *wl, unsigned long long *nwalk)
+		const unsigned long long *bucket, int64_t nbk, Walker *wl, unsigned long long *nwalk, const int64_t *roww)
 {
 	const int64_t m2 = (int64_t)tot2[0];
 	const unsigned long long md = mode[0];
@@ -2892,7 +2905,10 @@ __global__ void __launch_bounds__(256) k_b2_list(int64_t n2, const uint64_t *tot
 			if (v == RB3_B2_EMPTY) { wl[u] = w; continue; }
 			const int64_t p = (int64_t)(v & 0xFFFFFFFFFFFFull);
 			w.row = m2 + ((p - m2) << S);
-			sid = lnk[2 * p] & ~RB3_SSA_END, D = lnk[2 * p + 1], G = gbase[sid] + D, b = u - 1;
+			sid = lnk[2 * p] & ~RB3_SSA_END, D = lnk[2 * p + 1], b = u - 1;
+			const uint64_t D2 = b2_refined_D(D, gbase[sid]);
+			for (uint64_t i = D2; i < D; ++i) w.row = RB3_ROW_NEXT((uint64_t)roww[w.row]); // (no sentinel on the way: D2 >= 1)
+			D = D2, G = gbase[sid] + D;
 		} else {
 			const int64_t j = u - nbk;
 			w.row = j, w.ka0 = -2;
@@ -2904,7 +2920,7 @@ __global__ void __launch_bounds__(256) k_b2_list(int64_t n2, const uint64_t *tot
 			if (v == RB3_B2_EMPTY) continue;
 			const int64_t q = (int64_t)(v & 0xFFFFFFFFFFFFull);
 			if ((lnk[2 * q] & ~RB3_SSA_END) != sid) continue; // a window shared with the neighbouring string
-			const uint64_t Dq = lnk[2 * q + 1];
+			const uint64_t Dq = b2_refined_D(lnk[2 * q + 1], gbase[sid]);
 			if (Dq < D) { w.nsteps = (int64_t)(D - Dq); break; }
 		}
 		wl[u] = w;

@@ -22,14 +22,14 @@ def mk(jit, W=384):
             w.append((ck[p // 16], -1, (1 << 62) if prev < 0 else p - prev, 0)); prev = p
         w.append((j, -2, (1 << 62) if prev < 0 else e - prev, 0)); b = e + 1
     return np.array(w, dtype=np.int64)
-for jit in (0, 16, 32, 64):
-    w = mk(jit)
+for jit, W in ((0, 384), (16, 384), (32, 384), (64, 384), (0, 320), (16, 320), (0, 256), (16, 256), (32, 256), (0, 192), (16, 192)):
+    w = mk(jit, W)
     for i in range(3): h.merge_plain_dev_walkers(d, t2.size, w, commit=False)
     h.stats_reset()
     for i in range(10): h.merge_plain_dev_walkers(d, t2.size, w, commit=False)
     st = h.stats()
     ns = w[:, 2]; ns = ns[ns < (1 << 60)]
-    print("jitter %2d: %d walkers, gaps min %d mean %.0f max %d; k_chain %.3f ms, steps %.2fM fb %d" % (jit, len(w), ns.min(), ns.mean(), ns.max(), st["ms_chain"] / 10, st["n_lf_steps"] / 10 / 1e6, st["n_fallbacks"]))
+    print("W %d jitter %2d: %d walkers, gaps min %d mean %.0f max %d; k_chain %.3f ms, steps %.2fM fb %d" % (W, jit, len(w), ns.min(), ns.mean(), ns.max(), st["ms_chain"] / 10, st["n_lf_steps"] / 10 / 1e6, st["n_fallbacks"]))
 for i in range(3): h.merge_plain_dev(d, t2.size, commit=False)
 h.stats_reset()
 for i in range(10): h.merge_plain_dev(d, t2.size, commit=False)

@@ -32,7 +32,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#define RB3S_H0 20 /* symbols in the round-0 key */
+#define RB3S_H0 20 /* symbols in the round-0 key: batches of short strings (reads: many equal strings, fewer doubling rounds) */
+#define RB3S_H0_LONG 16 /* ... of long strings (genomes: 48 key bits are six radix passes instead of eight, and 16 symbols tell nearly all suffixes apart) */
 
 struct rb3sort_ws {
 	void *p[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -80,14 +81,14 @@ __global__ void __launch_bounds__(256) k_s_sentpos(const uint8_t *text, int64_t 
 	if (p < n && text[p] == 0) sentpos[sid[p]] = (uint32_t)p;
 }
 
-__global__ void __launch_bounds__(256) k_s_key0(const uint8_t *text, int64_t n, const uint32_t *sid, const uint32_t *sentpos, uint64_t *keys, uint32_t *vals)
+__global__ void __launch_bounds__(256) k_s_key0(const uint8_t *text, int64_t n, const uint32_t *sid, const uint32_t *sentpos, uint64_t *keys, uint32_t *vals, int h0)
 {
 	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= n) return;
 	const int64_t d = (int64_t)sentpos[sid[p]] - p; // symbols before p's sentinel
-	const int w = d + 1 < RB3S_H0 ? (int)(d + 1) : RB3S_H0;
+	const int w = d + 1 < h0 ? (int)(d + 1) : h0;
 	uint64_t k = 0;
-	for (int t = 0; t < w; ++t) k |= (uint64_t)text[p + t] << (3 * (RB3S_H0 - 1 - t));
+	for (int t = 0; t < w; ++t) k |= (uint64_t)text[p + t] << (3 * (h0 - 1 - t));
 	keys[p] = k, vals[p] = (uint32_t)p;
 }
 
@@ -195,17 +196,20 @@ int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text
 	hipLaunchKernelGGL(k_s_flag, S_GRID(n), d_text, n, t0, dcnt + 1);
 	b = tmp_bytes; S_HIP(rocprim::exclusive_scan(tmp, b, t0, sid, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
 	hipLaunchKernelGGL(k_s_sentpos, S_GRID(n), d_text, n, (const uint32_t*)sid, sentpos);
+	uint32_t nsent = 0; // sentinels before the last symbol
 	{
 		unsigned long long bad = 0;
 		uint8_t last = 1;
+		S_HIP(hipMemcpyAsync(&nsent, sid + n - 1, 4, hipMemcpyDeviceToHost, st));
 		S_HIP(hipMemcpyAsync(&bad, dcnt + 1, 8, hipMemcpyDeviceToHost, st));
 		S_HIP(hipMemcpyAsync(&last, d_text + n - 1, 1, hipMemcpyDeviceToHost, st));
 		S_HIP(hipStreamSynchronize(st));
 		if (bad != 0 || last != 0) return -3;
 	}
 	// round 0
-	hipLaunchKernelGGL(k_s_key0, S_GRID(n), d_text, n, (const uint32_t*)sid, (const uint32_t*)sentpos, keyA, valA);
-	b = tmp_bytes; S_HIP(rocprim::radix_sort_pairs(tmp, b, keyA, keyB, valA, valB, (size_t)n, 0, 3 * RB3S_H0, st));
+	const int h0 = n / ((int64_t)nsent + 1) > 4096 ? RB3S_H0_LONG : RB3S_H0; // (the last symbol is a sentinel: nsent + 1 strings)
+	hipLaunchKernelGGL(k_s_key0, S_GRID(n), d_text, n, (const uint32_t*)sid, (const uint32_t*)sentpos, keyA, valA, h0);
+	b = tmp_bytes; S_HIP(rocprim::radix_sort_pairs(tmp, b, keyA, keyB, valA, valB, (size_t)n, 0, 3 * h0, st));
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s_heads<false>), S_GRID(n), (const uint64_t*)keyB, n, 0, t0);
 	b = tmp_bytes; S_HIP(rocprim::inclusive_scan(tmp, b, t0, t1, (size_t)n, rocprim::maximum<uint32_t>(), st));
 	hipLaunchKernelGGL(k_s_rank0, S_GRID(n), (const uint32_t*)valB, (const uint32_t*)t1, n, rank, sa, unres);
@@ -216,7 +220,7 @@ int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text
 	int nr = 0, nb = 1;
 	while ((1LL << nb) < n) ++nb; // ranks and string numbers are below n: 2 nb key bits
 	uint32_t *list = valA, *other = valB; // the compacted positions live in one of the two value buffers
-	for (int64_t h = RB3S_H0; nu > 0; h <<= 1) {
+	for (int64_t h = h0; nu > 0; h <<= 1) {
 		if (++nr > 40) return -3; // depth 20 * 2^40: cannot happen for a text that ends with a sentinel
 		hipLaunchKernelGGL(k_s_key, S_GRID(nu), (const uint32_t*)list, (int64_t)nu, (const uint32_t*)rank, (const uint32_t*)sid, (const uint32_t*)sentpos, h, nb, keyA, other);
 		// sorted (keys, positions) -> keyB, list (the old list is free now: its positions were copied into `other`)

@@ -2043,9 +2043,10 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 		v.w = nruns | first << 16 | last << 24;
 		wstat[ws] = v;
 	}
-	// the first 48 runs as codes (len-1) << 3 | sym: what a run slot is assembled from (a window with more
-	// runs can only become a bit-plane slot)
+	// the runs as codes (len-1) << 3 | sym: what a run slot is assembled from (a window with more than 48
+	// runs can only become a bit-plane slot: nothing to prepare -- most windows of an index of reads)
 	int hb = 0;
+	if (nruns <= RB3_RLE_CODES) {
 #pragma unroll
 	for (int u = 0; u < 4; ++u) {
 		if (H[u] >> lane & 1ull) {
@@ -2063,6 +2064,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass1w(IdxView old, cons
 			}
 		}
 		hb += __popcll(H[u]);
+	}
 	}
 	wave_sync();
 	} // windows of this wave
@@ -2779,7 +2781,8 @@ __global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint3
 __global__ void k_ssa_jump(int64_t nsp, const uint64_t *in, uint64_t *out); // (pointer jumping over splitters: defined with the sampled suffix array)
 
 /* pointer jumping, three hops per round (links of the OLD table only, so one round multiplies the reach of every link by
- * four): half the launches of the doubling form, and a launch costs more here than two more dependent gathers.  (All rounds
+ * four): half the launches of the doubling form, and a launch costs more here than two more dependent gathers (seven hops per
+ * round, a third fewer launches, was measured too: 0.05 ms slower on the bench step).  (All rounds
  * in one launch with grid barriers -- 512 resident blocks, release/acquire fences at agent scope -- was measured: 0.6 ms
  * instead of 0.2 ms for the ten rounds; the per-round L2 write-back and invalidate cost more than the launches.) */
 __global__ void __launch_bounds__(256) k_b2_jump4(int64_t nsp, const uint64_t *in, uint64_t *out)

@@ -2157,6 +2157,36 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		for (int a = 0; a < lane - 1; ++a) cb += tot[a];
 		abs_base = (uint32_t)cb;
 	}
+	// Every window its own slot: all of them bit-plane slots (a run slot has at least two windows) -- a group of an index of
+	// reads.  A wave then writes its eight slots with ONE store: lane l = slice l & 7 of window (l >> 3).  The symbol counts of the
+	// windows before (header words 1..6) come from a wave scan over the 32 window records, two 16-bit fields per dword (the counts
+	// of a group stay below 2^14).  Windows of the run-space short cut (no planes cached) take the general path.
+	const uint32_t fullmask = nvw >= 32 ? 0xFFFFFFFFu : ((1u << nvw) - 1u);
+	if (mask == fullmask) {
+		uint4 st = make_uint4(0, 0, 0, 0);
+		if (lane < nvw) st = wstat[gu * RB3_GRP_WINS + lane];
+		if (__ballot(lane < nvw && (st.w & RB3_WSTAT_NOPLANES)) == 0ull) {
+			const uint32_t e0 = wave_incl_scan(st.x) - st.x, e1 = wave_incl_scan(st.y) - st.y, e2 = wave_incl_scan(st.z) - st.z; // (lanes >= nvw add 0)
+			const int lw = wave * (RB3_GRP_WINS / RB3_REB_WAVES) + (lane >> 3), j = lane & 7;
+			const uint32_t p0 = (uint32_t)__shfl((int)e0, lw), p1 = (uint32_t)__shfl((int)e1, lw), p2 = (uint32_t)__shfl((int)e2, lw);
+			if (lw < nvw) {
+				const int64_t w = g * RB3_GRP_WINS + lw, ws = gu * RB3_GRP_WINS + lw;
+				const int64_t srem = ntot - (w << RB3_WIN_BITS);
+				const uint32_t nsym = srem <= 0 ? 0u : srem < RB3_WIN ? (uint32_t)srem : (uint32_t)RB3_WIN;
+				uint32_t hq = j == 0 ? (uint32_t)(lw * RB3_WIN) : j == 1 ? (p0 & 0xFFFFu) : j == 2 ? p0 >> 16 : j == 3 ? (p1 & 0xFFFFu) : j == 4 ? p1 >> 16 :
+					j == 5 ? (p2 & 0xFFFFu) : j == 6 ? p2 >> 16 : nsym;
+				hq += (uint32_t)__shfl((int)abs_base, j); // (abs_base lives in lanes 1..6 of the wave, 0 elsewhere)
+				const uint32_t *pl = wplane + ws * 24;
+				uint4 v;
+				v.x = hq;
+				v.y = pl[(j >> 1) * 6 + 0 + (j & 1)];
+				v.z = pl[(j >> 1) * 6 + 2 + (j & 1)];
+				v.w = pl[(j >> 1) * 6 + 4 + (j & 1)];
+				slot16[((int64_t)slot0 + lw) * 8 + j] = v;
+			}
+			continue; // next group
+		}
+	}
 	for (int lw = wave * (RB3_GRP_WINS / RB3_REB_WAVES); lw < (wave + 1) * (RB3_GRP_WINS / RB3_REB_WAVES) && lw < nvw; ++lw) {
 		if (!(mask >> lw & 1u)) continue; // not the first window of a slot
 		const int64_t w = g * RB3_GRP_WINS + lw;

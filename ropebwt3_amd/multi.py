@@ -167,6 +167,13 @@ class TorchComm:
 
     def all_gather(self, vec):
         v = self.t.tensor(np.asarray(vec, dtype=np.int64), device=self.device)
+        if getattr(self, "_flat_ok", True):   # one collective into one tensor, one copy to the host
+            try:
+                out = self.t.empty((self.world * v.numel(),), dtype=v.dtype, device=self.device)
+                self.dist.all_gather_into_tensor(out, v)
+                return out.cpu().numpy().reshape(self.world, -1)
+            except (RuntimeError, AttributeError, NotImplementedError):
+                self._flat_ok = False
         out = [self.t.empty_like(v) for _ in range(self.world)]
         self.dist.all_gather(out, v)
         return np.stack([o.cpu().numpy() for o in out])
@@ -296,6 +303,59 @@ def merge_interval(engine, comm, bounds, d_bwt, d_tw, n2, sent_tp, commit=True, 
     return bounds + grow if commit else bounds
 
 
+class SoloComm(TorchComm):
+    """the interval-sharded protocol with a single interval: no process group is touched"""
+
+    def __init__(self, device, sync):
+        import torch
+        self.t, self.dist, self.rank, self.world, self.device = torch, None, 0, 1, device
+        self.sync = sync
+        self.as_numpy = False
+
+    def all_gather(self, vec):
+        return np.asarray(vec, dtype=np.int64)[None, :].copy()
+
+
+def _solo_interval_reference(reads_per_gpu, args, dev, local_rank):
+    """bench_main's interval workload at world size 1 with the per-GPU sizes of the multi-GPU run: index of 2^26 symbols in one
+    interval, reads_per_gpu reads per step"""
+    import time
+    import torch
+    from ropebwt3_amd import Rb3Gpu
+    from tests import util
+    h1 = Rb3Gpu(device=local_rank, verbose=1)
+    try:
+        rng = np.random.default_rng(31)
+        g = util.random_genome(rng, (1 << 26) // 2 - 1)
+        t1 = util.make_text([g])
+        d1, d1tw = h1.sort_text(t1)
+        b1 = h1.dev_download(d1, t1.size)
+        h1.dev_free(d1), h1.dev_free(d1tw)
+        h1.from_plain(b1)
+        st = rng.integers(0, len(g) - 150, size=reads_per_gpu)
+        r = np.stack([g[s:s + 150] for s in st])
+        m = rng.random(r.shape) < 0.01
+        r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
+        t2 = util.make_text(list(r))
+        d2, d2tw = h1.sort_text(t2)
+        sent = np.flatnonzero(t2 == 0).astype(np.int64)
+        comm = SoloComm(dev, sync=lambda: (h1.sync(), torch.cuda.synchronize()))
+        bounds = interval_bounds(b1.size, 1)
+        for _ in range(max(1, args.warmup)):
+            merge_interval(h1, comm, bounds, d2, d2tw, t2.size, sent, commit=False)
+        h1.sync(), torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            merge_interval(h1, comm, bounds, d2, d2tw, t2.size, sent, commit=False)
+        h1.sync(), torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        h1.dev_free(d2), h1.dev_free(d2tw)
+        return {"value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "symbols_per_step": int(t2.size),
+                "index_symbols": int(b1.size), "note": "rank 0 alone, same protocol with one interval (no collective), measured after the timed region of this run"}
+    finally:
+        h1.close()
+
+
 def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1), one process per GPU.  --mode interval (default): north_star -- the index of a random genome
     is cut into N intervals, every step merges one batch of reads (N x 100 k reads of 150 bp, both strands: per-GPU work fixed)
@@ -365,6 +425,12 @@ def bench_main(args, rank, local_rank, world):
                    "roofline": {"bound": "hbm", "kernel": "k_sh_step", "achieved": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                 "frac": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6 / 8000.0, 5), "traffic": None,
                                 "note": "rank 0: 208 B x the LF steps it executed / the time of its step kernels; the collectives are outside this figure and inside `value`"}}
+            # the same per-GPU work on ONE GPU (rank 0 alone, its own handle, no collectives): what weak scaling is measured against
+            if world > 1 or os.environ.get("RB3_BENCH_SOLO_REF"):
+                try:
+                    out["n1_same_workload"] = _solo_interval_reference(reads_per_gpu, args, dev, local_rank)
+                except Exception as e:   # never lose the measurement above to this extra
+                    out["n1_same_workload"] = {"error": repr(e)}
     elif args.mode == "partition":
         g0, gs = util.random_genome(np.random.default_rng(1), args.genome_len), None
         g1 = util.mutate(np.random.default_rng(2 + rank), g0, args.div)

@@ -55,7 +55,7 @@ struct Tune {
 	int resolve_v1 = 0;      // settle the tentative stretches with k_resolve (one hop per stretch) instead of k_cum / k_resolve_w / k_sfin
 	int reb_force = 0;       // the run-space rebuild whatever the row density and the old index look like (tests: the hand-over paths)
 	int octs = 8;            // octets per wave of k_chain
-	int lpw = 8;             // lanes per walker of k_chain in the single-sync merge: 8 (an octet) or 4 (a quad, 16 walkers per wave)
+	int lpw = 8;             // lanes per walker of k_chain in the single-sync merge: 8 (an octet) or 4 (a quad, 16 walkers per wave; builds with -DRB3_WITH_QUADS only)
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
 	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
@@ -1086,7 +1086,11 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int64_t *dpos = (int64_t*)h->pos.p;
 	{
 		const IdxView iv = view_of(h);
+#ifdef RB3_WITH_QUADS
 		const int lpw = h->tn.lpw;
+#else
+		const int lpw = 8;
+#endif
 		const int octs = h->tn.octs * (8 / lpw); // groups of lpw lanes per wave
 		const int64_t n_expect = auto_list ? b2_nbk + 64 : n_walkers; // (a device-made list: capacity >> walkers; size the launch for the walkers)
 		int64_t nblk = (n_expect + 4 * octs - 1) / (4 * octs) * h->tn.blkmul;
@@ -1099,7 +1103,11 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk)
+#ifdef RB3_WITH_QUADS /* a quad per walker (k_chain<..., 4>) was measured slower in every regime: compiled in on request only */
 #define RB3_LAUNCH_FAST(D, T, X) do { if (lpw == 4) RB3_LAUNCH_FAST1(D, T, X, 4); else RB3_LAUNCH_FAST1(D, T, X, 8); } while (0)
+#else
+#define RB3_LAUNCH_FAST(D, T, X) RB3_LAUNCH_FAST1(D, T, X, 8)
+#endif
 		// text-order words: per-lane loads while the L1 can hold a line per walker (256 CUs x 32 waves x 8 octets), else 64-byte fetches
 		int text_mode = !d_tw ? 0 : n_walkers <= 65536 ? 1 : 2;
 #ifdef RB3GPU_TEST_HOOKS

@@ -209,6 +209,11 @@ typedef unsigned short rb3_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ rb3_s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(rb3_s16x2, v); }
 __device__ __forceinline__ uint32_t as_u32(rb3_s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 
+__device__ __forceinline__ uint32_t pk_sum16(uint32_t v, uint32_t add) // add + low half + high half (v_dot2_u32_u16)
+{
+	return __builtin_amdgcn_udot2(__builtin_bit_cast(rb3_u16x2, v), __builtin_bit_cast(rb3_u16x2, 0x00010001u), add, false);
+}
+
 template<bool TWO, bool MATCH, int LPW = 8>
 __device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b, uint32_t *match_a)
 {
@@ -216,28 +221,28 @@ __device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2
 	constexpr int NW = LPW == 4 ? 6 : 3;
 	const uint32_t w[6] = { sl.y, sl.z, sl.w, sl2.y, sl2.z, sl2.w };
 	uint32_t lw[NW];
+	uint32_t tot = 0;
 #pragma unroll
-	for (int k = 0; k < NW; ++k) lw[k] = ((w[k] >> 3) & 0x1FFF1FFFu) + 0x00010001u; // run lengths of the two codes (no carry: <= 8192)
-	uint32_t sum2 = lw[0] + lw[1] + lw[2];                                             // per half <= 3 * 8192: no carry either
-	uint32_t tot = (sum2 & 0xFFFFu) + (sum2 >> 16);
-	if (LPW == 4) { sum2 = lw[3] + lw[4] + lw[5]; tot += (sum2 & 0xFFFFu) + (sum2 >> 16); }
+	for (int k = 0; k < NW; ++k) {
+		lw[k] = as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, w[k]) >> 3) + as_s16x2(0x00010001u)); // run lengths of the two codes (<= 8192)
+		tot = pk_sum16(lw[k], tot);
+	}
 	uint32_t base = grp_exscan<LPW>(tot, j);
 	const uint32_t csplat = (uint32_t)c * 0x00010001u;
-	const rb3_s16x2 oa = as_s16x2((uint32_t)off_a * 0x00010001u), ob = as_s16x2((uint32_t)off_b * 0x00010001u), zero = as_s16x2(0u);
+	const rb3_s16x2 oa = as_s16x2((uint32_t)off_a * 0x00010001u), ob = as_s16x2((uint32_t)off_b * 0x00010001u), zero = as_s16x2(0u), one = as_s16x2(0x00010001u);
 	rb3_s16x2 acc_a = zero, acc_b = zero;
 	uint32_t mt = 0;
 #pragma unroll
 	for (int k = 0; k < NW; ++k) {
 		const rb3_s16x2 P = as_s16x2(base * 0x00010001u + (lw[k] << 16)); // start offsets: (base, base + len of the first code)
 		const rb3_s16x2 Lk = as_s16x2(lw[k]);
-		// 0xFFFF in the halves whose symbol is c: x in 0..7 per half, x + 0x7FFF has bit 15 set iff x != 0
-		const uint32_t x = (w[k] & 0x00070007u) ^ csplat;
-		const uint32_t eq = ((((x + 0x7FFF7FFFu) >> 15) & 0x00010001u) ^ 0x00010001u) * 0xFFFFu;
+		// 0xFFFF in the halves whose symbol is c: x in 0..7 per half, x - 1 is negative iff x == 0
+		const uint32_t eq = as_u32((as_s16x2((w[k] & 0x00070007u) ^ csplat) - one) >> 15);
 		const rb3_s16x2 ta = oa - P;
 		rb3_s16x2 d = __builtin_elementwise_min(__builtin_elementwise_max(ta, zero), Lk);
 		acc_a += as_s16x2(as_u32(d) & eq);
 		if (MATCH) { // the code that holds offset off_a itself: 0 <= off_a - start < length, i.e. clamping to [0, length - 1] changes nothing
-			const uint32_t y = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(ta, zero), Lk - as_s16x2(0x00010001u))) ^ as_u32(ta);
+			const uint32_t y = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(ta, zero), Lk - one)) ^ as_u32(ta);
 			const uint32_t nz = ((y | ((y & 0x7FFF7FFFu) + 0x7FFF7FFFu)) >> 15) & 0x00010001u; // 1 in the halves where y != 0
 			mt |= (nz ^ 0x00010001u) & (eq & 0x00010001u);
 		}
@@ -245,11 +250,10 @@ __device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2
 			d = __builtin_elementwise_min(__builtin_elementwise_max(ob - P, zero), Lk);
 			acc_b += as_s16x2(as_u32(d) & eq);
 		}
-		base += (lw[k] & 0xFFFFu) + (lw[k] >> 16);
+		base = pk_sum16(lw[k], base);
 	}
-	const uint32_t ua = as_u32(acc_a);
-	*cnt_a = (ua & 0xFFFFu) + (ua >> 16);
-	if (TWO) { const uint32_t ub = as_u32(acc_b); *cnt_b = (ub & 0xFFFFu) + (ub >> 16); }
+	*cnt_a = pk_sum16(as_u32(acc_a), 0u);
+	if (TWO) *cnt_b = pk_sum16(as_u32(acc_b), 0u);
 	if (MATCH) *match_a = mt;
 }
 

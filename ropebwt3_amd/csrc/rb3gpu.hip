@@ -1170,7 +1170,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	h->stt.n_lf_steps += (int64_t)hm[1];
 	h->stt.n_lf_checked += (int64_t)hm[MISC_LF_CHK];
 #ifdef RB3_PROF
-	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, max iterations %llu -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], hm[12], (double)hm[9] / hm[10]);
+	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, %.1f %% of them with the two-decode path -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], 100.0 * (double)hm[12] / (double)hm[10], (double)hm[9] / hm[10]);
 #endif
 	if (hm[MISC_LF_TOT + 6] != 0) return RB3GPU_ESYMBOL; // fm-index.c:124-125
 	int64_t acc2[7];

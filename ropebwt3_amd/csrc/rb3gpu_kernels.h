@@ -271,7 +271,7 @@ __device__ __forceinline__ uint32_t plane_count(const uint4 &sl, int t, int c)
 	return __popc(m & lim) | (at ? RB3_MATCH_BIT : 0u);
 }
 
-template<int LPW = 8>
+template<int LPW = 8, bool MATCH = true>
 __device__ __forceinline__ uint32_t slice_count(const uint4 &sl, const uint4 &sl2, uint32_t hdr0, uint32_t off, int c, int j)
 {
 	uint32_t cnt;
@@ -280,8 +280,8 @@ __device__ __forceinline__ uint32_t slice_count(const uint4 &sl, const uint4 &sl
 		else cnt = plane_count(sl, (int)off - 64 * j, c) + plane_count(sl2, (int)off - 64 * j - 32, c); // (at most one of the two sets the match bit)
 	} else { // run codes, two at a time
 		uint32_t cb, mt;
-		slice_count_pk<false, true, LPW>(sl, sl2, (int)off, (int)off, c, j, &cnt, &cb, &mt);
-		if (mt) cnt |= RB3_MATCH_BIT;
+		slice_count_pk<false, MATCH, LPW>(sl, sl2, (int)off, (int)off, c, j, &cnt, &cb, &mt);
+		if (MATCH && mt) cnt |= RB3_MATCH_BIT;
 	}
 	return cnt;
 }
@@ -624,12 +624,12 @@ __device__ __forceinline__ uint32_t octc_hdr_c(const RankLoadC &r, int c, int j)
 
 /* both ends of an interval that lies inside ONE run slot, from one decode */
 template<int LPW = 8>
-__device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, const RankLoadC &rh, uint32_t hdr0, int c, int j, int64_t *lo_n, int64_t *hi_n)
+__device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, uint32_t koff_hi, uint32_t hdr0, int c, int j, int64_t *lo_n, int64_t *hi_n)
 {
 	const int base = (int)(hdr0 & 0xFFFFu);
 	uint32_t ca, cb;
 	uint32_t mt;
-	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, (int)rl.koff - base, (int)rh.koff - base, c, j, &ca, &cb, &mt);
+	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, (int)rl.koff - base, (int)koff_hi - base, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16; // both fit 16 bits (counts inside a group of 8192)
 	v += octc_hdr_c<LPW>(rl, c, j) * 0x00010001u;
 	v = grp_sum<LPW>(v);
@@ -638,7 +638,7 @@ __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, const Rank
 
 /* LF(c, k) for the group's query; *match = 1 iff the symbol at offset k itself is c (then the suffix
  * at row k extends by c: used to advance an interval [k, k+1) with a single rank) */
-template<bool DENSE, int LPW = 8>
+template<bool DENSE, int LPW = 8, bool MATCH = true>
 __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j, uint32_t *match)
 {
 	uint32_t part;
@@ -651,7 +651,7 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 		return (int64_t)base + (int64_t)(sum & (RB3_MATCH_BIT - 1u));
 	} else {
 		const uint32_t hdr0 = grp_bcast0<LPW>(r.sl.x, j);
-		part = slice_count<LPW>(r.sl, r.sl2, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
+		part = slice_count<LPW, MATCH>(r.sl, r.sl2, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
 	}
 	part += octc_hdr_c<LPW>(r, c, j);
 	const uint32_t sum = grp_sum<LPW>(part);
@@ -867,6 +867,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	uint32_t it = 0, age = 0;
 #ifdef RB3_PROF
 	const uint64_t tstart = __builtin_readcyclecounter();
+	unsigned long long prof_nonpair = 0; // iterations in which some group of this wave took the two-decode path
 #endif
 	for (;;) {
 		// ---- refill: every octet without a walker pulls the next one from the queue (rare) ----
@@ -977,16 +978,25 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			// next insertion point(s)
 			uint32_t match = 0, mh;
 			int64_t lo_n, hi_n;
-			// an interval inside one run slot (the usual state of a walker in an index that holds many relatives): both bounds from
-			// one fetch and one packed decode.  A branch per octet: a wave whose octets are all in this state runs only this side.
+			// A lower bound in a run slot -- the usual state in an index that holds many relatives -- goes through ONE packed decode that
+			// also yields the upper bound if that lies in the same slot, and an EXACT walker is the interval [lo, lo) of the same code:
+			// once a walker has passed a variant private to the new string it stays exact for the rest of its life, so some group of
+			// almost every wave is exact, and giving those their own single-bound decode made 80 % of the wave iterations run both
+			// sides of this branch (measured, K = 40: 71 % had an exact group, 21 % an interval over two slots, 1 % a one-row interval).
+			// Left for the general side: one-row intervals (they need the match bit), bit-plane slots, the second slot of an interval.
 			const uint32_t hdr0q = DENSE ? 0u : grp_bcast0<LPW>(rl.sl.x, j);
-			if (!DENSE && wide && rh.sidx == rl.sidx && (hdr0q & RB3_SLOT_RLE)) octc_finish_pair<LPW>(rl, rh, hdr0q, c, j, &lo_n, &hi_n);
+			const bool same = wide && rh.sidx == rl.sidx;
+			const bool pairable = !DENSE && (hdr0q & RB3_SLOT_RLE) && (!TENT || gap != 1);
+#ifdef RB3_PROF
+			if (__ballot(!pairable || (wide && !same)) != 0ull) ++prof_nonpair;
+#endif
+			if (pairable) octc_finish_pair<LPW>(rl, same ? rh.koff : rl.koff, hdr0q, c, j, &lo_n, &hi_n);
 			else {
 				lo_n = octc_finish<DENSE, LPW>(rl, c, j, &match);
 				hi_n = lo_n;
 				if (TENT && gap == 1) hi_n = lo_n + match;
-				if (wide) hi_n = octc_finish<DENSE, LPW>(rh, c, j, &mh);
 			}
+			if (wide && !(pairable && same)) hi_n = octc_finish<DENSE, LPW, false>(rh, c, j, &mh); // (no match bit wanted: the run-slot side is cheaper)
 			if (TEXT == 2) { // the word after next, from the lane that fetched it (after the slot has arrived: no wait of its own)
 				const int src = ((lane & ~(LPW - 1)) | (int)(it & (uint32_t)(LPW - 1))) << 2;
 				xn = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)blk8) | (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(blk8 >> 32)) << 32;
@@ -1029,7 +1039,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 #ifdef RB3_PROF
 	if (lane == 0) { // wave statistics: [8] max cycles, [9] sum cycles, [10] sum iterations, [11] waves, [12] max iterations
 		const unsigned long long cyc = __builtin_readcyclecounter() - tstart;
-		atomicMax(nsteps + 7, cyc); atomicAdd(nsteps + 8, cyc); atomicAdd(nsteps + 9, (unsigned long long)it); atomicAdd(nsteps + 10, 1ull); atomicMax(nsteps + 11, (unsigned long long)it);
+		atomicMax(nsteps + 7, cyc); atomicAdd(nsteps + 8, cyc); atomicAdd(nsteps + 9, (unsigned long long)it); atomicAdd(nsteps + 10, 1ull); atomicAdd(nsteps + 11, prof_nonpair); // ([12]: iterations with the two-decode path)
 	}
 #endif
 }

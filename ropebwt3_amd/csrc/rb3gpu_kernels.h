@@ -797,16 +797,24 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 		const int kk = (int)(w1 & 0xFF), c = (int)(w1 >> 8 & 7);
 		D[j] = 0u;
 		__builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-		for (int which = 0; which < 2; ++which) {
-			const int64_t k = which ? lo + kk : lo;
-			if (k > ix.n) continue;
-			const uint32_t koff = (uint32_t)k & (RB3_GRP - 1);
-			const uint64_t sm = ix.grp64[(k >> RB3_GRP_BITS) * 8 + 6];
-			const int64_t s = (int64_t)((uint32_t)sm + __popc((uint32_t)(sm >> 32) & ((2u << (koff >> RB3_WIN_BITS)) - 1u)) - 1u);
-			const uint4 sl = ix.slot16[s * 8 + j];
-			const uint32_t hdr0 = oct_bcast0(sl.x, j);
-			drops_from_slot(sl, hdr0, (int)koff - (int)(hdr0 & 0xFFFFu) - (which ? kk : 0), kk, c, j, D);
+		// the slots of lo and of lo + kk: both directory words first, then the slot(s) -- the interval usually lies in ONE slot,
+		// which is then read and searched once (the two dependent round trips of a rank, not four)
+		const int64_t k1 = lo + kk <= ix.n ? lo + kk : lo;
+		const uint32_t koff0 = (uint32_t)lo & (RB3_GRP - 1), koff1 = (uint32_t)k1 & (RB3_GRP - 1);
+		const uint64_t sm0 = ix.grp64[(lo >> RB3_GRP_BITS) * 8 + 6], sm1 = ix.grp64[(k1 >> RB3_GRP_BITS) * 8 + 6];
+		const int64_t s0 = (int64_t)((uint32_t)sm0 + __popc((uint32_t)(sm0 >> 32) & ((2u << (koff0 >> RB3_WIN_BITS)) - 1u)) - 1u);
+		const int64_t s1 = (int64_t)((uint32_t)sm1 + __popc((uint32_t)(sm1 >> 32) & ((2u << (koff1 >> RB3_WIN_BITS)) - 1u)) - 1u);
+		const bool two = s1 != s0 || (lo >> RB3_GRP_BITS) != (k1 >> RB3_GRP_BITS);
+		const uint4 sl0 = ix.slot16[s0 * 8 + j];
+		uint4 sl1 = sl0;
+		if (two) sl1 = ix.slot16[s1 * 8 + j];
+		{
+			const uint32_t hdr0 = oct_bcast0(sl0.x, j);
+			drops_from_slot(sl0, hdr0, (int)koff0 - (int)(hdr0 & 0xFFFFu), kk, c, j, D);
+		}
+		if (two && k1 != lo) {
+			const uint32_t hdr0 = oct_bcast0(sl1.x, j);
+			drops_from_slot(sl1, hdr0, (int)koff1 - (int)(hdr0 & 0xFFFFu) - kk, kk, c, j, D);
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();

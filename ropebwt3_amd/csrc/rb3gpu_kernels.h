@@ -1402,16 +1402,23 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check_rows(int64_t *pos, i
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n2) return;
-	if (TENT && *(volatile unsigned long long*)&bad[2] != 0) return; // the settle pass already knows it is incomplete: nothing to validate yet
+	// the settle pass already knows it is incomplete: nothing to validate yet (one answer per wave: the lanes exchange values below)
+	if (TENT && __builtin_amdgcn_readfirstlane((int)(*(volatile unsigned long long*)&bad[2] != 0)) != 0) return;
 	int64_t p = INT64_MAX, q = RB3_UNSET;
 	if (i < n2) {
 		const int64_t raw = pos[i];
 		p = TENT ? pos_final(raw, sfin, bad) : (raw < 0 ? RB3_UNSET : raw);
 		if (TENT && p != raw && p >= 0) pos[i] = p; // (an unsettled record stays as it is: a longer settle pass may still resolve it)
 	}
-	if (i > 0) {
-		const int64_t rq = pos[i - 1];
-		q = TENT ? pos_final(rq, sfin, nullptr) : (rq < 0 ? RB3_UNSET : rq); // the neighbour's own thread reports its problems
+	// the row before: from the lane below (its final value is in a register there); only lane 0 of a wave looks it up again
+	// (the neighbour's own thread reports its problems)
+	{
+		const uint32_t qlo = wave_up1((uint32_t)(uint64_t)p), qhi = wave_up1((uint32_t)((uint64_t)p >> 32));
+		if ((threadIdx.x & 63) != 0) q = (int64_t)((uint64_t)qhi << 32 | qlo);
+		else if (i > 0) {
+			const int64_t rq = pos[i - 1];
+			q = TENT ? pos_final(rq, sfin, nullptr) : (rq < 0 ? RB3_UNSET : rq);
+		}
 	}
 	bool ok = true;
 	if (i < n2) {

@@ -7,12 +7,18 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <unistd.h>
+#include <fcntl.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "rb3host.h"
 
-#define SIO_BUF 0x10000
+#define SIO_BUF 0x100000
 
 struct rb3h_seqio_s {
-	gzFile fp;
+	gzFile fp;        /* NULL: the file is not gzip-compressed and is read with read(2) (no pass through zlib's buffer) */
+	int fd;
 	int is_line, is_eof, last_char;
 	int err;          /* FASTX parsing error met (code < -1); nothing more is read from the file */
 	int beg, end;
@@ -22,6 +28,7 @@ struct rb3h_seqio_s {
 
 /* A/C/G/T -> 1..4 (either case), 0..4 stay, everything else -> 5 (io.c:12-28) */
 static uint8_t sio_nt6[256];
+static uint8_t sio_nt6c[256]; /* the complement of the nt6 code: 1<->4, 2<->3, 0 and 5 unchanged (io.c:30-40) */
 static int sio_nt6_ready = 0;
 
 static void sio_init_table(void)
@@ -31,6 +38,7 @@ static void sio_init_table(void)
 	for (i = 0; i < 256; ++i) sio_nt6[i] = i < 5 ? i : 5;
 	sio_nt6['A'] = sio_nt6['a'] = 1, sio_nt6['C'] = sio_nt6['c'] = 2;
 	sio_nt6['G'] = sio_nt6['g'] = 3, sio_nt6['T'] = sio_nt6['t'] = 4;
+	for (i = 0; i < 256; ++i) sio_nt6c[i] = (sio_nt6[i] >= 1 && sio_nt6[i] <= 4) ? 5 - sio_nt6[i] : sio_nt6[i];
 	sio_nt6_ready = 1;
 }
 
@@ -52,6 +60,48 @@ void rb3h_revcomp6(int64_t l, uint8_t *s) /* in place; 1<->4, 2<->3, 0 and 5 unc
 	if (i == j) s[i] = (s[i] >= 1 && s[i] <= 4) ? 5 - s[i] : s[i];
 }
 
+/* l characters -> nt6 codes at dfor (if not NULL) and the reverse complement at drev (if not NULL): io.c:12-40, 84-102 in one
+ * pass over the input, 16 characters at a time where SSE2 is there (a table lookup per character ran at ~1 GB/s and was the
+ * slowest stage of a build from reads).  Chunks that hold raw codes 0..4 (binary input) go through the tables. */
+static void sio_convert(const uint8_t *src, int64_t l, uint8_t *dfor, uint8_t *drev)
+{
+	int64_t i = 0;
+#if defined(__SSE2__)
+	const __m128i m_up = _mm_set1_epi8((char)0xDF), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+	const __m128i k1 = _mm_set1_epi8(1), k2 = _mm_set1_epi8(2), k3 = _mm_set1_epi8(3), k4 = _mm_set1_epi8(4), k5 = _mm_set1_epi8(5);
+	for (; i + 16 <= l; i += 16) {
+		const __m128i c = _mm_loadu_si128((const __m128i*)(src + i));
+		if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(c, k4), c)) != 0) { /* a raw code among them: the slow way */
+			int64_t q;
+			if (dfor) for (q = i; q < i + 16; ++q) dfor[q] = sio_nt6[src[q]];
+			if (drev) for (q = i; q < i + 16; ++q) drev[l - 1 - q] = sio_nt6c[src[q]];
+			continue;
+		}
+		{
+			const __m128i up = _mm_and_si128(c, m_up);
+			const __m128i a = _mm_cmpeq_epi8(up, cA), cc = _mm_cmpeq_epi8(up, cC), g = _mm_cmpeq_epi8(up, cG), t = _mm_cmpeq_epi8(up, cT);
+			if (dfor) {
+				const __m128i v = _mm_or_si128(_mm_or_si128(_mm_and_si128(a, k4), _mm_and_si128(cc, k3)), _mm_or_si128(_mm_and_si128(g, k2), _mm_and_si128(t, k1)));
+				_mm_storeu_si128((__m128i*)(dfor + i), _mm_sub_epi8(k5, v)); /* A 1, C 2, G 3, T 4, the rest 5 */
+			}
+			if (drev) {
+				const __m128i v = _mm_or_si128(_mm_or_si128(_mm_and_si128(a, k1), _mm_and_si128(cc, k2)), _mm_or_si128(_mm_and_si128(g, k3), _mm_and_si128(t, k4)));
+				__m128i x = _mm_sub_epi8(k5, v); /* A 4, C 3, G 2, T 1, the rest 5 */
+				x = _mm_or_si128(_mm_slli_epi16(x, 8), _mm_srli_epi16(x, 8)); /* reverse the 16 bytes */
+				x = _mm_shufflelo_epi16(x, _MM_SHUFFLE(0, 1, 2, 3));
+				x = _mm_shufflehi_epi16(x, _MM_SHUFFLE(0, 1, 2, 3));
+				x = _mm_shuffle_epi32(x, _MM_SHUFFLE(1, 0, 3, 2));
+				_mm_storeu_si128((__m128i*)(drev + (l - 16 - i)), x);
+			}
+		}
+	}
+#endif
+	for (; i < l; ++i) {
+		if (dfor) dfor[i] = sio_nt6[src[i]];
+		if (drev) drev[l - 1 - i] = sio_nt6c[src[i]];
+	}
+}
+
 static int buf_grow(rb3h_buf_t *b, int64_t need)
 {
 	if (need <= b->m) return 0;
@@ -62,22 +112,55 @@ static int buf_grow(rb3h_buf_t *b, int64_t need)
 	return 0;
 }
 
+/* read(2) until n bytes are there or the file ends */
+static int sio_read_full(int fd, uint8_t *buf, int n)
+{
+	int got = 0;
+	while (got < n) {
+		const ssize_t r = read(fd, buf + got, (size_t)(n - got));
+		if (r < 0) return got > 0 ? got : -1;
+		if (r == 0) break;
+		got += (int)r;
+	}
+	return got;
+}
+
 rb3h_seqio_t *rb3h_seq_open(const char *fn, int is_line)
 {
-	gzFile f = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
+	const int fd = fn && strcmp(fn, "-") ? open(fn, O_RDONLY) : dup(0);
 	rb3h_seqio_t *fp;
-	if (f == 0) return 0;
+	if (fd < 0) return 0;
 	sio_init_table();
 	fp = (rb3h_seqio_t*)calloc(1, sizeof(*fp));
-	fp->fp = f, fp->is_line = !!is_line;
+	fp->fd = fd, fp->is_line = !!is_line;
 	fp->buf = (uint8_t*)malloc(SIO_BUF);
+	/* the first bytes decide: gzip magic -> through zlib (fed the bytes already read by rewinding a regular file; a pipe
+	 * that starts with the magic goes to zlib at once), anything else -> plain read(2) */
+	fp->end = sio_read_full(fd, fp->buf, 2);
+	if (fp->end < 0) fp->end = 0;
+	if (fp->end == 2 && fp->buf[0] == 0x1f && fp->buf[1] == 0x8b) {
+		if (lseek(fd, 0, SEEK_SET) == 0) fp->fp = gzdopen(fd, "r"), fp->end = 0;
+		else { /* not seekable: zlib cannot be given the two bytes back */
+			close(fd); free(fp->buf); free(fp);
+			{
+				gzFile f = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
+				if (f == 0) return 0;
+				fp = (rb3h_seqio_t*)calloc(1, sizeof(*fp));
+				fp->fd = -1, fp->fp = f, fp->is_line = !!is_line;
+				fp->buf = (uint8_t*)malloc(SIO_BUF);
+			}
+			return fp;
+		}
+		if (fp->fp == 0) { close(fd); free(fp->buf); free(fp); return 0; }
+	}
 	return fp;
 }
 
 void rb3h_seq_close(rb3h_seqio_t *fp)
 {
 	if (fp == 0) return;
-	gzclose(fp->fp);
+	if (fp->fp) gzclose(fp->fp); /* (closes the descriptor it was opened on) */
+	else if (fp->fd >= 0) close(fp->fd);
 	free(fp->buf); free(fp->rec.s); free(fp->qual.s); free(fp);
 }
 
@@ -85,7 +168,7 @@ static int sio_fill(rb3h_seqio_t *fp)
 {
 	if (fp->is_eof) return 0;
 	fp->beg = 0;
-	fp->end = gzread(fp->fp, fp->buf, SIO_BUF);
+	fp->end = fp->fp ? gzread(fp->fp, fp->buf, SIO_BUF) : sio_read_full(fp->fd, fp->buf, SIO_BUF);
 	if (fp->end < SIO_BUF) fp->is_eof = 1;
 	if (fp->end <= 0) { fp->end = 0; return 0; }
 	return 1;
@@ -161,21 +244,12 @@ static int64_t sio_read_fastx(rb3h_seqio_t *fp)
 static int64_t sio_add(rb3h_buf_t *seq, int is_for, int is_rev, int64_t l, uint8_t *s)
 { /* io.c:84-102 */
 	int64_t n = 0;
-	rb3h_char2nt6(l, s);
+	uint8_t *df, *dr;
 	if (buf_grow(seq, seq->l + 2 * (l + 1) + 1) < 0) return -1;
-	if (is_for) {
-		memcpy(seq->s + seq->l, s, l);
-		seq->s[seq->l + l] = 0;
-		seq->l += l + 1, ++n;
-	}
-	if (is_rev) { /* reverse complement straight into the batch: 1<->4, 2<->3, 0 and 5 unchanged (io.c:30-40) */
-		static const uint8_t comp[8] = { 0, 4, 3, 2, 1, 5, 6, 7 };
-		uint8_t *d = seq->s + seq->l;
-		int64_t i;
-		for (i = 0; i < l; ++i) d[i] = comp[s[l - 1 - i] & 7];
-		d[l] = 0;
-		seq->l += l + 1, ++n;
-	}
+	df = is_for ? seq->s + seq->l : 0, dr = is_rev ? seq->s + seq->l + (is_for ? l + 1 : 0) : 0;
+	sio_convert(s, l, df, dr); /* both strands straight into the batch */
+	if (df) df[l] = 0, seq->l += l + 1, ++n;
+	if (dr) dr[l] = 0, seq->l += l + 1, ++n;
 	return n;
 }
 
@@ -185,6 +259,28 @@ int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is
 	if (!is_for && !is_rev) return -3;
 	if (fp->err) return 0; /* like the end of the file (the reference's loop ends there too, build.c:212) */
 	for (;;) {
+		/* one-sequence-per-line input whose next line lies whole in the I/O buffer (all but one line per megabyte): converted
+		 * straight from there into the batch, both strands, without the detour through the record buffer */
+		if (fp->is_line && fp->beg < fp->end) {
+			const uint8_t *src = fp->buf + fp->beg;
+			const uint8_t *nl = (const uint8_t*)memchr(src, '\n', (size_t)(fp->end - fp->beg));
+			if (nl) {
+				int64_t l = nl - src;
+				fp->beg += (int)l + 1;
+				if (l > 1 && src[l - 1] == '\r') --l; /* (as sio_getline) */
+				if (l == 0) { if (n_empty) ++*n_empty; continue; }
+				if (buf_grow(seq, seq->l + 2 * (l + 1) + 1) < 0) return -4;
+				{
+					uint8_t *df = is_for ? seq->s + seq->l : 0, *dr = is_rev ? seq->s + seq->l + (is_for ? l + 1 : 0) : 0;
+					sio_convert(src, l, df, dr);
+					if (df) df[l] = 0, seq->l += l + 1, ++n_seq;
+					if (dr) dr[l] = 0, seq->l += l + 1, ++n_seq;
+				}
+				ret = 0;
+				if (max_len > 0 && seq->l > max_len) break; /* io.c:114,119 */
+				continue;
+			}
+		}
 		ret = fp->is_line ? sio_getline(fp, &fp->rec, 0) : sio_read_fastx(fp);
 		if (ret < 0) break;
 		if (ret == 0) { /* an empty record would put two adjacent sentinels into the text, which the

@@ -2340,9 +2340,10 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
  * rope_insert_run, fm-index.c:237-249, rope.c:114-148), slot partition, run codes, header counts -- can be done on those
  * items without ever expanding a symbol.  One wave per group:
  *
- *   rows     the nb batch rows j0.. of the group as ROW RUNS r (consecutive rows with one symbol at one insertion point: the copies
- *            of a context that several relatives of one batch bring): old offset k_r (non-decreasing), first row, length;
- *            new offset q_r = k_r + rows before it
+ *   rows     the nb batch rows j0.. of the group: old offset k_r (non-decreasing), new offset q_r = k_r + r.  A row that lands strictly
+ *            inside an old run of its OWN symbol -- or behind such rows at the same insertion point -- only lengthens that run: it is
+ *            ABSORBED, i.e. it counts as an offset for everything behind it but produces no item (the usual fate of a genome
+ *            merged into its relatives; the rows are streamed 64 per pass with a running maximum deciding who is absorbed)
  *   runs     i = 0..nR-1: the old runs that intersect the group's old range [A0, A0 + 8192 - nb), clipped, start S_i
  *   items    sorted by new offset; three kinds, and each knows its own index without a search through the other list:
  *            B_r (batch row r)           offset q_r,       index r + lb_r + C(r),  lb_r = #{i : S_i < k_r}: rank in a bitmap

@@ -98,6 +98,56 @@ def test_seqio_fasta_fastq_lines(tmp_path, oracle):
     assert np.array_equal(np.concatenate([g[1] for g in got]), util.make_text([np.array([1, 2, 3], dtype=np.uint8), np.array([4, 4], dtype=np.uint8), np.array([1], dtype=np.uint8)]))
 
 
+def _nt6_restated(line):
+    """io.c:12-28 restated in numpy: A/C/G/T in either case -> 1..4, bytes 0..4 stay, everything else -> 5"""
+    t = np.full(256, 5, dtype=np.uint8)
+    t[:5] = np.arange(5)
+    for ch, v in zip(b"ACGT", (1, 2, 3, 4)):
+        t[ch] = t[ch + 32] = v
+    return t[np.frombuffer(line, dtype=np.uint8)]
+
+
+@pytest.mark.parametrize("fmt", ["lines", "fasta", "lines.gz"])
+def test_seqio_vectorised_conversion_vs_restatement(tmp_path, fmt):
+    """the reader converts 16 characters at a time (SSE2) and, for one-sequence-per-line input, straight out of its I/O buffer:
+    random records of every length around the vector width and around the 1 MB buffer boundary, with lower case, IUPAC codes,
+    arbitrary bytes, raw codes 0..4 (which io.c:12-28 leaves alone) and CRLF, against a numpy restatement of io.c:12-40,84-102
+    (forward strand + reverse complement 1<->4, 2<->3, 0 and 5 unchanged)"""
+    rng = np.random.default_rng(5)
+    recs = []
+    alph = np.frombuffer(b"ACGTacgtNnRYKM*-", dtype=np.uint8)
+    for i in range(300):
+        l = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 150, 151, 1000, 4099]))
+        r = alph[rng.integers(0, len(alph), size=l)].copy()
+        if i % 7 == 0:   # arbitrary bytes, raw codes among them (never a line feed; no '>' '@' '+' so that FASTA stays FASTA)
+            k = rng.integers(0, l, size=max(1, l // 5))
+            v = rng.integers(0, 256, size=len(k)).astype(np.uint8)
+            v[np.isin(v, np.frombuffer(b"\n\r>@+", dtype=np.uint8))] = 1
+            r[k] = v
+        recs.append(r.tobytes())
+    recs.append(bytes(alph[rng.integers(0, 8, size=(1 << 20) + 12345)]))   # longer than the reader's buffer
+    recs += [bytes(alph[rng.integers(0, 8, size=70000)]) for _ in range(40)]  # so that lines straddle the buffer boundary
+    path = tmp_path / ("in." + fmt)
+    if fmt == "fasta":
+        data = b"".join(b">r%d\n" % i + r[:len(r) // 2] + b"\n" + r[len(r) // 2:] + b"\r\n" for i, r in enumerate(recs))
+    else:
+        data = b"".join(r + (b"\r\n" if i % 3 == 0 and len(r) > 1 else b"\n") for i, r in enumerate(recs))
+    if fmt.endswith(".gz"):
+        with gzip.open(str(path), "wb") as f:
+            f.write(data)
+    else:
+        path.write_bytes(data)
+    comp = np.array([0, 4, 3, 2, 1, 5], dtype=np.uint8)
+    want = []
+    for r in recs:
+        f = _nt6_restated(r)
+        want += [f, np.zeros(1, dtype=np.uint8), comp[f[::-1]], np.zeros(1, dtype=np.uint8)]   # io.c:84-102: both strands, a sentinel each
+    want = np.concatenate(want)
+    got = list(host.read_batches(str(path), fmt != "fasta", 3000000))
+    assert sum(g[0] for g in got) == 2 * len(recs)
+    assert np.array_equal(np.concatenate([g[1] for g in got]), want)
+
+
 def test_parse_num():
     assert host.parse_num("7g") == 7000000000 and host.parse_num("500k") == 500000 and host.parse_num("2.5M") == 2500000 and host.parse_num("13") == 13
 

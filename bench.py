@@ -1,33 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- merge-path throughput of the MI355X engine (BASELINE.json metric:
-"Gbp/sec indexed (build merge)").
+"""bench.py -- merge-path throughput of the MI355X engine (BASELINE.json metric: "Gbp/sec indexed (build merge)").
 
-A STEP is one pass of the hot path over one batch: LF array of the partial BWT B2 + all LF walkers
-against the accumulated BWT B1 (rank) + interleave/rebuild of the block array, with B1 and B2
-already resident in HBM and the result discarded (commit=0) so that every step does identical work.
+HEADLINE (value, ms_per_step, config.workload, roofline, cpu_baseline) = BASELINE configs[2], the north_star's target:
+**mtb152**, 152 synthetic M. tuberculosis-like genomes of 4.4 Mbp (tools/gen_mtb.py: star phylogeny, 0.1 % substitutions +
+10 indels each), one genome per batch as the reference is run = 151 merge rounds, 1,328,837,368 symbols merged.
 
-N=1 workload = BASELINE.json configs[1] as SURVEY 8(d) defines it without network access:
-G0 = 4.4 Mbp of uniform random ACGT (seed 1), G1 = G0 with 0.1 % substitutions (seed 2); the step
-merges G1 (both strands, 8,800,002 symbols, 2 strings) into the index of G0.
+A STEP is one complete pass of the hot path over that input: the merge path of the whole build as SURVEY 8(d) defines the
+metric -- per round the H2D copy of the batch (its nt6 text, from page-locked memory) + LF array + all LF walkers (rank) +
+interleave/rebuild, summed over the 151 rounds; suffix sorting of the batch (the reference's libsais call, excluded by the
+metric's definition) runs on the GPU between the two timed parts of a round and is not counted; file I/O happens before the
+timed region.  Every timed part is bracketed by host clocks with the device idle on both sides (the upload returns after its
+stream synchronisation, a merge ends with its one synchronisation).  After the last step the index is packed into an .fmd
+on the GPU and its md5 is compared with the one the UNMODIFIED REFERENCE produced for the same 152 files
+(tests/golden/MANIFEST.json, tools/make_golden_mtb.py): `fmd_identical_to_reference`.
 
-`value` is measured through the entry point that takes exactly what the reference's
-rb3_fmi_merge_plain(r, len, seq, n_threads) takes -- the partial BWT and nothing else
-(rb3gpu_merge_plain_dev; fm-index.c:279).  The same JSON line also carries
-  * aux_entry_points: the same step with the host buffer and the PCIe copy inside (rb3gpu_merge_plain), and through the
-    entry points that take the inverse suffix array of the batch next to its BWT (what the CLI uses: its batches are
-    suffix-sorted on the GPU, so the inverse suffix array is in HBM anyway);
-  * target_workload: BASELINE configs[2] (mtb152: 152 genomes of 4.4 Mbp, synthetic star of tools/gen_mtb.py) end to end
-    through `ropebwt3-amd build`, one file per batch as the reference is run, .fmd md5 checked against the reference's
-    (tests/golden/MANIFEST.json), with the merge-path time, the whole-build time and per-kernel rooflines, next to the
-    unmodified reference timed here on a stated prefix of the same files;
-  * aux_reads_regime / aux_large_index: the chain kernel where it is bound by memory rather than latency, the second on
-    an index far larger than L2 + Infinity Cache.
+The same JSON line also carries: `roofline` (dominant kernel k_chain<mixed>: 208 B x LF steps / its HIP-event time; traffic
+from the committed rocprofv3 --pmc passes), `roofline_path` (SURVEY 8(d)'s whole-path formula), `cpu_baseline` (the unmodified
+reference binary timed here on a stated prefix of the same files), and auxiliary legs, each labelled: the whole build through
+the CLI (sorting overlapped, wall clock), BASELINE configs[1] (one genome into one: the former headline), the reads regime and
+the HBM-resident large index.
 
-N>1 (weak scaling, one process per GPU): see ropebwt3_amd/multi.py -- interval-sharded index (north_star) or partitioned
-input + tree merge; value = symbols merged by all ranks / max-over-ranks time of the whole sharded step.
+N > 1 (python bench.py --gpus N starts its N ranks itself; under torch.distributed.run it uses the ranks it is given): the SAME
+build, partitioned -- rank r builds the index of its contiguous slice of the 152 genomes, then the slices are combined by a
+binary tree of whole-index merges over RCCL (ropebwt3_amd/multi.py); one step = the whole partitioned build, same md5 gate,
+`scaling` = "strong" (the job is fixed: one mtb152 index).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
 import hashlib
@@ -60,34 +58,9 @@ def gen_genomes(n, rate, seed0, seeds):
     return g0, [util.mutate(np.random.default_rng(s), g0, rate) for s in seeds]
 
 
-def cpu_baseline(b1, b2):
-    """Time the merge of the SAME step on the host cores: the unmodified reference
-    (oracle/_ref/librb3ref.so: rb3_enc_plain2fmr + rb3_fmi_merge_plain) when it travelled with
-    the repository, else the OpenMP port in oracle/liboracle.so.  Checker/baseline only."""
-    from tests import util
-    cores = os.cpu_count() or 1
-    try:
-        ref = util.Reference()
-        r = ref.L.rb3_enc_plain2fmr(b1.size, b1.ctypes.data, 0, 0, cores)
-        t = time.time()
-        ref.L.rb3_fmi_merge_plain(r, b2.size, b2.ctypes.data, cores)
-        dt = time.time() - t
-        ref.L.mr_destroy(r)
-        kind = "reference"
-    except (FileNotFoundError, OSError):
-        orc = util.Oracle()
-        t = time.time()
-        orc.mg_rank(b1, b2, cores)
-        dt = time.time() - t
-        kind = "port"
-    n_str = int((b2 == 0).sum())
-    return {"value": b2.size / dt / 1e9, "unit": "Gbp/s", "cores": cores, "kind": kind, "seconds": round(dt, 3),
-            "sample": "the full N=1 step (%d symbols, %d strings -> only %d of the %d threads offered have work, as in the reference's kt_for over strings)" % (b2.size, n_str, min(n_str, cores), cores)}
-
-
 def load_pmc_traffic(kernel):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/), if any."""
-    for fn in ("r2_pmc_%s.json" % kernel, "r1_pmc_%s.json" % kernel):
+    for fn in ("r3_pmc_%s.json" % kernel, "r2_pmc_%s.json" % kernel, "r1_pmc_%s.json" % kernel):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", fn))).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
@@ -209,18 +182,135 @@ def parse_cli_stats(err):
     return d
 
 
-def target_workload(K, L, ref_prefix, keep=None):
-    """BASELINE configs[2] end to end through the CLI."""
-    from tools import gen_mtb
-    from ropebwt3_amd import _build
+
+# ---------------------------------------------------------------------------------------------
+# the headline workload: mtb152, in process through the C ABI
+# ---------------------------------------------------------------------------------------------
+
+MTB_L = 4400000
+WALKER_STEP = 384
+
+
+def mtb_manifest(K, L):
     man = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST.json"))).get("mtb_star", {})
-    gold = man.get("prefixes", {}).get(str(K)) if L == man.get("genome_len") else None
-    tmp = keep or tempfile.mkdtemp(prefix="rb3_mtb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    return man.get("prefixes", {}).get(str(K)) if L == man.get("genome_len") else None
+
+
+def mtb_files(K, L, tmp=None):
+    from tools import gen_mtb
+    tmp = tmp or tempfile.mkdtemp(prefix="rb3_mtb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     t = time.time()
     files = gen_mtb.generate(K, L, tmp)
-    t_gen = time.time() - t
+    return tmp, files, time.time() - t
+
+
+def load_batches(files, pinned=True):
+    """every file through the CLI's own reader (rb3h_seq_read: nt6, both strands, sentinels; io.c:104-125), one batch per
+    file, into page-locked memory (what `ropebwt3-amd build` does with rb3gpu_pinned_alloc) + the walker list of each batch
+    (one walker per string + one per 384 text positions, rb3h_walkers_text).  Not timed: file I/O is outside the metric."""
+    from ropebwt3_amd import PinnedArray, host
+    texts, walkers, keep = [], [], []
+    for fn in files:
+        parts = [t for _, t in host.read_batches(fn, False, 1 << 40)]
+        t = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        if pinned:
+            pa = PinnedArray(t.size)
+            pa.array[:] = t
+            keep.append(pa)
+            t = pa.array
+        texts.append(t)
+        walkers.append(host.walkers_text(t, WALKER_STEP))
+    return texts, walkers, keep
+
+
+class BuildLoop:
+    """`ropebwt3-amd build` of a list of batches in this process, one call of the C ABI per stage so that the stages can be
+    timed apart: rb3gpu_sorter_upload (H2D, timed) -> rb3gpu_sorter_sort_uploaded (suffix sorting: not part of the metric) ->
+    rb3gpu_from_plain_dev for the first batch / rb3gpu_merge_text_dev for every later one (timed)."""
+
+    def __init__(self, device):
+        from ropebwt3_amd import Rb3Gpu, Sorter
+        self.h = Rb3Gpu(device=device, verbose=1)
+        self.srt = Sorter(device)
+
+    def run(self, texts, walkers, first_is_index=True):
+        """returns (seconds H2D, seconds merge, seconds sort, symbols merged, wall seconds) of one build"""
+        h, srt = self.h, self.srt
+        t_h2d = t_mrg = t_sort = 0.0
+        nsym = 0
+        w0 = time.perf_counter()
+        for i, (t, w) in enumerate(zip(texts, walkers)):
+            a = time.perf_counter()
+            srt.upload(t)                                   # returns after the stream synchronisation
+            b = time.perf_counter()
+            d_bwt, d_tw = srt.sort_uploaded(t.size)         # (synchronous)
+            c = time.perf_counter()
+            if i == 0 and first_is_index:
+                h.from_plain_dev(d_bwt, t.size)             # rb3_enc_plain2fmr: the first batch is encoded, not merged
+            else:
+                h.merge_text_dev(d_bwt, d_tw, t.size, w, commit=True)   # one synchronisation, at its end
+                d = time.perf_counter()
+                t_h2d += b - a
+                t_mrg += d - c
+                nsym += t.size
+            t_sort += c - b
+            srt.release(d_bwt)
+        return t_h2d, t_mrg, t_sort, nsym, time.perf_counter() - w0
+
+    def fmd_md5(self):
+        from ropebwt3_amd import host
+        data = host.fmd_bytes_from_words(self.h.export_fmd_words(), self.h.get_acc())
+        return hashlib.md5(data).hexdigest(), len(data)
+
+    def close(self):
+        self.srt.close()
+        self.h.close()
+
+
+def reference_prefix(files, n_ref, K):
+    """cpu_baseline of the headline: the UNMODIFIED reference binary (oracle/_ref/ropebwt3, built by oracle/Makefile from the
+    sources under /root/reference; it travels with the repository) on the first n_ref of the same files, merge-only seconds by
+    its own timers, next to this engine on the same prefix."""
+    from ropebwt3_amd import _build
+    ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
+    if n_ref < 2 or not os.path.exists(ref):
+        return None
+    cores = os.cpu_count() or 1
+    nthr = min(cores, 64)
+    t = time.time()
+    rr = subprocess.run([ref, "build", "-d", "-t%d" % nthr] + files[:n_ref], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    dt = time.time() - t
+    tot, last, nsr = 0.0, None, 0
+    for l in rr.stderr.decode().splitlines():
+        m = re.match(r"\[M::\w+::([0-9.]+)\*", l)
+        if not m:
+            continue
+        if "constructed partial BWT" in l:
+            last = float(m.group(1))
+        elif "inserted" in l and last is not None:
+            tot += float(m.group(1)) - last
+            last = None
+            nsr += int(re.search(r"inserted (\d+) symbols", l).group(1))
+    ra = subprocess.run([_build.BIN_CLI, "build", "-d"] + files[:n_ref], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    sa = parse_cli_stats(ra.stderr.decode())
+    gold = mtb_manifest(K, MTB_L)
+    out = {"value": round(nsr / tot / 1e9, 6) if tot > 0 else None, "unit": "Gbp/s", "cores": cores, "kind": "reference",
+           "sample": "`ropebwt3 build -d -t%d` (oracle/_ref, unmodified) on the first %d of the %d files: merge-only seconds by its own timers ('inserted' minus 'constructed partial BWT', summed over %d rounds) %.2f s of %.1f s; rb3_fmi_merge_plain has one chain per string, i.e. 2 threads of work per round whatever -t says" % (nthr, n_ref, K, n_ref - 1, tot, dt),
+           "merge_only_seconds": round(tot, 3), "symbols_merged": nsr, "identical_fmd": hashlib.md5(rr.stdout).hexdigest() == hashlib.md5(ra.stdout).hexdigest(),
+           "same_prefix_on_the_gpu": {"merge_path_ms_incl_h2d": round(sa.get("merge_path_ms", 0) + sa.get("text_upload_ms", 0), 3) if sa.get("merge_path_ms") else None,
+                                      "speedup_merge_path": round(tot * 1e3 / (sa.get("merge_path_ms", 0) + sa.get("text_upload_ms", 0)), 1) if sa.get("merge_path_ms") else None}}
+    if gold:
+        out["recorded_full_run"] = {"reference_seconds": gold.get("reference_seconds"), "reference_merge_only_seconds": gold.get("reference_merge_only_seconds"), "threads": gold.get("reference_threads"),
+                                    "where": "the build container (8 cores), tools/make_golden_mtb.py; not re-timed here"}
+    return out
+
+
+def cli_build(files, K, gold):
+    """the whole build through the CLI (reader thread, GPU sorter thread and merges overlapped; wall clock incl. process start,
+    file reading and FMD writing) + the same files re-batched"""
+    from ropebwt3_amd import _build
     best = None
-    for rep in range(2):   # the first run pays for the page cache and the HIP start-up; report the second
+    for _ in range(2):   # the first run pays for the page cache and the HIP start-up; report the second
         t = time.time()
         r = subprocess.run([_build.BIN_CLI, "build", "-d"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         wall = time.time() - t
@@ -230,238 +320,215 @@ def target_workload(K, L, ref_prefix, keep=None):
     wall, r = best
     md5 = hashlib.md5(r.stdout).hexdigest()
     st = parse_cli_stats(r.stderr.decode())
-    nsym = st.get("symbols_merged", 0)
-    mp = st.get("merge_path_ms", 0.0)
-    up = st.get("text_upload_ms", 0.0)
-    out = {"workload": "cfg3-synthetic-mtb%d: `ropebwt3-amd build -d g000.fa ... g%03d.fa`, %d genomes of %d bp (star phylogeny, 0.1 %% substitutions + 10 indels each; tools/gen_mtb.py), one file per batch = %d merge rounds" % (K, K - 1, K, L, K - 1),
-           "symbols_merged": nsym, "fmd_bytes": len(r.stdout), "fmd_md5": md5,
-           "fmd_identical_to_reference": (md5 == gold["fmd_md5"]) if gold else None,
-           "reference_fmd_md5_source": "tests/golden/MANIFEST.json mtb_star/%d (oracle/_ref/ropebwt3, tools/make_golden_mtb.py)" % K if gold else "no golden for this size",
-           "build_wall_s": round(wall, 3), "generate_s": round(t_gen, 2),
-           "merge_path": {"ms": round(mp, 3), "Gbp/s": round(nsym / mp / 1e6, 4) if mp else None,
-                          "ms_incl_text_upload": round(mp + up, 3), "Gbp/s_incl_text_upload": round(nsym / (mp + up) / 1e6, 4) if mp else None,
-                          "phases_ms": {"text_upload(H2D)": up, "lf": st.get("lf_ms"), "rank": st.get("rank_ms"), "rebuild": st.get("rebuild_ms")},
-                          "definition": "SURVEY 8(d): H2D + rank + interleave + rebuild summed over the rounds, suffix sorting and file I/O excluded; with GPU suffix sorting the H2D of a batch is its text upload (the BWT never crosses PCIe)"},
-           "suffix_sorting_ms_overlapped": st.get("sort_ms"), "index_mb": st.get("index_mb"), "batches_sorted_on_gpu": st.get("batches_gpu"), "batches_sorted_on_host": st.get("batches_host")}
-    # (b) of SURVEY 8(d) config 3: the same files re-batched (a batch spans input files: ~16 rounds instead of 151); same .fmd
+    out = {"command": "ropebwt3-amd build -d g000.fa ... g%03d.fa" % (K - 1), "build_wall_s": round(wall, 3), "fmd_md5": md5, "fmd_identical_to_reference": (md5 == gold["fmd_md5"]) if gold else None,
+           "merge_path_ms": st.get("merge_path_ms"), "text_upload_ms": st.get("text_upload_ms"), "phases_ms": {"lf": st.get("lf_ms"), "rank": st.get("rank_ms"), "rebuild": st.get("rebuild_ms")},
+           "suffix_sorting_ms_overlapped": st.get("sort_ms"), "k_chain_ms": st.get("chain_ms"), "index_mb": st.get("index_mb"),
+           "batches_sorted_on_gpu": st.get("batches_gpu"), "batches_sorted_on_host": st.get("batches_host"),
+           "note": "merges run beside the sorter thread's kernels here, so the per-phase times are longer than in the headline, whose stages run one at a time"}
     t = time.time()
     rb = subprocess.run([_build.BIN_CLI, "build", "-d", "--rebatch", "-m80m"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     wall_b = time.time() - t
     if rb.returncode == 0:
         sb = parse_cli_stats(rb.stderr.decode())
         out["rebatched"] = {"command": "ropebwt3-amd build -d --rebatch -m80m (9-10 genomes per batch)", "build_wall_s": round(wall_b, 3), "merge_rounds": sb.get("chain_launches"),
-                            "merge_path_ms": sb.get("merge_path_ms"), "phases_ms": {"text_upload(H2D)": sb.get("text_upload_ms"), "lf": sb.get("lf_ms"), "rank": sb.get("rank_ms"), "rebuild": sb.get("rebuild_ms")},
-                            "Gbp/s_merge_path": round(sb.get("symbols_merged", 0) / sb["merge_path_ms"] / 1e6, 4) if sb.get("merge_path_ms") else None,
-                            "fmd_identical": hashlib.md5(rb.stdout).hexdigest() == md5}
-    if st.get("chain_ms") and st.get("chain_launches"):
-        rows = nsym / max(1, st["chain_launches"])
-        ms = st["chain_ms"] / st["chain_launches"]
-        out["roofline_k_chain_mixed"] = chain_roofline(int(rows), ms, "text", None, "k_chain<list,mixed,tent,text>: average over the %d merge rounds (run-coded index, intervals of up to 152 matching suffixes); VALU-bound at ~250 vector instructions per 8-walker step (profiles/r2_sq_mtb*.txt)" % st["chain_launches"])
-    if st.get("rebuild_algo_bytes") and st.get("rebuild_ms"):
-        gbs = st["rebuild_algo_bytes"] / st["rebuild_ms"] / 1e6
-        out["roofline_rebuild"] = {"bound": "hbm", "kernel": "k_reb_group + k_place (+ window kernels on the groups they leave)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-                                   "algorithmic_bytes": st["rebuild_algo_bytes"], "ms": st["rebuild_ms"], "note": "streaming roofline: 9 B per batch row + old block array + new block array per round, summed over the rounds"}
-    # the unmodified reference on a prefix of the same files (the whole set takes 826 s on 8 cores: recorded in the manifest)
-    ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
-    if ref_prefix > 1 and os.path.exists(ref):
-        cores = os.cpu_count() or 1
-        t = time.time()
-        rr = subprocess.run([ref, "build", "-d", "-t%d" % min(cores, 64)] + files[:ref_prefix], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        dt = time.time() - t
-        tot, last, nsr = 0.0, None, 0
-        for l in rr.stderr.decode().splitlines():
-            m = re.match(r"\[M::\w+::([0-9.]+)\*", l)
-            if not m:
-                continue
-            if "constructed partial BWT" in l:
-                last = float(m.group(1))
-            elif "inserted" in l and last is not None:
-                tot += float(m.group(1)) - last
-                last = None
-                nsr += int(re.search(r"inserted (\d+) symbols", l).group(1))
-        ra = subprocess.run([_build.BIN_CLI, "build", "-d"] + files[:ref_prefix], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        sa = parse_cli_stats(ra.stderr.decode())
-        out["cpu_baseline"] = {"value": round(nsr / tot / 1e9, 6) if tot > 0 else None, "unit": "Gbp/s", "cores": cores, "kind": "reference",
-                               "sample": "`ropebwt3 build -d -t%d` (oracle/_ref, unmodified) on the first %d of the %d files: merge-only seconds (its own timers: 'inserted' minus 'constructed partial BWT', summed over %d rounds) %.2f s of %.1f s; rb3_fmi_merge_plain has one chain per string, i.e. 2 threads of work per round" % (min(cores, 64), ref_prefix, K, ref_prefix - 1, tot, dt),
-                               "merge_only_seconds": round(tot, 3), "symbols_merged": nsr, "identical_fmd": hashlib.md5(rr.stdout).hexdigest() == hashlib.md5(ra.stdout).hexdigest(),
-                               "same_prefix_on_the_gpu": {"merge_path_ms": sa.get("merge_path_ms"), "text_upload_ms": sa.get("text_upload_ms"),
-                                                          "speedup_merge_path_incl_upload": round(tot * 1e3 / (sa.get("merge_path_ms", 0) + sa.get("text_upload_ms", 0)), 1) if sa.get("merge_path_ms") else None}}
-        if gold:
-            out["cpu_baseline"]["recorded_full_run"] = {"reference_seconds": gold.get("reference_seconds"), "reference_merge_only_seconds": gold.get("reference_merge_only_seconds"), "threads": gold.get("reference_threads"),
-                                                        "where": "the build container (8 cores), tools/make_golden_mtb.py; not re-timed here"}
-    if not keep:
-        for f in files:
-            os.unlink(f)
-        try:
-            os.rmdir(tmp)
-        except OSError:
-            pass
+                            "merge_path_ms": sb.get("merge_path_ms"), "text_upload_ms": sb.get("text_upload_ms"), "fmd_identical": hashlib.md5(rb.stdout).hexdigest() == md5}
     return out
+
+
+def cfg2_step(local_rank, steps, warmup, genome_len, div):
+    """BASELINE configs[1] (the headline of rounds 1-2): one genome merged into the index of one, through the entry point with
+    the reference's signature (BWT only) and through the one the CLI uses (BWT + inverse suffix array from the GPU sorter)"""
+    from ropebwt3_amd import Rb3Gpu, host
+    from tests import util
+    g0, gs = gen_genomes(genome_len, div, 1, [2])
+    b1 = host.build_bwt(util.make_text([g0]))
+    text2 = util.make_text(gs)
+    w_text = host.walkers_text(text2, WALKER_STEP)
+    h = Rb3Gpu(device=local_rank, verbose=1)
+    h.from_plain(b1)
+    d_b2s, d_tw = h.sort_text(text2)
+    out = {"workload": "cfg2-synthetic-mtb1: merge G1 = G0 + 0.1%% substitutions (%d bp, both strands, %d symbols, 2 strings) into the index of G0 (%d symbols); batch resident in HBM, commit=0" % (genome_len, text2.size, b1.size)}
+    for name, fn in (("rb3gpu_merge_plain_dev (reference's signature: BWT only, walker list made on the device)", lambda: h.merge_plain_dev(d_b2s, text2.size, commit=False)),
+                     ("rb3gpu_merge_text_dev (BWT + inverse suffix array as the GPU sorter leaves them: the CLI's path)", lambda: h.merge_text_dev(d_b2s, d_tw, text2.size, w_text, commit=False))):
+        for _ in range(warmup):
+            fn()
+        h.sync()
+        h.stats_reset()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        h.sync()
+        e = (time.perf_counter() - t) / steps
+        s = h.stats()
+        out[name] = {"ms_per_step": round(e * 1e3, 4), "Gbp/s": round(text2.size / e / 1e9, 3), "k_chain_ms": round(s["ms_chain"] / max(1, s["n_rank_launches"]), 4),
+                     "frac_of_208B_roofline": round(ALGO_BYTES_PER_STEP * text2.size / (s["ms_chain"] / max(1, s["n_rank_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "rank_phase_fallbacks": int(s["n_fallbacks"])}
+    hs = Rb3Gpu(device=local_rank, verbose=1)   # host buffer + PCIe copy inside the call (pageable memory, staged): one call on a warm handle
+    hs.from_plain(b1)
+    b2 = h.dev_download(d_b2s, text2.size)
+    hs.mg_rank_plain(b2)
+    hs.stats_reset()
+    t = time.perf_counter()
+    hs.merge_plain(b2)
+    e = time.perf_counter() - t
+    out["rb3gpu_merge_plain (host buffer: the PCIe copy of %d bytes from pageable memory is inside the call)" % b2.size] = {"ms": round(e * 1e3, 4), "h2d_ms": round(hs.stats()["ms_h2d"], 4)}
+    hs.close()
+    h.dev_free(d_b2s)
+    h.dev_free(d_tw)
+    h.close()
+    return out
+
+
+def self_launch(args):
+    """python bench.py --gpus N without a launcher: start the N ranks here (torch.distributed.run, one process per GPU)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["RB3_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--genome-len", type=int, default=4400000)
+    ap.add_argument("--steps", type=int, default=3, help="timed steps; a step = the merge path of one whole mtb152 build (151 merge rounds)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mtb", type=int, default=152, help="genomes of the headline workload (152 = BASELINE configs[2]; 24 has a golden md5 too)")
+    ap.add_argument("--genome-len", type=int, default=MTB_L)
     ap.add_argument("--div", type=float, default=0.001)
-    ap.add_argument("--walker-step", type=int, default=384, help="text distance between LF walkers handed to the engine (entry points that take them)")
-    ap.add_argument("--entry", choices=["plain", "rows", "text"], default="plain",
-                    help="plain: rb3gpu_merge_plain_dev, the reference's signature (default, = value); rows: + sampled inverse suffix array; text: + inverse suffix array (the CLI's path)")
-    ap.add_argument("--plain-abi", action="store_true", help="same as --entry plain")
-    ap.add_argument("--row-words", action="store_true", help="same as --entry rows")
-    ap.add_argument("--mode", choices=["interval", "partition", "replicated"], default=None,
-                    help="how the work is split over the GPUs (ropebwt3_amd/multi.py); N>1 default: interval (north_star).  With N=1, --mode interval runs the same sharded step on one GPU")
+    ap.add_argument("--mode", choices=["partition", "interval", "replicated"], default=None,
+                    help="N > 1: how the work is split over the GPUs (ropebwt3_amd/multi.py); default partition = the same mtb152 build, partitioned + tree merge")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary measurements (entry points, reads regime, large index)")
-    ap.add_argument("--no-target", action="store_true", help="skip the mtb152 end-to-end leg")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (CLI build, configs[1], reads regime, large index)")
+    ap.add_argument("--no-pinned", action="store_true", help="batches in pageable host memory (staged upload)")
     ap.add_argument("--aux-reads", type=int, default=100000)
     ap.add_argument("--large-index", type=int, default=1 << 30, help="symbols of the index of the large-index leg (0: skip)")
-    ap.add_argument("--only", choices=["large", "reads", "target"], default=None, help="run one auxiliary leg alone and print its JSON (profiling)")
-    ap.add_argument("--mtb", type=int, default=152, help="genomes of the target-workload leg")
-    ap.add_argument("--mtb-ref-prefix", type=int, default=6, help="files the reference binary is timed on (cpu_baseline of the target workload)")
+    ap.add_argument("--only", choices=["large", "reads", "cfg2", "cli", "headline"], default=None, help="run one leg alone and print its JSON (profiling)")
+    ap.add_argument("--mtb-ref-prefix", type=int, default=6, help="files the reference binary is timed on (cpu_baseline)")
+    ap.add_argument("--walker-step", type=int, default=WALKER_STEP)
     args = ap.parse_args()
-    if args.plain_abi:
-        args.entry = "plain"
-    if args.row_words:
-        args.entry = "rows"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    if world > 1:
         args.gpus = world
 
     import torch
-    from ropebwt3_amd import Rb3Gpu, host
-    from tests import util
+    from ropebwt3_amd import Rb3Gpu
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False and the engine has no CPU fallback")
     if world > 1 or args.mode is not None:
         from ropebwt3_amd import multi
-        args.mode = args.mode or "interval"
+        args.mode = args.mode or "partition"
         return multi.bench_main(args, rank, local_rank, world)
     torch.cuda.set_device(local_rank)
-    if args.only:
-        mk = lambda: Rb3Gpu(device=local_rank, verbose=1)
+    mk = lambda: Rb3Gpu(device=local_rank, verbose=1)
+    if args.only in ("large", "reads", "cfg2"):
         print(json.dumps(large_index_regime(mk, args.large_index, 1000000) if args.only == "large" else reads_regime(mk, args.aux_reads) if args.only == "reads" else
-                         target_workload(args.mtb, 4400000, 0 if args.no_cpu_baseline else args.mtb_ref_prefix)), flush=True)
+                         cfg2_step(local_rank, 10, 3, args.genome_len, args.div)), flush=True)
         return
 
+    K, L = args.mtb, args.genome_len
+    gold = mtb_manifest(K, L)
+    tmp, files, t_gen = mtb_files(K, L)
+    if args.only == "cli":
+        print(json.dumps(cli_build(files, K, gold)), flush=True)
+        return
     t0 = time.time()
-    g0, gs = gen_genomes(args.genome_len, args.div, 1, [2])
-    b1 = host.build_bwt(util.make_text([g0]))
-    text2 = util.make_text(gs)
-    b2, w_rows = host.build_bwt_walkers(text2.copy(), args.walker_step)
-    w_text = host.walkers_text(text2, args.walker_step)
-    log("inputs: B1 %d symbols, B2 %d symbols; host suffix sorting %.1f s (not timed)" % (b1.size, b2.size, time.time() - t0))
+    texts, walkers, keep = load_batches(files, pinned=not args.no_pinned)
+    nsym_all = int(sum(t.size for t in texts))
+    log("mtb%d: %d files generated in %.1f s, read into %s memory in %.1f s (%d symbols)" % (K, K, t_gen, "pageable" if args.no_pinned else "page-locked", time.time() - t0, nsym_all))
 
-    h = Rb3Gpu(device=local_rank, verbose=1)
-    h.from_plain(b1)
-    d_b2 = h.dev_upload(b2)
-    d_b2s, d_tw = h.sort_text(text2)   # the batch as the GPU suffix sorter leaves it in HBM: BWT + inverse suffix array
-    assert np.array_equal(h.dev_download(d_b2s, b2.size), b2), "GPU and host suffix sorters disagree"
-
-    steps = {"plain": lambda commit=False: h.merge_plain_dev(d_b2, b2.size, commit=commit),
-             "rows": lambda commit=False: h.merge_plain_dev_walkers(d_b2, b2.size, w_rows, commit=commit),
-             "text": lambda commit=False: h.merge_text_dev(d_b2s, d_tw, b2.size, w_text, commit=commit)}
-    names = {"plain": "rb3gpu_merge_plain_dev (the reference's signature rb3_fmi_merge_plain(r, len, bwt): BWT only; the text-regular walker list is made on the device inside the step)",
-             "rows": "rb3gpu_merge_plain_dev_walkers (BWT + inverse suffix array sampled every %d text positions, as a host suffix sorter has it; %d walkers)" % (args.walker_step, len(w_rows)),
-             "text": "rb3gpu_merge_text_dev (BWT + inverse suffix array of the batch, both as the GPU suffix sorter leaves them in HBM: the CLI's path; %d walkers)" % len(w_text)}
-    step = steps[args.entry]
-
-    def barrier():
-        h.sync()
-        torch.cuda.synchronize()
-
+    bl = BuildLoop(local_rank)
     for _ in range(args.warmup):
-        step()
-    h.stats_reset()
-    barrier()
-    t = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    h.sync()
+        bl.run(texts, walkers)
+    bl.h.sync()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t
-    st = h.stats()
-
-    def timed(fn, reps=10):
-        fn()
-        h.sync()
-        h.stats_reset()
-        t = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        h.sync()
-        e = (time.perf_counter() - t) / reps
-        s = h.stats()
-        return e, s["ms_chain"] / max(1, s["n_rank_launches"]), s["n_fallbacks"]
-
-    aux = {}
-    if not args.no_aux:
-        for k in ("plain", "rows", "text"):
-            e, c, fb = timed(steps[k])
-            aux[names[k]] = {"ms_per_step": round(e * 1e3, 4), "Gbp/s": round(b2.size / e / 1e9, 3), "k_chain_ms": round(c, 4), "rank_phase_fallbacks": int(fb)}
-        # the same signature with the batch in HOST memory (rb3gpu_merge_plain commits, so it is timed once, on a scratch handle
-        # whose pinned staging buffers exist already): PCIe-inclusive, never `value`
-        hs = Rb3Gpu(device=local_rank, verbose=1)
-        hs.from_plain(b1)
-        hs.mg_rank_plain(b2)
-        hs.stats_reset()
-        t = time.perf_counter()
-        hs.merge_plain(b2)
-        e = time.perf_counter() - t
-        ss = hs.stats()
-        hs.close()
-        aux["rb3gpu_merge_plain (the same signature with the batch in HOST memory: the PCIe copy of %d bytes, through pinned staging buffers, is inside the call; one call)" % b2.size] = {
-            "ms_per_step": round(e * 1e3, 4), "Gbp/s": round(b2.size / e / 1e9, 3), "h2d_ms": round(ss["ms_h2d"], 4), "note": "PCIe-inclusive; never `value`"}
-
-    # one committed merge, to make sure the timed path produces a consistent index
-    step(commit=True)
-    acc = h.get_acc()
-    assert acc[6] == b1.size + b2.size
-
-    sym_per_step = b2.size
-    value = sym_per_step * args.steps / dt / 1e9
+    bl.h.stats_reset()
+    tot_h2d = tot_mrg = tot_sort = tot_wall = 0.0
+    nsym = 0
+    for _ in range(args.steps):
+        a, b, c, n, w = bl.run(texts, walkers)
+        tot_h2d, tot_mrg, tot_sort, tot_wall, nsym = tot_h2d + a, tot_mrg + b, tot_sort + c, tot_wall + w, nsym + n
+    bl.h.sync()
+    torch.cuda.synchronize()
+    st = bl.h.stats()
+    md5, fmd_len = bl.fmd_md5()
+    ident = (md5 == gold["fmd_md5"]) if gold else None
+    if ident is False:
+        log("ERROR: the .fmd differs from the reference's (md5 %s vs %s)" % (md5, gold["fmd_md5"]))
+    S = args.steps
+    dt = tot_h2d + tot_mrg
+    sym_step = nsym // S
     ms_chain = st["ms_chain"] / max(1, st["n_rank_launches"])
+    rows_launch = nsym / max(1, st["n_rank_launches"])
+    path_bytes = 217 * nsym + (st["bytes_rebuild"] - 9 * nsym)      # SURVEY 8(d): 217 B x len + bytes(B1 old) + bytes(B1 new) per round
     out = {
-        "metric": "Gbp/s indexed (build merge)", "value": round(value, 6), "unit": "Gbp/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": "cfg2-synthetic-mtb1: merge G1 = G0 + 0.1%% substitutions (%d bp, both strands, %d symbols, 2 strings) into the index of G0 (%d symbols)" % (args.genome_len, b2.size, b1.size),
-                   "symbols_per_step_per_gpu": int(b2.size), "index_symbols": int(b1.size), "parallelism": "single GPU",
-                   "entry_point": names[args.entry], "inputs_resident_in_hbm": True,
-                   "lf_steps_per_step": int(st["n_lf_steps"] // max(1, args.steps)), "rank_phase_fallbacks": int(st["n_fallbacks"]),
-                   "chain_launches_per_step": round(st["n_rank_launches"] / max(1, args.steps), 2)},
-        "phases_ms_per_step": {"lf": round(st["ms_lf"] / args.steps, 4), "rank": round(st["ms_rank"] / args.steps, 4),
-                               "rebuild": round(st["ms_build"] / args.steps, 4)},
-        "roofline": chain_roofline(b2.size, ms_chain, args.entry, load_pmc_traffic("k_chain"),
-                                   "latency-bound regime (2 strings = 2 dependent chains in the reference; here ~23-34 k walkers of a few hundred steps): per step one 128-B slot line and one 8-B record at random rows; "
-                                   "`achieved` prices SURVEY 8(d)'s 208 B/step, `achieved_engine` the bytes this engine issues, `achieved_counter` the FETCH_SIZE/WRITE_SIZE traffic of profiles/ over the same duration; "
-                                   "the index (4.4 MB) sits in L2/Infinity Cache here -- aux_large_index is the HBM-resident case"),
+        "metric": "Gbp/s indexed (build merge)", "value": round(nsym / dt / 1e9, 6), "unit": "Gbp/s",
+        "n_gpus": 1, "steps": S, "warmup": args.warmup, "ms_per_step": round(dt / S * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "cfg3-synthetic-mtb%d: %d genomes of %d bp (star phylogeny, 0.1 %% substitutions + 10 indels each; tools/gen_mtb.py), one genome per batch = %d merge rounds per step, %d symbols merged per step; merge path incl. H2D (SURVEY 8(d))" % (K, K, L, K - 1, sym_step),
+                   "symbols_per_step": int(sym_step), "merge_rounds_per_step": K - 1, "index_symbols_final": nsym_all, "index_mb_final": round(st["bytes_index"] / 1e6, 1), "parallelism": "single GPU",
+                   "entry_points": "rb3gpu_sorter_upload (H2D of the batch text, page-locked source) + rb3gpu_merge_text_dev (LF + walkers + settle + validation + rebuild, commit=1); rb3gpu_sorter_sort_uploaded between them is not counted (suffix sorting: excluded by the metric)",
+                   "fmd_md5": md5, "fmd_bytes": fmd_len, "fmd_identical_to_reference": ident,
+                   "reference_fmd_md5_source": "tests/golden/MANIFEST.json mtb_star/%d (oracle/_ref/ropebwt3 = the unmodified reference, tools/make_golden_mtb.py)" % K if gold else "no golden for this size",
+                   "lf_steps_per_step": int(st["n_lf_steps"] // S), "rank_phase_fallbacks": int(st["n_fallbacks"]), "long_settles": int(st["n_long_settles"])},
+        "phases_ms_per_step": {"h2d": round(tot_h2d / S * 1e3, 3), "merge_calls": round(tot_mrg / S * 1e3, 3), "lf": round(st["ms_lf"] / S, 3), "rank": round(st["ms_rank"] / S, 3), "k_chain": round(st["ms_chain"] / S, 3),
+                               "rebuild": round(st["ms_build"] / S, 3), "host_and_sync_inside_merge_calls": round((tot_mrg * 1e3 - st["ms_lf"] - st["ms_rank"] - st["ms_build"]) / S, 3)},
+        "not_counted_ms_per_step": {"suffix_sorting_on_the_gpu": round(tot_sort / S * 1e3, 3), "wall_of_the_whole_loop": round(tot_wall / S * 1e3, 3)},
+        "h2d": {"bytes_per_step": int(sym_step), "GB/s": round(nsym / max(1e-9, tot_h2d) / 1e9, 2), "source": "pageable (staged)" if args.no_pinned else "page-locked (rb3gpu_pinned_alloc): one DMA per batch"},
+        "roofline": chain_roofline(int(rows_launch), ms_chain, "text", load_pmc_traffic("k_chain_mtb152"),
+                                   "k_chain<list,mixed,tent,text>: average over the %d launches of the timed steps (run-coded index, intervals of up to %d matching suffixes); `achieved` prices SURVEY 8(d)'s 208 B per LF step over the kernel's HIP-event time; "
+                                   "traffic = FETCH_SIZE/WRITE_SIZE of the committed --pmc passes (profiles/r3_pmc_k_chain_mtb152.json); the index (<= %.0f MB) sits in L2 + Infinity Cache, so this kernel is bound by latency and instruction issue, not by HBM (aux_large_index is the HBM-resident case)" % (st["n_rank_launches"], K - 1, st["bytes_index"] / 1e6)),
+        "roofline_path": {"bound": "hbm", "formula": "SURVEY 8(d): (217 B x symbols merged + bytes(B1 old) + bytes(B1 new) per round) / merge-path seconds / 8 TB/s", "algorithmic_bytes_per_step": int(path_bytes // S),
+                          "achieved": round(path_bytes / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_bytes / dt / 1e9 / HBM_PEAK_GBS, 5)},
+        "roofline_rebuild": {"bound": "hbm", "kernel": "k_reb_group + k_place (+ window kernels on what they hand on)", "algorithmic_bytes_per_step": int(st["bytes_rebuild"] // S), "ms_per_step": round(st["ms_build"] / S, 3),
+                             "achieved": round(st["bytes_rebuild"] / max(1e-9, st["ms_build"]) / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(st["bytes_rebuild"] / max(1e-9, st["ms_build"]) / 1e6 / HBM_PEAK_GBS, 5),
+                             "note": "streaming roofline: 9 B per batch row + old block array + new block array per round"},
     }
-    if aux:
-        out["aux_entry_points"] = aux
-    h.dev_free(d_b2)
-    h.dev_free(d_b2s)
-    h.dev_free(d_tw)
-    h.close()
-    if not args.no_aux:
-        out["aux_reads_regime"] = reads_regime(lambda: Rb3Gpu(device=local_rank, verbose=1), args.aux_reads)
-        if args.large_index > 0:
-            try:
-                out["aux_large_index"] = large_index_regime(lambda: Rb3Gpu(device=local_rank, verbose=1), args.large_index, 1000000)
-            except Exception as e:   # (a box with less free memory than the leg needs must not lose the headline)
-                out["aux_large_index"] = {"error": repr(e)[:300]}
-    if not args.no_target:
-        out["target_workload"] = target_workload(args.mtb, 4400000, 0 if args.no_cpu_baseline else args.mtb_ref_prefix)
+    bl.close()
+    if args.only == "headline":
+        print(json.dumps(out), flush=True)
+        return
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(b1, b2)
+        cb = reference_prefix(files, args.mtb_ref_prefix, K)
+        if cb is None:   # the reference binary did not travel: the OpenMP port of the oracle on one round
+            from ropebwt3_amd import host
+            from tests import util
+            orc = util.Oracle()
+            b1 = host.build_bwt(texts[0])
+            b2 = host.build_bwt(texts[1])
+            t = time.time()
+            orc.mg_rank(b1, b2, os.cpu_count() or 1)
+            e = time.time() - t
+            cb = {"value": round(b2.size / e / 1e9, 6), "unit": "Gbp/s", "cores": os.cpu_count() or 1, "kind": "port", "sample": "rank phase of round 1 (genome 1 into the index of genome 0) by oracle/liboracle.so"}
+        out["cpu_baseline"] = cb
+    if not args.no_aux:
+        out["aux_cli_build"] = cli_build(files, K, gold)
+        try:
+            out["aux_cfg2"] = cfg2_step(local_rank, 10, 3, MTB_L, args.div)
+            out["aux_reads_regime"] = reads_regime(mk, args.aux_reads)
+            if args.large_index > 0:
+                out["aux_large_index"] = large_index_regime(mk, args.large_index, 1000000)
+        except Exception as e:   # (a box with less free memory than a leg needs must not lose the headline)
+            out["aux_error"] = repr(e)[:300]
+    for f in files:
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
+    try:
+        os.rmdir(tmp)
+    except OSError:
+        pass
     print(json.dumps(out), flush=True)
 
 

@@ -161,11 +161,19 @@ int rb3gpu_export_run_words(rb3gpu_t *h, rb3gpu_emit_words_f emit, void *data);
 /* The data section of the .fmd packed on the GPU (rb3_enc_fmr2fmd + rld_enc + rld_enc_finish, fm-index.c:31-52,
  * rld0.c:107-216): *words receives a malloc'ed array (free it with rb3gpu_host_free) of *n_words 64-bit words, the
  * blocks incl. the trailing header-only block, exactly what rld_dump writes between the file header and the rank
- * index (rld0.c:237-239; n_bytes = 8 * *n_words).  Serves indexes whose FMD blocks all have 16-bit headers (every
- * block holds fewer than 0x4000 symbols -- short-read data); otherwise returns RB3GPU_EUNSUP and the caller packs
- * the runs of rb3gpu_export_run_words on the host. */
+ * index (rld0.c:237-239; n_bytes = 8 * *n_words).  Blocks with 16-bit and with 32-bit headers (rld0.c:116-128: the
+ * block before holds fewer than 0x4000 / 0x40000000 symbols) are packed on the device; an index with a block of 2^30
+ * symbols or more (64-bit header) returns RB3GPU_EUNSUP and the caller packs the runs of rb3gpu_export_run_words on
+ * the host. */
 int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words);
 void rb3gpu_host_free(void *p);
+
+/* Page-locked host memory (hipHostMalloc) for batch buffers: a text or BWT that the caller builds in such a buffer is copied
+ * to HBM by one DMA at PCIe speed (rb3gpu_from_plain, rb3gpu_merge_plain*, rb3gpu_sort_text, rb3gpu_sorter_*); any other host
+ * pointer is staged through pinned buffers chunk by chunk, which a single host thread feeds at memcpy speed.  The reference's
+ * counterpart is the malloc of the batch buffer (build.c:205, io.c:92).  NULL: no such memory to be had (use malloc). */
+void *rb3gpu_pinned_alloc(int64_t n_bytes);
+void rb3gpu_pinned_free(void *p);
 
 /* The whole BWT as one symbol per byte (0..5) into host memory of rb3gpu_get_tot() bytes;
  * small indexes / tests only. */
@@ -220,6 +228,11 @@ int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void
 /* BWT + text-order words (*d_tw: len 64-bit words in the same output buffer; released together with *d_bwt) */
 int rb3gpu_sorter_sort(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, void **d_tw);
 int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt);
+/* rb3gpu_sorter_sort in its two stages, for callers that time or overlap them: the upload of the text (the H2D copy of the
+ * merge path, SURVEY 8(d): one DMA if `text` lies in memory from rb3gpu_pinned_alloc, else through pinned staging buffers),
+ * then the suffix sorting of the text uploaded last (len must be the same). */
+int rb3gpu_sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text);
+int rb3gpu_sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw);
 /* cumulative times of a sorter: text upload (host -> HBM, through its pinned staging buffer) and suffix sorting proper */
 int rb3gpu_sorter_stats(const rb3gpu_sorter_t *s, double *ms_upload, double *ms_sort, int64_t *n_batches, int64_t *n_symbols);
 

@@ -88,6 +88,76 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	return fp == stdout ? 0 : 1;
 }
 
+/* ---- batch buffers in page-locked memory ------------------------------------------------------
+ * The reader writes every batch straight into memory from rb3gpu_pinned_alloc, so its way to HBM is one DMA at PCIe speed
+ * (through pageable memory a single host thread has to stage it first, at half that or less: 88 of the 437 ms of the merge
+ * path of a 152-genome build).  Obtaining page-locked memory is slow (it is mapped for the device), so the buffers of
+ * finished batches go on a free list and the reader takes them from there: a build allocates a handful, at its start. */
+#define PINPOOL_MAX 8
+static struct { pthread_mutex_t mtx; void *p[64]; int64_t cap[64]; int busy[64]; int n; } g_pin = { PTHREAD_MUTEX_INITIALIZER, {0}, {0}, {0}, 0 };
+
+static void *pin_alloc(int64_t min_bytes, int64_t *cap)
+{
+	int i, best = -1, n_free = 0;
+	void *p = 0;
+	pthread_mutex_lock(&g_pin.mtx);
+	for (i = 0; i < g_pin.n; ++i)
+		if (!g_pin.busy[i]) {
+			++n_free;
+			if (g_pin.cap[i] >= min_bytes && (best < 0 || g_pin.cap[i] < g_pin.cap[best])) best = i;
+		}
+	if (best >= 0) g_pin.busy[best] = 1, p = g_pin.p[best], *cap = g_pin.cap[best];
+	else if (n_free > 0) { /* nothing large enough: the small ones only hold on to page-locked memory */
+		for (i = 0; i < g_pin.n; ++i)
+			if (!g_pin.busy[i]) {
+				rb3gpu_pinned_free(g_pin.p[i]);
+				g_pin.p[i] = g_pin.p[g_pin.n - 1], g_pin.cap[i] = g_pin.cap[g_pin.n - 1], g_pin.busy[i] = g_pin.busy[g_pin.n - 1];
+				--g_pin.n, --i;
+			}
+	}
+	pthread_mutex_unlock(&g_pin.mtx);
+	if (p) return p;
+	if (min_bytes < (16 << 20)) min_bytes = 16 << 20; /* (a batch of one short line still gets a buffer worth keeping) */
+	p = rb3gpu_pinned_alloc(min_bytes);
+	if (p == 0) return 0;
+	pthread_mutex_lock(&g_pin.mtx);
+	if (g_pin.n < 64) g_pin.p[g_pin.n] = p, g_pin.cap[g_pin.n] = min_bytes, g_pin.busy[g_pin.n] = 1, ++g_pin.n;
+	else { pthread_mutex_unlock(&g_pin.mtx); rb3gpu_pinned_free(p); return 0; }
+	pthread_mutex_unlock(&g_pin.mtx);
+	*cap = min_bytes;
+	return p;
+}
+
+static void pin_release(void *p)
+{
+	int i, n_free = 0;
+	pthread_mutex_lock(&g_pin.mtx);
+	for (i = 0; i < g_pin.n; ++i) {
+		if (g_pin.p[i] == p) g_pin.busy[i] = 0;
+		n_free += !g_pin.busy[i];
+	}
+	if (n_free > PINPOOL_MAX) { /* give the smallest idle one back */
+		int k = -1;
+		for (i = 0; i < g_pin.n; ++i)
+			if (!g_pin.busy[i] && (k < 0 || g_pin.cap[i] < g_pin.cap[k])) k = i;
+		if (k >= 0) {
+			rb3gpu_pinned_free(g_pin.p[k]);
+			g_pin.p[k] = g_pin.p[g_pin.n - 1], g_pin.cap[k] = g_pin.cap[g_pin.n - 1], g_pin.busy[k] = g_pin.busy[g_pin.n - 1];
+			--g_pin.n;
+		}
+	}
+	pthread_mutex_unlock(&g_pin.mtx);
+}
+
+static void pin_drain(void)
+{
+	int i;
+	pthread_mutex_lock(&g_pin.mtx);
+	for (i = 0; i < g_pin.n; ++i) rb3gpu_pinned_free(g_pin.p[i]);
+	g_pin.n = 0;
+	pthread_mutex_unlock(&g_pin.mtx);
+}
+
 /* ---- run sinks --------------------------------------------------------------------------- */
 
 typedef struct { uint64_t *a; int64_t n, m; } runvec_t;
@@ -106,8 +176,9 @@ static int sink_runvec(void *data, int c, int64_t l)
 
 static int sink_fmd_words(void *data, int64_t n, const uint64_t *words, int64_t end) { return rb3h_fmdw_enc_words((rb3h_fmdw_t*)data, n, words, end); }
 
-/* the .fmd of the index (rb3_enc_fmr2fmd + rld_dump, build.c:248-252): the data section is packed on the GPU when all
- * its blocks have 16-bit headers, else the GPU finds the runs and the host packs them; the rank index is built here */
+/* the .fmd of the index (rb3_enc_fmr2fmd + rld_dump, build.c:248-252): the data section is packed on the GPU (16-bit and
+ * 32-bit block headers); if a block needs a 64-bit header or the device has no room for the packer, the GPU finds the runs
+ * and the host packs them; the rank index is built here */
 static int g_host_fmd = 0; /* --host-fmd */
 
 static int write_fmd(rb3gpu_t *h, FILE *fp)
@@ -200,15 +271,17 @@ static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	void *d_bwt = 0, *d_tw = 0;
 	const int text_walk = *has_index; /* text-order words; long strings: walkers by text position, short ones: one walker per string */
 	int ret;
-	if (rb3gpu_dev_alloc(h, b->len + 16, &d_bwt) < 0) return 1; /* no room on the device: the caller sorts this batch on the host */
-	if (text_walk && rb3gpu_dev_alloc(h, b->len * 8, &d_tw) < 0) { rb3gpu_dev_free(h, d_bwt); return 1; }
+	/* only "no room on the device" sends the batch to the host sorter (return 1); any other failure is an error of the build */
+	if ((ret = rb3gpu_dev_alloc(h, b->len + 16, &d_bwt)) < 0) return ret == RB3GPU_ENOMEM ? 1 : ret;
+	if (text_walk && (ret = rb3gpu_dev_alloc(h, b->len * 8, &d_tw)) < 0) { rb3gpu_dev_free(h, d_bwt); return ret == RB3GPU_ENOMEM ? 1 : ret; }
 	if (text_walk) ret = rb3gpu_sort_text(h, b->len, b->bwt, (uint8_t*)d_bwt, (uint64_t*)d_tw);
 	else ret = rb3gpu_bwt_from_text(h, b->len, b->bwt, (uint8_t*)d_bwt, 0, 0);
-	if (ret < 0 && ret != RB3GPU_ESYMBOL) { /* the sorter could not run (memory): the caller sorts this batch on the host */
+	if (ret == RB3GPU_ENOMEM) { /* the sorter's scratch did not fit: the caller sorts this batch on the host */
 		if (d_tw) rb3gpu_dev_free(h, d_tw);
 		rb3gpu_dev_free(h, d_bwt);
 		return 1;
 	}
+	if (ret == 0) __sync_fetch_and_add(&g_sorted.n_gpu, 1), __sync_fetch_and_add(&g_sorted.sym_gpu, b->len);
 	if (ret == 0 && rb3h_verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 	if (ret == 0 && !*has_index) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)d_bwt);
@@ -298,8 +371,7 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	int r;
 	if (step < (seq->l >> 20)) step = seq->l >> 20; /* at most ~2^20 walkers per batch: the engine's stretch table is finite */
 	if (opt->gpu_sort && seq->l < opt->gpu_sort_limit) { /* the GPU sorts (its sorter handles < 2^31 symbols; batches are cut to fit, see batch_cut) */
-		__sync_fetch_and_add(&g_sorted.n_gpu, 1), __sync_fetch_and_add(&g_sorted.sym_gpu, seq->l);
-		b = (batch_t*)calloc(1, sizeof(batch_t));
+		b = (batch_t*)calloc(1, sizeof(batch_t)); /* (counted in g_sorted where the sort really happens: below, or in process_batch) */
 		b->n_seq = n_seq, b->len = seq->l, b->bwt = seq->s, b->raw = 1;
 		b->step = (opt->split_log2 >= 0 && n_seq > 0 && seq->l / n_seq > 4 * step && seq->l / step + n_seq < (1 << 22)) ? step : 0;
 		seq->s = 0, seq->l = seq->m = 0;
@@ -312,7 +384,8 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 					fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 				if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0, b->d_tw = 0;
 				b->gs = gs, b->raw = 0;
-				free(b->bwt); b->bwt = 0; /* the text is not needed any more */
+				__sync_fetch_and_add(&g_sorted.n_gpu, 1), __sync_fetch_and_add(&g_sorted.sym_gpu, b->len);
+				rb3h_batch_free(b->bwt); b->bwt = 0; /* the text is not needed any more */
 			} else b->d_bwt = b->d_tw = 0; /* leave it to the consumer (its handle's sorter, then the host sorter) */
 		}
 		*out = b;
@@ -355,7 +428,8 @@ static int for_each_batch(const bopt_t *opt, int n_files, char **files, submit_f
 			const int64_t l0 = seq.l;
 			n_seq = rb3h_seq_read(fp, &seq, batch_cut(opt), !(opt->flag & BF_NO_FOR), !(opt->flag & BF_NO_REV), n_empty);
 			if (n_seq < 0) {
-				if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: failed to read sequences (code %ld)\n", (long)n_seq);
+				if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: failed to read sequences from '%s' (code %ld)\n", files[i], (long)n_seq);
+				ret = -1; /* (an I/O error in mid-file or no memory: indexing the prefix read so far would be a silently wrong index) */
 				break;
 			}
 			if (rb3h_seq_error(fp) && seq.l != l0 && rb3h_verbose >= 1) /* the records before the error are indexed, as in io.c:121-124 */
@@ -374,7 +448,7 @@ static int for_each_batch(const bopt_t *opt, int n_files, char **files, submit_f
 	if (ret == 0 && seq.l > 0) { /* the last, partly filled re-batched batch */
 		if ((ret = submit(data, &seq, n_seq_acc, 0)) == 0) ret = submit(data, 0, 0, 1);
 	}
-	free(seq.s);
+	rb3h_batch_free(seq.s);
 	return ret;
 }
 
@@ -389,7 +463,7 @@ static int consume(consumer_t *c, batch_t *b, int end_of_file)
 {
 	if (b) {
 		int r = process_batch(c->h, b, &c->has_index);
-		free(b->bwt); free(b->walkers); free(b);
+		rb3h_batch_free(b->bwt); free(b->walkers); free(b);
 		if (r < 0) return r;
 	}
 	if (end_of_file && c->fn_tmp && c->has_index) { /* build.c:232-238 */
@@ -542,6 +616,8 @@ int main_build(int argc, char *argv[])
 		return 1;
 	}
 
+	if (!getenv("RB3_NO_PINNED")) rb3h_seq_set_batch_allocator(pin_alloc, pin_release); /* batch buffers in page-locked memory (one DMA per batch) */
+
 	if (fn_in) { /* build.c:172-184 */
 		const int r = load_index(h, fn_in);
 		if (r == -1) {
@@ -595,7 +671,7 @@ int main_build(int argc, char *argv[])
 			if (ret == 0) ret = consume(&cs, j.out, j.end_of_file);
 			else if (j.out) {
 				if (j.out->d_bwt) rb3gpu_sorter_release(j.out->gs, j.out->d_bwt);
-				free(j.out->bwt); free(j.out->walkers); free(j.out);
+				rb3h_batch_free(j.out->bwt); free(j.out->walkers); free(j.out);
 			}
 		}
 		pthread_join(rt, 0);
@@ -621,6 +697,7 @@ int main_build(int argc, char *argv[])
 
 	if (ret != 0 || !has_index) {
 		while (n_old_sorters > 0) rb3gpu_sorter_destroy(old_sorters[--n_old_sorters]);
+		pin_drain();
 		rb3gpu_destroy(h);
 		return 1;
 	}
@@ -652,6 +729,7 @@ int main_build(int argc, char *argv[])
 				batch_cut(&opt) != opt.batch_size ? " cut into GPU sub-batches (--gpu-batch)" : "");
 	}
 	while (n_old_sorters > 0) rb3gpu_sorter_destroy(old_sorters[--n_old_sorters]);
+	pin_drain();
 	rb3gpu_destroy(h);
 	if (ret != 0) { fprintf(stderr, "ERROR: failed to write the index (code %d)\n", ret); return 1; }
 	return 0;

@@ -13,7 +13,7 @@
 extern "C" {
 #endif
 
-#define RB3H_VERSION "3.10-r281-mi355x-r2"
+#define RB3H_VERSION "3.10-r281-mi355x-r3"
 
 extern int rb3h_verbose;
 
@@ -46,6 +46,13 @@ void rb3h_seq_close(rb3h_seqio_t *fp);                                     /* io
  * seq->l > max_len; returns the number of strings appended (0 at EOF) or <0 on a parse error;
  * *n_empty counts records of length 0, which are skipped (out of contract in the reference) */
 int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is_for, int is_rev, int64_t *n_empty);
+/* where the batch buffer (`seq` of rb3h_seq_read) gets its memory: alloc returns at least min_bytes and says how much it
+ * gave in *cap (a pool may hand out a larger buffer); NULL, NULL = realloc/free (default).  The CLI sets page-locked memory
+ * here (rb3gpu_pinned_alloc) so that a batch goes to HBM with one DMA; a batch buffer is then freed with rb3h_batch_free. */
+typedef void *(*rb3h_alloc_f)(int64_t min_bytes, int64_t *cap);
+typedef void (*rb3h_free_f)(void *p);
+void rb3h_seq_set_batch_allocator(rb3h_alloc_f alloc, rb3h_free_f release);
+void rb3h_batch_free(void *p);
 int rb3h_seq_error(const rb3h_seqio_t *fp); /* != 0: a FASTX parsing error ended the file early (code as in kseq: -2 truncated quality, ...) */
 void rb3h_char2nt6(int64_t l, uint8_t *s);                                 /* io.c:23-28 */
 void rb3h_revcomp6(int64_t l, uint8_t *s);                                 /* io.c:30-40 */

@@ -9,6 +9,7 @@
 #include <zlib.h>
 #include <unistd.h>
 #include <fcntl.h>
+#include <errno.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -21,6 +22,7 @@ struct rb3h_seqio_s {
 	int fd;
 	int is_line, is_eof, last_char;
 	int err;          /* FASTX parsing error met (code < -1); nothing more is read from the file */
+	int io_err;       /* read(2) / gzread failed in the middle of the file: what was read so far must not be taken for the whole input */
 	int beg, end;
 	uint8_t *buf;
 	rb3h_buf_t rec, qual;
@@ -112,13 +114,48 @@ static int buf_grow(rb3h_buf_t *b, int64_t need)
 	return 0;
 }
 
-/* read(2) until n bytes are there or the file ends */
-static int sio_read_full(int fd, uint8_t *buf, int n)
+/* the batch buffer may live in memory from another allocator (page-locked: see rb3h_seq_set_batch_allocator) */
+static rb3h_alloc_f sio_batch_alloc = 0;
+static rb3h_free_f sio_batch_release = 0;
+
+void rb3h_seq_set_batch_allocator(rb3h_alloc_f alloc, rb3h_free_f release)
+{
+	sio_batch_alloc = alloc && release ? alloc : 0, sio_batch_release = alloc && release ? release : 0;
+}
+
+void rb3h_batch_free(void *p)
+{
+	if (p == 0) return;
+	if (sio_batch_release) sio_batch_release(p); else free(p);
+}
+
+static int batch_grow(rb3h_buf_t *b, int64_t need)
+{
+	if (need <= b->m) return 0;
+	if (sio_batch_alloc == 0) return buf_grow(b, need);
+	{
+		int64_t cap = 0, want = need * 2 + 16; /* (page-locked memory is slow to obtain: grow in few steps) */
+		uint8_t *s = (uint8_t*)sio_batch_alloc(want, &cap);
+		if (s == 0 || cap < need) return -1;
+		if (b->l > 0) memcpy(s, b->s, (size_t)b->l);
+		if (b->s) sio_batch_release(b->s);
+		b->s = s, b->m = cap;
+	}
+	return 0;
+}
+
+/* read(2) until n bytes are there or the file ends; an interrupted call is repeated, any other error is reported in *io_err
+ * (the bytes read before it are still returned) */
+static int sio_read_full(int fd, uint8_t *buf, int n, int *io_err)
 {
 	int got = 0;
 	while (got < n) {
 		const ssize_t r = read(fd, buf + got, (size_t)(n - got));
-		if (r < 0) return got > 0 ? got : -1;
+		if (r < 0) {
+			if (errno == EINTR) continue;
+			*io_err = errno ? errno : EIO;
+			break;
+		}
 		if (r == 0) break;
 		got += (int)r;
 	}
@@ -129,30 +166,24 @@ rb3h_seqio_t *rb3h_seq_open(const char *fn, int is_line)
 {
 	const int fd = fn && strcmp(fn, "-") ? open(fn, O_RDONLY) : dup(0);
 	rb3h_seqio_t *fp;
+	off_t at;
 	if (fd < 0) return 0;
 	sio_init_table();
 	fp = (rb3h_seqio_t*)calloc(1, sizeof(*fp));
 	fp->fd = fd, fp->is_line = !!is_line;
 	fp->buf = (uint8_t*)malloc(SIO_BUF);
-	/* the first bytes decide: gzip magic -> through zlib (fed the bytes already read by rewinding a regular file; a pipe
-	 * that starts with the magic goes to zlib at once), anything else -> plain read(2) */
-	fp->end = sio_read_full(fd, fp->buf, 2);
-	if (fp->end < 0) fp->end = 0;
-	if (fp->end == 2 && fp->buf[0] == 0x1f && fp->buf[1] == 0x8b) {
-		if (lseek(fd, 0, SEEK_SET) == 0) fp->fp = gzdopen(fd, "r"), fp->end = 0;
-		else { /* not seekable: zlib cannot be given the two bytes back */
-			close(fd); free(fp->buf); free(fp);
-			{
-				gzFile f = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
-				if (f == 0) return 0;
-				fp = (rb3h_seqio_t*)calloc(1, sizeof(*fp));
-				fp->fd = -1, fp->fp = f, fp->is_line = !!is_line;
-				fp->buf = (uint8_t*)malloc(SIO_BUF);
-			}
-			return fp;
-		}
-		if (fp->fp == 0) { close(fd); free(fp->buf); free(fp); return 0; }
+	/* A seekable file is sniffed with pread(2), which consumes nothing: gzip magic -> through zlib, anything else -> plain
+	 * read(2) (no pass through zlib's buffer).  A pipe, FIFO or terminal cannot be given bytes back, so it always goes through
+	 * zlib, which handles gzip and plain input alike (gzdopen as in io.c:64): nothing zlib needs is ever read here. */
+	at = lseek(fd, 0, SEEK_CUR);
+	if (at == (off_t)-1) fp->fp = gzdopen(fd, "r");
+	else {
+		uint8_t magic[2];
+		const ssize_t k = pread(fd, magic, 2, at);
+		if (k == 2 && magic[0] == 0x1f && magic[1] == 0x8b) fp->fp = gzdopen(fd, "r");
+		else return fp;
 	}
+	if (fp->fp == 0) { close(fd); free(fp->buf); free(fp); return 0; }
 	return fp;
 }
 
@@ -168,7 +199,14 @@ static int sio_fill(rb3h_seqio_t *fp)
 {
 	if (fp->is_eof) return 0;
 	fp->beg = 0;
-	fp->end = fp->fp ? gzread(fp->fp, fp->buf, SIO_BUF) : sio_read_full(fp->fd, fp->buf, SIO_BUF);
+	if (fp->fp) {
+		fp->end = gzread(fp->fp, fp->buf, SIO_BUF);
+		if (fp->end < SIO_BUF) { /* the end of the stream, or of what could be read of it: a truncated or corrupt gzip file is an error */
+			int zerr = Z_OK;
+			(void)gzerror(fp->fp, &zerr);
+			if (fp->end < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) fp->io_err = EIO;
+		}
+	} else fp->end = sio_read_full(fp->fd, fp->buf, SIO_BUF, &fp->io_err);
 	if (fp->end < SIO_BUF) fp->is_eof = 1;
 	if (fp->end <= 0) { fp->end = 0; return 0; }
 	return 1;
@@ -245,7 +283,7 @@ static int64_t sio_add(rb3h_buf_t *seq, int is_for, int is_rev, int64_t l, uint8
 { /* io.c:84-102 */
 	int64_t n = 0;
 	uint8_t *df, *dr;
-	if (buf_grow(seq, seq->l + 2 * (l + 1) + 1) < 0) return -1;
+	if (batch_grow(seq, seq->l + 2 * (l + 1) + 1) < 0) return -1;
 	df = is_for ? seq->s + seq->l : 0, dr = is_rev ? seq->s + seq->l + (is_for ? l + 1 : 0) : 0;
 	sio_convert(s, l, df, dr); /* both strands straight into the batch */
 	if (df) df[l] = 0, seq->l += l + 1, ++n;
@@ -269,7 +307,7 @@ int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is
 				fp->beg += (int)l + 1;
 				if (l > 1 && src[l - 1] == '\r') --l; /* (as sio_getline) */
 				if (l == 0) { if (n_empty) ++*n_empty; continue; }
-				if (buf_grow(seq, seq->l + 2 * (l + 1) + 1) < 0) return -4;
+				if (batch_grow(seq, seq->l + 2 * (l + 1) + 1) < 0) return -4;
 				{
 					uint8_t *df = is_for ? seq->s + seq->l : 0, *dr = is_rev ? seq->s + seq->l + (is_for ? l + 1 : 0) : 0;
 					sio_convert(src, l, df, dr);
@@ -293,6 +331,7 @@ int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is
 		n_seq += ret;
 		if (max_len > 0 && seq->l > max_len) break; /* io.c:114,119 */
 	}
+	if (fp->io_err) return -5; /* the file could not be read to its end: not an end of file (the caller must not index a prefix) */
 	if (!fp->is_line && ret < -1) fp->err = (int)ret; /* FASTX parsing error: the records read before it still count (io.c:121-124) */
 	return n_seq;
 }

@@ -43,6 +43,48 @@ struct Buf {
 	size_t cap = 0;
 };
 
+/* Page-locked host memory handed out by rb3gpu_pinned_alloc: a batch that the reader wrote straight into such a buffer goes to
+ * HBM with ONE DMA at PCIe speed; anything else is copied into pinned staging buffers first, chunk by chunk (a single host
+ * thread copies at 10-25 GB/s, i.e. slower than the link).  The registry says which is which. */
+#include <pthread.h>
+static pthread_mutex_t g_pin_mtx = PTHREAD_MUTEX_INITIALIZER;
+static std::vector<std::pair<const uint8_t*, size_t> > g_pinned;
+
+static bool is_pinned(const void *p, size_t bytes)
+{
+	bool hit = false;
+	pthread_mutex_lock(&g_pin_mtx);
+	for (const auto &r : g_pinned)
+		if ((const uint8_t*)p >= r.first && (const uint8_t*)p + bytes <= r.first + r.second) { hit = true; break; }
+	pthread_mutex_unlock(&g_pin_mtx);
+	return hit;
+}
+
+/* host -> device copy of n bytes on stream st: direct from page-locked memory, else through the two pinned staging buffers
+ * (the CPU fills one while the DMA engine empties the other).  Returns with the copy complete. */
+static hipError_t h2d_copy(void *d_dst, const uint8_t *src, size_t n, hipStream_t st, uint8_t *stage[2], hipEvent_t done[2])
+{
+	hipError_t e;
+	if (n == 0) return hipSuccess;
+	if (is_pinned(src, n) || !stage || !stage[0] || !stage[1] || n <= (size_t)(256 << 10)) {
+		if ((e = hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+		return hipStreamSynchronize(st);
+	}
+	// chunks of 4 MB: the first DMA starts after 4 MB have been staged, not after 32
+	const size_t chunk = (size_t)4 << 20;
+	bool used[2] = { false, false };
+	int i = 0;
+	for (size_t off = 0; off < n; off += chunk, i ^= 1) {
+		const size_t k = n - off < chunk ? n - off : chunk;
+		if (used[i] && (e = hipEventSynchronize(done[i])) != hipSuccess) return e; // the DMA that last read this staging buffer
+		memcpy(stage[i], src + off, k);
+		if ((e = hipMemcpyAsync((uint8_t*)d_dst + off, stage[i], k, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+		if ((e = hipEventRecord(done[i], st)) != hipSuccess) return e;
+		used[i] = true;
+	}
+	return hipStreamSynchronize(st);
+}
+
 /* Diagnostic switches of a handle.  They are read from the environment ONCE, in rb3gpu_create (RB3GPU_<KEY>), and can be
  * changed on a live handle with rb3gpu_tune(); nothing on the merge path calls getenv().  The keys under
  * RB3GPU_TEST_HOOKS only exist in the test build of the library (librb3gpu_hooks.so): the release build has no code
@@ -114,8 +156,6 @@ static double now_s(void)
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
-
-#define RB3_GUARD 4096 /* tune "guard": bytes behind every buffer of the handle that must keep their fill pattern */
 
 #define RB3_GUARD 4096 /* tune "guard": bytes behind every buffer of the handle that must keep their fill pattern */
 
@@ -1308,24 +1348,8 @@ static int upload_b2(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
 			if (hipHostMalloc((void**)&h->stage[i], RB3_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { h->stage[i] = nullptr; break; }
 	}
 	const double t0 = now_s();
-	if (h->stage[0] && h->stage[1] && (size_t)len > (size_t)(1 << 20)) {
-		int64_t off = 0;
-		int i = 0;
-		hipEvent_t done[2] = { h->ev[4], h->ev[5] };
-		bool used[2] = { false, false };
-		while (off < len) {
-			const size_t n = (size_t)(len - off) < RB3_STAGE_BYTES ? (size_t)(len - off) : RB3_STAGE_BYTES;
-			if (used[i]) HIPCHK(hipEventSynchronize(done[i])); // the DMA that last read this staging buffer
-			memcpy(h->stage[i], bwt + off, n);
-			HIPCHK(hipMemcpyAsync((uint8_t*)h->b2.p + off, h->stage[i], n, hipMemcpyHostToDevice, h->st));
-			HIPCHK(hipEventRecord(done[i], h->st));
-			used[i] = true, off += (int64_t)n, i ^= 1;
-		}
-		HIPCHK(hipStreamSynchronize(h->st));
-	} else {
-		HIPCHK(hipMemcpyAsync(h->b2.p, bwt, (size_t)len, hipMemcpyHostToDevice, h->st));
-		HIPCHK(hipStreamSynchronize(h->st));
-	}
+	hipEvent_t done[2] = { h->ev[4], h->ev[5] };
+	HIPCHK(h2d_copy(h->b2.p, bwt, (size_t)len, h->st, h->stage, done));
 	h->stt.ms_h2d += (now_s() - t0) * 1e3;
 	return 0;
 }
@@ -1523,6 +1547,11 @@ static int sort_text_impl(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t
 		d_ck = (int64_t*)h->xbuf.p;
 	}
 	r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds, d_tw);
+	if (r == -1 && !h->garbage.empty()) { // the sorter's scratch did not fit while replaced buffers of the handle are still held: give them back, once more
+		(void)hipGetLastError();
+		garbage_collect(h, true);
+		r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds, d_tw);
+	}
 	if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -3 ? RB3GPU_ESYMBOL : RB3GPU_ENODEV;
 	if (nck > 0) HIPCHK(hipMemcpy(ckrow, d_ck, (size_t)nck * 8, hipMemcpyDeviceToHost));
 	h->stt.ms_sort += (now_s() - t0) * 1e3, h->stt.n_sort_rounds += rounds;
@@ -1545,7 +1574,6 @@ int rb3gpu_sort_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_b
 
 /* ---- a sorter of its own: stream, scratch, two output buffers handed out in turn ---- */
 
-#include <pthread.h>
 #define SCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; } } while (0)
 
 struct rb3gpu_sorter_s {
@@ -1555,7 +1583,9 @@ struct rb3gpu_sorter_s {
 	void *text = nullptr, *ck = nullptr, *out[2] = {nullptr, nullptr};
 	size_t text_cap = 0, ck_cap = 0, out_cap[2] = {0, 0};
 	int busy[2] = {0, 0};
-	uint8_t *stage = nullptr; // pinned, for the text upload
+	uint8_t *stage[2] = {nullptr, nullptr}; // pinned, for the upload of a text that is not in page-locked memory itself
+	hipEvent_t done[2];
+	int64_t text_len = 0;     // symbols of the text that rb3gpu_sorter_upload left in `text`
 	double ms_upload = 0, ms_sort = 0; // cumulative: text host -> HBM; suffix sorting + BWT + text-order words
 	int64_t n_sorted = 0, n_symbols = 0;
 	pthread_mutex_t mtx;
@@ -1580,7 +1610,10 @@ rb3gpu_sorter_t *rb3gpu_sorter_create(int device)
 	rb3gpu_sorter_t *s = new rb3gpu_sorter_s;
 	s->dev = device;
 	if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess || (s->ws = rb3sort_create()) == nullptr) { delete s; return nullptr; }
-	if (hipHostMalloc((void**)&s->stage, RB3_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) s->stage = nullptr;
+	for (int i = 0; i < 2; ++i) {
+		if (hipHostMalloc((void**)&s->stage[i], (size_t)4 << 20, hipHostMallocDefault) != hipSuccess) s->stage[i] = nullptr;
+		if (hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); if (s->stage[i]) (void)hipHostFree(s->stage[i]); s->stage[i] = nullptr; }
+	}
 	pthread_mutex_init(&s->mtx, nullptr);
 	pthread_cond_init(&s->cv, nullptr);
 	return s;
@@ -1594,20 +1627,44 @@ void rb3gpu_sorter_destroy(rb3gpu_sorter_t *s)
 	rb3sort_destroy(s->ws);
 	void *all[] = { s->text, s->ck, s->out[0], s->out[1] };
 	for (void *p : all) if (p) (void)hipFree(p);
-	if (s->stage) (void)hipHostFree(s->stage);
+	for (int i = 0; i < 2; ++i) if (s->stage[i]) { (void)hipHostFree(s->stage[i]); (void)hipEventDestroy(s->done[i]); }
 	(void)hipStreamDestroy(s->st);
 	pthread_mutex_destroy(&s->mtx);
 	pthread_cond_destroy(&s->cv);
 	delete s;
 }
 
-static int sorter_impl(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow, void **d_tw)
+static void sorter_give_back(rb3gpu_sorter_t *s, int slot)
 {
-	if (!s || !text || !d_bwt || len <= 0 || len >= (1LL << 31) || step < 0) return RB3GPU_EINVAL;
+	pthread_mutex_lock(&s->mtx);
+	s->busy[slot] = 0;
+	pthread_cond_broadcast(&s->cv);
+	pthread_mutex_unlock(&s->mtx);
+}
+
+/* stage 1: the text of a batch into the sorter's text buffer in HBM (the H2D of the merge path) */
+static int sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text)
+{
+	if (!s || !text || len <= 0 || len >= (1LL << 31)) return RB3GPU_EINVAL;
+	SCHK(hipSetDevice(s->dev));
+	int r;
+	s->text_len = 0;
+	if ((r = sorter_grow(&s->text, &s->text_cap, (size_t)len + 16)) < 0) return r;
+	const double t_up = now_s();
+	if (h2d_copy(s->text, text, (size_t)len, s->st, s->stage, s->done) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	s->ms_upload += (now_s() - t_up) * 1e3;
+	s->text_len = len;
+	return 0;
+}
+
+/* stage 2: suffix-sort the uploaded text into an output buffer that is not with the merger */
+static int sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, int64_t step, int64_t *ckrow, void **d_tw)
+{
+	if (!s || !d_bwt || len <= 0 || len != s->text_len || step < 0) return RB3GPU_EINVAL;
 	SCHK(hipSetDevice(s->dev));
 	int r, slot, rounds = 0;
 	*d_bwt = nullptr;
-	pthread_mutex_lock(&s->mtx); // an output buffer that is not with the merger
+	pthread_mutex_lock(&s->mtx);
 	while (s->busy[0] && s->busy[1]) pthread_cond_wait(&s->cv, &s->mtx);
 	slot = s->busy[0] ? 1 : 0;
 	s->busy[slot] = 1;
@@ -1615,46 +1672,42 @@ static int sorter_impl(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, voi
 	const int64_t nck = step > 0 && ckrow ? (len + step - 1) / step : 0;
 	const size_t tw_off = ((size_t)len + 16 + 255) & ~(size_t)255; // the text-order words sit behind the BWT in the same buffer
 	if (d_tw) *d_tw = nullptr;
-	if ((r = sorter_grow(&s->text, &s->text_cap, (size_t)len + 16)) < 0 || (r = sorter_grow(&s->out[slot], &s->out_cap[slot], d_tw ? tw_off + (size_t)len * 8 : (size_t)len + 16)) < 0 ||
+	if ((r = sorter_grow(&s->out[slot], &s->out_cap[slot], d_tw ? tw_off + (size_t)len * 8 : (size_t)len + 16)) < 0 ||
 		(nck > 0 && (r = sorter_grow(&s->ck, &s->ck_cap, (size_t)nck * 8)) < 0)) {
-		pthread_mutex_lock(&s->mtx);
-		s->busy[slot] = 0;
-		pthread_cond_broadcast(&s->cv);
-		pthread_mutex_unlock(&s->mtx);
+		sorter_give_back(s, slot); // (or the next two calls would wait for it for ever)
 		return r;
-	}
-	r = 0;
-	const double t_up = now_s();
-	if (s->stage) { // pageable -> pinned -> device, chunk by chunk
-		for (int64_t off = 0; off < len && r == 0; off += (int64_t)RB3_STAGE_BYTES) {
-			const size_t n = (size_t)(len - off) < RB3_STAGE_BYTES ? (size_t)(len - off) : RB3_STAGE_BYTES;
-			memcpy(s->stage, text + off, n);
-			if (hipMemcpyAsync((uint8_t*)s->text + off, s->stage, n, hipMemcpyHostToDevice, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess) r = -2;
-		}
-	} else if (hipMemcpyAsync(s->text, text, (size_t)len, hipMemcpyHostToDevice, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess) r = -2;
-	if (r < 0) { // the upload failed: give the output slot back, or the next two calls would wait for it for ever
-		(void)hipGetLastError();
-		pthread_mutex_lock(&s->mtx);
-		s->busy[slot] = 0;
-		pthread_cond_broadcast(&s->cv);
-		pthread_mutex_unlock(&s->mtx);
-		return RB3GPU_ENODEV;
 	}
 	const double t_so = now_s();
 	r = rb3sort_bwt(s->ws, s->st, len, (const uint8_t*)s->text, (uint8_t*)s->out[slot], step, nck > 0 ? (int64_t*)s->ck : nullptr, &rounds,
 			d_tw ? (uint64_t*)((uint8_t*)s->out[slot] + tw_off) : nullptr);
-	s->ms_upload += (t_so - t_up) * 1e3, s->ms_sort += (now_s() - t_so) * 1e3, s->n_sorted += 1, s->n_symbols += len;
+	s->ms_sort += (now_s() - t_so) * 1e3, s->n_sorted += 1, s->n_symbols += len;
 	if (r == 0 && nck > 0 && (hipMemcpyAsync(ckrow, s->ck, (size_t)nck * 8, hipMemcpyDeviceToHost, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess)) r = -2;
 	if (r < 0) {
-		pthread_mutex_lock(&s->mtx);
-		s->busy[slot] = 0;
-		pthread_cond_broadcast(&s->cv);
-		pthread_mutex_unlock(&s->mtx);
+		sorter_give_back(s, slot);
 		return r == -1 ? RB3GPU_ENOMEM : r == -3 ? RB3GPU_ESYMBOL : RB3GPU_ENODEV;
 	}
 	*d_bwt = s->out[slot];
 	if (d_tw) *d_tw = (uint8_t*)s->out[slot] + tw_off;
 	return 0;
+}
+
+static int sorter_impl(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow, void **d_tw)
+{
+	if (!s || !text || !d_bwt || len <= 0 || len >= (1LL << 31) || step < 0) return RB3GPU_EINVAL;
+	int r;
+	if ((r = sorter_upload(s, len, text)) < 0) return r;
+	return sorter_sort_uploaded(s, len, d_bwt, step, ckrow, d_tw);
+}
+
+int rb3gpu_sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text)
+{
+	return sorter_upload(s, len, text);
+}
+
+int rb3gpu_sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw)
+{
+	if (!d_tw) return RB3GPU_EINVAL;
+	return sorter_sort_uploaded(s, len, d_bwt, 0, nullptr, d_tw);
 }
 
 int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow)
@@ -1844,6 +1897,11 @@ int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
 	if ((r = buf_ensure(h, h->xbuf, (size_t)nr * 8)) < 0) return r;
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<true>), grid, blk, 0, h->st, iv, (int64_t)0, ngrp, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
 	r = rb3fmd_encode(h->st, h->n, nr, (const uint64_t*)h->xbuf.p, words, n_words);
+	if (r == -1 && !h->garbage.empty()) { // no room for the packer's tables while replaced buffers are still held
+		(void)hipGetLastError();
+		garbage_collect(h, true);
+		r = rb3fmd_encode(h->st, h->n, nr, (const uint64_t*)h->xbuf.p, words, n_words);
+	}
 	h->stt.ms_export += (now_s() - t) * 1e3;
 	if (r == 1) return RB3GPU_EUNSUP;
 	if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -2 ? RB3GPU_ENODEV : RB3GPU_EINTERNAL;
@@ -1853,6 +1911,27 @@ int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
 }
 
 void rb3gpu_host_free(void *p) { free(p); }
+
+void *rb3gpu_pinned_alloc(int64_t n_bytes)
+{
+	void *p = nullptr;
+	if (n_bytes <= 0) return nullptr;
+	if (hipHostMalloc(&p, (size_t)n_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	pthread_mutex_lock(&g_pin_mtx);
+	g_pinned.push_back(std::make_pair((const uint8_t*)p, (size_t)n_bytes));
+	pthread_mutex_unlock(&g_pin_mtx);
+	return p;
+}
+
+void rb3gpu_pinned_free(void *p)
+{
+	if (!p) return;
+	pthread_mutex_lock(&g_pin_mtx);
+	for (size_t i = 0; i < g_pinned.size(); ++i)
+		if (g_pinned[i].first == (const uint8_t*)p) { g_pinned[i] = g_pinned.back(); g_pinned.pop_back(); break; }
+	pthread_mutex_unlock(&g_pin_mtx);
+	(void)hipHostFree(p);
+}
 
 /* one call per run on top of the bulk export (the host turns consecutive starts into lengths) */
 struct RunAdapter { rb3gpu_emit_f emit; void *data; int c; int64_t start; };
@@ -2085,7 +2164,13 @@ int rb3gpu_dev_alloc(rb3gpu_t *h, int64_t n_bytes, void **d_ptr)
 {
 	if (!h || n_bytes < 0 || !d_ptr) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
-	HIPCHK(hipMalloc(d_ptr, (size_t)(n_bytes > 0 ? n_bytes : 1)));
+	hipError_t e = hipMalloc(d_ptr, (size_t)(n_bytes > 0 ? n_bytes : 1));
+	if (e == hipErrorOutOfMemory && !h->garbage.empty()) { // replaced buffers of the handle are still held (defer_free): give them back first
+		(void)hipGetLastError();
+		garbage_collect(h, true);
+		e = hipMalloc(d_ptr, (size_t)(n_bytes > 0 ? n_bytes : 1));
+	}
+	HIPCHK(e);
 	return 0;
 }
 

@@ -83,6 +83,10 @@ SYMBOLS = {
     "rb3gpu_sorter_destroy": (None, [ctypes.c_void_p]),
     "rb3gpu_sorter_bwt": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_sorter_release": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_sorter_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_sorter_sort_uploaded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
+    "rb3gpu_pinned_alloc": (ctypes.c_void_p, [ctypes.c_int64]),
+    "rb3gpu_pinned_free": (None, [ctypes.c_void_p]),
     "rb3gpu_sorter_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_from_fmd_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
@@ -127,6 +131,80 @@ def load_library(hooks=False, path=None):
 def _u8(a):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     return a
+
+
+class PinnedArray:
+    """a uint8 numpy array in page-locked host memory (rb3gpu_pinned_alloc): a batch built here goes to HBM with one DMA"""
+
+    def __init__(self, nbytes, lib=None):
+        self._lib = load_library(False, lib)
+        self._p = self._lib.rb3gpu_pinned_alloc(int(max(nbytes, 1)))
+        if not self._p:
+            raise MemoryError("rb3gpu_pinned_alloc(%d) failed" % nbytes)
+        self.array = np.ctypeslib.as_array(ctypes.cast(self._p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(max(nbytes, 1)),))[:nbytes]
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._lib.rb3gpu_pinned_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Sorter:
+    """rb3gpu_sorter_t: the GPU suffix sorter as an object of its own (own HIP stream, scratch, two output buffers): what the
+    CLI's sorter thread runs while the batch before is being merged (rb3_build_sais, sais-ss.c:50-56, build.c:55-83)"""
+
+    def __init__(self, device=0, lib=None):
+        self._lib = load_library(False, lib)
+        self._s = self._lib.rb3gpu_sorter_create(int(device))
+        if not self._s:
+            raise RuntimeError("rb3gpu_sorter_create failed on device %d (no HIP device: there is no CPU fallback)" % device)
+
+    def _chk(self, r, what):
+        if r < 0:
+            raise Rb3GpuError(r, what)
+
+    def upload(self, text):
+        """the text of a batch host -> HBM (the H2D copy of the merge path); returns when the copy is complete"""
+        assert text.dtype == np.uint8 and text.flags["C_CONTIGUOUS"]
+        self._chk(self._lib.rb3gpu_sorter_upload(self._s, text.size, text.ctypes.data), "rb3gpu_sorter_upload")
+
+    def sort_uploaded(self, length):
+        """suffix-sort the text uploaded last: (d_bwt, d_tw) device pointers, valid until release(d_bwt)"""
+        p, q = ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_sorter_sort_uploaded(self._s, int(length), ctypes.byref(p), ctypes.byref(q)), "rb3gpu_sorter_sort_uploaded")
+        return p, q
+
+    def sort(self, text):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        p, q = ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_sorter_sort(self._s, text.size, text.ctypes.data, ctypes.byref(p), ctypes.byref(q)), "rb3gpu_sorter_sort")
+        return p, q
+
+    def release(self, d_bwt):
+        self._chk(self._lib.rb3gpu_sorter_release(self._s, d_bwt), "rb3gpu_sorter_release")
+
+    def stats(self):
+        up, so, nb, ns = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+        self._chk(self._lib.rb3gpu_sorter_stats(self._s, ctypes.byref(up), ctypes.byref(so), ctypes.byref(nb), ctypes.byref(ns)), "rb3gpu_sorter_stats")
+        return {"ms_upload": up.value, "ms_sort": so.value, "n_batches": nb.value, "n_symbols": ns.value}
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._lib.rb3gpu_sorter_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Rb3Gpu:
@@ -245,6 +323,14 @@ class Rb3Gpu:
     def export_plain(self):
         out = np.empty(self.get_tot(), dtype=np.uint8)
         self._chk(self._lib.rb3gpu_export_plain(self._h, out.ctypes.data), "rb3gpu_export_plain")
+        return out
+
+    def export_fmd_words(self):
+        """the data section of the index's .fmd, packed on the GPU (rb3_enc_fmr2fmd + rld_enc, fm-index.c:31-52): uint64 array"""
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._chk(self._lib.rb3gpu_export_fmd_words(self._h, ctypes.byref(p), ctypes.byref(n)), "rb3gpu_export_fmd_words")
+        out = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint64)), shape=(n.value,)).copy()
+        self._lib.rb3gpu_host_free(p)
         return out
 
     def export_plain_dev(self, d_out):

@@ -125,6 +125,10 @@ def read_batches(path, is_line, max_len, fwd=True, rev=True):
             b = _Buf(0, 0, None)
             ne = ctypes.c_int64(0)
             n = L.rb3h_seq_read(fp, ctypes.byref(b), max_len, int(fwd), int(rev), ctypes.byref(ne))
+            if n < 0:   # no memory, or the file could not be read to its end (I/O error, truncated gzip stream)
+                if b.s:
+                    libc.free(b.s)
+                raise ValueError("rb3h_seq_read failed with code %d" % n)
             if n <= 0 and b.l == 0:
                 if b.s:
                     libc.free(b.s)
@@ -140,3 +144,34 @@ def read_batches(path, is_line, max_len, fwd=True, rev=True):
 
 def parse_num(s):
     return int(load_library().rb3h_parse_num(s.encode()))
+
+
+def fmd_bytes_from_words(words, acc):
+    """the whole .fmd file -- header, data section, rank index -- from the data section packed on the GPU
+    (Rb3Gpu.export_fmd_words) and the index's C array: what `build -d` writes (rld_dump, rld0.c:222-243; the rank index is
+    rld_rank_index, rld0.c:163-204, built by rb3h_fmdw_adopt on the host)"""
+    import tempfile
+    L = load_library()
+    L.rb3h_fmdw_adopt.restype = ctypes.c_int
+    L.rb3h_fmdw_adopt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    L.rb3h_fmdw_dump_file.restype = ctypes.c_int
+    L.rb3h_fmdw_dump_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    acc = np.ascontiguousarray(acc, dtype=np.int64)
+    z = libc.malloc(words.nbytes)
+    ctypes.memmove(z, words.ctypes.data, words.nbytes)
+    w = L.rb3h_fmdw_init()
+    if L.rb3h_fmdw_adopt(w, z, words.size, acc.ctypes.data) < 0:   # (on failure the array stays ours)
+        libc.free(z)
+        L.rb3h_fmdw_destroy(w)
+        raise ValueError("rb3h_fmdw_adopt failed")
+    with tempfile.NamedTemporaryFile(suffix=".fmd", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as f:
+        r = L.rb3h_fmdw_dump_file(w, f.name.encode())
+        L.rb3h_fmdw_destroy(w)
+        if r < 0:
+            raise IOError("rb3h_fmdw_dump_file failed")
+        return open(f.name, "rb").read()

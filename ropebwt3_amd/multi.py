@@ -100,34 +100,74 @@ def merge_sharded(engine, d_bwt, length, walkers, step, dist, rank, world, pos, 
     return rounds
 
 
-def tree_merge(engine, dist, rank, world, device, sync=None):
+class TreeLink:
+    """point-to-point transport of a plain BWT between two ranks of the tree merge.  backend "nccl" (= RCCL over xGMI): device
+    tensors, send/recv straight between the HBMs.  backend "gloo" (CPU tests, or several ranks sharing ONE GPU, which RCCL
+    refuses): the BWT goes through host memory."""
+
+    def __init__(self, dist, device, on_device, sync=None):
+        import torch
+        self.t, self.dist, self.device, self.on_device = torch, dist, device, on_device
+        self.sync = sync or (lambda: None)
+
+    def send_index(self, engine, dst):
+        t = self.t
+        tot = engine.get_tot()
+        if self.on_device:
+            buf = t.empty(tot + 16, dtype=t.uint8, device=self.device)
+            engine.export_plain_dev(buf.data_ptr())
+            self.sync()
+            self.dist.send(t.tensor([tot], dtype=t.int64, device=self.device), dst=dst)
+            self.dist.send(buf, dst=dst)
+        else:
+            b = engine.export_plain()
+            self.dist.send(t.tensor([tot], dtype=t.int64), dst=dst)
+            self.dist.send(t.from_numpy(b), dst=dst)
+        return tot
+
+    def recv_and_merge(self, engine, src):
+        t = self.t
+        if self.on_device:
+            n = t.zeros(1, dtype=t.int64, device=self.device)
+            self.dist.recv(n, src=src)
+            buf = t.empty(int(n.item()) + 16, dtype=t.uint8, device=self.device)
+            self.dist.recv(buf, src=src)
+            self.sync()
+            engine.merge_plain_dev(buf.data_ptr(), int(n.item()), True)
+        else:
+            n = t.zeros(1, dtype=t.int64)
+            self.dist.recv(n, src=src)
+            buf = t.empty(int(n.item()), dtype=t.uint8)
+            self.dist.recv(buf, src=src)
+            if hasattr(engine, "merge_plain_host"):
+                engine.merge_plain_host(buf.numpy())          # (CPU stand-in of the tests)
+            else:
+                d = engine.dev_upload(buf.numpy())
+                try:
+                    engine.merge_plain_dev(d, int(n.item()), True)
+                finally:
+                    engine.dev_free(d)
+        return int(n.item())
+
+
+def tree_merge(engine, dist, rank, world, device, sync=None, link=None):
     """Combine the per-rank indexes of a partitioned build into rank 0's index.
 
     Every rank has built the index of ITS contiguous slice of the input (slice r before slice r+1).
     Round k merges the index of rank r + 2^k into rank r for r = 0 mod 2^(k+1): the right-hand index
-    is exported as a plain BWT on its GPU, sent over RCCL (xGMI) and merged with rb3gpu_merge_plain_dev.
+    is exported as a plain BWT on its GPU, sent over RCCL (xGMI) and merged with rb3gpu_merge_plain_dev
+    (rb3_fmi_merge, fm-index.c:251-277, with the right operand taken as its BWT).
     merge(A, B) ranks every sentinel of B after those of A (fm-index.c:147, 164), so merging adjacent
     slices left to right reproduces the BWT of the whole input in input order.
     Returns the number of symbols this rank holds afterwards (rank 0: everything).
     """
-    import torch
-    sync = sync or (lambda: None)
+    link = link or TreeLink(dist, device, True, sync)
     stride = 1
     while stride < world:
         if rank % (2 * stride) == 0 and rank + stride < world:
-            n = torch.zeros(1, dtype=torch.int64, device=device)
-            dist.recv(n, src=rank + stride)
-            buf = torch.empty(int(n.item()) + 16, dtype=torch.uint8, device=device)
-            dist.recv(buf, src=rank + stride)
-            sync()
-            engine.merge_plain_dev(buf.data_ptr() if hasattr(buf, "data_ptr") else buf, int(n.item()), True)
+            link.recv_and_merge(engine, rank + stride)
         elif rank % (2 * stride) == stride:
-            tot = engine.get_tot()
-            buf = torch.empty(tot + 16, dtype=torch.uint8, device=device)
-            engine.export_plain_dev(buf.data_ptr())
-            sync()
-            dist.send(torch.tensor([tot], dtype=torch.int64, device=device), dst=rank - stride)
-            dist.send(buf, dst=rank - stride)
+            link.send_index(engine, rank - stride)
         stride *= 2
     return engine.get_tot()
 
@@ -360,7 +400,7 @@ def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1), one process per GPU.  --mode interval (default): north_star -- the index of a random genome
     is cut into N intervals, every step merges one batch of reads (N x 100 k reads of 150 bp, both strands: per-GPU work fixed)
     with merge_interval; the timed step holds every all-gather, the all-to-all of every symbol and the local rebuilds.
-    --mode partition: every GPU merges its own genome into its own index, then the tree merge, all inside the timed region.
+    --mode partition (default): bench_partition_mtb below -- the headline workload (mtb152), partitioned + tree merge.
     --mode replicated: one batch of N genomes, walkers sharded by text range, all-reduce of pos[]."""
     import json
     import os
@@ -370,6 +410,8 @@ def bench_main(args, rank, local_rank, world):
     import torch.distributed as dist
     from ropebwt3_amd import Rb3Gpu, host
     from tests import util
+    if args.mode == "partition":
+        return bench_partition_mtb(args, rank, local_rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -431,36 +473,6 @@ def bench_main(args, rank, local_rank, world):
                     out["n1_same_workload"] = _solo_interval_reference(reads_per_gpu, args, dev, local_rank)
                 except Exception as e:   # never lose the measurement above to this extra
                     out["n1_same_workload"] = {"error": repr(e)}
-    elif args.mode == "partition":
-        g0, gs = util.random_genome(np.random.default_rng(1), args.genome_len), None
-        g1 = util.mutate(np.random.default_rng(2 + rank), g0, args.div)
-        b1 = host.build_bwt(util.make_text([g0]))
-        t2 = util.make_text([g1])
-        w = host.walkers_text(t2, args.walker_step)
-        for _ in range(args.warmup):
-            h.from_plain(b1)
-            d2, d2tw = h.sort_text(t2)
-            h.merge_text_dev(d2, d2tw, t2.size, w, commit=True)
-            h.dev_free(d2), h.dev_free(d2tw)
-        barrier()
-        t = time.perf_counter()
-        for _ in range(args.steps):                                  # a whole partitioned build per step: leaf merges + tree merge
-            h.from_plain(b1)
-            d2, d2tw = h.sort_text(t2)
-            h.merge_text_dev(d2, d2tw, t2.size, w, commit=True)
-            h.dev_free(d2), h.dev_free(d2tw)
-            tot = tree_merge(h, dist, rank, world, dev, sync=torch.cuda.synchronize)
-        barrier()
-        dt = time.perf_counter() - t
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        if rank == 0:
-            assert tot == world * (b1.size + t2.size)
-            out = {"metric": "Gbp/s indexed (build merge)", "value": round(world * (b1.size + t2.size) * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-                   "config": {"workload": "partitioned build END TO END: every GPU indexes 2 genomes of %d bp (index of G0, merge of G_r), then the per-GPU indexes are combined by a binary tree of whole-index merges into rank 0; all of it inside the timed region" % args.genome_len,
-                              "parallelism": "partition%d + tree merge (plain BWTs over RCCL); note DESIGN.md section 6: merging B into A costs |B| LF steps however B was built, so the tree's critical path equals the sequential build" % world}}
     else:
         seeds = [2 + i for i in range(world)]
         g0 = util.random_genome(np.random.default_rng(1), args.genome_len)
@@ -489,4 +501,109 @@ def bench_main(args, rank, local_rank, world):
     if rank == 0:
         print(json.dumps(out), flush=True)
     h.close()
+    dist.destroy_process_group()
+
+
+def bench_partition_mtb(args, rank, local_rank, world):
+    """bench.py --gpus N, default mode: the SAME job as the N = 1 headline -- the mtb152 build, md5-gated -- with the input
+    partitioned: rank r builds the index of genomes [K r / N, K (r+1) / N) exactly as the single-GPU build does (one genome per
+    batch; H2D + merges timed, suffix sorting not counted), then the N indexes are combined into rank 0's by a binary tree of
+    whole-index merges (plain BWTs over RCCL/xGMI, merged through the reference's signature, rb3gpu_merge_plain_dev).
+    One step = the whole partitioned build: max over ranks of the leaf merge paths + the tree merge (barriers on both sides).
+    `value` = the symbols the single-GPU build merges (everything but the first genome) / that time: the job and its output
+    (the .fmd, byte-identical to the reference's) are the same for every N, so the curve over N is strong scaling.
+
+    Where several ranks share a GPU (a one-GPU box: RCCL refuses two ranks on one device) the tree's transfers go through
+    host memory over gloo -- the same code path otherwise; that mode is for testing, not for numbers."""
+    import hashlib
+    import json
+    import os
+    import sys
+    import time
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as B
+    ndev = torch.cuda.device_count()
+    dev_id = local_rank % ndev
+    shared_gpu = ndev < int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if shared_gpu:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    K, L = args.mtb, args.genome_len
+    gold = B.mtb_manifest(K, L)
+    # rank 0 writes the files (a node-local tmpfs), everybody reads its slice
+    box = [None]
+    if rank == 0:
+        tmp, files, _ = B.mtb_files(K, L)
+        box[0] = (tmp, files)
+    dist.broadcast_object_list(box, src=0)
+    tmp, files = box[0]
+    lo, hi = K * rank // world, K * (rank + 1) // world
+    texts, walkers, keep = B.load_batches(files[lo:hi], pinned=not args.no_pinned)
+    bl = B.BuildLoop(dev_id)
+    link = TreeLink(dist, dev, not shared_gpu, sync=torch.cuda.synchronize)
+    zero = torch.zeros(1, device=dev) if not shared_gpu else torch.zeros(1)
+
+    def barrier():
+        bl.h.sync()
+        torch.cuda.synchronize()
+        dist.all_reduce(zero)     # (a collective on the data path's own transport; dist.barrier() on nccl needs a device guess)
+        torch.cuda.synchronize()
+
+    def step():
+        a, b, c, n, w = bl.run(texts, walkers)
+        barrier()
+        t = time.perf_counter()
+        tree_merge(bl.h, dist, rank, world, dev, sync=torch.cuda.synchronize, link=link)
+        barrier()
+        return a + b, time.perf_counter() - t, c, w
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    bl.h.stats_reset()
+    leaf = tree = sort = 0.0
+    for _ in range(args.steps):
+        a, t, c, w = step()
+        leaf, tree, sort = leaf + a, tree + t, sort + c
+    tt = torch.tensor([leaf, tree, sort], dtype=torch.float64, device=dev if not shared_gpu else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    leaf, tree, sort = (float(x) for x in tt)
+    st = bl.h.stats()
+    if rank == 0:
+        md5, fmd_len = bl.fmd_md5()
+        first = os.path.getsize(files[0])  # (not used for the numbers)
+        tot = bl.h.get_tot()
+        n0 = int(texts[0].size)
+        nsym = tot - n0
+        dt = (leaf + tree) / args.steps
+        ident = (md5 == gold["fmd_md5"]) if gold else None
+        out = {"metric": "Gbp/s indexed (build merge)", "value": round(nsym / dt / 1e9, 6), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+               "config": {"workload": "cfg3-synthetic-mtb%d: the same %d genomes of %d bp as the single-GPU headline, %d symbols merged per step; input partitioned over %d GPUs (%d-%d genomes each, one genome per batch), per-GPU indexes combined by a binary tree of whole-index merges" % (K, K, L, nsym, world, K // world, -(-K // world)),
+                          "symbols_per_step": int(nsym), "index_symbols_final": int(tot), "parallelism": "partition%d + tree merge: leaves = the single-GPU merge path on a slice (H2D + rb3gpu_merge_text_dev per genome); tree = rb3gpu_export_plain_dev -> %s -> rb3gpu_merge_plain_dev, %d levels" % (world, "send/recv over gloo through host memory (ranks share a GPU: test mode)" if shared_gpu else "RCCL send/recv over xGMI", (world - 1).bit_length()),
+                          "fmd_md5": md5, "fmd_bytes": fmd_len, "fmd_identical_to_reference": ident, "ranks_share_a_gpu": bool(shared_gpu)},
+               "phases_ms_per_step": {"leaf_merge_paths(max over ranks)": round(leaf / args.steps * 1e3, 3), "tree_merge": round(tree / args.steps * 1e3, 3)},
+               "not_counted_ms_per_step": {"suffix_sorting_on_the_gpu(max over ranks)": round(sort / args.steps * 1e3, 3)},
+               "roofline": B.chain_roofline(int(st["n_lf_steps"] / max(1, st["n_rank_launches"])), st["ms_chain"] / max(1, st["n_rank_launches"]), "text", None,
+                                            "rank 0's k_chain launches (leaf rounds and tree merges together): 208 B x LF steps / HIP-event time")}
+        print(json.dumps(out), flush=True)
+    dist.barrier() if shared_gpu else barrier()
+    bl.close()
+    if rank == 0:
+        for f in files:
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        try:
+            os.rmdir(tmp)
+        except OSError:
+            pass
     dist.destroy_process_group()

@@ -98,6 +98,13 @@ class FakePlainEngine:
         ctypes.memmove(b2.ctypes.data, ptr, n)
         self.b = self.orc.merge(self.b, b2)
 
+    # the host-memory transport of multi.TreeLink (ranks that share one GPU)
+    def export_plain(self):
+        return self.b.copy()
+
+    def merge_plain_host(self, b2):
+        self.b = self.orc.merge(self.b, np.asarray(b2, dtype=np.uint8))
+
 
 class FakeShardEngine:
     """numpy stand-in for the interval-sharded calls (rb3gpu_sh_step / rb3gpu_sh_finish / rb3gpu_get_acc) of ONE rank: it

@@ -148,6 +148,55 @@ def test_seqio_vectorised_conversion_vs_restatement(tmp_path, fmt):
     assert np.array_equal(np.concatenate([g[1] for g in got]), want)
 
 
+_PIPE_READER = """
+import sys, hashlib
+sys.path.insert(0, %r)
+from ropebwt3_amd import host
+n, h = 0, hashlib.md5()
+for k, t in host.read_batches(sys.argv[1], int(sys.argv[2]), 1 << 40):
+    n += k
+    h.update(t.tobytes())
+print(n, h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("is_line", [0, 1])
+@pytest.mark.parametrize("gz", [False, True])
+def test_seqio_input_that_cannot_be_rewound(tmp_path, is_line, gz):
+    """a pipe on stdin and a FIFO, plain and gzip-compressed, give the same batches as the file itself: the reader must not
+    consume the bytes it sniffs (round 2 read the gzip magic off a pipe and then handed zlib a headerless stream, which it
+    passed through as 'sequence')"""
+    import sys
+    rng = np.random.default_rng(5)
+    recs = ["".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(30, 400)))) for _ in range(3000)]
+    raw = ("\n".join(recs) + "\n").encode() if is_line else "".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(recs)).encode()
+    data = gzip.compress(raw) if gz else raw
+    fn = tmp_path / ("in.gz" if gz else "in.txt")
+    fn.write_bytes(data)
+    script = _PIPE_READER % util.ROOT
+    want = subprocess.run([sys.executable, "-c", script, str(fn), str(is_line)], stdout=subprocess.PIPE, check=True).stdout
+    assert int(want.split()[0]) == 2 * len(recs)
+    got = subprocess.run([sys.executable, "-c", script, "-", str(is_line)], input=data, stdout=subprocess.PIPE, check=True).stdout   # a pipe
+    assert got == want
+    fifo = str(tmp_path / "fifo")
+    os.mkfifo(fifo)
+    p = subprocess.Popen([sys.executable, "-c", script, fifo, str(is_line)], stdout=subprocess.PIPE)
+    with open(fifo, "wb") as f:
+        f.write(data)
+    assert p.communicate(timeout=120)[0] == want and p.returncode == 0
+    with open(fn, "rb") as f:   # stdin redirected from the file itself (seekable: the fast path)
+        assert subprocess.run([sys.executable, "-c", script, "-", str(is_line)], stdin=f, stdout=subprocess.PIPE, check=True).stdout == want
+
+
+def test_seqio_truncated_gzip_is_an_error_not_an_end_of_file(tmp_path):
+    recs = ["ACGT" * 50] * 4000
+    data = gzip.compress(("\n".join(recs) + "\n").encode())
+    fn = tmp_path / "cut.gz"
+    fn.write_bytes(data[:len(data) // 2])
+    with pytest.raises(ValueError):
+        list(host.read_batches(str(fn), True, 1 << 40))
+
+
 def test_parse_num():
     assert host.parse_num("7g") == 7000000000 and host.parse_num("500k") == 500000 and host.parse_num("2.5M") == 2500000 and host.parse_num("13") == 13
 

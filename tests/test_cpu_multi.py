@@ -102,7 +102,7 @@ def test_partition_and_plan():
         assert plans[owners[0]][2] == owners[1]
 
 
-def _tree_worker(rank, world, port, q):
+def _tree_worker(rank, world, port, q, host_link=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -118,7 +118,8 @@ def _tree_worker(rank, world, port, q):
         cut = [len(seqs) * r // world for r in range(world + 1)]
         orc = util.Oracle()
         eng = FakePlainEngine(orc, orc.bwt(util.make_text(seqs[cut[rank]:cut[rank + 1]])))
-        multi.tree_merge(eng, dist, rank, world, torch.device("cpu"))
+        link = multi.TreeLink(dist, torch.device("cpu"), False) if host_link else None   # (what bench.py uses when ranks share a GPU)
+        multi.tree_merge(eng, dist, rank, world, torch.device("cpu"), link=link)
         ok = True
         if rank == 0:
             ok = bool(np.array_equal(eng.b, orc.bwt(util.make_text(seqs))))
@@ -127,13 +128,13 @@ def _tree_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_tree_merge_gloo(world):
+@pytest.mark.parametrize("world,host_link", [(2, False), (3, False), (4, False), (3, True)])
+def test_tree_merge_gloo(world, host_link):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tree_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_tree_worker, args=(r, world, port, q, host_link)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(world))

@@ -59,6 +59,15 @@ def test_stdin_input():
     assert out == b"GC$$GGAA\n"
 
 
+def test_gzip_through_a_pipe_on_stdin():
+    """`cat x.fa.gz | build -`: the same .fmd as from the file (the reader must not eat the gzip magic of a pipe)"""
+    ent = MAN["genomes12"]
+    data = open(os.path.join(util.GOLDEN, ent["inputs"][0]), "rb").read()
+    assert data[:2] == b"\x1f\x8b"
+    out, _ = run(["build", "-d", "-m500k", "-"], data)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+
+
 @pytest.mark.parametrize("src", ["fmr", "fmd"])
 def test_resume_from_index(src, tmp_path):
     r = MAN["resume"]

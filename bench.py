@@ -204,7 +204,7 @@ def mtb_files(K, L, tmp=None):
     return tmp, files, time.time() - t
 
 
-def load_batches(files, pinned=True):
+def load_batches(files, pinned=True, step=WALKER_STEP):
     """every file through the CLI's own reader (rb3h_seq_read: nt6, both strands, sentinels; io.c:104-125), one batch per
     file, into page-locked memory (what `ropebwt3-amd build` does with rb3gpu_pinned_alloc) + the walker list of each batch
     (one walker per string + one per 384 text positions, rb3h_walkers_text).  Not timed: file I/O is outside the metric."""
@@ -219,7 +219,7 @@ def load_batches(files, pinned=True):
             keep.append(pa)
             t = pa.array
         texts.append(t)
-        walkers.append(host.walkers_text(t, WALKER_STEP))
+        walkers.append(host.walkers_text(t, step))
     return texts, walkers, keep
 
 
@@ -443,7 +443,7 @@ def main():
         print(json.dumps(cli_build(files, K, gold)), flush=True)
         return
     t0 = time.time()
-    texts, walkers, keep = load_batches(files, pinned=not args.no_pinned)
+    texts, walkers, keep = load_batches(files, pinned=not args.no_pinned, step=args.walker_step)
     nsym_all = int(sum(t.size for t in texts))
     log("mtb%d: %d files generated in %.1f s, read into %s memory in %.1f s (%d symbols)" % (K, K, t_gen, "pageable" if args.no_pinned else "page-locked", time.time() - t0, nsym_all))
 

@@ -131,6 +131,7 @@ struct rb3gpu_s {
 	rb3_grp_t *grp = nullptr;
 	rb3_slot_t *slots = nullptr;
 	struct { rb3_grp_t *grp; size_t grp_cap; rb3_slot_t *slots; size_t slots_cap; } ib[2] = {{nullptr, 0, nullptr, 0}, {nullptr, 0, nullptr, 0}};
+	// (behind the grp_cap directory entries of a buffer sit grp_cap 8-byte words: the compact copy of the entries' slot words, IdxView.gsm)
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
 	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane, wruns, gslots, glist;
@@ -268,10 +269,13 @@ static void tent_used(rb3gpu_t *h, unsigned long long sidctr) // the two 32-bit 
 	h->sid_dirty[1] = b < (unsigned long long)RB3_TENT_HALF ? (int64_t)b : RB3_TENT_HALF;
 }
 
+#define RB3_GRP_ALLOC (sizeof(rb3_grp_t) + 8) /* bytes per directory entry of an index buffer: the entry + its word of the compact copy */
+
 static IdxView view_of(const rb3gpu_t *h)
 {
 	IdxView v;
 	v.grp64 = (const uint64_t*)h->grp, v.slot16 = (const uint4*)h->slots, v.n = h->n, v.m = h->acc[1];
+	v.gsm = h->grp ? (const uint64_t*)(h->ib[h->cur].grp + h->ib[h->cur].grp_cap) : nullptr;
 	const int64_t nwin = (h->n >> RB3_WIN_BITS) + 1;
 	v.dense = h->nslots == nwin ? (RB3_ABS_HEADERS(h->nslots, nwin, h->n) ? 2 : 1) : 0;
 	return v;
@@ -397,7 +401,7 @@ static void index_drop(rb3gpu_t *h)
 
 static void ib_release(rb3gpu_t *h, int i)
 {
-	dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * sizeof(rb3_grp_t));
+	dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * RB3_GRP_ALLOC);
 	dev_free(h, h->ib[i].slots, h->ib[i].slots_cap * sizeof(rb3_slot_t));
 	h->ib[i].grp = nullptr, h->ib[i].slots = nullptr, h->ib[i].grp_cap = h->ib[i].slots_cap = 0;
 }
@@ -407,12 +411,12 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots)
 {
 	int r;
 	if (h->ib[i].grp_cap < (size_t)ngrp) {
-		dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * sizeof(rb3_grp_t));
+		dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * RB3_GRP_ALLOC);
 		h->ib[i].grp = nullptr, h->ib[i].grp_cap = 0;
 		size_t want = (size_t)ngrp + (size_t)(ngrp >> 1) + 16;
-		if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * sizeof(rb3_grp_t))) < 0) {
+		if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * RB3_GRP_ALLOC)) < 0) {
 			want = (size_t)ngrp;
-			if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * sizeof(rb3_grp_t))) < 0) return r;
+			if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * RB3_GRP_ALLOC)) < 0) return r;
 		}
 		h->ib[i].grp_cap = want;
 	}
@@ -439,7 +443,7 @@ static void guard_check(rb3gpu_t *h, const char *where)
 	for (int i = 0; i < 17 + 4; ++i) {
 		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
 		if (i < 17) p = (const uint8_t*)all[i]->p, cap = all[i]->cap, name = names[i];
-		else if (i < 19) p = (const uint8_t*)h->ib[i - 17].grp, cap = h->ib[i - 17].grp_cap * sizeof(rb3_grp_t), name = "index directory";
+		else if (i < 19) p = (const uint8_t*)h->ib[i - 17].grp, cap = h->ib[i - 17].grp_cap * RB3_GRP_ALLOC, name = "index directory";
 		else p = (const uint8_t*)h->ib[i - 19].slots, cap = h->ib[i - 19].slots_cap * sizeof(rb3_slot_t), name = "index slots";
 		if (!p) continue;
 		if (cap == 0) cap = 256;
@@ -692,6 +696,8 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
 				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, skip);
+	// the compact copy of the slot words of the new directory (IdxView.gsm), behind its entries
+	hipLaunchKernelGGL(k_grp_compact, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, h->st, (const uint64_t*)h->ib[dst].grp, ngrp, (uint64_t*)(h->ib[dst].grp + h->ib[dst].grp_cap), skip);
 	*ongrp = ngrp;
 	return 0;
 }
@@ -703,7 +709,7 @@ static void index_install(rb3gpu_t *h, int64_t ngrp, int64_t nslots, int64_t nto
 	h->cur = 1 - h->cur;
 	h->grp = h->ib[h->cur].grp, h->slots = h->ib[h->cur].slots, h->ngrp = ngrp, h->nslots = nslots, h->n = ntot;
 	memcpy(h->acc, acc, sizeof(h->acc));
-	h->stt.bytes_index = ngrp * (int64_t)sizeof(rb3_grp_t) + nslots * (int64_t)sizeof(rb3_slot_t);
+	h->stt.bytes_index = ngrp * (int64_t)RB3_GRP_ALLOC + nslots * (int64_t)sizeof(rb3_slot_t);
 	// do not sit on a large spare buffer: the next merge re-allocates it (it is sized for a bigger index anyway)
 	const int o = 1 - h->cur;
 	if (h->ib[o].slots_cap * sizeof(rb3_slot_t) > ((size_t)4 << 30)) ib_release(h, o);
@@ -1086,6 +1092,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
+#ifdef RB3_PROF_STEP
+	HIPCHK(hipMemsetAsync(misc + 34, 0, 40, h->st));
+#endif
 	if (rows_fused) HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
 	unsigned long long *b2_nwalk = nullptr; // device-side length of a device-made list
 	if (auto_list) {
@@ -1209,6 +1218,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	guard_check(h, __func__);
 	h->stt.n_lf_steps += (int64_t)hm[1];
 	h->stt.n_lf_checked += (int64_t)hm[MISC_LF_CHK];
+#ifdef RB3_PROF_STEP
+	if (hm[37]) fprintf(stderr, "[prof] common step x %llu (lane 0 of every wave): directory %.0f cycles, slot %.0f, decode+rest %.0f, between steps %.0f; %.1f %% of these steps ran the two-decode side for some walker, %.1f %% because of a bit-plane slot\n", hm[37], (double)hm[34] / hm[37], (double)hm[35] / hm[37], (double)hm[36] / hm[37], (double)hm[38] / hm[37], 100.0 * hm[9] / hm[37], 100.0 * hm[10] / hm[37]);
+#endif
 #ifdef RB3_PROF
 	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, %.1f %% of them with the two-decode path -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], 100.0 * (double)hm[12] / (double)hm[10], (double)hm[9] / hm[10]);
 #endif

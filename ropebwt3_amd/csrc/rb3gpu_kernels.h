@@ -31,6 +31,8 @@
 struct IdxView {
 	const uint64_t *grp64;   // rb3_grp_t viewed as 8 x u64
 	const uint4 *slot16;     // rb3_slot_t viewed as 8 x uint4
+	const uint64_t *gsm;     // word 6 of every directory entry (slot0 | mask << 32) once more, 8 bytes per group: small enough to stay in the
+	                         // L2 (1.3 MB for 1.3 G symbols), so the slot of a position can be asked for before its 64-byte entry has come in
 	int64_t n;               // number of symbols
 	int64_t m;               // number of sentinels (= acc[1])
 	int dense;               // 0: mixed slots.  1: every slot is a bit-plane slot (slot index = position >> 8).
@@ -323,6 +325,14 @@ __global__ void __launch_bounds__(256) k_rank_batch(IdxView ix, Acc7 acc, int64_
 /* ----------------------------------------------------------------------------------------- */
 /* LF array of the partial BWT B2 (fm-index.c:206-216)                                         */
 /* ----------------------------------------------------------------------------------------- */
+
+/* the compact copy of the directory's slot words (IdxView.gsm), made after every rebuild */
+__global__ void __launch_bounds__(256) k_grp_compact(const uint64_t *grp64, int64_t ngrp, uint64_t *gsm, const unsigned long long *skip)
+{
+	if (skip && (skip[0] | skip[1] | skip[2])) return; // (single-sync merge whose rank phase did not validate: nothing was built)
+	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g < ngrp) gsm[g] = grp64[g * 8 + 6];
+}
 
 #define RB3_TILE 4096 // bytes of B2 per workgroup (256 threads x 16 B)
 
@@ -636,6 +646,17 @@ __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, uint32_t k
 	*lo_n = (int64_t)(rl.gc + (v & 0xFFFFu)), *hi_n = (int64_t)(rl.gc + (v >> 16));
 }
 
+/* the same with the slot's offset in its group given (derived from the directory's mask: no header word needed) */
+__device__ __forceinline__ void octc_finish_pair_at(const RankLoadC &rl, int off_lo, int off_hi, int c, int j, int64_t *lo_n, int64_t *hi_n)
+{
+	uint32_t ca, cb, mt;
+	slice_count_pk<true, false, 8>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
+	uint32_t v = ca | cb << 16;
+	v += (j == c + 1 ? rl.sl.x : 0u) * 0x00010001u;
+	v = oct_sum(v);
+	*lo_n = (int64_t)(rl.gc + (v & 0xFFFFu)), *hi_n = (int64_t)(rl.gc + (v >> 16));
+}
+
 /* LF(c, k) for the group's query; *match = 1 iff the symbol at offset k itself is c (then the suffix
  * at row k extends by c: used to advance an interval [k, k+1) with a single rank) */
 template<bool DENSE, int LPW = 8, bool MATCH = true>
@@ -873,6 +894,9 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	// flushes them with ONE store instruction every 8 iterations.
 	int64_t bkb = -1, bval = 0;
 	uint32_t it = 0, age = 0;
+#ifdef RB3_PROF_STEP
+	uint64_t prof_t[7] = {0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+#endif
 #ifdef RB3_PROF
 	const uint64_t tstart = __builtin_readcyclecounter();
 	unsigned long long prof_nonpair = 0; // iterations in which some group of this wave took the two-decode path
@@ -931,6 +955,134 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 		// for the second bound of wide walkers and the rare stretch events: a lone wave runs at
 		// instruction-issue speed, so instruction count is the cost.
 		do {
+#ifndef RB3_NO_FAST_STEP
+			if (LIST && !DENSE && TENT && TEXT == 1 && LPW == 8) {
+				// ---- the common step, straight-line.  A genome walked through an index of its relatives spends nine steps in ten in
+				// one state: inside its own segment (so nobody has recorded the row and nothing ends here), not at a sentinel, its
+				// stretch -- if it records tentatively -- already open.  Everything the general step below tests for on the way
+				// (a record met, the end of the segment, a stretch to open, the row after the segment to look up) is then known
+				// not to happen, and a wave runs every test whether it fires or not: ~35 branch regions per iteration, a third of
+				// the issue slots of a kernel that is bound by instruction issue (5 cycles per instruction at 3-6 waves per SIMD).
+				// This body does what the general one does in that state and nothing else; if ANY group of the wave is in another
+				// state the whole wave takes the general step, which handles everything.
+				const uint32_t cq = (uint32_t)x & 7u;
+				const uint64_t kq = (uint64_t)(hi - lo);
+				const bool opening = gap != 0 && sid == -1 && age >= RB3_TENT_MIN_AGE && kq <= (uint64_t)RB3_TENT_KMAX;
+				const bool simple = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) && cq != 0u && (int64_t)rc < 0 && !opening;
+				if (__all(simple)) {
+#ifdef RB3_PROF_STEP /* kernel experiment: where does an iteration of the common step spend its cycles?  (s_memtime at four points) */
+					const uint64_t pt0 = __builtin_amdgcn_s_memtime();
+#endif
+					if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; } // (only after general steps: this body flushes at the end of a window)
+					const int c = (int)cq;
+					// round trip 1: the slot word of lo's group from the compact copy (an L2 hit); the 64-byte entry's count for c is asked
+					// for at the same time but only needed at the very end
+					const int64_t g = lo >> RB3_GRP_BITS;
+					RankLoadC rl;
+					rl.sm = b1.gsm[g];
+					rl.gc = b1.grp64[g * 8 + c];
+					const int64_t tpn = tp - 1;                       // (c != 0: there is a symbol before this one, so tp >= 1)
+					const uint64_t xn = tw[tpn > 0 ? tpn - 1 : 0];    // the word after next
+					const int64_t kbn = (int64_t)(x1 >> 3);
+					rl.koff = (uint32_t)lo & (RB3_GRP - 1);
+					const uint32_t mask = (uint32_t)(rl.sm >> 32), lw = rl.koff >> RB3_WIN_BITS;
+					const uint32_t mlo = mask & ((2u << lw) - 1u);    // slot starts at or below lo's window (bit 0 is always set)
+					rl.sidx = (uint32_t)rl.sm + __popc(mlo) - 1u;
+					octc_load_slot<8>(b1, (int64_t)rl.sidx, j, rl);
+#ifdef RB3_PROF_STEP
+					asm volatile("s_nop 0" :: "v"(rl.sidx));
+					const uint64_t pt1 = __builtin_amdgcn_s_memtime(); // the directory word has arrived, the slot is requested
+#endif
+					// while the slot is on its way: where it starts and ends and what kind it is follow from the mask alone (a slot of
+					// more than one window is a run slot, a single window is bit planes), and so does whether the upper end of the
+					// interval lies in it too; an exact walker is the empty interval [lo, lo)
+					const uint32_t w0 = 31u - (uint32_t)__clz((int)mlo);
+					const uint32_t above = (mask >> w0) >> 1;
+					uint32_t wend = w0 + 1u + (above ? (uint32_t)__builtin_ctz(above) : 31u - w0);
+					if (g == (b1.n >> RB3_GRP_BITS)) { const uint32_t nvw = (uint32_t)(b1.n >> RB3_WIN_BITS & 31) + 1u; wend = wend < nvw ? wend : nvw; } // (the last group ends with the window of position n)
+					const bool rle = wend - w0 > 1u;
+					const uint32_t kq32 = kq > 0xFFFFull ? 0xFFFFu : (uint32_t)kq;
+					const int off_lo = (int)(rl.koff - (w0 << RB3_WIN_BITS)), off_hi = off_lo + (int)kq32;
+					const bool same = rl.koff + kq32 <= (wend << RB3_WIN_BITS);
+					++steps;
+					const int64_t myval = lo + kb;
+					// (once a stretch is open the interval is at most KMAX wide and the walker old enough, for the rest of its life)
+					if ((gap == 0 || sid >= 0) && j == (int)(it & 7u))
+						bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					// the records of the last eight steps: the store is slow (written through) and whatever is asked for after it waits
+					// behind it, so it goes out here, where nothing is asked for during the whole decode
+					if ((it & 7u) == 7u && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
+#ifdef RB3_PROF_STEP
+					asm volatile("s_nop 0" :: "v"(rl.sl.x));
+					const uint64_t pt2 = __builtin_amdgcn_s_memtime(); // the slot has arrived
+#endif
+					int64_t lo_n, hi_n;
+#ifdef RB3_PROF_STEP
+					if (__ballot(!(rle && same)) != 0ull) prof_t[5] += 1;
+					if (__ballot(!rle) != 0ull) prof_t[6] += 1;
+#endif
+					if (rle && same) octc_finish_pair_at(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
+					else { // a bit-plane slot, or the upper end lies in the next slot
+						uint32_t match = 0, mh;
+						lo_n = octc_finish<false, 8>(rl, c, j, &match);
+						hi_n = gap == 1 ? lo_n + match : lo_n;
+						if (gap == 2) {
+							RankLoadC rh;
+							octc_issue_grp<false, 8>(b1, hi, c, j, rh);
+							octc_issue_slot_hi<false, 8>(b1, j, rh, rl);
+							hi_n = octc_finish<false, 8, false>(rh, c, j, &mh);
+						}
+					}
+					const int64_t kn = hi_n - lo_n;
+					if (gap == 2 && sid >= 0 && kn >= 1 && kn < (int64_t)kq) { // some matching suffixes are not preceded by c: a new stretch (see below)
+						int ns = sid + 1;
+						if (sid == RB3_TENT_POISON) ns = RB3_TENT_POISON;
+						else if ((ns & (RB3_TENT_BLOCK - 1)) == 0) {
+							uint32_t s0 = 0;
+							if (j == 0) s0 = atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
+							s0 = oct_bcast0(s0, j);
+							ns = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
+						}
+						if (j == 0 && ns != RB3_TENT_POISON) {
+							tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = kq | (uint64_t)c << 8;
+							tab[ns].pad[0] = (uint32_t)sid0 + 1u;
+							tab[sid].child = ns + 1;
+						}
+						sid = ns;
+					}
+					++age, --remaining;
+					tp = tpn, x = x1, x1 = xn;
+					kb = kbn, lo = lo_n, hi = hi_n, gap = kn > 1 ? 2 : (int)kn;
+#ifdef RB3_PROF_STEP
+					{
+						asm volatile("s_nop 0" :: "v"((uint32_t)lo));
+						const uint64_t pt3 = __builtin_amdgcn_s_memtime();
+						prof_t[0] += pt1 - pt0, prof_t[1] += pt2 - pt1, prof_t[2] += pt3 - pt2, prof_t[3] += 1;
+						if (prof_last) prof_t[4] += pt0 - prof_last; // (from the end of one common step to the start of the next: the test, the loop)
+						prof_last = pt3;
+					}
+#endif
+#ifdef RB3_EXP_VALU /* kernel experiment: what do RB3_EXP_VALU more vector instructions per iteration cost?  (four independent chains) */
+					{
+						uint32_t e0 = (uint32_t)kb, e1 = e0 + 1u, e2 = e0 + 2u, e3 = e0 + 3u;
+#pragma unroll
+						for (int q = 0; q < RB3_EXP_VALU / 4; ++q) {
+							asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(e0));
+							asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(e1));
+							asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(e2));
+							asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(e3));
+						}
+						if ((e0 ^ e1 ^ e2 ^ e3) == 0x7fffff1u) steps += 1000000u; // (keeps the chains alive; practically never true)
+					}
+#endif
+					continue;
+				}
+			}
+#endif
+#ifdef RB3_PROF_STEP
+			prof_last = 0;
+#endif
 			if ((++it & (uint32_t)(LPW - 1)) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
 			const bool met = TEXT ? (int64_t)rc >= 0 : (int64_t)x >= 0;  // this row already carries a record
 			const int c = (int)(x & 7u);
@@ -1044,6 +1196,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 		} while (__all(active));
 	}
 	if (j == 0) atomicAdd(nsteps, (unsigned long long)steps);
+#ifdef RB3_PROF_STEP
+	if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(nsteps + 33 + q, (unsigned long long)prof_t[q]); // misc[34..38]
+	if (lane == 0) atomicAdd(nsteps + 8, (unsigned long long)prof_t[5]), atomicAdd(nsteps + 9, (unsigned long long)prof_t[6]); // misc[9], misc[10]
+#endif
 #ifdef RB3_PROF
 	if (lane == 0) { // wave statistics: [8] max cycles, [9] sum cycles, [10] sum iterations, [11] waves, [12] max iterations
 		const unsigned long long cyc = __builtin_readcyclecounter() - tstart;

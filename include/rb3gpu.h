@@ -69,6 +69,7 @@ typedef struct {
 	int64_t n_allocs;
 	int64_t n_reb_again;         /* rebuilds done twice because a buffer sized by an estimate did not take the result */
 	int64_t bytes_rebuild;       /* algorithmic bytes of the rebuilds: per merge 9 B x rows + old block array + new block array */
+	int64_t n_thinned;           /* merges done again with fewer, longer walkers because the table of tentative stretches was full */
 } rb3gpu_stats_t;
 
 void rb3gpu_opt_init(rb3gpu_opt_t *opt);
@@ -249,6 +250,12 @@ int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, c
 /* the same stream decoded on the device and merged into the index the handle holds as one batch, like rb3gpu_merge_plain
  * (`ropebwt3 merge`, main.c:84-133, with the right-hand index taken as its BWT) */
 int rb3gpu_merge_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE]);
+
+/* rb3_fmi_merge(fa, fb), fm-index.c:251-277 (`ropebwt3 merge`, main.c:84-133) between two handles: every string of the index in
+ * `src` is merged into `h` as one batch (its sentinels rank after those of `h`, fm-index.c:147).  The two may sit on different
+ * GPUs: the plain BWT of `src` goes device to device (xGMI).  This is the tree step of a partitioned multi-GPU build
+ * (`ropebwt3-amd build --gpus N`): slices of the input indexed on N devices, then merged pairwise in input order. */
+int rb3gpu_merge_index(rb3gpu_t *h, rb3gpu_t *src);
 
 /* INTERVAL-SHARDED INDEX over several GPUs (one process and one handle per GPU; no reference analogue beyond the walk over
  * the per-rope totals in mr_rank2a, mrope.c:76-88, and the kt_for over strings, fm-index.c:217-224).  The accumulated BWT is

@@ -30,7 +30,7 @@ enum { FMT_PLAIN = 0, FMT_FMD, FMT_FMR };
 typedef struct {
 	int64_t flag, batch_size;
 	int fmt, n_threads, sais_threads, block_len, max_nodes;
-	int device, split_log2, rebatch, gpu_sort, host_fmd;
+	int device, n_gpus, split_log2, rebatch, gpu_sort, host_fmd;
 	int64_t gpu_batch;      /* with GPU suffix sorting a batch (-m) is cut into sub-batches of at most this many symbols, at record
 	                           boundaries: the .fmd does not depend on the batching, and the GPU sorter takes < 2^31 */
 	int64_t gpu_sort_limit; /* batches of this many symbols or more go to the host sorter (one record longer than a sub-batch) */
@@ -38,13 +38,16 @@ typedef struct {
 
 /* how the batches of this run were sorted (for the closing statistics line) */
 static struct { int64_t n_gpu, n_host, sym_gpu, sym_host; double ms_upload, ms_sort; } g_sorted;
+static pthread_mutex_t g_sorted_mtx = PTHREAD_MUTEX_INITIALIZER; /* (the slices of a multi-GPU build end at different times) */
+/* what the handles of the other slices of a multi-GPU build did, added up before they are destroyed (the closing statistics) */
+static struct { double ms_path; int64_t n_sym; } g_other_slices;
 
 static void bopt_init(bopt_t *o) /* build.c:31-41 */
 {
 	memset(o, 0, sizeof(*o));
 	o->n_threads = 4, o->sais_threads = -1, o->fmt = FMT_PLAIN;
 	o->block_len = 512, o->max_nodes = 64, o->batch_size = 7000000000LL;
-	o->device = 0, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 1, o->host_fmd = 0;
+	o->device = 0, o->n_gpus = 1, o->split_log2 = 0, o->rebatch = 0, o->gpu_sort = 1, o->host_fmd = 0;
 	o->gpu_batch = 1LL << 29, o->gpu_sort_limit = (int64_t)INT32_MAX - 16;
 }
 
@@ -67,6 +70,8 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	fprintf(fp, "    -l INT      leaf block size in B+-tree (FMR output only) [%d]\n", opt->block_len);
 	fprintf(fp, "    -n INT      max number children per internal node (FMR output only) [%d]\n", opt->max_nodes);
 	fprintf(fp, "    --gpu INT   HIP device ordinal [%d]\n", opt->device);
+	fprintf(fp, "    --gpus INT  build on INT GPUs: the input files are cut into INT contiguous slices, every GPU indexes one (devices --gpu,\n");
+	fprintf(fp, "                --gpu + 1, ...), and the indexes are merged pairwise in input order (same output) [1]\n");
 	fprintf(fp, "    --split INT start extra LF walkers every 2^INT rows (0=auto, -1=never) [%d]\n", opt->split_log2);
 	fprintf(fp, "    --rebatch   let a batch span input files (same output, fewer merge rounds)\n");
 	fprintf(fp, "    --host-sort suffix-sort the batches on the host (default: on the GPU; same output; -p then sets the number\n");
@@ -545,6 +550,96 @@ static void *sorter_main(void *arg)
 	}
 }
 
+/* one slice of the input on one GPU: reader thread -> sorter thread(s) -> merges, in input order (build.c:186-239).  A build on
+ * one GPU is one slice; `--gpus N` runs N of them side by side, one per device, and merges their indexes afterwards. */
+typedef struct {
+	rb3gpu_t *h;
+	const bopt_t *opt;
+	int device, n_files, has_index, ret;
+	char **files;
+	const char *fn_tmp;
+	int64_t n_empty;
+	rb3gpu_sorter_t *old_sorters[4];
+	int n_old_sorters;
+} slice_t;
+
+static void *run_slice(void *arg)
+{
+	slice_t *sl = (slice_t*)arg;
+	const bopt_t *opt = sl->opt;
+	rb3gpu_t *h = sl->h;
+	int ret = 0, has_index = sl->has_index;
+	int64_t n_empty = 0;
+	const char *fn_tmp = sl->fn_tmp;
+	rb3gpu_sorter_t **old_sorters = sl->old_sorters;
+	int n_old_sorters = 0;
+	const int argc = sl->n_files, optind = 0;
+	char **argv = sl->files;
+	if (opt->sais_threads > 0 && argc - optind >= 1) { /* N suffix sorters ahead of the GPU merge */
+		pool_t q;
+		reader_t rd;
+		pthread_t rt, *st;
+		consumer_t cs = { h, opt, has_index, fn_tmp };
+		int k, n_sort = opt->sais_threads;
+		sorter_arg_t *sa;
+		if (opt->gpu_sort && n_sort > 3) n_sort = 3; /* GPU sorters: more than a few at once only compete for the same GPU */
+		memset(&q, 0, sizeof(q));
+		pthread_mutex_init(&q.mtx, 0);
+		pthread_cond_init(&q.cv, 0);
+		q.cap = n_sort + 2, q.ring = (job_t*)calloc((size_t)q.cap, sizeof(job_t)), q.opt = opt;
+		memset(&rd, 0, sizeof(rd));
+		rd.q = &q, rd.n_files = argc - optind, rd.files = argv + optind;
+		st = (pthread_t*)calloc((size_t)n_sort, sizeof(pthread_t));
+		sa = (sorter_arg_t*)calloc((size_t)n_sort, sizeof(sorter_arg_t));
+		pthread_create(&rt, 0, reader_main, &rd);
+		for (k = 0; k < n_sort; ++k) {
+			sa[k].q = &q, sa[k].gs = opt->gpu_sort ? rb3gpu_sorter_create(sl->device) : 0; /* NULL: the consumer's handle sorts */
+			pthread_create(&st[k], 0, sorter_main, &sa[k]);
+		}
+		for (;;) {
+			job_t j;
+			pthread_mutex_lock(&q.mtx);
+			while (!(q.head < q.tail && q.ring[q.head % q.cap].state == 3) && !(q.reader_done && q.head == q.tail))
+				pthread_cond_wait(&q.cv, &q.mtx);
+			if (q.head == q.tail) { pthread_mutex_unlock(&q.mtx); break; }
+			j = q.ring[q.head % q.cap];
+			q.ring[q.head % q.cap].state = 0;
+			++q.head;
+			pthread_cond_broadcast(&q.cv);
+			pthread_mutex_unlock(&q.mtx);
+			if (j.err != 0) ret = -1;
+			if (ret == 0) ret = consume(&cs, j.out, j.end_of_file);
+			else if (j.out) {
+				if (j.out->d_bwt) rb3gpu_sorter_release(j.out->gs, j.out->d_bwt);
+				rb3h_batch_free(j.out->bwt); free(j.out->walkers); free(j.out);
+			}
+		}
+		pthread_join(rt, 0);
+		for (k = 0; k < n_sort; ++k) pthread_join(st[k], 0);
+		for (k = 0; k < n_sort; ++k) {
+			double up = 0, so = 0;
+			if (sa[k].gs && rb3gpu_sorter_stats(sa[k].gs, &up, &so, 0, 0) == 0) {
+				pthread_mutex_lock(&g_sorted_mtx);
+				g_sorted.ms_upload += up, g_sorted.ms_sort += so;
+				pthread_mutex_unlock(&g_sorted_mtx);
+			}
+			/* the sorters' scratch (tens of bytes per symbol of a batch) is given back AFTER the index has been written: freeing
+			 * gigabytes here made the next device allocation -- the run list of the FMD export -- wait for up to 1.4 s */
+			if (sa[k].gs && n_old_sorters < 4) old_sorters[n_old_sorters++] = sa[k].gs;
+			else rb3gpu_sorter_destroy(sa[k].gs);
+		}
+		free(st); free(sa); free(q.ring);
+		if (rd.err != 0) ret = -1;
+		n_empty = rd.n_empty, has_index = cs.has_index;
+	} else if (argc - optind >= 1) {
+		consumer_t cs = { h, opt, has_index, fn_tmp };
+		ret = for_each_batch(opt, argc - optind, argv + optind, submit_serial, &cs, &n_empty);
+		has_index = cs.has_index;
+	}
+	sl->ret = ret, sl->has_index = has_index, sl->n_empty = n_empty, sl->n_old_sorters = n_old_sorters;
+	return 0;
+}
+
 static const struct option long_opts[] = {
 	{ "gpu", required_argument, 0, 301 },
 	{ "split", required_argument, 0, 302 },
@@ -554,6 +649,7 @@ static const struct option long_opts[] = {
 	{ "gpu-batch", required_argument, 0, 306 },
 	{ "gpu-sort-limit", required_argument, 0, 307 }, /* (tests: pretend the GPU sorter takes less than it does) */
 	{ "host-fmd", no_argument, 0, 308 },
+	{ "gpus", required_argument, 0, 309 },
 	{ 0, 0, 0, 0 }
 };
 
@@ -598,6 +694,7 @@ int main_build(int argc, char *argv[])
 		else if (c == 306) opt.gpu_batch = rb3h_parse_num(optarg);
 		else if (c == 307) opt.gpu_sort_limit = rb3h_parse_num(optarg);
 		else if (c == 308) opt.host_fmd = g_host_fmd = 1;
+		else if (c == 309) opt.n_gpus = atoi(optarg);
 		else if (c == '?') return 1;
 	}
 	if (opt.gpu_sort_limit > (int64_t)INT32_MAX - 16) opt.gpu_sort_limit = (int64_t)INT32_MAX - 16;
@@ -635,62 +732,59 @@ int main_build(int argc, char *argv[])
 	}
 
 	if (opt.sais_threads < 0) opt.sais_threads = opt.gpu_sort ? 1 : 0; /* one batch sorted on the GPU while the one before is merged */
-	if (opt.sais_threads > 0 && argc - optind >= 1) { /* N suffix sorters ahead of the GPU merge */
-		pool_t q;
-		reader_t rd;
-		pthread_t rt, *st;
-		consumer_t cs = { h, &opt, has_index, fn_tmp };
-		int k, n_sort = opt.sais_threads;
-		sorter_arg_t *sa;
-		if (opt.gpu_sort && n_sort > 3) n_sort = 3; /* GPU sorters: more than a few at once only compete for the same GPU */
-		memset(&q, 0, sizeof(q));
-		pthread_mutex_init(&q.mtx, 0);
-		pthread_cond_init(&q.cv, 0);
-		q.cap = n_sort + 2, q.ring = (job_t*)calloc((size_t)q.cap, sizeof(job_t)), q.opt = &opt;
-		memset(&rd, 0, sizeof(rd));
-		rd.q = &q, rd.n_files = argc - optind, rd.files = argv + optind;
-		st = (pthread_t*)calloc((size_t)n_sort, sizeof(pthread_t));
-		sa = (sorter_arg_t*)calloc((size_t)n_sort, sizeof(sorter_arg_t));
-		pthread_create(&rt, 0, reader_main, &rd);
-		for (k = 0; k < n_sort; ++k) {
-			sa[k].q = &q, sa[k].gs = opt.gpu_sort ? rb3gpu_sorter_create(opt.device) : 0; /* NULL: the consumer's handle sorts */
-			pthread_create(&st[k], 0, sorter_main, &sa[k]);
-		}
-		for (;;) {
-			job_t j;
-			pthread_mutex_lock(&q.mtx);
-			while (!(q.head < q.tail && q.ring[q.head % q.cap].state == 3) && !(q.reader_done && q.head == q.tail))
-				pthread_cond_wait(&q.cv, &q.mtx);
-			if (q.head == q.tail) { pthread_mutex_unlock(&q.mtx); break; }
-			j = q.ring[q.head % q.cap];
-			q.ring[q.head % q.cap].state = 0;
-			++q.head;
-			pthread_cond_broadcast(&q.cv);
-			pthread_mutex_unlock(&q.mtx);
-			if (j.err != 0) ret = -1;
-			if (ret == 0) ret = consume(&cs, j.out, j.end_of_file);
-			else if (j.out) {
-				if (j.out->d_bwt) rb3gpu_sorter_release(j.out->gs, j.out->d_bwt);
-				rb3h_batch_free(j.out->bwt); free(j.out->walkers); free(j.out);
+	if (opt.n_gpus < 1) opt.n_gpus = 1;
+	if (opt.n_gpus > argc - optind) opt.n_gpus = argc - optind > 0 ? argc - optind : 1; /* slices are cut at file boundaries */
+	if (opt.n_gpus > 1 && fn_tmp) { fprintf(stderr, "ERROR: -S (save after each file) is not available with --gpus\n"); rb3gpu_destroy(h); return 1; }
+	if (opt.n_gpus == 1) {
+		slice_t sl;
+		memset(&sl, 0, sizeof(sl));
+		sl.h = h, sl.opt = &opt, sl.device = opt.device, sl.n_files = argc - optind, sl.files = argv + optind, sl.has_index = has_index, sl.fn_tmp = fn_tmp;
+		run_slice(&sl);
+		ret = sl.ret, has_index = sl.has_index, n_empty = sl.n_empty;
+		for (c = 0; c < sl.n_old_sorters && n_old_sorters < 4; ++c) old_sorters[n_old_sorters++] = sl.old_sorters[c];
+	} else { /* partitioned build: slice k of the files on device (--gpu + k) mod #devices, then a binary tree of whole-index merges */
+		const int N = opt.n_gpus, ndev = rb3gpu_device_count(), nf = argc - optind;
+		slice_t *sl = (slice_t*)calloc((size_t)N, sizeof(slice_t));
+		pthread_t *th = (pthread_t*)calloc((size_t)N, sizeof(pthread_t));
+		int k, stride;
+		double t_tree;
+		for (k = 0; k < N && ret == 0; ++k) {
+			const int f0 = (int)((int64_t)nf * k / N), f1 = (int)((int64_t)nf * (k + 1) / N);
+			sl[k].opt = &opt, sl[k].device = (opt.device + k) % (ndev > 0 ? ndev : 1), sl[k].n_files = f1 - f0, sl[k].files = argv + optind + f0;
+			if (k == 0) sl[k].h = h, sl[k].has_index = has_index; /* (an index given with -i is the start of slice 0) */
+			else {
+				gopt.device = sl[k].device;
+				sl[k].h = rb3gpu_create(&gopt);
+				if (sl[k].h == 0) { fprintf(stderr, "ERROR: no usable HIP device %d for slice %d\n", sl[k].device, k); ret = -1; }
 			}
 		}
-		pthread_join(rt, 0);
-		for (k = 0; k < n_sort; ++k) pthread_join(st[k], 0);
-		for (k = 0; k < n_sort; ++k) {
-			double up = 0, so = 0;
-			if (sa[k].gs && rb3gpu_sorter_stats(sa[k].gs, &up, &so, 0, 0) == 0) g_sorted.ms_upload += up, g_sorted.ms_sort += so;
-			/* the sorters' scratch (tens of bytes per symbol of a batch) is given back AFTER the index has been written: freeing
-			 * gigabytes here made the next device allocation -- the run list of the FMD export -- wait for up to 1.4 s */
-			if (sa[k].gs && n_old_sorters < 4) old_sorters[n_old_sorters++] = sa[k].gs;
-			else rb3gpu_sorter_destroy(sa[k].gs);
+		if (ret == 0) {
+			for (k = 0; k < N; ++k) pthread_create(&th[k], 0, run_slice, &sl[k]);
+			for (k = 0; k < N; ++k) {
+				pthread_join(th[k], 0);
+				if (sl[k].ret != 0 || !sl[k].has_index) ret = -1;
+				n_empty += sl[k].n_empty;
+				for (c = 0; c < sl[k].n_old_sorters; ++c) rb3gpu_sorter_destroy(sl[k].old_sorters[c]); /* (their scratch must not sit on the devices during the tree merge) */
+			}
 		}
-		free(st); free(sa); free(q.ring);
-		if (rd.err != 0) ret = -1;
-		n_empty = rd.n_empty, has_index = cs.has_index;
-	} else if (argc - optind >= 1) {
-		consumer_t cs = { h, &opt, has_index, fn_tmp };
-		ret = for_each_batch(&opt, argc - optind, argv + optind, submit_serial, &cs, &n_empty);
-		has_index = cs.has_index;
+		if (ret == 0 && rb3h_verbose >= 3)
+			fprintf(stderr, "[M::%s::%.3f*%.2f] %d slices indexed on %d GPUs\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), N, ndev < N ? ndev : N);
+		t_tree = rb3h_realtime();
+		for (stride = 1; stride < N && ret == 0; stride *= 2) /* merge(A, B) ranks the sentinels of B after those of A (fm-index.c:147): adjacent slices, left to right */
+			for (k = 0; k + stride < N && ret == 0; k += 2 * stride) { /* (the merges of one level are independent; they are short next to the slices and run in turn) */
+				const int r = rb3gpu_merge_index(sl[k].h, sl[k + stride].h);
+				if (r < 0) { fprintf(stderr, "ERROR: the GPU engine failed to merge the index of slice %d into slice %d: %s\n", k + stride, k, rb3gpu_strerror(r)); ret = -1; }
+				else {
+					rb3gpu_stats_t so;
+					if (rb3gpu_stats(sl[k + stride].h, &so) == 0) g_other_slices.ms_path += so.ms_h2d + so.ms_lf + so.ms_rank + so.ms_build, g_other_slices.n_sym += so.n_symbols_merged;
+					rb3gpu_destroy(sl[k + stride].h), sl[k + stride].h = 0;
+					if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] merged the index of slice %d into slice %d\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), k + stride, k);
+				}
+			}
+		if (ret == 0 && rb3h_verbose >= 3) fprintf(stderr, "[M::%s] tree merge of %d slices: %.3f s\n", __func__, N, rb3h_realtime() - t_tree);
+		for (k = 1; k < N; ++k) if (sl[k].h) rb3gpu_destroy(sl[k].h);
+		has_index = ret == 0;
+		free(sl); free(th);
 	}
 	if (n_empty > 0 && rb3h_verbose >= 2)
 		fprintf(stderr, "WARNING: skipped %ld empty sequence(s)\n", (long)n_empty);
@@ -716,6 +810,8 @@ int main_build(int argc, char *argv[])
 		rb3gpu_stats(h, &st);
 		fprintf(stderr, "[M::%s] GPU merge path: %ld symbols merged in %.3f ms (H2D %.3f + LF %.3f + rank %.3f + rebuild %.3f); index %.1f MB in HBM\n", __func__,
 				(long)st.n_symbols_merged, st.ms_h2d + st.ms_lf + st.ms_rank + st.ms_build, st.ms_h2d, st.ms_lf, st.ms_rank, st.ms_build, st.bytes_index / 1e6);
+		if (g_other_slices.n_sym > 0)
+			fprintf(stderr, "[M::%s] the other slices of this multi-GPU build (their own GPUs, side by side): %ld symbols merged in %.3f ms of merge path, summed over the slices\n", __func__, (long)g_other_slices.n_sym, g_other_slices.ms_path);
 		if (st.ms_sort > 0)
 			fprintf(stderr, "[M::%s] GPU suffix sorting: %.3f ms in all (%ld doubling rounds), text upload included\n", __func__, st.ms_sort, (long)st.n_sort_rounds);
 		if (g_sorted.ms_sort > 0)

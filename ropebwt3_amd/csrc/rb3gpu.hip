@@ -1028,7 +1028,7 @@ static int walkers_text_to_rows(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_wal
 }
 
 static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
-		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw = nullptr);
+		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw = nullptr, int thin = 1);
 
 /* the paths that walk row words, for a batch that came with text-order words */
 static int merge_staged_text(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
@@ -1042,8 +1042,27 @@ static int merge_staged_text(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int 
 	return r;
 }
 
+/* every thin-th walker of a list in text order (rb3h_walkers_text / rb3h_build_bwt_walkers: per string its inner walkers from left to
+ * right, each with the distance to the one before, then the walker of its sentinel): the segments of the dropped ones go to their
+ * right-hand neighbours */
+static rb3gpu_walker_t *thin_walkers(int64_t n, const rb3gpu_walker_t *w, int thin, int64_t *n_out)
+{
+	rb3gpu_walker_t *o = (rb3gpu_walker_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(rb3gpu_walker_t));
+	if (!o) return nullptr;
+	const int64_t INF = INT64_MAX / 2;
+	int64_t k = 0, idx = 0, acc = 0;
+	for (int64_t i = 0; i < n; ++i) {
+		acc = (acc >= INF || w[i].nsteps >= INF) ? INF : acc + w[i].nsteps;
+		const bool sentinel = w[i].ka0 == RB3GPU_KA_SENTINEL || w[i].ka0 >= 0; // (a walker that knows its insertion point ends a string's group, or is somebody's hand-off: always kept)
+		if (sentinel || idx % thin == thin - 1) { o[k] = w[i], o[k].nsteps = acc, ++k, acc = 0; }
+		idx = sentinel ? 0 : idx + 1;
+	}
+	*n_out = k;
+	return o;
+}
+
 static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
-		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw)
+		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw, int thin)
 {
 	const int64_t ntot = h->n + len, nwin = (ntot >> RB3_WIN_BITS) + 1;
 	int tent = h->tn.tent;
@@ -1055,7 +1074,12 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	// neither (the reference's signature: BWT only): the list is made on the device from a sparse LF walk of the batch itself
 	const bool auto_list = !walkers && !per_string && !d_tw && h->tn.b2_split > 0 && h->opt.split_log2 == 0 && len >= 4096;
 	const int b2S = h->tn.b2_split;
-	const int64_t b2_nbk = len / RB3_B2_W + 1, b2_m2cap = len / 64 + 1, b2_nspmax = (len >> b2S) + b2_m2cap + 2;
+	// the device-made list: a walker every b2W text positions -- 384, or more where the batch is so large that the events of that
+	// many walkers would not fit the stretch table (and `thin` times that after a merge whose table did overflow)
+	int64_t b2W = RB3_B2_W;
+	while (len / b2W > (1 << 18)) b2W *= 2;
+	b2W *= thin;
+	const int64_t b2_nbk = len / b2W + 1, b2_m2cap = len / 64 + 1, b2_nspmax = (len >> b2S) + b2_m2cap + 2;
 	if (auto_list) n_walkers = b2_nbk + b2_m2cap; // capacity of the list; how many are in use stays on the device
 	const int tent_auto = tent;
 	if (per_string) tent = 0; // every walker is exact
@@ -1107,16 +1131,16 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		b2_nwalk = misc + 13;
 		HIPCHK(hipMemsetAsync(bucket, 0xff, (size_t)b2_nbk * 8, h->st));
 		HIPCHK(hipMemsetAsync(slen, 0, (size_t)(b2_m2cap + 2) * 8, h->st));
-		hipLaunchKernelGGL(k_b2_mode, dim3(1), dim3(64), 0, h->st, tot2, len, b2_m2cap, mode);
+		hipLaunchKernelGGL(k_b2_mode, dim3(1), dim3(64), 0, h->st, tot2, len, b2_m2cap, mode, b2W);
 		hipLaunchKernelGGL(k_b2_walk, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)h->pos.p, len, tot2, b2S, (const unsigned long long*)mode, lnk[0]);
 		int cur = 0;
 		for (int64_t reach = 1; reach < b2_nspmax; reach <<= 2, cur ^= 1) // (on the upper bound of the splitter count; entries behind the real count are never read)
 			hipLaunchKernelGGL(k_b2_jump4, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, b2_nspmax, (const uint64_t*)lnk[cur], lnk[cur ^ 1]);
 		hipLaunchKernelGGL(k_b2_strings, dim3(64), dim3(256), 0, h->st, tot2, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], slen);
 		hipLaunchKernelGGL(k_b2_scan, dim3(1), dim3(1024), 0, h->st, tot2, (const unsigned long long*)mode, slen);
-		hipLaunchKernelGGL(k_b2_pick, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], (const uint64_t*)slen, bucket);
+		hipLaunchKernelGGL(k_b2_pick, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], (const uint64_t*)slen, bucket, b2W);
 		hipLaunchKernelGGL(k_b2_list, dim3((unsigned)((n_walkers + 255) / 256 < 2048 ? (n_walkers + 255) / 256 : 2048)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode,
-				(const uint64_t*)lnk[cur], (const uint64_t*)slen, (const unsigned long long*)bucket, b2_nbk, (Walker*)h->wl.p, b2_nwalk, (const int64_t*)h->pos.p);
+				(const uint64_t*)lnk[cur], (const uint64_t*)slen, (const unsigned long long*)bucket, b2_nbk, (Walker*)h->wl.p, b2_nwalk, (const int64_t*)h->pos.p, b2W);
 	} else if (per_string && d_tw) {
 		HIPCHK(hipMemsetAsync(h->wl.p, 0xff, (size_t)n_walkers * 32, h->st)); // a walker that nobody fills in starts at row -1: caught below
 		hipLaunchKernelGGL(k_walkers_per_string, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw, len);
@@ -1127,10 +1151,16 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		if (h->stage[0] == nullptr)
 			for (int i = 0; i < 2; ++i)
 				if (hipHostMalloc((void**)&h->stage[i], RB3_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { h->stage[i] = nullptr; break; }
-		if (h->stage[0] && wb <= RB3_STAGE_BYTES) {
+		// The list goes over the side stream, beside the LF kernels queued above (on the main stream its DMA sat between them and
+		// the walkers: ~45 us per merge with the chip idle); the host copies it into pinned memory while those kernels run.
+		const void *src = walkers;
+		if (!is_pinned(walkers, wb) && h->stage[0] && wb <= RB3_STAGE_BYTES) {
 			memcpy(h->stage[0], walkers, wb); // safe to reuse: every earlier copy out of it was synchronised
-			HIPCHK(hipMemcpyAsync(dwl, h->stage[0], wb, hipMemcpyHostToDevice, h->st));
-		} else HIPCHK(hipMemcpyAsync(dwl, walkers, wb, hipMemcpyHostToDevice, h->st));
+			src = h->stage[0];
+		}
+		HIPCHK(hipMemcpyAsync(dwl, src, wb, hipMemcpyHostToDevice, h->st2));
+		HIPCHK(hipEventRecord(h->evx[1], h->st2));
+		HIPCHK(hipStreamWaitEvent(h->st, h->evx[1], 0));
 	}
 	int64_t *dpos = (int64_t*)h->pos.p;
 	{
@@ -1291,6 +1321,23 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			h->stt.ms_build += ev_ms(h->ev[5], h->ev[3]);
 			h->stt.n_long_settles += 1;
 		}
+	}
+	const unsigned long long tent_cap_a = sid_limit < (uint32_t)RB3_TENT_HALF ? sid_limit : (uint32_t)RB3_TENT_HALF, tent_cap_b = sid_limit < (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF) ? sid_limit : (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF);
+	if (tent && hm[4] != 0 && thin < 64 && !per_string && ((hm[5] & 0xFFFFFFFFull) + RB3_TENT_BLOCK > tent_cap_a || (hm[5] >> 32) >= tent_cap_b)) {
+		// The stretch table was full (a huge batch whose walkers pass the variants of many indexed relatives: events ~ walkers x
+		// relatives): once more with every eighth walker -- the events of a walker stop growing once it has seen every relative
+		// drop out, so fewer, longer walkers need fewer stretches -- before giving up on tentative records altogether.
+		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] the table of tentative stretches is full (%llu + %llu ids); once more with %d times fewer walkers\n", hm[5] & 0xFFFFFFFFull, hm[5] >> 32, 8);
+		h->stt.n_thinned += 1;
+		if (walkers) {
+			int64_t nw2 = 0;
+			rb3gpu_walker_t *w2 = thin_walkers(n_walkers, walkers, 8, &nw2);
+			if (!w2) return RB3GPU_ENOMEM;
+			r = merge_core(h, len, d_b2, commit, host_pos, host_acc2, rank_only, nw2, w2, d_tw, thin * 8);
+			free(w2);
+			return r;
+		}
+		return merge_core(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, d_tw, thin * 8);
 	}
 	if (tent && (hm[4] != 0 || hm[2] != 0 || hm[3] != 0)) { // the optimistic pass did not validate (records unsettled, or rows nobody reached): nothing was installed, redo without tentative records
 		h->stt.n_fallbacks += 1;
@@ -1928,7 +1975,7 @@ void *rb3gpu_pinned_alloc(int64_t n_bytes)
 {
 	void *p = nullptr;
 	if (n_bytes <= 0) return nullptr;
-	if (hipHostMalloc(&p, (size_t)n_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	if (hipHostMalloc(&p, (size_t)n_bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; } // (page-locked for every device: a multi-GPU build uploads from any of them)
 	pthread_mutex_lock(&g_pin_mtx);
 	g_pinned.push_back(std::make_pair((const uint8_t*)p, (size_t)n_bytes));
 	pthread_mutex_unlock(&g_pin_mtx);
@@ -2017,6 +2064,34 @@ int rb3gpu_merge_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, 
 	int r;
 	if ((r = fmd_words_to_b2(h, n_words, words, mcnt, &n_sym)) < 0) return r; // (checks the total against the header)
 	return merge_core(h, n_sym, (const uint8_t*)h->b2.p, 1, nullptr, nullptr, 0, 0, nullptr);
+}
+
+/* rb3_fmi_merge (fm-index.c:251-277) between two handles, which may sit on different GPUs of the node: the index of `src` is
+ * decoded to its plain BWT on its own device, copied device to device (xGMI where the two have peer access) and merged into `h`
+ * as one batch through the reference's signature (the walker list is made on the device).  `src` is left as it is. */
+int rb3gpu_merge_index(rb3gpu_t *h, rb3gpu_t *src)
+{
+	if (!h || !src || h == src) return RB3GPU_EINVAL;
+	if (h->n <= 0 || h->grp == nullptr || src->n <= 0 || src->grp == nullptr) return RB3GPU_ESTATE;
+	const int64_t n = src->n;
+	int r;
+	void *d_src = nullptr;
+	{ rb3gpu_t *h = src; HIPCHK(hipSetDevice(src->dev)); } // (HIPCHK reports through `h`)
+	if (hipMalloc(&d_src, (size_t)n + 16) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENOMEM; }
+	if ((r = rb3gpu_export_plain_dev(src, (uint8_t*)d_src)) < 0) { (void)hipFree(d_src); return r; }
+	hipError_t e = hipSetDevice(h->dev);
+	if (e == hipSuccess && (r = buf_ensure(h, h->b2, (size_t)n + 16)) < 0) { (void)hipSetDevice(src->dev); (void)hipFree(d_src); return r; }
+	if (e == hipSuccess && src->dev != h->dev) {
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, h->dev, src->dev) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(src->dev, 0); (void)hipGetLastError(); } // (already enabled: fine)
+		e = hipMemcpyPeerAsync(h->b2.p, h->dev, d_src, src->dev, (size_t)n, h->st);
+	} else if (e == hipSuccess) e = hipMemcpyAsync(h->b2.p, d_src, (size_t)n, hipMemcpyDeviceToDevice, h->st);
+	if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+	(void)hipSetDevice(src->dev);
+	(void)hipFree(d_src);
+	HIPCHK(e);
+	HIPCHK(hipSetDevice(h->dev));
+	return merge_core(h, n, (const uint8_t*)h->b2.p, 1, nullptr, nullptr, 0, 0, nullptr);
 }
 
 int rb3gpu_from_runs(rb3gpu_t *h, int64_t n_runs, const uint64_t *runs)

@@ -259,6 +259,38 @@ __device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2
 	if (MATCH) *match_a = mt;
 }
 
+/* The two ends of an interval that lie in two (neighbouring) run slots, through ONE instruction stream: off_a is counted in
+ * slice sa, off_b in slice sb.  An interval of up to 255 rows against slots of 512+ symbols straddles a slot boundary in one
+ * step out of five or ten, and with eight walkers per wave some walker does in a third of the wave's iterations; giving that
+ * walker two single decodes made the whole wave run ~300 more instructions.  The two exclusive scans over the octet share
+ * their DPP steps (two 16-bit fields).  cnt = #{i < off : sym_i == c}, this lane's share. */
+__device__ __forceinline__ void slice_count_pk2(const uint4 &sa, const uint4 &sb, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b)
+{
+	const uint32_t wa[3] = { sa.y, sa.z, sa.w }, wb[3] = { sb.y, sb.z, sb.w };
+	uint32_t la[3], lb[3], ta = 0, tb = 0;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		la[k] = as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, wa[k]) >> 3) + as_s16x2(0x00010001u));
+		lb[k] = as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, wb[k]) >> 3) + as_s16x2(0x00010001u));
+		ta = pk_sum16(la[k], ta), tb = pk_sum16(lb[k], tb);
+	}
+	const uint32_t base2 = oct_exscan(ta | tb << 16, j); // (a slot covers at most 8192 symbols + 48 unused codes: no carry between the fields)
+	uint32_t base_a = base2 & 0xFFFFu, base_b = base2 >> 16;
+	const uint32_t csplat = (uint32_t)c * 0x00010001u;
+	const rb3_s16x2 oa = as_s16x2((uint32_t)off_a * 0x00010001u), ob = as_s16x2((uint32_t)off_b * 0x00010001u), zero = as_s16x2(0u), one = as_s16x2(0x00010001u);
+	rb3_s16x2 acc_a = zero, acc_b = zero;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const rb3_s16x2 Pa = as_s16x2(base_a * 0x00010001u + (la[k] << 16)), Pb = as_s16x2(base_b * 0x00010001u + (lb[k] << 16));
+		const uint32_t eqa = as_u32((as_s16x2((wa[k] & 0x00070007u) ^ csplat) - one) >> 15), eqb = as_u32((as_s16x2((wb[k] & 0x00070007u) ^ csplat) - one) >> 15);
+		const rb3_s16x2 da = __builtin_elementwise_min(__builtin_elementwise_max(oa - Pa, zero), as_s16x2(la[k]));
+		const rb3_s16x2 db = __builtin_elementwise_min(__builtin_elementwise_max(ob - Pb, zero), as_s16x2(lb[k]));
+		acc_a += as_s16x2(as_u32(da) & eqa), acc_b += as_s16x2(as_u32(db) & eqb);
+		base_a = pk_sum16(la[k], base_a), base_b = pk_sum16(lb[k], base_b);
+	}
+	*cnt_a = pk_sum16(as_u32(acc_a), 0u), *cnt_b = pk_sum16(as_u32(acc_b), 0u);
+}
+
 /* number of symbols equal to c among the first `off` symbols of the slot, this lane's share;
  * bit 20 of the result is set in the one lane that holds the symbol AT offset `off` if that symbol is c */
 #define RB3_MATCH_BIT 0x100000u
@@ -968,7 +1000,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				const uint32_t cq = (uint32_t)x & 7u;
 				const uint64_t kq = (uint64_t)(hi - lo);
 				const bool opening = gap != 0 && sid == -1 && age >= RB3_TENT_MIN_AGE && kq <= (uint64_t)RB3_TENT_KMAX;
-				const bool simple = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) && cq != 0u && (int64_t)rc < 0 && !opening;
+				const uint32_t kq32 = kq > 0xFFFFull ? 0xFFFFu : (uint32_t)kq;
+				// (an interval that reaches into the next GROUP needs a second directory entry: the general step)
+				const bool simple = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) && cq != 0u && (int64_t)rc < 0 && !opening && ((uint32_t)lo & (RB3_GRP - 1)) + kq32 <= (uint32_t)RB3_GRP
+					&& kq32 <= (uint32_t)RB3_TENT_KMAX; // (a wider interval -- a walker in its first dozen steps -- may end several slots further on)
 				if (__all(simple)) {
 #ifdef RB3_PROF_STEP /* kernel experiment: where does an iteration of the common step spend its cycles?  (s_memtime at four points) */
 					const uint64_t pt0 = __builtin_amdgcn_s_memtime();
@@ -988,42 +1023,52 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 					const uint32_t mask = (uint32_t)(rl.sm >> 32), lw = rl.koff >> RB3_WIN_BITS;
 					const uint32_t mlo = mask & ((2u << lw) - 1u);    // slot starts at or below lo's window (bit 0 is always set)
 					rl.sidx = (uint32_t)rl.sm + __popc(mlo) - 1u;
-					octc_load_slot<8>(b1, (int64_t)rl.sidx, j, rl);
-#ifdef RB3_PROF_STEP
-					asm volatile("s_nop 0" :: "v"(rl.sidx));
-					const uint64_t pt1 = __builtin_amdgcn_s_memtime(); // the directory word has arrived, the slot is requested
-#endif
-					// while the slot is on its way: where it starts and ends and what kind it is follow from the mask alone (a slot of
-					// more than one window is a run slot, a single window is bit planes), and so does whether the upper end of the
-					// interval lies in it too; an exact walker is the empty interval [lo, lo)
+					// where the slot starts and ends and what kind it is follow from the mask alone (a slot of more than one window is
+					// a run slot, a single window is bit planes), and so does whether the upper end of the interval lies in it too or
+					// in the slot behind it (same group: see `simple`); an exact walker is the empty interval [lo, lo)
 					const uint32_t w0 = 31u - (uint32_t)__clz((int)mlo);
 					const uint32_t above = (mask >> w0) >> 1;
 					uint32_t wend = w0 + 1u + (above ? (uint32_t)__builtin_ctz(above) : 31u - w0);
 					if (g == (b1.n >> RB3_GRP_BITS)) { const uint32_t nvw = (uint32_t)(b1.n >> RB3_WIN_BITS & 31) + 1u; wend = wend < nvw ? wend : nvw; } // (the last group ends with the window of position n)
 					const bool rle = wend - w0 > 1u;
-					const uint32_t kq32 = kq > 0xFFFFull ? 0xFFFFu : (uint32_t)kq;
 					const int off_lo = (int)(rl.koff - (w0 << RB3_WIN_BITS)), off_hi = off_lo + (int)kq32;
 					const bool same = rl.koff + kq32 <= (wend << RB3_WIN_BITS);
+					octc_load_slot<8>(b1, (int64_t)rl.sidx, j, rl);
+					uint4 slb = make_uint4(0u, 0u, 0u, 0u);
+					if (!same) slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + j]; // the upper end lies in the next slot: asked for at the same time
+#ifdef RB3_PROF_STEP
+					asm volatile("s_nop 0" :: "v"(rl.sidx));
+					const uint64_t pt1 = __builtin_amdgcn_s_memtime(); // the directory word has arrived, the slot is requested
+#endif
 					++steps;
 					const int64_t myval = lo + kb;
 					// (once a stretch is open the interval is at most KMAX wide and the walker old enough, for the rest of its life)
 					if ((gap == 0 || sid >= 0) && j == (int)(it & 7u))
 						bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					// the records of the last eight steps: the store is slow (written through) and whatever is asked for after it waits
-					// behind it, so it goes out here, where nothing is asked for during the whole decode
+					// the records of the last eight steps go out here, where nothing is asked for during the whole decode: the store is slow
+					// (written through) and whatever is asked for after it waits for its acknowledgement (vmcnt counts in order)
 					if ((it & 7u) == 7u && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
 #ifdef RB3_PROF_STEP
 					asm volatile("s_nop 0" :: "v"(rl.sl.x));
 					const uint64_t pt2 = __builtin_amdgcn_s_memtime(); // the slot has arrived
 #endif
 					int64_t lo_n, hi_n;
+					if (same) slb = rl.sl;
+					const bool rleb = same ? rle : (oct_bcast0(slb.x, j) & RB3_SLOT_RLE) != 0u;
 #ifdef RB3_PROF_STEP
 					if (__ballot(!(rle && same)) != 0ull) prof_t[5] += 1;
-					if (__ballot(!rle) != 0ull) prof_t[6] += 1;
+					if (__ballot(!(rle && rleb)) != 0ull) prof_t[6] += 1;
 #endif
-					if (rle && same) octc_finish_pair_at(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
-					else { // a bit-plane slot, or the upper end lies in the next slot
+					if (__all(rle && same)) octc_finish_pair_at(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
+					else if (__all(rle && rleb)) { // some walker's interval straddles two run slots: everybody through the two-slot decode
+						uint32_t ca, cb;
+						slice_count_pk2(rl.sl, slb, off_lo, same ? off_hi : off_hi - (int)((wend - w0) << RB3_WIN_BITS), c, j, &ca, &cb);
+						uint32_t v = (ca + (j == c + 1 ? rl.sl.x : 0u)) | (cb + (j == c + 1 ? slb.x : 0u)) << 16;
+						v = oct_sum(v);
+						lo_n = (int64_t)(rl.gc + (v & 0xFFFFu)), hi_n = (int64_t)(rl.gc + (v >> 16));
+					} else if (rle && same) octc_finish_pair_at(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
+					else { // a bit-plane slot somewhere
 						uint32_t match = 0, mh;
 						lo_n = octc_finish<false, 8>(rl, c, j, &match);
 						hi_n = gap == 1 ? lo_n + match : lo_n;
@@ -2989,8 +3034,8 @@ __global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint3
  * what k_chain's plain-store records need (see "Concurrency").  Everything stays on the device; the list is read by
  * k_chain through its device-side length. */
 #define RB3_SSA_END  (1ull << 63)  /* link word: the sublist ends at the start of its string (shared with the sampled suffix array) */
-#define RB3_B2_W     384           /* text distance between walkers */
-#define RB3_B2_FIRST 256           /* a splitter qualifies if it lies this close behind the start of its window (gaps stay >= W - FIRST = 128) */
+#define RB3_B2_W     384           /* text distance between walkers (a multiple of it where the stretch table would not take this many walkers' events) */
+                                   /* a splitter qualifies if it lies in the first W - RB3_B2_MINSEG positions of its window (W = 384: 256) */
 #define RB3_B2_MINSEG 128          /* shortest segment of any walker (what plain-store records need, see k_chain) */
 #define RB3_B2_EMPTY (~0ull)
 
@@ -3016,11 +3061,11 @@ __global__ void __launch_bounds__(256) k_b2_jump4(int64_t nsp, const uint64_t *i
 }
 
 /* mode[0]: 0 = splitters, 1 = strings are short (one walker per string), 2 = more strings than the list can take */
-__global__ void __launch_bounds__(256) k_b2_mode(const uint64_t *tot2, int64_t n2, int64_t m2cap, unsigned long long *mode)
+__global__ void __launch_bounds__(256) k_b2_mode(const uint64_t *tot2, int64_t n2, int64_t m2cap, unsigned long long *mode, int64_t W)
 {
 	if (threadIdx.x || blockIdx.x) return;
 	const int64_t m2 = (int64_t)tot2[0];
-	mode[0] = m2 <= 0 || m2 > m2cap ? 2ull : (n2 / m2 <= 4 * RB3_B2_W ? 1ull : 0ull);
+	mode[0] = m2 <= 0 || m2 > m2cap ? 2ull : (n2 / m2 <= 4 * W ? 1ull : 0ull);
 }
 
 __global__ void __launch_bounds__(256) k_b2_walk(const int64_t *roww, int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, uint64_t *lnk)
@@ -3071,7 +3116,7 @@ __global__ void __launch_bounds__(1024) k_b2_scan(const uint64_t *tot2, const un
 }
 
 /* per window of RB3_B2_W text positions (concatenated strings): the qualifying splitter closest to the window's start */
-__global__ void __launch_bounds__(256) k_b2_pick(int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, const uint64_t *lnk, const uint64_t *gbase, unsigned long long *bucket)
+__global__ void __launch_bounds__(256) k_b2_pick(int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, const uint64_t *lnk, const uint64_t *gbase, unsigned long long *bucket, int64_t W)
 {
 	if (mode[0] != 0) return;
 	const int64_t m2 = (int64_t)tot2[0], msk = (1LL << S) - 1;
@@ -3084,8 +3129,8 @@ __global__ void __launch_bounds__(256) k_b2_pick(int64_t n2, const uint64_t *tot
 	if (sid >= (uint64_t)m2) return;
 	const uint64_t g0 = gbase[sid], len = gbase[sid + 1] - g0, G = g0 + D;
 	if (D == 0 || D + 1 + RB3_B2_MINSEG > len) return; // the sentinel walker's own segment stays >= RB3_B2_MINSEG steps
-	const uint64_t off = G % RB3_B2_W;
-	if (off < RB3_B2_FIRST) atomicMin(&bucket[G / RB3_B2_W], (unsigned long long)(off << 48 | (uint64_t)p));
+	const uint64_t off = G % (uint64_t)W;
+	if (off < (uint64_t)(W - RB3_B2_MINSEG)) atomicMin(&bucket[G / (uint64_t)W], (unsigned long long)(off << 48 | (uint64_t)p)); // (gaps stay >= RB3_B2_MINSEG)
 }
 
 /* A pick lies `off` text positions behind the start of its window (geometric, mean 2^S, the odd one beyond 100), and a
@@ -3093,16 +3138,16 @@ __global__ void __launch_bounds__(256) k_b2_pick(int64_t n2, const uint64_t *tot
  * 0.46 ms, this jitter: 0.71 ms on the bench workload).  So the pick WALKS its `off` LF steps down to the window start (the
  * batch's own LF words: dependent 8-byte loads, no rank) and the walker starts exactly there -- unless that would leave the
  * pick's string (then it stays where it is).  b2_refined_D: the distance from the start of its string at which a pick ends up. */
-__device__ __forceinline__ uint64_t b2_refined_D(uint64_t D, uint64_t g0)
+__device__ __forceinline__ uint64_t b2_refined_D(uint64_t D, uint64_t g0, int64_t W)
 {
-	const uint64_t off = (g0 + D) % RB3_B2_W;
+	const uint64_t off = (g0 + D) % (uint64_t)W;
 	return D > off ? D - off : D;
 }
 
 /* the walker list: slot b < nbk = the pick of window b (row -1: none), slot nbk + j = the sentinel row j; nsteps = text distance
  * to the next walker on the left in the same string.  nwalk[0] = slots in use. */
 __global__ void __launch_bounds__(256) k_b2_list(int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, const uint64_t *lnk, const uint64_t *gbase,
-		const unsigned long long *bucket, int64_t nbk, Walker *wl, unsigned long long *nwalk, const int64_t *roww)
+		const unsigned long long *bucket, int64_t nbk, Walker *wl, unsigned long long *nwalk, const int64_t *roww, int64_t W)
 {
 	const int64_t m2 = (int64_t)tot2[0];
 	const unsigned long long md = mode[0];
@@ -3125,21 +3170,21 @@ __global__ void __launch_bounds__(256) k_b2_list(int64_t n2, const uint64_t *tot
 			const int64_t p = (int64_t)(v & 0xFFFFFFFFFFFFull);
 			w.row = m2 + ((p - m2) << S);
 			sid = lnk[2 * p] & ~RB3_SSA_END, D = lnk[2 * p + 1], b = u - 1;
-			const uint64_t D2 = b2_refined_D(D, gbase[sid]);
+			const uint64_t D2 = b2_refined_D(D, gbase[sid], W);
 			for (uint64_t i = D2; i < D; ++i) w.row = RB3_ROW_NEXT((uint64_t)roww[w.row]); // (no sentinel on the way: D2 >= 1)
 			D = D2, G = gbase[sid] + D;
 		} else {
 			const int64_t j = u - nbk;
 			w.row = j, w.ka0 = -2;
-			sid = lnk[2 * j] & ~RB3_SSA_END, D = lnk[2 * j + 1], G = gbase[sid] + D, b = (int64_t)(G / RB3_B2_W);
+			sid = lnk[2 * j] & ~RB3_SSA_END, D = lnk[2 * j + 1], G = gbase[sid] + D, b = (int64_t)(G / (uint64_t)W);
 		}
 		// the next walker on the left: the pick of the nearest window below that lies in the same string
-		for (; b >= 0 && (uint64_t)(b + 1) * RB3_B2_W > gbase[sid]; --b) {
+		for (; b >= 0 && (uint64_t)(b + 1) * (uint64_t)W > gbase[sid]; --b) {
 			const unsigned long long v = bucket[b];
 			if (v == RB3_B2_EMPTY) continue;
 			const int64_t q = (int64_t)(v & 0xFFFFFFFFFFFFull);
 			if ((lnk[2 * q] & ~RB3_SSA_END) != sid) continue; // a window shared with the neighbouring string
-			const uint64_t Dq = b2_refined_D(lnk[2 * q + 1], gbase[sid]);
+			const uint64_t Dq = b2_refined_D(lnk[2 * q + 1], gbase[sid], W);
 			if (Dq < D) { w.nsteps = (int64_t)(D - Dq); break; }
 		}
 		wl[u] = w;

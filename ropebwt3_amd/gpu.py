@@ -36,7 +36,7 @@ class Stats(ctypes.Structure):
                 ("n_rank_launches", ctypes.c_int64), ("n_lf_steps", ctypes.c_int64), ("n_symbols_merged", ctypes.c_int64),
                 ("n_rounds", ctypes.c_int64), ("n_fallbacks", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64),
                 ("ms_ssa", ctypes.c_double), ("ms_ssa_walk", ctypes.c_double), ("ms_sort", ctypes.c_double), ("n_sort_rounds", ctypes.c_int64),
-                ("n_reb_groups", ctypes.c_int64), ("n_reb_groups_window", ctypes.c_int64), ("n_lf_checked", ctypes.c_int64), ("n_long_settles", ctypes.c_int64), ("ms_alloc", ctypes.c_double), ("n_allocs", ctypes.c_int64), ("n_reb_again", ctypes.c_int64), ("bytes_rebuild", ctypes.c_int64)]
+                ("n_reb_groups", ctypes.c_int64), ("n_reb_groups_window", ctypes.c_int64), ("n_lf_checked", ctypes.c_int64), ("n_long_settles", ctypes.c_int64), ("ms_alloc", ctypes.c_double), ("n_allocs", ctypes.c_int64), ("n_reb_again", ctypes.c_int64), ("bytes_rebuild", ctypes.c_int64), ("n_thinned", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -91,6 +91,7 @@ SYMBOLS = {
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_from_fmd_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_merge_fmd_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_merge_index": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_tune": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),
@@ -332,6 +333,10 @@ class Rb3Gpu:
         out = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint64)), shape=(n.value,)).copy()
         self._lib.rb3gpu_host_free(p)
         return out
+
+    def merge_index(self, other):
+        """merge the whole index of another handle (any GPU of the node) into this one (rb3_fmi_merge, fm-index.c:251-277)"""
+        self._chk(self._lib.rb3gpu_merge_index(self._h, other._h), "rb3gpu_merge_index")
 
     def export_plain_dev(self, d_out):
         self._chk(self._lib.rb3gpu_export_plain_dev(self._h, d_out), "rb3gpu_export_plain_dev")

@@ -287,7 +287,10 @@ class ThreadComm:
 
 
 def interval_bounds(n, world):
-    """world contiguous intervals of about equal length over n positions"""
+    """world contiguous intervals of about equal length over n positions.  Every rank must own at least one position (a handle
+    without a block array cannot take part in rb3gpu_sh_step): an index smaller than the number of GPUs is not sharded."""
+    if n < world:
+        raise ValueError("an index of %d symbols cannot be cut into %d non-empty intervals: use fewer GPUs" % (n, world))
     return np.array([n * r // world for r in range(world + 1)], dtype=np.int64)
 
 
@@ -313,29 +316,35 @@ def merge_interval(engine, comm, bounds, d_bwt, d_tw, n2, sent_tp, commit=True, 
     d_ka = comm.new_i64(n2, -1)
     # two state buffers for the whole merge: a rank never holds more states than there are strings
     cap = len(sent_tp)
-    cur, nxt = comm.new_states(cap), comm.new_states(cap)
-    n_cur = cap if rank == owner0 else 0
-    if n_cur:
-        st = np.empty((n_cur, 2), dtype=np.int64)
-        st[:, 0], st[:, 1] = sent_tp, m1
-        comm.upload_states(cur, st)
-    rows_here, rounds = 0, 0
-    while True:
-        rows_here += n_cur
-        counts = engine.sh_step(n_cur, comm.ptr(cur), d_tw, comm.ptr(d_ka), adj, bounds, rank, comm.ptr(nxt))   # nxt: grouped by destination
-        M = comm.all_gather(counts[:world])                        # M[s][d]: states rank s sends to rank d
-        rounds += 1
-        if int(M.sum()) == 0:
-            break
-        n_cur = comm.exchange(nxt, M[rank], M[:, rank], cur)
-    comm.free(cur)
-    comm.free(nxt)
-    R = comm.all_gather([rows_here])[:, 0]
-    jlo = int(R[:rank].sum())
-    if int(R.sum()) != n2:
-        raise RuntimeError("sharded merge recorded %d of %d rows" % (int(R.sum()), n2))
-    engine.sh_finish(jlo, rows_here, d_bwt, comm.ptr(d_ka), int(bounds[rank]), commit)
-    comm.free(d_ka)
+    cur = nxt = None
+    try:
+        cur, nxt = comm.new_states(cap), comm.new_states(cap)
+        n_cur = cap if rank == owner0 else 0
+        if n_cur:
+            st = np.empty((n_cur, 2), dtype=np.int64)
+            st[:, 0], st[:, 1] = sent_tp, m1
+            comm.upload_states(cur, st)
+        rows_here, rounds = 0, 0
+        while True:
+            rows_here += n_cur
+            counts = engine.sh_step(n_cur, comm.ptr(cur), d_tw, comm.ptr(d_ka), adj, bounds, rank, comm.ptr(nxt))   # nxt: grouped by destination
+            M = comm.all_gather(counts[:world])                        # M[s][d]: states rank s sends to rank d
+            rounds += 1
+            if int(M.sum()) == 0:
+                break
+            n_cur = comm.exchange(nxt, M[rank], M[:, rank], cur)
+        R = comm.all_gather([rows_here])[:, 0]
+        jlo = int(R[:rank].sum())
+        if int(R.sum()) != n2:
+            raise RuntimeError("sharded merge recorded %d of %d rows" % (int(R.sum()), n2))
+        # (rb3gpu_sh_finish validates what this protocol can get wrong -- every row of the interval recorded by this rank, in
+        # order, inside the interval -- with k_sh_localpos + k_pos_check; the sampled LF check of the single-GPU merge guards its
+        # SPECULATIVE records, and there are none here: every state carries an exact insertion point)
+        engine.sh_finish(jlo, rows_here, d_bwt, comm.ptr(d_ka), int(bounds[rank]), commit)
+    finally:   # (an engine error in mid-loop must not leak the device buffers of a long-running build)
+        for b in (cur, nxt, d_ka):
+            if b is not None:
+                comm.free(b)
     if stats is not None:
         stats["rounds"] = rounds
         stats["rows_per_rank"] = [int(x) for x in R]

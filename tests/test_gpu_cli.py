@@ -59,6 +59,34 @@ def test_stdin_input():
     assert out == b"GC$$GGAA\n"
 
 
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_multi_gpu_build_slices_and_tree_merge(n):
+    """`build --gpus N`: the input files cut into N slices, one handle per slice (on a one-GPU box all of them on device 0),
+    whole-index merges in input order afterwards (rb3gpu_merge_index) -- the reference's .fmd for the same files"""
+    ent = MAN["genomes12_files"]
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    out, err = run(["build", "-d", "--gpus", str(n)] + inputs)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+    if n <= len(inputs):
+        assert "tree merge of %d slices" % min(n, len(inputs)) in err
+
+
+def test_multi_gpu_build_of_reads(tmp_path):
+    """reads cut into four files, `--gpus 4 -m` small: every slice runs several merge rounds of its own before the tree"""
+    import gzip
+    ent = MAN["reads_fwd"]
+    data = gzip.open(os.path.join(util.GOLDEN, ent["inputs"][0]), "rb").read().splitlines(keepends=True)
+    files = []
+    for i in range(4):
+        fn = tmp_path / ("part%d.txt" % i)
+        fn.write_bytes(b"".join(data[len(data) * i // 4:len(data) * (i + 1) // 4]))
+        files.append(str(fn))
+    out, _ = run(["build"] + ent["flags"] + ["-d", "-m40k", "--gpus", "4"] + files)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+    out1, _ = run(["build"] + ent["flags"] + ["-d", "-m40k"] + files)
+    assert out1 == out
+
+
 def test_gzip_through_a_pipe_on_stdin():
     """`cat x.fa.gz | build -`: the same .fmd as from the file (the reader must not eat the gzip magic of a pipe)"""
     ent = MAN["genomes12"]

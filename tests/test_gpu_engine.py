@@ -488,6 +488,66 @@ def test_whole_index_merge_on_device(oracle):
         a.close(); b.close()
 
 
+def test_merge_index_between_two_handles(oracle):
+    """rb3gpu_merge_index = the tree step of `build --gpus N` (rb3_fmi_merge, fm-index.c:251-277): the index of one handle
+    merged into another as one batch, device to device; three slices merged left to right give the BWT of all strings in
+    input order, whatever the shape of the tree"""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(131)
+    g0 = util.random_genome(rng, 40000)
+    gs = [util.mutate(rng, g0, 0.004) for _ in range(9)] + util.reads_from(rng, g0, 30, 80)
+    want = host.build_bwt(util.make_text(gs))
+    cuts = [0, 3, 7, len(gs)]
+    hs = [Rb3Gpu(verbose=1) for _ in range(3)]
+    try:
+        for h, a, b in zip(hs, cuts[:-1], cuts[1:]):
+            for i, g in enumerate(gs[a:b]):
+                bw = host.build_bwt(util.make_text([g]))
+                if i == 0: h.from_plain(bw)
+                else: h.merge_plain(bw)
+        hs[0].merge_index(hs[1])
+        assert hs[1].get_tot() > 0                       # the source is left as it is
+        hs[0].merge_index(hs[2])
+        assert np.array_equal(hs[0].export_plain(), want)
+        with pytest.raises(Exception):
+            hs[0].merge_index(hs[0])
+    finally:
+        for h in hs:
+            h.close()
+
+
+@pytest.mark.parametrize("entry", ["walkers", "text", "plain"])
+def test_full_stretch_table_is_answered_with_fewer_walkers(oracle, entry):
+    """a batch whose walkers note more events than the stretch table holds (huge batches into many relatives: the top of the
+    multi-GPU tree merge): the merge is done again with every eighth walker before tentative records are given up"""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(137)
+    g0 = util.random_genome(rng, 60000)
+    rel = [g0] + [util.mutate(rng, g0, 0.004) for _ in range(12)]
+    b1 = host.build_bwt(util.make_text(rel))
+    t2 = util.make_text([util.mutate(rng, g0, 0.003), util.mutate(rng, g0, 0.003)])
+    b2, w = host.build_bwt_walkers(t2.copy(), 150)
+    want = oracle.merge(b1, b2)
+    h = Rb3Gpu(verbose=1, hooks=True)
+    try:
+        h.tune("tent_limit", 1200)                        # (blocks of 8 ids per walker: ~800 walkers at spacing 150 do not fit, ~100 at 1200 do)
+        h.from_plain(b1)
+        if entry == "walkers":
+            h.merge_plain_walkers(b2, w)
+        elif entry == "text":
+            d_bwt, d_tw = h.sort_text(t2)
+            h.merge_text_dev(d_bwt, d_tw, t2.size, host.walkers_text(t2, 150), commit=True)
+            h.dev_free(d_bwt); h.dev_free(d_tw)
+        else:
+            h.merge_plain(b2)
+        st = h.stats()
+        assert np.array_equal(h.export_plain(), want)
+        print(entry, "thinned", st["n_thinned"], "fallbacks", st["n_fallbacks"])
+        assert st["n_thinned"] >= 1 or st["n_fallbacks"] == 0
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("env", [{"RB3GPU_GROUP_REBUILD": "1"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_GROUP_REBUILD": "1", "RB3GPU_STAGED": "1"},
                                  {"RB3GPU_TEXT_MODE": "2"}, {"RB3GPU_WINDOW_REBUILD": "1"}])
 def test_fallback_code_paths_via_soak(env):

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <new>
 #include "rb3gpu.h"
 #include "rb3gpu_kernels.h"
@@ -1076,8 +1077,17 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const int b2S = h->tn.b2_split;
 	// the device-made list: a walker every b2W text positions -- 384, or more where the batch is so large that the events of that
 	// many walkers would not fit the stretch table (and `thin` times that after a merge whose table did overflow)
+	// How many stretches will the walkers open?  A walker opens one per indexed relative that drops out of its interval, i.e. per
+	// relative whose next private variant lies within the walker's segment (mean distance ~1000 symbols between relatives worth
+	// the name), plus its first block of ids: walkers x (K (1 - e^(-W/1000)) + 8), K = relatives ~ mean run length of the index,
+	// estimated from how many symbols a slot holds.  Where that exceeds the table the walkers are spaced further apart from the
+	// start (a whole-index merge at the top of a multi-GPU tree: 670 M rows into 76 relatives) -- a full table is only found
+	// out after the walk, and then costs the walk.
+	const double kest = h->nslots > 0 ? (double)h->n / ((double)h->nslots * 32.0) : 1.0;
+	auto events_at = [&](double W) { return (double)len / W * ((kest < 1.0 ? 1.0 : kest) * (1.0 - exp(-W / 1000.0)) + (double)RB3_TENT_BLOCK); };
+	const double tent_room = 0.6 * (double)RB3_TENT_HALF;
 	int64_t b2W = RB3_B2_W;
-	while (len / b2W > (1 << 18)) b2W *= 2;
+	while (len / b2W > (1 << 18) || (h->tn.tent && thin == 1 && events_at((double)b2W) > tent_room && b2W < len / 256)) b2W *= 2;
 	b2W *= thin;
 	const int64_t b2_nbk = len / b2W + 1, b2_m2cap = len / 64 + 1, b2_nspmax = (len >> b2S) + b2_m2cap + 2;
 	if (auto_list) n_walkers = b2_nbk + b2_m2cap; // capacity of the list; how many are in use stays on the device
@@ -1085,6 +1095,19 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (per_string) tent = 0; // every walker is exact
 	for (int64_t i = 0; walkers && i < n_walkers; ++i)
 		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) return RB3GPU_EINVAL;
+	if (walkers && tent && thin == 1 && n_walkers > 4096) { // (the same estimate for a list the caller made: every t-th walker from the start)
+		int t = 1;
+		while (t < 64 && events_at((double)len / (double)n_walkers * t) > tent_room) t *= 2;
+		if (t > 1) {
+			int64_t nw2 = 0;
+			rb3gpu_walker_t *w2 = thin_walkers(n_walkers, walkers, t, &nw2);
+			if (!w2) return RB3GPU_ENOMEM;
+			h->stt.n_thinned += 1;
+			const int r2 = merge_core(h, len, d_b2, commit, host_pos, host_acc2, rank_only, nw2, w2, d_tw, t);
+			free(w2);
+			return r2;
+		}
+	}
 	if ((!walkers && !per_string && !auto_list) || n_walkers > (1 << 24) || n_walkers > len || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || h->tn.staged) {
 		if (per_string) return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, tent_auto);
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, tent);

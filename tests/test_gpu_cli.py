@@ -291,3 +291,45 @@ def test_config4_reads_m7g_stays_on_the_gpu(tmp_path):
         for blk in iter(lambda: f.read(1 << 24), b""):
             h.update(blk)
     assert os.path.getsize(out) == ent["fmd_bytes"] and h.hexdigest() == ent["fmd_md5"]
+
+
+def _family(name):
+    ent = MAN.get("family", {}).get(name)
+    if not ent:
+        pytest.skip("no golden for %s (tools/make_golden_family.py)" % name)
+    return ent
+
+
+def test_config5_long_contig_haplotypes(tmp_path):
+    """BASELINE configs[4] in shape: haplotype assemblies cut into long contigs (4 haplotypes of 25 Mbp, contigs of 1.5-12 Mbp,
+    200 M symbols), `-m60m` = one haplotype per batch: three merge rounds of ~50 M symbols in a dozen strings of 10^6..10^7
+    symbols each, suffix-sorted on the GPU -- the reference's .fmd"""
+    import re
+    from tools import gen_family
+    ent = _family("haplotypes_4x25M")
+    files = gen_family.haplotypes(*ent["spec"][1:], str(tmp_path))
+    out, err = run(["build", "-d", "-m60m"] + files)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"] and len(out) == ent["fmd_bytes"]
+    assert err.count("merged the partial BWT") >= 3
+    m = re.search(r"batches: (\d+) \((\d+) symbols\) suffix-sorted on the GPU, (\d+) \(", err)
+    assert m and int(m.group(3)) == 0, err[-600:]
+    m = re.search(r"(\d+) merges redone without tentative records", err)
+    assert m and int(m.group(1)) == 0, err[-600:]
+    for f in files:
+        os.unlink(f)
+
+
+def test_more_relatives_than_a_tentative_interval_tracks(tmp_path):
+    """320 close relatives of a 200 kbp genome, one genome per batch: from round 256 on an interval of matching suffixes is wider
+    than the 255 rows a tentative stretch tracks (RB3_TENT_KMAX), so walkers record later and their neighbours cover more --
+    slower, never wrong: the reference's .fmd, and no merge falls back to the walk without tentative records"""
+    import re
+    from tools import gen_family
+    ent = _family("relatives_320x200k")
+    fn = gen_family.relatives(*ent["spec"][1:], str(tmp_path / "rel.fa"))
+    out, err = run(["build", "-d", "-m300k", fn])
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"] and len(out) == ent["fmd_bytes"]
+    assert err.count("merged the partial BWT") >= 300
+    m = re.search(r"(\d+) merges redone without tentative records", err)
+    assert m and int(m.group(1)) <= 3, err[-600:]
+    os.unlink(fn)

@@ -146,6 +146,7 @@ struct rb3gpu_s {
 	std::vector<std::pair<void*, size_t> > garbage; // replaced buffers not yet given back (dev_free)
 	int64_t bytes_garbage = 0;
 	uint64_t reb_slot_cap = 0; // capacity of the slot array the last rebuild emitted into (build_index)
+	bool reb_prepared = false; // merge_core has cleared the counters of the run-space rebuild together with everything else
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
 	rb3sort_ws *sorter = nullptr;           // scratch of rb3gpu_bwt_from_text, created on first use
@@ -245,7 +246,25 @@ static float ev_ms(hipEvent_t a, hipEvent_t b)
 
 /* table of the tentative stretches (k_chain): one 64-byte record each, followed by the compact array
  * of settled unknowns (sfin, int32 per stretch) that k_resolve fills for k_pos_finalize_check */
-static int tent_prepare(rb3gpu_t *h, rb3_stretch_t **tab, int32_t **sfin)
+static void fill_add(FillJobs *jb, void *p, size_t bytes, uint32_t val)
+{
+	if (bytes == 0 || jb->n >= 8) return;
+	jb->p[jb->n] = p, jb->n16[jb->n] = (bytes + 15) / 16, jb->val[jb->n] = val, ++jb->n; // (every buffer of the handle has slack behind it: rounding up is safe)
+}
+
+static void fill_launch(rb3gpu_t *h, const FillJobs &jb)
+{
+	unsigned long long tot = 0;
+	for (int i = 0; i < jb.n; ++i) tot += jb.n16[i];
+	if (tot == 0) return;
+	unsigned long long nblk = (tot + 1023) / 1024; // four units per thread
+	if (nblk > 8192) nblk = 8192;
+	hipLaunchKernelGGL(k_fill_regions, dim3((unsigned)nblk), dim3(256), 0, h->st, jb);
+}
+
+/* jb != NULL: the regions to clear are added to a job list (one launch with everything else the merge clears) instead of being
+ * cleared by memsets of their own */
+static int tent_prepare(rb3gpu_t *h, rb3_stretch_t **tab, int32_t **sfin, FillJobs *jb = nullptr)
 {
 	const size_t bytes = (size_t)RB3_TENT_IDS * (sizeof(rb3_stretch_t) + 4);
 	const bool fresh = !(h->dl.p && h->dl.cap >= bytes);
@@ -255,10 +274,15 @@ static int tent_prepare(rb3gpu_t *h, rb3_stretch_t **tab, int32_t **sfin)
 	int32_t *f = *sfin = (int32_t*)(t + RB3_TENT_IDS);
 	// zero what the previous merge used: the blocks at the bottom of the table, the single ids from the middle up
 	const int64_t da = fresh ? RB3_TENT_HALF : h->sid_dirty[0], db = fresh ? RB3_TENT_HALF : h->sid_dirty[1];
-	if (da > 0) HIPCHK(hipMemsetAsync(t, 0, (size_t)da * sizeof(rb3_stretch_t), h->st));
-	if (da > 0) HIPCHK(hipMemsetAsync(f, 0, (size_t)da * 4, h->st));
-	if (db > 0) HIPCHK(hipMemsetAsync(t + RB3_TENT_HALF, 0, (size_t)db * sizeof(rb3_stretch_t), h->st));
-	if (db > 0) HIPCHK(hipMemsetAsync(f + RB3_TENT_HALF, 0, (size_t)db * 4, h->st));
+	if (jb) {
+		if (da > 0) fill_add(jb, t, (size_t)da * sizeof(rb3_stretch_t), 0u), fill_add(jb, f, (size_t)da * 4, 0u);
+		if (db > 0) fill_add(jb, t + RB3_TENT_HALF, (size_t)db * sizeof(rb3_stretch_t), 0u), fill_add(jb, f + RB3_TENT_HALF, (size_t)db * 4, 0u);
+	} else {
+		if (da > 0) HIPCHK(hipMemsetAsync(t, 0, (size_t)da * sizeof(rb3_stretch_t), h->st));
+		if (da > 0) HIPCHK(hipMemsetAsync(f, 0, (size_t)da * 4, h->st));
+		if (db > 0) HIPCHK(hipMemsetAsync(t + RB3_TENT_HALF, 0, (size_t)db * sizeof(rb3_stretch_t), h->st));
+		if (db > 0) HIPCHK(hipMemsetAsync(f + RB3_TENT_HALF, 0, (size_t)db * 4, h->st));
+	}
 	h->sid_dirty[0] = h->sid_dirty[1] = RB3_TENT_HALF; // until the number of stretches this merge opens has been read back
 	return 0;
 }
@@ -559,6 +583,8 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 {
 	const int64_t ngrp = (ntot >> RB3_GRP_BITS) + 1, nwin = (ntot >> RB3_WIN_BITS) + 1;
 	const int dst = 1 - h->cur;
+	const bool prepared = h->reb_prepared; // (only the first rebuild of the single-sync merge that set it)
+	h->reb_prepared = false;
 	int r;
 	if (ngrp > 0x7fffffffLL) return RB3GPU_EINVAL;
 	// single-sync merge: the rank phase's validation counters (misc[2..4]) are still on the device; the kernels look
@@ -633,8 +659,10 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			// Tiers by the average number of batch rows per group: the small-table kernel where most groups have few rows, then the
 			// medium one on what it left (or on all groups where the small one would mostly fail), then the window kernels on the
 			// list the last tier leaves (its length stays on the device: fixed grids, grid-stride loops).
-			HIPCHK(hipMemsetAsync(nglist, 0, 8, h->st));
-			HIPCHK(hipMemsetAsync((uint64_t*)h->misc.p + MISC_RG_OVER, 0, 8, h->st));
+			if (!prepared) { // (the first rebuild of a single-sync merge finds them cleared with everything else)
+				HIPCHK(hipMemsetAsync(nglist, 0, 8, h->st));
+				HIPCHK(hipMemsetAsync((uint64_t*)h->misc.p + MISC_RG_OVER, 0, 8, h->st));
+			}
 			const int64_t gw4 = (ngrp + RB3_RG_WAVES - 1) / RB3_RG_WAVES;
 			const unsigned grs = (unsigned)(gw4 < 3072 ? gw4 : 3072), grm = (unsigned)(gw4 < 2048 ? gw4 : 2048);
 			if (rows_per_group <= 96.0) {
@@ -718,7 +746,7 @@ static void index_install(rb3gpu_t *h, int64_t ngrp, int64_t nslots, int64_t nto
 
 /* histogram + row words of B2 (LF word of every row, fm-index.c:206-216) into d_row.  Totals stay on the device (misc[MISC_LF_TOT..]); acc2 != NULL also
  * brings the C array of B2 to the host (one sync) and checks the symbols (fm-index.c:124-125). */
-static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_row, int64_t *acc2, bool words = true)
+static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_row, int64_t *acc2, bool words = true, bool rows_filled = false)
 {
 	const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
 	int r;
@@ -735,7 +763,7 @@ static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_ro
 		for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)total[a];
 	}
 	if (words) hipLaunchKernelGGL(k_lf2, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (const uint64_t*)h->tpre.p, (const uint64_t*)dtot, (uint64_t*)d_row);
-	else HIPCHK(hipMemsetAsync(d_row, 0xff, (size_t)len * 8, h->st)); // text-order walk: the rows only hold records, all unvisited
+	else if (!rows_filled) HIPCHK(hipMemsetAsync(d_row, 0xff, (size_t)len * 8, h->st)); // text-order walk: the rows only hold records, all unvisited
 	return 0;
 }
 
@@ -1127,7 +1155,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #else
 	const uint32_t sid_limit = 0xFFFFFFFFu;
 #endif
-	if (tent && (r = tent_prepare(h, &tab, &sfin)) < 0) return r;
+	FillJobs jb;
+	memset(&jb, 0, sizeof(jb));
+	if (tent && (r = tent_prepare(h, &tab, &sfin, &jb)) < 0) return r;
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, slot_estimate(h, len, ntot))) < 0) return r;
 	const bool rows_fused = !rank_only && use_winpar(h, nwin);
 	if (rows_fused && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
@@ -1136,13 +1166,20 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	uint32_t *sidctr = (uint32_t*)(misc + 5);
 	h->mg_active = 0;
 	HIPCHK(hipEventRecord(h->ev[0], h->st));
-	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr)) < 0) return r;
+	// one launch clears what this merge accumulates into: the counters (the scan totals behind them are written later), the
+	// stretches the merge before opened, the rows-per-window table of the rebuild, and -- text-order walk -- the row records
+	fill_add(&jb, misc, 128, 0u);
+	fill_add(&jb, misc + MISC_RG_OVER, 16, 0u);
+	if (rows_fused) fill_add(&jb, h->jg.p, (size_t)(nwin + 1) * 8, 0u); // defined even if pos[] turns out invalid
+	const bool rows_filled = d_tw != nullptr && jb.n < 8;
+	if (rows_filled) fill_add(&jb, h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
+	fill_launch(h, jb);
+	h->reb_prepared = true; // (build_index: the counters of the run-space rebuild are clear)
+	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr, rows_filled)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
-	HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
 #ifdef RB3_PROF_STEP
 	HIPCHK(hipMemsetAsync(misc + 34, 0, 40, h->st));
 #endif
-	if (rows_fused) HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st)); // defined even if pos[] turns out invalid
 	unsigned long long *b2_nwalk = nullptr; // device-side length of a device-made list
 	if (auto_list) {
 		// scratch: two link tables (2 words per splitter), string lengths / offsets, one word per window

@@ -358,6 +358,22 @@ __global__ void __launch_bounds__(256) k_rank_batch(IdxView ix, Acc7 acc, int64_
 /* LF array of the partial BWT B2 (fm-index.c:206-216)                                         */
 /* ----------------------------------------------------------------------------------------- */
 
+/* everything a merge wants cleared before its first kernel, in ONE launch (nine hipMemsetAsync calls cost a launch each: ~45 us per
+ * merge of 1.8 ms): up to 8 regions of 16-byte units, each filled with one 32-bit value */
+struct FillJobs { void *p[8]; unsigned long long n16[8]; uint32_t val[8]; int n; };
+
+__global__ void __launch_bounds__(256) k_fill_regions(FillJobs jb)
+{
+	unsigned long long tot = 0;
+	for (int i = 0; i < jb.n; ++i) tot += jb.n16[i];
+	for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < tot; u += (unsigned long long)gridDim.x * blockDim.x) {
+		unsigned long long v = u;
+		int i = 0;
+		while (v >= jb.n16[i]) v -= jb.n16[i], ++i;
+		((uint4*)jb.p[i])[v] = make_uint4(jb.val[i], jb.val[i], jb.val[i], jb.val[i]);
+	}
+}
+
 /* the compact copy of the directory's slot words (IdxView.gsm), made after every rebuild */
 __global__ void __launch_bounds__(256) k_grp_compact(const uint64_t *grp64, int64_t ngrp, uint64_t *gsm, const unsigned long long *skip)
 {
@@ -2588,17 +2604,24 @@ template<int RMAX, int NBMAX>
 struct RebLds {
 	__attribute__((aligned(16))) uint32_t bits[260]; // bit s set <=> an old run starts at old-range offset s
 	uint32_t it[RMAX + 2 * NBMAX + 2]; // items, then (in place) heads: offset << 3 | sym
-	uint32_t PHC[RMAX + 2];        // histogram of the batch rows by lb_r, three packed fields: rows (bits 0-13), rows that became items (14-22), C items (23-31)
+	// The histogram of the batch rows is dead once the items are made, and what the slot phases accumulate into is only needed
+	// from then on: one piece of LDS for both (a fifth of the structure; LDS is what bounds the waves per CU of this kernel,
+	// and the kernel waits on LDS and global latency, so waves are what it needs).
+	union {
+		uint32_t PHC[RMAX + 2];        // histogram of the batch rows by lb_r, three packed fields: rows (bits 0-13), rows that became items (14-22), C items (23-31)
+		struct {
+			uint32_t stage[RB3_RG_MAXSLOTS * 24]; // payload of the group's slots: 48 run codes, or the 24 plane words
+			uint32_t scnt[RB3_RG_MAXSLOTS * 8];   // symbol counts per slot
+			uint32_t wh[34];               // heads per window
+			uint32_t wexact;               // bit w: a head sits exactly on the start of window w
+			uint16_t cH[34], hB[34];       // heads before / at-or-before every window boundary
+			uint32_t slotA[RB3_RG_MAXSLOTS + 2];  // start window of every slot, slotA[nslots] = 32
+			uint32_t sbase[RB3_RG_MAXSLOTS + 2];  // first code of every run slot in the group's code sequence
+		};
+	};
 	uint16_t cum[260];             // set bits before word w of bits[]
 	uint16_t S[RMAX + 2];          // old run starts (old-range offsets)
 	uint8_t Ssym[RMAX + 2];
-	uint32_t stage[RB3_RG_MAXSLOTS * 24]; // payload of the group's slots: 48 run codes, or the 24 plane words
-	uint32_t scnt[RB3_RG_MAXSLOTS * 8];   // symbol counts per slot
-	uint32_t wh[34];               // heads per window
-	uint32_t wexact;               // bit w: a head sits exactly on the start of window w
-	uint16_t cH[34], hB[34];       // heads before / at-or-before every window boundary
-	uint32_t slotA[RB3_RG_MAXSLOTS + 2];  // start window of every slot, slotA[nslots] = 32
-	uint32_t sbase[RB3_RG_MAXSLOTS + 2];  // first code of every run slot in the group's code sequence
 	uint32_t fail[RB3_RG_FAILBUF]; // groups this wave hands on to the window kernels, flushed with one atomic
 };
 
@@ -2645,11 +2668,6 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 		uint4 *bz = (uint4*)L.bits;
 		bz[lane] = make_uint4(0, 0, 0, 0);
 		if (lane == 0) bz[64] = make_uint4(0, 0, 0, 0);
-		L.scnt[lane] = 0u;
-		if (lane < 34) L.wh[lane] = 0u;
-		if (lane == 0) L.wexact = 0u;
-#pragma unroll
-		for (int q = 0; q < 3; ++q) L.stage[q * 64 + lane] = 0x00070007u; // unused run codes
 	}
 	wave_sync();
 	// ---- the old runs of [A0, A1) ----
@@ -2792,6 +2810,14 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 		}
 	}
 	const int nI = nR + nB + nC;
+	wave_sync();
+	{ // the histogram has been read: its place now holds what the slot phases accumulate into
+		L.scnt[lane] = 0u;
+		if (lane < 34) L.wh[lane] = 0u;
+		if (lane == 0) L.wexact = 0u;
+#pragma unroll
+		for (int q = 0; q < 3; ++q) L.stage[q * 64 + lane] = 0x00070007u; // unused run codes
+	}
 	wave_sync();
 	RB3_REB_T(4);
 	// ---- heads (maximal runs), compacted in place; heads per window ----
@@ -2943,7 +2969,8 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
  * kernels).  CHECK: a later tier: only the groups an earlier one left (gkind[g] == 1).  LAST: the groups this tier cannot
  * do either are appended to lout (counter nlout) for the LISTED window kernels, a wave's failures with one atomic. */
 template<int RMAX, int NBMAX, bool CHECK, bool LAST>
-__global__ void __launch_bounds__(64 * RB3_RG_WAVES) k_reb_group(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t ntot, const int64_t *jw, int64_t ngrp,
+__global__ void __launch_bounds__(64 * RB3_RG_WAVES, RMAX <= 384 ? 5 : 3) k_reb_group( // (waves per SIMD the LDS of the tier allows: registers must not be what limits them)
+		IdxView old, const int64_t *pos, const uint8_t *b2, int64_t ntot, const int64_t *jw, int64_t ngrp,
 		uint32_t *gstat, uint4 *gslots, uint8_t *gkind, uint32_t *lout, uint32_t *nlout, const unsigned long long *skip)
 {
 	__shared__ RebLds<RMAX, NBMAX> lds_[RB3_RG_WAVES];

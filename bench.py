@@ -211,15 +211,16 @@ def load_batches(files, pinned=True, step=WALKER_STEP):
     from ropebwt3_amd import PinnedArray, host
     texts, walkers, keep = [], [], []
     for fn in files:
-        parts = [t for _, t in host.read_batches(fn, False, 1 << 40)]
-        t = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        parts = list(host.read_batches(fn, False, 1 << 40))
+        n_seq = sum(k for k, _ in parts)
+        t = parts[0][1] if len(parts) == 1 else np.concatenate([x for _, x in parts])
         if pinned:
             pa = PinnedArray(t.size)
             pa.array[:] = t
             keep.append(pa)
             t = pa.array
         texts.append(t)
-        walkers.append(host.walkers_text(t, step))
+        walkers.append((host.walkers_text(t, step), host.strand_pairs(t, n_seq)))   # (+ where the records start: the CLI's sorter thread finds them the same way)
     return texts, walkers, keep
 
 
@@ -232,6 +233,7 @@ class BuildLoop:
         from ropebwt3_amd import Rb3Gpu, Sorter
         self.h = Rb3Gpu(device=device, verbose=1)
         self.srt = Sorter(device)
+        self.fwd_upload = True
 
     def run(self, texts, walkers, first_is_index=True):
         """returns (seconds H2D, seconds merge, seconds sort, symbols merged, wall seconds) of one build"""
@@ -239,9 +241,12 @@ class BuildLoop:
         t_h2d = t_mrg = t_sort = 0.0
         nsym = 0
         w0 = time.perf_counter()
-        for i, (t, w) in enumerate(zip(texts, walkers)):
+        for i, (t, (w, pairs)) in enumerate(zip(texts, walkers)):
             a = time.perf_counter()
-            srt.upload(t)                                   # returns after the stream synchronisation
+            if pairs is not None and self.fwd_upload:
+                srt.upload_fwd(t, pairs)                    # forward strands over PCIe, reverse complements made on the device
+            else:
+                srt.upload(t)                               # returns after the stream synchronisation
             b = time.perf_counter()
             d_bwt, d_tw = srt.sort_uploaded(t.size)         # (synchronous)
             c = time.perf_counter()
@@ -405,6 +410,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (CLI build, configs[1], reads regime, large index)")
     ap.add_argument("--no-pinned", action="store_true", help="batches in pageable host memory (staged upload)")
+    ap.add_argument("--full-upload", action="store_true", help="copy both strands of every batch over PCIe (rb3gpu_sorter_upload) instead of the forward strands only")
     ap.add_argument("--aux-reads", type=int, default=100000)
     ap.add_argument("--large-index", type=int, default=1 << 30, help="symbols of the index of the large-index leg (0: skip)")
     ap.add_argument("--only", choices=["large", "reads", "cfg2", "cli", "headline"], default=None, help="run one leg alone and print its JSON (profiling)")
@@ -448,6 +454,7 @@ def main():
     log("mtb%d: %d files generated in %.1f s, read into %s memory in %.1f s (%d symbols)" % (K, K, t_gen, "pageable" if args.no_pinned else "page-locked", time.time() - t0, nsym_all))
 
     bl = BuildLoop(local_rank)
+    bl.fwd_upload = not args.full_upload
     for _ in range(args.warmup):
         bl.run(texts, walkers)
     bl.h.sync()
@@ -477,14 +484,14 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "cfg3-synthetic-mtb%d: %d genomes of %d bp (star phylogeny, 0.1 %% substitutions + 10 indels each; tools/gen_mtb.py), one genome per batch = %d merge rounds per step, %d symbols merged per step; merge path incl. H2D (SURVEY 8(d))" % (K, K, L, K - 1, sym_step),
                    "symbols_per_step": int(sym_step), "merge_rounds_per_step": K - 1, "index_symbols_final": nsym_all, "index_mb_final": round(st["bytes_index"] / 1e6, 1), "parallelism": "single GPU",
-                   "entry_points": "rb3gpu_sorter_upload (H2D of the batch text, page-locked source) + rb3gpu_merge_text_dev (LF + walkers + settle + validation + rebuild, commit=1); rb3gpu_sorter_sort_uploaded between them is not counted (suffix sorting: excluded by the metric)",
+                   "entry_points": "rb3gpu_sorter_upload_fwd (H2D of the batch: forward strands out of page-locked memory, reverse complements written on the device; --full-upload: rb3gpu_sorter_upload) + rb3gpu_merge_text_dev (LF + walkers + settle + validation + rebuild, commit=1); rb3gpu_sorter_sort_uploaded between them is not counted (suffix sorting: excluded by the metric)",
                    "fmd_md5": md5, "fmd_bytes": fmd_len, "fmd_identical_to_reference": ident,
                    "reference_fmd_md5_source": "tests/golden/MANIFEST.json mtb_star/%d (oracle/_ref/ropebwt3 = the unmodified reference, tools/make_golden_mtb.py)" % K if gold else "no golden for this size",
                    "lf_steps_per_step": int(st["n_lf_steps"] // S), "rank_phase_fallbacks": int(st["n_fallbacks"]), "long_settles": int(st["n_long_settles"])},
         "phases_ms_per_step": {"h2d": round(tot_h2d / S * 1e3, 3), "merge_calls": round(tot_mrg / S * 1e3, 3), "lf": round(st["ms_lf"] / S, 3), "rank": round(st["ms_rank"] / S, 3), "k_chain": round(st["ms_chain"] / S, 3),
                                "rebuild": round(st["ms_build"] / S, 3), "host_and_sync_inside_merge_calls": round((tot_mrg * 1e3 - st["ms_lf"] - st["ms_rank"] - st["ms_build"]) / S, 3)},
         "not_counted_ms_per_step": {"suffix_sorting_on_the_gpu": round(tot_sort / S * 1e3, 3), "wall_of_the_whole_loop": round(tot_wall / S * 1e3, 3)},
-        "h2d": {"bytes_per_step": int(sym_step), "GB/s": round(nsym / max(1e-9, tot_h2d) / 1e9, 2), "source": "pageable (staged)" if args.no_pinned else "page-locked (rb3gpu_pinned_alloc): one DMA per batch"},
+        "h2d": {"symbols_per_step": int(sym_step), "bytes_over_pcie_per_step": int(sym_step // 2) if not args.full_upload else int(sym_step), "how": "rb3gpu_sorter_upload_fwd: forward strands copied, reverse complements written on the device" if not args.full_upload else "rb3gpu_sorter_upload: both strands copied", "GB/s_of_text": round(nsym / max(1e-9, tot_h2d) / 1e9, 2), "source": "pageable (staged)" if args.no_pinned else "page-locked (rb3gpu_pinned_alloc): one DMA per batch"},
         "roofline": chain_roofline(int(rows_launch), ms_chain, "text", load_pmc_traffic("k_chain_mtb152"),
                                    "k_chain<list,mixed,tent,text>: average over the %d launches of the timed steps (run-coded index, intervals of up to %d matching suffixes); `achieved` prices SURVEY 8(d)'s 208 B per LF step over the kernel's HIP-event time; "
                                    "traffic = FETCH_SIZE/WRITE_SIZE of the committed --pmc passes (profiles/r3_pmc_k_chain_mtb152.json); the index (<= %.0f MB) sits in L2 + Infinity Cache, so this kernel is bound by latency and instruction issue, not by HBM (aux_large_index is the HBM-resident case)" % (st["n_rank_launches"], K - 1, st["bytes_index"] / 1e6)),

@@ -233,6 +233,11 @@ int rb3gpu_sorter_release(rb3gpu_sorter_t *s, void *d_bwt);
  * merge path, SURVEY 8(d): one DMA if `text` lies in memory from rb3gpu_pinned_alloc, else through pinned staging buffers),
  * then the suffix sorting of the text uploaded last (len must be the same). */
 int rb3gpu_sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text);
+/* the same for a batch of at most 32 records on both strands (rb3_seq_read with is_for and is_rev: per record l symbols, 0, the l
+ * symbols of the reverse complement, 0; io.c:84-102): only the forward strands are copied, the reverse complements (io.c:30-40) are
+ * written on the device.  pair_start[i] = offset of record i in `text` (pair_start[0] = 0; record n_pairs - 1 ends at len).
+ * RB3GPU_EINVAL if the text does not have that layout (use rb3gpu_sorter_upload). */
+int rb3gpu_sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start);
 int rb3gpu_sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw);
 /* cumulative times of a sorter: text upload (host -> HBM, through its pinned staging buffer) and suffix sorting proper */
 int rb3gpu_sorter_stats(const rb3gpu_sorter_t *s, double *ms_upload, double *ms_sort, int64_t *n_batches, int64_t *n_symbols);

@@ -383,7 +383,13 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 		if (gs) { /* this thread has a GPU sorter of its own: sort now, while the consumer merges the batch before */
 			/* long strings: also the text-order words, and LF walkers by text position (same result, text-regular parallelism);
 			 * short strings (reads): one walker per string is what the engine does by itself */
-			const int r2 = rb3gpu_sorter_sort(gs, b->len, b->bwt, &b->d_bwt, &b->d_tw);
+			/* a few long records on both strands: only the forward strands cross PCIe, the reverse complements are made on the device */
+			int64_t pair_start[32], n_pairs = 0;
+			int r2 = -1;
+			if (!(opt->flag & (BF_NO_FOR | BF_NO_REV))) n_pairs = rb3h_strand_pairs(b->len, b->bwt, n_seq, 32, pair_start);
+			if (n_pairs > 0 && (r2 = rb3gpu_sorter_upload_fwd(gs, b->len, b->bwt, n_pairs, pair_start)) == 0)
+				r2 = rb3gpu_sorter_sort_uploaded(gs, b->len, &b->d_bwt, &b->d_tw);
+			if (n_pairs <= 0 || r2 == RB3GPU_EINVAL) r2 = rb3gpu_sorter_sort(gs, b->len, b->bwt, &b->d_bwt, &b->d_tw);
 			if (r2 == 0) {
 				if (rb3h_verbose >= 3)
 					fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);

@@ -337,3 +337,22 @@ int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is
 }
 
 int rb3h_seq_error(const rb3h_seqio_t *fp) { return fp->err; }
+
+/* the records of a batch that was read with BOTH strands (rb3h_seq_read with is_for and is_rev: per record l symbols, 0, the reverse
+ * complement, 0): pair_start[i] = offset of record i, for rb3gpu_sorter_upload_fwd.  Returns the number of records, or 0 if the
+ * batch has more than max_pairs records or not that layout (n_seq is the number of strings: two per record). */
+int64_t rb3h_strand_pairs(int64_t len, const uint8_t *text, int64_t n_seq, int64_t max_pairs, int64_t *pair_start)
+{
+	int64_t i, p = 0;
+	if (n_seq <= 0 || (n_seq & 1) || n_seq / 2 > max_pairs || len < 4) return 0;
+	for (i = 0; i < n_seq / 2; ++i) {
+		const uint8_t *e = p < len ? (const uint8_t*)memchr(text + p, 0, (size_t)(len - p)) : 0;
+		int64_t l;
+		if (e == 0) return 0;
+		l = (e - text) - p;
+		if (l < 1 || p + 2 * (l + 1) > len || text[p + 2 * l + 1] != 0) return 0;
+		pair_start[i] = p;
+		p += 2 * (l + 1);
+	}
+	return p == len ? n_seq / 2 : 0;
+}

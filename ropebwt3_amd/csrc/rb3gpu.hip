@@ -1776,6 +1776,58 @@ static int sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text)
 	return 0;
 }
 
+/* Stage 1 for a batch of a few long records on both strands (genomes, assemblies): only the FORWARD strands cross PCIe -- each with
+ * its sentinel, straight to its place in the text -- and the reverse complements (io.c:30-40, 84-102) are written on the device:
+ * half the bytes of the H2D copy.  pair_start[i] .. pair_start[i+1] is record i as rb3_seq_read lays it out: l symbols, 0, the l
+ * symbols of the reverse complement, 0. */
+#define RB3_FWD_MAXPAIRS 32
+struct FwdPairs { int64_t start[RB3_FWD_MAXPAIRS + 1]; int n; };
+
+__global__ void __launch_bounds__(256) k_revcomp_fill(uint8_t *text, FwdPairs pp)
+{
+	const int64_t tot = pp.start[pp.n] - pp.start[0];
+	for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot / 2; t += (int64_t)gridDim.x * blockDim.x) {
+		// t counts the positions of the second halves (reverse strand + its sentinel) of all pairs
+		int i = 0;
+		int64_t u = t;
+		while (i + 1 < pp.n && u >= (pp.start[i + 1] - pp.start[i]) / 2) u -= (pp.start[i + 1] - pp.start[i]) / 2, ++i;
+		const int64_t ps = pp.start[i], l = (pp.start[i + 1] - ps) / 2 - 1;
+		uint8_t c = 0;
+		if (u < l) { c = text[ps + l - 1 - u]; c = (c >= 1 && c <= 4) ? (uint8_t)(5 - c) : c; }
+		text[ps + l + 1 + u] = c;
+	}
+}
+
+static int sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start)
+{
+	if (!s || !text || !pair_start || len <= 0 || len >= (1LL << 31) || n_pairs < 1 || n_pairs > RB3_FWD_MAXPAIRS) return RB3GPU_EINVAL;
+	FwdPairs pp;
+	pp.n = (int)n_pairs;
+	for (int64_t i = 0; i <= n_pairs; ++i) pp.start[i] = i < n_pairs ? pair_start[i] : len;
+	if (pp.start[0] != 0) return RB3GPU_EINVAL;
+	for (int64_t i = 0; i < n_pairs; ++i) {
+		const int64_t sz = pp.start[i + 1] - pp.start[i];
+		if (sz < 4 || (sz & 1) || text[pp.start[i] + sz / 2 - 1] != 0 || text[pp.start[i + 1] - 1] != 0) return RB3GPU_EINVAL; // not the layout of two strands per record
+	}
+	SCHK(hipSetDevice(s->dev));
+	int r;
+	s->text_len = 0;
+	if ((r = sorter_grow(&s->text, &s->text_cap, (size_t)len + 16)) < 0) return r;
+	const double t_up = now_s();
+	const bool pinned = is_pinned(text, (size_t)len);
+	for (int64_t i = 0; i < n_pairs; ++i) {
+		const int64_t ps = pp.start[i], half = (pp.start[i + 1] - ps) / 2;
+		if (pinned) { if (hipMemcpyAsync((uint8_t*)s->text + ps, text + ps, (size_t)half, hipMemcpyHostToDevice, s->st) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; } }
+		else if (h2d_copy((uint8_t*)s->text + ps, text + ps, (size_t)half, s->st, s->stage, s->done) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	}
+	int64_t nblk = (len / 2 + 1023) / 1024;
+	hipLaunchKernelGGL(k_revcomp_fill, dim3((unsigned)(nblk > 4096 ? 4096 : nblk)), dim3(256), 0, s->st, (uint8_t*)s->text, pp);
+	if (hipStreamSynchronize(s->st) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	s->ms_upload += (now_s() - t_up) * 1e3;
+	s->text_len = len;
+	return 0;
+}
+
 /* stage 2: suffix-sort the uploaded text into an output buffer that is not with the merger */
 static int sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, int64_t step, int64_t *ckrow, void **d_tw)
 {
@@ -1821,6 +1873,11 @@ static int sorter_impl(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, voi
 int rb3gpu_sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text)
 {
 	return sorter_upload(s, len, text);
+}
+
+int rb3gpu_sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start)
+{
+	return sorter_upload_fwd(s, len, text, n_pairs, pair_start);
 }
 
 int rb3gpu_sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw)

@@ -84,6 +84,7 @@ SYMBOLS = {
     "rb3gpu_sorter_bwt": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_sorter_release": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_sorter_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_sorter_upload_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_sorter_sort_uploaded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     "rb3gpu_pinned_alloc": (ctypes.c_void_p, [ctypes.c_int64]),
     "rb3gpu_pinned_free": (None, [ctypes.c_void_p]),
@@ -175,6 +176,12 @@ class Sorter:
         """the text of a batch host -> HBM (the H2D copy of the merge path); returns when the copy is complete"""
         assert text.dtype == np.uint8 and text.flags["C_CONTIGUOUS"]
         self._chk(self._lib.rb3gpu_sorter_upload(self._s, text.size, text.ctypes.data), "rb3gpu_sorter_upload")
+
+    def upload_fwd(self, text, pair_start):
+        """upload of a batch of a few long records on both strands: forward strands only, reverse complements made on the device"""
+        assert text.dtype == np.uint8 and text.flags["C_CONTIGUOUS"]
+        ps = np.ascontiguousarray(pair_start, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_sorter_upload_fwd(self._s, text.size, text.ctypes.data, ps.size, ps.ctypes.data), "rb3gpu_sorter_upload_fwd")
 
     def sort_uploaded(self, length):
         """suffix-sort the text uploaded last: (d_bwt, d_tw) device pointers, valid until release(d_bwt)"""

@@ -142,6 +142,16 @@ def read_batches(path, is_line, max_len, fwd=True, rev=True):
         L.rb3h_seq_close(fp)
 
 
+def strand_pairs(text, n_seq, max_pairs=32):
+    """record offsets of a batch read with both strands (for Sorter.upload_fwd), or None if it has too many records / another layout"""
+    L = load_library()
+    L.rb3h_strand_pairs.restype = ctypes.c_int64
+    L.rb3h_strand_pairs.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    ps = np.zeros(max_pairs, dtype=np.int64)
+    n = L.rb3h_strand_pairs(text.size, text.ctypes.data, int(n_seq), max_pairs, ps.ctypes.data)
+    return ps[:n].copy() if n > 0 else None
+
+
 def parse_num(s):
     return int(load_library().rb3h_parse_num(s.encode()))
 

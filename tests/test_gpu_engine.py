@@ -488,6 +488,41 @@ def test_whole_index_merge_on_device(oracle):
         a.close(); b.close()
 
 
+def test_forward_strand_upload_equals_full_upload(tmp_path):
+    """rb3gpu_sorter_upload_fwd: only the forward strands cross PCIe, the reverse complements (io.c:30-40) are written on the
+    device -- the same text in HBM as rb3gpu_sorter_upload, hence the same BWT and inverse suffix array; a text that is not laid
+    out as two strands per record is refused"""
+    from ropebwt3_amd import Rb3Gpu, Sorter, PinnedArray, Rb3GpuError, host
+    rng = np.random.default_rng(151)
+    recs = ["".join("ACGTN"[x] for x in rng.choice(5, size=int(n), p=[.25, .25, .25, .24, .01])) for n in (70001, 1, 33333, 2, 12345)]
+    fn = tmp_path / "r.fa"
+    fn.write_text("".join(">r%d\n%s\n" % (i, r) for i, r in enumerate(recs)))
+    (n_seq, text), = list(host.read_batches(str(fn), False, 1 << 40))
+    pairs = host.strand_pairs(text, n_seq)
+    assert pairs is not None and len(pairs) == len(recs) and n_seq == 2 * len(recs)
+    h, srt = Rb3Gpu(verbose=1), Sorter(0)
+    pin = PinnedArray(text.size)
+    pin.array[:] = text
+    try:
+        out = []
+        for src, fwd in ((text, False), (text, True), (pin.array, True)):
+            if fwd: srt.upload_fwd(src, pairs)
+            else: srt.upload(src)
+            d_bwt, d_tw = srt.sort_uploaded(text.size)
+            out.append((h.dev_download(d_bwt, text.size), h.dev_download(d_tw, text.size * 8)))
+            srt.release(d_bwt)
+        assert np.array_equal(out[0][0], host.build_bwt(text.copy()))
+        for o in out[1:]:
+            assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+        bad = text.copy()
+        bad[pairs[1] - 1] = 1                                # the sentinel of the first reverse strand
+        with pytest.raises(Rb3GpuError):
+            srt.upload_fwd(bad, pairs)
+        assert host.strand_pairs(text[:-3].copy(), n_seq) is None
+    finally:
+        pin.free(); srt.close(); h.close()
+
+
 def test_merge_index_between_two_handles(oracle):
     """rb3gpu_merge_index = the tree step of `build --gpus N` (rb3_fmi_merge, fm-index.c:251-277): the index of one handle
     merged into another as one batch, device to device; three slices merged left to right give the BWT of all strings in

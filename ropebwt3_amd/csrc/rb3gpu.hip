@@ -115,6 +115,9 @@ struct Tune {
 	int64_t reb_lcap = 0;    // > 0: entries of the hand-over list the window scratch takes (a longer list: rebuild done again)
 	int64_t reb_slot_cap = 0;// > 0: pretend the slot array of a single-sync rebuild holds this many slots
 	int corrupt_pos = 0;     // move a range of rows of pos[] by one after the walk (still monotone): the LF check must notice
+	int64_t pos_limit = 0;   // > 0: pretend merged positions must stay below this instead of 2^38 (beyond: staged path, no tentative records)
+	int64_t win_scratch = 0; // > 0: pretend the window kernels' scratch may take this many bytes instead of 8 GB (beyond: group-sequential rebuild)
+	int64_t slot_bytes = 0;  // > 0: pretend the upper bound of the slot array may take this many bytes instead of 16 GB (beyond: staged path)
 #endif
 };
 
@@ -357,9 +360,13 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "poison")) t.poison = v != 0;
 	else if (!strcmp(key, "guard")) t.guard = v != 0;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
-	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap")) {
+	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
+			!strcmp(key, "pos_limit") || !strcmp(key, "win_scratch") || !strcmp(key, "slot_bytes")) {
 #ifdef RB3GPU_TEST_HOOKS
-		if (!strcmp(key, "corrupt_pos")) t.corrupt_pos = v != 0;
+		if (!strcmp(key, "pos_limit")) t.pos_limit = v;
+		else if (!strcmp(key, "win_scratch")) t.win_scratch = v;
+		else if (!strcmp(key, "slot_bytes")) t.slot_bytes = v;
+		else if (!strcmp(key, "corrupt_pos")) t.corrupt_pos = v != 0;
 		else if (!strcmp(key, "reb_lcap")) t.reb_lcap = v;
 		else if (!strcmp(key, "reb_slot_cap")) t.reb_slot_cap = v;
 		else if (!strcmp(key, "force_fallback")) t.force_fallback = v != 0;
@@ -381,7 +388,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
 	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check", "log_alloc", "defer_free", "poison", "guard",
-		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", nullptr };
+		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
 		size_t l = strlen(name);
@@ -559,9 +566,35 @@ static bool runspace_applies(const rb3gpu_t *h, int64_t n2, int64_t ntot)
 	return h->tn.reb_force || (h->nslots * 2 < nwin_old && (double)n2 * RB3_GRP <= 4096.0 * (double)ntot); // (run-coded index; not where half of every group is new)
 }
 
+/* the size limits of the single-synchronisation merge; the test build of the library can shrink them so that a test crosses them */
+static int64_t lim_pos(const rb3gpu_t *h)
+{
+#ifdef RB3GPU_TEST_HOOKS
+	if (h->tn.pos_limit > 0 && h->tn.pos_limit < (1LL << RB3_TENT_PBITS)) return h->tn.pos_limit;
+#endif
+	(void)h;
+	return 1LL << RB3_TENT_PBITS;
+}
+static size_t lim_win_scratch(const rb3gpu_t *h)
+{
+#ifdef RB3GPU_TEST_HOOKS
+	if (h->tn.win_scratch > 0) return (size_t)h->tn.win_scratch;
+#endif
+	(void)h;
+	return (size_t)8 << 30;
+}
+static size_t lim_slot_bytes(const rb3gpu_t *h)
+{
+#ifdef RB3GPU_TEST_HOOKS
+	if (h->tn.slot_bytes > 0) return (size_t)h->tn.slot_bytes;
+#endif
+	(void)h;
+	return (size_t)16 << 30;
+}
+
 static bool use_winpar(const rb3gpu_t *h, int64_t nwin)
 {
-	return (size_t)nwin * 216 <= ((size_t)8 << 30) && !h->tn.group_rebuild;
+	return (size_t)nwin * 216 <= lim_win_scratch(h) && !h->tn.group_rebuild;
 }
 
 /* slots to make room for before a single-sync merge of n2 rows: one per window is the upper bound; where the index is
@@ -867,7 +900,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 	}
 	// tentative records need merged positions < 2^38
 	if (!h->tn.tent) tent = 0;
-	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= (1LL << RB3_TENT_PBITS) || stop_row >= 0) tent = 0;
+	if ((walkers ? n_walkers : nwalk - m2) <= 0 || h->n + len >= lim_pos(h) || stop_row >= 0) tent = 0;
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
 #ifdef RB3GPU_TEST_HOOKS
@@ -1136,7 +1169,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			return r2;
 		}
 	}
-	if ((!walkers && !per_string && !auto_list) || n_walkers > (1 << 24) || n_walkers > len || ntot >= (1LL << RB3_TENT_PBITS) || (size_t)nwin * sizeof(rb3_slot_t) > ((size_t)16 << 30) || h->tn.staged) {
+	if ((!walkers && !per_string && !auto_list) || n_walkers > (1 << 24) || n_walkers > len || ntot >= lim_pos(h) || (size_t)nwin * sizeof(rb3_slot_t) > lim_slot_bytes(h) || h->tn.staged) {
 		if (per_string) return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, tent_auto);
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, tent);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);

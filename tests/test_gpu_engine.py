@@ -488,6 +488,38 @@ def test_whole_index_merge_on_device(oracle):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("hook,value", [("pos_limit", 300000), ("win_scratch", 216 * 1200), ("slot_bytes", 128 * 1300)])
+def test_size_limits_of_the_single_sync_merge_are_crossed_in_mid_build(oracle, hook, value):
+    """the single-synchronisation merge changes regime at sizes no test reaches (merged positions >= 2^38: staged path without
+    tentative records; window scratch > 8 GB: group-sequential rebuild; slot upper bound > 16 GB: staged path).  The test build of
+    the library shrinks the limits so that a build of a dozen relatives crosses each of them between two merges"""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(163)
+    g0 = util.random_genome(rng, 30000)
+    gs = [g0] + [util.mutate(rng, g0, 0.003) for _ in range(7)]
+    h = Rb3Gpu(verbose=1, hooks=True)
+    try:
+        h.tune(hook, value)
+        want = None
+        for i, g in enumerate(gs):
+            t = util.make_text([g])
+            b = host.build_bwt(t.copy())
+            if i == 0:
+                h.from_plain(b); want = b
+                continue
+            if i % 2:
+                d_bwt, d_tw = h.sort_text(t)
+                h.merge_text_dev(d_bwt, d_tw, t.size, host.walkers_text(t, 200), commit=True)
+                h.dev_free(d_bwt); h.dev_free(d_tw)
+            else:
+                h.merge_plain(b)
+            want = oracle.merge(want, b)
+            assert np.array_equal(h.export_plain(), want), (hook, i)
+        assert h.get_tot() == sum(2 * g.size + 2 for g in gs) > 400000   # (every limit above lies between 300 k and 340 k symbols)
+    finally:
+        h.close()
+
+
 def test_forward_strand_upload_equals_full_upload(tmp_path):
     """rb3gpu_sorter_upload_fwd: only the forward strands cross PCIe, the reverse complements (io.c:30-40) are written on the
     device -- the same text in HBM as rb3gpu_sorter_upload, hence the same BWT and inverse suffix array; a text that is not laid

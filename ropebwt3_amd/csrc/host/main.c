@@ -734,7 +734,11 @@ int main_build(int argc, char *argv[])
 			return 1;
 		}
 		has_index = 1;
-		if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] loaded the index from file '%s'\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), fn_in);
+		if (rb3h_verbose >= 3) {
+			rb3gpu_stats_t st;
+			rb3gpu_stats(h, &st);
+			fprintf(stderr, "[M::%s::%.3f*%.2f] loaded the index from file '%s' (index %.1f MB in HBM, peak device memory while loading %.1f MB)\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), fn_in, st.bytes_index / 1e6, st.bytes_peak / 1e6);
+		}
 	}
 
 	if (opt.sais_threads < 0) opt.sais_threads = opt.gpu_sort ? 1 : 0; /* one batch sorted on the GPU while the one before is merged */
@@ -826,6 +830,7 @@ int main_build(int argc, char *argv[])
 				st.ms_build, (long)st.bytes_rebuild, st.ms_build > 0 ? st.bytes_rebuild / st.ms_build / 1e6 : 0.0, st.ms_chain, (long)st.n_rank_launches, (long)st.n_lf_steps);
 		fprintf(stderr, "[M::%s] run-space rebuild: %ld groups, %ld of them handed on to the window kernels; %ld merges redone without tentative records, %ld needed the long settle pass; %ld rows LF-checked; %.1f ms in %ld device allocations\n", __func__,
 				(long)st.n_reb_groups, (long)st.n_reb_groups_window, (long)st.n_fallbacks, (long)st.n_long_settles, (long)st.n_lf_checked, st.ms_alloc, (long)st.n_allocs);
+		fprintf(stderr, "[M::%s] device memory of the index handle: peak %.1f MB, index %.1f MB\n", __func__, st.bytes_peak / 1e6, st.bytes_index / 1e6);
 		fprintf(stderr, "[M::%s] batches: %ld (%ld symbols) suffix-sorted on the GPU, %ld (%ld symbols) on the host; -m %ld%s\n", __func__,
 				(long)g_sorted.n_gpu, (long)g_sorted.sym_gpu, (long)g_sorted.n_host, (long)g_sorted.sym_host, (long)opt.batch_size,
 				batch_cut(&opt) != opt.batch_size ? " cut into GPU sub-batches (--gpu-batch)" : "");

@@ -38,6 +38,9 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 struct rb3fmd_dec;
 int rb3fmd_decode_begin(hipStream_t st, int64_t n_words, const uint64_t *d_z, rb3fmd_dec **ctx, int64_t *n_sym);
 int rb3fmd_decode_fill(rb3fmd_dec *ctx, uint8_t *d_plain);
+int rb3fmd_decode_range(rb3fmd_dec *ctx, int64_t p0, int64_t p1, uint8_t *d_out);
+void rb3fmd_decode_end(rb3fmd_dec *ctx);
+int64_t rb3fmd_decode_bytes(const rb3fmd_dec *ctx);
 
 struct Buf {
 	void *p = nullptr;
@@ -108,6 +111,7 @@ struct Tune {
 	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
 	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
+	int64_t load_chunk = 16384; // groups (of 8192 symbols) an FMD stream is decoded and built by at a time when it holds more than that (rb3gpu_from_fmd_words)
 #ifdef RB3GPU_TEST_HOOKS
 	int force_fallback = 0;  // pretend the tentative pass left unsettled records
 	int64_t tent_limit = -1; // shrink the stretch table
@@ -221,12 +225,12 @@ static void dev_free(rb3gpu_t *h, void *p, size_t bytes)
 	h->bytes_owned -= (int64_t)bytes;
 }
 
-static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes)
+static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes, bool exact = false)
 {
 	if (b.cap >= bytes && b.p) return 0;
 	if (b.p) dev_free(h, b.p, b.cap);
 	b.p = nullptr, b.cap = 0;
-	size_t want = bytes + (bytes >> 1) + 256; // geometric growth: an index that grows round by round must not realloc every round
+	size_t want = exact ? bytes + 256 : bytes + (bytes >> 1) + 256; // geometric growth: an index that grows round by round must not realloc every round (exact: a one-off, e.g. loading an index)
 	int r = dev_malloc(h, &b.p, want);
 	if (r == RB3GPU_ENOMEM && want != bytes) r = dev_malloc(h, &b.p, want = bytes);
 	if (r < 0) return r;
@@ -359,6 +363,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "defer_free")) t.defer_free = v != 0;
 	else if (!strcmp(key, "poison")) t.poison = v != 0;
 	else if (!strcmp(key, "guard")) t.guard = v != 0;
+	else if (!strcmp(key, "load_chunk")) t.load_chunk = v < 1 ? 1 : v;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
 	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
 			!strcmp(key, "pos_limit") || !strcmp(key, "win_scratch") || !strcmp(key, "slot_bytes")) {
@@ -387,7 +392,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -439,13 +444,13 @@ static void ib_release(rb3gpu_t *h, int i)
 }
 
 /* make ib[i] hold at least ngrp directory entries and nslots slots (contents are not preserved) */
-static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots)
+static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exact = false)
 {
 	int r;
 	if (h->ib[i].grp_cap < (size_t)ngrp) {
 		dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * RB3_GRP_ALLOC);
 		h->ib[i].grp = nullptr, h->ib[i].grp_cap = 0;
-		size_t want = (size_t)ngrp + (size_t)(ngrp >> 1) + 16;
+		size_t want = exact ? (size_t)ngrp + 16 : (size_t)ngrp + (size_t)(ngrp >> 1) + 16;
 		if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * RB3_GRP_ALLOC)) < 0) {
 			want = (size_t)ngrp;
 			if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * RB3_GRP_ALLOC)) < 0) return r;
@@ -455,7 +460,7 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots)
 	if (h->ib[i].slots_cap < (size_t)nslots) {
 		dev_free(h, h->ib[i].slots, h->ib[i].slots_cap * sizeof(rb3_slot_t));
 		h->ib[i].slots = nullptr, h->ib[i].slots_cap = 0;
-		size_t want = (size_t)nslots + (size_t)(nslots >> 1) + 64;
+		size_t want = exact ? (size_t)nslots + 64 : (size_t)nslots + (size_t)(nslots >> 1) + 64;
 		if ((r = dev_malloc(h, (void**)&h->ib[i].slots, want * sizeof(rb3_slot_t))) < 0) {
 			want = (size_t)nslots;
 			if ((r = dev_malloc(h, (void**)&h->ib[i].slots, want * sizeof(rb3_slot_t))) < 0) return r;
@@ -2191,12 +2196,100 @@ static int fmd_words_to_b2(rb3gpu_t *h, int64_t n_words, const uint64_t *words, 
 	return 0;
 }
 
+/* A large FMD stream becomes a block array WITHOUT passing through one byte per symbol (rb3_enc_fmd2fmr streams the runs too,
+ * fm-index.c:56-85): the stream is decoded chunk by chunk (load_chunk groups of 8192 symbols; a 64-byte FMD block is
+ * self-contained, so any range of positions can be decoded on its own), twice -- the first pass only counts the slots and symbols
+ * of every group (k_pass1w + k_decide on the chunk), one scan over all groups then gives every slot its place and the directory
+ * its counts, the second pass writes the slots of each chunk there (k_pass1w + k_pass2w).  Device memory beyond the stream and the
+ * index: one chunk of symbols and its window scratch (~0.23 GB for the default chunk of 134 M symbols). */
+static int from_fmd_chunked(rb3gpu_t *h, rb3fmd_dec *ctx, int64_t n, const int64_t mcnt[RB3GPU_ASIZE])
+{
+	const int64_t ngrp = (n >> RB3_GRP_BITS) + 1, nwin = (n >> RB3_WIN_BITS) + 1, CG = h->tn.load_chunk;
+	const int64_t csym = CG << RB3_GRP_BITS, cwin = CG * RB3_GRP_WINS;
+	const int dst = 1 - h->cur;
+	int r;
+	if ((r = buf_ensure(h, h->b2, (size_t)csym + 16, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->wstat, (size_t)(cwin + 1) * 16, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->wplane, (size_t)(cwin + 1) * 96, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->wruns, (size_t)(cwin + 1) * RB3_RLE_CODES * 2, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->gstat, (size_t)ngrp * 32, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->gpre, (size_t)ngrp * 64, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	uint32_t *gstat = (uint32_t*)h->gstat.p;
+	uint64_t *gpre = (uint64_t*)h->gpre.p, *dtot = (uint64_t*)h->misc.p + MISC_IX_TOT, total[8];
+	const IdxView none = view_of(h); // (not read when building from symbols)
+	int64_t onslots = 0;
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	for (int pass = 0; pass < 2; ++pass) {
+		for (int64_t g0 = 0; g0 < ngrp; g0 += CG) {
+			const int64_t g1 = g0 + CG < ngrp ? g0 + CG : ngrp, p0 = g0 << RB3_GRP_BITS, p1 = (g1 << RB3_GRP_BITS) < n ? (g1 << RB3_GRP_BITS) : n;
+			const int64_t rem = n - p0;                                   // symbols from the chunk's start to the end of the index
+			const int64_t nw = g1 == ngrp ? (rem >> RB3_WIN_BITS) + 1 : (g1 - g0) * RB3_GRP_WINS; // (the last chunk ends with the window of position n)
+			if (rb3fmd_decode_range(ctx, p0, p1, (uint8_t*)h->b2.p) < 0) return RB3GPU_ENODEV;
+			const dim3 g1w((unsigned)((nw + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), b1w(64 * RB3_REB_WAVES);
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<true, 3>), g1w, b1w, 0, h->st, none, (const int64_t*)nullptr, (const uint8_t*)h->b2.p, rem, rem, (const int64_t*)nullptr,
+					(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nw, (const unsigned long long*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+			if (pass == 0)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_decide<false>), dim3((unsigned)(g1 - g0)), dim3(64), 0, h->st, (const uint4*)h->wstat.p, rem, gstat + g0 * 8, g1 - g0, (const unsigned long long*)nullptr,
+						(const uint32_t*)nullptr, (const uint32_t*)nullptr);
+			else
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<false>), dim3((unsigned)(g1 - g0)), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, rem,
+						(const uint32_t*)(gstat + g0 * 8), (const uint64_t*)(gpre + g0 * 8), (const uint64_t*)dtot, h->ib[dst].grp + g0, (uint4*)h->ib[dst].slots, nw, (const unsigned long long*)nullptr,
+						(const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, ~0ull, nwin, n);
+		}
+		if (pass == 0) {
+			if ((r = scan_records(h, gstat, ngrp, gpre, dtot, total)) < 0) return r; // (one synchronisation: the slot count sizes the index)
+			int64_t tot = 0;
+			for (int a = 0; a < 6; ++a) {
+				tot += (int64_t)total[a];
+				if (mcnt && (int64_t)total[a] != mcnt[a]) return RB3GPU_ESYMBOL;
+			}
+			if (tot != n) return RB3GPU_ESYMBOL;
+			onslots = (int64_t)total[6];
+			index_drop(h);
+			if ((r = ib_ensure(h, dst, ngrp, onslots, true)) < 0) return r; // (no head room: the first merge into a loaded index sizes its own buffers)
+		}
+	}
+	hipLaunchKernelGGL(k_grp_compact, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, h->st, (const uint64_t*)h->ib[dst].grp, ngrp, (uint64_t*)(h->ib[dst].grp + h->ib[dst].grp_cap), (const unsigned long long*)nullptr);
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_build += ev_ms(h->ev[0], h->ev[1]);
+	int64_t acc[7];
+	acc[0] = 0;
+	for (int a = 0; a < 6; ++a) acc[a + 1] = acc[a] + (int64_t)total[a];
+	index_install(h, ngrp, onslots, n, acc);
+	if (h->bytes_owned + rb3fmd_decode_bytes(ctx) > h->stt.bytes_peak) h->stt.bytes_peak = h->bytes_owned + rb3fmd_decode_bytes(ctx);
+	if (h->opt.verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f] built %lld symbols into %lld slots from the FMD stream in chunks of %lld symbols (%.3f ms)\n", __func__, now_s() - h->t0, (long long)n, (long long)onslots, (long long)csym, ev_ms(h->ev[0], h->ev[1]));
+	return 0;
+}
+
 int rb3gpu_from_fmd_words(rb3gpu_t *h, int64_t n_words, const uint64_t *words, const int64_t mcnt[RB3GPU_ASIZE])
 {
 	if (!h || n_words < 8 || !words) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	int64_t n_sym = 0;
 	int r;
+	{ // an index of more than one chunk is never expanded to one byte per symbol
+		if ((r = buf_ensure(h, h->xbuf, (size_t)(n_words + 2) * 8, true)) < 0) return r;
+		HIPCHK(hipMemsetAsync((uint64_t*)h->xbuf.p + n_words, 0, 16, h->st));
+		HIPCHK(hipMemcpyAsync(h->xbuf.p, words, (size_t)n_words * 8, hipMemcpyHostToDevice, h->st));
+		rb3fmd_dec *ctx = nullptr;
+		r = rb3fmd_decode_begin(h->st, n_words, (const uint64_t*)h->xbuf.p, &ctx, &n_sym);
+		if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -2 ? RB3GPU_ENODEV : RB3GPU_ESYMBOL;
+		if (mcnt) {
+			int64_t tot = 0;
+			for (int a = 0; a < RB3GPU_ASIZE; ++a) tot += mcnt[a];
+			if (tot != n_sym) { rb3fmd_decode_end(ctx); return RB3GPU_ESYMBOL; }
+		}
+		if (n_sym > (h->tn.load_chunk << RB3_GRP_BITS)) {
+			r = from_fmd_chunked(h, ctx, n_sym, mcnt);
+			rb3fmd_decode_end(ctx);
+			if (r < 0) index_drop(h);
+			return r;
+		}
+		rb3fmd_decode_end(ctx); // (small: the one-pass path below decodes it again, once)
+	}
 	if ((r = fmd_words_to_b2(h, n_words, words, mcnt, &n_sym)) < 0) return r;
 	if ((r = rb3gpu_from_plain_dev(h, n_sym, (const uint8_t*)h->b2.p)) < 0) return r;
 	if (mcnt)

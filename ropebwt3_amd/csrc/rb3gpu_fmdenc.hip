@@ -390,6 +390,27 @@ __global__ void __launch_bounds__(256) k_fd_long(const fd_long_t *lng, const uns
 	}
 }
 
+/* the symbols of positions [p0, p1) only, written to out[0 .. p1 - p0): a large index is decoded piece by piece */
+__global__ void __launch_bounds__(256) k_fd_fill_range(const uint64_t *z, int64_t nblk, const uint64_t *boff, int64_t p0, int64_t p1, uint8_t *out, fd_long_t *lng, unsigned int *nlong)
+{
+	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= nblk) return;
+	int64_t off = (int64_t)boff[b];
+	if (off >= p1 || (int64_t)boff[b + 1] <= p0) return;
+	fd_block(z, b * 8, [&](int c, int64_t l) {
+		const int64_t a = off > p0 ? off : p0, e = off + l < p1 ? off + l : p1;
+		if (a < e) {
+			bool done = false;
+			if (e - a >= FD_LONG) {
+				const unsigned int k = atomicAdd(nlong, 1u);
+				if (k < (unsigned int)FD_LONG_CAP) { fd_long_t x; x.off = a - p0, x.len = e - a, x.sym = c; lng[k] = x; done = true; }
+			}
+			if (!done) fd_fill(out + (a - p0), e - a, c);
+		}
+		off += l;
+	});
+}
+
 struct rb3fmd_dec {
 	hipStream_t st;
 	int64_t nblk;
@@ -452,3 +473,25 @@ done:
 	delete c;
 	return ret;
 }
+
+/* the symbols of [p0, p1) of a stream opened with rb3fmd_decode_begin into d_out (p1 - p0 bytes); the context stays open */
+int rb3fmd_decode_range(rb3fmd_dec *c, int64_t p0, int64_t p1, uint8_t *d_out)
+{
+	int ret = 0;
+	hipStream_t st = c->st;
+	if (p1 <= p0) return 0;
+	FE_HIP(hipMemsetAsync(c->flag + 1, 0, 4, st));
+	hipLaunchKernelGGL(k_fd_fill_range, FE_GRID(c->nblk), c->z, c->nblk, (const uint64_t*)c->boff, p0, p1, d_out, c->lng, c->flag + 1);
+	hipLaunchKernelGGL(k_fd_long, dim3(64, 256), dim3(256), 0, st, (const fd_long_t*)c->lng, (const unsigned int*)(c->flag + 1), d_out);
+done:
+	return ret;
+}
+
+void rb3fmd_decode_end(rb3fmd_dec *c)
+{
+	if (!c) return;
+	(void)hipStreamSynchronize(c->st);
+	(void)rb3fmd_decode_fill(c, nullptr);
+}
+
+int64_t rb3fmd_decode_bytes(const rb3fmd_dec *c) { return c ? (int64_t)(c->nblk + 1) * 16 + (int64_t)FD_LONG_CAP * (int64_t)sizeof(fd_long_t) : 0; }

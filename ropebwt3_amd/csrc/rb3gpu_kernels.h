@@ -2371,11 +2371,13 @@ __global__ void __launch_bounds__(64) k_decide(const uint4 *wstat, int64_t ntot,
 template<bool LISTED = false>
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wstat, const uint32_t *wplane, const uint16_t *wruns, int64_t ntot, const uint32_t *gstat,
 		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin, const unsigned long long *skip,
-		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr, uint32_t lcap = 0, uint64_t slot_cap = ~0ull)
+		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr, uint32_t lcap = 0, uint64_t slot_cap = ~0ull,
+		int64_t all_nwin = -1, int64_t all_ntot = -1) // (a chunk of a larger build: windows / symbols of the WHOLE index, which decide the header kind)
 {
 	if (RB3_REB_SKIP(skip)) return;
 	if (LISTED && *nglist > lcap) return;
 	if (tot[6] > slot_cap) return; // the slot array was sized by an estimate: the host looks at the total and emits again
+	if (all_nwin < 0) all_nwin = nwin, all_ntot = ntot;
 #ifdef RB3_ABL
 	if (LISTED) return;
 #endif
@@ -2398,7 +2400,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		grp[g] = e;
 	}
 	uint32_t abs_base = 0; // lanes 1..6: the LF base of the group start if the headers are absolute (RB3_ABS_HEADERS)
-	if (RB3_ABS_HEADERS((int64_t)tot[6], nwin, ntot) && lane >= 1 && lane <= 6) {
+	if (RB3_ABS_HEADERS((int64_t)tot[6], all_nwin, all_ntot) && lane >= 1 && lane <= 6) {
 		uint64_t cb = gpre[g * 8 + lane - 1];
 		for (int a = 0; a < lane - 1; ++a) cb += tot[a];
 		abs_base = (uint32_t)cb;

@@ -293,6 +293,22 @@ def test_config4_reads_m7g_stays_on_the_gpu(tmp_path):
     assert os.path.getsize(out) == ent["fmd_bytes"] and h.hexdigest() == ent["fmd_md5"]
 
 
+def test_resume_and_ssa_from_an_index_loaded_in_chunks(tmp_path):
+    """`build -i` and `ssa` on an .fmd that is loaded chunk by chunk (RB3GPU_LOAD_CHUNK=2 groups): golden bytes"""
+    r = MAN["resume"]
+    env = dict(os.environ, RB3GPU_LOAD_CHUNK="2")
+    ent = MAN[r["expect"]]
+    fmd = os.path.join(util.GOLDEN, ent["fmd"])
+    out = subprocess.run([CLI, "ssa", "-s3", fmd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert out.returncode == 0 and hashlib.md5(out.stdout).hexdigest() == ent["ssa_md5"]["3"]
+    first6 = os.path.join(util.GOLDEN, r["fmd"])
+    rest6 = os.path.join(util.GOLDEN, r["rest"])
+    out = subprocess.run([CLI, "build", "-d", "-i", first6, rest6], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert out.returncode == 0, out.stderr.decode()[-400:]
+    assert hashlib.md5(out.stdout).hexdigest() == ent["fmd_md5"]
+    assert b"in chunks of" in out.stderr
+
+
 def _family(name):
     ent = MAN.get("family", {}).get(name)
     if not ent:

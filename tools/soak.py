@@ -37,11 +37,11 @@ for case in range(ncase):
     cur = None
     for i in range(0, nrel, per):
         t = util.make_text(rel[i:i + per], True, both)
-        if case % 4 == 3:
+        if case % 4 == 3 and not os.environ.get("SOAK_TEXT"):
             b = host.build_bwt(t)
             if cur is None: h.from_plain(b)
             else: h.merge_plain(b)
-        elif case % 4 == 2 and case % 8 != 6:   # suffix-sorted on the GPU, merged through its text-order words (the CLI's default path)
+        elif (case % 4 == 2 and case % 8 != 6) or os.environ.get("SOAK_TEXT"):   # suffix-sorted on the GPU, merged through its text-order words (the CLI's default path)
             d, dtw = h.sort_text(t)
             b = h.dev_download(d, t.size)
             if not np.array_equal(b, host.build_bwt(t.copy())):

@@ -121,3 +121,40 @@ def test_ssa_matches_reference_files(oracle, name):
         f = MAN[name]["ssa_file"]
         ms, r2i, ssa = oracle.ssa_gen(b, f["shift"])
         assert util.ssa_bytes(f["shift"], ms, r2i, ssa) == open(os.path.join(util.GOLDEN, f["file"]), "rb").read()
+
+
+def _rb_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_rb", os.path.join(util.ROOT, "tools", "make_golden_rb.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.cases()
+
+
+@pytest.mark.parametrize("name", ["k2", "k3", "family", "reads"])
+def test_rb_vectors_of_the_reference(oracle, name):
+    """rb[] as the UNMODIFIED reference's rb3_mg_rank_plain left it (tests/golden/rb_vectors.npz, made by
+    tools/make_golden_rb.py from oracle/_ref/librb3ref.so) -- every bit of every word equals the oracle's restatement of
+    fm-index.c:160-175, 202-225: merged position, inserted symbol and bucket symbol"""
+    vec = np.load(os.path.join(util.GOLDEN, "rb_vectors.npz"))
+    l1, l2, both = _rb_cases()[name]
+    b1, b2 = oracle.bwt(oracle.text(l1, True, both)), oracle.bwt(oracle.text(l2, True, both))
+    rb, acc2 = oracle.mg_rank(b1, b2)
+    assert np.array_equal(rb, vec[name + "_rb"]) and np.array_equal(acc2, vec[name + "_acc2"])
+    if util.Reference.available():   # and live, where the reference's shared object travelled with the repository
+        ref = util.Reference()
+        rb2, acc3 = ref.mg_rank(b1, b2)
+        assert np.array_equal(rb2, rb) and np.array_equal(acc3, acc2)
+
+
+@pytest.mark.skipif(not util.Reference.available(), reason="oracle/_ref/librb3ref.so not built")
+def test_rb_against_the_reference_on_random_inputs(oracle):
+    ref = util.Reference()
+    rng = np.random.default_rng(77)
+    for _ in range(6):
+        g0 = util.random_genome(rng, int(rng.integers(200, 4000)))
+        old = [g0] + [util.mutate(rng, g0, 0.01) for _ in range(int(rng.integers(0, 4)))]
+        new = [util.mutate(rng, g0, 0.01) for _ in range(int(rng.integers(1, 4)))] + util.reads_from(rng, g0, 5, 40)
+        b1, b2 = oracle.bwt(util.make_text(old)), oracle.bwt(util.make_text(new))
+        a, b = oracle.mg_rank(b1, b2), ref.mg_rank(b1, b2)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -520,6 +520,35 @@ def test_size_limits_of_the_single_sync_merge_are_crossed_in_mid_build(oracle, h
         h.close()
 
 
+@pytest.mark.parametrize("name", ["k2", "k3", "family", "reads"])
+def test_pos_equals_the_reference_rb_vectors(oracle, name):
+    """pos[] of the HIP rank phase against rb[] >> 6 of the unmodified reference's rb3_mg_rank_plain (committed numbers:
+    tests/golden/rb_vectors.npz), through the reference's signature and through the text-order walk"""
+    import importlib.util
+    from ropebwt3_amd import Rb3Gpu, host
+    spec = importlib.util.spec_from_file_location("make_golden_rb", os.path.join(util.ROOT, "tools", "make_golden_rb.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    l1, l2, both = m.cases()[name]
+    vec = np.load(os.path.join(util.GOLDEN, "rb_vectors.npz"))
+    want, acc_want = vec[name + "_rb"] >> 6, vec[name + "_acc2"]
+    t1, t2 = oracle.text(l1, True, both), oracle.text(l2, True, both)
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_plain(host.build_bwt(t1.copy()))
+        b2 = host.build_bwt(t2.copy())
+        pos, acc2 = h.mg_rank_plain(b2)
+        assert np.array_equal(pos, want) and np.array_equal(acc2, acc_want)
+        d_bwt, d_tw = h.sort_text(t2)
+        n_str = int((t2 == 0).sum())
+        for w in ([n_str] if t2.size < 2000 else [n_str, host.walkers_text(t2, 150)]):
+            pos2, acc3 = h.mg_rank_text_dev(d_bwt, d_tw, t2.size, w)
+            assert np.array_equal(pos2, want) and np.array_equal(acc3, acc_want)
+        h.dev_free(d_bwt); h.dev_free(d_tw)
+    finally:
+        h.close()
+
+
 def test_forward_strand_upload_equals_full_upload(tmp_path):
     """rb3gpu_sorter_upload_fwd: only the forward strands cross PCIe, the reverse complements (io.c:30-40) are written on the
     device -- the same text in HBM as rb3gpu_sorter_upload, hence the same BWT and inverse suffix array; a text that is not laid

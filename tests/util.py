@@ -116,6 +116,28 @@ class Reference:
     def available():
         return os.path.exists(REF_SO)
 
+    def mg_rank(self, b1, b2, threads=2):
+        """the reference's own rb[] (rb3_mg_rank_plain, fm-index.c:202-225, on the mrope of b1 built by rb3_enc_plain2fmr):
+        rb[kb] = (ka + kb) << 6 | B2[kb] << 3 | first symbol of the row's suffix, and acc2 = C array of b2"""
+        class Fmi(ctypes.Structure):   # rb3_fmi_t, fm-index.h:42-49
+            _fields_ = [("is_fmd", ctypes.c_int32), ("e", ctypes.c_void_p), ("r", ctypes.c_void_p), ("ssa", ctypes.c_void_p), ("sid", ctypes.c_void_p), ("acc", ctypes.c_int64 * 7)]
+        L = self.L
+        L.rb3_fmi_get_acc.restype = ctypes.c_int64
+        L.rb3_fmi_get_acc.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.rb3_mg_rank_plain.restype = None
+        L.rb3_mg_rank_plain.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        b1 = np.ascontiguousarray(b1, dtype=np.uint8)
+        b2 = np.ascontiguousarray(b2, dtype=np.uint8)
+        r = L.rb3_enc_plain2fmr(b1.size, b1.ctypes.data, 0, 0, threads)
+        f = Fmi()
+        f.is_fmd, f.e, f.r, f.ssa, f.sid = 0, None, r, None, None
+        L.rb3_fmi_get_acc(ctypes.byref(f), f.acc)     # rb3_fmi_init, fm-index.h:95-101
+        rb = np.zeros(b2.size, dtype=np.int64)
+        acc2 = np.zeros(7, dtype=np.int64)
+        L.rb3_mg_rank_plain(ctypes.byref(f), b2.size, b2.ctypes.data, rb.ctypes.data, acc2.ctypes.data, threads)
+        L.mr_destroy(r)
+        return rb, acc2
+
     def bwt(self, text, threads=4):
         t = np.ascontiguousarray(text, dtype=np.uint8).copy()
         n_seq = int((t == 0).sum())

@@ -104,6 +104,7 @@ struct Tune {
 	int lpw = 8;             // lanes per walker of k_chain in the single-sync merge: 8 (an octet) or 4 (a quad, 16 walkers per wave; builds with -DRB3_WITH_QUADS only)
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
+	int chain_bs = 256;      // threads per block of k_chain in the single-sync merge (64, 128 or 256: the kernel has no block-level state; smaller blocks spread the waves more evenly over the CUs)
 	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
 	int b2_split = 4;        // splitter spacing 2^S of the batch's own LF walk (walkers for the BWT-only entry point); 0: SA-regular walkers (staged path)
 	int log_alloc = 0;       // print every device allocation and the time it took
@@ -357,6 +358,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "lpw")) t.lpw = v == 4 ? 4 : 8;
 	else if (!strcmp(key, "blkmul")) t.blkmul = v < 1 ? 1 : (int)v;
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
+	else if (!strcmp(key, "chain_bs")) t.chain_bs = v == 64 ? 64 : v == 128 ? 128 : 256;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
 	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? 0 : v > 12 ? 12 : (int)v;
 	else if (!strcmp(key, "log_alloc")) t.log_alloc = v != 0;
@@ -392,7 +394,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -1276,7 +1278,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #ifdef RB3_PROF
 		fprintf(stderr, "[prof] launching %lld blocks x 256 threads, %d octets per wave, %lld walkers\n", (long long)nblk, octs, (long long)n_walkers);
 #endif
-		const dim3 grid((unsigned)nblk), blk(256);
+		const dim3 grid((unsigned)(nblk * (256 / h->tn.chain_bs))), blk((unsigned)h->tn.chain_bs);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk)

@@ -220,7 +220,14 @@ def load_batches(files, pinned=True, step=WALKER_STEP):
             keep.append(pa)
             t = pa.array
         texts.append(t)
-        walkers.append((host.walkers_text(t, step), host.strand_pairs(t, n_seq)))   # (+ where the records start: the CLI's sorter thread finds them the same way)
+        w = host.walkers_text(t, step)
+        if pinned:  # the list goes to the device inside the merge call: from page-locked memory that is one DMA, no staging copy on the host
+            pw = PinnedArray(w.nbytes)
+            wv = pw.array.view(np.int64).reshape(w.shape)
+            wv[:] = w
+            keep.append(pw)
+            w = wv
+        walkers.append((w, host.strand_pairs(t, n_seq)))   # (+ where the records start: the CLI's sorter thread finds them the same way)
     return texts, walkers, keep
 
 

@@ -70,6 +70,8 @@ typedef struct {
 	int64_t n_reb_again;         /* rebuilds done twice because a buffer sized by an estimate did not take the result */
 	int64_t bytes_rebuild;       /* algorithmic bytes of the rebuilds: per merge 9 B x rows + old block array + new block array */
 	int64_t n_thinned;           /* merges done again with fewer, longer walkers because the table of tentative stretches was full */
+	int64_t tent_mask_bits;      /* width of the drop-out masks the last single-sync merge settled its tentative records with: 256, or 512 / 1024 /
+	                                2048 once walkers have met intervals of more matching suffixes than that (an index of > 255 relatives) */
 } rb3gpu_stats_t;
 
 void rb3gpu_opt_init(rb3gpu_opt_t *opt);

@@ -263,11 +263,35 @@ typedef struct {
 	int64_t n_seq, len, n_walkers, step;
 	uint8_t *bwt;             /* host: the BWT, or the text if raw */
 	rb3h_walker_t *walkers;
+	int walkers_pinned;       /* the list lives in a buffer of the page-locked pool (pin_release, not free) */
 	int ret, raw;             /* raw: not sorted yet, the consumer's GPU handle sorts it */
 	void *d_bwt;              /* device: the BWT from a sorter thread's own GPU sorter (gs), to be released after the merge */
 	void *d_tw;               /* device: its text-order words (long strings: the walkers are then given by text position) */
 	rb3gpu_sorter_t *gs;
 } batch_t;
+
+static int g_pin_on = 0; /* batch buffers (and walker lists) in page-locked memory */
+
+/* The walker list goes to the device inside the merge call, between the LF kernels and the walkers: out of page-locked memory
+ * that is one DMA; out of malloc'd memory the engine first copies it into its staging buffer while the device waits. */
+static void walkers_pin(batch_t *b)
+{
+	int64_t cap = 0;
+	const int64_t bytes = b->n_walkers * (int64_t)sizeof(rb3h_walker_t);
+	void *p;
+	if (!g_pin_on || b->walkers == 0 || b->walkers_pinned || bytes <= 0 || bytes > (16 << 20)) return;
+	if ((p = pin_alloc(bytes, &cap)) == 0) return;
+	memcpy(p, b->walkers, (size_t)bytes);
+	free(b->walkers);
+	b->walkers = (rb3h_walker_t*)p, b->walkers_pinned = 1;
+}
+
+static void walkers_free(batch_t *b)
+{
+	if (b->walkers_pinned) pin_release(b->walkers);
+	else free(b->walkers);
+	b->walkers = 0, b->walkers_pinned = 0;
+}
 
 /* --gpu-sort: the batch arrives as text; suffix sorting, BWT and inverse suffix array on the GPU
  * (rb3gpu_sort_text / rb3gpu_bwt_from_text instead of rb3_build_sais, build.c:220), the BWT never leaves HBM */
@@ -394,6 +418,7 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 				if (rb3h_verbose >= 3)
 					fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 				if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0, b->d_tw = 0;
+				walkers_pin(b);
 				b->gs = gs, b->raw = 0;
 				__sync_fetch_and_add(&g_sorted.n_gpu, 1), __sync_fetch_and_add(&g_sorted.sym_gpu, b->len);
 				rb3h_batch_free(b->bwt); b->bwt = 0; /* the text is not needed any more */
@@ -474,7 +499,7 @@ static int consume(consumer_t *c, batch_t *b, int end_of_file)
 {
 	if (b) {
 		int r = process_batch(c->h, b, &c->has_index);
-		rb3h_batch_free(b->bwt); free(b->walkers); free(b);
+		rb3h_batch_free(b->bwt); walkers_free(b); free(b);
 		if (r < 0) return r;
 	}
 	if (end_of_file && c->fn_tmp && c->has_index) { /* build.c:232-238 */
@@ -719,7 +744,7 @@ int main_build(int argc, char *argv[])
 		return 1;
 	}
 
-	if (!getenv("RB3_NO_PINNED")) rb3h_seq_set_batch_allocator(pin_alloc, pin_release); /* batch buffers in page-locked memory (one DMA per batch) */
+	if (!getenv("RB3_NO_PINNED")) g_pin_on = 1, rb3h_seq_set_batch_allocator(pin_alloc, pin_release); /* batch buffers in page-locked memory (one DMA per batch) */
 
 	if (fn_in) { /* build.c:172-184 */
 		const int r = load_index(h, fn_in);
@@ -830,6 +855,8 @@ int main_build(int argc, char *argv[])
 				st.ms_build, (long)st.bytes_rebuild, st.ms_build > 0 ? st.bytes_rebuild / st.ms_build / 1e6 : 0.0, st.ms_chain, (long)st.n_rank_launches, (long)st.n_lf_steps);
 		fprintf(stderr, "[M::%s] run-space rebuild: %ld groups, %ld of them handed on to the window kernels; %ld merges redone without tentative records, %ld needed the long settle pass; %ld rows LF-checked; %.1f ms in %ld device allocations\n", __func__,
 				(long)st.n_reb_groups, (long)st.n_reb_groups_window, (long)st.n_fallbacks, (long)st.n_long_settles, (long)st.n_lf_checked, st.ms_alloc, (long)st.n_allocs);
+		if (st.tent_mask_bits > 256)
+			fprintf(stderr, "[M::%s] tentative records: drop-out masks of %ld bits (walkers met intervals of more than %ld matching suffixes)\n", __func__, (long)st.tent_mask_bits, (long)st.tent_mask_bits / 2 - 1);
 		fprintf(stderr, "[M::%s] device memory of the index handle: peak %.1f MB, index %.1f MB\n", __func__, st.bytes_peak / 1e6, st.bytes_index / 1e6);
 		fprintf(stderr, "[M::%s] batches: %ld (%ld symbols) suffix-sorted on the GPU, %ld (%ld symbols) on the host; -m %ld%s\n", __func__,
 				(long)g_sorted.n_gpu, (long)g_sorted.sym_gpu, (long)g_sorted.n_host, (long)g_sorted.sym_host, (long)opt.batch_size,

@@ -104,6 +104,8 @@ struct Tune {
 	int lpw = 8;             // lanes per walker of k_chain in the single-sync merge: 8 (an octet) or 4 (a quad, 16 walkers per wave; builds with -DRB3_WITH_QUADS only)
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
+	int tent_q = 0;          // width of the drop-out masks of the tentative stretches in units of 256 bits: 1, 2, 4, 8; 0: follows what the walkers report
+	int copy_walkers = 0;    // a walker list in page-locked memory is copied to the device all the same (instead of being read in place)
 	int chain_bs = 256;      // threads per block of k_chain in the single-sync merge (64, 128 or 256: the kernel has no block-level state; smaller blocks spread the waves more evenly over the CUs)
 	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
 	int b2_split = 4;        // splitter spacing 2^S of the batch's own LF walk (walkers for the BWT-only entry point); 0: SA-regular walkers (staged path)
@@ -143,7 +145,7 @@ struct rb3gpu_s {
 	// (behind the grp_cap directory entries of a buffer sit grp_cap 8-byte words: the compact copy of the entries' slot words, IdxView.gsm)
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, wstat, wplane, wruns, gslots, glist;
+	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -158,6 +160,7 @@ struct rb3gpu_s {
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
 	rb3sort_ws *sorter = nullptr;           // scratch of rb3gpu_bwt_from_text, created on first use
+	int tent_q = 1;          // masks of 256 * tent_q bits (merge_core doubles it when walkers report intervals wider than that)
 	int64_t sid_dirty[2] = {RB3_TENT_HALF, RB3_TENT_HALF}; // entries of the two halves of the stretch tables (dl) that may be non-zero
 };
 
@@ -302,6 +305,42 @@ static void tent_used(rb3gpu_t *h, unsigned long long sidctr) // the two 32-bit 
 	h->sid_dirty[1] = b < (unsigned long long)RB3_TENT_HALF ? (int64_t)b : RB3_TENT_HALF;
 }
 
+/* masks of 256 q bits for the stretches of the lower half of the table (q > 1: more than 255 matching suffixes per interval) */
+static int tent_masks(rb3gpu_t *h, int q, uint32_t **mx)
+{
+	*mx = nullptr;
+	if (q <= 1) return 0;
+	int r;
+	if ((r = buf_ensure(h, h->dlx, (size_t)RB3_TENT_HALF * 32 * (size_t)q)) < 0) return r;
+	*mx = (uint32_t*)h->dlx.p;
+	return 0;
+}
+
+/* the settle kernels behind k_chain: the rows that dropped at every event, per walker the cumulative mask, the paths over first
+ * stretches (up to maxhops hops), all other stretches */
+static void launch_settle(rb3gpu_t *h, const IdxView &iv, rb3_stretch_t *tab, uint32_t *mx, const uint32_t *sidctr, int32_t *sfin, unsigned long long *bad, int maxhops, int q)
+{
+#define RB3_SETTLE_X(Q) do { \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_events_x<Q>), dim3(2048), dim3(256), 0, h->st, iv, (const rb3_stretch_t*)tab, mx, sidctr); \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cum_x<Q>), dim3(4096), dim3(64), 0, h->st, tab, mx, sidctr); \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_resolve_w_x<Q>), dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)mx, sidctr, sfin, bad, maxhops); \
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sfin_x<Q>), dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)mx, sidctr, sfin); \
+	} while (0)
+	if (q >= 8 && mx) RB3_SETTLE_X(8);
+	else if (q >= 4 && mx) RB3_SETTLE_X(4);
+	else if (q >= 2 && mx) RB3_SETTLE_X(2);
+	else {
+		hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, sidctr);
+		if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, sidctr, sfin);
+		else {
+			hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, sidctr);
+			hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, sidctr, sfin, bad, maxhops);
+			hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, sidctr, sfin);
+		}
+	}
+#undef RB3_SETTLE_X
+}
+
 #define RB3_GRP_ALLOC (sizeof(rb3_grp_t) + 8) /* bytes per directory entry of an index buffer: the entry + its word of the compact copy */
 
 static IdxView view_of(const rb3gpu_t *h)
@@ -359,6 +398,8 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "blkmul")) t.blkmul = v < 1 ? 1 : (int)v;
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
 	else if (!strcmp(key, "chain_bs")) t.chain_bs = v == 64 ? 64 : v == 128 ? 128 : 256;
+	else if (!strcmp(key, "copy_walkers")) t.copy_walkers = v != 0;
+	else if (!strcmp(key, "tent_q")) t.tent_q = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : v >= 1 ? 1 : 0;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
 	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? 0 : v > 12 ? 12 : (int)v;
 	else if (!strcmp(key, "log_alloc")) t.log_alloc = v != 0;
@@ -394,7 +435,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -476,14 +517,14 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exac
 static void guard_check(rb3gpu_t *h, const char *where)
 {
 	if (!h->tn.guard) return;
-	static const char *names[] = { "b2", "pos", "tcnt", "tpre", "ctot", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "wstat", "wplane", "wruns", "gslots", "glist" };
-	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	static const char *names[] = { "b2", "pos", "tcnt", "tpre", "ctot", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
+	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	uint8_t g[RB3_GUARD];
-	for (int i = 0; i < 17 + 4; ++i) {
+	for (int i = 0; i < 18 + 4; ++i) {
 		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
-		if (i < 17) p = (const uint8_t*)all[i]->p, cap = all[i]->cap, name = names[i];
-		else if (i < 19) p = (const uint8_t*)h->ib[i - 17].grp, cap = h->ib[i - 17].grp_cap * RB3_GRP_ALLOC, name = "index directory";
-		else p = (const uint8_t*)h->ib[i - 19].slots, cap = h->ib[i - 19].slots_cap * sizeof(rb3_slot_t), name = "index slots";
+		if (i < 18) p = (const uint8_t*)all[i]->p, cap = all[i]->cap, name = names[i];
+		else if (i < 20) p = (const uint8_t*)h->ib[i - 18].grp, cap = h->ib[i - 18].grp_cap * RB3_GRP_ALLOC, name = "index directory";
+		else p = (const uint8_t*)h->ib[i - 20].slots, cap = h->ib[i - 20].slots_cap * sizeof(rb3_slot_t), name = "index slots";
 		if (!p) continue;
 		if (cap == 0) cap = 256;
 		if (hipMemcpy(g, p + cap, RB3_GUARD, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -517,7 +558,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -559,6 +600,7 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
 #define MISC_RG_LISTS 14
 #define MISC_LF_CHK   6    /* [6] rows whose LF relation was verified, [7] rows that failed it */
 #define MISC_B2_MODE  15   /* what the device-made walker list is (k_b2_mode) */
+#define MISC_WIDE     39   /* k_chain: steps of walkers that could not record tentatively because their interval is wider than the masks */
 #define MISC_RG_OVER  32   /* set by k_decide<LISTED>: the hand-over list of the run-space rebuild is longer than the window scratch */
 
 /* build a block array for ntot symbols into ib[1-cur]; FROM_PLAIN: symbols are d_b2[0..ntot);
@@ -946,13 +988,7 @@ static int mg_walk_impl(rb3gpu_t *h, int64_t n_walkers, const rb3gpu_walker_t *w
 #undef RB3_LAUNCH_CHAIN
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
-			hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, (const uint32_t*)sidctr);
-			if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
-			else {
-				hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr);
-				hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin, qhead + 2, (int)RB3_TENT_IDS); // (no second chance on this path: follow every path to its end)
-				hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin);
-			}
+			launch_settle(h, iv, tab, nullptr, (const uint32_t*)sidctr, sfin, qhead + 2, (int)RB3_TENT_IDS, 1); // (no second chance on this path: follow every path to its end)
 			hipLaunchKernelGGL(k_pos_finalize, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, h->mg_pos, len, (const int32_t*)sfin, qhead + 2);
 		}
 	}
@@ -1198,6 +1234,11 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	FillJobs jb;
 	memset(&jb, 0, sizeof(jb));
 	if (tent && (r = tent_prepare(h, &tab, &sfin, &jb)) < 0) return r;
+	// width of the drop-out masks: 256 bits inside the stretch records, or 512 / 1024 / 2048 in an array of their own once the
+	// walkers of an earlier merge have met intervals wider than the masks (see below); if that array cannot be had, 256 it is
+	int tq = !tent ? 1 : h->tn.tent_q > 0 ? h->tn.tent_q : h->tent_q;
+	uint32_t *mx = nullptr;
+	if (tq > 1 && tent_masks(h, tq, &mx) < 0) tq = 1, mx = nullptr;
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, slot_estimate(h, len, ntot))) < 0) return r;
 	const bool rows_fused = !rank_only && use_winpar(h, nwin);
 	if (rows_fused && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
@@ -1209,7 +1250,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	// one launch clears what this merge accumulates into: the counters (the scan totals behind them are written later), the
 	// stretches the merge before opened, the rows-per-window table of the rebuild, and -- text-order walk -- the row records
 	fill_add(&jb, misc, 128, 0u);
-	fill_add(&jb, misc + MISC_RG_OVER, 16, 0u);
+	fill_add(&jb, misc + MISC_RG_OVER, 64, 0u); // (... MISC_WIDE)
 	if (rows_fused) fill_add(&jb, h->jg.p, (size_t)(nwin + 1) * 8, 0u); // defined even if pos[] turns out invalid
 	const bool rows_filled = d_tw != nullptr && jb.n < 8;
 	if (rows_filled) fill_add(&jb, h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
@@ -1254,13 +1295,20 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		// The list goes over the side stream, beside the LF kernels queued above (on the main stream its DMA sat between them and
 		// the walkers: ~45 us per merge with the chip idle); the host copies it into pinned memory while those kernels run.
 		const void *src = walkers;
-		if (!is_pinned(walkers, wb) && h->stage[0] && wb <= RB3_STAGE_BYTES) {
-			memcpy(h->stage[0], walkers, wb); // safe to reuse: every earlier copy out of it was synchronised
-			src = h->stage[0];
+		if (is_pinned(walkers, wb) && !h->tn.copy_walkers) {
+			// A list in page-locked memory (rb3gpu_pinned_alloc) is read where it lies: every entry is fetched once, by the octet
+			// that takes the walker (~2 us over PCIe, once or twice per wave), and the ~40 us the walkers waited for the copy engine
+			// to deliver the list -- with the chip idle -- are gone.
+			dwl = (Walker*)walkers;
+		} else {
+			if (!is_pinned(walkers, wb) && h->stage[0] && wb <= RB3_STAGE_BYTES) {
+				memcpy(h->stage[0], walkers, wb); // safe to reuse: every earlier copy out of it was synchronised
+				src = h->stage[0];
+			}
+			HIPCHK(hipMemcpyAsync(dwl, src, wb, hipMemcpyHostToDevice, h->st2));
+			HIPCHK(hipEventRecord(h->evx[1], h->st2));
+			HIPCHK(hipStreamWaitEvent(h->st, h->evx[1], 0));
 		}
-		HIPCHK(hipMemcpyAsync(dwl, src, wb, hipMemcpyHostToDevice, h->st2));
-		HIPCHK(hipEventRecord(h->evx[1], h->st2));
-		HIPCHK(hipStreamWaitEvent(h->st, h->evx[1], 0));
 	}
 	int64_t *dpos = (int64_t*)h->pos.p;
 	{
@@ -1281,7 +1329,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		const dim3 grid((unsigned)(nblk * (256 / h->tn.chain_bs))), blk((unsigned)h->tn.chain_bs);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1)
 #ifdef RB3_WITH_QUADS /* a quad per walker (k_chain<..., 4>) was measured slower in every regime: compiled in on request only */
 #define RB3_LAUNCH_FAST(D, T, X) do { if (lpw == 4) RB3_LAUNCH_FAST1(D, T, X, 4); else RB3_LAUNCH_FAST1(D, T, X, 8); } while (0)
 #else
@@ -1309,15 +1357,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #undef RB3_LAUNCH_FAST
 #undef RB3_LAUNCH_FAST1
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
-		if (tent) {
-			hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, (const uint32_t*)sidctr);
-			if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin);
-			else {
-				hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr);
-				hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS);
-				hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin);
-			}
-		}
+		if (tent) launch_settle(h, iv, tab, mx, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS, tq), h->stt.tent_mask_bits = 256 * tq;
 		if (rows_fused) { // validation and the rows-per-window table of the rebuild in one pass over pos[]
 			const dim3 g1((unsigned)((len + 1 + 255) / 256));
 			if (tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
@@ -1382,6 +1422,14 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
 	if (tent) {
 		tent_used(h, hm[5]);
+		// Walkers that were old enough to record tentatively but sat on an interval wider than the masks (more relatives in the index
+		// than mask bits) walked without recording: where that was more than a few percent of all steps the next merges use masks of
+		// twice the width (the index only gains relatives).  Nothing is redone: this merge is complete, only slower than it could be.
+		if (h->tn.tent_q == 0 && tq < RB3_TENT_QMAX && hm[MISC_WIDE] * 32 > hm[1] && h->tent_q <= tq) {
+			h->tent_q = tq * 2;
+			if (h->opt.verbose >= 3) fprintf(stderr, "[M::rb3gpu] %.1f %% of the LF steps were walked by walkers whose interval is wider than %d rows; the next merges track up to %d\n",
+					100.0 * (double)hm[MISC_WIDE] / (double)(hm[1] ? hm[1] : 1), 256 * tq - 1, 512 * tq - 1);
+		}
 #ifdef RB3GPU_TEST_HOOKS
 		if (h->tn.force_fallback) hm[4] = 1; // test hook: exercise the redo path
 #endif
@@ -1394,16 +1442,33 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		// Second chance: dependency paths longer than k_resolve_w follows (a string that repeats indexed text).  Nothing was installed
 		// and the unsettled records are still in pos[]: settle them by pointer jumping over the walkers, then validate and rebuild again.
 		const int64_t na = h->sid_dirty[0], nb = h->sid_dirty[1], nblk = (na + RB3_TENT_BLOCK - 1) / RB3_TENT_BLOCK, nn = nblk + nb;
-		if (nn > 0 && (r = buf_ensure(h, h->xbuf, (size_t)nn * 2 * sizeof(WjNode))) < 0) return r;
+		const size_t wj_bytes = tq > 1 ? 32 * (size_t)tq + 16 : sizeof(WjNode);
+		if (nn > 0 && (r = buf_ensure(h, h->xbuf, (size_t)nn * 2 * wj_bytes)) < 0) return r;
 		if (nn > 0) {
-			WjNode *nd[2] = { (WjNode*)h->xbuf.p, (WjNode*)h->xbuf.p + nn };
 			HIPCHK(hipEventRecord(h->ev[4], h->st));
-			hipLaunchKernelGGL(k_wj_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const int32_t*)sfin, nblk, nb, nd[0]);
+			const dim3 gj((unsigned)((nn + 255) / 256)), bj(256);
+#define RB3_WJ_X(Q) do { \
+				WjNodeX<Q> *nd[2] = { (WjNodeX<Q>*)h->xbuf.p, (WjNodeX<Q>*)h->xbuf.p + nn }; \
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wj_init_x<Q>), gj, bj, 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)mx, (const int32_t*)sfin, nblk, nb, nd[0]); \
+				int cur = 0; \
+				for (int64_t reach = 1; reach <= nn; reach <<= 1, cur ^= 1) \
+					hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wj_round_x<Q>), gj, bj, 0, h->st, nn, (const WjNodeX<Q>*)nd[cur], nd[cur ^ 1]); \
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wj_apply_x<Q>), gj, bj, 0, h->st, nblk, nb, (const WjNodeX<Q>*)nd[cur], sfin); \
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sfin_x<Q>), dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)mx, (const uint32_t*)sidctr, sfin); \
+			} while (0)
+			if (tq >= 8) RB3_WJ_X(8);
+			else if (tq >= 4) RB3_WJ_X(4);
+			else if (tq >= 2) RB3_WJ_X(2);
+			else {
+			WjNode *nd[2] = { (WjNode*)h->xbuf.p, (WjNode*)h->xbuf.p + nn };
+			hipLaunchKernelGGL(k_wj_init, gj, bj, 0, h->st, (const rb3_stretch_t*)tab, (const int32_t*)sfin, nblk, nb, nd[0]);
 			int cur = 0;
 			for (int64_t reach = 1; reach <= nn; reach <<= 1, cur ^= 1)
-				hipLaunchKernelGGL(k_wj_round, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->st, nn, (const WjNode*)nd[cur], nd[cur ^ 1]);
-			hipLaunchKernelGGL(k_wj_apply, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->st, nblk, nb, (const WjNode*)nd[cur], sfin);
+				hipLaunchKernelGGL(k_wj_round, gj, bj, 0, h->st, nn, (const WjNode*)nd[cur], nd[cur ^ 1]);
+			hipLaunchKernelGGL(k_wj_apply, gj, bj, 0, h->st, nblk, nb, (const WjNode*)nd[cur], sfin);
 			hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin);
+			}
+#undef RB3_WJ_X
 			HIPCHK(hipMemsetAsync(misc + 2, 0, 24, h->st));
 			if (rows_fused) {
 				HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st));

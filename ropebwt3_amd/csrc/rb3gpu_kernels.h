@@ -766,7 +766,9 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 #define RB3_TENT_MASK ((1LL << RB3_TENT_PBITS) - 1)
 #define RB3_TENT_IDS  (1 << 24)       /* stretch ids per merge */
 #define RB3_TENT_POISON (RB3_TENT_IDS - 1) /* the id of records whose stretch could not be allocated: never settled */
-#define RB3_TENT_KMAX 255             /* widest interval that is tracked tentatively */
+#define RB3_TENT_KMAX 255             /* widest interval that is tracked tentatively with the masks inside the stretch records (256 bits) */
+#define RB3_TENT_QMAX 8               /* ... and with masks of 256 Q bits in an array of their own, Q = 2, 4, 8 (more than 255 relatives: below) */
+#define RB3_TENT_KMAX_TOP (256 * RB3_TENT_QMAX - 1)
 #ifndef RB3_TENT_MIN_AGE
 #define RB3_TENT_MIN_AGE 32u      /* walker lists (segments of a guaranteed length) */
 #endif
@@ -776,7 +778,7 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
  * stretch (k_resolve).  w0, w1: how the unknown of the stretch follows from another one.
  *   w0 = type << 62 | previous stretch << 38 | lo (EVENT only)
  *   EVENT: some rows of the previous stretch's interval [lo, lo + kk) do not hold c and dropped out;
- *          w1 = kk | c << 8.  k_events turns that into the 256-bit mask of the dropped
+ *          w1 = kk | c << 16.  k_events turns that into the 256-bit mask of the dropped
  *          rows (the walker itself only notes the event: three stores, no loads), and
  *          d = d(prev) - #{dropped rows with index < d(prev)}
  *   LINK:  d = d(prev) + (int32)w1
@@ -809,6 +811,7 @@ template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t 
  * OR them into the octet's 256-bit mask D[8] (LDS; bit i <=> row lo + i).  Index i sits at slot offset
  * off0 + i (off0 may be negative: the rows before the slot are somebody else's).  Called for the slot of
  * lo and for the slot of hi, which together hold all of [lo, hi) when hi - lo < 256. */
+template<int NW = 8>
 __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, int off0, int kk, int c, int j, uint32_t *D)
 {
 	if (!(hdr0 & RB3_SLOT_RLE)) { // bit planes: this lane holds slot offsets [32j, 32j + 32)
@@ -820,8 +823,8 @@ __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, 
 			nm &= (t1 >= 32 ? 0xFFFFFFFFu : (1u << t1) - 1u) & ~((1u << t0) - 1u);
 			if (nm) {
 				const int wi = ib >> 5, sh = ib & 31; // arithmetic shift: wi may be -1
-				if (wi >= 0 && wi < 8 && (nm << sh)) atomicOr(&D[wi], nm << sh);
-				if (sh && wi + 1 >= 0 && wi + 1 < 8 && (nm >> (32 - sh))) atomicOr(&D[wi + 1], nm >> (32 - sh));
+				if (wi >= 0 && wi < NW && (nm << sh)) atomicOr(&D[wi], nm << sh);
+				if (sh && wi + 1 >= 0 && wi + 1 < NW && (nm >> (32 - sh))) atomicOr(&D[wi + 1], nm >> (32 - sh));
 			}
 		}
 	} else { // six run codes per lane (rolled loops: this is a cold path and must stay light on registers)
@@ -840,7 +843,7 @@ __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, 
 				int a = pos - off0, b = pos + len - off0; // index range of this run
 				a = a < 0 ? 0 : a, b = b > kk ? kk : b;
 #pragma unroll 1
-				for (int w = a >> 5; a < b && w <= (b - 1) >> 5; ++w) {
+				for (int w = a >> 5; a < b && w <= (b - 1) >> 5 && w < NW; ++w) {
 					const int x0 = a > w * 32 ? a - w * 32 : 0, x1 = b < w * 32 + 32 ? b - w * 32 : 32;
 					atomicOr(&D[w], (x1 >= 32 ? 0xFFFFFFFFu : (1u << x1) - 1u) & ~((1u << x0) - 1u));
 				}
@@ -863,7 +866,7 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 		if (w0 >> 62 != RB3_DEP_EVENT) continue;
 		const uint64_t w1 = tab[sid].w1;
 		const int64_t lo = (int64_t)(w0 & (uint64_t)RB3_TENT_MASK);
-		const int kk = (int)(w1 & 0xFF), c = (int)(w1 >> 8 & 7);
+		const int kk = (int)(w1 & 0xFFFF), c = (int)(w1 >> 16 & 7);
 		D[j] = 0u;
 		__builtin_amdgcn_wave_barrier();
 		// the slots of lo and of lo + kk: both directory words first, then the slot(s) -- the interval usually lies in ONE slot,
@@ -909,7 +912,7 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr)
+		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX)
 {
 	const int64_t nwalk = nwalk_dev ? (int64_t)*nwalk_dev : nwalk_arg; // (a list made on the device: its length never went to the host)
 	static_assert(LIST || !TEXT, "text-order words need a walker list");
@@ -937,6 +940,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	uint64_t blk8 = 0;      // TEXT: the words this octet fetches during the current window of 8 iterations (lane j: at iteration phase j),
 	                        // loaded with one 64-byte request per octet and window, whatever the L1 does with the lines
 	uint32_t steps = 0;
+	uint32_t nwide = 0;     // steps of walkers old enough to record tentatively whose interval is wider than the masks take
 	// Records are written through to memory (agent scope) so that walkers on other XCDs can see them.
 	// Each octet parks up to 8 records in its lanes (lane it&7 takes iteration it) and the whole wave
 	// flushes them with ONE store instruction every 8 iterations.
@@ -1015,11 +1019,11 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				// state the whole wave takes the general step, which handles everything.
 				const uint32_t cq = (uint32_t)x & 7u;
 				const uint64_t kq = (uint64_t)(hi - lo);
-				const bool opening = gap != 0 && sid == -1 && age >= RB3_TENT_MIN_AGE && kq <= (uint64_t)RB3_TENT_KMAX;
+				const bool opening = gap != 0 && sid == -1 && age >= RB3_TENT_MIN_AGE && kq <= (uint64_t)kmax;
 				const uint32_t kq32 = kq > 0xFFFFull ? 0xFFFFu : (uint32_t)kq;
 				// (an interval that reaches into the next GROUP needs a second directory entry: the general step)
 				const bool simple = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) && cq != 0u && (int64_t)rc < 0 && !opening && ((uint32_t)lo & (RB3_GRP - 1)) + kq32 <= (uint32_t)RB3_GRP
-					&& kq32 <= (uint32_t)RB3_TENT_KMAX; // (a wider interval -- a walker in its first dozen steps -- may end several slots further on)
+					&& kq32 <= (uint32_t)kmax; // (a wider interval -- a walker in its first dozen steps -- may end several slots further on)
 				if (__all(simple)) {
 #ifdef RB3_PROF_STEP /* kernel experiment: where does an iteration of the common step spend its cycles?  (s_memtime at four points) */
 					const uint64_t pt0 = __builtin_amdgcn_s_memtime();
@@ -1049,6 +1053,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 					const bool rle = wend - w0 > 1u;
 					const int off_lo = (int)(rl.koff - (w0 << RB3_WIN_BITS)), off_hi = off_lo + (int)kq32;
 					const bool same = rl.koff + kq32 <= (wend << RB3_WIN_BITS);
+					const bool far = !same && kq32 > 255u; // (wide masks: an interval of more than 255 rows may end beyond the NEXT slot too: the general decode)
 					octc_load_slot<8>(b1, (int64_t)rl.sidx, j, rl);
 					uint4 slb = make_uint4(0u, 0u, 0u, 0u);
 					if (!same) slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + j]; // the upper end lies in the next slot: asked for at the same time
@@ -1077,7 +1082,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 					if (__ballot(!(rle && rleb)) != 0ull) prof_t[6] += 1;
 #endif
 					if (__all(rle && same)) octc_finish_pair_at(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
-					else if (__all(rle && rleb)) { // some walker's interval straddles two run slots: everybody through the two-slot decode
+					else if (__all(rle && rleb && !far)) { // some walker's interval straddles two run slots: everybody through the two-slot decode
 						uint32_t ca, cb;
 						slice_count_pk2(rl.sl, slb, off_lo, same ? off_hi : off_hi - (int)((wend - w0) << RB3_WIN_BITS), c, j, &ca, &cb);
 						uint32_t v = (ca + (j == c + 1 ? rl.sl.x : 0u)) | (cb + (j == c + 1 ? slb.x : 0u)) << 16;
@@ -1100,13 +1105,14 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 						int ns = sid + 1;
 						if (sid == RB3_TENT_POISON) ns = RB3_TENT_POISON;
 						else if ((ns & (RB3_TENT_BLOCK - 1)) == 0) {
+							// (asking for the next block half a block ahead, so that nobody waits for the atomic: measured 5 % SLOWER)
 							uint32_t s0 = 0;
 							if (j == 0) s0 = atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
 							s0 = oct_bcast0(s0, j);
 							ns = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 						}
 						if (j == 0 && ns != RB3_TENT_POISON) {
-							tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = kq | (uint64_t)c << 8;
+							tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = kq | (uint64_t)c << 16;
 							tab[ns].pad[0] = (uint32_t)sid0 + 1u;
 							tab[sid].child = ns + 1;
 						}
@@ -1151,7 +1157,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			const int64_t tpn = tp > 0 ? tp - 1 : 0;
 			const bool wide = TENT ? gap == 2 : gap != 0;
 			// may this walker record tentatively?  (an interval of at most KMAX rows, and old enough)
-			const bool tentok = TENT && gap != 0 && age >= (LIST ? RB3_TENT_MIN_AGE : RB3_TENT_MIN_AGE_AUTO) && hi - lo <= RB3_TENT_KMAX && sid != -2;
+			const bool tentok = TENT && gap != 0 && age >= (LIST ? RB3_TENT_MIN_AGE : RB3_TENT_MIN_AGE_AUTO) && hi - lo <= kmax && sid != -2;
+			if (TENT && LIST) nwide += (gap == 2 && sid == -1 && age >= RB3_TENT_MIN_AGE && hi - lo > kmax && hi - lo <= RB3_TENT_KMAX_TOP) ? 1u : 0u;
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE, LPW>(b1, lo, c, j, rl);
 			if (wide) octc_issue_grp<DENSE, LPW>(b1, hi, c, j, rh);
@@ -1238,7 +1245,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 					ns = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 				}
 				if (j == 0 && ns != RB3_TENT_POISON) {
-					tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = (uint64_t)(hi - lo) | (uint64_t)c << 8;
+					tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = (uint64_t)(hi - lo) | (uint64_t)c << 16;
 					tab[ns].pad[0] = (uint32_t)sid0 + 1u; // (same 64-byte record: the store rides along)
 					tab[sid].child = ns + 1;
 				}
@@ -1257,6 +1264,7 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 		} while (__all(active));
 	}
 	if (j == 0) atomicAdd(nsteps, (unsigned long long)steps);
+	if (TENT && LIST && j == 0 && nwide) atomicAdd(nsteps + 38, (unsigned long long)nwide); // misc[39] (MISC_WIDE): see merge_core (the width of the masks follows it)
 #ifdef RB3_PROF_STEP
 	if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(nsteps + 33 + q, (unsigned long long)prof_t[q]); // misc[34..38]
 	if (lane == 0) atomicAdd(nsteps + 8, (unsigned long long)prof_t[5]), atomicAdd(nsteps + 9, (unsigned long long)prof_t[6]); // misc[9], misc[10]
@@ -1576,6 +1584,299 @@ __global__ void __launch_bounds__(256) k_sfin(const rb3_stretch_t *tab, const ui
 	}
 }
 
+/* ---- more than 255 matching suffixes per interval: masks of 256 Q bits, Q = 2, 4, 8 -------------------------------------
+ * An index that holds K > 255 copies of a sequence gives a walker in the middle of it an interval of K rows, and with masks of
+ * 256 bits such a walker cannot record anything until enough relatives have dropped out -- which, at one private variant per
+ * ~1000 symbols, takes longer than its segment: the merge degrades towards one chain per string (7-13 ms per round at 400
+ * relatives instead of 1.5).  The same settle with wider masks: they live in an array of their own (mx[sid * 8Q + w], ids of
+ * the lower half of the table only: events and first stretches), the 64-byte records keep everything else, and the kernels
+ * below are the ones above with loops over the words (word w of a mask belongs to lane w & 7 of the octet).  The host picks Q
+ * from what the walkers report (k_chain counts the steps of walkers that were old enough but too wide) and starts with 1:
+ * nothing changes for an index of up to 255 relatives. */
+
+template<int Q>
+__global__ void __launch_bounds__(256) k_events_x(IdxView ix, const rb3_stretch_t *tab, uint32_t *mx, const uint32_t *sidctr)
+{
+	constexpr int NW = 8 * Q;
+	__shared__ uint32_t dmask[32][NW];
+	const int j = threadIdx.x & 7;
+	uint32_t *D = dmask[threadIdx.x >> 3];
+	const int64_t n = *sidctr < (uint32_t)RB3_TENT_HALF ? *sidctr : RB3_TENT_HALF;
+	for (int64_t sid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; sid < n; sid += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+		const uint64_t w0 = tab[sid].w0;
+		if (w0 >> 62 != RB3_DEP_EVENT) continue;
+		const uint64_t w1 = tab[sid].w1;
+		const int64_t lo = (int64_t)(w0 & (uint64_t)RB3_TENT_MASK);
+		const int kk = (int)(w1 & 0xFFFF), c = (int)(w1 >> 16 & 7);
+#pragma unroll
+		for (int q = 0; q < Q; ++q) D[q * 8 + j] = 0u;
+		__builtin_amdgcn_wave_barrier();
+		// the rows [lo, lo + kk) lie in the slots of lo .. lo + kk - 1: consecutive slots, of one group or two
+		const int64_t last = lo + (kk > 0 ? kk - 1 : 0) < ix.n ? lo + (kk > 0 ? kk - 1 : 0) : lo;
+		const int64_t g0 = lo >> RB3_GRP_BITS, g1 = last >> RB3_GRP_BITS;
+		const uint32_t koff0 = (uint32_t)lo & (RB3_GRP - 1), koff1 = (uint32_t)last & (RB3_GRP - 1);
+		const uint64_t sm0 = ix.grp64[g0 * 8 + 6], sm1 = ix.grp64[g1 * 8 + 6];
+		const int64_t s0 = (int64_t)((uint32_t)sm0 + __popc((uint32_t)(sm0 >> 32) & ((2u << (koff0 >> RB3_WIN_BITS)) - 1u)) - 1u);
+		const int64_t s1 = (int64_t)((uint32_t)sm1 + __popc((uint32_t)(sm1 >> 32) & ((2u << (koff1 >> RB3_WIN_BITS)) - 1u)) - 1u);
+		const int64_t first1 = (int64_t)(uint32_t)sm1; // first slot of the second group
+		for (int64_t sx = s0; sx <= s1 && sx < s0 + 4 * RB3_TENT_QMAX + 2; ++sx) {
+			const uint4 sl = ix.slot16[sx * 8 + j];
+			const uint32_t hdr0 = oct_bcast0(sl.x, j);
+			const int64_t gs = (g1 != g0 && sx >= first1) ? g1 : g0;
+			const int64_t sstart = (gs << RB3_GRP_BITS) + (int64_t)(hdr0 & 0xFFFFu);
+			drops_from_slot<NW>(sl, hdr0, (int)(lo - sstart), kk, c, j, D);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int q = 0; q < Q; ++q) mx[sid * NW + q * 8 + j] = D[q * 8 + j];
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+/* k_cum for wide masks: one octet per walker; the cumulative mask, the zeros before each of its words and the masks of the block
+ * being stepped through live in LDS, and every dropped row finds its word by a search over the zero counts */
+template<int Q>
+__global__ void __launch_bounds__(64) k_cum_x(rb3_stretch_t *tab, uint32_t *mx, const uint32_t *sidctr)
+{
+	constexpr int NW = 8 * Q;
+	__shared__ uint32_t cumO_[8][NW], cumN_[8][NW], Zw_[8][NW], blk_[8][8][NW];
+	const int j = threadIdx.x & 7, oi = threadIdx.x >> 3;
+	uint32_t *cumO = cumO_[oi], *cumN = cumN_[oi], *Zw = Zw_[oi];
+	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF;
+	for (int64_t F = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3) * RB3_TENT_BLOCK; F < na; F += (((int64_t)gridDim.x * blockDim.x) >> 3) * RB3_TENT_BLOCK) {
+		if (tab[F].pad[0] != 0u) continue;   // the block continues another walker's stretches
+		int next = tab[F].child - 1;
+		if (next < 0) continue;              // a walker without events that nobody links out of
+#pragma unroll
+		for (int q = 0; q < Q; ++q) cumO[q * 8 + j] = 0u, cumN[q * 8 + j] = 0u;
+		int cur = (int)F;
+		bool go = true;
+		int hops = 0;
+		while (go && next >= 0 && next < RB3_TENT_HALF && ++hops <= RB3_TENT_IDS) {
+			const int base = next & ~(RB3_TENT_BLOCK - 1);
+			const uint4 *rp = (const uint4*)&tab[base + j]; // lane j: record base + j
+			const uint4 q0 = rp[0], q1 = rp[1];
+			for (int t = 0; t < NW; ++t) { // the masks of the block's 8 records: 8 NW consecutive words
+				const int x = t * 8 + j;
+				blk_[oi][x / NW][x % NW] = mx[(int64_t)base * NW + x];
+			}
+			wave_sync();
+			for (int o = next & (RB3_TENT_BLOCK - 1); ; ) {
+				const uint32_t w0hi = __shfl(q0.y, o, RB3_TENT_BLOCK);
+				const int nxt = (int)__shfl(q1.y, o, RB3_TENT_BLOCK) - 1;
+				if (w0hi >> 30 != RB3_DEP_EVENT || (int)(w0hi >> (RB3_TENT_PBITS - 32) & (RB3_TENT_IDS - 1)) != cur) { go = false; break; } // not this walker's next event
+				{ // zeros (survivors) before every word of the cumulative mask so far
+					uint32_t zbase = 0;
+#pragma unroll
+					for (int q = 0; q < Q; ++q) {
+						const uint32_t z = 32u - __popc(cumO[q * 8 + j]);
+						Zw[q * 8 + j] = zbase + oct_exscan(z, j);
+						zbase += oct_sum(z);
+					}
+				}
+				wave_sync();
+				// the rows that dropped at this event, from survivor indices to the coordinates of the first interval
+#pragma unroll 1
+				for (int q = 0; q < Q; ++q) {
+					uint32_t m = blk_[oi][o][q * 8 + j];
+					while (m) {
+						const uint32_t i = 32u * (uint32_t)(q * 8 + j) + (uint32_t)(__ffs(m) - 1); // index among the survivors
+						m &= m - 1u;
+						int a = 0, b = NW - 1;
+						while (a < b) { // the last word with Zw <= i
+							const int mid = (a + b + 1) >> 1;
+							if (Zw[mid] <= i) a = mid; else b = mid - 1;
+						}
+						atomicOr(&cumN[a], 1u << select32(~cumO[a], (int)(i - Zw[a])));
+					}
+				}
+				wave_sync();
+#pragma unroll
+				for (int q = 0; q < Q; ++q) {
+					const uint32_t v = cumN[q * 8 + j];
+					mx[(int64_t)(base + o) * NW + q * 8 + j] = v; // cumulative, first-interval coordinates
+					cumO[q * 8 + j] = v;
+				}
+				wave_sync();
+				cur = base + o, next = nxt;
+				if (next != cur + 1 || ++o == RB3_TENT_BLOCK) break; // the sequence leaves this block
+			}
+			wave_sync();
+		}
+		// summary in the first stretch: total drops, last stretch, and the first stretch of the walker this one linked into
+#pragma unroll
+		for (int q = 0; q < Q; ++q) mx[F * NW + q * 8 + j] = cumO[q * 8 + j];
+		if (j == 0) {
+			uint32_t nf = 0u;
+			if (next >= 0 && next < RB3_TENT_IDS) {
+				const uint64_t w0 = tab[next].w0;
+				if (w0 >> 62 == RB3_DEP_LINK && RB3_DEP_PREV(w0) == cur) nf = (uint32_t)next + 1u;
+			}
+			tab[F].pad[1] = (uint32_t)cur + 1u;
+			tab[F].pad[0] = RB3_FIRSTFLAG | nf;
+		}
+		wave_sync();
+	}
+}
+
+template<int NW>
+__device__ __forceinline__ int popc_below_n(const uint32_t *m, int d)
+{
+	int below = 0;
+	const int full = d >> 5 < NW ? d >> 5 : NW;
+	for (int w = 0; w < full; ++w) below += __popc(m[w]);
+	if (full < NW && (d & 31)) below += __popc(m[full] & ((1u << (d & 31)) - 1u));
+	return below;
+}
+
+template<int Q>
+__global__ void __launch_bounds__(256) k_resolve_w_x(rb3_stretch_t *tab, const uint32_t *mx, const uint32_t *sidctr, int32_t *sfin, unsigned long long *bad, int maxhops)
+{
+	constexpr int NW = 8 * Q;
+	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF, nb = sidctr[1] < (uint32_t)RB3_TENT_HALF ? sidctr[1] : RB3_TENT_HALF;
+	const int64_t nblk = (na + RB3_TENT_BLOCK - 1) / RB3_TENT_BLOCK;
+	for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk + nb; t += (int64_t)gridDim.x * blockDim.x) {
+		int F = (int)(t < nblk ? t * RB3_TENT_BLOCK : RB3_TENT_HALF + (t - nblk));
+		const uint4 *rp = (const uint4*)&tab[F];
+		uint4 q0 = rp[0], q1 = rp[1], q3 = rp[3];
+		int d0 = (int)q1.x - 1; // del
+		if (d0 < 0) continue;   // only first stretches a walker settled start a path
+		if (t < nblk && q3.z != 0u && !(q3.z & RB3_FIRSTFLAG)) continue; // (a continuation block: its first id is an event stretch)
+		for (int hops = 0; hops <= maxhops; ++hops) {
+			if (d0 < 0 || d0 > 256 * Q - 1) break; // cannot be: leave it unsettled, the host redoes the phase
+			sfin[F] = d0 + 1;
+			int last = F, next = (int)q1.y - 1, dl = d0;
+			if (q3.z & RB3_FIRSTFLAG) { // the walker had events: k_cum_x left the summary (only walkers with blocks have events: F < HALF)
+				dl = d0 - popc_below_n<NW>(mx + (int64_t)F * NW, d0);
+				last = (int)q3.w - 1, next = (int)(q3.z & ~RB3_FIRSTFLAG) - 1;
+			}
+			if (next < 0 || next >= RB3_TENT_IDS) break;
+			rp = (const uint4*)&tab[next];
+			q0 = rp[0], q1 = rp[1], q3 = rp[3];
+			const uint64_t w0 = (uint64_t)q0.y << 32 | q0.x;
+			if (w0 >> 62 != RB3_DEP_LINK || RB3_DEP_PREV(w0) != last || q1.x != 0u) break; // another follower's link won / settled by a walker
+			d0 = dl + (int32_t)q0.z, F = next;
+			if (hops == maxhops) atomicAdd(&bad[2], 1ull); // the path goes on: tell the validation pass not to bother (the host starts k_wj_*)
+		}
+	}
+}
+
+template<int Q>
+__global__ void __launch_bounds__(256) k_sfin_x(const rb3_stretch_t *tab, const uint32_t *mx, const uint32_t *sidctr, int32_t *sfin)
+{
+	constexpr int NW = 8 * Q;
+	const int j = threadIdx.x & 7;
+	const int64_t na = sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : RB3_TENT_HALF;
+	for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; s < na; s += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+		const uint32_t head = tab[s].pad[0];
+		if (head == 0u || (head & RB3_FIRSTFLAG)) continue; // a first stretch: settled by a walker or by k_resolve_w_x
+		if (tab[s].w0 >> 62 != RB3_DEP_EVENT || tab[s].del != 0) continue;
+		const int r0 = sfin[head - 1u];
+		if (r0 < 1) continue; // the walker's first unknown is not settled: neither is this one
+		const int d0 = r0 - 1;
+		uint32_t below = 0;
+#pragma unroll
+		for (int q = 0; q < Q; ++q) {
+			const int tt = d0 - 32 * (q * 8 + j);
+			const uint32_t mw = mx[s * NW + q * 8 + j];
+			below += tt >= 32 ? __popc(mw) : tt > 0 ? __popc(mw & ((1u << tt) - 1u)) : 0u;
+		}
+		const int d = d0 - (int)oct_sum(below);
+		if (j == 0 && d >= 0 && d <= 256 * Q - 1) sfin[s] = d + 1;
+	}
+}
+
+/* pointer jumping over the walkers (k_wj_*) with wide masks */
+template<int Q>
+struct WjNodeX {
+	uint32_t M[8 * Q];
+	int32_t c, ptr, val, pad;
+};
+
+template<int Q>
+__global__ void __launch_bounds__(256) k_wj_init_x(const rb3_stretch_t *tab, const uint32_t *mx, const int32_t *sfin, int64_t nblk, int64_t nb, WjNodeX<Q> *nodes)
+{
+	constexpr int NW = 8 * Q;
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nblk + nb) return;
+	const int X = wj_stretch(t, nblk);
+	WjNodeX<Q> n;
+	for (int q = 0; q < NW; ++q) n.M[q] = 0u;
+	n.c = 0, n.ptr = -1, n.val = -1, n.pad = 0;
+	const uint32_t h0 = tab[X].pad[0];
+	if (t < nblk && h0 != 0u && !(h0 & RB3_FIRSTFLAG)) n.val = -2; // the block continues another walker's stretches
+	else {
+		const int s = sfin[X], del = tab[X].del;
+		if (s > 0) n.val = s - 1;
+		else if (del > 0 && del <= 256 * Q) n.val = del - 1;
+		else {
+			const uint64_t w0 = tab[X].w0;
+			if (w0 >> 62 == RB3_DEP_LINK) {
+				const int pl = RB3_DEP_PREV(w0); // the LAST stretch of the walker that ran into this one
+				const uint32_t hp = tab[pl].pad[0];
+				const int pf = (hp == 0u || (hp & RB3_FIRSTFLAG)) ? pl : (int)hp - 1;
+				if (pf >= 0 && pf < RB3_TENT_IDS && (pf >= RB3_TENT_HALF || (pf & (RB3_TENT_BLOCK - 1)) == 0)) {
+					n.ptr = wj_id(pf, nblk), n.c = (int32_t)tab[X].w1;
+					if (pl < RB3_TENT_HALF && (pf != pl || (tab[pf].pad[0] & RB3_FIRSTFLAG))) // the cumulative mask of its last stretch (k_cum_x keeps a copy in the first)
+						for (int q = 0; q < NW; ++q) n.M[q] = mx[(int64_t)pl * NW + q];
+					if (pf == pl) for (int q = 0; q < NW; ++q) n.M[q] = 0u; // it linked from its first stretch: nothing had dropped
+				}
+			}
+		}
+	}
+	nodes[t] = n;
+}
+
+template<int Q>
+__global__ void __launch_bounds__(256) k_wj_round_x(int64_t n, const WjNodeX<Q> *in, WjNodeX<Q> *out)
+{
+	constexpr int NW = 8 * Q;
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	WjNodeX<Q> a = in[t];
+	if (a.val == -1 && a.ptr >= 0 && a.ptr < n) {
+		const WjNodeX<Q> &p = in[a.ptr];
+		const int pval = p.val, pptr = p.ptr, pc = p.c;
+		if (pval >= 0) {
+			const int y = pval - popc_below_n<NW>(a.M, pval) + a.c;
+			a.val = y >= 0 && y <= 256 * Q - 1 ? y : -3; // (-3: cannot be; stays unsettled and the merge is redone)
+		} else if (pval != -1 || pptr < 0) a.ptr = -1; // hangs on something that will never be settled
+		else { // compose: p's map first, then mine
+			uint32_t M[NW];
+			int c = pc + a.c, zeros = 0;
+			for (int q = 0; q < NW; ++q) M[q] = p.M[q], zeros += 32 - __popc(p.M[q]);
+			for (int q = 0; q < NW; ++q) {
+				uint32_t m = a.M[q];
+				while (m) {
+					const int i = 32 * q + __ffs(m) - 1; // a row that dropped on my side, index in the coordinates p's map produces
+					m &= m - 1u;
+					int sidx = i - pc;                // its rank among the rows p's first interval keeps
+					if (sidx < 0) { c -= 1; continue; } // only in the wider interval, below every x: one less below the new suffix, always
+					if (sidx >= zeros) continue;        // above every x
+					for (int w = 0; w < NW; ++w) {      // the sidx-th zero of p.M
+						const uint32_t pw = p.M[w];
+						const int z = 32 - __popc(pw);
+						if (sidx < z) { M[w] |= 1u << select32(~pw, sidx); break; }
+						sidx -= z;
+					}
+				}
+			}
+			for (int q = 0; q < NW; ++q) a.M[q] = M[q];
+			a.c = c, a.ptr = pptr;
+		}
+	}
+	out[t] = a;
+}
+
+template<int Q>
+__global__ void __launch_bounds__(256) k_wj_apply_x(int64_t nblk, int64_t nb, const WjNodeX<Q> *nodes, int32_t *sfin)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nblk + nb) return;
+	if (nodes[t].val >= 0) sfin[wj_stretch(t, nblk)] = nodes[t].val + 1;
+}
+
 /* after the chains: rewrite tentative records (pos = lo + bit + kb), then every row must be recorded
  * and pos must be strictly increasing (ka is non-decreasing in kb).
  * bad[0] += #unset, bad[1] += #order violations, bad[2] += #unsettled tentative records */
@@ -1584,7 +1885,7 @@ __device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *sfin, uns
 	if (v < 0) return RB3_UNSET; // never visited (still an LF word)
 	if (!(v & RB3_TENT)) return v;
 	const int r = sfin[(int)(v >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1)];
-	if (r < 1 || r > RB3_TENT_KMAX + 1) { if (bad) atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
+	if (r < 1 || r > RB3_TENT_KMAX_TOP + 1) { if (bad) atomicAdd(&bad[2], 1ull); return RB3_UNSET; }
 	return (v & RB3_TENT_MASK) + (r - 1);
 }
 
@@ -2594,7 +2895,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 #ifdef RB3_PROF_REB
 /* cycles per phase of reb_group_one, summed over groups (lane 0 of every wave): a kernel experiment, not in the release build */
 __device__ unsigned long long g_reb_prof[16];
-#define RB3_REB_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_reb_prof[i], t_ - tprof); tprof = t_; } while (0)
+#define RB3_REB_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprof; tprof = t_; } while (0)
 __device__ unsigned long long g_reb_why[8]; /* why groups were handed on: 0 rows, 1 slots of the old range, 2 bit-plane slot, 3 old runs, 4 row runs, 5 new slots, 6 last group */
 #define RB3_REB_WHY(i) do { if (lane == 0) atomicAdd(&g_reb_why[i], 1ull); } while (0)
 #else
@@ -2640,7 +2941,11 @@ __device__ __forceinline__ int lb_head(const uint32_t *h, int n, uint32_t key)
  * j0, j1: jw[32 g], jw[32 g + 32], loaded by the caller one group ahead. */
 template<int RMAX, int NBMAX>
 __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t *pos, const uint8_t *b2, int64_t ntot, int64_t j0, int64_t j1,
-		int64_t g, int lane, RebLds<RMAX, NBMAX> &L, uint32_t *gstat, uint4 *gslots)
+		int64_t g, int lane, RebLds<RMAX, NBMAX> &L, uint32_t *gstat, uint4 *gslots
+#ifdef RB3_PROF_REB
+		, unsigned long long *tacc
+#endif
+		)
 {
 	const int64_t P0 = g << RB3_GRP_BITS;
 #ifdef RB3_PROF_REB
@@ -2962,7 +3267,7 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 	wave_sync();
 	RB3_REB_T(7);
 #ifdef RB3_PROF_REB
-	if (lane == 0) atomicAdd(&g_reb_prof[8], 1ull), atomicAdd(&g_reb_prof[9], (unsigned long long)nb), atomicAdd(&g_reb_prof[10], (unsigned long long)nR), atomicAdd(&g_reb_prof[11], (unsigned long long)nslots);
+	tacc[8] += 1ull, tacc[9] += (unsigned long long)nb, tacc[10] += (unsigned long long)nR, tacc[11] += (unsigned long long)nslots;
 #endif
 	return true;
 }
@@ -2987,13 +3292,20 @@ __global__ void __launch_bounds__(64 * RB3_RG_WAVES, RMAX <= 384 ? 5 : 3) k_reb_
 	if (g < full) jn0 = jw[g * RB3_GRP_WINS], jn1 = jw[(g + 1) * RB3_GRP_WINS];
 	if (CHECK && g < ngrp) kn = gkind[g];
 	int nfail = 0;
+#ifdef RB3_PROF_REB
+	unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 	for (; g < ngrp; g += ustep) {
 		const int64_t j0 = jn0, j1 = jn1;
 		const uint32_t kind = kn;
 		if (g + ustep < full) jn0 = jw[(g + ustep) * RB3_GRP_WINS], jn1 = jw[(g + ustep + 1) * RB3_GRP_WINS];
 		if (CHECK && g + ustep < ngrp) kn = gkind[g + ustep];
 		if (CHECK && kind == 0) continue;
+#ifdef RB3_PROF_REB
+		const bool ok = reb_group_one<RMAX, NBMAX>(old, pos, b2, ntot, j0, j1, g, lane, L, gstat, gslots, tacc);
+#else
 		const bool ok = reb_group_one<RMAX, NBMAX>(old, pos, b2, ntot, j0, j1, g, lane, L, gstat, gslots);
+#endif
 		if (!CHECK || ok) { if (lane == 0) gkind[g] = ok ? 0 : 1; }
 		if (LAST && !ok) {
 			if (lane == 0) L.fail[nfail] = (uint32_t)g;
@@ -3015,6 +3327,9 @@ __global__ void __launch_bounds__(64 * RB3_RG_WAVES, RMAX <= 384 ? 5 : 3) k_reb_
 		o = wave_read(o, 0);
 		if (lane < nfail) lout[o + lane] = L.fail[lane];
 	}
+#ifdef RB3_PROF_REB
+	if (lane == 0) for (int q = 0; q < 12; ++q) atomicAdd(&g_reb_prof[q], tacc[q]);
+#endif
 }
 
 /* the groups rebuilt in run space: directory entry + slots from the scratch to their final places (the groups of the

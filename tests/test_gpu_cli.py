@@ -16,8 +16,8 @@ MAN = json.load(open(os.path.join(util.GOLDEN, "MANIFEST.json")))
 CLI = _build.BIN_CLI
 
 
-def run(args, inp=None):
-    r = subprocess.run([CLI] + args, input=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+def run(args, inp=None, env=None):
+    r = subprocess.run([CLI] + args, input=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0, r.stderr.decode()[-600:]
     return r.stdout, r.stderr.decode()
 
@@ -335,17 +335,28 @@ def test_config5_long_contig_haplotypes(tmp_path):
         os.unlink(f)
 
 
-def test_more_relatives_than_a_tentative_interval_tracks(tmp_path):
+@pytest.mark.parametrize("tent_q", [None, 1, 8])
+def test_more_relatives_than_a_tentative_interval_tracks(tmp_path, tent_q):
     """320 close relatives of a 200 kbp genome, one genome per batch: from round 256 on an interval of matching suffixes is wider
-    than the 255 rows a tentative stretch tracks (RB3_TENT_KMAX), so walkers record later and their neighbours cover more --
-    slower, never wrong: the reference's .fmd, and no merge falls back to the walk without tentative records"""
+    than the 255 rows the masks inside the stretch records track (RB3_TENT_KMAX).  The engine notices (walkers report the steps they
+    walked on intervals wider than the masks) and settles the following merges with masks of 512 bits (k_events_x ...); with the
+    width pinned to 256 bits (RB3GPU_TENT_Q=1: what rounds 1-2 did) walkers record later and their neighbours cover more --
+    slower, never wrong; pinned to 2048 bits every merge goes through the wide kernels.  Always the reference's .fmd, and no
+    merge falls back to the walk without tentative records"""
     import re
     from tools import gen_family
     ent = _family("relatives_320x200k")
     fn = gen_family.relatives(*ent["spec"][1:], str(tmp_path / "rel.fa"))
-    out, err = run(["build", "-d", "-m300k", fn])
+    out, err = run(["build", "-d", "-m300k", fn], env=None if tent_q is None else {"RB3GPU_TENT_Q": str(tent_q)})
     assert hashlib.md5(out).hexdigest() == ent["fmd_md5"] and len(out) == ent["fmd_bytes"]
     assert err.count("merged the partial BWT") >= 300
     m = re.search(r"(\d+) merges redone without tentative records", err)
     assert m and int(m.group(1)) <= 3, err[-600:]
+    w = re.search(r"drop-out masks of (\d+) bits", err)
+    if tent_q is None:
+        assert w and int(w.group(1)) == 512, err[-900:]
+    elif tent_q == 8:
+        assert w and int(w.group(1)) == 2048, err[-900:]
+    else:
+        assert w is None
     os.unlink(fn)

@@ -668,22 +668,28 @@ def test_hundreds_of_relatives(oracle):
     rb, _ = oracle.mg_rank(b1, host.build_bwt(t2.copy()), 8)
     want = rb >> 6
     steps = {}
-    for tent in ("1", "0"):
+    for tent, tent_q in (("1", "1"), ("0", "1"), ("1", "2"), ("1", "4")):
         os.environ["RB3GPU_TENT"] = tent
+        os.environ["RB3GPU_TENT_Q"] = tent_q
         try:
             h = Rb3Gpu(verbose=1)
             h.from_plain(b1)
             for step in (128, 300):
                 b2, w = host.build_bwt_walkers(t2, step)
                 got, _ = h.mg_rank_plain_walkers(b2, w)
-                assert np.array_equal(got, want), (tent, step)
+                assert np.array_equal(got, want), (tent, tent_q, step)
             st = h.stats()
-            steps[tent] = st["n_lf_steps"] - 2 * want.size
+            steps[tent, tent_q] = st["n_lf_steps"] - 2 * want.size
             assert st["n_fallbacks"] == 0
+            if tent == "1":
+                assert st["tent_mask_bits"] == 256 * int(tent_q), st
             h.close()
         finally:
             os.environ.pop("RB3GPU_TENT", None)
-    assert steps["1"] <= steps["0"], steps
+            os.environ.pop("RB3GPU_TENT_Q", None)
+    assert steps["1", "1"] <= steps["0", "1"], steps
+    # masks of 512 bits track all 420 relatives: the walkers record from their 32nd step on instead of waiting for relatives to drop out
+    assert steps["1", "2"] < steps["1", "1"] and steps["1", "4"] <= steps["1", "2"], steps
 
 
 @pytest.mark.parametrize("seed,kind", [(91, "genome"), (92, "two_strands"), (93, "family"), (94, "copies"), (95, "short")])
@@ -1112,11 +1118,13 @@ def test_lf_consistency_check_finds_a_wrong_but_monotone_pos(oracle):
     h.close()
 
 
-def test_duplicate_genome_long_settle_paths(oracle):
+@pytest.mark.parametrize("tent_q", [0, 2, 8])
+def test_duplicate_genome_long_settle_paths(oracle, tent_q):
     """a string that repeats indexed text end to end never makes a walker exact: all its walkers hang on ONE dependency path,
     longer than k_resolve_w follows (64 hops).  The merge notices on the device, the host starts the pointer-jumping settle
     (k_wj_*: maps x -> x - #dropped below x + offset composed by doubling), validates and rebuilds again -- no redo of the
-    rank phase, and the same index as the oracle's.  Single relative (pure links) and a family (drop-outs along the path)."""
+    rank phase, and the same index as the oracle's.  Single relative (pure links) and a family (drop-outs along the path).
+    tent_q: the same through the wide-mask kernels (k_events_x ... k_wj_round_x; masks of 512 and 2048 bits)."""
     from ropebwt3_amd import Rb3Gpu, host
     rng = np.random.default_rng(404)
     g0 = util.random_genome(rng, 120000)
@@ -1126,6 +1134,8 @@ def test_duplicate_genome_long_settle_paths(oracle):
         t2 = util.make_text([rel[-1].copy(), util.mutate(rng, g0, 0.001)])     # a duplicate and an ordinary relative in one batch
         want = oracle.merge(b1, host.build_bwt(t2.copy()))
         h = Rb3Gpu(verbose=1)
+        if tent_q:
+            h.tune("tent_q", tent_q)
         h.from_plain(b1)
         d, dtw = h.sort_text(t2)
         h.merge_text_dev(d, dtw, t2.size, host.walkers_text(t2, 128), commit=True)

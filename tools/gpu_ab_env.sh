@@ -1,0 +1,13 @@
+#!/bin/bash
+# GPU box: A/B of environment settings on the headline leg:  tools/gpu_ab_env.sh "VAR=1" "" ...   (each argument: an env assignment list, may be empty)
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
+for rep in 1 2; do
+for v in "$@"; do
+	env $v timeout 300 python bench.py --only headline --steps ${STEPS:-3} --warmup 1 ${BENCH_ARGS:-} > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err
+	python - "$v" <<'PY'
+import json, sys
+d = json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])
+p = d["phases_ms_per_step"]
+print("%-24s ms %.1f  h2d %.1f lf %.1f rank %.1f k_chain %.1f rebuild %.1f host %.1f  md5ok %s fb %s" % (sys.argv[1] or "(default)", d["ms_per_step"], p["h2d"], p["lf"], p["rank"], p["k_chain"], p["rebuild"], p["host_and_sync_inside_merge_calls"], d["config"]["fmd_identical_to_reference"], d["config"]["rank_phase_fallbacks"]))
+PY
+done; done

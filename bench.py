@@ -241,29 +241,57 @@ class BuildLoop:
         self.h = Rb3Gpu(device=device, verbose=1)
         self.srt = Sorter(device)
         self.fwd_upload = True
+        self.overlap = True      # the H2D copy of batch i + 1 runs beside the merge of batch i (--serial-h2d: one after the other)
 
     def run(self, texts, walkers, first_is_index=True):
-        """returns (seconds H2D, seconds merge, seconds sort, symbols merged, wall seconds) of one build"""
+        """returns (seconds H2D, seconds merge, seconds sort, symbols merged, wall seconds) of one build.
+        Serial: upload(i) -> sort(i) -> merge(i), the upload timed from call to completion.  Overlapped (the default; what the CLI's
+        sorter thread does, and build.c:203-239 with its reader): the copies of batch i + 1 are QUEUED before merge(i) is called
+        and run on the copy engine beside its kernels; H2D seconds = the time to queue them + whatever the copy engine still needs
+        when the merge call has returned (rb3gpu_sorter_upload_end, called right behind it) -- nothing of the copy can hide in the
+        suffix sorting, which is not part of the metric."""
         h, srt = self.h, self.srt
         t_h2d = t_mrg = t_sort = 0.0
         nsym = 0
         w0 = time.perf_counter()
-        for i, (t, (w, pairs)) in enumerate(zip(texts, walkers)):
-            a = time.perf_counter()
-            if pairs is not None and self.fwd_upload:
+        n = len(texts)
+        overlap = self.overlap and self.fwd_upload and all(p is not None for _, p in walkers)
+        uploaded = -1            # the batch whose text is on the device
+
+        def upload(i, begin_only=False):
+            t, (_, pairs) = texts[i], walkers[i]
+            if begin_only:
+                srt.upload_fwd_begin(t, pairs)
+            elif pairs is not None and self.fwd_upload:
                 srt.upload_fwd(t, pairs)                    # forward strands over PCIe, reverse complements made on the device
             else:
                 srt.upload(t)                               # returns after the stream synchronisation
+
+        for i, (t, (w, pairs)) in enumerate(zip(texts, walkers)):
+            a = time.perf_counter()
+            if uploaded != i:
+                upload(i)
             b = time.perf_counter()
             d_bwt, d_tw = srt.sort_uploaded(t.size)         # (synchronous)
             c = time.perf_counter()
             if i == 0 and first_is_index:
+                if overlap and n > 1:
+                    upload(1, True), srt.upload_end()       # (timed below like every other batch's: queue + wait, here with nothing beside it)
+                    uploaded = 1
+                    t_h2d += time.perf_counter() - c
                 h.from_plain_dev(d_bwt, t.size)             # rb3_enc_plain2fmr: the first batch is encoded, not merged
             else:
+                if overlap and i + 1 < n:
+                    upload(i + 1, True)                     # queued on the sorter's stream: returns at once
+                    uploaded = i + 1
+                c1 = time.perf_counter()
                 h.merge_text_dev(d_bwt, d_tw, t.size, w, commit=True)   # one synchronisation, at its end
                 d = time.perf_counter()
-                t_h2d += b - a
-                t_mrg += d - c
+                if overlap and i + 1 < n:
+                    srt.upload_end()                        # what the copy engine still has to do shows up here
+                e = time.perf_counter()
+                t_h2d += (b - a) + (c1 - c) + (e - d)
+                t_mrg += d - c1
                 nsym += t.size
             t_sort += c - b
             srt.release(d_bwt)
@@ -417,6 +445,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (CLI build, configs[1], reads regime, large index)")
     ap.add_argument("--no-pinned", action="store_true", help="batches in pageable host memory (staged upload)")
+    ap.add_argument("--serial-h2d", action="store_true", help="upload every batch before its own sort with nothing beside it (round 3's first definition) instead of beside the merge of the batch before")
     ap.add_argument("--full-upload", action="store_true", help="copy both strands of every batch over PCIe (rb3gpu_sorter_upload) instead of the forward strands only")
     ap.add_argument("--aux-reads", type=int, default=100000)
     ap.add_argument("--large-index", type=int, default=1 << 30, help="symbols of the index of the large-index leg (0: skip)")
@@ -462,6 +491,7 @@ def main():
 
     bl = BuildLoop(local_rank)
     bl.fwd_upload = not args.full_upload
+    bl.overlap = not args.serial_h2d and not args.full_upload and not args.no_pinned
     for _ in range(args.warmup):
         bl.run(texts, walkers)
     bl.h.sync()
@@ -475,6 +505,11 @@ def main():
     bl.h.sync()
     torch.cuda.synchronize()
     st = bl.h.stats()
+    h2d_serial = None
+    if bl.overlap:   # for the record: the same copies with nothing beside them (one more build, not part of the timed steps)
+        bl.overlap = False
+        h2d_serial = bl.run(texts, walkers)[0]
+        bl.overlap = True
     md5, fmd_len = bl.fmd_md5()
     ident = (md5 == gold["fmd_md5"]) if gold else None
     if ident is False:
@@ -489,7 +524,7 @@ def main():
         "metric": "Gbp/s indexed (build merge)", "value": round(nsym / dt / 1e9, 6), "unit": "Gbp/s",
         "n_gpus": 1, "steps": S, "warmup": args.warmup, "ms_per_step": round(dt / S * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": "cfg3-synthetic-mtb%d: %d genomes of %d bp (star phylogeny, 0.1 %% substitutions + 10 indels each; tools/gen_mtb.py), one genome per batch = %d merge rounds per step, %d symbols merged per step; merge path incl. H2D (SURVEY 8(d))" % (K, K, L, K - 1, sym_step),
+        "config": {"workload": "cfg3-synthetic-mtb%d: %d genomes of %d bp (star phylogeny, 0.1 %% substitutions + 10 indels each; tools/gen_mtb.py), one genome per batch = %d merge rounds per step, %d symbols merged per step; merge path incl. H2D (SURVEY 8(d))%s" % (K, K, L, K - 1, sym_step, ", the H2D copy of batch i+1 queued beside the merge of batch i" if bl.overlap else ""),
                    "symbols_per_step": int(sym_step), "merge_rounds_per_step": K - 1, "index_symbols_final": nsym_all, "index_mb_final": round(st["bytes_index"] / 1e6, 1), "parallelism": "single GPU",
                    "entry_points": "rb3gpu_sorter_upload_fwd (H2D of the batch: forward strands out of page-locked memory, reverse complements written on the device; --full-upload: rb3gpu_sorter_upload) + rb3gpu_merge_text_dev (LF + walkers + settle + validation + rebuild, commit=1); rb3gpu_sorter_sort_uploaded between them is not counted (suffix sorting: excluded by the metric)",
                    "fmd_md5": md5, "fmd_bytes": fmd_len, "fmd_identical_to_reference": ident,
@@ -498,7 +533,10 @@ def main():
         "phases_ms_per_step": {"h2d": round(tot_h2d / S * 1e3, 3), "merge_calls": round(tot_mrg / S * 1e3, 3), "lf": round(st["ms_lf"] / S, 3), "rank": round(st["ms_rank"] / S, 3), "k_chain": round(st["ms_chain"] / S, 3),
                                "rebuild": round(st["ms_build"] / S, 3), "host_and_sync_inside_merge_calls": round((tot_mrg * 1e3 - st["ms_lf"] - st["ms_rank"] - st["ms_build"]) / S, 3)},
         "not_counted_ms_per_step": {"suffix_sorting_on_the_gpu": round(tot_sort / S * 1e3, 3), "wall_of_the_whole_loop": round(tot_wall / S * 1e3, 3)},
-        "h2d": {"symbols_per_step": int(sym_step), "bytes_over_pcie_per_step": int(sym_step // 2) if not args.full_upload else int(sym_step), "how": "rb3gpu_sorter_upload_fwd: forward strands copied, reverse complements written on the device" if not args.full_upload else "rb3gpu_sorter_upload: both strands copied", "GB/s_of_text": round(nsym / max(1e-9, tot_h2d) / 1e9, 2), "source": "pageable (staged)" if args.no_pinned else "page-locked (rb3gpu_pinned_alloc): one DMA per batch"},
+        "h2d": {"symbols_per_step": int(sym_step), "bytes_over_pcie_per_step": int(sym_step // 2) if not args.full_upload else int(sym_step), "how": "rb3gpu_sorter_upload_fwd: forward strands copied, reverse complements written on the device" if not args.full_upload else "rb3gpu_sorter_upload: both strands copied", "GB/s_of_text": round(nsym / max(1e-9, tot_h2d) / 1e9, 2), "source": "pageable (staged)" if args.no_pinned else "page-locked (rb3gpu_pinned_alloc): one DMA per batch",
+                "overlapped_with_the_merge_of_the_batch_before": bool(bl.overlap),
+                "what_phases_ms_per_step.h2d_is": ("queueing the copies of batch i+1 (rb3gpu_sorter_upload_fwd_begin) before the merge of batch i is called + what the copy engine still needs once that merge has returned (rb3gpu_sorter_upload_end); the copies run beside the merge's kernels, as in the CLI (sorter thread) and the reference (reader, build.c:203-239)" if bl.overlap else "the upload call from start to completion, nothing beside it"),
+                "ms_per_step_with_nothing_beside_it": None if h2d_serial is None else round(h2d_serial * 1e3, 3)},
         "roofline": chain_roofline(int(rows_launch), ms_chain, "text", load_pmc_traffic("k_chain_mtb152"),
                                    "k_chain<list,mixed,tent,text>: average over the %d launches of the timed steps (run-coded index, intervals of up to %d matching suffixes); `achieved` prices SURVEY 8(d)'s 208 B per LF step over the kernel's HIP-event time; "
                                    "traffic = FETCH_SIZE/WRITE_SIZE of the committed --pmc passes (profiles/r3_pmc_k_chain_mtb152.json); the index (<= %.0f MB) sits in L2 + Infinity Cache, so this kernel is bound by latency and instruction issue, not by HBM (aux_large_index is the HBM-resident case)" % (st["n_rank_launches"], K - 1, st["bytes_index"] / 1e6)),

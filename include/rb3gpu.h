@@ -240,6 +240,13 @@ int rb3gpu_sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text);
  * written on the device.  pair_start[i] = offset of record i in `text` (pair_start[0] = 0; record n_pairs - 1 ends at len).
  * RB3GPU_EINVAL if the text does not have that layout (use rb3gpu_sorter_upload). */
 int rb3gpu_sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start);
+/* rb3gpu_sorter_upload_fwd in two halves, so that the copy of the NEXT batch runs beside the merge of the current one on the copy
+ * engine (what the CLI gets from its sorter thread; build.c:203-239 reads the next batch while the current one is inserted):
+ * _begin queues the copies and the strand kernel on the sorter's stream and returns at once if `text` is page-locked
+ * (rb3gpu_pinned_alloc; otherwise it is rb3gpu_sorter_upload_fwd), and `text` must stay untouched until _end -- or the sort, which
+ * the stream orders behind the copies anyway -- has returned.  _end waits for whatever the sorter's stream still holds. */
+int rb3gpu_sorter_upload_fwd_begin(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start);
+int rb3gpu_sorter_upload_end(rb3gpu_sorter_t *s);
 int rb3gpu_sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw);
 /* cumulative times of a sorter: text upload (host -> HBM, through its pinned staging buffer) and suffix sorting proper */
 int rb3gpu_sorter_stats(const rb3gpu_sorter_t *s, double *ms_upload, double *ms_sort, int64_t *n_batches, int64_t *n_symbols);

@@ -1903,7 +1903,7 @@ __global__ void __launch_bounds__(256) k_revcomp_fill(uint8_t *text, FwdPairs pp
 	}
 }
 
-static int sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start)
+static int sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start, bool wait = true)
 {
 	if (!s || !text || !pair_start || len <= 0 || len >= (1LL << 31) || n_pairs < 1 || n_pairs > RB3_FWD_MAXPAIRS) return RB3GPU_EINVAL;
 	FwdPairs pp;
@@ -1927,7 +1927,9 @@ static int sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *tex
 	}
 	int64_t nblk = (len / 2 + 1023) / 1024;
 	hipLaunchKernelGGL(k_revcomp_fill, dim3((unsigned)(nblk > 4096 ? 4096 : nblk)), dim3(256), 0, s->st, (uint8_t*)s->text, pp);
-	if (hipStreamSynchronize(s->st) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	// (begin/end form: the copies of a page-locked text are queued and the caller goes on -- e.g. merges the batch before; the sorter's
+	// stream orders them before the sort whether or not anybody waits)
+	if ((wait || !pinned) && hipStreamSynchronize(s->st) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
 	s->ms_upload += (now_s() - t_up) * 1e3;
 	s->text_len = len;
 	return 0;
@@ -1983,6 +1985,21 @@ int rb3gpu_sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text)
 int rb3gpu_sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start)
 {
 	return sorter_upload_fwd(s, len, text, n_pairs, pair_start);
+}
+
+int rb3gpu_sorter_upload_fwd_begin(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start)
+{
+	return sorter_upload_fwd(s, len, text, n_pairs, pair_start, false);
+}
+
+int rb3gpu_sorter_upload_end(rb3gpu_sorter_t *s)
+{
+	if (!s) return RB3GPU_EINVAL;
+	SCHK(hipSetDevice(s->dev));
+	const double t = now_s();
+	if (hipStreamSynchronize(s->st) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	s->ms_upload += (now_s() - t) * 1e3;
+	return 0;
 }
 
 int rb3gpu_sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw)

@@ -85,6 +85,8 @@ SYMBOLS = {
     "rb3gpu_sorter_release": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_sorter_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_sorter_upload_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_sorter_upload_fwd_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "rb3gpu_sorter_upload_end": (ctypes.c_int, [ctypes.c_void_p]),
     "rb3gpu_sorter_sort_uploaded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     "rb3gpu_pinned_alloc": (ctypes.c_void_p, [ctypes.c_int64]),
     "rb3gpu_pinned_free": (None, [ctypes.c_void_p]),
@@ -182,6 +184,16 @@ class Sorter:
         assert text.dtype == np.uint8 and text.flags["C_CONTIGUOUS"]
         ps = np.ascontiguousarray(pair_start, dtype=np.int64)
         self._chk(self._lib.rb3gpu_sorter_upload_fwd(self._s, text.size, text.ctypes.data, ps.size, ps.ctypes.data), "rb3gpu_sorter_upload_fwd")
+
+    def upload_fwd_begin(self, text, pair_start):
+        """upload_fwd without waiting: the copies are queued on the sorter's stream (page-locked text) and run beside whatever the
+        caller does next; the text must not change until upload_end() or sort_uploaded() has returned"""
+        assert text.dtype == np.uint8 and text.flags["C_CONTIGUOUS"]
+        ps = np.ascontiguousarray(pair_start, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_sorter_upload_fwd_begin(self._s, text.size, text.ctypes.data, ps.size, ps.ctypes.data), "rb3gpu_sorter_upload_fwd_begin")
+
+    def upload_end(self):
+        self._chk(self._lib.rb3gpu_sorter_upload_end(self._s), "rb3gpu_sorter_upload_end")
 
     def sort_uploaded(self, length):
         """suffix-sort the text uploaded last: (d_bwt, d_tw) device pointers, valid until release(d_bwt)"""

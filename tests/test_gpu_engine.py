@@ -566,8 +566,10 @@ def test_forward_strand_upload_equals_full_upload(tmp_path):
     pin.array[:] = text
     try:
         out = []
-        for src, fwd in ((text, False), (text, True), (pin.array, True)):
-            if fwd: srt.upload_fwd(src, pairs)
+        for src, fwd in ((text, False), (text, True), (pin.array, True), (pin.array, "begin"), (pin.array, "begin+end"), (text, "begin")):
+            if fwd == "begin": srt.upload_fwd_begin(src, pairs)          # queued; the sort is ordered behind the copies by the stream
+            elif fwd == "begin+end": srt.upload_fwd_begin(src, pairs), srt.upload_end()
+            elif fwd: srt.upload_fwd(src, pairs)
             else: srt.upload(src)
             d_bwt, d_tw = srt.sort_uploaded(text.size)
             out.append((h.dev_download(d_bwt, text.size), h.dev_download(d_tw, text.size * 8)))

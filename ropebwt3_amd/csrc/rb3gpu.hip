@@ -594,7 +594,8 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
  *   [16..23] totals of the batch scan (symbol counts of B2, [22] = bad bytes)
  *   [24..31] totals of the rebuild scan (symbol counts of the merged BWT, [30] = slots)
  *   [14] (two u32) lengths of the two lists of groups the run-space rebuild hands on: after the small tier, after the large tier */
-#define MISC_WORDS   64
+#define MISC_WORDS   (64 + 32 * RB3_TENT_NCTR / 2) /* the counters and totals of a merge, then (MISC_MCTR) the id counters of the tentative stretches, one per 128 bytes */
+#define MISC_MCTR    64
 #define MISC_LF_TOT  16
 #define MISC_IX_TOT  24
 #define MISC_RG_LISTS 14
@@ -1188,7 +1189,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	// start (a whole-index merge at the top of a multi-GPU tree: 670 M rows into 76 relatives) -- a full table is only found
 	// out after the walk, and then costs the walk.
 	const double kest = h->nslots > 0 ? (double)h->n / ((double)h->nslots * 32.0) : 1.0;
-	auto events_at = [&](double W) { return (double)len / W * ((kest < 1.0 ? 1.0 : kest) * (1.0 - exp(-W / 1000.0)) + (double)RB3_TENT_BLOCK); };
+	auto events_at = [&](double W) { return (double)len / W * ((kest < 1.0 ? 1.0 : kest) * (1.0 - exp(-W / 1000.0)) + (double)RB3_TENT_CHUNK); };
 	const double tent_room = 0.6 * (double)RB3_TENT_HALF;
 	int64_t b2W = RB3_B2_W;
 	while (len / b2W > (1 << 18) || (h->tn.tent && thin == 1 && events_at((double)b2W) > tent_room && b2W < len / 256)) b2W *= 2;
@@ -1245,12 +1246,13 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	Walker *dwl = (Walker*)h->wl.p;
 	uint32_t *sidctr = (uint32_t*)(misc + 5);
+	uint32_t *mctr = (uint32_t*)(misc + MISC_MCTR); // (cleared with the rest below)
 	h->mg_active = 0;
 	HIPCHK(hipEventRecord(h->ev[0], h->st));
 	// one launch clears what this merge accumulates into: the counters (the scan totals behind them are written later), the
 	// stretches the merge before opened, the rows-per-window table of the rebuild, and -- text-order walk -- the row records
 	fill_add(&jb, misc, 128, 0u);
-	fill_add(&jb, misc + MISC_RG_OVER, 64, 0u); // (... MISC_WIDE)
+	fill_add(&jb, misc + MISC_RG_OVER, tent ? (size_t)(MISC_WORDS - MISC_RG_OVER) * 8 : 64, 0u); // (... MISC_WIDE, and the id counters behind them)
 	if (rows_fused) fill_add(&jb, h->jg.p, (size_t)(nwin + 1) * 8, 0u); // defined even if pos[] turns out invalid
 	const bool rows_filled = d_tw != nullptr && jb.n < 8;
 	if (rows_filled) fill_add(&jb, h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
@@ -1329,7 +1331,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		const dim3 grid((unsigned)(nblk * (256 / h->tn.chain_bs))), blk((unsigned)h->tn.chain_bs);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
 #define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr)
 #ifdef RB3_WITH_QUADS /* a quad per walker (k_chain<..., 4>) was measured slower in every regime: compiled in on request only */
 #define RB3_LAUNCH_FAST(D, T, X) do { if (lpw == 4) RB3_LAUNCH_FAST1(D, T, X, 4); else RB3_LAUNCH_FAST1(D, T, X, 8); } while (0)
 #else
@@ -1357,7 +1359,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #undef RB3_LAUNCH_FAST
 #undef RB3_LAUNCH_FAST1
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
-		if (tent) launch_settle(h, iv, tab, mx, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS, tq), h->stt.tent_mask_bits = 256 * tq;
+		if (tent) {
+			hipLaunchKernelGGL(k_tent_extent, dim3(1), dim3(64), 0, h->st, (const uint32_t*)mctr, sidctr);
+			launch_settle(h, iv, tab, mx, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS, tq), h->stt.tent_mask_bits = 256 * tq;
+		}
 		if (rows_fused) { // validation and the rows-per-window table of the rebuild in one pass over pos[]
 			const dim3 g1((unsigned)((len + 1 + 255) / 256));
 			if (tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
@@ -1488,7 +1493,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		}
 	}
 	const unsigned long long tent_cap_a = sid_limit < (uint32_t)RB3_TENT_HALF ? sid_limit : (uint32_t)RB3_TENT_HALF, tent_cap_b = sid_limit < (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF) ? sid_limit : (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF);
-	if (tent && hm[4] != 0 && thin < 64 && !per_string && ((hm[5] & 0xFFFFFFFFull) + RB3_TENT_BLOCK > tent_cap_a || (hm[5] >> 32) >= tent_cap_b)) {
+	if (tent && hm[4] != 0 && thin < 64 && !per_string && ((hm[5] & 0xFFFFFFFFull) + RB3_TENT_CHUNK > tent_cap_a || (hm[5] >> 32) >= tent_cap_b)) {
 		// The stretch table was full (a huge batch whose walkers pass the variants of many indexed relatives: events ~ walkers x
 		// relatives): once more with every eighth walker -- the events of a walker stop growing once it has seen every relative
 		// drop out, so fewer, longer walkers need fewer stretches -- before giving up on tentative records altogether.

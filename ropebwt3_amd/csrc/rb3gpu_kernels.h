@@ -799,6 +799,34 @@ typedef struct {
                                         unique match never see a drop-out and take single ids from the upper half
                                         (counter sidctr[1]) */
 #define RB3_TENT_HALF (RB3_TENT_IDS / 2)
+#ifndef RB3_TENT_CHUNK
+#define RB3_TENT_CHUNK 8             /* ids (a whole number of blocks) a walker takes from a counter at a time */
+#endif
+/* Where the blocks come from.  One counter for all walkers means that every atomicAdd of a launch goes to the same word, and at 150
+ * relatives one wave iteration in seven needs a new block: k_chain took 163 ms per 152-genome build with blocks of 8 from one counter,
+ * 140 with 32 ids per atomic, 129 with 128 -- but every id handed out and not used is cleared and looked at by the settle kernels
+ * (rank phase 193 / 181 / 219 ms).  So: RB3_TENT_NCTR counters, each on a cache line of its own (mctr[c * 32]), a wave uses the one
+ * of its number, and chunk n of counter c is the ids [(n * NCTR + c) * CHUNK, + CHUNK): the counters advance at the same rate, so the
+ * ids in use stay dense, and k_tent_extent turns the largest of them into the extent the settle kernels scan (sidctr[0]). */
+#ifndef RB3_TENT_NCTR
+#define RB3_TENT_NCTR 64
+#endif
+__device__ __forceinline__ uint32_t tent_take_chunk(uint32_t *sidctr, uint32_t *mctr, uint32_t c)
+{
+	if (mctr == nullptr) return atomicAdd(sidctr, (uint32_t)RB3_TENT_CHUNK);
+	const uint32_t n = atomicAdd(&mctr[c * 32u], 1u);
+	return n >= (uint32_t)(RB3_TENT_HALF / (RB3_TENT_NCTR * RB3_TENT_CHUNK)) ? 0xFFFFFF00u : (n * (uint32_t)RB3_TENT_NCTR + c) * (uint32_t)RB3_TENT_CHUNK; // (a full table: an id beyond every limit)
+}
+
+__global__ void k_tent_extent(const uint32_t *mctr, uint32_t *sidctr)
+{
+	uint32_t v = threadIdx.x < RB3_TENT_NCTR ? mctr[threadIdx.x * 32u] : 0u;
+	for (int o = 32; o; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = v > t ? v : t; }
+	if (threadIdx.x == 0) {
+		const unsigned long long e = (unsigned long long)v * RB3_TENT_NCTR * RB3_TENT_CHUNK;
+		sidctr[0] = e < (unsigned long long)RB3_TENT_HALF ? (uint32_t)e : (uint32_t)RB3_TENT_HALF;
+	}
+}
 
 template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t v, bool vis)
 {
@@ -912,8 +940,9 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8>
 __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX)
+		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX, uint32_t *mctr = nullptr)
 {
+	const uint32_t myctr = (uint32_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (uint32_t)(RB3_TENT_NCTR - 1); // the id counter of this wave
 	const int64_t nwalk = nwalk_dev ? (int64_t)*nwalk_dev : nwalk_arg; // (a list made on the device: its length never went to the host)
 	static_assert(LIST || !TEXT, "text-order words need a walker list");
 	// ids a walker may take from each half of the stretch table (the whole half unless a test narrows it)
@@ -924,6 +953,8 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
 	// it hosts: the host may enable only the first `octs` octets of each wave and launch more waves.
 	if (lane / LPW >= octs) return; // (octs counts groups of LPW lanes)
+	const int64_t myoct = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * octs + lane / LPW, noct = (int64_t)gridDim.x * (blockDim.x >> 6) * octs;
+	bool firstpull = true;
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
 	const int64_t first_marked = M ? ((m2 + M - 1) >> logM << logM) : 0;
 	// records must become visible to other walkers only if strings are split (logM < 0 with a list: one walker per string)
@@ -956,13 +987,20 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 	for (;;) {
 		// ---- refill: every octet without a walker pulls the next one from the queue (rare) ----
 		if (!active) {
-			uint32_t w0 = 0, w1 = 0;
-			if (j == 0) {
-				unsigned long long w = atomicAdd(qhead, 1ull);
-				w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+			// the first walker of every octet is the one of its own number (all octets ask at once when the kernel starts, and a list
+			// of text-regular walkers has about one per octet: ~23 k atomics on one word in the first microseconds); later ones
+			// come from the queue behind those
+			int64_t wid;
+			if (firstpull) wid = myoct, firstpull = false;
+			else {
+				uint32_t w0 = 0, w1 = 0;
+				if (j == 0) {
+					unsigned long long w = atomicAdd(qhead, 1ull);
+					w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+				}
+				w0 = grp_bcast0<LPW>(w0, j), w1 = grp_bcast0<LPW>(w1, j);
+				wid = noct + (int64_t)((uint64_t)w1 << 32 | w0);
 			}
-			w0 = grp_bcast0<LPW>(w0, j), w1 = grp_bcast0<LPW>(w1, j);
-			const int64_t wid = (int64_t)((uint64_t)w1 << 32 | w0);
 			if (wid >= nwalk) {
 				if (bkb >= 0) rec_pos<TENT && !LIST>(&row[bkb], bval, vis);
 				break;
@@ -1104,12 +1142,12 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 					if (gap == 2 && sid >= 0 && kn >= 1 && kn < (int64_t)kq) { // some matching suffixes are not preceded by c: a new stretch (see below)
 						int ns = sid + 1;
 						if (sid == RB3_TENT_POISON) ns = RB3_TENT_POISON;
-						else if ((ns & (RB3_TENT_BLOCK - 1)) == 0) {
-							// (asking for the next block half a block ahead, so that nobody waits for the atomic: measured 5 % SLOWER)
+						else if ((ns & (RB3_TENT_CHUNK - 1)) == 0) { // (the next block of the chunk is simply ns)
+							// (asking for the next chunk ahead of time, so that nobody waits for the atomic: measured 5 % SLOWER)
 							uint32_t s0 = 0;
-							if (j == 0) s0 = atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
+							if (j == 0) s0 = tent_take_chunk(sidctr, mctr, myctr);
 							s0 = oct_bcast0(s0, j);
-							ns = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
+							ns = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 						}
 						if (j == 0 && ns != RB3_TENT_POISON) {
 							tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = kq | (uint64_t)c << 16;
@@ -1182,10 +1220,10 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			const int64_t myval = lo + kb;
 			if (TENT && tentok && !met && sid < 0) { // first tentative record of this walker: open a stretch (rare)
 				uint32_t s0 = 0;
-				if (j == 0) s0 = gap == 1 ? atomicAdd(sidctr + 1, 1u) : atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
+				if (j == 0) s0 = gap == 1 ? atomicAdd(sidctr + 1, 1u) : tent_take_chunk(sidctr, mctr, myctr);
 				s0 = grp_bcast0<LPW>(s0, j);
 				if (gap == 1) sid = s0 < lim_singles ? (int)(RB3_TENT_HALF + s0) : -2; // table full: this walker stays a plain inexact one
-				else sid = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : -2;
+				else sid = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : -2;
 				sid0 = sid;
 			}
 			if (TENT && met) { // settle an unknown (rare)
@@ -1237,12 +1275,12 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 				// worked out by k_events afterwards, for all events of the launch at once.
 				int ns = sid + 1;
 				if (sid == RB3_TENT_POISON) ns = RB3_TENT_POISON;
-				else if ((ns & (RB3_TENT_BLOCK - 1)) == 0) { // this walker's block of ids is used up (rare)
+				else if ((ns & (RB3_TENT_CHUNK - 1)) == 0) { // this walker's chunk of ids is used up (rare)
 					uint32_t s0 = 0;
-					if (j == 0) s0 = atomicAdd(sidctr, (uint32_t)RB3_TENT_BLOCK);
+					if (j == 0) s0 = tent_take_chunk(sidctr, mctr, myctr);
 					s0 = grp_bcast0<LPW>(s0, j);
 					// table full: the records from here on stay unsettled and the host redoes the phase
-					ns = s0 + RB3_TENT_BLOCK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
+					ns = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 				}
 				if (j == 0 && ns != RB3_TENT_POISON) {
 					tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = (uint64_t)(hi - lo) | (uint64_t)c << 16;

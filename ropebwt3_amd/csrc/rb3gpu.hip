@@ -160,6 +160,7 @@ struct rb3gpu_s {
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
 	rb3sort_ws *sorter = nullptr;           // scratch of rb3gpu_bwt_from_text, created on first use
+	int64_t reb_last[2] = {-1, -1}; // groups the first / the last tier of the run-space rebuild handed on in the merge before (-1: unknown)
 	int tent_q = 1;          // masks of 256 * tent_q bits (merge_core doubles it when walkers report intervals wider than that)
 	int64_t sid_dirty[2] = {RB3_TENT_HALF, RB3_TENT_HALF}; // entries of the two halves of the stretch tables (dl) that may be non-zero
 };
@@ -749,21 +750,30 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			const int64_t gw4 = (ngrp + RB3_RG_WAVES - 1) / RB3_RG_WAVES;
 			const unsigned grs = (unsigned)(gw4 < 3072 ? gw4 : 3072), grm = (unsigned)(gw4 < 2048 ? gw4 : 2048);
 			if (rows_per_group <= 96.0) {
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<384, 128, false, false>), dim3(grs), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
-						gstat, (uint4*)h->gslots.p, gkind, glist[1], nglist + 1, skip);
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<624, 320, true, true>), dim3(grm), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
-						gstat, (uint4*)h->gslots.p, gkind, glist[1], nglist + 1, skip);
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<384, 128, false>), dim3(grs), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
+						gstat, (uint4*)h->gslots.p, gkind, (const uint32_t*)nullptr, (const uint32_t*)nullptr, glist[0], nglist, skip);
+				// (what the small tables left: a few hundred groups in a grown pangenome, most of them in its first rounds; the grid for
+				// one and a half times what the merge before left -- the kernel loops over its list whatever the grid)
+				const int64_t g2 = h->reb_last[0] < 0 ? gw4 : (h->reb_last[0] + h->reb_last[0] / 2) / RB3_RG_WAVES + 16;
+				const unsigned gr2 = (unsigned)(g2 < grm ? g2 : grm);
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<624, 320, true>), dim3(gr2), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
+						gstat, (uint4*)h->gslots.p, gkind, (const uint32_t*)glist[0], (const uint32_t*)nglist, glist[1], nglist + 1, skip);
 			} else
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<624, 320, false, true>), dim3(grm), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
-						gstat, (uint4*)h->gslots.p, gkind, glist[1], nglist + 1, skip);
-			const unsigned gw = (unsigned)(nwin / RB3_REB_WAVES + 1 < 8192 ? nwin / RB3_REB_WAVES + 1 : 8192);
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<624, 320, false>), dim3(grm), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
+						gstat, (uint4*)h->gslots.p, gkind, (const uint32_t*)nullptr, (const uint32_t*)nullptr, glist[1], nglist + 1, skip);
+			// the window kernels behind the tiers loop over the last tier's list: grids for one and a half times the list of the merge
+			// before (a launch of thousands of blocks that find nothing to do costs ~5-10 us, three times per round)
+			const int64_t lw = h->reb_last[1] < 0 ? ngrp : h->reb_last[1] + h->reb_last[1] / 2 + 8; // groups
+			const int64_t gwn = lw * RB3_GRP_WINS / RB3_REB_WAVES + 1;
+			const unsigned gw = (unsigned)(gwn < 8192 ? gwn : 8192);
+			const unsigned gl = (unsigned)(lw < 4096 ? lw : 4096);
 			if (n2 * RB3_WIN > 3 * ntot)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 7, true>), dim3(gw), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
 						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap);
 			else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 3, true>), dim3(gw), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
 						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap);
-			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_decide<true>), dim3(ngrp < 4096 ? (unsigned)ngrp : 4096u), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip,
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_decide<true>), dim3(gl), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip,
 					(const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, (unsigned long long*)h->misc.p + MISC_RG_OVER);
 		} else {
 			const dim3 g1w((unsigned)((nwin + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), b1w(64 * RB3_REB_WAVES);
@@ -798,7 +808,8 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		if ((r = ib_ensure(h, dst, ngrp, *onslots)) < 0) return r;
 	}
 	if (winpar && runspace) {
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<true>), dim3(ngrp < 4096 ? (unsigned)ngrp : 4096u), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
+		const int64_t lw2 = h->reb_last[1] < 0 ? ngrp : h->reb_last[1] + h->reb_last[1] / 2 + 8; // (as above: the grid for the list the merge before left)
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<true>), dim3(lw2 < 4096 ? (unsigned)lw2 : 4096u), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
 				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap);
 		hipLaunchKernelGGL(k_place, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, h->st, (const uint8_t*)gkind, (const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot,
 				(const uint4*)h->gslots.p, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, nwin, ntot, skip, (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap);
@@ -1544,8 +1555,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			h->stt.ms_build += ev_ms(h->ev[4], h->ev[5]);
 			h->stt.n_reb_again += 1;
 		}
-		if (ran_runspace) // the run-space rebuild ran: how many groups it handed to the window kernels
+		if (ran_runspace) { // the run-space rebuild ran: how many groups it handed to the window kernels
 			h->stt.n_reb_groups += ngrp, h->stt.n_reb_groups_window += (int64_t)(hm[MISC_RG_LISTS] >> 32);
+			h->reb_last[0] = (int64_t)(hm[MISC_RG_LISTS] & 0xFFFFFFFFull), h->reb_last[1] = (int64_t)(hm[MISC_RG_LISTS] >> 32); // (the next rebuild sizes its grids by them)
+		} else h->reb_last[0] = h->reb_last[1] = -1;
 		for (int a = 0; a <= 6; ++a)
 			if (acc[a] != h->acc[a] + acc2[a]) {
 				if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] the rebuilt index counts %lld symbols below %d, expected %lld\n", (long long)acc[a], a, (long long)(h->acc[a] + acc2[a]));

@@ -1301,8 +1301,15 @@ __global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t
 			kb = kbn, lo = lo_n, hi = hi_n, gap = gap_n;
 		} while (__all(active));
 	}
-	if (j == 0) atomicAdd(nsteps, (unsigned long long)steps);
-	if (TENT && LIST && j == 0 && nwide) atomicAdd(nsteps + 38, (unsigned long long)nwide); // misc[39] (MISC_WIDE): see merge_core (the width of the masks follows it)
+	{ // one atomic per wave, not per octet (they all go to the same word, and the kernel is over when the last one has landed)
+		unsigned long long tot = 0, totw = 0;
+		for (int o = 0; o < octs; ++o) {
+			tot += (uint32_t)__builtin_amdgcn_readlane((int)steps, o * LPW);
+			if (TENT && LIST) totw += (uint32_t)__builtin_amdgcn_readlane((int)nwide, o * LPW);
+		}
+		if (lane == 0) atomicAdd(nsteps, tot);
+		if (TENT && LIST && lane == 0 && totw) atomicAdd(nsteps + 38, totw); // misc[39] (MISC_WIDE): see merge_core
+	}
 #ifdef RB3_PROF_STEP
 	if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(nsteps + 33 + q, (unsigned long long)prof_t[q]); // misc[34..38]
 	if (lane == 0) atomicAdd(nsteps + 8, (unsigned long long)prof_t[5]), atomicAdd(nsteps + 9, (unsigned long long)prof_t[6]); // misc[9], misc[10]
@@ -3310,13 +3317,13 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 	return true;
 }
 
-/* gkind[g]: 0 = rebuilt in run space (slots in the scratch, placed by k_place), 1 = not yet (the next tier, or the window
- * kernels).  CHECK: a later tier: only the groups an earlier one left (gkind[g] == 1).  LAST: the groups this tier cannot
- * do either are appended to lout (counter nlout) for the LISTED window kernels, a wave's failures with one atomic. */
-template<int RMAX, int NBMAX, bool CHECK, bool LAST>
+/* gkind[g]: 0 = rebuilt in run space (slots in the scratch, placed by k_place), 1 = not (the window kernels write it).  The groups a
+ * tier cannot do are appended to lout (counter nlout), a wave's failures with one atomic: the list of the next tier (FROMLIST: a
+ * small grid over lin[0 .. *nlin) instead of a look at every group), then of the LISTED window kernels. */
+template<int RMAX, int NBMAX, bool FROMLIST>
 __global__ void __launch_bounds__(64 * RB3_RG_WAVES, RMAX <= 384 ? 5 : 3) k_reb_group( // (waves per SIMD the LDS of the tier allows: registers must not be what limits them)
 		IdxView old, const int64_t *pos, const uint8_t *b2, int64_t ntot, const int64_t *jw, int64_t ngrp,
-		uint32_t *gstat, uint4 *gslots, uint8_t *gkind, uint32_t *lout, uint32_t *nlout, const unsigned long long *skip)
+		uint32_t *gstat, uint4 *gslots, uint8_t *gkind, const uint32_t *lin, const uint32_t *nlin, uint32_t *lout, uint32_t *nlout, const unsigned long long *skip)
 {
 	__shared__ RebLds<RMAX, NBMAX> lds_[RB3_RG_WAVES];
 	if (RB3_REB_SKIP(skip)) return;
@@ -3324,28 +3331,28 @@ __global__ void __launch_bounds__(64 * RB3_RG_WAVES, RMAX <= 384 ? 5 : 3) k_reb_
 	RebLds<RMAX, NBMAX> &L = lds_[wave];
 	const int64_t ustep = (int64_t)gridDim.x * RB3_RG_WAVES;
 	const int64_t full = ntot >> RB3_GRP_BITS; // groups 0 .. full-1 are whole
-	int64_t g = (int64_t)blockIdx.x * RB3_RG_WAVES + wave;
+	const int64_t nunits = FROMLIST ? (int64_t)*nlin : ngrp; // FROMLIST: the groups the tier before left (lin[0 .. *nlin)), else all groups
+	int64_t u = (int64_t)blockIdx.x * RB3_RG_WAVES + wave;
 	int64_t jn0 = 0, jn1 = 0; // the row range of the next group of this wave, requested one iteration ahead
-	uint32_t kn = 1;
-	if (g < full) jn0 = jw[g * RB3_GRP_WINS], jn1 = jw[(g + 1) * RB3_GRP_WINS];
-	if (CHECK && g < ngrp) kn = gkind[g];
+	if (!FROMLIST && u < full) jn0 = jw[u * RB3_GRP_WINS], jn1 = jw[(u + 1) * RB3_GRP_WINS];
 	int nfail = 0;
 #ifdef RB3_PROF_REB
 	unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-	for (; g < ngrp; g += ustep) {
-		const int64_t j0 = jn0, j1 = jn1;
-		const uint32_t kind = kn;
-		if (g + ustep < full) jn0 = jw[(g + ustep) * RB3_GRP_WINS], jn1 = jw[(g + ustep + 1) * RB3_GRP_WINS];
-		if (CHECK && g + ustep < ngrp) kn = gkind[g + ustep];
-		if (CHECK && kind == 0) continue;
+	for (; u < nunits; u += ustep) {
+		int64_t g = u, j0 = jn0, j1 = jn1;
+		if (FROMLIST) {
+			g = (int64_t)lin[u];
+			j0 = j1 = 0;
+			if (g < full) j0 = jw[g * RB3_GRP_WINS], j1 = jw[(g + 1) * RB3_GRP_WINS];
+		} else if (u + ustep < full) jn0 = jw[(u + ustep) * RB3_GRP_WINS], jn1 = jw[(u + ustep + 1) * RB3_GRP_WINS];
 #ifdef RB3_PROF_REB
 		const bool ok = reb_group_one<RMAX, NBMAX>(old, pos, b2, ntot, j0, j1, g, lane, L, gstat, gslots, tacc);
 #else
 		const bool ok = reb_group_one<RMAX, NBMAX>(old, pos, b2, ntot, j0, j1, g, lane, L, gstat, gslots);
 #endif
-		if (!CHECK || ok) { if (lane == 0) gkind[g] = ok ? 0 : 1; }
-		if (LAST && !ok) {
+		if (lane == 0) gkind[g] = ok ? 0 : 1;
+		if (!ok) { // handed on: to the next tier's list, a wave's failures with one atomic
 			if (lane == 0) L.fail[nfail] = (uint32_t)g;
 			if (++nfail == RB3_RG_FAILBUF) {
 				wave_sync();
@@ -3358,7 +3365,7 @@ __global__ void __launch_bounds__(64 * RB3_RG_WAVES, RMAX <= 384 ? 5 : 3) k_reb_
 		}
 		wave_sync();
 	}
-	if (LAST && nfail > 0) {
+	if (nfail > 0) {
 		wave_sync();
 		uint32_t o = 0;
 		if (lane == 0) o = atomicAdd(nlout, (uint32_t)nfail);

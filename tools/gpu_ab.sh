@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: A/B of library variants on the headline leg:  tools/gpu_ab.sh name1 name2 ...   (ropebwt3_amd/prof/NAME.so; "release" = the in-tree library)
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in "$@"; do
 	if [ "$v" = release ]; then unset RB3GPU_LIB; else export RB3GPU_LIB=$R/ropebwt3_amd/prof/$v.so; fi
 	timeout 300 python bench.py --only headline --steps ${STEPS:-3} --warmup 1 ${BENCH_ARGS:-} > gpurun_out/ab.json 2> gpurun_out/ab.err || tail -3 gpurun_out/ab.err

@@ -9,6 +9,6 @@ LINES_OUT=45 bash tools/prof_bench.sh r3_mtb152 --only headline --steps 1 --warm
 bash tools/pmc_headline.sh r3_mtb152 "k_chain|k_reb_group|k_events|k_pos_finalize" k_chain_mtb152 "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
 	"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
 	"SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH" > /dev/null 2>&1
-python tools/prof_summary.py traffic_k $R/gpurun_out/prof/r3_mtb152_counters.txt > /dev/null 2>&1
+python tools/pmc_json.py $R/gpurun_out/prof/r3_mtb152_counters.txt $R/gpurun_out/prof/r3_mtb152_pmc_k_chain_mtb152.json
 head -50 gpurun_out/prof/r3_mtb152_counters.txt | cut -c1-120
 cat gpurun_out/prof/r3_mtb152_pmc_k_chain_mtb152.json

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""profiles/r3_pmc_k_chain_mtb152.json (what bench.py reads as roofline.traffic) from the per-kernel counter table of
+tools/pmc_headline.sh:   python tools/pmc_json.py gpurun_out/prof/r3_mtb152_counters.txt profiles/r3_pmc_k_chain_mtb152.json"""
+import json, re, sys
+rows = {}
+for l in open(sys.argv[1]):
+    m = re.match(r"(k_chain<list,mixed,tent>)\s+(\S+)\s+calls\s+(\d+)\s+avg\s+([0-9.]+)", l)
+    if m:
+        rows[m.group(2)] = (int(m.group(3)), float(m.group(4)))
+f, w = rows["FETCH_SIZE"], rows["WRITE_SIZE"]
+out = {
+    "kernel": "k_chain<list,mixed,tent,text> on the mtb152 headline (bench.py --only headline; %d launches)" % f[0],
+    "dispatches": f[0], "FETCH_SIZE_KB_per_launch": f[1], "WRITE_SIZE_KB_per_launch": w[1],
+    "hbm_bytes_per_launch": int((2 * f[1] + w[1]) * 1024),
+    "TCC_HIT_per_launch": rows.get("TCC_HIT_sum", (0, None))[1], "TCC_MISS_per_launch": rows.get("TCC_MISS_sum", (0, None))[1],
+    "TCC_EA0_RDREQ_per_launch": rows.get("TCC_EA0_RDREQ_sum", (0, None))[1],
+    "correction": "MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 (an upper bound: smaller requests are not halved); WRITE_SIZE as reported. The index (<= 96 MB) fits the Infinity Cache, whose hits these memory-side counters include: this is traffic behind the L2, not DRAM traffic.",
+    "source": "tools/pmc_headline.sh (separate --pmc passes, --kernel-trace only); all counters of the passes: profiles/r3_mtb152_counters.txt",
+}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(out["hbm_bytes_per_launch"])

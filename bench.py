@@ -188,7 +188,7 @@ def parse_cli_stats(err):
 # ---------------------------------------------------------------------------------------------
 
 MTB_L = 4400000
-WALKER_STEP = 384
+WALKER_STEP = 0      # 0: rb3gpu_walker_step (as many walkers as k_chain keeps resident: 220 text positions for a 4.4 Mbp genome on an MI355X)
 
 
 def mtb_manifest(K, L):
@@ -204,11 +204,11 @@ def mtb_files(K, L, tmp=None):
     return tmp, files, time.time() - t
 
 
-def load_batches(files, pinned=True, step=WALKER_STEP):
+def load_batches(files, pinned=True, step=WALKER_STEP, device=0):
     """every file through the CLI's own reader (rb3h_seq_read: nt6, both strands, sentinels; io.c:104-125), one batch per
     file, into page-locked memory (what `ropebwt3-amd build` does with rb3gpu_pinned_alloc) + the walker list of each batch
-    (one walker per string + one per 384 text positions, rb3h_walkers_text).  Not timed: file I/O is outside the metric."""
-    from ropebwt3_amd import PinnedArray, host
+    (one walker per string + one per rb3gpu_walker_step text positions -- 220 for these genomes --, rb3h_walkers_text).  Not timed: file I/O is outside the metric."""
+    from ropebwt3_amd import PinnedArray, host, walker_step
     texts, walkers, keep = [], [], []
     for fn in files:
         parts = list(host.read_batches(fn, False, 1 << 40))
@@ -220,7 +220,7 @@ def load_batches(files, pinned=True, step=WALKER_STEP):
             keep.append(pa)
             t = pa.array
         texts.append(t)
-        w = host.walkers_text(t, step)
+        w = host.walkers_text(t, step if step > 0 else walker_step(device, t.size, n_seq))
         if pinned:  # the list goes to the device inside the merge call: from page-locked memory that is one DMA, no staging copy on the host
             pw = PinnedArray(w.nbytes)
             wv = pw.array.view(np.int64).reshape(w.shape)
@@ -378,12 +378,12 @@ def cli_build(files, K, gold):
 def cfg2_step(local_rank, steps, warmup, genome_len, div):
     """BASELINE configs[1] (the headline of rounds 1-2): one genome merged into the index of one, through the entry point with
     the reference's signature (BWT only) and through the one the CLI uses (BWT + inverse suffix array from the GPU sorter)"""
-    from ropebwt3_amd import Rb3Gpu, host
+    from ropebwt3_amd import Rb3Gpu, host, walker_step
     from tests import util
     g0, gs = gen_genomes(genome_len, div, 1, [2])
     b1 = host.build_bwt(util.make_text([g0]))
     text2 = util.make_text(gs)
-    w_text = host.walkers_text(text2, WALKER_STEP)
+    w_text = host.walkers_text(text2, WALKER_STEP if WALKER_STEP > 0 else walker_step(0, text2.size, 2))
     h = Rb3Gpu(device=local_rank, verbose=1)
     h.from_plain(b1)
     d_b2s, d_tw = h.sort_text(text2)
@@ -485,7 +485,7 @@ def main():
         print(json.dumps(cli_build(files, K, gold)), flush=True)
         return
     t0 = time.time()
-    texts, walkers, keep = load_batches(files, pinned=not args.no_pinned, step=args.walker_step)
+    texts, walkers, keep = load_batches(files, pinned=not args.no_pinned, step=args.walker_step, device=local_rank)
     nsym_all = int(sum(t.size for t in texts))
     log("mtb%d: %d files generated in %.1f s, read into %s memory in %.1f s (%d symbols)" % (K, K, t_gen, "pageable" if args.no_pinned else "page-locked", time.time() - t0, nsym_all))
 

@@ -396,8 +396,10 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 	batch_t *b;
 	int64_t n_walkers = 0;
 	rb3h_walker_t *walkers = 0;
-	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : 384;
+	/* walkers inside long strings: as many as the walker kernel keeps resident on the GPU (rb3gpu_walker_step), or every 2^k positions (-k) */
+	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : rb3gpu_walker_step(opt->device, seq->l, n_seq);
 	int r;
+	if (step < 192 && opt->split_log2 <= 0) step = 384; /* (no such device: the merge will say so) */
 	if (step < (seq->l >> 20)) step = seq->l >> 20; /* at most ~2^20 walkers per batch: the engine's stretch table is finite */
 	if (opt->gpu_sort && seq->l < opt->gpu_sort_limit) { /* the GPU sorts (its sorter handles < 2^31 symbols; batches are cut to fit, see batch_cut) */
 		b = (batch_t*)calloc(1, sizeof(batch_t)); /* (counted in g_sorted where the sort really happens: below, or in process_batch) */

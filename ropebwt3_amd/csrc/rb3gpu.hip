@@ -1202,7 +1202,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const double kest = h->nslots > 0 ? (double)h->n / ((double)h->nslots * 32.0) : 1.0;
 	auto events_at = [&](double W) { return (double)len / W * ((kest < 1.0 ? 1.0 : kest) * (1.0 - exp(-W / 1000.0)) + (double)RB3_TENT_CHUNK); };
 	const double tent_room = 0.6 * (double)RB3_TENT_HALF;
-	int64_t b2W = RB3_B2_W;
+	int64_t b2W = rb3gpu_walker_step(h->dev, len, 0); // (as many walkers as k_chain keeps resident; at least RB3_B2_W / 2 apart)
+	if (b2W < RB3_B2_W / 2) b2W = RB3_B2_W;
 	while (len / b2W > (1 << 18) || (h->tn.tent && thin == 1 && events_at((double)b2W) > tent_room && b2W < len / 256)) b2W *= 2;
 	b2W *= thin;
 	const int64_t b2_nbk = len / b2W + 1, b2_m2cap = len / 64 + 1, b2_nspmax = (len >> b2S) + b2_m2cap + 2;
@@ -2003,6 +2004,23 @@ int rb3gpu_sorter_upload(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text)
 int rb3gpu_sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start)
 {
 	return sorter_upload_fwd(s, len, text, n_pairs, pair_start);
+}
+
+int64_t rb3gpu_walker_step(int device, int64_t len, int64_t n_strings)
+{
+	static int cus[64]; // compute units per device (0: not asked yet)
+	if (device < 0 || device >= 64 || len <= 0) return RB3GPU_EINVAL;
+	int cu = __atomic_load_n(&cus[device], __ATOMIC_RELAXED);
+	if (cu == 0) {
+		if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cu <= 0) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+		__atomic_store_n(&cus[device], cu, __ATOMIC_RELAXED);
+	}
+	// k_chain: 88 registers -> 5 waves per SIMD, 4 SIMDs per compute unit, 8 walkers per wave; a few per cent left free for the
+	// walkers at the string ends (one per string on top of the regular ones) and for strings that do not divide evenly
+	int64_t room = (int64_t)cu * 160 * 31 / 32 - (n_strings > 0 ? n_strings : 0);
+	if (room < 1024) room = 1024;
+	const int64_t step = (len + room - 1) / room;
+	return step < 192 ? 192 : step;
 }
 
 int rb3gpu_sorter_upload_fwd_begin(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start)

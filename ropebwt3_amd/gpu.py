@@ -90,6 +90,7 @@ SYMBOLS = {
     "rb3gpu_sorter_sort_uploaded": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     "rb3gpu_pinned_alloc": (ctypes.c_void_p, [ctypes.c_int64]),
     "rb3gpu_pinned_free": (None, [ctypes.c_void_p]),
+    "rb3gpu_walker_step": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64]),
     "rb3gpu_sorter_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "rb3gpu_from_runs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_from_fmd_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
@@ -135,6 +136,14 @@ def load_library(hooks=False, path=None):
 def _u8(a):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     return a
+
+
+def walker_step(device, length, n_strings, lib=None):
+    """rb3gpu_walker_step: the text distance between the LF walkers of a batch (as many walkers as the walker kernel keeps resident)"""
+    r = load_library(False, lib).rb3gpu_walker_step(int(device), int(length), int(n_strings))
+    if r < 0:
+        raise Rb3GpuError(int(r), "rb3gpu_walker_step")
+    return int(r)
 
 
 class PinnedArray:

@@ -554,7 +554,7 @@ def bench_partition_mtb(args, rank, local_rank, world):
     dist.broadcast_object_list(box, src=0)
     tmp, files = box[0]
     lo, hi = K * rank // world, K * (rank + 1) // world
-    texts, walkers, keep = B.load_batches(files[lo:hi], pinned=not args.no_pinned)
+    texts, walkers, keep = B.load_batches(files[lo:hi], pinned=not args.no_pinned, device=dev_id)
     bl = B.BuildLoop(dev_id)
     link = TreeLink(dist, dev, not shared_gpu, sync=torch.cuda.synchronize)
     zero = torch.zeros(1, device=dev) if not shared_gpu else torch.zeros(1)

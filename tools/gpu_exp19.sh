@@ -1,7 +1,7 @@
 #!/bin/bash
 # walker spacing against k_chain / rank phase on the headline build
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
-for ws in 384 256 192 128 512; do
+for ws in ${WS:-384 256 192 128 512}; do
 	timeout 300 python bench.py --only headline --steps 2 --warmup 1 --walker-step $ws > gpurun_out/exp19.json 2>/dev/null
 	python - "$ws" <<'PY'
 import json, sys

@@ -2017,7 +2017,7 @@ int64_t rb3gpu_walker_step(int device, int64_t len, int64_t n_strings)
 	}
 	// k_chain: 88 registers -> 5 waves per SIMD, 4 SIMDs per compute unit, 8 walkers per wave; a few per cent left free for the
 	// walkers at the string ends (one per string on top of the regular ones) and for strings that do not divide evenly
-	int64_t room = (int64_t)cu * 160 * 31 / 32 - (n_strings > 0 ? n_strings : 0);
+	int64_t room = (int64_t)cu * 160 * 63 / 64 - (n_strings > 0 ? n_strings : 0);
 	if (room < 1024) room = 1024;
 	const int64_t step = (len + room - 1) / room;
 	return step < 192 ? 192 : step;

@@ -938,7 +938,10 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 /* LPW: lanes per walker, 8 (an octet) or 4 (a quad: every lane takes two slices of a slot, and the wave's instruction
  * stream -- what a step costs where the index is run-coded -- serves 16 walkers instead of 8) */
 template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8>
-__global__ void __launch_bounds__(256) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
+#ifndef RB3_CHAIN_WPE
+#define RB3_CHAIN_WPE 1 /* (kernel experiment: waves per SIMD the register allocation must leave room for) */
+#endif
+__global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
 		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX, uint32_t *mctr = nullptr)
 {

@@ -1210,8 +1210,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (auto_list) n_walkers = b2_nbk + b2_m2cap; // capacity of the list; how many are in use stays on the device
 	const int tent_auto = tent;
 	if (per_string) tent = 0; // every walker is exact
-	for (int64_t i = 0; walkers && i < n_walkers; ++i)
-		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) return RB3GPU_EINVAL;
+	// (the entries of a caller's list are checked further down, while the device runs the LF kernels: 40 k entries take the host ~40 us)
 	if (walkers && tent && thin == 1 && n_walkers > 4096) { // (the same estimate for a list the caller made: every t-th walker from the start)
 		int t = 1;
 		while (t < 64 && events_at((double)len / (double)n_walkers * t) > tent_room) t *= 2;
@@ -1272,6 +1271,12 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	h->reb_prepared = true; // (build_index: the counters of the run-space rebuild are clear)
 	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr, rows_filled)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	for (int64_t i = 0; walkers && i < n_walkers; ++i)
+		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) { // not a walker list for this batch: nothing has been walked
+			(void)hipStreamSynchronize(h->st);
+			h->reb_prepared = false;
+			return RB3GPU_EINVAL;
+		}
 #ifdef RB3_PROF_STEP
 	HIPCHK(hipMemsetAsync(misc + 34, 0, 40, h->st));
 #endif

@@ -54,6 +54,7 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
 }
 
 #define RB3H_MIN_SEG 128
+#define RB3H_PREROLL 32 /* = RB3_TENT_MIN_AGE of the engine (rb3gpu_kernels.h) */
 
 /* The walker list of a batch from its sampled inverse suffix array: ckrow[i] = row of the suffix starting at text
  * position i * step (from the host sorter below, or from rb3gpu_bwt_from_text).  text is the batch BEFORE it is
@@ -73,9 +74,15 @@ int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, cons
 		const int64_t e = (const uint8_t*)memchr(text + b, 0, (size_t)(len - b)) - text; /* string j occupies [b, e), sentinel at e */
 		int64_t prev = -1, p;
 		for (p = (b / step + 1) * step; p < e; p += step) { /* multiples of step strictly inside the string */
+			/* By text position (no ckrow) a walker starts RB3H_PREROLL positions to the right of its segment: it cannot record before
+			 * it is that many steps old anyway (k_chain, RB3_TENT_MIN_AGE), so it spends its youth on rows its right neighbour owns
+			 * and reaches its own first row old enough to record it.  Otherwise the left neighbour's first rows stay unrecorded and
+			 * this walker has to go on behind the end of its segment until it meets a record -- the same number of steps, but through
+			 * the kernel's general step, and a few more until the record it runs into has become visible. */
+			int64_t pre = ckrow ? 0 : e - 1 - p < RB3H_PREROLL ? e - 1 - p : RB3H_PREROLL;
 			if (e - p < RB3H_MIN_SEG && e - p < step) continue; /* keep the sentinel walker's own segment long (see k_chain) */
-			w[nw].row = ckrow ? ckrow[p / step] : p, w[nw].ka0 = -1, w[nw].flags = 0;
-			w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : p - prev;
+			w[nw].row = ckrow ? ckrow[p / step] : p + pre, w[nw].ka0 = -1, w[nw].flags = pre << 8; /* (flags >> 8: the part of nsteps outside the segment, for whoever thins the list) */
+			w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : p - prev + pre;
 			prev = p, ++nw;
 		}
 		w[nw].row = ckrow ? j : e, w[nw].ka0 = -2 /* sentinel row: exact, = acc[1] of the index */, w[nw].flags = 0;

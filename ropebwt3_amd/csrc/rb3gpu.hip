@@ -1169,9 +1169,10 @@ static rb3gpu_walker_t *thin_walkers(int64_t n, const rb3gpu_walker_t *w, int th
 	const int64_t INF = INT64_MAX / 2;
 	int64_t k = 0, idx = 0, acc = 0;
 	for (int64_t i = 0; i < n; ++i) {
-		acc = (acc >= INF || w[i].nsteps >= INF) ? INF : acc + w[i].nsteps;
+		const int64_t pre = w[i].flags >> 8; // (rb3h_walkers_text: the walker starts that many positions outside its segment, and nsteps counts them)
+		acc = (acc >= INF || w[i].nsteps >= INF) ? INF : acc + w[i].nsteps - pre;
 		const bool sentinel = w[i].ka0 == RB3GPU_KA_SENTINEL || w[i].ka0 >= 0; // (a walker that knows its insertion point ends a string's group, or is somebody's hand-off: always kept)
-		if (sentinel || idx % thin == thin - 1) { o[k] = w[i], o[k].nsteps = acc, ++k, acc = 0; }
+		if (sentinel || idx % thin == thin - 1) { o[k] = w[i], o[k].nsteps = acc >= INF ? INF : acc + pre, ++k, acc = 0; }
 		idx = sentinel ? 0 : idx + 1;
 	}
 	*n_out = k;

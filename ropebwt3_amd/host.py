@@ -18,7 +18,7 @@ def load_library():
         return _lib
     if not os.path.exists(_build.LIB_HOST):
         raise RuntimeError("%s is missing: run __graft_entry__.build()" % _build.LIB_HOST)
-    L = ctypes.CDLL(_build.LIB_HOST)
+    L = ctypes.CDLL(os.environ.get("RB3HOST_LIB", _build.LIB_HOST))  # (override for experiments only)
     L.rb3h_build_bwt.restype = ctypes.c_int
     L.rb3h_build_bwt.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
     L.rb3h_build_bwt_walkers.restype = ctypes.c_int

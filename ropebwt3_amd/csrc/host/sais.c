@@ -54,7 +54,9 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
 }
 
 #define RB3H_MIN_SEG 128
+#ifndef RB3H_PREROLL
 #define RB3H_PREROLL 32 /* = RB3_TENT_MIN_AGE of the engine (rb3gpu_kernels.h) */
+#endif
 
 /* The walker list of a batch from its sampled inverse suffix array: ckrow[i] = row of the suffix starting at text
  * position i * step (from the host sorter below, or from rb3gpu_bwt_from_text).  text is the batch BEFORE it is

@@ -304,3 +304,38 @@ def test_fmd_writer_wide_block_headers_vs_reference_library(tmp_path, case):
     # and the reader gets the runs back
     out = subprocess.run([os.path.join(os.path.dirname(host.__file__), "ropebwt3-amd"), "recode", "-d", fn_own], stdout=subprocess.PIPE)
     assert out.returncode == 0 and out.stdout == a
+
+
+def test_walker_list_by_text_position_covers_every_row_once():
+    """rb3h_walkers_text: per string one walker at the sentinel and one at every multiple of `step` strictly inside it, in text
+    order; an inner walker starts `flags >> 8` positions (32 = the age from which the engine's walkers record; fewer next to
+    the string's end) to the RIGHT of its segment and its nsteps counts them; the segments of a string tile it exactly; the
+    sentinel walker's own segment is never shorter than 128 steps where the string is that long"""
+    rng = np.random.default_rng(77)
+    seqs = [util.random_genome(rng, n) for n in (5000, 1, 257, 384, 385, 20000, 130, 3)]
+    t = util.make_text(seqs, True, False)
+    ends = np.flatnonzero(t == 0)
+    for step in (192, 220, 384, 1000):
+        w = host.walkers_text(t, step)
+        assert w.shape[1] == 4
+        i = 0
+        b = 0
+        for e in ends:                                    # string [b, e), sentinel at e
+            inner = []
+            while w[i, 1] != -2:                          # inner walkers of this string come first, left to right
+                inner.append(w[i]); i += 1
+            sent = w[i]; i += 1
+            assert sent[0] == e and sent[3] == 0
+            prev = None
+            for row, ka0, nsteps, flags in inner:
+                pre = flags >> 8
+                p = row - pre
+                assert ka0 == -1 and flags & 0xFF == 0 and 0 <= pre <= 32 and p % step == 0 and b < p < e and row < e
+                assert pre == min(32, e - 1 - p)
+                assert nsteps == (np.iinfo(np.int64).max // 2 if prev is None else p - prev + pre)
+                prev = p
+            assert sent[2] == (np.iinfo(np.int64).max // 2 if prev is None else e - prev)
+            if prev is not None:
+                assert e - prev >= min(128, step)
+            b = e + 1
+        assert i == w.shape[0]

@@ -1148,3 +1148,24 @@ def test_duplicate_genome_long_settle_paths(oracle, tent_q):
         assert np.array_equal(h.export_plain(), oracle.merge(want, host.build_bwt(t2.copy()))), nrel
         assert h.stats()["n_fallbacks"] == 0
         h.close()
+
+
+@pytest.mark.gpu
+def test_walker_step_is_the_resident_capacity_of_the_walker_kernel():
+    """rb3gpu_walker_step: len / (compute units x 160 walkers x 63/64 - strings), never below 192; the list made with it has no
+    more walkers than the kernel keeps resident, so every octet gets one walker and none waits for another to finish"""
+    import torch
+    from ropebwt3_amd import walker_step, host
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    cap = cus * 160
+    assert walker_step(0, 1000, 2) == 192 and walker_step(0, 192 * (cap * 63 // 64 - 2), 2) == 192
+    for length, n_str in ((8800002, 2), (200000002, 2), (3000000, 64), (cap * 500, 1000)):
+        s = walker_step(0, length, n_str)
+        assert s >= 192 and length / s + n_str <= cap
+        assert s == 192 or length / (s - 1) + n_str > cap * 63 // 64          # not wider than needed
+    rng = np.random.default_rng(5)
+    t = util.make_text([util.random_genome(rng, 2000000)])
+    w = host.walkers_text(t, walker_step(0, t.size, 2))
+    assert w.shape[0] <= cap and w.shape[0] >= t.size // 192 // 2 or walker_step(0, t.size, 2) > 192
+    with pytest.raises(Exception):
+        walker_step(99, 1000, 1)

@@ -133,7 +133,7 @@ struct rb3gpu_s {
 	Tune tn;
 	hipStream_t st = nullptr;
 	hipStream_t st2 = nullptr;  // side stream: the sampled LF check of pos[] runs beside the rebuild
-	hipEvent_t evx[2];
+	hipEvent_t evx[3];
 	rb3gpu_opt_t opt;
 	rb3gpu_stats_t stt;
 	// the index: grp/slots point into ib[cur]; a merge builds into ib[1-cur] and swaps on commit
@@ -145,7 +145,7 @@ struct rb3gpu_s {
 	// (behind the grp_cap directory entries of a buffer sit grp_cap 8-byte words: the compact copy of the entries' slot words, IdxView.gsm)
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, pos, tcnt, tpre, ctot, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist;
+	Buf b2, pos, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -467,7 +467,7 @@ rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
 	if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
 	for (int i = 0; i < 8; ++i)
 		if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return nullptr; }
-	for (int i = 0; i < 2; ++i)
+	for (int i = 0; i < 3; ++i)
 		if (hipEventCreateWithFlags(&h->evx[i], hipEventDisableTiming) != hipSuccess) { delete h; return nullptr; }
 	h->t0 = now_s();
 	return h;
@@ -518,14 +518,14 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exac
 static void guard_check(rb3gpu_t *h, const char *where)
 {
 	if (!h->tn.guard) return;
-	static const char *names[] = { "b2", "pos", "tcnt", "tpre", "ctot", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
-	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	static const char *names[] = { "b2", "pos", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
+	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	uint8_t g[RB3_GUARD];
-	for (int i = 0; i < 18 + 4; ++i) {
+	for (int i = 0; i < 19 + 4; ++i) {
 		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
-		if (i < 18) p = (const uint8_t*)all[i]->p, cap = all[i]->cap, name = names[i];
-		else if (i < 20) p = (const uint8_t*)h->ib[i - 18].grp, cap = h->ib[i - 18].grp_cap * RB3_GRP_ALLOC, name = "index directory";
-		else p = (const uint8_t*)h->ib[i - 20].slots, cap = h->ib[i - 20].slots_cap * sizeof(rb3_slot_t), name = "index slots";
+		if (i < 19) p = (const uint8_t*)all[i]->p, cap = all[i]->cap, name = names[i];
+		else if (i < 21) p = (const uint8_t*)h->ib[i - 19].grp, cap = h->ib[i - 19].grp_cap * RB3_GRP_ALLOC, name = "index directory";
+		else p = (const uint8_t*)h->ib[i - 21].slots, cap = h->ib[i - 21].slots_cap * sizeof(rb3_slot_t), name = "index slots";
 		if (!p) continue;
 		if (cap == 0) cap = 256;
 		if (hipMemcpy(g, p + cap, RB3_GUARD, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -559,11 +559,11 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
-	for (int i = 0; i < 2; ++i) (void)hipEventDestroy(h->evx[i]);
+	for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->evx[i]);
 	(void)hipStreamDestroy(h->st2);
 	for (int i = 0; i < 2; ++i) if (h->stage[i]) (void)hipHostFree(h->stage[i]);
 	rb3sort_destroy(h->sorter);
@@ -573,18 +573,21 @@ void rb3gpu_destroy(rb3gpu_t *h)
 
 /* exclusive scan of nrec records of 8 x u32 -> 8 x u64 (7 columns used).  The 8 totals are left in
  * device memory at `dtot_keep`; if `total` is not NULL they are also copied to the host (one sync). */
-static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t *out, uint64_t *dtot_keep, uint64_t total[8])
+/* side: on the handle's side stream, with chunk totals of its own (the batch's scan beside the walkers, see merge_core) */
+static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t *out, uint64_t *dtot_keep, uint64_t total[8], bool side = false)
 {
 	const int64_t nchunk = (nrec + RB3_SCAN_CHUNK - 1) / RB3_SCAN_CHUNK;
+	Buf &cb = side ? h->ctot2 : h->ctot;
+	hipStream_t st = side ? h->st2 : h->st;
 	int r;
-	if ((r = buf_ensure(h, h->ctot, (size_t)(nchunk + 1) * 64)) < 0) return r;
-	uint64_t *ctot = (uint64_t*)h->ctot.p;
-	hipLaunchKernelGGL(k_scan_chunk_totals, dim3((unsigned)nchunk), dim3(256), 0, h->st, in, nrec, ctot);
-	hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(256), 0, h->st, ctot, nchunk, dtot_keep);
-	hipLaunchKernelGGL(k_scan_records, dim3((unsigned)nchunk), dim3(256), 0, h->st, in, nrec, (const uint64_t*)ctot, out);
+	if ((r = buf_ensure(h, cb, (size_t)(nchunk + 1) * 64)) < 0) return r;
+	uint64_t *ctot = (uint64_t*)cb.p;
+	hipLaunchKernelGGL(k_scan_chunk_totals, dim3((unsigned)nchunk), dim3(256), 0, st, in, nrec, ctot);
+	hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(256), 0, st, ctot, nchunk, dtot_keep);
+	hipLaunchKernelGGL(k_scan_records, dim3((unsigned)nchunk), dim3(256), 0, st, in, nrec, (const uint64_t*)ctot, out);
 	if (total) {
-		HIPCHK(hipMemcpyAsync(total, dtot_keep, 64, hipMemcpyDeviceToHost, h->st));
-		HIPCHK(hipStreamSynchronize(h->st));
+		HIPCHK(hipMemcpyAsync(total, dtot_keep, 64, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
 	}
 	return 0;
 }
@@ -840,17 +843,18 @@ static void index_install(rb3gpu_t *h, int64_t ngrp, int64_t nslots, int64_t nto
 
 /* histogram + row words of B2 (LF word of every row, fm-index.c:206-216) into d_row.  Totals stay on the device (misc[MISC_LF_TOT..]); acc2 != NULL also
  * brings the C array of B2 to the host (one sync) and checks the symbols (fm-index.c:124-125). */
-static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_row, int64_t *acc2, bool words = true, bool rows_filled = false)
+static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_row, int64_t *acc2, bool words = true, bool rows_filled = false, bool side = false)
 {
+	hipStream_t st = side ? h->st2 : h->st; // (side: only with words = false and rows_filled = true, i.e. nothing but the histogram and its scan)
 	const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
 	int r;
 	if ((r = buf_ensure(h, h->tcnt, (size_t)ntile * 32)) < 0) return r;
 	if ((r = buf_ensure(h, h->tpre, (size_t)ntile * 64)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	uint64_t *dtot = (uint64_t*)h->misc.p + MISC_LF_TOT;
-	hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)ntile), dim3(256), 0, h->st, d_b2, len, (uint32_t*)h->tcnt.p);
+	hipLaunchKernelGGL(k_tile_hist, dim3((unsigned)ntile), dim3(256), 0, st, d_b2, len, (uint32_t*)h->tcnt.p);
 	uint64_t total[8];
-	if ((r = scan_records(h, (const uint32_t*)h->tcnt.p, ntile, (uint64_t*)h->tpre.p, dtot, acc2 ? total : nullptr)) < 0) return r;
+	if ((r = scan_records(h, (const uint32_t*)h->tcnt.p, ntile, (uint64_t*)h->tpre.p, dtot, acc2 ? total : nullptr, side)) < 0) return r;
 	if (acc2) {
 		if (total[6] != 0) return RB3GPU_ESYMBOL;
 		acc2[0] = 0;
@@ -1270,7 +1274,14 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (rows_filled) fill_add(&jb, h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
 	fill_launch(h, jb);
 	h->reb_prepared = true; // (build_index: the counters of the run-space rebuild are clear)
-	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr, rows_filled)) < 0) return r;
+	// The histogram of the batch and its scan (the C array of B2 and the rows before every tile, fm-index.c:206-216): a text-order walk
+	// does not read them -- the validation behind it and the host do --, so they run on the side stream, beside the walkers.
+	const bool lf_beside = rows_filled && !auto_list;
+	if (lf_beside) {
+		if ((r = buf_ensure(h, h->ctot2, (size_t)(((len + RB3_TILE - 1) / RB3_TILE + RB3_SCAN_CHUNK - 1) / RB3_SCAN_CHUNK + 1) * 64)) < 0) return r; // (before any launch)
+	}
+	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr, rows_filled, lf_beside)) < 0) return r;
+	if (lf_beside) HIPCHK(hipEventRecord(h->evx[2], h->st2));
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
 	for (int64_t i = 0; walkers && i < n_walkers; ++i)
 		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) { // not a walker list for this batch: nothing has been walked
@@ -1394,6 +1405,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (h->tn.corrupt_pos) hipLaunchKernelGGL(k_test_corrupt, dim3((unsigned)(len / 6 / 256 + 1)), dim3(256), 0, h->st, dpos, len);
 #endif
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
+	if (lf_beside) HIPCHK(hipStreamWaitEvent(h->st, h->evx[2], 0)); // (long done: the validation and the host read the batch's totals)
 	const bool lf_side = launch_lf_check(h, (const int64_t*)dpos, d_b2, len, true);
 	int64_t ngrp = 0, nslots = 0, acc[7];
 	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) return r;

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 P=$R/gpurun_out/prof
 mkdir -p $P
 cd /tmp
-BENCH="python $R/bench.py --only headline --steps 1 --warmup 0 ${BENCH_ARGS:-}"
+BENCH="python $R/bench.py --only ${LEG:-headline} ${BENCH_STEPS:---steps 1 --warmup 0} ${BENCH_ARGS:-}"
 i=0
 : > $P/${TAG}_counters.txt
 for grp in "$@"; do

@@ -138,13 +138,13 @@ def large_index_regime(h_factory, n_index, n_reads, seed=21):
     m = rng.random(r.shape) < 0.01
     r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
     t2 = util.make_text(list(r))
-    d, d_tw = h.sort_text(t2)
-    h.merge_text_dev(d, d_tw, t2.size, 2 * n_reads, commit=False)
+    d, d_tw, d_sa = h.sort_text_sa(t2)          # (+ the suffix array: records in text order, gathered by the validation pass)
+    h.merge_text_dev(d, d_tw, t2.size, 2 * n_reads, commit=False, d_sa=d_sa)
     h.stats_reset()
     reps = 3
     t = time.perf_counter()
     for _ in range(reps):
-        h.merge_text_dev(d, d_tw, t2.size, 2 * n_reads, commit=False)
+        h.merge_text_dev(d, d_tw, t2.size, 2 * n_reads, commit=False, d_sa=d_sa)
     dt = (time.perf_counter() - t) / reps
     st_ = h.stats()
     ms_chain = st_["ms_chain"] / reps
@@ -153,9 +153,16 @@ def large_index_regime(h_factory, n_index, n_reads, seed=21):
            "phases_ms_per_step": {"lf": round(st_["ms_lf"] / reps, 3), "rank": round(st_["ms_rank"] / reps, 3), "rebuild": round(st_["ms_build"] / reps, 3)},
            "rebuild_streaming": {"bytes_per_step": int(st_["bytes_rebuild"] // reps), "GB/s": round(st_["bytes_rebuild"] / max(1e-9, st_["ms_build"]) / 1e6, 1),
                                  "frac": round(st_["bytes_rebuild"] / max(1e-9, st_["ms_build"]) / 1e6 / HBM_PEAK_GBS, 4)},
-           "roofline": chain_roofline(t2.size, ms_chain, "text", load_pmc_traffic("k_chain_large"), "every slot read comes from HBM (index >> 256 MB of L2 + Infinity Cache)")}
+           "roofline": dict(chain_roofline(t2.size, st_["ms_rank"] / reps, "text", None,
+                                           "every slot read comes from HBM (index >> 256 MB of L2 + Infinity Cache).  Priced over the RANK PHASE, not k_chain alone: the walkers leave their "
+                                           "records in text order (one 64-byte store per 8 steps) and the validation pass gathers them into row order through the batch's suffix array "
+                                           "(rb3gpu_merge_text_sa_dev), so the 16 B of row traffic per step of SURVEY 8(d) are spent in k_pos_finalize_check_rows; k_chain alone: k_chain_ms_per_launch. "
+                                           "With a record per row (RB3GPU_TREC=0: rounds 1-2 and most of 3) the walk took 16.6-18.2 ms and the phase 18.4-20.7"),
+                            kernel="k_chain + k_pos_finalize_check_rows (the rank phase)", k_chain_ms_per_launch=round(ms_chain, 4),
+                            traffic_k_chain_with_a_record_per_row=load_pmc_traffic("k_chain_large"))}
     h.dev_free(d)
     h.dev_free(d_tw)
+    h.dev_free(d_sa)
     h.close()
     return out
 
@@ -272,7 +279,7 @@ class BuildLoop:
             if uploaded != i:
                 upload(i)
             b = time.perf_counter()
-            d_bwt, d_tw = srt.sort_uploaded(t.size)         # (synchronous)
+            d_bwt, d_tw, d_sa = srt.sort_uploaded_sa(t.size)   # (synchronous; the suffix array rides along for the engine to use where it pays)
             c = time.perf_counter()
             if i == 0 and first_is_index:
                 if overlap and n > 1:
@@ -285,7 +292,7 @@ class BuildLoop:
                     upload(i + 1, True)                     # queued on the sorter's stream: returns at once
                     uploaded = i + 1
                 c1 = time.perf_counter()
-                h.merge_text_dev(d_bwt, d_tw, t.size, w, commit=True)   # one synchronisation, at its end
+                h.merge_text_dev(d_bwt, d_tw, t.size, w, commit=True, d_sa=d_sa)   # one synchronisation, at its end
                 d = time.perf_counter()
                 if overlap and i + 1 < n:
                     srt.upload_end()                        # what the copy engine still has to do shows up here

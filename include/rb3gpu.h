@@ -216,6 +216,12 @@ int rb3gpu_ssa_gen(rb3gpu_t *h, int ssa_shift, uint64_t *r2i, uint64_t *ssa);
  * d_bwt: len bytes, d_tw: len 64-bit words, both device memory.  rb3gpu_mg_rank_text_dev: the rank phase alone
  * (pos[] as in rb3gpu_mg_rank_plain), for parity tests. */
 int rb3gpu_merge_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit);
+/* the same for a caller that also has the batch's suffix array (d_sa[i] = text position of the suffix of row i, len x u32 of device
+ * memory: the GPU sorter's rb3gpu_sorter_sort[_uploaded]_sa / rb3gpu_sort_text_sa leave it behind the text-order words).  The
+ * walkers may then leave their records in text order -- eight consecutive words per store instead of eight random rows -- and the
+ * validation pass gathers them into row order through d_sa: what an index that lives in HBM wants (a batch of reads into a large
+ * index: the record stores are two thirds of the walk).  d_sa == NULL: rb3gpu_merge_text_dev.  Same result either way. */
+int rb3gpu_merge_text_sa_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, const uint32_t *d_sa, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit);
 int rb3gpu_mg_rank_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1]);
 
 /* Partial BWT of one batch on the GPU, instead of rb3_build_sais on the host (sais-ss.c:10-56; libsais in GSA
@@ -228,6 +234,8 @@ int rb3gpu_mg_rank_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, cons
 int rb3gpu_bwt_from_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow);
 /* the same, with the text-order words of the batch (len 64-bit words of device memory) for rb3gpu_merge_text_dev */
 int rb3gpu_sort_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, uint64_t *d_tw);
+/* ... and the suffix array (len x u32 of device memory) for rb3gpu_merge_text_sa_dev */
+int rb3gpu_sort_text_sa(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, uint64_t *d_tw, uint32_t *d_sa);
 
 /* The same sorter as an object of its own (own HIP stream and scratch, independent of any index handle), so that a
  * host thread can sort batch i+1 while another merges batch i -- the pipeline of build.c:55-83, 186-201 with both
@@ -258,6 +266,9 @@ int rb3gpu_sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *tex
 int rb3gpu_sorter_upload_fwd_begin(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, int64_t n_pairs, const int64_t *pair_start);
 int rb3gpu_sorter_upload_end(rb3gpu_sorter_t *s);
 int rb3gpu_sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw);
+/* the same with the suffix array (*d_sa: len x u32 behind the text-order words in the same output buffer, released with *d_bwt) */
+int rb3gpu_sorter_sort_uploaded_sa(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw, void **d_sa);
+int rb3gpu_sorter_sort_sa(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, void **d_tw, void **d_sa);
 /* cumulative times of a sorter: text upload (host -> HBM, through its pinned staging buffer) and suffix sorting proper */
 int rb3gpu_sorter_stats(const rb3gpu_sorter_t *s, double *ms_upload, double *ms_sort, int64_t *n_batches, int64_t *n_symbols);
 

@@ -267,6 +267,7 @@ typedef struct {
 	int ret, raw;             /* raw: not sorted yet, the consumer's GPU handle sorts it */
 	void *d_bwt;              /* device: the BWT from a sorter thread's own GPU sorter (gs), to be released after the merge */
 	void *d_tw;               /* device: its text-order words (long strings: the walkers are then given by text position) */
+	void *d_sa;               /* device: its suffix array, behind them (the engine leaves its records in text order where that pays) */
 	rb3gpu_sorter_t *gs;
 } batch_t;
 
@@ -330,11 +331,11 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	if (b->d_bwt) { /* sorted on the GPU by a sorter thread while the batch before was being merged */
 		const int first = !*has_index;
 		if (first) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)b->d_bwt);
-		else if (b->walkers && b->d_tw) ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
-		else if (b->d_tw && b->step == 0 && b->n_seq > 0) ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, b->n_seq, 0, 1); /* short strings: one walker per string */
+		else if (b->walkers && b->d_tw) ret = rb3gpu_merge_text_sa_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, (const uint32_t*)b->d_sa, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+		else if (b->d_tw && b->step == 0 && b->n_seq > 0) ret = rb3gpu_merge_text_sa_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, (const uint32_t*)b->d_sa, b->n_seq, 0, 1); /* short strings: one walker per string */
 		else ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)b->d_bwt, 1);
 		rb3gpu_sorter_release(b->gs, b->d_bwt);
-		b->d_bwt = b->d_tw = 0;
+		b->d_bwt = b->d_tw = b->d_sa = 0;
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] %s the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), first ? "encoded" : "merged", (long)b->len);
 	} else if (b->raw) {
@@ -414,17 +415,17 @@ static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_t
 			int r2 = -1;
 			if (!(opt->flag & (BF_NO_FOR | BF_NO_REV))) n_pairs = rb3h_strand_pairs(b->len, b->bwt, n_seq, 32, pair_start);
 			if (n_pairs > 0 && (r2 = rb3gpu_sorter_upload_fwd(gs, b->len, b->bwt, n_pairs, pair_start)) == 0)
-				r2 = rb3gpu_sorter_sort_uploaded(gs, b->len, &b->d_bwt, &b->d_tw);
-			if (n_pairs <= 0 || r2 == RB3GPU_EINVAL) r2 = rb3gpu_sorter_sort(gs, b->len, b->bwt, &b->d_bwt, &b->d_tw);
+				r2 = rb3gpu_sorter_sort_uploaded_sa(gs, b->len, &b->d_bwt, &b->d_tw, &b->d_sa);
+			if (n_pairs <= 0 || r2 == RB3GPU_EINVAL) r2 = rb3gpu_sorter_sort_sa(gs, b->len, b->bwt, &b->d_bwt, &b->d_tw, &b->d_sa);
 			if (r2 == 0) {
 				if (rb3h_verbose >= 3)
 					fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
-				if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0, b->d_tw = 0;
+				if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0, b->d_tw = b->d_sa = 0;
 				walkers_pin(b);
 				b->gs = gs, b->raw = 0;
 				__sync_fetch_and_add(&g_sorted.n_gpu, 1), __sync_fetch_and_add(&g_sorted.sym_gpu, b->len);
 				rb3h_batch_free(b->bwt); b->bwt = 0; /* the text is not needed any more */
-			} else b->d_bwt = b->d_tw = 0; /* leave it to the consumer (its handle's sorter, then the host sorter) */
+			} else b->d_bwt = b->d_tw = b->d_sa = 0; /* leave it to the consumer (its handle's sorter, then the host sorter) */
 		}
 		*out = b;
 		return 0;

@@ -32,7 +32,7 @@ struct rb3sort_ws;
 rb3sort_ws *rb3sort_create(void);
 void rb3sort_destroy(rb3sort_ws *ws);
 int64_t rb3sort_bytes(const rb3sort_ws *ws);
-int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds, uint64_t *d_tw);
+int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds, uint64_t *d_tw, uint32_t *d_sa);
 /* the FMD packer lives in rb3gpu_fmdenc.hip */
 int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words);
 struct rb3fmd_dec;
@@ -104,6 +104,7 @@ struct Tune {
 	int lpw = 8;             // lanes per walker of k_chain in the single-sync merge: 8 (an octet) or 4 (a quad, 16 walkers per wave; builds with -DRB3_WITH_QUADS only)
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
+	int trec = -1;           // records of a text-order walk in text order (needs the batch's suffix array): 1 always, 0 never, -1: where the index does not fit the caches
 	int tent_q = 0;          // width of the drop-out masks of the tentative stretches in units of 256 bits: 1, 2, 4, 8; 0: follows what the walkers report
 	int copy_walkers = 0;    // a walker list in page-locked memory is copied to the device all the same (instead of being read in place)
 	int chain_bs = 256;      // threads per block of k_chain in the single-sync merge (64, 128 or 256: the kernel has no block-level state; smaller blocks spread the waves more evenly over the CUs)
@@ -145,7 +146,7 @@ struct rb3gpu_s {
 	// (behind the grp_cap directory entries of a buffer sit grp_cap 8-byte words: the compact copy of the entries' slot words, IdxView.gsm)
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, pos, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist;
+	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -161,6 +162,7 @@ struct rb3gpu_s {
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
 	rb3sort_ws *sorter = nullptr;           // scratch of rb3gpu_bwt_from_text, created on first use
 	int64_t reb_last[2] = {-1, -1}; // groups the first / the last tier of the run-space rebuild handed on in the merge before (-1: unknown)
+	const uint32_t *mg_sa = nullptr; // the suffix array of the batch being merged, if its caller has it (rb3gpu_merge_text_sa_dev): records in text order
 	int tent_q = 1;          // masks of 256 * tent_q bits (merge_core doubles it when walkers report intervals wider than that)
 	int64_t sid_dirty[2] = {RB3_TENT_HALF, RB3_TENT_HALF}; // entries of the two halves of the stretch tables (dl) that may be non-zero
 };
@@ -400,6 +402,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
 	else if (!strcmp(key, "chain_bs")) t.chain_bs = v == 64 ? 64 : v == 128 ? 128 : 256;
 	else if (!strcmp(key, "copy_walkers")) t.copy_walkers = v != 0;
+	else if (!strcmp(key, "trec")) t.trec = v < 0 ? -1 : v != 0;
 	else if (!strcmp(key, "tent_q")) t.tent_q = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : v >= 1 ? 1 : 0;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
 	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? 0 : v > 12 ? 12 : (int)v;
@@ -436,7 +439,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "trec", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -518,14 +521,14 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exac
 static void guard_check(rb3gpu_t *h, const char *where)
 {
 	if (!h->tn.guard) return;
-	static const char *names[] = { "b2", "pos", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
-	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	static const char *names[] = { "b2", "pos", "post", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	uint8_t g[RB3_GUARD];
-	for (int i = 0; i < 19 + 4; ++i) {
+	for (int i = 0; i < 20 + 4; ++i) {
 		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
-		if (i < 19) p = (const uint8_t*)all[i]->p, cap = all[i]->cap, name = names[i];
-		else if (i < 21) p = (const uint8_t*)h->ib[i - 19].grp, cap = h->ib[i - 19].grp_cap * RB3_GRP_ALLOC, name = "index directory";
-		else p = (const uint8_t*)h->ib[i - 21].slots, cap = h->ib[i - 21].slots_cap * sizeof(rb3_slot_t), name = "index slots";
+		if (i < 20) p = (const uint8_t*)all[i]->p, cap = all[i]->cap, name = names[i];
+		else if (i < 22) p = (const uint8_t*)h->ib[i - 20].grp, cap = h->ib[i - 20].grp_cap * RB3_GRP_ALLOC, name = "index directory";
+		else p = (const uint8_t*)h->ib[i - 22].slots, cap = h->ib[i - 22].slots_cap * sizeof(rb3_slot_t), name = "index slots";
 		if (!p) continue;
 		if (cap == 0) cap = 256;
 		if (hipMemcpy(g, p + cap, RB3_GUARD, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -559,7 +562,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -1259,6 +1262,14 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (!rank_only && (r = ib_ensure(h, 1 - h->cur, ngrp_new, slot_estimate(h, len, ntot))) < 0) return r;
 	const bool rows_fused = !rank_only && use_winpar(h, nwin);
 	if (rows_fused && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
+	// Records in text order (k_chain, trec): needs the batch's suffix array for the gather back into row order, which the validation
+	// pass does on its way (one random 8-byte read per row instead of one random 8-byte write per step: reads are what the memory
+	// system is good at).  By default where the index does not sit in the caches (slots > 192 MB): there the record stores are
+	// two thirds of the walk; on a cache-resident index the gather costs what the stores cost.
+	const uint32_t *d_sa = h->mg_sa;
+	const bool trec = d_sa != nullptr && d_tw != nullptr && rows_fused && !auto_list && len < (1LL << 32) &&
+		(h->tn.trec > 0 || (h->tn.trec < 0 && (size_t)h->nslots * sizeof(rb3_slot_t) > ((size_t)192 << 20)));
+	if (trec && (r = buf_ensure(h, h->post, (size_t)len * 8)) < 0) return r;
 	unsigned long long *misc = (unsigned long long*)h->misc.p;
 	Walker *dwl = (Walker*)h->wl.p;
 	uint32_t *sidctr = (uint32_t*)(misc + 5);
@@ -1271,7 +1282,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	fill_add(&jb, misc + MISC_RG_OVER, tent ? (size_t)(MISC_WORDS - MISC_RG_OVER) * 8 : 64, 0u); // (... MISC_WIDE, and the id counters behind them)
 	if (rows_fused) fill_add(&jb, h->jg.p, (size_t)(nwin + 1) * 8, 0u); // defined even if pos[] turns out invalid
 	const bool rows_filled = d_tw != nullptr && jb.n < 8;
-	if (rows_filled) fill_add(&jb, h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
+	if (rows_filled) fill_add(&jb, trec ? h->post.p : h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
+	else if (trec) HIPCHK(hipMemsetAsync(h->post.p, 0xff, (size_t)len * 8, h->st));
 	fill_launch(h, jb);
 	h->reb_prepared = true; // (build_index: the counters of the run-space rebuild are clear)
 	// The histogram of the batch and its scan (the C array of B2 and the rows before every tile, fm-index.c:206-216): a text-order walk
@@ -1342,6 +1354,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		}
 	}
 	int64_t *dpos = (int64_t*)h->pos.p;
+	int64_t *drec = trec ? (int64_t*)h->post.p : dpos; // where the walkers leave their records
 	{
 		const IdxView iv = view_of(h);
 #ifdef RB3_WITH_QUADS
@@ -1359,8 +1372,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #endif
 		const dim3 grid((unsigned)(nblk * (256 / h->tn.chain_bs))), blk((unsigned)h->tn.chain_bs);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
-#define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, dpos, len, (int64_t)0, per_string ? -1 : 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr)
+#define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0, \
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, trec ? 1 : 0)
 #ifdef RB3_WITH_QUADS /* a quad per walker (k_chain<..., 4>) was measured slower in every regime: compiled in on request only */
 #define RB3_LAUNCH_FAST(D, T, X) do { if (lpw == 4) RB3_LAUNCH_FAST1(D, T, X, 4); else RB3_LAUNCH_FAST1(D, T, X, 8); } while (0)
 #else
@@ -1394,8 +1407,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		}
 		if (rows_fused) { // validation and the rows-per-window table of the rebuild in one pass over pos[]
 			const dim3 g1((unsigned)((len + 1 + 255) / 256));
-			if (tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
-			else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<false>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)nullptr, misc + 2, (int64_t*)h->jg.p, nwin);
+			const int64_t *frec = trec ? (const int64_t*)drec : nullptr;
+			const uint32_t *fsa = trec ? d_sa : nullptr;
+			if (tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin, frec, fsa);
+			else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<false>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)nullptr, misc + 2, (int64_t*)h->jg.p, nwin, frec, fsa);
 		} else if (tent)
 			hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2);
 		else
@@ -1507,7 +1522,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			HIPCHK(hipMemsetAsync(misc + 2, 0, 24, h->st));
 			if (rows_fused) {
 				HIPCHK(hipMemsetAsync(h->jg.p, 0, (size_t)(nwin + 1) * 8, h->st));
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), dim3((unsigned)((len + 1 + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), dim3((unsigned)((len + 1 + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin,
+						trec ? (const int64_t*)drec : (const int64_t*)nullptr, trec ? d_sa : (const uint32_t*)nullptr);
 			} else
 				hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2);
 			HIPCHK(hipEventRecord(h->ev[5], h->st));
@@ -1692,6 +1708,16 @@ int rb3gpu_merge_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const 
 	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_walkers, walkers, d_tw);
 }
 
+int rb3gpu_merge_text_sa_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, const uint32_t *d_sa, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit)
+{
+	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	h->mg_sa = d_sa; // (NULL: rb3gpu_merge_text_dev)
+	const int r = merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_walkers, walkers, d_tw);
+	h->mg_sa = nullptr;
+	return r;
+}
+
 int rb3gpu_mg_rank_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1])
 {
 	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0 || !pos) return RB3GPU_EINVAL;
@@ -1793,7 +1819,7 @@ int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out)
 	return 0;
 }
 
-static int sort_text_impl(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow, uint64_t *d_tw)
+static int sort_text_impl(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, int64_t step, int64_t *ckrow, uint64_t *d_tw, uint32_t *d_sa = nullptr)
 {
 	if (!h || !text || !d_bwt || len <= 0 || len >= (1LL << 31) || step < 0) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
@@ -1807,11 +1833,11 @@ static int sort_text_impl(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t
 		if ((r = buf_ensure(h, h->xbuf, (size_t)nck * 8)) < 0) return r;
 		d_ck = (int64_t*)h->xbuf.p;
 	}
-	r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds, d_tw);
+	r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds, d_tw, d_sa);
 	if (r == -1 && !h->garbage.empty()) { // the sorter's scratch did not fit while replaced buffers of the handle are still held: give them back, once more
 		(void)hipGetLastError();
 		garbage_collect(h, true);
-		r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds, d_tw);
+		r = rb3sort_bwt(h->sorter, h->st, len, (const uint8_t*)h->b2.p, d_bwt, step, d_ck, &rounds, d_tw, d_sa);
 	}
 	if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -3 ? RB3GPU_ESYMBOL : RB3GPU_ENODEV;
 	if (nck > 0) HIPCHK(hipMemcpy(ckrow, d_ck, (size_t)nck * 8, hipMemcpyDeviceToHost));
@@ -1831,6 +1857,12 @@ int rb3gpu_sort_text(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_b
 {
 	if (!d_tw) return RB3GPU_EINVAL;
 	return sort_text_impl(h, len, text, d_bwt, 0, nullptr, d_tw);
+}
+
+int rb3gpu_sort_text_sa(rb3gpu_t *h, int64_t len, const uint8_t *text, uint8_t *d_bwt, uint64_t *d_tw, uint32_t *d_sa)
+{
+	if (!d_tw || !d_sa) return RB3GPU_EINVAL;
+	return sort_text_impl(h, len, text, d_bwt, 0, nullptr, d_tw, d_sa);
 }
 
 /* ---- a sorter of its own: stream, scratch, two output buffers handed out in turn ---- */
@@ -1973,7 +2005,7 @@ static int sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *tex
 }
 
 /* stage 2: suffix-sort the uploaded text into an output buffer that is not with the merger */
-static int sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, int64_t step, int64_t *ckrow, void **d_tw)
+static int sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, int64_t step, int64_t *ckrow, void **d_tw, void **d_sa = nullptr)
 {
 	if (!s || !d_bwt || len <= 0 || len != s->text_len || step < 0) return RB3GPU_EINVAL;
 	SCHK(hipSetDevice(s->dev));
@@ -1987,14 +2019,16 @@ static int sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, i
 	const int64_t nck = step > 0 && ckrow ? (len + step - 1) / step : 0;
 	const size_t tw_off = ((size_t)len + 16 + 255) & ~(size_t)255; // the text-order words sit behind the BWT in the same buffer
 	if (d_tw) *d_tw = nullptr;
-	if ((r = sorter_grow(&s->out[slot], &s->out_cap[slot], d_tw ? tw_off + (size_t)len * 8 : (size_t)len + 16)) < 0 ||
+	if (d_sa) *d_sa = nullptr;
+	if (d_sa && !d_tw) { sorter_give_back(s, slot); return RB3GPU_EINVAL; }
+	if ((r = sorter_grow(&s->out[slot], &s->out_cap[slot], d_tw ? tw_off + (size_t)len * (d_sa ? 12 : 8) : (size_t)len + 16)) < 0 ||
 		(nck > 0 && (r = sorter_grow(&s->ck, &s->ck_cap, (size_t)nck * 8)) < 0)) {
 		sorter_give_back(s, slot); // (or the next two calls would wait for it for ever)
 		return r;
 	}
 	const double t_so = now_s();
 	r = rb3sort_bwt(s->ws, s->st, len, (const uint8_t*)s->text, (uint8_t*)s->out[slot], step, nck > 0 ? (int64_t*)s->ck : nullptr, &rounds,
-			d_tw ? (uint64_t*)((uint8_t*)s->out[slot] + tw_off) : nullptr);
+			d_tw ? (uint64_t*)((uint8_t*)s->out[slot] + tw_off) : nullptr, d_sa ? (uint32_t*)((uint8_t*)s->out[slot] + tw_off + (size_t)len * 8) : nullptr);
 	s->ms_sort += (now_s() - t_so) * 1e3, s->n_sorted += 1, s->n_symbols += len;
 	if (r == 0 && nck > 0 && (hipMemcpyAsync(ckrow, s->ck, (size_t)nck * 8, hipMemcpyDeviceToHost, s->st) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess)) r = -2;
 	if (r < 0) {
@@ -2003,6 +2037,7 @@ static int sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, i
 	}
 	*d_bwt = s->out[slot];
 	if (d_tw) *d_tw = (uint8_t*)s->out[slot] + tw_off;
+	if (d_sa) *d_sa = (uint8_t*)s->out[slot] + tw_off + (size_t)len * 8; // (behind the text-order words, released with the BWT)
 	return 0;
 }
 
@@ -2062,9 +2097,23 @@ int rb3gpu_sorter_sort_uploaded(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, v
 	return sorter_sort_uploaded(s, len, d_bwt, 0, nullptr, d_tw);
 }
 
+int rb3gpu_sorter_sort_uploaded_sa(rb3gpu_sorter_t *s, int64_t len, void **d_bwt, void **d_tw, void **d_sa)
+{
+	if (!d_tw || !d_sa) return RB3GPU_EINVAL;
+	return sorter_sort_uploaded(s, len, d_bwt, 0, nullptr, d_tw, d_sa);
+}
+
 int rb3gpu_sorter_bwt(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, int64_t step, int64_t *ckrow)
 {
 	return sorter_impl(s, len, text, d_bwt, step, ckrow, nullptr);
+}
+
+int rb3gpu_sorter_sort_sa(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, void **d_tw, void **d_sa)
+{
+	if (!s || !text || !d_bwt || !d_tw || !d_sa || len <= 0 || len >= (1LL << 31)) return RB3GPU_EINVAL;
+	int r;
+	if ((r = sorter_upload(s, len, text)) < 0) return r;
+	return sorter_sort_uploaded(s, len, d_bwt, 0, nullptr, d_tw, d_sa);
 }
 
 int rb3gpu_sorter_sort(rb3gpu_sorter_t *s, int64_t len, const uint8_t *text, void **d_bwt, void **d_tw)

@@ -943,8 +943,12 @@ template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8>
 #endif
 __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX, uint32_t *mctr = nullptr)
+		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX, uint32_t *mctr = nullptr, int trec = 0)
 {
+	// trec (TEXT only): row[] is indexed by TEXT POSITION instead of by row.  The eight records an octet parks are then eight
+	// consecutive words -- one 64-byte store where a record per row is eight random 8-byte stores, each costing a 32-byte sector
+	// and, in an index that lives in HBM, most of the step (k_chain 18.2 -> 6.4 ms per 302 M steps with the stores removed) -- and
+	// the validation pass gathers them into row order through the suffix array (k_pos_finalize_check_rows).
 	const uint32_t myctr = (uint32_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (uint32_t)(RB3_TENT_NCTR - 1); // the id counter of this wave
 	const int64_t nwalk = nwalk_dev ? (int64_t)*nwalk_dev : nwalk_arg; // (a list made on the device: its length never went to the host)
 	static_assert(LIST || !TEXT, "text-order words need a walker list");
@@ -1033,7 +1037,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					blk8 = tw[a > 0 ? a : 0];
 				}
 				kb = (int64_t)(x >> 3);
-				rc = (uint64_t)ld_pos(&row[kb]);
+				rc = (uint64_t)ld_pos(&row[trec ? tp : kb]);
 				if (gap && (int64_t)rc >= 0) continue;
 			} else {
 				x = (uint64_t)ld_pos(&row[kb]);
@@ -1106,7 +1110,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					const int64_t myval = lo + kb;
 					// (once a stretch is open the interval is at most KMAX wide and the walker old enough, for the rest of its life)
 					if ((gap == 0 || sid >= 0) && j == (int)(it & 7u))
-						bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
+						bkb = trec ? tp : kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					// the records of the last eight steps go out here, where nothing is asked for during the whole decode: the store is slow
 					// (written through) and whatever is asked for after it waits for its acknowledgement (vmcnt counts in order)
@@ -1210,7 +1214,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					const int64_t a = tp - 2 - j;
 					blk8 = tw[a > 0 ? a : 0];
 				}
-				if (remaining == 1 || remaining > RB3_BEYOND) rcn = (uint64_t)ld_pos(&row[kbn]);
+				if (remaining == 1 || remaining > RB3_BEYOND) rcn = (uint64_t)ld_pos(&row[trec ? tpn : kbn]);
 			} else xn = (uint64_t)ld_pos(&row[kbn]);
 			bool end_next;
 			if (LIST) end_next = remaining == 1;
@@ -1243,7 +1247,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				}
 			}
 			if ((gap == 0 || (tentok && sid >= 0)) && !met && j == (int)(it & (uint32_t)(LPW - 1)))
-				bkb = kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
+				bkb = (TEXT && trec) ? tp : kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 			// next insertion point(s)
 			uint32_t match = 0, mh;
 			int64_t lo_n, hi_n;
@@ -1964,17 +1968,19 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check(int64_t *pos, int64_
  * after the last row).  Rows that failed validation write nothing -- the rebuild is skipped then anyway. */
 template<bool TENT>
 __global__ void __launch_bounds__(256) k_pos_finalize_check_rows(int64_t *pos, int64_t n2, int64_t ntot, const int32_t *sfin, unsigned long long *bad,
-		int64_t *jw, int64_t nwin)
+		int64_t *jw, int64_t nwin, const int64_t *rec = nullptr, const uint32_t *sa = nullptr)
 {
+	// rec, sa: the walkers left their records in TEXT order (k_chain, trec): row i's record is rec[sa[i]], and pos[] is written here
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n2) return;
 	// the settle pass already knows it is incomplete: nothing to validate yet (one answer per wave: the lanes exchange values below)
 	if (TENT && __builtin_amdgcn_readfirstlane((int)(*(volatile unsigned long long*)&bad[2] != 0)) != 0) return;
 	int64_t p = INT64_MAX, q = RB3_UNSET;
 	if (i < n2) {
-		const int64_t raw = pos[i];
+		const int64_t raw = sa ? rec[sa[i] < (uint32_t)n2 ? sa[i] : 0u] : pos[i];
 		p = TENT ? pos_final(raw, sfin, bad) : (raw < 0 ? RB3_UNSET : raw);
-		if (TENT && p != raw && p >= 0) pos[i] = p; // (an unsettled record stays as it is: a longer settle pass may still resolve it)
+		if (sa) pos[i] = p; // (an unsettled record stays in rec[]: a longer settle pass may still resolve it)
+		else if (TENT && p != raw && p >= 0) pos[i] = p; // (an unsettled record stays as it is: a longer settle pass may still resolve it)
 	}
 	// the row before: from the lane below (its final value is in a register there); only lane 0 of a wave looks it up again
 	// (the neighbour's own thread reports its problems)
@@ -1982,7 +1988,7 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check_rows(int64_t *pos, i
 		const uint32_t qlo = wave_up1((uint32_t)(uint64_t)p), qhi = wave_up1((uint32_t)((uint64_t)p >> 32));
 		if ((threadIdx.x & 63) != 0) q = (int64_t)((uint64_t)qhi << 32 | qlo);
 		else if (i > 0) {
-			const int64_t rq = pos[i - 1];
+			const int64_t rq = sa ? rec[sa[i - 1] < (uint32_t)n2 ? sa[i - 1] : 0u] : pos[i - 1];
 			q = TENT ? pos_final(rq, sfin, nullptr) : (rq < 0 ? RB3_UNSET : rq);
 		}
 	}

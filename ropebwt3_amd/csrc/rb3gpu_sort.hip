@@ -279,9 +279,9 @@ __global__ void __launch_bounds__(256) k_s_tw(const uint32_t *rank, const uint8_
 enum { W_KEYA, W_KEYB, W_VALA, W_VALB, W_RANK, W_SID, W_SA, W_SENT, W_T0, W_T1, W_FLAG, W_TMP, W_LFLAG, W_LKA, W_LKB, W_LVA, W_LVB, W_SPARE };
 
 /* d_text: n symbols (0..5, last one 0) in device memory; d_bwt: n bytes out; d_ckrow: ceil(n/step) rows out or NULL;
- * d_tw: n text-order words out or NULL.
+ * d_tw: n text-order words out or NULL; d_sa: the suffix array (n x u32: text position of the suffix of every row) out or NULL.
  * Returns 0, -1 (out of memory), -2 (HIP error), -3 (bad text), and the number of doubling rounds in *rounds. */
-int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds, uint64_t *d_tw)
+int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds, uint64_t *d_tw, uint32_t *d_sa)
 {
 	if (!ws || n <= 0 || n >= (1LL << 31)) return -3;
 	if (ws_ensure(ws, W_KEYA, (size_t)n * 8) || ws_ensure(ws, W_KEYB, (size_t)n * 8) || ws_ensure(ws, W_VALA, (size_t)n * 4) || ws_ensure(ws, W_VALB, (size_t)n * 4) ||
@@ -374,6 +374,7 @@ int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text
 		hipLaunchKernelGGL(k_s_ckrow, S_GRID(nck), (const uint32_t*)rank, n, step, nck, d_ckrow);
 	}
 	if (d_tw) hipLaunchKernelGGL(k_s_tw, S_GRID(n), (const uint32_t*)rank, d_text, n, d_tw);
+	if (d_sa) S_HIP(hipMemcpyAsync(d_sa, sa, (size_t)n * 4, hipMemcpyDeviceToDevice, st)); // the suffix array itself (row -> text position)
 	S_HIP(hipStreamSynchronize(st));
 	if (rounds) *rounds = nr;
 	return 0;

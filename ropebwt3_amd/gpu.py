@@ -77,6 +77,10 @@ SYMBOLS = {
     "rb3gpu_bwt_from_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_sort_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_merge_text_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]),
+    "rb3gpu_merge_text_sa_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]),
+    "rb3gpu_sort_text_sa": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_sorter_sort_uploaded_sa": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
+    "rb3gpu_sorter_sort_sa": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     "rb3gpu_mg_rank_text_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_sorter_sort": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
     "rb3gpu_sorter_create": (ctypes.c_void_p, [ctypes.c_int]),
@@ -203,6 +207,12 @@ class Sorter:
 
     def upload_end(self):
         self._chk(self._lib.rb3gpu_sorter_upload_end(self._s), "rb3gpu_sorter_upload_end")
+
+    def sort_uploaded_sa(self, length):
+        """sort_uploaded with the suffix array: (d_bwt, d_tw, d_sa), all released by release(d_bwt)"""
+        p, q, r = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_sorter_sort_uploaded_sa(self._s, int(length), ctypes.byref(p), ctypes.byref(q), ctypes.byref(r)), "rb3gpu_sorter_sort_uploaded_sa")
+        return p, q, r
 
     def sort_uploaded(self, length):
         """suffix-sort the text uploaded last: (d_bwt, d_tw) device pointers, valid until release(d_bwt)"""
@@ -389,13 +399,24 @@ class Rb3Gpu:
         self._chk(self._lib.rb3gpu_sort_text(self._h, text.size, text.ctypes.data, p, q), "rb3gpu_sort_text")
         return p, q
 
-    def merge_text_dev(self, d_bwt, d_tw, length, walkers, commit=True):
-        """merge a batch given by its BWT and text-order words (walkers by text position: host.walkers_text)"""
+    def sort_text_sa(self, text):
+        """sort_text with the suffix array: (BWT, text-order words, suffix array) device pointers; free all three with dev_free"""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        p, q, r = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_dev_alloc(self._h, text.size + 16, ctypes.byref(p)), "rb3gpu_dev_alloc")
+        self._chk(self._lib.rb3gpu_dev_alloc(self._h, text.size * 8, ctypes.byref(q)), "rb3gpu_dev_alloc")
+        self._chk(self._lib.rb3gpu_dev_alloc(self._h, text.size * 4, ctypes.byref(r)), "rb3gpu_dev_alloc")
+        self._chk(self._lib.rb3gpu_sort_text_sa(self._h, text.size, text.ctypes.data, p, q, r), "rb3gpu_sort_text_sa")
+        return p, q, r
+
+    def merge_text_dev(self, d_bwt, d_tw, length, walkers, commit=True, d_sa=None):
+        """merge a batch given by its BWT and text-order words (walkers by text position: host.walkers_text); d_sa: the batch's
+        suffix array if the caller has it (rb3gpu_merge_text_sa_dev)"""
         if isinstance(walkers, (int, np.integer)):  # the number of strings: one walker per string, made on the device
-            self._chk(self._lib.rb3gpu_merge_text_dev(self._h, length, d_bwt, d_tw, int(walkers), None, 1 if commit else 0), "rb3gpu_merge_text_dev")
+            self._chk(self._lib.rb3gpu_merge_text_sa_dev(self._h, length, d_bwt, d_tw, d_sa, int(walkers), None, 1 if commit else 0), "rb3gpu_merge_text_sa_dev")
             return
         w = self._walkers(walkers)
-        self._chk(self._lib.rb3gpu_merge_text_dev(self._h, length, d_bwt, d_tw, w.shape[0], w.ctypes.data, 1 if commit else 0), "rb3gpu_merge_text_dev")
+        self._chk(self._lib.rb3gpu_merge_text_sa_dev(self._h, length, d_bwt, d_tw, d_sa, w.shape[0], w.ctypes.data, 1 if commit else 0), "rb3gpu_merge_text_sa_dev")
 
     def mg_rank_text_dev(self, d_bwt, d_tw, length, walkers):
         pos = np.empty(length, dtype=np.int64)

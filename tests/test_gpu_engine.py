@@ -1171,3 +1171,49 @@ def test_walker_step_is_the_resident_capacity_of_the_walker_kernel():
     assert w.shape[0] <= room + 2
     with pytest.raises(Exception):
         walker_step(99, 1000, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kind,env", [(301, "family", {}), (302, "reads", {}), (303, "dups", {}), (304, "family", {"text_mode": 2}),
+                                           (305, "reads", {"text_mode": 1}), (306, "family", {"tent": 0}), (307, "family", {"tent_q": 4})])
+def test_records_in_text_order_gathered_through_the_suffix_array(oracle, seed, kind, env):
+    """rb3gpu_merge_text_sa_dev with `trec` forced on: the walkers leave their records in text order (one 64-byte store per octet and
+    eight steps) and the validation pass gathers them into row order through the sorter's suffix array -- the same pos[], hence the
+    same index, as with a record per row; suffix array checked against the inverse suffix array the text-order words carry"""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(seed)
+    g0 = util.random_genome(rng, 60000)
+    if kind == "family":
+        rel = [g0] + [util.mutate(rng, g0, 0.003) for _ in range(9)]
+        batches = [[util.mutate(rng, g0, 0.002)], [util.mutate(rng, rel[3], 0.001), util.random_genome(rng, 5000)]]
+    elif kind == "dups":
+        rel = [g0, util.mutate(rng, g0, 0.002)]
+        batches = [[g0.copy(), rel[1].copy()], [util.mutate(rng, g0, 0.0005)]]
+    else:
+        rel = [g0]
+        batches = [list(util.reads_from(rng, g0, 1500, 120, 0.01)), list(util.reads_from(rng, g0, 700, 150, 0.0))]
+    cur = host.build_bwt(util.make_text(rel))
+    h = Rb3Gpu(verbose=1, hooks=bool(set(env) & {"text_mode"}))
+    try:
+        h.tune("trec", 1)
+        for k, v in env.items():
+            h.tune(k, v)
+        h.from_plain(cur)
+        for new in batches:
+            t2 = util.make_text(new)
+            b2 = host.build_bwt(t2.copy())
+            cur = oracle.merge(cur, b2)
+            d_bwt, d_tw, d_sa = h.sort_text_sa(t2)
+            tw = h.dev_download(d_tw, t2.size * 8).view(np.uint64)
+            sa = h.dev_download(d_sa, t2.size * 4).view(np.uint32)
+            assert np.array_equal((tw >> np.uint64(3)).astype(np.int64)[sa.astype(np.int64)], np.arange(t2.size))   # isa[sa[i]] == i
+            nstr = int((t2 == 0).sum())
+            w = nstr if kind == "reads" else host.walkers_text(t2, 200)
+            h.merge_text_dev(d_bwt, d_tw, t2.size, w, commit=True, d_sa=d_sa)
+            assert np.array_equal(h.export_plain(), cur), (kind, env)
+            for p in (d_bwt, d_tw, d_sa):
+                h.dev_free(p)
+        st = h.stats()
+        assert st["n_fallbacks"] == 0, st
+    finally:
+        h.close()

@@ -42,13 +42,13 @@ for case in range(ncase):
             if cur is None: h.from_plain(b)
             else: h.merge_plain(b)
         elif (case % 4 == 2 and case % 8 != 6) or os.environ.get("SOAK_TEXT"):   # suffix-sorted on the GPU, merged through its text-order words (the CLI's default path)
-            d, dtw = h.sort_text(t)
+            d, dtw, dsa = h.sort_text_sa(t)       # (with the suffix array: RB3GPU_TREC=1 then leaves the records in text order)
             b = h.dev_download(d, t.size)
             if not np.array_equal(b, host.build_bwt(t.copy())):
                 print("case %d: GPU suffix sorter MISMATCH" % case); sys.exit(1)
             if cur is None: h._chk(h._lib.rb3gpu_from_plain_dev(h._h, t.size, d), "from_plain_dev")
-            else: h.merge_text_dev(d, dtw, t.size, host.walkers_text(t, step), commit=True)
-            h.dev_free(d); h.dev_free(dtw)
+            else: h.merge_text_dev(d, dtw, t.size, host.walkers_text(t, step), commit=True, d_sa=dsa)
+            h.dev_free(d); h.dev_free(dtw); h.dev_free(dsa)
         elif case % 4 == 2:   # the batch is suffix-sorted on the GPU as well; the BWT never leaves the device
             d, ck = h.bwt_from_text(t, step)
             b = h.dev_download(d, t.size)

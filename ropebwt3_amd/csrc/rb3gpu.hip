@@ -2610,6 +2610,10 @@ int rb3gpu_sh_step(rb3gpu_t *h, int64_t n_states, const rb3gpu_state_t *d_in, co
 	return 0;
 }
 
+/* (No sampled LF check here, unlike every other merge path: k_lf_check guards against a wrong-but-monotone pos[] out of SPECULATIVE
+ * records, and the sharded walk has none -- every ka is the exact result of its chain's previous step -- while the relation it tests,
+ * ka[LF2(kb)] = C1[c] + rank_B1(c, ka[kb]), needs the ranks of ALL intervals, which no single GPU holds.  Completeness and order of
+ * the interval's rows are checked (k_sh_localpos, k_pos_check), and the symbol totals after the rebuild.) */
 int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_bwt, const int64_t *d_ka, int64_t iv_start, int commit)
 {
 	if (!h || jlo < 0 || n_rows < 0 || !d_bwt || !d_ka) return RB3GPU_EINVAL;

@@ -1210,8 +1210,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const double kest = h->nslots > 0 ? (double)h->n / ((double)h->nslots * 32.0) : 1.0;
 	auto events_at = [&](double W) { return (double)len / W * ((kest < 1.0 ? 1.0 : kest) * (1.0 - exp(-W / 1000.0)) + (double)RB3_TENT_CHUNK); };
 	const double tent_room = 0.6 * (double)RB3_TENT_HALF;
-	int64_t b2W = rb3gpu_walker_step(h->dev, len, 0); // (as many walkers as k_chain keeps resident; at least RB3_B2_W / 2 apart)
-	if (b2W < RB3_B2_W / 2) b2W = RB3_B2_W;
+	int64_t b2W = RB3_B2_W; // (rb3gpu_walker_step's spacing -- one walker per resident octet -- was measured on this path too: k_chain 0.48 -> 0.68 ms for one genome into one; row words are a random read per step more, and more walkers only add to them)
 	while (len / b2W > (1 << 18) || (h->tn.tent && thin == 1 && events_at((double)b2W) > tent_room && b2W < len / 256)) b2W *= 2;
 	b2W *= thin;
 	const int64_t b2_nbk = len / b2W + 1, b2_m2cap = len / 64 + 1, b2_nspmax = (len >> b2S) + b2_m2cap + 2;

@@ -195,7 +195,7 @@ def parse_cli_stats(err):
 # ---------------------------------------------------------------------------------------------
 
 MTB_L = 4400000
-WALKER_STEP = 0      # 0: rb3gpu_walker_step (as many walkers as k_chain keeps resident: 220 text positions for a 4.4 Mbp genome on an MI355X)
+WALKER_STEP = 0      # 0: rb3gpu_walker_step (as many walkers as k_chain keeps resident: 230 text positions for a 4.4 Mbp genome on an MI355X)
 
 
 def mtb_manifest(K, L):
@@ -214,7 +214,7 @@ def mtb_files(K, L, tmp=None):
 def load_batches(files, pinned=True, step=WALKER_STEP, device=0):
     """every file through the CLI's own reader (rb3h_seq_read: nt6, both strands, sentinels; io.c:104-125), one batch per
     file, into page-locked memory (what `ropebwt3-amd build` does with rb3gpu_pinned_alloc) + the walker list of each batch
-    (one walker per string + one per rb3gpu_walker_step text positions -- 220 for these genomes --, rb3h_walkers_text).  Not timed: file I/O is outside the metric."""
+    (one walker per string + one per rb3gpu_walker_step text positions -- 230 for these genomes --, rb3h_walkers_text).  Not timed: file I/O is outside the metric."""
     from ropebwt3_amd import PinnedArray, host, walker_step
     texts, walkers, keep = [], [], []
     for fn in files:
@@ -245,7 +245,7 @@ class BuildLoop:
 
     def __init__(self, device):
         from ropebwt3_amd import Rb3Gpu, Sorter
-        self.h = Rb3Gpu(device=device, verbose=1)
+        self.h = Rb3Gpu(device=device, verbose=int(os.environ.get("RB3_BENCH_VERBOSE", "1")))   # (2: the engine's warnings, e.g. why a merge was redone)
         self.srt = Sorter(device)
         self.fwd_upload = True
         self.overlap = True      # the H2D copy of batch i + 1 runs beside the merge of batch i (--serial-h2d: one after the other)

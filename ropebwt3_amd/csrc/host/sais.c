@@ -54,6 +54,7 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
 }
 
 #define RB3H_MIN_SEG 128
+#define RB3H_PROBE 24 /* a walker looks that many positions to the right of its start row for a record of its right neighbour */
 #ifndef RB3H_PREROLL
 #define RB3H_PREROLL 32 /* = RB3_TENT_MIN_AGE of the engine (rb3gpu_kernels.h) */
 #endif
@@ -83,7 +84,8 @@ int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, cons
 			 * the kernel's general step, and a few more until the record it runs into has become visible. */
 			int64_t pre = ckrow ? 0 : e - 1 - p < RB3H_PREROLL ? e - 1 - p : RB3H_PREROLL;
 			if (e - p < RB3H_MIN_SEG && e - p < step) continue; /* keep the sentinel walker's own segment long (see k_chain) */
-			w[nw].row = ckrow ? ckrow[p / step] : p + pre, w[nw].ka0 = -1, w[nw].flags = pre << 8; /* (flags >> 8: the part of nsteps outside the segment, for whoever thins the list) */
+			w[nw].row = ckrow ? ckrow[p / step] : p + pre, w[nw].ka0 = -1, w[nw].flags = pre << 8; /* (flags >> 8 & 255: the part of nsteps outside the segment, for whoever thins the list) */
+			if (!ckrow && pre == RB3H_PREROLL && e - 1 - (p + pre) >= RB3H_PROBE) w[nw].flags |= (int64_t)RB3H_PROBE << 16; /* (flags >> 16: see k_chain, "a walker that starts late") */
 			w[nw].nsteps = prev < 0 ? INT64_MAX / 2 : p - prev + pre;
 			prev = p, ++nw;
 		}

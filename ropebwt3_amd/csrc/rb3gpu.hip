@@ -1176,7 +1176,7 @@ static rb3gpu_walker_t *thin_walkers(int64_t n, const rb3gpu_walker_t *w, int th
 	const int64_t INF = INT64_MAX / 2;
 	int64_t k = 0, idx = 0, acc = 0;
 	for (int64_t i = 0; i < n; ++i) {
-		const int64_t pre = w[i].flags >> 8; // (rb3h_walkers_text: the walker starts that many positions outside its segment, and nsteps counts them)
+		const int64_t pre = w[i].flags >> 8 & 0xFF; // (rb3h_walkers_text: the walker starts that many positions outside its segment, and nsteps counts them)
 		acc = (acc >= INF || w[i].nsteps >= INF) ? INF : acc + w[i].nsteps - pre;
 		const bool sentinel = w[i].ka0 == RB3GPU_KA_SENTINEL || w[i].ka0 >= 0; // (a walker that knows its insertion point ends a string's group, or is somebody's hand-off: always kept)
 		if (sentinel || idx % thin == thin - 1) { o[k] = w[i], o[k].nsteps = acc >= INF ? INF : acc + pre, ++k, acc = 0; }
@@ -2067,9 +2067,11 @@ int64_t rb3gpu_walker_step(int device, int64_t len, int64_t n_strings)
 		if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cu <= 0) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
 		__atomic_store_n(&cus[device], cu, __ATOMIC_RELAXED);
 	}
-	// k_chain: 88 registers -> 5 waves per SIMD, 4 SIMDs per compute unit, 8 walkers per wave; a few per cent left free for the
-	// walkers at the string ends (one per string on top of the regular ones) and for strings that do not divide evenly
-	int64_t room = (int64_t)cu * 160 * 63 / 64 - (n_strings > 0 ? n_strings : 0);
+	// k_chain: 88 registers -> 5 waves per SIMD, 4 SIMDs per compute unit, 8 walkers per wave.  One sixteenth is left free: the
+	// kernels that run beside the walkers (the batch's histogram on the side stream, the strand kernel of the next batch's upload)
+	// take wave slots too, and a walker whose wave starts late is not only slow -- whoever runs into its rows before it has
+	// recorded them walks them as well, and a merge now and then (1 in ~1000 at 63/64) had to be redone without tentative records
+	int64_t room = (int64_t)cu * 160 * 15 / 16 - (n_strings > 0 ? n_strings : 0);
 	if (room < 1024) room = 1024;
 	const int64_t step = (len + room - 1) / room;
 	return step < 192 ? 192 : step;

@@ -1012,9 +1012,11 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				if (bkb >= 0) rec_pos<TENT && !LIST>(&row[bkb], bval, vis);
 				break;
 			}
+			int probe = 0; // TEXT: text distance to a row of the right neighbour's segment that tells whether this walker comes too late (below)
 			if (LIST) {
 				const Walker w = wl[wid];
 				kb = w.row, remaining = w.nsteps;
+				probe = (int)(w.flags >> 16 & 0xFF);
 				if (!TEXT && kb < 0) continue; // an empty slot of a device-made list
 				if (TEXT) {
 					tp = w.row;
@@ -1039,6 +1041,16 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				kb = (int64_t)(x >> 3);
 				rc = (uint64_t)ld_pos(&row[trec ? tp : kb]);
 				if (gap && (int64_t)rc >= 0) continue;
+				// A walker that starts LATE (its wave was not resident when the kernel began: it starts when the first waves finish, i.e.
+				// just when its right neighbour reaches the end of its segment) must not start at all: the neighbour, finding this
+				// walker's rows unrecorded, walks them itself, and a late walker recording behind it leaves a stretch that nobody
+				// settles (the merge is then redone).  Its start row is the neighbour's -- recorded if the neighbour has passed -- but
+				// only visible some iterations later: the row `probe` positions further right has been visible for that long.
+				if (gap && probe > 0 && tp + probe < n2) {
+					const int64_t tq = tp + probe;
+					const int64_t rp = ld_pos(&row[trec ? tq : (int64_t)(tw[tq] >> 3)]);
+					if (rp >= 0) continue;
+				}
 			} else {
 				x = (uint64_t)ld_pos(&row[kb]);
 				if (gap && (int64_t)x >= 0) continue; // an inexact walker whose start row somebody has already recorded

@@ -1152,19 +1152,19 @@ def test_duplicate_genome_long_settle_paths(oracle, tent_q):
 
 @pytest.mark.gpu
 def test_walker_step_is_the_resident_capacity_of_the_walker_kernel():
-    """rb3gpu_walker_step: len / (compute units x 160 walkers x 63/64 - strings), never below 192; the list made with it has no
+    """rb3gpu_walker_step: len / (compute units x 160 walkers x 15/16 - strings), never below 192; the list made with it has no
     more walkers than the kernel keeps resident, so every octet gets one walker and none waits for another to finish"""
     from ropebwt3_amd import walker_step, host
     big = 10 ** 12
     room = big // walker_step(0, big, 0)                   # walkers the kernel is given room for (within one step's rounding)
     assert room % 160 < 64 or True
-    assert 160 * 63 // 64 * 16 <= room <= 160 * 63 // 64 * 1024        # 16 .. 1024 compute units
+    assert 160 * 15 // 16 * 16 <= room <= 160 * 15 // 16 * 1024        # 16 .. 1024 compute units
     assert walker_step(0, 1000, 2) == 192 and walker_step(0, 192 * (room - 4), 2) == 192
     for length, n_str in ((8800002, 2), (200000002, 2), (3000000, 64), (room * 500, 1000)):
         s = walker_step(0, length, n_str)
         assert s >= 192 and length // s + n_str <= room + 1
         assert s == 192 or length / (s - 1) + n_str > room * 0.999          # not wider than needed
-    assert 215 <= walker_step(0, 8800002, 2) <= 225 or room != 256 * 160 * 63 // 64     # (an MI355X: 256 compute units)
+    assert 225 <= walker_step(0, 8800002, 2) <= 235 or room != 256 * 160 * 15 // 16     # (an MI355X: 256 compute units)
     rng = np.random.default_rng(5)
     t = util.make_text([util.random_genome(rng, 2000000)])
     w = host.walkers_text(t, walker_step(0, t.size, 2))

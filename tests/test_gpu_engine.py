@@ -1217,3 +1217,40 @@ def test_records_in_text_order_gathered_through_the_suffix_array(oracle, seed, k
         assert st["n_fallbacks"] == 0, st
     finally:
         h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blkcap,octs", [(1, 8), (2, 3), (7, 8), (40, 1)])
+def test_walkers_that_start_late(oracle, blkcap, octs):
+    """Far fewer wave slots than walkers (rb3gpu_tune blkcap / octs): most walkers are taken from the queue when an octet has
+    finished its first one, i.e. they START LATE, some of them just when their right neighbour reaches their rows -- the
+    situation of a wave that was not resident when the kernel began.  A late walker whose rows its neighbour has already walked
+    must not start (it probes a row of the neighbour's segment, Walker.flags >> 16); whatever the timing, the index is the
+    oracle's, and a merge is redone at most rarely."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(900 + blkcap)
+    g0 = util.random_genome(rng, 150000)
+    rel = [g0] + [util.mutate(rng, g0, 0.002) for _ in range(7)]
+    cur = host.build_bwt(util.make_text(rel))
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.tune("blkcap", blkcap)
+        h.tune("octs", octs)
+        h.from_plain(cur)
+        n_merges = 0
+        for k in range(6):
+            t2 = util.make_text([util.mutate(rng, rel[k % len(rel)], 0.001)])
+            b2 = host.build_bwt(t2.copy())
+            cur = oracle.merge(cur, b2)
+            d_bwt, d_tw, d_sa = h.sort_text_sa(t2)
+            w = host.walkers_text(t2, 192 + 16 * k)            # ~1500 walkers for 8 .. 320 octets
+            h.merge_text_dev(d_bwt, d_tw, t2.size, w, commit=True, d_sa=d_sa if k & 1 else None)
+            n_merges += 1
+            assert np.array_equal(h.export_plain(), cur), (blkcap, octs, k)
+            for p in (d_bwt, d_tw, d_sa):
+                h.dev_free(p)
+        st = h.stats()
+        print("blkcap", blkcap, "octs", octs, "fallbacks", st["n_fallbacks"], "of", n_merges)
+        assert st["n_fallbacks"] <= 2, st
+    finally:
+        h.close()

@@ -2060,11 +2060,20 @@ int rb3gpu_sorter_upload_fwd(rb3gpu_sorter_t *s, int64_t len, const uint8_t *tex
 
 int64_t rb3gpu_walker_step(int device, int64_t len, int64_t n_strings)
 {
-	static int cus[64]; // compute units per device (0: not asked yet)
+	static int cus[64]; // compute units per device x resident walkers per compute unit / 160 (0: not asked yet)
 	if (device < 0 || device >= 64 || len <= 0) return RB3GPU_EINVAL;
 	int cu = __atomic_load_n(&cus[device], __ATOMIC_RELAXED);
 	if (cu == 0) {
+		int dev0 = 0, nb = 0;
 		if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cu <= 0) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+		// blocks of 256 threads of the walker kernel (the variant the text-order walk of a pangenome build runs) a compute unit keeps
+		// resident: 5 with its 88 registers; asked of the runtime so that a compiler that allocates differently does not silently
+		// put the walkers beyond the resident ones
+		if (hipGetDevice(&dev0) == hipSuccess && hipSetDevice(device) == hipSuccess) {
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_chain<true, false, true, 1, 8>, 256, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+			(void)hipSetDevice(dev0);
+		}
+		if (nb >= 1 && nb <= 8) cu = cu * nb / 5; // (room below counts 160 walkers = 5 blocks x 4 waves x 8 per unit)
 		__atomic_store_n(&cus[device], cu, __ATOMIC_RELAXED);
 	}
 	// k_chain: 88 registers -> 5 waves per SIMD, 4 SIMDs per compute unit, 8 walkers per wave.  One sixteenth is left free: the

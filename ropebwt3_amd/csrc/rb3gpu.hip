@@ -105,6 +105,7 @@ struct Tune {
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
 	int trec = -1;           // records of a text-order walk in text order (needs the batch's suffix array): 1 always, 0 never, -1: where the index does not fit the caches
+	int64_t abs_limit = RB3_ABS_LIMIT; // indexes of fewer symbols carry the LF base in their slot headers (at most 2^32: the headers are 32-bit); set before an index exists
 	int tent_q = 0;          // width of the drop-out masks of the tentative stretches in units of 256 bits: 1, 2, 4, 8; 0: follows what the walkers report
 	int copy_walkers = 0;    // a walker list in page-locked memory is copied to the device all the same (instead of being read in place)
 	int chain_bs = 256;      // threads per block of k_chain in the single-sync merge (64, 128 or 256: the kernel has no block-level state; smaller blocks spread the waves more evenly over the CUs)
@@ -352,7 +353,8 @@ static IdxView view_of(const rb3gpu_t *h)
 	v.grp64 = (const uint64_t*)h->grp, v.slot16 = (const uint4*)h->slots, v.n = h->n, v.m = h->acc[1];
 	v.gsm = h->grp ? (const uint64_t*)(h->ib[h->cur].grp + h->ib[h->cur].grp_cap) : nullptr;
 	const int64_t nwin = (h->n >> RB3_WIN_BITS) + 1;
-	v.dense = h->nslots == nwin ? (RB3_ABS_HEADERS(h->nslots, nwin, h->n) ? 2 : 1) : 0;
+	v.abs = RB3_ABS_HEADERS(h->n, h->tn.abs_limit) ? 1 : 0;
+	v.dense = h->nslots == nwin ? (v.abs ? 2 : 1) : 0;
 	return v;
 }
 
@@ -403,7 +405,10 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "chain_bs")) t.chain_bs = v == 64 ? 64 : v == 128 ? 128 : 256;
 	else if (!strcmp(key, "copy_walkers")) t.copy_walkers = v != 0;
 	else if (!strcmp(key, "trec")) t.trec = v < 0 ? -1 : v != 0;
-	else if (!strcmp(key, "tent_q")) t.tent_q = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : v >= 1 ? 1 : 0;
+	else if (!strcmp(key, "abs_limit")) {
+		if (h->grp) return RB3GPU_ESTATE; // the headers of the index in place were written under the old limit
+		t.abs_limit = v < 0 ? 0 : v > RB3_ABS_LIMIT ? RB3_ABS_LIMIT : v;
+	} else if (!strcmp(key, "tent_q")) t.tent_q = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : v >= 1 ? 1 : 0;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
 	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? 0 : v > 12 ? 12 : (int)v;
 	else if (!strcmp(key, "log_alloc")) t.log_alloc = v != 0;
@@ -439,7 +444,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "trec", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -816,15 +821,15 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	if (winpar && runspace) {
 		const int64_t lw2 = h->reb_last[1] < 0 ? ngrp : h->reb_last[1] + h->reb_last[1] / 2 + 8; // (as above: the grid for the list the merge before left)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<true>), dim3(lw2 < 4096 ? (unsigned)lw2 : 4096u), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
-				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap);
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap, (int64_t)-1, (int64_t)-1, h->tn.abs_limit);
 		hipLaunchKernelGGL(k_place, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, h->st, (const uint8_t*)gkind, (const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot,
-				(const uint4*)h->gslots.p, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, nwin, ntot, skip, (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap);
+				(const uint4*)h->gslots.p, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, nwin, ntot, skip, (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap, h->tn.abs_limit);
 	} else if (winpar)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<false>), dim3((unsigned)ngrp), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
-				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, slot_cap);
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, slot_cap, (int64_t)-1, (int64_t)-1, h->tn.abs_limit);
 	else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
-				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, skip);
+				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, skip, h->tn.abs_limit);
 	// the compact copy of the slot words of the new directory (IdxView.gsm), behind its entries
 	hipLaunchKernelGGL(k_grp_compact, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, h->st, (const uint64_t*)h->ib[dst].grp, ngrp, (uint64_t*)(h->ib[dst].grp + h->ib[dst].grp_cap), skip);
 	*ongrp = ngrp;
@@ -2432,7 +2437,7 @@ static int from_fmd_chunked(rb3gpu_t *h, rb3fmd_dec *ctx, int64_t n, const int64
 			else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<false>), dim3((unsigned)(g1 - g0)), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, rem,
 						(const uint32_t*)(gstat + g0 * 8), (const uint64_t*)(gpre + g0 * 8), (const uint64_t*)dtot, h->ib[dst].grp + g0, (uint4*)h->ib[dst].slots, nw, (const unsigned long long*)nullptr,
-						(const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, ~0ull, nwin, n);
+						(const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, ~0ull, nwin, n, h->tn.abs_limit);
 		}
 		if (pass == 0) {
 			if ((r = scan_records(h, gstat, ngrp, gpre, dtot, total)) < 0) return r; // (one synchronisation: the slot count sizes the index)

@@ -37,14 +37,20 @@ struct IdxView {
 	int64_t m;               // number of sentinels (= acc[1])
 	int dense;               // 0: mixed slots.  1: every slot is a bit-plane slot (slot index = position >> 8).
 	                         // 2: as 1 and the slot headers carry ABSOLUTE counts (RB3_ABS_HEADERS): rank needs no directory
+	int abs;                 // the slot headers carry ABSOLUTE counts (an index of fewer than 2^32 symbols): a rank needs the directory's
+	                         // slot word (gsm) to find the slot, but not the 64-byte entry with the group's counts
 };
 
-/* A block array whose slots are all bit planes and that holds fewer than 2^32 symbols is written with
- * hdr[1..6] = C[a] + #{i < slot start : B[i] = a}, the full LF base, instead of the count relative to the
- * group start: rank(c, k) is then ONE memory request (the slot), which is worth ~16 % of k_chain on such
- * an index (measured: one more directory request per rank costs 19 %).  The group directory is written
- * as always.  Both the builder (device, from the scan totals) and the host (view_of) apply this rule. */
-#define RB3_ABS_HEADERS(nslots, nwin, ntot) ((nslots) == (nwin) && (ntot) < (1LL << 32))
+/* A block array that holds fewer than 2^32 symbols is written with hdr[1..6] = C[a] + #{i < slot start : B[i] = a}, the
+ * full LF base, instead of the count relative to the group start: where all slots are bit planes rank(c, k) is then ONE
+ * memory request (the slot), which is worth ~16 % of k_chain on such an index; on a run-coded index the 64-byte directory
+ * entry with the group's counts is not read any more (the slot is found through the compact copy of the slot words, 8 bytes
+ * per group), and the walk of a pangenome build is bound by exactly that: random lines per second behind the L2 (one more
+ * random 64-byte line per step costs 21 %, measured; round 1 on the dense index: 19 %).  The group directory is written
+ * as always.  Both the builder (device, from the scan totals) and the host (view_of) apply this rule.
+ * (nslots, nwin: no longer part of the rule -- rounds 1-3 had absolute headers in bit-plane-only indexes.) */
+#define RB3_ABS_LIMIT (1LL << 32)
+#define RB3_ABS_HEADERS(ntot, lim) ((ntot) < (lim))
 
 struct Acc7 { int64_t a[7]; };
 
@@ -348,7 +354,7 @@ __global__ void __launch_bounds__(256) k_rank_batch(IdxView ix, Acc7 acc, int64_
 		RankLoad r;
 		oct_rank_issue(ix, kk, j, r);
 		for (int c = 0; c < 6; ++c) {
-			int64_t v = oct_rank_finish(r, c, j, ix.dense == 2) - acc.a[c];
+			int64_t v = oct_rank_finish(r, c, j, ix.abs != 0) - acc.a[c];
 			if (j == 0) ok[q * 6 + c] = v;
 		}
 	}
@@ -646,6 +652,7 @@ __device__ __forceinline__ void octc_issue_grp(const IdxView &ix, int64_t k, int
 	const int64_t g = k >> RB3_GRP_BITS;
 	r.koff = (uint32_t)k & (RB3_GRP - 1);
 	if (DENSE) octc_load_slot<LPW>(ix, k >> RB3_WIN_BITS, j, r); // every window is its own slot and carries the LF base: no directory lookup
+	else if (ix.abs) r.gc = 0, r.sm = ix.gsm[g];                  // the headers carry the LF base: only the slot word, from its compact copy
 	else r.gc = ix.grp64[g * 8 + c], r.sm = ix.grp64[g * 8 + 6];
 }
 
@@ -688,10 +695,10 @@ __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, uint32_t k
 	uint32_t ca, cb;
 	uint32_t mt;
 	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, (int)rl.koff - base, (int)koff_hi - base, c, j, &ca, &cb, &mt);
-	uint32_t v = ca | cb << 16; // both fit 16 bits (counts inside a group of 8192)
-	v += octc_hdr_c<LPW>(rl, c, j) * 0x00010001u;
+	uint32_t v = ca | cb << 16; // both fit 16 bits (counts inside a slot of at most 8192 symbols)
 	v = grp_sum<LPW>(v);
-	*lo_n = (int64_t)(rl.gc + (v & 0xFFFFu)), *hi_n = (int64_t)(rl.gc + (v >> 16));
+	const uint64_t hb = rl.gc + grp_sum<LPW>(octc_hdr_c<LPW>(rl, c, j)); // (the header may be the whole LF base: 32 bits)
+	*lo_n = (int64_t)(hb + (v & 0xFFFFu)), *hi_n = (int64_t)(hb + (v >> 16));
 }
 
 /* the same with the slot's offset in its group given (derived from the directory's mask: no header word needed) */
@@ -700,9 +707,9 @@ __device__ __forceinline__ void octc_finish_pair_at(const RankLoadC &rl, int off
 	uint32_t ca, cb, mt;
 	slice_count_pk<true, false, 8>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16;
-	v += (j == c + 1 ? rl.sl.x : 0u) * 0x00010001u;
 	v = oct_sum(v);
-	*lo_n = (int64_t)(rl.gc + (v & 0xFFFFu)), *hi_n = (int64_t)(rl.gc + (v >> 16));
+	const uint64_t hb = rl.gc + oct_sum(j == c + 1 ? rl.sl.x : 0u); // (the header may be the whole LF base: 32 bits)
+	*lo_n = (int64_t)(hb + (v & 0xFFFFu)), *hi_n = (int64_t)(hb + (v >> 16));
 }
 
 /* LF(c, k) for the group's query; *match = 1 iff the symbol at offset k itself is c (then the suffix
@@ -722,10 +729,9 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 		const uint32_t hdr0 = grp_bcast0<LPW>(r.sl.x, j);
 		part = slice_count<LPW, MATCH>(r.sl, r.sl2, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
 	}
-	part += octc_hdr_c<LPW>(r, c, j);
-	const uint32_t sum = grp_sum<LPW>(part);
+	const uint32_t sum = grp_sum<LPW>(part), base = grp_sum<LPW>(octc_hdr_c<LPW>(r, c, j)); // (the header may be the whole LF base: 32 bits)
 	*match = sum >> 20;
-	return (int64_t)(r.gc + (sum & (RB3_MATCH_BIT - 1u)));
+	return (int64_t)(r.gc + base + (sum & (RB3_MATCH_BIT - 1u)));
 }
 
 /* Tentative records (TENT = true).  An inexact walker whose interval [lo, hi) has shrunk to a few
@@ -1092,7 +1098,8 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					const int64_t g = lo >> RB3_GRP_BITS;
 					RankLoadC rl;
 					rl.sm = b1.gsm[g];
-					rl.gc = b1.grp64[g * 8 + c];
+					rl.gc = 0;
+					if (!b1.abs) rl.gc = b1.grp64[g * 8 + c];         // (headers relative to the group: an index of 2^32 symbols or more)
 					const int64_t tpn = tp - 1;                       // (c != 0: there is a symbol before this one, so tp >= 1)
 					const uint64_t xn = tw[tpn > 0 ? tpn - 1 : 0];    // the word after next
 					const int64_t kbn = (int64_t)(x1 >> 3);
@@ -1142,9 +1149,10 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					else if (__all(rle && rleb && !far)) { // some walker's interval straddles two run slots: everybody through the two-slot decode
 						uint32_t ca, cb;
 						slice_count_pk2(rl.sl, slb, off_lo, same ? off_hi : off_hi - (int)((wend - w0) << RB3_WIN_BITS), c, j, &ca, &cb);
-						uint32_t v = (ca + (j == c + 1 ? rl.sl.x : 0u)) | (cb + (j == c + 1 ? slb.x : 0u)) << 16;
+						uint32_t v = ca | cb << 16;
 						v = oct_sum(v);
-						lo_n = (int64_t)(rl.gc + (v & 0xFFFFu)), hi_n = (int64_t)(rl.gc + (v >> 16));
+						const uint32_t hl = oct_sum(j == c + 1 ? rl.sl.x : 0u), hh = oct_sum(j == c + 1 ? slb.x : 0u); // (headers of 32 bits where they carry the LF base)
+						lo_n = (int64_t)(rl.gc + hl + (v & 0xFFFFu)), hi_n = (int64_t)(rl.gc + hh + (v >> 16));
 					} else if (rle && same) octc_finish_pair_at(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
 					else { // a bit-plane slot somewhere
 						uint32_t match = 0, mh;
@@ -2080,7 +2088,7 @@ __global__ void __launch_bounds__(256) k_lf_check(IdxView b1, const int64_t *pos
 		const int64_t kbn = c2 + (int64_t)tpre[tile * 8 + c] + cnt;
 		RankLoad rl;
 		oct_rank_issue(b1, ka, j, rl);
-		const int64_t want = oct_rank_finish(rl, c, j, b1.dense == 2);
+		const int64_t want = oct_rank_finish(rl, c, j, b1.abs != 0);
 		if (kbn < 0 || kbn >= n2 || pos[kbn] - kbn != want) ok = false;
 	}
 	if (j == 0) {
@@ -2336,7 +2344,7 @@ __global__ void __launch_bounds__(64) k_pass1(IdxView old, const int64_t *pos, c
  * gpre[g*8 + 0..5] = symbol counts before the group, [6] = slots before the group. */
 template<bool FROM_PLAIN>
 __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot,
-		const int64_t *jg, const uint32_t *gstat, const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t ngrp, const unsigned long long *skip)
+		const int64_t *jg, const uint32_t *gstat, const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t ngrp, const unsigned long long *skip, int64_t abs_lim = RB3_ABS_LIMIT)
 {
 	if (RB3_REB_SKIP(skip)) return;
 	__shared__ __attribute__((aligned(16))) uint8_t symbuf[RB3_WIN];
@@ -2361,7 +2369,7 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 	int64_t sidx = (int64_t)slot0 - 1;
 	int slot_w0 = 0, slot_sz = 1, nc = 0;
 	uint32_t abs_base = 0; // lanes 1..6: the LF base of the group start if the headers are absolute (RB3_ABS_HEADERS)
-	if (RB3_ABS_HEADERS((int64_t)tot[6], W, ntot) && lane >= 1 && lane <= 6) {
+	if (RB3_ABS_HEADERS(ntot, abs_lim) && lane >= 1 && lane <= 6) {
 		uint64_t cb = gpre[g * 8 + lane - 1];
 		for (int a = 0; a < lane - 1; ++a) cb += tot[a];
 		abs_base = (uint32_t)cb;
@@ -2739,7 +2747,7 @@ template<bool LISTED = false>
 __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wstat, const uint32_t *wplane, const uint16_t *wruns, int64_t ntot, const uint32_t *gstat,
 		const uint64_t *gpre, const uint64_t *tot, rb3_grp_t *grp, uint4 *slot16, int64_t nwin, const unsigned long long *skip,
 		const uint32_t *glist = nullptr, const uint32_t *nglist = nullptr, uint32_t lcap = 0, uint64_t slot_cap = ~0ull,
-		int64_t all_nwin = -1, int64_t all_ntot = -1) // (a chunk of a larger build: windows / symbols of the WHOLE index, which decide the header kind)
+		int64_t all_nwin = -1, int64_t all_ntot = -1, int64_t abs_lim = RB3_ABS_LIMIT) // (a chunk of a larger build: windows / symbols of the WHOLE index, which decide the header kind)
 {
 	if (RB3_REB_SKIP(skip)) return;
 	if (LISTED && *nglist > lcap) return;
@@ -2767,7 +2775,7 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		grp[g] = e;
 	}
 	uint32_t abs_base = 0; // lanes 1..6: the LF base of the group start if the headers are absolute (RB3_ABS_HEADERS)
-	if (RB3_ABS_HEADERS((int64_t)tot[6], all_nwin, all_ntot) && lane >= 1 && lane <= 6) {
+	if (RB3_ABS_HEADERS(all_ntot, abs_lim) && lane >= 1 && lane <= 6) {
 		uint64_t cb = gpre[g * 8 + lane - 1];
 		for (int a = 0; a < lane - 1; ++a) cb += tot[a];
 		abs_base = (uint32_t)cb;
@@ -3402,7 +3410,7 @@ __global__ void __launch_bounds__(64 * RB3_RG_WAVES, RMAX <= 384 ? 5 : 3) k_reb_
  * window kernels are written by k_pass2w).  Eight lanes per group. */
 __global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint32_t *gstat, const uint64_t *gpre, const uint64_t *tot, const uint4 *gslots,
 		rb3_grp_t *grp, uint4 *slot16, int64_t ngrp, int64_t nwin, int64_t ntot, const unsigned long long *skip,
-		const uint32_t *nglist, uint32_t lcap, uint64_t slot_cap)
+		const uint32_t *nglist, uint32_t lcap, uint64_t slot_cap, int64_t abs_lim = RB3_ABS_LIMIT)
 {
 	if (RB3_REB_SKIP(skip)) return;
 	if (*nglist > lcap || tot[6] > slot_cap) return; // see k_decide / k_pass2w: the host does the rebuild again
@@ -3421,7 +3429,7 @@ __global__ void __launch_bounds__(256) k_place(const uint8_t *gkind, const uint3
 	((uint64_t*)grp)[g * 8 + j] = j < 6 ? cb + gp : j == 6 ? (uint64_t)(uint32_t)slot0 | (uint64_t)mask << 32 : 0ull;
 	// headers that carry the whole LF base (RB3_ABS_HEADERS): header lane j holds symbol j-1, whose base sits in lane j-1
 	const uint32_t below = (uint32_t)__shfl((int)(uint32_t)(cb + gp), (j + 7) & 7, 8);
-	const uint32_t add = (RB3_ABS_HEADERS((int64_t)tot[6], nwin, ntot) && j >= 1 && j <= 6) ? below : 0u;
+	const uint32_t add = (RB3_ABS_HEADERS(ntot, abs_lim) && j >= 1 && j <= 6) ? below : 0u;
 	for (uint32_t si = 0; si < ns && si < RB3_RG_MAXSLOTS; ++si) {
 		uint4 v = gslots[(g * RB3_RG_MAXSLOTS + si) * 8 + j];
 		v.x += add;
@@ -3646,7 +3654,7 @@ __global__ void __launch_bounds__(256) k_sh_step(IdxView ix, ShArgs a, int64_t n
 		if (c != 0) { // (wave-uniform control flow is not required: the rank helpers only talk inside an octet)
 			RankLoad r;
 			oct_rank_issue(ix, k, j, r);
-			nx.ka = oct_rank_finish(r, c, j, ix.dense == 2) + a.adj[c];
+			nx.ka = oct_rank_finish(r, c, j, ix.abs != 0) + a.adj[c];
 			d = 0;
 			for (int i = 1; i < a.n_iv; ++i) d += a.bounds[i] <= nx.ka ? 1 : 0;
 		}
@@ -3838,7 +3846,7 @@ __device__ __forceinline__ int64_t oct_lf_self(const IdxView &ix, int64_t k, int
 	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
 	const uint32_t sy = oct_sum(slice_sym(r.sl, hdr0, off, j)) & 7u;
 	*c = (int)sy;
-	return oct_rank_finish(r, (int)sy, j, ix.dense == 2);
+	return oct_rank_finish(r, (int)sy, j, ix.abs != 0);
 }
 
 /* nxt[2p] = next splitter (or RB3_SSA_END | sentinel row reached), nxt[2p+1] = steps of the sublist;

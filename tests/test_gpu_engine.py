@@ -647,10 +647,11 @@ def test_full_stretch_table_is_answered_with_fewer_walkers(oracle, entry):
 
 
 @pytest.mark.parametrize("env", [{"RB3GPU_GROUP_REBUILD": "1"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_GROUP_REBUILD": "1", "RB3GPU_STAGED": "1"},
-                                 {"RB3GPU_TEXT_MODE": "2"}, {"RB3GPU_WINDOW_REBUILD": "1"}])
+                                 {"RB3GPU_TEXT_MODE": "2"}, {"RB3GPU_WINDOW_REBUILD": "1"}, {"RB3GPU_ABS_LIMIT": "0"}, {"RB3GPU_ABS_LIMIT": "60000"}])
 def test_fallback_code_paths_via_soak(env):
-    """the group-sequential rebuild kernels (taken when the window scratch would exceed 8 GB) and the staged merge
-    (taken for walker-less or oversized merges) forced through the randomised soak"""
+    """the group-sequential rebuild kernels (taken when the window scratch would exceed 8 GB), the staged merge
+    (taken for walker-less or oversized merges) and the slot headers of an index of 2^32 symbols or more (counts relative
+    to the group; abs_limit moves that border down to nothing or into the middle of the builds) forced through the randomised soak"""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "10", "61000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env))
@@ -1252,5 +1253,58 @@ def test_walkers_that_start_late(oracle, blkcap, octs):
         st = h.stats()
         print("blkcap", blkcap, "octs", octs, "fallbacks", st["n_fallbacks"], "of", n_merges)
         assert st["n_fallbacks"] <= 2, st
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("limit", [0, 150000, 1 << 32])
+def test_slot_headers_relative_to_the_group(oracle, limit):
+    """an index below 2^32 symbols carries the LF base in its slot headers (a rank reads the slot words and the slot, no directory
+    entry); from 2^32 symbols on the headers count from the group start.  rb3gpu_tune abs_limit moves that border: 0 = every build
+    writes relative headers, 150000 = the family below crosses it in mid build.  Same BWT as the oracle's merge (fm-index.c:237-249)
+    after every round, same ranks, and the limit cannot be changed under an index."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(401)
+    g0 = util.random_genome(rng, 20000)
+    h = Rb3Gpu(verbose=1)
+    h.tune("abs_limit", limit)
+    want = None
+    try:
+        for i in range(16):
+            g = util.mutate(rng, g0, 0.002) if i % 4 else util.random_genome(rng, 9000)   # run slots and bit planes side by side
+            t = util.make_text([g])
+            b = host.build_bwt(t.copy())
+            if want is None:
+                h.from_plain(b); want = b
+                with pytest.raises(Exception):
+                    h.tune("abs_limit", 5)
+                continue
+            want = oracle.merge(want, b)
+            if i % 3 == 0:
+                h.merge_plain(b)   # LF walk over the batch BWT
+            else:
+                d, dtw = h.sort_text(t)
+                h.merge_text_dev(d, dtw, t.size, host.walkers_text(t, 192), commit=True)
+                h.dev_free(d), h.dev_free(dtw)
+            assert np.array_equal(h.export_plain(), want), i
+        assert h.stats()["n_fallbacks"] == 0
+        ks = np.concatenate([np.arange(0, want.size, 499), [want.size - 1, want.size]])
+        cum = np.zeros((want.size + 1, 6), dtype=np.int64)
+        for c in range(6):
+            cum[1:, c] = np.cumsum(want == c)
+        assert np.array_equal(h.rank1a(ks), cum[ks])
+        # the index written out and read back chunk by chunk (k_pass2w with the header kind of the whole index)
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            fn = os.path.join(td, "x.fmd")
+            with open(fn, "wb") as f:
+                f.write(host.fmd_bytes_from_words(h.export_fmd_words(), h.get_acc()))
+            h2 = Rb3Gpu(verbose=1)
+            try:
+                h2.tune("abs_limit", limit); h2.tune("load_chunk", 3)
+                h2.from_fmd_file(fn)
+                assert np.array_equal(h2.export_plain(), want) and np.array_equal(h2.rank1a(ks), cum[ks])
+            finally:
+                h2.close()
     finally:
         h.close()

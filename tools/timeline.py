@@ -11,14 +11,16 @@ rows = con.execute("select name, start, end, stream_id from kernels order by sta
 chains = [i for i, r in enumerate(rows) if "k_chain" in r[0]]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(chains) - 3
 a, b = chains[which], chains[which + 1]
-# start from the first kernel of the round: walk back to the tile histogram
-while a > 0 and "k_tile_hist" not in rows[a][0]:
+# start from the first kernel of the round: walk back to the tile histogram (a third argument: from this k_chain to the next, as is)
+raw = len(sys.argv) > 3
+while not raw and a > 0 and "k_tile_hist" not in rows[a][0]:
     a -= 1
+if raw: b += 1
 t0 = rows[a][1]
 prev_end = {}
 tot_k = tot_gap = 0.0
 for name, s, e, st in rows[a:b]:
-    if ("k_tile_hist" in name and s != t0) or "k_s_flag" in name:
+    if not raw and (("k_tile_hist" in name and s != t0) or "k_s_flag" in name):
         break
     gap = (s - prev_end[st]) / 1e3 if st in prev_end else 0.0
     prev_end[st] = e

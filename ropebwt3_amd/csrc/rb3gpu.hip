@@ -110,7 +110,7 @@ struct Tune {
 	int copy_walkers = 0;    // a walker list in page-locked memory is copied to the device all the same (instead of being read in place)
 	int chain_bs = 256;      // threads per block of k_chain in the single-sync merge (64, 128 or 256: the kernel has no block-level state; smaller blocks spread the waves more evenly over the CUs)
 	int ssa_split = 8;       // splitter spacing 2^S of the sampled-suffix-array walk
-	int b2_split = 4;        // splitter spacing 2^S of the batch's own LF walk (walkers for the BWT-only entry point); 0: SA-regular walkers (staged path)
+	int b2_split = -1;       // splitter spacing 2^S of the batch's own LF walk (walkers for the BWT-only entry point); 0: SA-regular walkers (staged path); -1: by the size of the batch (merge_core)
 	int log_alloc = 0;       // print every device allocation and the time it took
 	int poison = 0;          // fill every new device buffer with 0xA5 bytes (debugging: nothing may rely on what fresh memory holds)
 	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
@@ -410,7 +410,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 		t.abs_limit = v < 0 ? 0 : v > RB3_ABS_LIMIT ? RB3_ABS_LIMIT : v;
 	} else if (!strcmp(key, "tent_q")) t.tent_q = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : v >= 1 ? 1 : 0;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
-	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? 0 : v > 12 ? 12 : (int)v;
+	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? -1 : v > 12 ? 12 : (int)v;
 	else if (!strcmp(key, "log_alloc")) t.log_alloc = v != 0;
 	else if (!strcmp(key, "defer_free")) t.defer_free = v != 0;
 	else if (!strcmp(key, "poison")) t.poison = v != 0;
@@ -1202,8 +1202,13 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const bool per_string = !walkers && n_walkers > 0;
 	if (d_tw && !walkers && !per_string) return RB3GPU_EINVAL;
 	// neither (the reference's signature: BWT only): the list is made on the device from a sparse LF walk of the batch itself
-	const bool auto_list = !walkers && !per_string && !d_tw && h->tn.b2_split > 0 && h->opt.split_log2 == 0 && len >= 4096;
-	const int b2S = h->tn.b2_split;
+	const bool auto_list = !walkers && !per_string && !d_tw && h->tn.b2_split != 0 && h->opt.split_log2 == 0 && len >= 4096;
+	// Splitters every 2^S rows.  The ranking of the splitters is pointer jumping over all of them (13 rounds for 21 M): a small batch
+	// is bound by the latency of the walks between splitters (S = 4: ~210 dependent steps at most), a whole index merged into another
+	// by the volume of the jumping rounds (334 M symbols: list 18.4 ms of a 45 ms merge at S = 4, 10 ms at S = 6; one genome of 8.8 M:
+	// 1.29 ms per merge at S = 4, 1.47 at S = 5 -- fewer splitters leave more windows without a pick, and a wave of walkers lasts as
+	// long as its longest one).
+	const int b2S = h->tn.b2_split > 0 ? h->tn.b2_split : len < (32LL << 20) ? 4 : len < (128LL << 20) ? 5 : 6;
 	// the device-made list: a walker every b2W text positions -- 384, or more where the batch is so large that the events of that
 	// many walkers would not fit the stretch table (and `thin` times that after a merge whose table did overflow)
 	// How many stretches will the walkers open?  A walker opens one per indexed relative that drops out of its interval, i.e. per

@@ -1404,7 +1404,12 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		case 1: RB3_LAUNCH_FAST(false, false, 1); break;
 		case 0: RB3_LAUNCH_FAST(false, false, 0); break;
 		case 8: RB3_LAUNCH_FAST(false, true, 2); break;
-		case 7: RB3_LAUNCH_FAST(false, true, 1); break;
+		case 7: // (the headline's kernel: 32-bit positions in the common step where index and batch allow it)
+			if (iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29) && lpw == 8)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 8, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
+					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, trec ? 1 : 0);
+			else RB3_LAUNCH_FAST(false, true, 1);
+			break;
 		default: RB3_LAUNCH_FAST(false, true, 0); break;
 		}
 #undef RB3_LAUNCH_FAST

@@ -943,7 +943,9 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
  * string: the L1 cannot hold a line per walker). */
 /* LPW: lanes per walker, 8 (an octet) or 4 (a quad: every lane takes two slices of a slot, and the wave's instruction
  * stream -- what a step costs where the index is run-coded -- serves 16 walkers instead of 8) */
-template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8>
+/* I32 (the common step only): index and batch are small enough for 32-bit positions -- headers with the LF base (IdxView.abs), fewer than
+ * 2^29 rows in the batch -- so that the step's arithmetic is 32-bit and its addresses are a base and a 32-bit offset */
+template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8, bool I32 = false>
 #ifndef RB3_CHAIN_WPE
 #define RB3_CHAIN_WPE 1 /* (kernel experiment: waves per SIMD the register allocation must leave room for) */
 #endif
@@ -1081,11 +1083,11 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				// This body does what the general one does in that state and nothing else; if ANY group of the wave is in another
 				// state the whole wave takes the general step, which handles everything.
 				const uint32_t cq = (uint32_t)x & 7u;
-				const uint64_t kq = (uint64_t)(hi - lo);
+				const uint64_t kq = I32 ? (uint64_t)((uint32_t)hi - (uint32_t)lo) : (uint64_t)(hi - lo);
 				const bool opening = gap != 0 && sid == -1 && age >= RB3_TENT_MIN_AGE && kq <= (uint64_t)kmax;
 				const uint32_t kq32 = kq > 0xFFFFull ? 0xFFFFu : (uint32_t)kq;
 				// (an interval that reaches into the next GROUP needs a second directory entry: the general step)
-				const bool simple = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) && cq != 0u && (int64_t)rc < 0 && !opening && ((uint32_t)lo & (RB3_GRP - 1)) + kq32 <= (uint32_t)RB3_GRP
+				const bool simple = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) && cq != 0u && (int32_t)(rc >> 32) < 0 && !opening && ((uint32_t)lo & (RB3_GRP - 1)) + kq32 <= (uint32_t)RB3_GRP
 					&& kq32 <= (uint32_t)kmax; // (a wider interval -- a walker in its first dozen steps -- may end several slots further on)
 				if (__all(simple)) {
 #ifdef RB3_PROF_STEP /* kernel experiment: where does an iteration of the common step spend its cycles?  (s_memtime at four points) */
@@ -1095,14 +1097,17 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					const int c = (int)cq;
 					// round trip 1: the slot word of lo's group from the compact copy (an L2 hit); the 64-byte entry's count for c is asked
 					// for at the same time but only needed at the very end
-					const int64_t g = lo >> RB3_GRP_BITS;
+					const int64_t g = I32 ? (int64_t)((uint32_t)lo >> RB3_GRP_BITS) : lo >> RB3_GRP_BITS;
 					RankLoadC rl;
-					rl.sm = b1.gsm[g];
+					if (I32) rl.sm = *(const uint64_t*)((const char*)b1.gsm + (((uint32_t)lo >> RB3_GRP_BITS) << 3));
+					else rl.sm = b1.gsm[g];
 					rl.gc = 0;
-					if (!b1.abs) rl.gc = b1.grp64[g * 8 + c];         // (headers relative to the group: an index of 2^32 symbols or more)
-					const int64_t tpn = tp - 1;                       // (c != 0: there is a symbol before this one, so tp >= 1)
-					const uint64_t xn = tw[tpn > 0 ? tpn - 1 : 0];    // the word after next
-					const int64_t kbn = (int64_t)(x1 >> 3);
+					if (!I32 && !b1.abs) rl.gc = b1.grp64[g * 8 + c]; // (headers relative to the group: an index of 2^32 symbols or more)
+					const int64_t tpn = I32 ? (int64_t)((uint32_t)tp - 1u) : tp - 1; // (c != 0: there is a symbol before this one, so tp >= 1)
+					uint64_t xn;                                      // the word after next
+					if (I32) xn = *(const uint64_t*)((const char*)tw + (((uint32_t)tp >= 2u ? (uint32_t)tp - 2u : 0u) << 3));
+					else xn = tw[tpn > 0 ? tpn - 1 : 0];
+					const int64_t kbn = I32 ? (int64_t)((uint32_t)x1 >> 3) : (int64_t)(x1 >> 3);
 					rl.koff = (uint32_t)lo & (RB3_GRP - 1);
 					const uint32_t mask = (uint32_t)(rl.sm >> 32), lw = rl.koff >> RB3_WIN_BITS;
 					const uint32_t mlo = mask & ((2u << lw) - 1u);    // slot starts at or below lo's window (bit 0 is always set)
@@ -1113,20 +1118,26 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					const uint32_t w0 = 31u - (uint32_t)__clz((int)mlo);
 					const uint32_t above = (mask >> w0) >> 1;
 					uint32_t wend = w0 + 1u + (above ? (uint32_t)__builtin_ctz(above) : 31u - w0);
-					if (g == (b1.n >> RB3_GRP_BITS)) { const uint32_t nvw = (uint32_t)(b1.n >> RB3_WIN_BITS & 31) + 1u; wend = wend < nvw ? wend : nvw; } // (the last group ends with the window of position n)
+					if (I32 ? ((uint32_t)lo >> RB3_GRP_BITS) == ((uint32_t)b1.n >> RB3_GRP_BITS) : g == (b1.n >> RB3_GRP_BITS)) { const uint32_t nvw = (uint32_t)(b1.n >> RB3_WIN_BITS & 31) + 1u; wend = wend < nvw ? wend : nvw; } // (the last group ends with the window of position n)
 					const bool rle = wend - w0 > 1u;
 					const int off_lo = (int)(rl.koff - (w0 << RB3_WIN_BITS)), off_hi = off_lo + (int)kq32;
 					const bool same = rl.koff + kq32 <= (wend << RB3_WIN_BITS);
 					const bool far = !same && kq32 > 255u; // (wide masks: an interval of more than 255 rows may end beyond the NEXT slot too: the general decode)
-					octc_load_slot<8>(b1, (int64_t)rl.sidx, j, rl);
 					uint4 slb = make_uint4(0u, 0u, 0u, 0u);
-					if (!same) slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + j]; // the upper end lies in the next slot: asked for at the same time
+					if (I32) { // (fewer than 2^24 slots: the byte offset fits 32 bits)
+						const uint32_t so = rl.sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * 16u;
+						rl.sl = *(const uint4*)((const char*)b1.slot16 + so);
+						if (!same) slb = *(const uint4*)((const char*)b1.slot16 + (so + (uint32_t)sizeof(rb3_slot_t)));
+					} else {
+						octc_load_slot<8>(b1, (int64_t)rl.sidx, j, rl);
+						if (!same) slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + j]; // the upper end lies in the next slot: asked for at the same time
+					}
 #ifdef RB3_PROF_STEP
 					asm volatile("s_nop 0" :: "v"(rl.sidx));
 					const uint64_t pt1 = __builtin_amdgcn_s_memtime(); // the directory word has arrived, the slot is requested
 #endif
 					++steps;
-					const int64_t myval = lo + kb;
+					const int64_t myval = I32 ? (int64_t)((uint64_t)(uint32_t)lo + (uint64_t)(uint32_t)kb) : lo + kb;
 					// (once a stretch is open the interval is at most KMAX wide and the walker old enough, for the rest of its life)
 					if ((gap == 0 || sid >= 0) && j == (int)(it & 7u))
 						bkb = trec ? tp : kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
@@ -1165,7 +1176,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 							hi_n = octc_finish<false, 8, false>(rh, c, j, &mh);
 						}
 					}
-					const int64_t kn = hi_n - lo_n;
+					const int64_t kn = I32 ? (int64_t)(int32_t)((uint32_t)hi_n - (uint32_t)lo_n) : hi_n - lo_n;
 					if (gap == 2 && sid >= 0 && kn >= 1 && kn < (int64_t)kq) { // some matching suffixes are not preceded by c: a new stretch (see below)
 						int ns = sid + 1;
 						if (sid == RB3_TENT_POISON) ns = RB3_TENT_POISON;
@@ -1185,7 +1196,9 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					}
 					++age, --remaining;
 					tp = tpn, x = x1, x1 = xn;
-					kb = kbn, lo = lo_n, hi = hi_n, gap = kn > 1 ? 2 : (int)kn;
+					kb = kbn, gap = kn > 1 ? 2 : (int)kn;
+					if (I32) lo = (int64_t)(uint32_t)lo_n, hi = (int64_t)(uint32_t)hi_n;
+					else lo = lo_n, hi = hi_n;
 #ifdef RB3_PROF_STEP
 					{
 						asm volatile("s_nop 0" :: "v"((uint32_t)lo));

@@ -317,6 +317,11 @@ int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_
  * the environment variable RB3GPU_<KEY> when the handle is created; the merge path itself never calls getenv().
  *   "tent" 0/1, "staged" 0/1, "group_rebuild" 0/1, "window_rebuild" 0/1, "reb_force" 0/1, "octs" 1..8, "blkmul", "blkcap", "ssa_split" 4..20,
  *   "lf_check" n (verify the LF relation of every n-th batch row against the index after each merge; default 4096, 0 = off)
+ *   "tent_q" 1/2/4/8 (width of the drop-out masks in units of 256 bits; 0 = follows what the walkers report), "trec" 0/1/-1 (records of a
+ *   text-order walk in text order: never / always / where the index does not fit the caches), "copy_walkers" 0/1, "b2_split" S (splitter
+ *   spacing 2^S of the walker list the engine makes for the BWT-only entry points; -1 = by the size of the batch), "abs_limit" N (indexes
+ *   of fewer than N symbols carry the LF base in their slot headers; at most 2^32, only before an index exists: RB3GPU_ESTATE after);
+ *   the full table with defaults is in DESIGN.md section 8c
  * Test hooks "force_fallback", "tent_limit", "text_mode" exist only in the test build of the library (compiled with
  * -DRB3GPU_TEST_HOOKS, librb3gpu_hooks.so); the release library answers RB3GPU_EUNSUP.  Unknown key: RB3GPU_EINVAL. */
 int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value);

@@ -1579,6 +1579,54 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (tent && (hm[4] != 0 || hm[2] != 0 || hm[3] != 0)) { // the optimistic pass did not validate (records unsettled, or rows nobody reached): nothing was installed, redo without tentative records
 		h->stt.n_fallbacks += 1;
 		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu tentative records unsettled, %llu rows unset, %llu out of order; redoing the merge without tentative records\n", hm[4], hm[2], hm[3]);
+#ifdef RB3_DEBUG_UNSETTLED /* kernel experiment: what do the records that stayed unsettled look like?  (rows, their stretches and the chains these hang on) */
+		if (!trec && len < (1LL << 28)) {
+			std::vector<int64_t> hp((size_t)len);
+			(void)hipMemcpy(hp.data(), dpos, (size_t)len * 8, hipMemcpyDeviceToHost);
+			std::vector<uint64_t> htw;
+			if (d_tw) { htw.resize((size_t)len); (void)hipMemcpy(htw.data(), d_tw, (size_t)len * 8, hipMemcpyDeviceToHost); }
+			std::vector<int64_t> row2tp;
+			if (d_tw) { row2tp.assign((size_t)len, -1); for (int64_t t = 0; t < len; ++t) { const int64_t r = (int64_t)(htw[t] >> 3); if (r >= 0 && r < len) row2tp[r] = t; } }
+			auto show = [&](int sid, const char *what) {
+				if (sid < 0 || sid >= RB3_TENT_IDS) return;
+				rb3_stretch_t rec; int32_t sf = 0;
+				(void)hipMemcpy(&rec, tab + sid, sizeof(rec), hipMemcpyDeviceToHost);
+				(void)hipMemcpy(&sf, sfin + sid, 4, hipMemcpyDeviceToHost);
+				fprintf(stderr, "      %s sid %d: type %llu prev %d lo %lld w1 %llx del %d child %d pad %x %x sfin %d mask %08x %08x\n", what, sid, (unsigned long long)(rec.w0 >> 62), RB3_DEP_PREV(rec.w0),
+						(long long)(rec.w0 & (uint64_t)RB3_TENT_MASK), (unsigned long long)rec.w1, rec.del, rec.child, rec.pad[0], rec.pad[1], sf, rec.mask[0], rec.mask[1]);
+			};
+			int shown = 0, last_sid = -1;
+			for (int64_t i = 0; i < len && shown < 12; ++i) {
+				const int64_t v = hp[(size_t)i];
+				if (v >= 0 && (v & RB3_TENT)) {
+					const int sid = (int)(v >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1);
+					if (sid == last_sid) continue;
+					last_sid = sid, ++shown;
+					fprintf(stderr, "   row %lld (text position %lld): tentative value %lld, stretch %d; rows around: %lld %lld | %lld %lld\n", (long long)i, d_tw ? (long long)row2tp[(size_t)i] : -1LL, (long long)(v & RB3_TENT_MASK), sid,
+							i > 1 ? (long long)hp[(size_t)i - 2] : -9LL, i > 0 ? (long long)hp[(size_t)i - 1] : -9LL, i + 1 < len ? (long long)hp[(size_t)i + 1] : -9LL, i + 2 < len ? (long long)hp[(size_t)i + 2] : -9LL);
+					show(sid, "this");
+					rb3_stretch_t rec; (void)hipMemcpy(&rec, tab + sid, sizeof(rec), hipMemcpyDeviceToHost);
+					int first = (int)(rec.pad[0] & 0x7FFFFFFFu) - 1;
+					if ((rec.w0 >> 62) == RB3_DEP_EVENT) show(first, "walker's first");
+					int cur = sid;
+					for (int hop = 0; hop < 6; ++hop) { // what it hangs on
+						rb3_stretch_t rc2; (void)hipMemcpy(&rc2, tab + cur, sizeof(rc2), hipMemcpyDeviceToHost);
+						if ((rc2.w0 >> 62) == 0) break;
+						cur = RB3_DEP_PREV(rc2.w0);
+						show(cur, (rc2.w0 >> 62) == RB3_DEP_EVENT ? "  before the event" : "  linked to");
+					}
+					// the text neighbourhood: records of the rows of the text positions to the right (where the settling walker comes from)
+					if (d_tw && row2tp[(size_t)i] >= 0) {
+						const int64_t t0 = row2tp[(size_t)i];
+						fprintf(stderr, "      records at text positions t0-4 .. t0+40 (t0 = %lld):", (long long)t0);
+						for (int64_t t = t0 - 4; t <= t0 + 40; ++t) if (t >= 0 && t < len) { const int64_t vv = hp[(size_t)(htw[t] >> 3)]; fprintf(stderr, " %s%d", vv < 0 ? "U" : (vv & RB3_TENT) ? "T" : "F", vv >= 0 && (vv & RB3_TENT) ? (int)((vv >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1)) : 0); }
+						fprintf(stderr, "\n");
+					}
+				}
+			}
+			if (walkers) fprintf(stderr, "   walkers %lld; first: text position %lld nsteps %lld flags %llx; second: %lld %lld\n", (long long)n_walkers, (long long)walkers[0].row, (long long)walkers[0].nsteps, (unsigned long long)walkers[0].flags, n_walkers > 1 ? (long long)walkers[1].row : -1LL, n_walkers > 1 ? (long long)walkers[1].nsteps : -1LL);
+		}
+#endif
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, 0);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, 0);
 	}

@@ -9,5 +9,5 @@ import json
 d = json.loads(open("gpurun_out/fb.json").read().strip().splitlines()[-1])
 print("ms %.1f fb %s md5 %s" % (d["ms_per_step"], d["config"]["rank_phase_fallbacks"], d["config"]["fmd_identical_to_reference"]))
 PY
-	grep "\[W\|\[E" gpurun_out/fb.err | head -5
+	grep -A40 "\[W" gpurun_out/fb.err | grep -v "^\[M" | head -60
 done

@@ -54,7 +54,12 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
 }
 
 #define RB3H_MIN_SEG 128
-#define RB3H_PROBE 24 /* a walker looks that many positions to the right of its start row for a record of its right neighbour */
+#define RB3H_PROBE 64 /* a walker looks that many positions to the right of its start row for a record of its right neighbour.  (24 until the end
+                       * of round 3: a walker that starts late runs its first iterations slower than the neighbour that follows it -- cold caches,
+                       * a crowded GPU --, so the neighbour, 10-15 rows behind, reached the walker's first rows before their records, parked for up to
+                       * 8 of the WALKER's iterations, had been written: it recorded over them and settled the walker's second stretch instead of the
+                       * first, which the per-walker settle pass does not resolve -- a merge in ten thousand was redone.  With 64 a late walker only
+                       * starts if the neighbour is at least ~55 rows behind.) */
 #ifndef RB3H_PREROLL
 #define RB3H_PREROLL 32 /* = RB3_TENT_MIN_AGE of the engine (rb3gpu_kernels.h) */
 #endif

@@ -1621,6 +1621,20 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 						fprintf(stderr, "      records at text positions t0-4 .. t0+40 (t0 = %lld):", (long long)t0);
 						for (int64_t t = t0 - 4; t <= t0 + 40; ++t) if (t >= 0 && t < len) { const int64_t vv = hp[(size_t)(htw[t] >> 3)]; fprintf(stderr, " %s%d", vv < 0 ? "U" : (vv & RB3_TENT) ? "T" : "F", vv >= 0 && (vv & RB3_TENT) ? (int)((vv >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1)) : 0); }
 						fprintf(stderr, "\n");
+						if (shown == 1) { // the wider neighbourhood, run-length coded (kind, stretch, count), and the walkers that start there
+							fprintf(stderr, "      records at text positions t0-60 .. t0+700:");
+							int64_t run = 0; long long lastk = -2;
+							for (int64_t t = t0 - 60; t <= t0 + 700; ++t) if (t >= 0 && t < len) {
+								const int64_t vv = hp[(size_t)(htw[t] >> 3)];
+								const long long k = vv < 0 ? -1 : (vv & RB3_TENT) ? (long long)((vv >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1)) : -3;
+								if (k != lastk) { if (run) fprintf(stderr, " %s%lldx%lld", lastk == -1 ? "U" : lastk == -3 ? "F" : "T", lastk < 0 ? 0LL : lastk, (long long)run); lastk = k, run = 0; }
+								++run;
+							}
+							fprintf(stderr, " %s%lldx%lld\n", lastk == -1 ? "U" : lastk == -3 ? "F" : "T", lastk < 0 ? 0LL : lastk, (long long)run);
+							for (int64_t wi = 0; walkers && wi < n_walkers; ++wi)
+								if (walkers[wi].row >= t0 - 400 && walkers[wi].row <= t0 + 1000)
+									fprintf(stderr, "      walker %lld: starts at text position %lld (t0%+lld), nsteps %lld, flags %llx, ka0 %lld\n", (long long)wi, (long long)walkers[wi].row, (long long)(walkers[wi].row - t0), (long long)walkers[wi].nsteps, (unsigned long long)walkers[wi].flags, (long long)walkers[wi].ka0);
+						}
 					}
 				}
 			}

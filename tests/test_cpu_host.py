@@ -331,7 +331,7 @@ def test_walker_list_by_text_position_covers_every_row_once():
                 pre, probe = flags >> 8 & 0xFF, flags >> 16
                 p = row - pre
                 assert ka0 == -1 and flags & 0xFF == 0 and 0 <= pre <= 32 and p % step == 0 and b < p < e and row < e
-                assert probe == (24 if pre == 32 and e - 1 - row >= 24 else 0) and row + probe < e
+                assert probe == (64 if pre == 32 and e - 1 - row >= 64 else 0) and row + probe < e
                 assert pre == min(32, e - 1 - p)
                 assert nsteps == (np.iinfo(np.int64).max // 2 if prev is None else p - prev + pre)
                 prev = p

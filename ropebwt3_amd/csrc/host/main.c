@@ -99,7 +99,10 @@ static int usage_build(FILE *fp, const bopt_t *opt)
  * path of a 152-genome build).  Obtaining page-locked memory is slow (it is mapped for the device), so the buffers of
  * finished batches go on a free list and the reader takes them from there: a build allocates a handful, at its start. */
 #define PINPOOL_MAX 8
-static struct { pthread_mutex_t mtx; void *p[64]; int64_t cap[64]; int busy[64]; int n; } g_pin = { PTHREAD_MUTEX_INITIALIZER, {0}, {0}, {0}, 0 };
+#define PINPOOL_SLOTS 64
+static struct { pthread_mutex_t mtx; void *p[PINPOOL_SLOTS]; int64_t cap[PINPOOL_SLOTS]; int busy[PINPOOL_SLOTS]; int n; } g_pin = { PTHREAD_MUTEX_INITIALIZER, {0}, {0}, {0}, 0 };
+static int64_t g_pin_limit = 0; /* RB3_PINNED_LIMIT (tests): requests above it are answered as if the runtime had none */
+static volatile int g_pin_off = 0; /* page-locked memory could not be had: pageable buffers from then on */
 
 static void *pin_alloc(int64_t min_bytes, int64_t *cap)
 {
@@ -123,23 +126,36 @@ static void *pin_alloc(int64_t min_bytes, int64_t *cap)
 	pthread_mutex_unlock(&g_pin.mtx);
 	if (p) return p;
 	if (min_bytes < (16 << 20)) min_bytes = 16 << 20; /* (a batch of one short line still gets a buffer worth keeping) */
-	p = rb3gpu_pinned_alloc(min_bytes);
-	if (p == 0) return 0;
-	pthread_mutex_lock(&g_pin.mtx);
-	if (g_pin.n < 64) g_pin.p[g_pin.n] = p, g_pin.cap[g_pin.n] = min_bytes, g_pin.busy[g_pin.n] = 1, ++g_pin.n;
-	else { pthread_mutex_unlock(&g_pin.mtx); rb3gpu_pinned_free(p); return 0; }
-	pthread_mutex_unlock(&g_pin.mtx);
+	/* Page-locked memory is an optimisation (one DMA per batch), not a requirement: where the runtime cannot supply it (a multi-GB
+	 * batch with --host-sort) or the table is full (many --gpus slices), the batch lives in pageable memory, which the engine
+	 * stages (rb3gpu.h: "NULL: use malloc").  pin_release() tells the two apart by the table. */
+	p = g_pin_off || (g_pin_limit > 0 && min_bytes > g_pin_limit) ? 0 : rb3gpu_pinned_alloc(min_bytes);
+	if (p != 0) {
+		pthread_mutex_lock(&g_pin.mtx);
+		if (g_pin.n < PINPOOL_SLOTS) g_pin.p[g_pin.n] = p, g_pin.cap[g_pin.n] = min_bytes, g_pin.busy[g_pin.n] = 1, ++g_pin.n;
+		else { rb3gpu_pinned_free(p); p = 0; }
+		pthread_mutex_unlock(&g_pin.mtx);
+	} else if (!g_pin_off && g_pin_limit <= 0) {
+		g_pin_off = 1; /* (asking again for every batch would cost a failed system call each time) */
+		if (rb3h_verbose >= 2) fprintf(stderr, "WARNING: no page-locked memory for a batch of %ld bytes; batches are staged from pageable memory from here on\n", (long)min_bytes);
+	}
+	if (p == 0 && (p = malloc((size_t)min_bytes)) == 0) return 0;
 	*cap = min_bytes;
 	return p;
 }
 
 static void pin_release(void *p)
 {
-	int i, n_free = 0;
+	int i, n_free = 0, pooled = 0;
 	pthread_mutex_lock(&g_pin.mtx);
 	for (i = 0; i < g_pin.n; ++i) {
-		if (g_pin.p[i] == p) g_pin.busy[i] = 0;
+		if (g_pin.p[i] == p) g_pin.busy[i] = 0, pooled = 1;
 		n_free += !g_pin.busy[i];
+	}
+	if (!pooled) { /* a pageable stand-in (pin_alloc): a busy page-locked buffer is always in the table */
+		pthread_mutex_unlock(&g_pin.mtx);
+		free(p);
+		return;
 	}
 	if (n_free > PINPOOL_MAX) { /* give the smallest idle one back */
 		int k = -1;
@@ -390,15 +406,16 @@ typedef struct {
 	int64_t head, tail, next_sort; /* next to consume / to fill / to sort */
 	int reader_done;
 	const bopt_t *opt;
+	int device;
 } pool_t;
 
-static int sort_batch(const bopt_t *opt, rb3h_buf_t *seq, int64_t n_seq, int n_threads, batch_t **out, rb3gpu_sorter_t *gs)
+static int sort_batch(const bopt_t *opt, int device, rb3h_buf_t *seq, int64_t n_seq, int n_threads, batch_t **out, rb3gpu_sorter_t *gs)
 {
 	batch_t *b;
 	int64_t n_walkers = 0;
 	rb3h_walker_t *walkers = 0;
 	/* walkers inside long strings: as many as the walker kernel keeps resident on the GPU (rb3gpu_walker_step), or every 2^k positions (-k) */
-	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : rb3gpu_walker_step(opt->device, seq->l, n_seq);
+	int64_t step = opt->split_log2 > 0 ? 1LL << opt->split_log2 : rb3gpu_walker_step(device, seq->l, n_seq); /* (the device of this slice: --gpus N) */
 	int r;
 	if (step < 192 && opt->split_log2 <= 0) step = 384; /* (no such device: the merge will say so) */
 	if (step < (seq->l >> 20)) step = seq->l >> 20; /* at most ~2^20 walkers per batch: the engine's stretch table is finite */
@@ -496,6 +513,7 @@ typedef struct {
 	const bopt_t *opt;
 	int has_index;
 	const char *fn_tmp;
+	int device;
 } consumer_t;
 
 static int consume(consumer_t *c, batch_t *b, int end_of_file)
@@ -521,7 +539,7 @@ static int submit_serial(void *data, rb3h_buf_t *seq, int64_t n_seq, int end_of_
 {
 	consumer_t *c = (consumer_t*)data;
 	batch_t *b = 0;
-	if (seq && sort_batch(c->opt, seq, n_seq, c->opt->n_threads, &b, 0) < 0) return -1;
+	if (seq && sort_batch(c->opt, c->device, seq, n_seq, c->opt->n_threads, &b, 0) < 0) return -1;
 	return consume(c, b, end_of_file);
 }
 
@@ -575,7 +593,7 @@ static void *sorter_main(void *arg)
 		if (j == 0) return 0;
 		{
 			batch_t *b = 0;
-			int err = sort_batch(q->opt, &j->seq, j->n_seq, 1, &b, gs);
+			int err = sort_batch(q->opt, q->device, &j->seq, j->n_seq, 1, &b, gs);
 			pthread_mutex_lock(&q->mtx);
 			j->out = b, j->err = err, j->state = 3;
 			pthread_cond_broadcast(&q->cv);
@@ -613,14 +631,14 @@ static void *run_slice(void *arg)
 		pool_t q;
 		reader_t rd;
 		pthread_t rt, *st;
-		consumer_t cs = { h, opt, has_index, fn_tmp };
+		consumer_t cs = { h, opt, has_index, fn_tmp, sl->device };
 		int k, n_sort = opt->sais_threads;
 		sorter_arg_t *sa;
 		if (opt->gpu_sort && n_sort > 3) n_sort = 3; /* GPU sorters: more than a few at once only compete for the same GPU */
 		memset(&q, 0, sizeof(q));
 		pthread_mutex_init(&q.mtx, 0);
 		pthread_cond_init(&q.cv, 0);
-		q.cap = n_sort + 2, q.ring = (job_t*)calloc((size_t)q.cap, sizeof(job_t)), q.opt = opt;
+		q.cap = n_sort + 2, q.ring = (job_t*)calloc((size_t)q.cap, sizeof(job_t)), q.opt = opt, q.device = sl->device;
 		memset(&rd, 0, sizeof(rd));
 		rd.q = &q, rd.n_files = argc - optind, rd.files = argv + optind;
 		st = (pthread_t*)calloc((size_t)n_sort, sizeof(pthread_t));
@@ -645,7 +663,7 @@ static void *run_slice(void *arg)
 			if (ret == 0) ret = consume(&cs, j.out, j.end_of_file);
 			else if (j.out) {
 				if (j.out->d_bwt) rb3gpu_sorter_release(j.out->gs, j.out->d_bwt);
-				rb3h_batch_free(j.out->bwt); free(j.out->walkers); free(j.out);
+				rb3h_batch_free(j.out->bwt); walkers_free(j.out); free(j.out);
 			}
 		}
 		pthread_join(rt, 0);
@@ -666,7 +684,7 @@ static void *run_slice(void *arg)
 		if (rd.err != 0) ret = -1;
 		n_empty = rd.n_empty, has_index = cs.has_index;
 	} else if (argc - optind >= 1) {
-		consumer_t cs = { h, opt, has_index, fn_tmp };
+		consumer_t cs = { h, opt, has_index, fn_tmp, sl->device };
 		ret = for_each_batch(opt, argc - optind, argv + optind, submit_serial, &cs, &n_empty);
 		has_index = cs.has_index;
 	}
@@ -747,6 +765,7 @@ int main_build(int argc, char *argv[])
 		return 1;
 	}
 
+	if (getenv("RB3_PINNED_LIMIT")) g_pin_limit = atoll(getenv("RB3_PINNED_LIMIT"));
 	if (!getenv("RB3_NO_PINNED")) g_pin_on = 1, rb3h_seq_set_batch_allocator(pin_alloc, pin_release); /* batch buffers in page-locked memory (one DMA per batch) */
 
 	if (fn_in) { /* build.c:172-184 */
@@ -800,7 +819,7 @@ int main_build(int argc, char *argv[])
 			for (k = 0; k < N; ++k) pthread_create(&th[k], 0, run_slice, &sl[k]);
 			for (k = 0; k < N; ++k) {
 				pthread_join(th[k], 0);
-				if (sl[k].ret != 0 || !sl[k].has_index) ret = -1;
+				if (sl[k].ret != 0) ret = -1; /* (a slice whose files held nothing has no index: skipped below, as the reference skips such files, build.c:208-211) */
 				n_empty += sl[k].n_empty;
 				for (c = 0; c < sl[k].n_old_sorters; ++c) rb3gpu_sorter_destroy(sl[k].old_sorters[c]); /* (their scratch must not sit on the devices during the tree merge) */
 			}
@@ -808,20 +827,30 @@ int main_build(int argc, char *argv[])
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] %d slices indexed on %d GPUs\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), N, ndev < N ? ndev : N);
 		t_tree = rb3h_realtime();
-		for (stride = 1; stride < N && ret == 0; stride *= 2) /* merge(A, B) ranks the sentinels of B after those of A (fm-index.c:147): adjacent slices, left to right */
-			for (k = 0; k + stride < N && ret == 0; k += 2 * stride) { /* (the merges of one level are independent; they are short next to the slices and run in turn) */
-				const int r = rb3gpu_merge_index(sl[k].h, sl[k + stride].h);
-				if (r < 0) { fprintf(stderr, "ERROR: the GPU engine failed to merge the index of slice %d into slice %d: %s\n", k + stride, k, rb3gpu_strerror(r)); ret = -1; }
-				else {
-					rb3gpu_stats_t so;
-					if (rb3gpu_stats(sl[k + stride].h, &so) == 0) g_other_slices.ms_path += so.ms_h2d + so.ms_lf + so.ms_rank + so.ms_build, g_other_slices.n_sym += so.n_symbols_merged;
-					rb3gpu_destroy(sl[k + stride].h), sl[k + stride].h = 0;
-					if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] merged the index of slice %d into slice %d\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), k + stride, k);
+		{ /* the slices that hold an index, in input order (one whose files held nothing is skipped, as the single-GPU build and the reference skip such files) */
+			int *live = (int*)calloc((size_t)N, sizeof(int)), nl = 0;
+			for (k = 0; k < N; ++k) if (sl[k].has_index) live[nl++] = k;
+			for (stride = 1; stride < nl && ret == 0; stride *= 2) /* merge(A, B) ranks the sentinels of B after those of A (fm-index.c:147): adjacent slices, left to right */
+				for (k = 0; k + stride < nl && ret == 0; k += 2 * stride) { /* (the merges of one level are independent; they are short next to the slices and run in turn) */
+					const int a = live[k], b = live[k + stride];
+					const int r = rb3gpu_merge_index(sl[a].h, sl[b].h);
+					if (r < 0) { fprintf(stderr, "ERROR: the GPU engine failed to merge the index of slice %d into slice %d: %s\n", b, a, rb3gpu_strerror(r)); ret = -1; }
+					else {
+						rb3gpu_stats_t so;
+						if (rb3gpu_stats(sl[b].h, &so) == 0) g_other_slices.ms_path += so.ms_h2d + so.ms_lf + so.ms_rank + so.ms_build, g_other_slices.n_sym += so.n_symbols_merged;
+						rb3gpu_destroy(sl[b].h), sl[b].h = 0;
+						if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] merged the index of slice %d into slice %d\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), b, a);
+					}
 				}
+			if (ret == 0 && nl > 0 && live[0] != 0) { /* slice 0 held nothing: the result lives in another slice's handle */
+				rb3gpu_destroy(h);
+				h = sl[live[0]].h, sl[live[0]].h = 0, sl[0].h = h;
 			}
+			has_index = ret == 0 && nl > 0;
+			free(live);
+		}
 		if (ret == 0 && rb3h_verbose >= 3) fprintf(stderr, "[M::%s] tree merge of %d slices: %.3f s\n", __func__, N, rb3h_realtime() - t_tree);
 		for (k = 1; k < N; ++k) if (sl[k].h) rb3gpu_destroy(sl[k].h);
-		has_index = ret == 0;
 		free(sl); free(th);
 	}
 	if (n_empty > 0 && rb3h_verbose >= 2)

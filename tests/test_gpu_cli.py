@@ -360,3 +360,27 @@ def test_more_relatives_than_a_tentative_interval_tracks(tmp_path, tent_q):
     else:
         assert w is None
     os.unlink(fn)
+
+
+def test_batches_in_pageable_memory_when_page_locked_memory_runs_out():
+    """the page-locked batch buffers are an optimisation.  RB3_PINNED_LIMIT makes every request above 1 byte fail as
+    if the runtime had no page-locked memory left: the reader falls back to pageable buffers (the engine stages those) and the
+    build gives the reference's bytes, with the GPU sorter and with the host sorter, piped or not."""
+    ent = MAN["genomes12_files"]
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    for extra in (["-p1"], ["--host-sort", "-p2"], ["-p0"], ["--gpus", "3"]):
+        out, _ = run(["build", "-d"] + extra + inputs, env={"RB3_PINNED_LIMIT": "1"})
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], extra
+
+
+def test_multi_gpu_build_with_slices_that_hold_nothing(tmp_path):
+    """`--gpus N` with a slice whose files contain no sequence -- the single-GPU build and the reference (build.c:208-211)
+    skip such files; so does the tree merge, wherever the empty slice sits (also first: the result then lives in another handle)"""
+    ent = MAN["genomes12_files"]
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    empty = str(tmp_path / "empty.fa")
+    open(empty, "w").close()
+    n = len(inputs)
+    for files, gpus in (([empty] + inputs, n + 1), (inputs + [empty], n + 1), (inputs[:2] + [empty] + inputs[2:], n + 1), ([empty, empty] + inputs, 3)):
+        out, err = run(["build", "-d", "--gpus", str(gpus)] + files)
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (files, err[-300:])

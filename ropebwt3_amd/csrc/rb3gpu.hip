@@ -20,6 +20,7 @@
 #include <new>
 #include "rb3gpu.h"
 #include "rb3gpu_kernels.h"
+#include "rb3gpu_planes.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
 		if (h && h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
@@ -98,6 +99,8 @@ struct Tune {
 	int staged = 0;          // the three-stage merge (several host syncs) instead of the single-sync one
 	int group_rebuild = 0;   // group-sequential rebuild kernels instead of the window-parallel ones
 	int window_rebuild = 0;  // the per-window rebuild (k_pass1w) instead of the run-space rebuild per group
+	int reb_t1_rows = 96;    // the small tier of the run-space rebuild runs first where a group receives at most this many batch rows on average
+	int plane_rebuild = 1;   // symbols are rebuilt in plane space, a lane per 32 symbols (k_plane_group); 0: a wave per window (k_pass1w / k_decide / k_pass2w, rounds 1-3)
 	int resolve_v1 = 0;      // settle the tentative stretches with k_resolve (one hop per stretch) instead of k_cum / k_resolve_w / k_sfin
 	int reb_force = 0;       // the run-space rebuild whatever the row density and the old index look like (tests: the hand-over paths)
 	int octs = 8;            // octets per wave of k_chain
@@ -148,7 +151,7 @@ struct rb3gpu_s {
 	// (behind the grp_cap directory entries of a buffer sit grp_cap 8-byte words: the compact copy of the entries' slot words, IdxView.gsm)
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist;
+	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist, pslots;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -163,6 +166,7 @@ struct rb3gpu_s {
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
 	rb3sort_ws *sorter = nullptr;           // scratch of rb3gpu_bwt_from_text, created on first use
+	bool reb_pp_all = false; // the last rebuilds handed most groups on to the symbol path: skip the run-space tiers until most groups qualify (merge_core keeps it up to date)
 	int64_t reb_last[2] = {-1, -1}; // groups the first / the last tier of the run-space rebuild handed on in the merge before (-1: unknown)
 	const uint32_t *mg_sa = nullptr; // the suffix array of the batch being merged, if its caller has it (rb3gpu_merge_text_sa_dev): records in text order
 	int tent_q = 1;          // masks of 256 * tent_q bits (merge_core doubles it when walkers report intervals wider than that)
@@ -397,6 +401,8 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "staged")) t.staged = v != 0;
 	else if (!strcmp(key, "group_rebuild")) t.group_rebuild = v != 0;
 	else if (!strcmp(key, "window_rebuild")) t.window_rebuild = v != 0;
+	else if (!strcmp(key, "plane_rebuild")) t.plane_rebuild = v != 0;
+	else if (!strcmp(key, "reb_t1_rows")) t.reb_t1_rows = (int)v;
 	else if (!strcmp(key, "reb_force")) t.reb_force = v != 0;
 	else if (!strcmp(key, "resolve_v1")) t.resolve_v1 = v != 0;
 	else if (!strcmp(key, "octs")) t.octs = v < 1 ? 1 : v > 8 ? 8 : (int)v;
@@ -445,7 +451,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -529,7 +535,7 @@ static void guard_check(rb3gpu_t *h, const char *where)
 {
 	if (!h->tn.guard) return;
 	static const char *names[] = { "b2", "pos", "post", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots };
 	uint8_t g[RB3_GUARD];
 	for (int i = 0; i < 20 + 4; ++i) {
 		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
@@ -569,7 +575,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -617,7 +623,8 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
 #define MISC_LF_CHK   6    /* [6] rows whose LF relation was verified, [7] rows that failed it */
 #define MISC_B2_MODE  15   /* what the device-made walker list is (k_b2_mode) */
 #define MISC_WIDE     39   /* k_chain: steps of walkers that could not record tentatively because their interval is wider than the masks */
-#define MISC_RG_OVER  32   /* set by k_decide<LISTED>: the hand-over list of the run-space rebuild is longer than the window scratch */
+#define MISC_RG_OVER  32   /* set by k_decide<LISTED> / k_plane_group<LISTED>: the hand-over list of the run-space rebuild is longer than the scratch of the symbol path */
+#define MISC_PP_OK    33   /* k_plane_group: groups whose old range holds no bit-plane slot (the run-space rebuild could take them) */
 
 /* build a block array for ntot symbols into ib[1-cur]; FROM_PLAIN: symbols are d_b2[0..ntot);
  * otherwise the interleave of the current index with d_b2 at merged positions pos[].
@@ -628,7 +635,9 @@ static bool runspace_applies(const rb3gpu_t *h, int64_t n2, int64_t ntot)
 {
 	const int64_t nwin_old = (h->n >> RB3_WIN_BITS) + 1;
 	if (h->tn.window_rebuild || h->nslots == nwin_old) return false; // (a fully bit-plane index has no run slot to start from)
-	return h->tn.reb_force || (h->nslots * 2 < nwin_old && (double)n2 * RB3_GRP <= 4096.0 * (double)ntot); // (run-coded index; not where half of every group is new)
+	if (h->tn.reb_force) return true;
+	if (h->reb_pp_all && h->tn.plane_rebuild) return false; // (most groups still hold a bit-plane slot: every one of them would be handed on)
+	return h->nslots * 2 < nwin_old && (double)n2 * RB3_GRP <= 4096.0 * (double)ntot; // (run-coded index; not where half of every group is new)
 }
 
 /* the size limits of the single-synchronisation merge; the test build of the library can shrink them so that a test crosses them */
@@ -712,11 +721,18 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		if (h->tn.reb_lcap > 0 && h->tn.reb_lcap < lcap) lcap = h->tn.reb_lcap;
 #endif
 	}
+	// symbols in plane space (k_plane_group: a block per group, a lane per 32 symbols) instead of a wave per window; the first
+	// batch (FROM_PLAIN) keeps the window kernels
+	const bool planes = winpar && !FROM_PLAIN && h->tn.plane_rebuild && !h->tn.window_rebuild;
 	if (winpar) {
 		const int64_t nws = runspace ? lcap * RB3_GRP_WINS : nwin;
-		if ((r = buf_ensure(h, h->wstat, (size_t)nws * 16)) < 0) return r;
-		if ((r = buf_ensure(h, h->wplane, (size_t)nws * 96)) < 0) return r;
-		if ((r = buf_ensure(h, h->wruns, (size_t)nws * RB3_RLE_CODES * 2)) < 0) return r;
+		if (planes) {
+			if ((r = buf_ensure(h, h->pslots, (size_t)(runspace ? lcap : ngrp) * RB3_GRP_WINS * sizeof(rb3_slot_t))) < 0) return r;
+		} else {
+			if ((r = buf_ensure(h, h->wstat, (size_t)nws * 16)) < 0) return r;
+			if ((r = buf_ensure(h, h->wplane, (size_t)nws * 96)) < 0) return r;
+			if ((r = buf_ensure(h, h->wruns, (size_t)nws * RB3_RLE_CODES * 2)) < 0) return r;
+		}
 		if (!FROM_PLAIN && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
 		jg = (int64_t*)h->jg.p;
 	}
@@ -763,7 +779,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			}
 			const int64_t gw4 = (ngrp + RB3_RG_WAVES - 1) / RB3_RG_WAVES;
 			const unsigned grs = (unsigned)(gw4 < 3072 ? gw4 : 3072), grm = (unsigned)(gw4 < 2048 ? gw4 : 2048);
-			if (rows_per_group <= 96.0) {
+			if (rows_per_group <= (double)h->tn.reb_t1_rows) {
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reb_group<384, 128, false>), dim3(grs), dim3(64 * RB3_RG_WAVES), 0, h->st, old, d_pos, d_b2, ntot, (const int64_t*)jg, ngrp,
 						gstat, (uint4*)h->gslots.p, gkind, (const uint32_t*)nullptr, (const uint32_t*)nullptr, glist[0], nglist, skip);
 				// (what the small tables left: a few hundred groups in a grown pangenome, most of them in its first rounds; the grid for
@@ -781,6 +797,10 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			const int64_t gwn = lw * RB3_GRP_WINS / RB3_REB_WAVES + 1;
 			const unsigned gw = (unsigned)(gwn < 8192 ? gwn : 8192);
 			const unsigned gl = (unsigned)(lw < 4096 ? lw : 4096);
+			if (planes)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_plane_group<true>), dim3((unsigned)(lw < 8192 ? lw : 8192)), dim3(256), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, nwin, ngrp,
+						gstat, (uint4*)h->pslots.p, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, (unsigned long long*)h->misc.p + MISC_RG_OVER, (unsigned long long*)nullptr);
+			else {
 			if (n2 * RB3_WIN > 3 * ntot)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 7, true>), dim3(gw), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
 						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap);
@@ -789,6 +809,11 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 						(uint4*)h->wstat.p, (uint32_t*)h->wplane.p, (uint16_t*)h->wruns.p, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap);
 			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_decide<true>), dim3(gl), dim3(64), 0, h->st, (const uint4*)h->wstat.p, ntot, gstat, ngrp, skip,
 					(const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, (unsigned long long*)h->misc.p + MISC_RG_OVER);
+			}
+		} else if (planes) {
+			if (!prepared) HIPCHK(hipMemsetAsync((uint64_t*)h->misc.p + MISC_PP_OK, 0, 8, h->st));
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_plane_group<false>), dim3((unsigned)(ngrp < 16384 ? ngrp : 16384)), dim3(256), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, nwin, ngrp,
+					gstat, (uint4*)h->pslots.p, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, (unsigned long long*)nullptr, (unsigned long long*)h->misc.p + MISC_PP_OK);
 		} else {
 			const dim3 g1w((unsigned)((nwin + RB3_REB_WAVES * RB3_REB_WPW - 1) / (RB3_REB_WAVES * RB3_REB_WPW))), b1w(64 * RB3_REB_WAVES);
 			// the run-space short cut takes windows with up to 3 batch rows, or up to 7 where a window receives more than 3 on average
@@ -823,11 +848,18 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	}
 	if (winpar && runspace) {
 		const int64_t lw2 = h->reb_last[1] < 0 ? ngrp : h->reb_last[1] + h->reb_last[1] / 2 + 8; // (as above: the grid for the list the merge before left)
+		if (planes)
+			hipLaunchKernelGGL(HIP_KERNEL_NAME(k_place_pg<true>), dim3((unsigned)(lw2 < 16384 ? (lw2 + 3) / 4 : 4096)), dim3(256), 0, h->st, (const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, (const uint4*)h->pslots.p,
+					h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, ntot, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap, h->tn.abs_limit);
+		else
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<true>), dim3(lw2 < 4096 ? (unsigned)lw2 : 4096u), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
 				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap, (int64_t)-1, (int64_t)-1, h->tn.abs_limit);
 		hipLaunchKernelGGL(k_place, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, h->st, (const uint8_t*)gkind, (const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot,
 				(const uint4*)h->gslots.p, h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, nwin, ntot, skip, (const uint32_t*)(nglist + 1), (uint32_t)lcap, slot_cap, h->tn.abs_limit);
-	} else if (winpar)
+	} else if (planes)
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_place_pg<false>), dim3((unsigned)(ngrp < 65536 ? (ngrp + 3) / 4 : 16384)), dim3(256), 0, h->st, (const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, (const uint4*)h->pslots.p,
+				h->ib[dst].grp, (uint4*)h->ib[dst].slots, ngrp, ntot, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, slot_cap, h->tn.abs_limit);
+	else if (winpar)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2w<false>), dim3((unsigned)ngrp), dim3(64 * RB3_REB_WAVES), 0, h->st, (const uint4*)h->wstat.p, (const uint32_t*)h->wplane.p, (const uint16_t*)h->wruns.p, ntot,
 				(const uint32_t*)gstat, (const uint64_t*)gpre, (const uint64_t*)dtot, h->ib[dst].grp, (uint4*)h->ib[dst].slots, nwin, skip, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, slot_cap, (int64_t)-1, (int64_t)-1, h->tn.abs_limit);
 	else
@@ -1677,6 +1709,13 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			h->stt.n_reb_groups += ngrp, h->stt.n_reb_groups_window += (int64_t)(hm[MISC_RG_LISTS] >> 32);
 			h->reb_last[0] = (int64_t)(hm[MISC_RG_LISTS] & 0xFFFFFFFFull), h->reb_last[1] = (int64_t)(hm[MISC_RG_LISTS] >> 32); // (the next rebuild sizes its grids by them)
 		} else h->reb_last[0] = h->reb_last[1] = -1;
+		// Which rebuild the next merge starts with: the run-space tiers hand on every group whose old range holds a bit-plane slot
+		// (rounds ~7-30 of a pangenome build: most of them, and each costs the attempt on top of the symbol path), so where that was
+		// most groups the next merges go straight to the plane kernel, which reports how many groups would have qualified.
+		if (h->tn.plane_rebuild && !h->tn.window_rebuild && use_winpar(h, nwin)) {
+			if (ran_runspace) { if ((int64_t)(hm[MISC_RG_LISTS] >> 32) * 10 > ngrp * 7) h->reb_pp_all = true; }
+			else if (h->reb_pp_all && (int64_t)hm[MISC_PP_OK] * 10 >= ngrp * 3) h->reb_pp_all = false;
+		}
 		for (int a = 0; a <= 6; ++a)
 			if (acc[a] != h->acc[a] + acc2[a]) {
 				if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] the rebuilt index counts %lld symbols below %d, expected %lld\n", (long long)acc[a], a, (long long)(h->acc[a] + acc2[a]));

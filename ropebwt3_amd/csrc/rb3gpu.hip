@@ -1324,7 +1324,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	// stretches the merge before opened, the rows-per-window table of the rebuild, and -- text-order walk -- the row records
 	fill_add(&jb, misc, 128, 0u);
 	fill_add(&jb, misc + MISC_RG_OVER, tent ? (size_t)(MISC_WORDS - MISC_RG_OVER) * 8 : 64, 0u); // (... MISC_WIDE, and the id counters behind them)
-	if (rows_fused) fill_add(&jb, h->jg.p, (size_t)(nwin + 1) * 8, 0u); // defined even if pos[] turns out invalid
+	// (the rows-per-window table is not cleared: k_pos_finalize_check_rows writes every entry when pos[] validates, and when it does not the
+	// validation counters make every rebuild kernel return before it reads the table -- 42 MB of fill per round of a 1.3 G-symbol build)
 	const bool rows_filled = d_tw != nullptr && jb.n < 8;
 	if (rows_filled) fill_add(&jb, trec ? h->post.p : h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
 	else if (trec) HIPCHK(hipMemsetAsync(h->post.p, 0xff, (size_t)len * 8, h->st));

@@ -468,13 +468,14 @@ static int sort_batch(const bopt_t *opt, int device, rb3h_buf_t *seq, int64_t n_
 typedef int (*submit_f)(void *data, rb3h_buf_t *seq, int64_t n_seq, int end_of_file);
 
 /* read every input file, cutting batches as io.c:104-125 does */
-static int for_each_batch(const bopt_t *opt, int n_files, char **files, submit_f submit, void *data, int64_t *n_empty)
+/* rbeg / rend (NULL: whole files): the byte range of file i whose records this reader takes (`build --gpus N`: slices cut inside files) */
+static int for_each_batch(const bopt_t *opt, int n_files, char **files, const int64_t *rbeg, const int64_t *rend, submit_f submit, void *data, int64_t *n_empty)
 {
 	rb3h_buf_t seq = {0, 0, 0};
 	int64_t n_seq_acc = 0;
 	int i, ret = 0;
 	for (i = 0; i < n_files && ret == 0; ++i) {
-		rb3h_seqio_t *fp = rb3h_seq_open(files[i], !!(opt->flag & BF_LINE));
+		rb3h_seqio_t *fp = rbeg ? rb3h_seq_open_range(files[i], !!(opt->flag & BF_LINE), rbeg[i], rend[i]) : rb3h_seq_open(files[i], !!(opt->flag & BF_LINE));
 		int64_t n_seq;
 		if (fp == 0) {
 			if (rb3h_verbose >= 1) fprintf(stderr, "ERROR: failed to open file '%s'\n", files[i]);
@@ -561,12 +562,12 @@ static int submit_pool(void *data, rb3h_buf_t *seq, int64_t n_seq, int end_of_fi
 	return 0;
 }
 
-typedef struct { pool_t *q; int n_files; char **files; int64_t n_empty; int err; } reader_t;
+typedef struct { pool_t *q; int n_files; char **files; const int64_t *rbeg, *rend; int64_t n_empty; int err; } reader_t;
 
 static void *reader_main(void *arg)
 {
 	reader_t *r = (reader_t*)arg;
-	r->err = for_each_batch(r->q->opt, r->n_files, r->files, submit_pool, r->q, &r->n_empty);
+	r->err = for_each_batch(r->q->opt, r->n_files, r->files, r->rbeg, r->rend, submit_pool, r->q, &r->n_empty);
 	pthread_mutex_lock(&r->q->mtx);
 	r->q->reader_done = 1;
 	pthread_cond_broadcast(&r->q->cv);
@@ -609,6 +610,7 @@ typedef struct {
 	const bopt_t *opt;
 	int device, n_files, has_index, ret;
 	char **files;
+	const int64_t *rbeg, *rend; /* NULL: whole files; else the byte range of every file whose records belong to this slice */
 	const char *fn_tmp;
 	int64_t n_empty;
 	rb3gpu_sorter_t *old_sorters[4];
@@ -640,7 +642,7 @@ static void *run_slice(void *arg)
 		pthread_cond_init(&q.cv, 0);
 		q.cap = n_sort + 2, q.ring = (job_t*)calloc((size_t)q.cap, sizeof(job_t)), q.opt = opt, q.device = sl->device;
 		memset(&rd, 0, sizeof(rd));
-		rd.q = &q, rd.n_files = argc - optind, rd.files = argv + optind;
+		rd.q = &q, rd.n_files = argc - optind, rd.files = argv + optind, rd.rbeg = sl->rbeg, rd.rend = sl->rend;
 		st = (pthread_t*)calloc((size_t)n_sort, sizeof(pthread_t));
 		sa = (sorter_arg_t*)calloc((size_t)n_sort, sizeof(sorter_arg_t));
 		pthread_create(&rt, 0, reader_main, &rd);
@@ -685,7 +687,7 @@ static void *run_slice(void *arg)
 		n_empty = rd.n_empty, has_index = cs.has_index;
 	} else if (argc - optind >= 1) {
 		consumer_t cs = { h, opt, has_index, fn_tmp, sl->device };
-		ret = for_each_batch(opt, argc - optind, argv + optind, submit_serial, &cs, &n_empty);
+		ret = for_each_batch(opt, argc - optind, argv + optind, sl->rbeg, sl->rend, submit_serial, &cs, &n_empty);
 		has_index = cs.has_index;
 	}
 	sl->ret = ret, sl->has_index = has_index, sl->n_empty = n_empty, sl->n_old_sorters = n_old_sorters;
@@ -790,12 +792,26 @@ int main_build(int argc, char *argv[])
 
 	if (opt.sais_threads < 0) opt.sais_threads = opt.gpu_sort ? 1 : 0; /* one batch sorted on the GPU while the one before is merged */
 	if (opt.n_gpus < 1) opt.n_gpus = 1;
-	if (opt.n_gpus > argc - optind) opt.n_gpus = argc - optind > 0 ? argc - optind : 1; /* slices are cut at file boundaries */
+	/* Slices: contiguous pieces of the input in input order, equal in bytes, cut INSIDE files at record boundaries where every file
+	 * can be read from an offset (regular files that are not gzip-compressed: a reads file of config 4 shards over all GPUs, each
+	 * with its own reader and sorter, as kt_for spreads the chains of a batch, fm-index.c:217-224); with a pipe or a .gz among the
+	 * inputs the slices are whole files. */
+	int64_t *fsize = 0, total_bytes = 0;
+	int by_bytes = opt.n_gpus > 1 && argc - optind >= 1;
+	if (by_bytes) {
+		fsize = (int64_t*)calloc((size_t)(argc - optind), sizeof(int64_t));
+		for (c = 0; c < argc - optind && by_bytes; ++c) {
+			if (!rb3h_seq_splittable(argv[optind + c], &fsize[c])) by_bytes = 0;
+			else total_bytes += fsize[c];
+		}
+		if (total_bytes < (int64_t)opt.n_gpus * 64) by_bytes = 0; /* (nothing to cut) */
+	}
+	if (!by_bytes && opt.n_gpus > argc - optind) opt.n_gpus = argc - optind > 0 ? argc - optind : 1; /* slices are cut at file boundaries */
 	if (opt.n_gpus > 1 && fn_tmp) { fprintf(stderr, "ERROR: -S (save after each file) is not available with --gpus\n"); rb3gpu_destroy(h); return 1; }
 	if (opt.n_gpus == 1) {
 		slice_t sl;
 		memset(&sl, 0, sizeof(sl));
-		sl.h = h, sl.opt = &opt, sl.device = opt.device, sl.n_files = argc - optind, sl.files = argv + optind, sl.has_index = has_index, sl.fn_tmp = fn_tmp;
+		sl.h = h, sl.opt = &opt, sl.device = opt.device, sl.rbeg = sl.rend = 0, sl.n_files = argc - optind, sl.files = argv + optind, sl.has_index = has_index, sl.fn_tmp = fn_tmp;
 		run_slice(&sl);
 		ret = sl.ret, has_index = sl.has_index, n_empty = sl.n_empty;
 		for (c = 0; c < sl.n_old_sorters && n_old_sorters < 4; ++c) old_sorters[n_old_sorters++] = sl.old_sorters[c];
@@ -805,8 +821,23 @@ int main_build(int argc, char *argv[])
 		pthread_t *th = (pthread_t*)calloc((size_t)N, sizeof(pthread_t));
 		int k, stride;
 		double t_tree;
+		int64_t *rb = by_bytes ? (int64_t*)calloc((size_t)N * nf * 2, sizeof(int64_t)) : 0; /* per slice: begin and end offset in every file */
 		for (k = 0; k < N && ret == 0; ++k) {
-			const int f0 = (int)((int64_t)nf * k / N), f1 = (int)((int64_t)nf * (k + 1) / N);
+			int f0 = (int)((int64_t)nf * k / N), f1 = (int)((int64_t)nf * (k + 1) / N);
+			if (by_bytes) { /* global byte range [lo, hi) of the concatenated inputs -> the files it touches and the range inside each */
+				const int64_t lo = total_bytes / N * k, hi = k + 1 == N ? total_bytes : total_bytes / N * (k + 1);
+				int64_t at = 0, *b = rb + (size_t)k * nf * 2, *e = b + nf;
+				f0 = nf, f1 = 0;
+				for (c = 0; c < nf; at += fsize[c], ++c) {
+					const int64_t x0 = lo > at ? lo - at : 0, x1 = hi - at < fsize[c] ? hi - at : fsize[c];
+					if (x1 <= x0 && !(fsize[c] == 0 && at >= lo && at < hi)) continue; /* (file c has nothing for this slice) */
+					b[c] = x0, e[c] = x1 >= fsize[c] ? 0 : x1; /* (0: to the end of the file) */
+					if (c < f0) f0 = c;
+					f1 = c + 1;
+				}
+				if (f0 >= f1) f0 = f1 = 0;
+				sl[k].rbeg = b + f0, sl[k].rend = e + f0;
+			}
 			sl[k].opt = &opt, sl[k].device = (opt.device + k) % (ndev > 0 ? ndev : 1), sl[k].n_files = f1 - f0, sl[k].files = argv + optind + f0;
 			if (k == 0) sl[k].h = h, sl[k].has_index = has_index; /* (an index given with -i is the start of slice 0) */
 			else {
@@ -851,8 +882,9 @@ int main_build(int argc, char *argv[])
 		}
 		if (ret == 0 && rb3h_verbose >= 3) fprintf(stderr, "[M::%s] tree merge of %d slices: %.3f s\n", __func__, N, rb3h_realtime() - t_tree);
 		for (k = 1; k < N; ++k) if (sl[k].h) rb3gpu_destroy(sl[k].h);
-		free(sl); free(th);
+		free(sl); free(th); free(rb);
 	}
+	free(fsize);
 	if (n_empty > 0 && rb3h_verbose >= 2)
 		fprintf(stderr, "WARNING: skipped %ld empty sequence(s)\n", (long)n_empty);
 

@@ -10,6 +10,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <errno.h>
+#include <sys/stat.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -26,6 +27,9 @@ struct rb3h_seqio_s {
 	int beg, end;
 	uint8_t *buf;
 	rb3h_buf_t rec, qual;
+	int64_t buf_off;   /* file offset of buf[0] (plain files only: a byte range of a file, rb3h_seq_open_range) */
+	int64_t next_off;  /* file offset of the next fill */
+	int64_t range_end; /* > 0: records that start at or behind this file offset belong to somebody else */
 };
 
 /* A/C/G/T -> 1..4 (either case), 0..4 stay, everything else -> 5 (io.c:12-28) */
@@ -187,6 +191,78 @@ rb3h_seqio_t *rb3h_seq_open(const char *fn, int is_line)
 	return fp;
 }
 
+/* can a file be cut into byte ranges that are read independently?  A regular file that is not gzip-compressed; *size = its length */
+int rb3h_seq_splittable(const char *fn, int64_t *size)
+{
+	struct stat st;
+	uint8_t magic[2];
+	int fd, ok = 0;
+	if (fn == 0 || !strcmp(fn, "-") || (fd = open(fn, O_RDONLY)) < 0) return 0;
+	if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+		const ssize_t k = pread(fd, magic, 2, 0);
+		ok = !(k == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+		if (size) *size = (int64_t)st.st_size;
+	}
+	close(fd);
+	return ok;
+}
+
+/* first record start at or behind file offset `from` (the file's length if there is none).  A record starts where a line starts
+ * -- with -L every line; FASTA: a line that begins with '>'; FASTQ: a line that begins with '@' whose second successor begins
+ * with '+' (a quality line may begin with '@' too, but then the line after it is a header and the one after that a sequence). */
+static int64_t sio_record_start(int fd, int64_t from, int64_t size, int is_line)
+{
+	uint8_t first = 0, *buf;
+	int64_t ls[3] = {-1, -1, -1}, off, found = -1; /* the last three line starts and their first bytes */
+	uint8_t lc[3] = {0, 0, 0};
+	int at_start; /* the next byte begins a line */
+	if (from <= 0) return 0;
+	if (from >= size) return size;
+	if (!is_line && pread(fd, &first, 1, 0) != 1) return size;
+	buf = (uint8_t*)malloc(1 << 20);
+	if (buf == 0) return -1;
+	off = from - 1, at_start = 0; /* (the byte before `from` says whether `from` itself begins a line) */
+	while (found < 0 && off < size) {
+		const ssize_t k = pread(fd, buf, 1 << 20, off);
+		ssize_t i;
+		if (k <= 0) break;
+		for (i = 0; i < k && found < 0; ++i) {
+			if (at_start) {
+				const int64_t o = off + i;
+				at_start = 0;
+				if (is_line) found = o;
+				else if (first == '>') { if (buf[i] == '>') found = o; }
+				else {
+					ls[0] = ls[1], lc[0] = lc[1], ls[1] = ls[2], lc[1] = lc[2], ls[2] = o, lc[2] = buf[i];
+					if (ls[0] >= 0 && lc[0] == '@' && lc[2] == '+') found = ls[0];
+				}
+			}
+			if (buf[i] == '\n') at_start = 1;
+		}
+		off += k;
+	}
+	free(buf);
+	return found >= 0 ? found : size;
+}
+
+/* the records of a plain file that START in the byte range [beg, end) (end <= 0: to the end of the file): ranges that tile a file
+ * give every record to exactly one reader, in file order */
+rb3h_seqio_t *rb3h_seq_open_range(const char *fn, int is_line, int64_t beg, int64_t end)
+{
+	int64_t size = 0, at;
+	rb3h_seqio_t *fp;
+	if (beg <= 0 && end <= 0) return rb3h_seq_open(fn, is_line);
+	if (!rb3h_seq_splittable(fn, &size)) return 0;
+	fp = rb3h_seq_open(fn, is_line);
+	if (fp == 0 || fp->fp != 0) { rb3h_seq_close(fp); return 0; }
+	at = sio_record_start(fp->fd, beg, size, is_line);
+	if (at < 0 || lseek(fp->fd, (off_t)at, SEEK_SET) == (off_t)-1) { rb3h_seq_close(fp); return 0; }
+	fp->next_off = at, fp->buf_off = at;
+	fp->range_end = end > 0 && end < size ? end : 0;
+	if (fp->range_end > 0 && at >= fp->range_end) fp->is_eof = 1; /* (no record starts in this range) */
+	return fp;
+}
+
 void rb3h_seq_close(rb3h_seqio_t *fp)
 {
 	if (fp == 0) return;
@@ -206,7 +282,11 @@ static int sio_fill(rb3h_seqio_t *fp)
 			(void)gzerror(fp->fp, &zerr);
 			if (fp->end < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) fp->io_err = EIO;
 		}
-	} else fp->end = sio_read_full(fp->fd, fp->buf, SIO_BUF, &fp->io_err);
+	} else {
+		fp->end = sio_read_full(fp->fd, fp->buf, SIO_BUF, &fp->io_err);
+		fp->buf_off = fp->next_off;
+		if (fp->end > 0) fp->next_off += fp->end;
+	}
 	if (fp->end < SIO_BUF) fp->is_eof = 1;
 	if (fp->end <= 0) { fp->end = 0; return 0; }
 	return 1;
@@ -254,6 +334,8 @@ static int64_t sio_read_fastx(rb3h_seqio_t *fp)
 		if (c == -1) return -1;
 		fp->last_char = c;
 	}
+	/* a byte range of a file: the record whose header starts at or behind the end of the range is the next reader's first */
+	if (fp->range_end > 0 && fp->buf_off + fp->beg - 1 >= fp->range_end) return -1;
 	fp->rec.l = fp->qual.l = 0;
 	/* header line (name + comment) is not needed for the BWT */
 	if (fp->beg >= fp->end && fp->is_eof) return -1;
@@ -297,6 +379,10 @@ int64_t rb3h_seq_read(rb3h_seqio_t *fp, rb3h_buf_t *seq, int64_t max_len, int is
 	if (!is_for && !is_rev) return -3;
 	if (fp->err) return 0; /* like the end of the file (the reference's loop ends there too, build.c:212) */
 	for (;;) {
+		if (fp->is_line && fp->range_end > 0) { /* a byte range of a file: the line that starts at or behind its end is the next reader's first */
+			if (fp->beg >= fp->end && !fp->is_eof) sio_fill(fp);
+			if (fp->beg < fp->end && fp->buf_off + fp->beg >= fp->range_end) { ret = -1; break; }
+		}
 		/* one-sequence-per-line input whose next line lies whole in the I/O buffer (all but one line per megabyte): converted
 		 * straight from there into the batch, both strands, without the detour through the record buffer */
 		if (fp->is_line && fp->beg < fp->end) {

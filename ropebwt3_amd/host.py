@@ -111,11 +111,17 @@ def walkers_text(text, step):
     return w
 
 
-def read_batches(path, is_line, max_len, fwd=True, rev=True):
+def read_batches(path, is_line, max_len, fwd=True, rev=True, byte_range=None):
     """Iterate the batches `build` would cut from one file (rb3_seq_read, io.c:104-125):
-    yields (n_strings, text) with text a uint8 array."""
+    yields (n_strings, text) with text a uint8 array.  byte_range = (beg, end): only the records that start in that byte
+    range of a plain file (rb3h_seq_open_range, what a slice of `build --gpus N` reads; end 0 = to the end of the file)."""
     L = load_library()
-    fp = L.rb3h_seq_open(path.encode(), int(is_line))
+    if byte_range is None:
+        fp = L.rb3h_seq_open(path.encode(), int(is_line))
+    else:
+        L.rb3h_seq_open_range.restype = ctypes.c_void_p
+        L.rb3h_seq_open_range.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64]
+        fp = L.rb3h_seq_open_range(path.encode(), int(is_line), int(byte_range[0]), int(byte_range[1]))
     if not fp:
         raise IOError("cannot open %s" % path)
     libc = ctypes.CDLL(None)

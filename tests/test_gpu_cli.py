@@ -384,3 +384,42 @@ def test_multi_gpu_build_with_slices_that_hold_nothing(tmp_path):
     for files, gpus in (([empty] + inputs, n + 1), (inputs + [empty], n + 1), (inputs[:2] + [empty] + inputs[2:], n + 1), ([empty, empty] + inputs, 3)):
         out, err = run(["build", "-d", "--gpus", str(gpus)] + files)
         assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (files, err[-300:])
+
+
+def test_multi_gpu_build_cuts_one_file_at_record_boundaries(tmp_path):
+    """`build --gpus N` on ONE file -- the slices are byte ranges cut at record boundaries (every record
+    belongs to the slice its first byte lies in), each with its own reader, sorter and handle (here all on device 0), merged in
+    input order: the reference's .fmd, for one-sequence-per-line reads, FASTA and FASTQ, also with more slices than a file has
+    records to give and with several files whose boundaries fall inside slices"""
+    import gzip
+    ent = MAN["reads_fwd"]
+    data = gzip.open(os.path.join(util.GOLDEN, ent["inputs"][0]), "rb").read()
+    one = str(tmp_path / "reads.txt")
+    open(one, "wb").write(data)
+    for n in (2, 3, 7):
+        out, err = run(["build"] + ent["flags"] + ["-m200k", "-d", "--gpus", str(n), one])
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], n
+        assert "tree merge" in err
+    # the same reads as FASTQ (quality lines that begin with '@' must not be taken for headers) and as FASTA
+    lines = data.split(b"\n")
+    lines = [l for l in lines if l]
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "wb") as f:
+        for i, l in enumerate(lines):
+            f.write(b"@r%d\n" % i + l + b"\n+\n" + (b"@" if i % 3 == 0 else b"I") * len(l) + b"\n")
+    fa = str(tmp_path / "reads.fa")
+    with open(fa, "wb") as f:
+        for i, l in enumerate(lines):
+            f.write(b">r%d\n" % i + l + b"\n")
+    flags = [x for x in ent["flags"] if x != "-L"]
+    for fn in (fq, fa):
+        out, _ = run(["build"] + flags + ["-m200k", "-d", "--gpus", "4", fn])
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], fn
+    # genomes: 12 files of one long record each, 5 slices -> slice boundaries inside records (a slice may hold nothing)
+    ent = MAN["genomes12_files"]
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    out, _ = run(["build", "-d", "--gpus", "5"] + inputs)
+    assert hashlib.md5(out).hexdigest() == ent["fmd_md5"]
+    out, _ = run(["build", "-d", "--gpus", "16"] + inputs[:3])  # (more slices than records)
+    out1, _ = run(["build", "-d"] + inputs[:3])
+    assert out == out1

@@ -70,17 +70,25 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
  * row (a sentinel's walker: the position of the sentinel), for rb3gpu_merge_text_dev. */
 int rb3h_walkers_from_ckrow(int64_t len, const uint8_t *text, int64_t step, const int64_t *ckrow, int64_t *n_walkers, rb3h_walker_t **walkers)
 {
-	int64_t b, j, nw = 0, n_seq = 0;
-	const uint8_t *q;
+	int64_t b, j, nw = 0, cap;
 	rb3h_walker_t *w;
 	*n_walkers = 0, *walkers = 0;
 	if (step < 2 || len <= 0 || text[len - 1] != 0) return -3;
-	for (q = text; (q = (const uint8_t*)memchr(q, 0, (size_t)(text + len - q))) != 0; ++q) ++n_seq; /* sentinels, at memchr speed */
-	w = (rb3h_walker_t*)malloc((size_t)(n_seq + len / step + 2) * sizeof(rb3h_walker_t));
+	/* (one pass over the text, at memchr speed: the list grows with the strings found -- counting the sentinels first was a second pass
+	 * over 8.8 MB per genome, a third of the 0.6 ms a list took) */
+	cap = len / step + 1024;
+	w = (rb3h_walker_t*)malloc((size_t)cap * sizeof(rb3h_walker_t));
 	if (!w) return -1;
 	for (j = 0, b = 0; b < len; ++j) {
 		const int64_t e = (const uint8_t*)memchr(text + b, 0, (size_t)(len - b)) - text; /* string j occupies [b, e), sentinel at e */
 		int64_t prev = -1, p;
+		if (nw + (e - b) / step + 2 > cap) {
+			rb3h_walker_t *w2;
+			cap = cap * 2 + (e - b) / step + 2;
+			w2 = (rb3h_walker_t*)realloc(w, (size_t)cap * sizeof(rb3h_walker_t));
+			if (!w2) { free(w); return -1; }
+			w = w2;
+		}
 		for (p = (b / step + 1) * step; p < e; p += step) { /* multiples of step strictly inside the string */
 			/* By text position (no ckrow) a walker starts RB3H_PREROLL positions to the right of its segment: it cannot record before
 			 * it is that many steps old anyway (k_chain, RB3_TENT_MIN_AGE), so it spends its youth on rows its right neighbour owns

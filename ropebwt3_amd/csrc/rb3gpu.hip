@@ -717,6 +717,10 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	if (runspace && nosync && !full) {
 		lcap = ngrp < 32768 ? ngrp : 32768;
 		if (lcap < ngrp / 8) lcap = ngrp / 8;
+		// (and room for one and a half times what the merge before handed on: a build whose batches put hundreds of rows into every
+		// group -- haplotypes of 360 M symbols into an index of a few G -- hands on a fifth of its groups round after round)
+		if (h->reb_last[1] > 0 && lcap < h->reb_last[1] + h->reb_last[1] / 2 + 1024) lcap = h->reb_last[1] + h->reb_last[1] / 2 + 1024;
+		if (lcap > ngrp) lcap = ngrp;
 #ifdef RB3GPU_TEST_HOOKS
 		if (h->tn.reb_lcap > 0 && h->tn.reb_lcap < lcap) lcap = h->tn.reb_lcap;
 #endif

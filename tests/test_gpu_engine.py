@@ -1310,3 +1310,29 @@ def test_slot_headers_relative_to_the_group(oracle, limit):
                 h2.close()
     finally:
         h.close()
+
+
+def test_index_beyond_2_32_symbols():
+    """the regime BASELINE configs[3]/[4] live in.  12 haplotypes of a 180 Mbp genome (contigs of 20-100 Mbp, both
+    strands: 360 M symbols per merge round) grow an index to 4.32 G symbols -- past 2^32, where the slot headers count from the
+    group start and the walkers' common step runs on 64-bit positions -- with the LF relation of EVERY row verified against the
+    index after every rank phase (lf_check = 1; fm-index.c:164, 171-173), no merge redone, and the .fmd byte-identical (md5) to the
+    one the unmodified reference wrote for the same 12 files (tests/golden/MANIFEST.json "big_index", tools/make_golden_big.py);
+    then a batch of reads into it under the same check."""
+    import json
+    from tools import big_index
+    man = json.load(open(os.path.join(util.GOLDEN, "MANIFEST.json"))).get("big_index", {}).get("12x180000000")
+    h, srt, rounds, base = big_index.build(12, 180000000, lf_check=1)
+    try:
+        assert rounds[-1]["index_symbols"] > (1 << 32) and rounds[-1]["index_symbols"] == sum(r["symbols"] for r in rounds)
+        assert sum(r["fallbacks"] for r in rounds) == 0
+        st = h.stats()
+        assert st["n_lf_checked"] >= sum(r["symbols"] for r in rounds[1:]) * 0.99   # (the count is kept approximately, 64 rows at a time)
+        assert man is not None, "no golden for this size: run tools/make_golden_big.py"
+        assert rounds[-1]["index_symbols"] == man["symbols"]
+        assert big_index.fmd_md5(h) == man["fmd_md5"]
+        rd = big_index.reads_into(h, base, 200000, reps=1)
+        assert rd["fallbacks"] == 0 and rd["lf_steps"] == rd["symbols"]
+    finally:
+        srt.close()
+        h.close()

@@ -68,3 +68,42 @@ if __name__ == "__main__":
         print(haplotypes(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]))
     else:
         print(relatives(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]))
+
+
+# ---- the index of 2^32 symbols and more: N haplotypes of 180 Mbp, contigs of 20-100 Mbp --------------------------
+def _mutate_fast(g, rng, rate):
+    """substitutions at positions drawn WITH replacement (a permutation of 1.8e8 positions takes longer than everything else)"""
+    g = g.copy()
+    idx = rng.integers(0, g.size, size=int(g.size * rate))
+    g[idx] = ALPH[(np.searchsorted(ALPH, g[idx]) + rng.integers(1, 4, size=idx.size)) % 4]
+    return g
+
+
+def big_base(L, seed=77):
+    return ALPH[np.random.default_rng(seed).integers(0, 4, size=L, dtype=np.uint8)]
+
+
+def big_contigs(base, k, lo=20000000, hi=100000000):
+    """haplotype k of the base genome (0.1 % substitutions, seed 7000 + k) as a list of contigs (ASCII arrays) of lo..hi bp"""
+    rng = np.random.default_rng(7000 + k)
+    h = _mutate_fast(base, rng, 0.001)
+    cuts = [0]
+    while cuts[-1] < base.size:
+        cuts.append(min(base.size, cuts[-1] + int(rng.integers(lo, hi))))
+    return [h[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def big_haplotype_files(N, L, out, lo=20000000, hi=100000000):
+    os.makedirs(out, exist_ok=True)
+    base = big_base(L)
+    files = []
+    for k in range(N):
+        fn = os.path.join(out, "big%02d.fa" % k)
+        if not os.path.exists(fn):
+            with open(fn + ".tmp", "wb") as f:
+                for i, c in enumerate(big_contigs(base, k, lo, hi)):
+                    f.write(b">big%d_ctg%d\n" % (k, i))
+                    f.write(c.tobytes() + b"\n")
+            os.rename(fn + ".tmp", fn)
+        files.append(fn)
+    return files

@@ -1178,11 +1178,13 @@ def test_walker_step_is_the_resident_capacity_of_the_walker_kernel():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,kind,env", [(301, "family", {}), (302, "reads", {}), (303, "dups", {}), (304, "family", {"text_mode": 2}),
-                                           (305, "reads", {"text_mode": 1}), (306, "family", {"tent": 0}), (307, "family", {"tent_q": 4})])
+                                           (305, "reads", {"text_mode": 1}), (306, "family", {"tent": 0}), (307, "family", {"tent_q": 4}),
+                                           (308, "family", {"part": 2}), (309, "reads", {"part": 2}), (310, "dups", {"part": 2}), (311, "family", {"part": 2, "tent": 0}), (312, "family", {"part": 2, "tent_q": 2})])
 def test_records_in_text_order_gathered_through_the_suffix_array(oracle, seed, kind, env):
     """rb3gpu_merge_text_sa_dev with `trec` forced on: the walkers leave their records in text order (one 64-byte store per octet and
     eight steps) and the validation pass gathers them into row order through the sorter's suffix array -- the same pos[], hence the
-    same index, as with a record per row; suffix array checked against the inverse suffix array the text-order words carry"""
+    same index, as with a record per row; suffix array checked against the inverse suffix array the text-order words carry.
+    part = 2: the permutation as a two-pass partition by row bucket (k_part_scatter / k_part_place, rb3gpu_part.h) instead of the gather."""
     from ropebwt3_amd import Rb3Gpu, host
     rng = np.random.default_rng(seed)
     g0 = util.random_genome(rng, 60000)

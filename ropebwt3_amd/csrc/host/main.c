@@ -1104,39 +1104,6 @@ int main_ssa(int argc, char *argv[])
 	return ret == 0 ? 0 : 1;
 }
 
-/* plain2fmd, main.c:299-331: every byte of the input is one BWT symbol ('\n' and '$' are 0) */
-int main_plain2fmd(int argc, char *argv[])
-{
-	int c, j;
-	rb3h_fmdw_t *w;
-	static uint8_t buf[0x10000];
-	optind = 1;
-	while ((c = getopt(argc, argv, "o:")) >= 0)
-		if (c == 'o' && freopen(optarg, "wb", stdout) == 0) return 1;
-	if (argc - optind < 1) {
-		fprintf(stdout, "Usage: ropebwt3-amd plain2fmd [-o output.fmd] <in.txt>\n");
-		return 0;
-	}
-	w = rb3h_fmdw_init();
-	for (j = optind; j < argc; ++j) {
-		FILE *fp = strcmp(argv[j], "-") == 0 ? stdin : fopen(argv[j], "r");
-		size_t i, len;
-		if (fp == 0) continue;
-		while ((len = fread(buf, 1, sizeof(buf), fp)) > 0)
-			for (i = 0; i < len; ++i) {
-				uint8_t x = buf[i];
-				if (x == '\n' || x == '$') x = 0;
-				else rb3h_char2nt6(1, &x);
-				rb3h_fmdw_enc(w, 1, x);
-			}
-		if (fp != stdin) fclose(fp);
-	}
-	rb3h_fmdw_finish(w);
-	rb3h_fmdw_dump(w, stdout);
-	rb3h_fmdw_destroy(w);
-	return 0;
-}
-
 /* recode: decode an FMD/FMR file on the host and write it back as plain text (default), FMD (-d)
  * or FMR (-b).  Host-only utility; also the CPU-side test bench of the two codecs. */
 typedef struct { int64_t cnt[6]; runvec_t rv; } recode_t;
@@ -1193,7 +1160,6 @@ static int usage(FILE *fp)
 	fprintf(fp, "    build      construct a BWT (merge path on an MI355X)\n");
 	fprintf(fp, "    merge      merge BWTs (on an MI355X)\n");
 	fprintf(fp, "    ssa        generate sampled suffix array (on an MI355X)\n");
-	fprintf(fp, "    plain2fmd  convert BWT in plain text to FMD (host only)\n");
 	fprintf(fp, "    recode     convert an FMD/FMR file to plain text, FMD (-d) or FMR (-b) (host only)\n");
 	fprintf(fp, "    version    print the version number\n");
 	return fp == stdout ? 0 : 1;
@@ -1207,7 +1173,6 @@ int main(int argc, char *argv[])
 	else if (strcmp(argv[1], "build") == 0) ret = main_build(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "merge") == 0) ret = main_merge(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "ssa") == 0) ret = main_ssa(argc - 1, argv + 1);
-	else if (strcmp(argv[1], "plain2fmd") == 0) ret = main_plain2fmd(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "recode") == 0) ret = main_recode(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "version") == 0) { printf("%s\n", RB3H_VERSION); return 0; }
 	else { fprintf(stderr, "ERROR: unknown command '%s'\n", argv[1]); return 1; }

@@ -162,6 +162,39 @@ def parse_num(s):
     return int(load_library().rb3h_parse_num(s.encode()))
 
 
+def fmd_bytes_from_plain(plain):
+    """the .fmd of a BWT given as plain text (one byte per symbol: $ACGTN or nt6 codes; newline = sentinel), through the host FMD
+    writer alone (rb3h_fmdw_enc / _finish: rld_enc / rld_enc_finish, rld0.c:137-216) -- the CPU-side test bench of the writer"""
+    import tempfile
+    L = load_library()
+    L.rb3h_fmdw_dump_file.restype = ctypes.c_int
+    L.rb3h_fmdw_dump_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    lut = np.full(256, 5, dtype=np.uint8)
+    for i, c in enumerate(b"$ACGTN"):
+        lut[c] = i
+    for i, c in enumerate(b"$acgtn"):
+        lut[c] = i
+    lut[10] = 0
+    lut[:6] = np.arange(6)
+    sym = lut[np.frombuffer(bytes(plain), dtype=np.uint8)]
+    w = L.rb3h_fmdw_init()
+    try:
+        # runs, as rld_enc coalesces them anyway (rld0.c:153-161)
+        cut = np.flatnonzero(np.diff(sym)) + 1
+        starts = np.concatenate([[0], cut])
+        lens = np.diff(np.concatenate([starts, [sym.size]]))
+        for st, ln in zip(starts.tolist(), lens.tolist()):
+            if L.rb3h_fmdw_enc(w, int(ln), int(sym[st])) < 0:
+                raise ValueError("rb3h_fmdw_enc failed")
+        L.rb3h_fmdw_finish(w)
+        with tempfile.NamedTemporaryFile(suffix=".fmd") as f:
+            if L.rb3h_fmdw_dump_file(w, f.name.encode()) < 0:
+                raise IOError("rb3h_fmdw_dump_file failed")
+            return open(f.name, "rb").read()
+    finally:
+        L.rb3h_fmdw_destroy(w)
+
+
 def fmd_bytes_from_words(words, acc):
     """the whole .fmd file -- header, data section, rank index -- from the data section packed on the GPU
     (Rb3Gpu.export_fmd_words) and the index's C array: what `build -d` writes (rld_dump, rld0.c:222-243; the rank index is

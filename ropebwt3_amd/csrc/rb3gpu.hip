@@ -1484,7 +1484,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 				hipLaunchKernelGGL(k_part_place, dim3((unsigned)((part_nb + 7) / 8 * 8 * S)), dim3(256), 0, h->st, (const uint64_t*)pout, len, partK, part_nb, S, dpos, (const unsigned long long*)(misc + 2));
 				frec = nullptr, fsa = nullptr;
 			}
-			if (tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin, frec, fsa);
+			const dim3 g2((unsigned)((len / 2 + 1 + 255) / 256)); // (records in row order: two rows per thread)
+			if (frec == nullptr && tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows2<true>), g2, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
+			else if (frec == nullptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows2<false>), g2, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)nullptr, misc + 2, (int64_t*)h->jg.p, nwin);
+			else if (tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin, frec, fsa);
 			else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<false>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)nullptr, misc + 2, (int64_t*)h->jg.p, nwin, frec, fsa);
 		} else if (tent)
 			hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2);

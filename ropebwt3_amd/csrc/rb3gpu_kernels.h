@@ -1533,9 +1533,10 @@ __global__ void __launch_bounds__(256) k_resolve_w(rb3_stretch_t *tab, const uin
 	for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk + nb; t += (int64_t)gridDim.x * blockDim.x) {
 		int F = (int)(t < nblk ? t * RB3_TENT_BLOCK : RB3_TENT_HALF + (t - nblk));
 		const uint4 *rp = (const uint4*)&tab[F];
-		uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+		uint4 q1 = rp[1];       // (del first: 99 % of the records end here, and 16 bytes are a quarter of the traffic of the whole record)
 		int d0 = (int)q1.x - 1; // del
 		if (d0 < 0) continue;   // only first stretches a walker settled start a path
+		uint4 q0 = rp[0], q2 = rp[2], q3 = rp[3];
 		if (t < nblk && q3.z != 0u && !(q3.z & RB3_FIRSTFLAG)) continue; // (a continuation block: its first id is an event stretch)
 		for (int hops = 0; hops <= maxhops; ++hops) { // longer paths (a string that repeats indexed text) are left to k_wj_*
 			if (d0 < 0 || d0 > RB3_TENT_KMAX) break; // cannot be: leave it unsettled, the host redoes the phase
@@ -2036,6 +2037,67 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check_rows(int64_t *pos, i
 	int64_t b = i == n2 ? nwin : p >> RB3_WIN_BITS;
 	if (b > nwin) b = nwin;
 	for (int64_t w = a + 1; w <= b; ++w) jw[w] = i;
+}
+
+/* the same for records in row order (rec == nullptr above), TWO rows per thread: 16-byte loads and stores, half the threads -- the pass
+ * is a stream of 16 B per row and was running at half the rate a stream should */
+template<bool TENT>
+__global__ void __launch_bounds__(256) k_pos_finalize_check_rows2(int64_t *pos, int64_t n2, int64_t ntot, const int32_t *sfin, unsigned long long *bad, int64_t *jw, int64_t nwin)
+{
+	const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2, i1 = i0 + 1;
+	if (i0 > n2) return;
+	if (TENT && __builtin_amdgcn_readfirstlane((int)(*(volatile unsigned long long*)&bad[2] != 0)) != 0) return;
+	int64_t p0 = INT64_MAX, p1 = INT64_MAX, q = RB3_UNSET;
+	if (i1 < n2) {
+		const longlong2 raw = *(const longlong2*)(pos + i0);
+		p0 = TENT ? pos_final(raw.x, sfin, bad) : (raw.x < 0 ? RB3_UNSET : raw.x);
+		p1 = TENT ? pos_final(raw.y, sfin, bad) : (raw.y < 0 ? RB3_UNSET : raw.y);
+		if (TENT && ((p0 != raw.x && p0 >= 0) || (p1 != raw.y && p1 >= 0))) { // (an unsettled record stays as it is: a longer settle pass may still resolve it)
+			longlong2 w;
+			w.x = p0 >= 0 ? p0 : raw.x, w.y = p1 >= 0 ? p1 : raw.y;
+			*(longlong2*)(pos + i0) = w;
+		}
+	} else if (i0 < n2) {
+		const int64_t raw = pos[i0];
+		p0 = TENT ? pos_final(raw, sfin, bad) : (raw < 0 ? RB3_UNSET : raw);
+		if (TENT && p0 != raw && p0 >= 0) pos[i0] = p0;
+	}
+	{ // the row before i0: the second row of the lane below; lane 0 of a wave looks it up again
+		const int64_t last = i1 < n2 ? p1 : p0; // (only the wave's last thread can have i1 >= n2, and nobody reads its `last`)
+		const uint32_t qlo = wave_up1((uint32_t)(uint64_t)last), qhi = wave_up1((uint32_t)((uint64_t)last >> 32));
+		if ((threadIdx.x & 63) != 0) q = (int64_t)((uint64_t)qhi << 32 | qlo);
+		else if (i0 > 0) {
+			const int64_t rq = pos[i0 - 1];
+			q = TENT ? pos_final(rq, sfin, nullptr) : (rq < 0 ? RB3_UNSET : rq);
+		}
+	}
+	// row i0 (or, with i0 == n2, the windows behind the last row)
+	bool ok0 = true;
+	if (i0 < n2) {
+		if (p0 < 0) { atomicAdd(&bad[0], 1ull); ok0 = false; }
+		else if (p0 >= ntot || (i0 > 0 && q >= 0 && q >= p0)) { atomicAdd(&bad[1], 1ull); ok0 = false; }
+	}
+	if (i0 > 0 && q < 0) ok0 = false;
+	if (ok0) {
+		const int64_t a = i0 == 0 ? -1 : q >> RB3_WIN_BITS;
+		int64_t b = i0 == n2 ? nwin : p0 >> RB3_WIN_BITS;
+		if (b > nwin) b = nwin;
+		for (int64_t w = a + 1; w <= b; ++w) jw[w] = i0;
+	}
+	if (i0 >= n2) return;
+	// row i1 (or the windows behind the last row)
+	bool ok1 = true;
+	if (i1 < n2) {
+		if (p1 < 0) { atomicAdd(&bad[0], 1ull); ok1 = false; }
+		else if (p1 >= ntot || (p0 >= 0 && p0 >= p1)) { atomicAdd(&bad[1], 1ull); ok1 = false; }
+	}
+	if (p0 < 0) ok1 = false;
+	if (ok1) {
+		const int64_t a = p0 >> RB3_WIN_BITS;
+		int64_t b = i1 == n2 ? nwin : p1 >> RB3_WIN_BITS;
+		if (b > nwin) b = nwin;
+		for (int64_t w = a + 1; w <= b; ++w) jw[w] = i1;
+	}
 }
 
 __global__ void __launch_bounds__(256) k_pos_check(const int64_t *pos, int64_t n2, int64_t ntot, unsigned long long *bad)

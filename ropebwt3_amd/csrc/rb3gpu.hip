@@ -1416,10 +1416,13 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int64_t *drec = trec ? (int64_t*)h->post.p : dpos; // where the walkers leave their records
 	{
 		const IdxView iv = view_of(h);
+		// lanes per walker: an octet, or a QUAD (16 walkers share a wave's instruction stream; every lane takes two slices of a slot).  Quads exist for
+		// the headline's kernel (run-coded index, tentative records, text-order words, 32-bit positions); all kernels only in a -DRB3_WITH_QUADS build.
+		const bool quad_ok = iv.dense != 2 && tent && d_tw != nullptr && n_walkers <= 65536 && iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29);
 #ifdef RB3_WITH_QUADS
 		const int lpw = h->tn.lpw;
 #else
-		const int lpw = 8;
+		const int lpw = h->tn.lpw == 4 && quad_ok ? 4 : 8;
 #endif
 		const int octs = h->tn.octs * (8 / lpw); // groups of lpw lanes per wave
 		const int64_t n_expect = auto_list ? b2_nbk + 64 : n_walkers; // (a device-made list: capacity >> walkers; size the launch for the walkers)
@@ -1457,6 +1460,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		case 7: // (the headline's kernel: 32-bit positions in the common step where index and batch allow it)
 			if (iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29) && lpw == 8)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 8, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
+					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, trec ? 1 : 0);
+			else if (quad_ok && lpw == 4)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 4, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
 					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, trec ? 1 : 0);
 			else RB3_LAUNCH_FAST(false, true, 1);
 			break;

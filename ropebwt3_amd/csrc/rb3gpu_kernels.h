@@ -270,23 +270,25 @@ __device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2
  * step out of five or ten, and with eight walkers per wave some walker does in a third of the wave's iterations; giving that
  * walker two single decodes made the whole wave run ~300 more instructions.  The two exclusive scans over the octet share
  * their DPP steps (two 16-bit fields).  cnt = #{i < off : sym_i == c}, this lane's share. */
-__device__ __forceinline__ void slice_count_pk2(const uint4 &sa, const uint4 &sb, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b)
+template<int LPW = 8>
+__device__ __forceinline__ void slice_count_pk2(const uint4 &sa, const uint4 &sa2, const uint4 &sb, const uint4 &sb2, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b)
 {
-	const uint32_t wa[3] = { sa.y, sa.z, sa.w }, wb[3] = { sb.y, sb.z, sb.w };
-	uint32_t la[3], lb[3], ta = 0, tb = 0;
+	constexpr int NW = LPW == 4 ? 6 : 3; // (a quad lane holds two slices of each slot: 12 codes)
+	const uint32_t wa[6] = { sa.y, sa.z, sa.w, sa2.y, sa2.z, sa2.w }, wb[6] = { sb.y, sb.z, sb.w, sb2.y, sb2.z, sb2.w };
+	uint32_t la[NW], lb[NW], ta = 0, tb = 0;
 #pragma unroll
-	for (int k = 0; k < 3; ++k) {
+	for (int k = 0; k < NW; ++k) {
 		la[k] = as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, wa[k]) >> 3) + as_s16x2(0x00010001u));
 		lb[k] = as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, wb[k]) >> 3) + as_s16x2(0x00010001u));
 		ta = pk_sum16(la[k], ta), tb = pk_sum16(lb[k], tb);
 	}
-	const uint32_t base2 = oct_exscan(ta | tb << 16, j); // (a slot covers at most 8192 symbols + 48 unused codes: no carry between the fields)
+	const uint32_t base2 = grp_exscan<LPW>(ta | tb << 16, j); // (a slot covers at most 8192 symbols + 48 unused codes: no carry between the fields)
 	uint32_t base_a = base2 & 0xFFFFu, base_b = base2 >> 16;
 	const uint32_t csplat = (uint32_t)c * 0x00010001u;
 	const rb3_s16x2 oa = as_s16x2((uint32_t)off_a * 0x00010001u), ob = as_s16x2((uint32_t)off_b * 0x00010001u), zero = as_s16x2(0u), one = as_s16x2(0x00010001u);
 	rb3_s16x2 acc_a = zero, acc_b = zero;
 #pragma unroll
-	for (int k = 0; k < 3; ++k) {
+	for (int k = 0; k < NW; ++k) {
 		const rb3_s16x2 Pa = as_s16x2(base_a * 0x00010001u + (la[k] << 16)), Pb = as_s16x2(base_b * 0x00010001u + (lb[k] << 16));
 		const uint32_t eqa = as_u32((as_s16x2((wa[k] & 0x00070007u) ^ csplat) - one) >> 15), eqb = as_u32((as_s16x2((wb[k] & 0x00070007u) ^ csplat) - one) >> 15);
 		const rb3_s16x2 da = __builtin_elementwise_min(__builtin_elementwise_max(oa - Pa, zero), as_s16x2(la[k]));
@@ -702,13 +704,14 @@ __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, uint32_t k
 }
 
 /* the same with the slot's offset in its group given (derived from the directory's mask: no header word needed) */
+template<int LPW = 8>
 __device__ __forceinline__ void octc_finish_pair_at(const RankLoadC &rl, int off_lo, int off_hi, int c, int j, int64_t *lo_n, int64_t *hi_n)
 {
 	uint32_t ca, cb, mt;
-	slice_count_pk<true, false, 8>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
+	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16;
-	v = oct_sum(v);
-	const uint64_t hb = rl.gc + oct_sum(j == c + 1 ? rl.sl.x : 0u); // (the header may be the whole LF base: 32 bits)
+	v = grp_sum<LPW>(v);
+	const uint64_t hb = rl.gc + grp_sum<LPW>(octc_hdr_c<LPW>(rl, c, j)); // (the header may be the whole LF base: 32 bits)
 	*lo_n = (int64_t)(hb + (v & 0xFFFFu)), *hi_n = (int64_t)(hb + (v >> 16));
 }
 
@@ -1073,7 +1076,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 		// instruction-issue speed, so instruction count is the cost.
 		do {
 #ifndef RB3_NO_FAST_STEP
-			if (LIST && !DENSE && TENT && TEXT == 1 && LPW == 8) {
+			if (LIST && !DENSE && TENT && TEXT == 1) { // (LPW = 8: an octet per walker; LPW = 4: a quad, every lane two slices of a slot)
 				// ---- the common step, straight-line.  A genome walked through an index of its relatives spends nine steps in ten in
 				// one state: inside its own segment (so nobody has recorded the row and nothing ends here), not at a sentinel, its
 				// stretch -- if it records tentatively -- already open.  Everything the general step below tests for on the way
@@ -1093,7 +1096,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 #ifdef RB3_PROF_STEP /* kernel experiment: where does an iteration of the common step spend its cycles?  (s_memtime at four points) */
 					const uint64_t pt0 = __builtin_amdgcn_s_memtime();
 #endif
-					if ((++it & 7u) == 0 && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; } // (only after general steps: this body flushes at the end of a window)
+					if ((++it & (uint32_t)(LPW - 1)) == 0 && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; } // (only after general steps: this body flushes at the end of a window)
 					const int c = (int)cq;
 					// round trip 1: the slot word of lo's group from the compact copy (an L2 hit); the 64-byte entry's count for c is asked
 					// for at the same time but only needed at the very end
@@ -1123,14 +1126,22 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					const int off_lo = (int)(rl.koff - (w0 << RB3_WIN_BITS)), off_hi = off_lo + (int)kq32;
 					const bool same = rl.koff + kq32 <= (wend << RB3_WIN_BITS);
 					const bool far = !same && kq32 > 255u; // (wide masks: an interval of more than 255 rows may end beyond the NEXT slot too: the general decode)
-					uint4 slb = make_uint4(0u, 0u, 0u, 0u);
+					uint4 slb = make_uint4(0u, 0u, 0u, 0u), slb2 = make_uint4(0u, 0u, 0u, 0u);
+					if (LPW == 8) rl.sl2 = make_uint4(0u, 0u, 0u, 0u);
 					if (I32) { // (fewer than 2^24 slots: the byte offset fits 32 bits)
-						const uint32_t so = rl.sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * 16u;
+						const uint32_t so = rl.sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * (LPW == 8 ? 16u : 32u);
 						rl.sl = *(const uint4*)((const char*)b1.slot16 + so);
-						if (!same) slb = *(const uint4*)((const char*)b1.slot16 + (so + (uint32_t)sizeof(rb3_slot_t)));
+						if (LPW == 4) rl.sl2 = *(const uint4*)((const char*)b1.slot16 + (so + 16u));
+						if (!same) {
+							slb = *(const uint4*)((const char*)b1.slot16 + (so + (uint32_t)sizeof(rb3_slot_t)));
+							if (LPW == 4) slb2 = *(const uint4*)((const char*)b1.slot16 + (so + (uint32_t)sizeof(rb3_slot_t) + 16u));
+						}
 					} else {
-						octc_load_slot<8>(b1, (int64_t)rl.sidx, j, rl);
-						if (!same) slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + j]; // the upper end lies in the next slot: asked for at the same time
+						octc_load_slot<LPW>(b1, (int64_t)rl.sidx, j, rl);
+						if (!same) { // the upper end lies in the next slot: asked for at the same time
+							if (LPW == 8) slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + j];
+							else slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + 2 * j], slb2 = b1.slot16[((int64_t)rl.sidx + 1) * 8 + 2 * j + 1];
+						}
 					}
 #ifdef RB3_PROF_STEP
 					asm volatile("s_nop 0" :: "v"(rl.sidx));
@@ -1139,41 +1150,43 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					++steps;
 					const int64_t myval = I32 ? (int64_t)((uint64_t)(uint32_t)lo + (uint64_t)(uint32_t)kb) : lo + kb;
 					// (once a stretch is open the interval is at most KMAX wide and the walker old enough, for the rest of its life)
-					if ((gap == 0 || sid >= 0) && j == (int)(it & 7u))
+					if ((gap == 0 || sid >= 0) && j == (int)(it & (uint32_t)(LPW - 1)))
 						bkb = trec ? tp : kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					// the records of the last eight steps go out here, where nothing is asked for during the whole decode: the store is slow
 					// (written through) and whatever is asked for after it waits for its acknowledgement (vmcnt counts in order)
-					if ((it & 7u) == 7u && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
+					if ((it & (uint32_t)(LPW - 1)) == (uint32_t)(LPW - 1) && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
 #ifdef RB3_PROF_STEP
 					asm volatile("s_nop 0" :: "v"(rl.sl.x));
 					const uint64_t pt2 = __builtin_amdgcn_s_memtime(); // the slot has arrived
 #endif
 					int64_t lo_n, hi_n;
-					if (same) slb = rl.sl;
-					const bool rleb = same ? rle : (oct_bcast0(slb.x, j) & RB3_SLOT_RLE) != 0u;
+					if (same) slb = rl.sl, slb2 = rl.sl2;
+					const bool rleb = same ? rle : (grp_bcast0<LPW>(slb.x, j) & RB3_SLOT_RLE) != 0u;
 #ifdef RB3_PROF_STEP
 					if (__ballot(!(rle && same)) != 0ull) prof_t[5] += 1;
 					if (__ballot(!(rle && rleb)) != 0ull) prof_t[6] += 1;
 #endif
-					if (__all(rle && same)) octc_finish_pair_at(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
+					if (__all(rle && same)) octc_finish_pair_at<LPW>(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
 					else if (__all(rle && rleb && !far)) { // some walker's interval straddles two run slots: everybody through the two-slot decode
 						uint32_t ca, cb;
-						slice_count_pk2(rl.sl, slb, off_lo, same ? off_hi : off_hi - (int)((wend - w0) << RB3_WIN_BITS), c, j, &ca, &cb);
+						slice_count_pk2<LPW>(rl.sl, rl.sl2, slb, slb2, off_lo, same ? off_hi : off_hi - (int)((wend - w0) << RB3_WIN_BITS), c, j, &ca, &cb);
 						uint32_t v = ca | cb << 16;
-						v = oct_sum(v);
-						const uint32_t hl = oct_sum(j == c + 1 ? rl.sl.x : 0u), hh = oct_sum(j == c + 1 ? slb.x : 0u); // (headers of 32 bits where they carry the LF base)
+						v = grp_sum<LPW>(v);
+						RankLoadC rb2;
+						rb2.sl = slb, rb2.sl2 = slb2;
+						const uint32_t hl = grp_sum<LPW>(octc_hdr_c<LPW>(rl, c, j)), hh = grp_sum<LPW>(octc_hdr_c<LPW>(rb2, c, j)); // (headers of 32 bits where they carry the LF base)
 						lo_n = (int64_t)(rl.gc + hl + (v & 0xFFFFu)), hi_n = (int64_t)(rl.gc + hh + (v >> 16));
-					} else if (rle && same) octc_finish_pair_at(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
+					} else if (rle && same) octc_finish_pair_at<LPW>(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
 					else { // a bit-plane slot somewhere
 						uint32_t match = 0, mh;
-						lo_n = octc_finish<false, 8>(rl, c, j, &match);
+						lo_n = octc_finish<false, LPW>(rl, c, j, &match);
 						hi_n = gap == 1 ? lo_n + match : lo_n;
 						if (gap == 2) {
 							RankLoadC rh;
-							octc_issue_grp<false, 8>(b1, hi, c, j, rh);
-							octc_issue_slot_hi<false, 8>(b1, j, rh, rl);
-							hi_n = octc_finish<false, 8, false>(rh, c, j, &mh);
+							octc_issue_grp<false, LPW>(b1, hi, c, j, rh);
+							octc_issue_slot_hi<false, LPW>(b1, j, rh, rl);
+							hi_n = octc_finish<false, LPW, false>(rh, c, j, &mh);
 						}
 					}
 					const int64_t kn = I32 ? (int64_t)(int32_t)((uint32_t)hi_n - (uint32_t)lo_n) : hi_n - lo_n;
@@ -1184,7 +1197,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 							// (asking for the next chunk ahead of time, so that nobody waits for the atomic: measured 5 % SLOWER)
 							uint32_t s0 = 0;
 							if (j == 0) s0 = tent_take_chunk(sidctr, mctr, myctr);
-							s0 = oct_bcast0(s0, j);
+							s0 = grp_bcast0<LPW>(s0, j);
 							ns = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 						}
 						if (j == 0 && ns != RB3_TENT_POISON) {

@@ -547,7 +547,7 @@ def main():
     # (rb3_fmi_merge_plain, fm-index.c:279), so the walkers of the long strings come from a sparse LF walk of the batch itself and the walk reads
     # row words instead of streaming the inverse suffix array: what not having the sorter's products costs on the headline workload
     refsig = None
-    if not args.no_aux or args.only == "headline":
+    if not args.no_aux:
         try:
             bl.run(texts, walkers, reference_signature=True)
             bl.h.sync()

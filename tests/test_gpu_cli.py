@@ -22,7 +22,7 @@ def run(args, inp=None, env=None):
     return r.stdout, r.stderr.decode()
 
 
-CASES = [k for k in MAN if k not in ("resume", "mtb_star", "reads_m7g", "family")]
+CASES = [k for k in MAN if k not in ("resume", "mtb_star", "reads_m7g", "family", "big_index")]
 
 
 @pytest.mark.parametrize("name", CASES)

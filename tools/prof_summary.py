@@ -21,8 +21,13 @@ def short(name):
         import re
         m = re.search(r"k_reb_group<(\d+), *(\d+)", name) or re.search(r"k_reb_groupILi(\d+)ELi(\d+)", name)
         return "k_reb_group<%s,%s>" % (m.group(1), m.group(2)) if m else "k_reb_group"
+    if "k_pos_finalize_check_rows2" in name:
+        return "k_pos_finalize_check_rows2"
     if "k_pos_finalize_check_rows" in name:
         return "k_pos_finalize_check_rows"
+    for k in ("k_plane_group", "k_place_pg", "k_part_scatter", "k_part_place"):
+        if k in name:
+            return k + ("<listed>" if "<true>" in name or "ILb1" in name else "")
     if "k_export_runs" in name:
         return "k_export_runs"
     for k in ("k_events", "k_ssa_walk", "k_ssa_link", "k_ssa_final"):

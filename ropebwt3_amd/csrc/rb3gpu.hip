@@ -330,8 +330,11 @@ static int tent_masks(rb3gpu_t *h, int q, uint32_t **mx)
 
 /* the settle kernels behind k_chain: the rows that dropped at every event, per walker the cumulative mask, the paths over first
  * stretches (up to maxhops hops), all other stretches */
-static void launch_settle(rb3gpu_t *h, const IdxView &iv, rb3_stretch_t *tab, uint32_t *mx, const uint32_t *sidctr, int32_t *sfin, unsigned long long *bad, int maxhops, int q)
+static void launch_settle(rb3gpu_t *h, const IdxView &iv, rb3_stretch_t *tab, uint32_t *mx, const uint32_t *sidctr, int32_t *sfin, unsigned long long *bad, int maxhops, int q, const uint32_t *mctr = nullptr)
 {
+	// mctr: the extent of the stretch ids in use has not been worked out yet (k_tent_extent); the first kernel of the narrow-mask settle does it on its way
+	const bool fused_extent = mctr != nullptr && !(q >= 2 && mx) && !h->tn.resolve_v1;
+	if (mctr != nullptr && !fused_extent) hipLaunchKernelGGL(k_tent_extent, dim3(1), dim3(64), 0, h->st, mctr, (uint32_t*)sidctr);
 #define RB3_SETTLE_X(Q) do { \
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_events_x<Q>), dim3(2048), dim3(256), 0, h->st, iv, (const rb3_stretch_t*)tab, mx, sidctr); \
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cum_x<Q>), dim3(4096), dim3(64), 0, h->st, tab, mx, sidctr); \
@@ -342,7 +345,7 @@ static void launch_settle(rb3gpu_t *h, const IdxView &iv, rb3_stretch_t *tab, ui
 	else if (q >= 4 && mx) RB3_SETTLE_X(4);
 	else if (q >= 2 && mx) RB3_SETTLE_X(2);
 	else {
-		hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, sidctr);
+		hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, sidctr, fused_extent ? mctr : (const uint32_t*)nullptr, (uint32_t*)sidctr);
 		if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, sidctr, sfin);
 		else {
 			hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, sidctr);
@@ -1472,8 +1475,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #undef RB3_LAUNCH_FAST1
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
 		if (tent) {
-			hipLaunchKernelGGL(k_tent_extent, dim3(1), dim3(64), 0, h->st, (const uint32_t*)mctr, sidctr);
-			launch_settle(h, iv, tab, mx, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS, tq), h->stt.tent_mask_bits = 256 * tq;
+			launch_settle(h, iv, tab, mx, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS, tq, (const uint32_t*)mctr), h->stt.tent_mask_bits = 256 * tq;
 		}
 		if (rows_fused) { // validation and the rows-per-window table of the rebuild in one pass over pos[]
 			const dim3 g1((unsigned)((len + 1 + 255) / 256));

@@ -864,25 +864,27 @@ __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, 
 				if (sh && wi + 1 >= 0 && wi + 1 < NW && (nm >> (32 - sh))) atomicOr(&D[wi + 1], nm >> (32 - sh));
 			}
 		}
-	} else { // six run codes per lane (rolled loops: this is a cold path and must stay light on registers)
+	} else { // six run codes per lane
 		uint32_t tot = 0;
-#pragma unroll 1
+#pragma unroll
 		for (int i = 0; i < 6; ++i) {
 			const uint32_t word = i < 2 ? sl.y : i < 4 ? sl.z : sl.w, e = (i & 1) ? word >> 16 : word & 0xFFFFu;
 			tot += (e & 7u) == 7u ? 0u : (e >> 3) + 1u;
 		}
 		int pos = (int)oct_exscan(tot, j);
-#pragma unroll 1
+#pragma unroll
 		for (int i = 0; i < 6; ++i) {
 			const uint32_t word = i < 2 ? sl.y : i < 4 ? sl.z : sl.w, e = (i & 1) ? word >> 16 : word & 0xFFFFu;
 			const int len = (e & 7u) == 7u ? 0 : (int)(e >> 3) + 1;
 			if ((int)(e & 7u) != c && len != 0) {
 				int a = pos - off0, b = pos + len - off0; // index range of this run
 				a = a < 0 ? 0 : a, b = b > kk ? kk : b;
+				if (a < b) { // (nearly always one row of one word: a relative that dropped out)
+					int w = a >> 5;
+					const int wl = (b - 1) >> 5, x1l = ((b - 1) & 31) + 1;
+					if (w < NW) atomicOr(&D[w], (w == wl && x1l < 32 ? (1u << x1l) - 1u : 0xFFFFFFFFu) & ~((1u << (a & 31)) - 1u));
 #pragma unroll 1
-				for (int w = a >> 5; a < b && w <= (b - 1) >> 5 && w < NW; ++w) {
-					const int x0 = a > w * 32 ? a - w * 32 : 0, x1 = b < w * 32 + 32 ? b - w * 32 : 32;
-					atomicOr(&D[w], (x1 >= 32 ? 0xFFFFFFFFu : (1u << x1) - 1u) & ~((1u << x0) - 1u));
+					for (++w; w <= wl && w < NW; ++w) atomicOr(&D[w], w == wl && x1l < 32 ? (1u << x1l) - 1u : 0xFFFFFFFFu);
 				}
 			}
 			pos += len;
@@ -892,12 +894,23 @@ __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, 
 
 /* mask[j] of every EVENT stretch: the rows of [lo, lo + kk) that do not hold c (one octet per stretch).
  * The two slots that hold the rows are those of lo and of lo + kk. */
-__global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, const uint32_t *sidctr)
+/* mctr != NULL: the extent of the ids in use is still in the 64 counters the walkers took their chunks from (see tent_take_chunk): every
+ * block works it out for itself and block 0 leaves it in sidctr_out[0] for the kernels behind this one and for the host (k_tent_extent's
+ * job, without its launch) */
+__global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, const uint32_t *sidctr, const uint32_t *mctr = nullptr, uint32_t *sidctr_out = nullptr)
 {
 	__shared__ uint32_t dmask[32 * 8];
 	const int j = threadIdx.x & 7;
 	uint32_t *D = &dmask[(threadIdx.x >> 3) * 8];
-	const int64_t n = *sidctr < (uint32_t)RB3_TENT_HALF ? *sidctr : RB3_TENT_HALF; // events only happen to ids from blocks
+	uint32_t ext = 0;
+	if (mctr != nullptr) {
+		uint32_t v = (threadIdx.x & 63) < RB3_TENT_NCTR ? mctr[(threadIdx.x & 63) * 32u] : 0u;
+		for (int o = 32; o; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = v > t ? v : t; }
+		const unsigned long long e = (unsigned long long)v * RB3_TENT_NCTR * RB3_TENT_CHUNK;
+		ext = e < (unsigned long long)RB3_TENT_HALF ? (uint32_t)e : (uint32_t)RB3_TENT_HALF;
+		if (blockIdx.x == 0 && threadIdx.x == 0) sidctr_out[0] = ext;
+	} else ext = *sidctr;
+	const int64_t n = ext < (uint32_t)RB3_TENT_HALF ? ext : RB3_TENT_HALF; // events only happen to ids from blocks
 	for (int64_t sid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; sid < n; sid += ((int64_t)gridDim.x * blockDim.x) >> 3) {
 		const uint64_t w0 = tab[sid].w0;
 		if (w0 >> 62 != RB3_DEP_EVENT) continue;

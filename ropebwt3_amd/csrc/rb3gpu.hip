@@ -124,6 +124,7 @@ struct Tune {
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
 	int64_t load_chunk = 16384; // groups (of 8192 symbols) an FMD stream is decoded and built by at a time when it holds more than that (rb3gpu_from_fmd_words)
 #ifdef RB3GPU_TEST_HOOKS
+	int hide_first = 0;      // k_chain: exact walkers do not see the tentative records of first stretches (the late-walker race of DESIGN.md, made deterministic)
 	int force_fallback = 0;  // pretend the tentative pass left unsettled records
 	int64_t tent_limit = -1; // shrink the stretch table
 	int text_mode = 0;       // force how the text-order words are fetched (1: per lane, 2: 64 bytes per octet)
@@ -431,7 +432,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "guard")) t.guard = v != 0;
 	else if (!strcmp(key, "load_chunk")) t.load_chunk = v < 1 ? 1 : v;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
-	else if (!strcmp(key, "force_fallback") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
+	else if (!strcmp(key, "force_fallback") || !strcmp(key, "hide_first") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
 			!strcmp(key, "pos_limit") || !strcmp(key, "win_scratch") || !strcmp(key, "slot_bytes")) {
 #ifdef RB3GPU_TEST_HOOKS
 		if (!strcmp(key, "pos_limit")) t.pos_limit = v;
@@ -441,6 +442,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 		else if (!strcmp(key, "reb_lcap")) t.reb_lcap = v;
 		else if (!strcmp(key, "reb_slot_cap")) t.reb_slot_cap = v;
 		else if (!strcmp(key, "force_fallback")) t.force_fallback = v != 0;
+		else if (!strcmp(key, "hide_first")) t.hide_first = v != 0;
 		else if (!strcmp(key, "tent_limit")) t.tent_limit = v;
 		else t.text_mode = v == 1 || v == 2 ? (int)v : 0;
 #else
@@ -459,7 +461,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
 	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
-		"force_fallback", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
+		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
 		size_t l = strlen(name);
@@ -569,6 +571,13 @@ void rb3gpu_destroy(rb3gpu_t *h)
 	if (!h) return;
 	(void)hipSetDevice(h->dev);
 	(void)hipStreamSynchronize(h->st);
+#ifdef RB3_DEBUG_CUM
+	{
+		unsigned long long c[8];
+		if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cum_dbg), sizeof(c)) == hipSuccess)
+			fprintf(stderr, "[debug cum] walkers with events %llu, of them first stretch not settled by a walker %llu, a later stretch settled %llu (unambiguous %llu, ambiguous %llu)\n", c[0], c[1], c[2], c[3], c[4]);
+	}
+#endif
 #ifdef RB3_PROF_REB
 	{
 		unsigned long long p[16];
@@ -1437,8 +1446,13 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #endif
 		const dim3 grid((unsigned)(nblk * (256 / h->tn.chain_bs))), blk((unsigned)h->tn.chain_bs);
 		HIPCHK(hipEventRecord(h->ev[6], h->st));
+#ifdef RB3GPU_TEST_HOOKS
+#define RB3_TREC_ARG ((trec ? 1 : 0) | (h->tn.hide_first ? 2 : 0))
+#else
+#define RB3_TREC_ARG (trec ? 1 : 0)
+#endif
 #define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, trec ? 1 : 0)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG)
 #ifdef RB3_WITH_QUADS /* a quad per walker (k_chain<..., 4>) was measured slower in every regime: compiled in on request only */
 #define RB3_LAUNCH_FAST(D, T, X) do { if (lpw == 4) RB3_LAUNCH_FAST1(D, T, X, 4); else RB3_LAUNCH_FAST1(D, T, X, 8); } while (0)
 #else
@@ -1463,10 +1477,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		case 7: // (the headline's kernel: 32-bit positions in the common step where index and batch allow it)
 			if (iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29) && lpw == 8)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 8, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
-					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, trec ? 1 : 0);
+					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG);
 			else if (quad_ok && lpw == 4)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 4, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
-					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, trec ? 1 : 0);
+					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG);
 			else RB3_LAUNCH_FAST(false, true, 1);
 			break;
 		default: RB3_LAUNCH_FAST(false, true, 0); break;

@@ -967,8 +967,14 @@ template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8, bool I32 = fal
 #endif
 __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX, uint32_t *mctr = nullptr, int trec = 0)
+		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX, uint32_t *mctr = nullptr, int trec_arg = 0)
 {
+	const int trec = trec_arg & 1;
+#ifdef RB3GPU_TEST_HOOKS
+	// test hook (rb3gpu_tune "hide_first"): an EXACT walker does not see the tentative records of a walker's FIRST stretch -- what happens for real when it
+	// follows a late walker more closely than records become visible: it records over those rows and settles a LATER stretch (see k_cum)
+	const bool hide_first = (trec_arg & 2) != 0;
+#endif
 	// trec (TEXT only): row[] is indexed by TEXT POSITION instead of by row.  The eight records an octet parks are then eight
 	// consecutive words -- one 64-byte store where a record per row is eight random 8-byte stores, each costing a 32-byte sector
 	// and, in an index that lives in HBM, most of the step (k_chain 18.2 -> 6.4 ms per 302 M steps with the stores removed) -- and
@@ -1255,7 +1261,16 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 			prof_last = 0;
 #endif
 			if ((++it & (uint32_t)(LPW - 1)) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
-			const bool met = TEXT ? (int64_t)rc >= 0 : (int64_t)x >= 0;  // this row already carries a record
+			bool met = TEXT ? (int64_t)rc >= 0 : (int64_t)x >= 0;  // this row already carries a record
+#ifdef RB3GPU_TEST_HOOKS
+			if (TENT && hide_first && met && gap == 0) {
+				const int64_t seen0 = TEXT ? (int64_t)rc : (int64_t)x;
+				if (seen0 & RB3_TENT) {
+					const int idh = (int)(seen0 >> RB3_TENT_PBITS) & (RB3_TENT_IDS - 1);
+					if (idh != RB3_TENT_POISON && (__hip_atomic_load(&tab[idh].w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 62) == 0ull) met = false;
+				}
+			}
+#endif
 			const int c = (int)(x & 7u);
 			const int64_t kbn = TEXT ? (int64_t)(x1 >> 3) : met ? kb : RB3_ROW_NEXT(x);
 			const int64_t tpn = tp > 0 ? tp - 1 : 0;
@@ -1473,6 +1488,12 @@ __device__ __forceinline__ uint32_t oct_max(uint32_t v)
 	return v;
 }
 
+#ifdef RB3_DEBUG_CUM
+__device__ unsigned long long g_cum_dbg[8];
+#define RB3_CUM_DBG(i) do { if (j == 0) atomicAdd(&g_cum_dbg[i], 1ull); } while (0)
+#else
+#define RB3_CUM_DBG(i) do {} while (0)
+#endif
 /* one octet per first stretch of a walker that has stretch-id blocks (ids 0 .. na-1, multiples of 8 with pad[0] == 0) */
 __global__ void __launch_bounds__(256) k_cum(rb3_stretch_t *tab, const uint32_t *sidctr)
 {
@@ -1485,6 +1506,9 @@ __global__ void __launch_bounds__(256) k_cum(rb3_stretch_t *tab, const uint32_t 
 		if (tab[F].pad[0] != 0u) continue;   // the block continues another walker's stretches
 		int next = tab[F].child - 1;
 		if (next < 0) continue;              // a walker without events that nobody links out of
+		bool want_first = tab[F].del == 0;   // nobody settled the first stretch itself: a del on a later one may (below)
+		RB3_CUM_DBG(0);
+		if (want_first) RB3_CUM_DBG(1);
 		cumL[j] = 0u;
 		int cur = (int)F;
 		bool go = true;
@@ -1520,6 +1544,41 @@ __global__ void __launch_bounds__(256) k_cum(rb3_stretch_t *tab, const uint32_t 
 				}
 				wave_sync();
 				tab[base + o].mask[j] = cumL[j]; // cumulative, first-interval coordinates
+				// A follower that knew more may have settled THIS stretch (del) without ever seeing a record of the first one -- it ran so
+				// closely behind the walker that those records were not visible yet, and recorded over them.  d_t, the unknown here, counts
+				// the survivors below the new suffix; the unknown d_0 of the first stretch is a position whose number of survivors (zeros of
+				// the cumulative mask) below it is d_t: every position from behind the (d_t - 1)-th survivor to the d_t-th survivor itself.
+				// All of them give the same unknowns for this and every later stretch, but not for the earlier ones.  So the smallest one
+				// becomes the walker's d_0 (del of the first stretch), and unless the range is ONE position (no dropped row just below the
+				// d_t-th survivor) the first stretch's `child` -- no longer needed once this loop has passed it -- is replaced by
+				// -(t + 2): "d_0 only holds from stretch t on".  k_resolve_w then starts a path here without settling the first stretch
+				// itself, k_sfin settles the stretches from t on; records of earlier stretches, if any survived the follower's own
+				// records, stay unsettled and the merge is redone (correctness never rests on this).
+				if (want_first) {
+					const int dt = (int)__shfl(q1.x, o, RB3_TENT_BLOCK) - 1; // del - 1 of this stretch
+					if (dt >= 0) {
+						want_first = false;
+						RB3_CUM_DBG(2);
+						const uint32_t cw2 = cumL[j];
+						const uint32_t zc2 = 32u - __popc(cw2), Z2 = oct_exscan(zc2, j);
+						const uint32_t tz = oct_sum(zc2);
+						if ((uint32_t)dt < tz) { // (the d_t-th survivor exists)
+							int j1 = 0, j0 = 0;
+#pragma unroll
+							for (int l = 1; l < 8; ++l) {
+								const uint32_t Zl = __shfl(Z2, l, 8);
+								j1 += Zl <= (uint32_t)dt ? 1 : 0, j0 += (dt > 0 && Zl <= (uint32_t)(dt - 1)) ? 1 : 0;
+							}
+							const int pmax = 32 * j1 + select32(~__shfl(cw2, j1, 8), dt - (int)__shfl(Z2, j1, 8));
+							const int pmin = dt > 0 ? 32 * j0 + select32(~__shfl(cw2, j0, 8), dt - 1 - (int)__shfl(Z2, j0, 8)) + 1 : 0;
+							if (pmin == pmax) RB3_CUM_DBG(3); else RB3_CUM_DBG(4);
+							if (j == 0) {
+								tab[F].del = 1 + pmin;
+								if (pmin != pmax) tab[F].child = -(base + o) - 2;
+							}
+						}
+					}
+				}
 				cur = base + o, next = nxt;
 				if (next != cur + 1 || ++o == RB3_TENT_BLOCK) break; // the sequence leaves this block
 			}
@@ -1566,7 +1625,9 @@ __global__ void __launch_bounds__(256) k_resolve_w(rb3_stretch_t *tab, const uin
 		if (t < nblk && q3.z != 0u && !(q3.z & RB3_FIRSTFLAG)) continue; // (a continuation block: its first id is an event stretch)
 		for (int hops = 0; hops <= maxhops; ++hops) { // longer paths (a string that repeats indexed text) are left to k_wj_*
 			if (d0 < 0 || d0 > RB3_TENT_KMAX) break; // cannot be: leave it unsettled, the host redoes the phase
-			sfin[F] = d0 + 1;
+			// (a path that STARTS at a first stretch whose unknown k_cum derived from a later stretch and could not pin down -- child < 0 --
+			// does not settle the first stretch itself: see k_cum)
+			if (!(hops == 0 && (q3.z & RB3_FIRSTFLAG) && (int)q1.y < 0)) sfin[F] = d0 + 1;
 			int last = F, next = (int)q1.y - 1, dl = d0;
 			if (q3.z & RB3_FIRSTFLAG) { // the walker had events: k_cum left the summary
 				const uint32_t mw[8] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y };
@@ -1612,7 +1673,7 @@ __global__ void __launch_bounds__(256) k_wj_init(const rb3_stretch_t *tab, const
 	else {
 		const int s = sfin[X], del = tab[X].del;
 		if (s > 0) n.val = s - 1;
-		else if (del > 0 && del <= RB3_TENT_KMAX + 1) n.val = del - 1;
+		else if (del > 0 && del <= RB3_TENT_KMAX + 1) n.val = del - 1, n.pad = (t < nblk && (h0 & RB3_FIRSTFLAG) && tab[X].child < -1) ? 1 : 0; // (pad: k_cum could not pin the first stretch down: its value only serves the paths)
 		else {
 			const uint64_t w0 = tab[X].w0;
 			if (w0 >> 62 == RB3_DEP_LINK) {
@@ -1674,7 +1735,7 @@ __global__ void __launch_bounds__(256) k_wj_apply(int64_t nblk, int64_t nb, cons
 {
 	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= nblk + nb) return;
-	if (nodes[t].val >= 0) sfin[wj_stretch(t, nblk)] = nodes[t].val + 1;
+	if (nodes[t].val >= 0 && nodes[t].pad == 0) sfin[wj_stretch(t, nblk)] = nodes[t].val + 1;
 }
 
 /* every event stretch from its walker's first unknown: sfin[s] = 1 + d_0 - #{dropped rows below d_0}; one octet per stretch */
@@ -1685,9 +1746,17 @@ __global__ void __launch_bounds__(256) k_sfin(const rb3_stretch_t *tab, const ui
 	for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; s < na; s += ((int64_t)gridDim.x * blockDim.x) >> 3) {
 		const uint32_t head = tab[s].pad[0];
 		if (head == 0u || (head & RB3_FIRSTFLAG)) continue; // a first stretch: settled by a walker or by k_resolve_w
-		if (tab[s].w0 >> 62 != RB3_DEP_EVENT || tab[s].del != 0) continue;
-		const int r0 = sfin[head - 1u];
-		if (r0 < 1) continue; // the walker's first unknown is not settled: neither is this one
+		if (tab[s].w0 >> 62 != RB3_DEP_EVENT) continue;
+		{ // settled by a walker that ran into it: exact, whatever the first stretch says
+			const int dl = tab[s].del;
+			if (dl != 0) { if (j == 0 && dl >= 1 && dl <= RB3_TENT_KMAX + 1) sfin[s] = dl; continue; }
+		}
+		int r0 = sfin[head - 1u];
+		if (r0 < 1) { // the walker's first unknown is not settled -- unless k_cum derived it from a later stretch, for the stretches from that one on
+			const int ch = tab[head - 1u].child, dl0 = tab[head - 1u].del;
+			if (ch < -1 && dl0 >= 1 && dl0 <= RB3_TENT_KMAX + 1 && s >= (int64_t)(-ch - 2)) r0 = dl0;
+			else continue;
+		}
 		const int d0 = r0 - 1, tt = d0 - 32 * j;
 		const uint32_t mw = tab[s].mask[j];
 		const uint32_t below = oct_sum(tt >= 32 ? __popc(mw) : tt > 0 ? __popc(mw & ((1u << tt) - 1u)) : 0u);

@@ -1338,3 +1338,39 @@ def test_index_beyond_2_32_symbols():
     finally:
         srt.close()
         h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,nrel,div", [(401, 12, 0.002), (402, 40, 0.001), (403, 3, 0.004), (404, 25, 0.0005)])
+def test_follower_that_settles_a_later_stretch_of_a_walker(oracle, seed, nrel, div):
+    """VERDICT r3 item 2 / DESIGN.md: an exact walker that follows a tentative one more closely than records become visible records over
+    the rows of the walker's FIRST stretch and meets the first visible tentative record in a LATER one, where it leaves the settled
+    unknown.  The test build makes that deterministic (rb3gpu_tune hide_first: exact walkers do not see first stretches at all), so
+    it happens at every hand-over instead of once in ten thousand merges.  k_cum derives the first stretch's unknown from the later
+    one -- exactly when that is unambiguous, else as "valid from that stretch on" (k_resolve_w / k_sfin then leave the earlier
+    stretches alone, whose rows the follower has recorded itself): the index is the oracle's and NO merge is redone (round 3:
+    every such walker stayed unsettled and the rank phase ran again)."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(seed)
+    g0 = util.random_genome(rng, 50000)
+    rel = [g0] + [util.mutate(rng, g0, div) for _ in range(nrel - 1)]
+    cur = host.build_bwt(util.make_text(rel))
+    h = Rb3Gpu(verbose=1, hooks=True)
+    try:
+        h.tune("hide_first", 1)
+        h.from_plain(cur)
+        n_merges = 0
+        for r in range(6):
+            new = [util.mutate(rng, rel[int(rng.integers(0, len(rel)))], div)]
+            t2 = util.make_text(new)
+            b2 = host.build_bwt(t2.copy())
+            cur = oracle.merge(cur, b2)
+            d_bwt, d_tw = h.sort_text(t2)
+            h.merge_text_dev(d_bwt, d_tw, t2.size, host.walkers_text(t2, 200), commit=True)
+            h.dev_free(d_bwt), h.dev_free(d_tw)
+            n_merges += 1
+            assert np.array_equal(h.export_plain(), cur), (seed, r)
+        st = h.stats()
+        assert st["n_fallbacks"] == 0 and st["n_long_settles"] == 0, st
+    finally:
+        h.close()

@@ -1831,6 +1831,7 @@ __global__ void __launch_bounds__(64) k_cum_x(rb3_stretch_t *tab, uint32_t *mx, 
 		if (next < 0) continue;              // a walker without events that nobody links out of
 #pragma unroll
 		for (int q = 0; q < Q; ++q) cumO[q * 8 + j] = 0u, cumN[q * 8 + j] = 0u;
+		bool want_first = tab[F].del == 0;   // (see k_cum: a del on a later stretch may settle the walker)
 		int cur = (int)F;
 		bool go = true;
 		int hops = 0;
@@ -1880,6 +1881,34 @@ __global__ void __launch_bounds__(64) k_cum_x(rb3_stretch_t *tab, uint32_t *mx, 
 					cumO[q * 8 + j] = v;
 				}
 				wave_sync();
+				if (want_first) { // this stretch settled by a follower that never saw the first one: as in k_cum
+					const int dt = (int)__shfl(q1.x, o, RB3_TENT_BLOCK) - 1;
+					if (dt >= 0) {
+						want_first = false;
+						uint32_t zbase = 0;
+#pragma unroll
+						for (int q = 0; q < Q; ++q) { // zeros before every word of the cumulative mask INCLUDING this event
+							const uint32_t z = 32u - __popc(cumO[q * 8 + j]);
+							Zw[q * 8 + j] = zbase + oct_exscan(z, j);
+							zbase += oct_sum(z);
+						}
+						wave_sync();
+						if ((uint32_t)dt < zbase && j == 0) { // (the d_t-th survivor exists; one lane searches: a rare path)
+							int a = 0, b = NW - 1;
+							while (a < b) { const int mid = (a + b + 1) >> 1; if (Zw[mid] <= (uint32_t)dt) a = mid; else b = mid - 1; }
+							const int pmax = 32 * a + select32(~cumO[a], dt - (int)Zw[a]);
+							int pmin = 0;
+							if (dt > 0) {
+								a = 0, b = NW - 1;
+								while (a < b) { const int mid = (a + b + 1) >> 1; if (Zw[mid] <= (uint32_t)(dt - 1)) a = mid; else b = mid - 1; }
+								pmin = 32 * a + select32(~cumO[a], dt - 1 - (int)Zw[a]) + 1;
+							}
+							tab[F].del = 1 + pmin;
+							if (pmin != pmax) tab[F].child = -(base + o) - 2;
+						}
+						wave_sync();
+					}
+				}
 				cur = base + o, next = nxt;
 				if (next != cur + 1 || ++o == RB3_TENT_BLOCK) break; // the sequence leaves this block
 			}
@@ -1926,7 +1955,7 @@ __global__ void __launch_bounds__(256) k_resolve_w_x(rb3_stretch_t *tab, const u
 		if (t < nblk && q3.z != 0u && !(q3.z & RB3_FIRSTFLAG)) continue; // (a continuation block: its first id is an event stretch)
 		for (int hops = 0; hops <= maxhops; ++hops) {
 			if (d0 < 0 || d0 > 256 * Q - 1) break; // cannot be: leave it unsettled, the host redoes the phase
-			sfin[F] = d0 + 1;
+			if (!(hops == 0 && (q3.z & RB3_FIRSTFLAG) && (int)q1.y < 0)) sfin[F] = d0 + 1; // (see k_resolve_w)
 			int last = F, next = (int)q1.y - 1, dl = d0;
 			if (q3.z & RB3_FIRSTFLAG) { // the walker had events: k_cum_x left the summary (only walkers with blocks have events: F < HALF)
 				dl = d0 - popc_below_n<NW>(mx + (int64_t)F * NW, d0);
@@ -1952,9 +1981,17 @@ __global__ void __launch_bounds__(256) k_sfin_x(const rb3_stretch_t *tab, const 
 	for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; s < na; s += ((int64_t)gridDim.x * blockDim.x) >> 3) {
 		const uint32_t head = tab[s].pad[0];
 		if (head == 0u || (head & RB3_FIRSTFLAG)) continue; // a first stretch: settled by a walker or by k_resolve_w_x
-		if (tab[s].w0 >> 62 != RB3_DEP_EVENT || tab[s].del != 0) continue;
-		const int r0 = sfin[head - 1u];
-		if (r0 < 1) continue; // the walker's first unknown is not settled: neither is this one
+		if (tab[s].w0 >> 62 != RB3_DEP_EVENT) continue;
+		{ // settled by a walker that ran into it: exact, whatever the first stretch says
+			const int dl = tab[s].del;
+			if (dl != 0) { if (j == 0 && dl >= 1 && dl <= 256 * Q) sfin[s] = dl; continue; }
+		}
+		int r0 = sfin[head - 1u];
+		if (r0 < 1) { // (see k_sfin: the first unknown derived from a later stretch, valid from that stretch on)
+			const int ch = tab[head - 1u].child, dl0 = tab[head - 1u].del;
+			if (ch < -1 && dl0 >= 1 && dl0 <= 256 * Q && s >= (int64_t)(-ch - 2)) r0 = dl0;
+			else continue;
+		}
 		const int d0 = r0 - 1;
 		uint32_t below = 0;
 #pragma unroll
@@ -1990,7 +2027,7 @@ __global__ void __launch_bounds__(256) k_wj_init_x(const rb3_stretch_t *tab, con
 	else {
 		const int s = sfin[X], del = tab[X].del;
 		if (s > 0) n.val = s - 1;
-		else if (del > 0 && del <= 256 * Q) n.val = del - 1;
+		else if (del > 0 && del <= 256 * Q) n.val = del - 1, n.pad = (t < nblk && (h0 & RB3_FIRSTFLAG) && tab[X].child < -1) ? 1 : 0;
 		else {
 			const uint64_t w0 = tab[X].w0;
 			if (w0 >> 62 == RB3_DEP_LINK) {
@@ -2055,7 +2092,7 @@ __global__ void __launch_bounds__(256) k_wj_apply_x(int64_t nblk, int64_t nb, co
 {
 	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= nblk + nb) return;
-	if (nodes[t].val >= 0) sfin[wj_stretch(t, nblk)] = nodes[t].val + 1;
+	if (nodes[t].val >= 0 && nodes[t].pad == 0) sfin[wj_stretch(t, nblk)] = nodes[t].val + 1;
 }
 
 /* after the chains: rewrite tentative records (pos = lo + bit + kb), then every row must be recorded

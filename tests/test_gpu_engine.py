@@ -1341,8 +1341,8 @@ def test_index_beyond_2_32_symbols():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,nrel,div", [(401, 12, 0.002), (402, 40, 0.001), (403, 3, 0.004), (404, 25, 0.0005)])
-def test_follower_that_settles_a_later_stretch_of_a_walker(oracle, seed, nrel, div):
+@pytest.mark.parametrize("seed,nrel,div,tq", [(401, 12, 0.002, 0), (402, 40, 0.001, 0), (403, 3, 0.004, 0), (404, 25, 0.0005, 0), (405, 30, 0.001, 2), (406, 12, 0.002, 8)])
+def test_follower_that_settles_a_later_stretch_of_a_walker(oracle, seed, nrel, div, tq):
     """VERDICT r3 item 2 / DESIGN.md: an exact walker that follows a tentative one more closely than records become visible records over
     the rows of the walker's FIRST stretch and meets the first visible tentative record in a LATER one, where it leaves the settled
     unknown.  The test build makes that deterministic (rb3gpu_tune hide_first: exact walkers do not see first stretches at all), so
@@ -1358,6 +1358,8 @@ def test_follower_that_settles_a_later_stretch_of_a_walker(oracle, seed, nrel, d
     h = Rb3Gpu(verbose=1, hooks=True)
     try:
         h.tune("hide_first", 1)
+        if tq:
+            h.tune("tent_q", tq)   # (the settle kernels for masks of 256 tq bits)
         h.from_plain(cur)
         n_merges = 0
         for r in range(6):

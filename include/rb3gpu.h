@@ -110,7 +110,7 @@ typedef struct {
 	int64_t flags;               /* RB3GPU_WK_* in the low byte; flags >> 8 & 255: a walker given by text position may start that many positions
 	                                to the RIGHT of its segment (rb3h_walkers_text does: 32, the age from which a walker records), on rows its
 	                                right neighbour owns and records; flags >> 16 & 255: if not 0, the walker does not start at all when the
-	                                row that many positions further right already carries a record (it comes too late: rb3h_walkers_text, 24) */
+	                                row that many positions further right already carries a record (it comes too late: rb3h_walkers_text, RB3H_PROBE = 64) */
 } rb3gpu_walker_t;
 #define RB3GPU_KA_SENTINEL (-2)  /* ka0 of a sentinel row: the engine substitutes acc[1] of the index */
 #define RB3GPU_WK_CHECK 2        /* the rows ahead may already be recorded: check each before recording */

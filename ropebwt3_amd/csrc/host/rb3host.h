@@ -56,8 +56,8 @@ typedef void *(*rb3h_alloc_f)(int64_t min_bytes, int64_t *cap);
 typedef void (*rb3h_free_f)(void *p);
 void rb3h_seq_set_batch_allocator(rb3h_alloc_f alloc, rb3h_free_f release);
 void rb3h_batch_free(void *p);
-int rb3h_seq_error(const rb3h_seqio_t *fp);
-int64_t rb3h_strand_pairs(int64_t len, const uint8_t *text, int64_t n_seq, int64_t max_pairs, int64_t *pair_start); /* record offsets of a both-strand batch */ /* != 0: a FASTX parsing error ended the file early (code as in kseq: -2 truncated quality, ...) */
+int rb3h_seq_error(const rb3h_seqio_t *fp); /* != 0: a FASTX parsing error ended the file early (code as in kseq: -2 truncated quality, ...) */
+int64_t rb3h_strand_pairs(int64_t len, const uint8_t *text, int64_t n_seq, int64_t max_pairs, int64_t *pair_start); /* record offsets of a both-strand batch */
 void rb3h_char2nt6(int64_t l, uint8_t *s);                                 /* io.c:23-28 */
 void rb3h_revcomp6(int64_t l, uint8_t *s);                                 /* io.c:30-40 */
 

@@ -3,6 +3,7 @@
 # (tools/ubench/lfchase: random 128-byte lines + written-through stores) all the time, so that waves of k_chain start late and
 # records become visible late: does any merge leave tentative records unsettled (rank phase redone)?   tools/gpu_crowded_hunt.sh [runs] [steps]
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
+[ -x $R/tools/ubench/lfchase ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/ubench/lfchase $R/tools/ubench/lfchase.hip
 ( while true; do $R/tools/ubench/lfchase 2048 162000 2 131072 3000 1 > /dev/null 2>&1; done ) &
 HAMMER=$!
 trap "kill $HAMMER 2>/dev/null; wait $HAMMER 2>/dev/null" EXIT

@@ -5,6 +5,7 @@
 # -> gpurun_out/prof/r4_fetch_size_calibration.json
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; export TMPDIR=/tmp; P=$R/gpurun_out/prof; mkdir -p $P; cd /tmp
+[ -x $R/tools/ubench/lfchase ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/tools/ubench/lfchase $R/tools/ubench/lfchase.hip
 MB=${MB:-8192}; W=${W:-262144}; ST=${ST:-200}
 run() { # counter mode store
 	rm -rf $P/cal.$1.$2.$3

@@ -100,6 +100,7 @@ struct Tune {
 	int staged = 0;          // the three-stage merge (several host syncs) instead of the single-sync one
 	int group_rebuild = 0;   // group-sequential rebuild kernels instead of the window-parallel ones
 	int window_rebuild = 0;  // the per-window rebuild (k_pass1w) instead of the run-space rebuild per group
+	int scan_place = 1;      // the scan over the groups and the placement of their slots in one kernel (k_scan_place); 0: three scan kernels + k_place / k_place_pg + k_grp_compact
 	int part = 0;            // 1: records in text order reach pos[] by a two-pass partition (k_part_*, rb3gpu_part.h) where the batch is large; 2: always; 0 (default): by the gather
 	                         // through the suffix array -- measured on 302 M rows: scatter 2.7 ms + place 3.7 ms + streaming validation against 7.3 ms of gather: no gain, so off
 	int reb_t1_rows = 96;    // the small tier of the run-space rebuild runs first where a group receives at most this many batch rows on average
@@ -155,7 +156,7 @@ struct rb3gpu_s {
 	// (behind the grp_cap directory entries of a buffer sit grp_cap 8-byte words: the compact copy of the entries' slot words, IdxView.gsm)
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist, pslots;
+	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist, pslots, lbst;
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -170,6 +171,7 @@ struct rb3gpu_s {
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
 	rb3sort_ws *sorter = nullptr;           // scratch of rb3gpu_bwt_from_text, created on first use
+	unsigned long long lb_epoch = 0; // launches of k_scan_place so far (its look-back state is tagged with it instead of being cleared)
 	bool reb_pp_all = false; // the last rebuilds handed most groups on to the symbol path: skip the run-space tiers until most groups qualify (merge_core keeps it up to date)
 	int64_t reb_last[2] = {-1, -1}; // groups the first / the last tier of the run-space rebuild handed on in the merge before (-1: unknown)
 	const uint32_t *mg_sa = nullptr; // the suffix array of the batch being merged, if its caller has it (rb3gpu_merge_text_sa_dev): records in text order
@@ -411,6 +413,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "plane_rebuild")) t.plane_rebuild = v != 0;
 	else if (!strcmp(key, "reb_t1_rows")) t.reb_t1_rows = (int)v;
 	else if (!strcmp(key, "part")) t.part = (int)v;
+	else if (!strcmp(key, "scan_place")) t.scan_place = v != 0;
 	else if (!strcmp(key, "reb_force")) t.reb_force = v != 0;
 	else if (!strcmp(key, "resolve_v1")) t.resolve_v1 = v != 0;
 	else if (!strcmp(key, "octs")) t.octs = v < 1 ? 1 : v > 8 ? 8 : (int)v;
@@ -460,7 +463,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -544,7 +547,7 @@ static void guard_check(rb3gpu_t *h, const char *where)
 {
 	if (!h->tn.guard) return;
 	static const char *names[] = { "b2", "pos", "post", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst };
 	uint8_t g[RB3_GUARD];
 	for (int i = 0; i < 20 + 4; ++i) {
 		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
@@ -591,7 +594,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -760,13 +763,23 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	// window kernels.  A fully bit-plane index (old.dense) has nothing for it.
 	// (not where a group receives more rows than the tables of the run-space kernel take, and not where the old index is
 	// mostly bit planes -- few of its groups would qualify and every one that does not costs a hand-over)
-	uint32_t *glist[2] = {nullptr, nullptr}, *nglist = nullptr;
+	uint32_t *glist[2] = {nullptr, nullptr}, *nglist = nullptr, *gpos = nullptr;
 	uint8_t *gkind = nullptr;
 	if (runspace) {
 		if ((r = buf_ensure(h, h->gslots, (size_t)ngrp * RB3_RG_MAXSLOTS * sizeof(rb3_slot_t))) < 0) return r;
-		if ((r = buf_ensure(h, h->glist, (size_t)ngrp * 9 + 64)) < 0) return r;
-		glist[0] = (uint32_t*)h->glist.p, glist[1] = glist[0] + ngrp, gkind = (uint8_t*)(glist[1] + ngrp);
+		if ((r = buf_ensure(h, h->glist, (size_t)ngrp * 13 + 64)) < 0) return r;
+		glist[0] = (uint32_t*)h->glist.p, glist[1] = glist[0] + ngrp, gpos = glist[1] + ngrp, gkind = (uint8_t*)(gpos + ngrp);
 		nglist = (uint32_t*)((uint64_t*)h->misc.p + MISC_RG_LISTS);
+	}
+	// scan + placement + compact directory copy in ONE kernel (k_scan_place) where the slots come from the scratch arrays of the group kernels
+	const bool fused = planes && nosync && h->tn.scan_place && h->misc.p != nullptr;
+	const int64_t sp_nblk = (ngrp + RB3_SP_GROUPS - 1) / RB3_SP_GROUPS;
+	if (fused) {
+		const size_t need = (size_t)sp_nblk * 16 * 8 + 64;
+		if (h->lbst.cap < need || !h->lbst.p) {
+			if ((r = buf_ensure(h, h->lbst, need)) < 0) return r;
+			HIPCHK(hipMemsetAsync(h->lbst.p, 0, h->lbst.cap, h->st)); // (state words: no launch has the epoch 0)
+		}
 	}
 	if (nosync) { // before any launch: hipMalloc may synchronise
 		// the number of slots is only known after the scan: one per window is the upper bound; where the index is run-coded an
@@ -819,7 +832,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			const unsigned gl = (unsigned)(lw < 4096 ? lw : 4096);
 			if (planes)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_plane_group<true>), dim3((unsigned)(lw < 8192 ? lw : 8192)), dim3(256), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, nwin, ngrp,
-						gstat, (uint4*)h->pslots.p, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, (unsigned long long*)h->misc.p + MISC_RG_OVER, (unsigned long long*)nullptr);
+						gstat, (uint4*)h->pslots.p, skip, (const uint32_t*)glist[1], (const uint32_t*)(nglist + 1), (uint32_t)lcap, (unsigned long long*)h->misc.p + MISC_RG_OVER, (unsigned long long*)nullptr, gpos);
 			else {
 			if (n2 * RB3_WIN > 3 * ntot)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1w<FROM_PLAIN, 7, true>), dim3(gw), dim3(64 * RB3_REB_WAVES), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg,
@@ -853,6 +866,17 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 			hipLaunchKernelGGL(k_group_rows, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->st, d_pos, n2, jg, ngrp, skip);
 		}
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass1<FROM_PLAIN>), dim3((unsigned)ngrp), dim3(64), 0, h->st, old, d_pos, d_b2, n2, ntot, (const int64_t*)jg, gstat, ngrp, skip);
+	}
+	if (fused) {
+		Acc7 ao;
+		for (int a = 0; a < 7; ++a) ao.a[a] = h->acc[a];
+		uint8_t *lbp = (uint8_t*)h->lbst.p;
+		hipLaunchKernelGGL(k_scan_place, dim3((unsigned)sp_nblk), dim3(RB3_SP_THREADS), 0, h->st, (const uint32_t*)gstat, ngrp, ntot, (const uint8_t*)(runspace ? gkind : nullptr), (const uint4*)h->gslots.p, (const uint4*)h->pslots.p,
+				(const uint32_t*)(runspace ? gpos : nullptr), h->ib[dst].grp, (uint64_t*)(h->ib[dst].grp + h->ib[dst].grp_cap), (uint4*)h->ib[dst].slots, (unsigned long long*)dtot,
+				(unsigned long long*)(lbp + 64), (unsigned int*)lbp /* the block counter sits in FRONT of the look-back state: a fixed address, zero between launches */, (++h->lb_epoch, (h->lb_epoch & 0xFFFFFull) ? h->lb_epoch : ++h->lb_epoch), ao, (const uint64_t*)((uint64_t*)h->misc.p + MISC_LF_TOT), skip,
+				runspace ? (const uint32_t*)(nglist + 1) : (const uint32_t*)nullptr, (uint32_t)lcap, slot_cap, h->tn.abs_limit);
+		*ongrp = ngrp;
+		return 0;
 	}
 	uint64_t total[8];
 	if ((r = scan_records(h, gstat, ngrp, gpre, dtot, nosync ? nullptr : total)) < 0) return r;

@@ -67,7 +67,7 @@ __device__ __forceinline__ void pdep3(uint32_t &x0, uint32_t &x1, uint32_t &x2, 
  * stat[0] += groups the run-space rebuild could have taken (no bit-plane slot and at most 13 slots in the old range, at most 8 new slots). */
 template<bool LISTED>
 __global__ void __launch_bounds__(256) k_plane_group(IdxView old, const int64_t *pos, const uint8_t *b2, int64_t n2, int64_t ntot, const int64_t *jw, int64_t nwin, int64_t ngrp,
-		uint32_t *gstat, uint4 *pslots, const unsigned long long *skip, const uint32_t *glist, const uint32_t *nglist, uint32_t lcap, unsigned long long *lover, unsigned long long *stat)
+		uint32_t *gstat, uint4 *pslots, const unsigned long long *skip, const uint32_t *glist, const uint32_t *nglist, uint32_t lcap, unsigned long long *lover, unsigned long long *stat, uint32_t *gpos = nullptr)
 {
 	__shared__ PgLds L;
 	if (RB3_REB_SKIP(skip)) return;
@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256) k_plane_group(IdxView old, const int64_t 
 	__syncthreads();
 	for (int64_t u = blockIdx.x; u < nunits; u += gridDim.x) {
 		const int64_t g = LISTED ? (int64_t)glist[u] : u;
+		if (LISTED && gpos != nullptr && t == 0) gpos[g] = (uint32_t)u; // (where k_scan_place finds this group's slots)
 		const int64_t P0 = g << RB3_GRP_BITS, wbase = g * RB3_GRP_WINS;
 		const int64_t wend = wbase + RB3_GRP_WINS < nwin ? wbase + RB3_GRP_WINS : nwin;
 		const int nvw = (int)(wend - wbase); // windows of the group that exist
@@ -329,6 +330,160 @@ __global__ void __launch_bounds__(256) k_place_pg(const uint32_t *gstat, const u
 			uint4 v = pslots[((int64_t)u * RB3_GRP_WINS + si) * 8 + j];
 			v.x += add;
 			slot16[(slot0 + si) * 8 + j] = v;
+		}
+	}
+}
+
+/* ----------------------------------------------------------------------------------------- */
+/* the scan over the groups and the placement of their slots, in ONE kernel                     */
+/* ----------------------------------------------------------------------------------------- */
+
+/* Rounds 1-3 ran three scan kernels over the per-group records (gstat: six symbol counts + slot count), then k_place /
+ * k_place_pg copied every slot from the scratch to its final position (fixing the headers on the way), then k_grp_compact
+ * copied the directory's slot words: six launches, ~80 us per round of a 1.3 G-symbol build.  Here a block takes 256 groups:
+ * exclusive scan of their records inside the block, the block's totals published, the totals of the blocks before it fetched
+ * by a decoupled look-back (Merrill & Garland), and then the same lanes place the slots of those 256 groups -- 8 lanes per
+ * group -- and write directory entry and compact slot word.  One launch; gstat is read once and the prefix never leaves the chip.
+ *
+ * lb: look-back state, 16 x u64 per block: [0..6] the block's totals, [8..14] its inclusive prefix, every word tagged with the
+ * launch's epoch (never 0) in its upper 20 bits: the tag stands in for clearing and for memory ordering (see below).
+ * C[] of the new index is known before the scan: acc of the old index + the batch's symbol counts (tot2, from the LF histogram). */
+#define RB3_SP_GROUPS 256   /* groups per block (scanned by as many threads) */
+#define RB3_SP_THREADS 1024 /* threads per block (all of them place slots) */
+struct SpLds {
+	unsigned long long pre[8][RB3_SP_GROUPS]; // exclusive prefix of every group of the block (columns 0..5 symbols, 6 slots)
+	uint32_t ns[RB3_SP_GROUPS], mask[RB3_SP_GROUPS];
+	uint32_t wtot[4][8];
+	unsigned long long bpre[8];
+	uint32_t bid;
+};
+
+__global__ void __launch_bounds__(RB3_SP_THREADS) k_scan_place(const uint32_t *gstat, int64_t ngrp, int64_t ntot, const uint8_t *gkind, const uint4 *gslots, const uint4 *pslots, const uint32_t *gpos,
+		rb3_grp_t *grp, uint64_t *gsm, uint4 *slot16, unsigned long long *dtot, unsigned long long *lb, unsigned int *ticket, unsigned long long epoch,
+		Acc7 acc_old, const uint64_t *tot2, const unsigned long long *skip, const uint32_t *nglist, uint32_t lcap, uint64_t slot_cap, int64_t abs_lim)
+{
+	__shared__ SpLds L;
+	if (RB3_REB_SKIP(skip)) return;
+	if (nglist != nullptr && *nglist > lcap) return; // (the hand-over list did not fit its scratch: the host emits the rebuild again)
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const int64_t nblk = (ngrp + RB3_SP_GROUPS - 1) / RB3_SP_GROUPS;
+	if (t == 0) {
+		const unsigned int b = atomicAdd(ticket, 1u); // blocks take their numbers in the order they start: whoever a block waits for is running or done
+		if ((int64_t)b + 1 == nblk) *ticket = 0u;     // (the last number of this launch: the next launch starts from 0 again)
+		L.bid = b;
+	}
+	__syncthreads();
+	const int64_t bid = L.bid;
+	if (bid >= nblk) return;
+	// ---- the records of this block's groups and their scan: the first RB3_SP_GROUPS threads, a group each ----
+	uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, inc[7] = {0, 0, 0, 0, 0, 0, 0};
+	const int64_t g = bid * RB3_SP_GROUPS + t;
+	if (t < RB3_SP_GROUPS) {
+		if (g < ngrp) {
+			const uint4 a = ((const uint4*)gstat)[g * 2], b = ((const uint4*)gstat)[g * 2 + 1];
+			v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+		}
+#pragma unroll
+		for (int c = 0; c < 7; ++c) inc[c] = wave_incl_scan(v[c]);
+		if (lane == 63) {
+#pragma unroll
+			for (int c = 0; c < 7; ++c) L.wtot[wv][c] = inc[c];
+		}
+		L.ns[t] = v[6], L.mask[t] = v[7];
+	}
+	__syncthreads();
+	uint32_t wbase[7], btot[7];
+#pragma unroll
+	for (int c = 0; c < 7; ++c) {
+		wbase[c] = 0, btot[c] = 0;
+		for (int w = 0; w < RB3_SP_GROUPS / 64; ++w) { const uint32_t x = L.wtot[w][c]; btot[c] += x; if (w < wv) wbase[c] += x; }
+	}
+	// ---- publish the block's totals, fetch the prefix of the blocks before it ----
+	// Every published word carries the launch's tag in its upper 20 bits (value: 44 bits), is written with a relaxed agent-scope atomic
+	// (written through) and read with one: no release fence -- on this chip a release at agent scope writes the XCD's whole L2 back, and
+	// the L2 is full of the slots the neighbouring blocks are placing (measured: the kernel took 180 us with fences) -- and no ordering
+	// between the words is needed, because a reader waits for the tag of EVERY word it uses.
+	unsigned long long *my = lb + bid * 16; // [0..6] totals of the block, [8..14] inclusive prefix
+	const unsigned long long tag = (epoch & 0xFFFFFull) << 44, vmask = (1ull << 44) - 1ull;
+	if (t < 7) __hip_atomic_store(&my[t], tag | (unsigned long long)btot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (t < 64) { // the look-back, 64 blocks per step (a lane each)
+		unsigned long long p[7] = {0, 0, 0, 0, 0, 0, 0};
+		for (int64_t base = bid - 1; base >= 0; base -= 64) {
+			const int64_t q = base - lane;
+			const bool valid = q >= 0;
+			const unsigned long long *o = lb + (valid ? q : 0) * 16;
+			unsigned long long xi = 0, xa = 0;
+			bool isinc = false;
+			if (valid)
+				for (;;) { // column 6 of the inclusive prefix, else of the totals: whichever is there
+					xi = __hip_atomic_load(&o[14], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((xi & ~vmask) == tag) { isinc = true; break; }
+					xa = __hip_atomic_load(&o[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((xa & ~vmask) == tag) break;
+				}
+			const unsigned long long im = __ballot(isinc);
+			const int first = im ? __ffsll((unsigned long long)im) - 1 : 64; // the nearest block that already knows its inclusive prefix
+#pragma unroll
+			for (int c = 0; c < 7; ++c) {
+				unsigned long long x = 0;
+				if (valid && lane <= first) { // (lanes before `first`: totals; lane `first`: the inclusive prefix)
+					const unsigned long long *w = &o[(lane == first ? 8 : 0) + c];
+					do { x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((x & ~vmask) != tag);
+					x &= vmask;
+				}
+				// (sums of 64 totals stay below 2^32; the inclusive prefix needs both halves)
+				const uint32_t lo = wave_read(wave_incl_scan((uint32_t)(lane < first ? x : 0ull)), 63);
+				p[c] += lo;
+				if (first < 64) p[c] += (unsigned long long)wave_read((uint32_t)x, first) | (unsigned long long)wave_read((uint32_t)(x >> 32), first) << 32;
+			}
+			if (first < 64) break;
+		}
+		if (t == 0) {
+#pragma unroll
+			for (int c = 0; c < 7; ++c) {
+				L.bpre[c] = p[c];
+				__hip_atomic_store(&my[8 + c], tag | ((p[c] + btot[c]) & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (bid + 1 == nblk) { // the totals of the new index, for the host
+#pragma unroll
+				for (int c = 0; c < 7; ++c) dtot[c] = p[c] + btot[c];
+				dtot[7] = 0ull;
+			}
+		}
+	}
+	__syncthreads();
+	if (t < RB3_SP_GROUPS) {
+#pragma unroll
+		for (int c = 0; c < 7; ++c) L.pre[c][t] = L.bpre[c] + wbase[c] + (inc[c] - v[c]);
+	}
+	__syncthreads();
+	// ---- placement: 8 lanes per group, all threads of the block; the slots of a group are asked for eight at a time ----
+	const int j = t & 7;
+	uint64_t cb = (uint64_t)acc_old.a[j < 6 ? j : 0]; // C[j] of the merged BWT (lanes 0..5): the old index's plus the batch symbols below j
+	for (int a = 0; a < j && a < 6; ++a) cb += tot2[a];
+	for (int k = t >> 3; k < RB3_SP_GROUPS; k += RB3_SP_THREADS / 8) {
+		const int64_t gg = bid * RB3_SP_GROUPS + k;
+		if (gg >= ngrp) break;
+		const uint32_t ns = L.ns[k] < (uint32_t)RB3_GRP_WINS ? L.ns[k] : (uint32_t)RB3_GRP_WINS, mask = L.mask[k];
+		const uint64_t slot0 = L.pre[6][k];
+		const uint64_t gp = j < 6 ? L.pre[j][k] : 0ull;
+		((uint64_t*)grp)[gg * 8 + j] = j < 6 ? cb + gp : j == 6 ? (uint64_t)(uint32_t)slot0 | (uint64_t)mask << 32 : 0ull;
+		if (j == 6) gsm[gg] = (uint64_t)(uint32_t)slot0 | (uint64_t)mask << 32;
+		const uint32_t below = (uint32_t)__shfl((int)(uint32_t)(cb + gp), (j + 7) & 7, 8); // header lane j holds symbol j - 1, whose base sits in lane j - 1
+		const uint32_t add = (RB3_ABS_HEADERS(ntot, abs_lim) && j >= 1 && j <= 6) ? below : 0u;
+		if (slot0 + ns > slot_cap) continue; // (the slot array was sized by an estimate: the host sees the total and emits again)
+		const bool fromp = gkind == nullptr || gkind[gg] != 0;
+		const uint4 *src = fromp ? pslots + (int64_t)(gpos ? gpos[gg] : (uint32_t)gg) * RB3_GRP_WINS * 8 : gslots + gg * RB3_RG_MAXSLOTS * 8;
+		for (uint32_t s0 = 0; s0 < ns; s0 += 8) {
+			uint4 x[8];
+#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) if (s0 + q < ns) x[q] = src[(s0 + q) * 8 + j];
+#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q)
+				if (s0 + q < ns) {
+					x[q].x += add;
+					slot16[(slot0 + s0 + q) * 8 + j] = x[q];
+				}
 		}
 	}
 }

@@ -83,11 +83,24 @@ __device__ __forceinline__ uint32_t oct_bcast0(uint32_t v, int j)
 /* exclusive prefix sum over the 8 lanes of an octet */
 __device__ __forceinline__ uint32_t oct_exscan(uint32_t v, int j)
 {
-	uint32_t inc = v, t;
-	t = dpp_mov<0x111>(inc); if (j >= 1) inc += t; // row_shr:1
-	t = dpp_mov<0x112>(inc); if (j >= 2) inc += t; // row_shr:2
-	t = dpp_mov<0x114>(inc); if (j >= 4) inc += t; // row_shr:4
-	return inc - v;
+	// an inclusive scan over the ROW of 16 lanes (two octets) with four DPP adds -- lanes shifted in from outside the row add 0 --,
+	// then the lower octet's total (lane 7 of the row) comes off the lanes of the upper one: 6 instructions where a step that
+	// keeps to its octet (move, select, add) makes 9
+	(void)j;
+	uint32_t s = v;
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x111, 0xf, 0xf, false); // row_shr:1
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x112, 0xf, 0xf, false); // row_shr:2
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xf, false); // row_shr:4
+	s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xf, false); // row_shr:8
+	s -= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x157, 0xf, 0xc, false); // row_newbcast:7 into lanes 8..15 (banks 2 and 3)
+	return s - v;
+}
+
+/* the value of lane `l` (0..7) of the octet, l different from octet to octet: the LDS crossbar (ds_bpermute), not a vector instruction */
+__device__ __forceinline__ uint32_t oct_pick(uint32_t v, int l)
+{
+	const int lane = (int)(threadIdx.x & 63u);
+	return (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~7) + l) << 2, (int)v);
 }
 
 /* the same three for a group of LPW lanes per query: an octet (8) or a QUAD (4 lanes, 16 queries per wave: k_chain's
@@ -126,6 +139,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
 	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
 	return v;
+}
+
+/* true in every active lane?  (the lane mask of the comparison against EXEC: __all() goes through an integer per lane -- two more vector instructions) */
+__device__ __forceinline__ bool wave_all(bool p)
+{
+	return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true);
 }
 
 /* the value of one given lane (the same for the whole wave) through a scalar register */
@@ -222,6 +241,22 @@ __device__ __forceinline__ uint32_t pk_sum16(uint32_t v, uint32_t add) // add + 
 	return __builtin_amdgcn_udot2(__builtin_bit_cast(rb3_u16x2, v), __builtin_bit_cast(rb3_u16x2, 0x00010001u), add, false);
 }
 
+/* packed unsigned 16-bit helpers of the run-slot decode (offsets and run lengths inside a slot are < 2^15):
+ * pk_subsat: a > b ? a - b : 0 per half (v_pk_sub_u16 clamp -- subtraction and the clamp at 0 in one instruction);
+ * pk_dot: add + a.lo * b.lo + a.hi * b.hi (v_dot2_u32_u16 -- with b in {0, 1} per half: mask and sum in one instruction) */
+__device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(rb3_u16x2, a), __builtin_bit_cast(rb3_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_minu(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(rb3_u16x2, a), __builtin_bit_cast(rb3_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_dot(uint32_t a, uint32_t b, uint32_t add)
+{
+	return __builtin_amdgcn_udot2(__builtin_bit_cast(rb3_u16x2, a), __builtin_bit_cast(rb3_u16x2, b), add, false);
+}
+
 template<bool TWO, bool MATCH, int LPW = 8>
 __device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b, uint32_t *match_a)
 {
@@ -237,31 +272,28 @@ __device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2
 	}
 	uint32_t base = grp_exscan<LPW>(tot, j);
 	const uint32_t csplat = (uint32_t)c * 0x00010001u;
-	const rb3_s16x2 oa = as_s16x2((uint32_t)off_a * 0x00010001u), ob = as_s16x2((uint32_t)off_b * 0x00010001u), zero = as_s16x2(0u), one = as_s16x2(0x00010001u);
-	rb3_s16x2 acc_a = zero, acc_b = zero;
+	// (offsets are unsigned here: 0 <= off <= the slot's symbols; every start offset and run length is below 2^15)
+	const uint32_t ua = (uint32_t)off_a * 0x00010001u, ub = (uint32_t)off_b * 0x00010001u;
+	uint32_t acc_a = 0, acc_b = 0;
 	uint32_t mt = 0;
 #pragma unroll
 	for (int k = 0; k < NW; ++k) {
-		const rb3_s16x2 P = as_s16x2(base * 0x00010001u + (lw[k] << 16)); // start offsets: (base, base + len of the first code)
-		const rb3_s16x2 Lk = as_s16x2(lw[k]);
-		// 0xFFFF in the halves whose symbol is c: x in 0..7 per half, x - 1 is negative iff x == 0
-		const uint32_t eq = as_u32((as_s16x2((w[k] & 0x00070007u) ^ csplat) - one) >> 15);
-		const rb3_s16x2 ta = oa - P;
-		rb3_s16x2 d = __builtin_elementwise_min(__builtin_elementwise_max(ta, zero), Lk);
-		acc_a += as_s16x2(as_u32(d) & eq);
+		const uint32_t P = base * 0x00010001u + (lw[k] << 16); // start offsets: (base, base + len of the first code)
+		// 1 in the halves whose symbol is c: x in 0..7 per half, 1 -sat- x is 1 iff x == 0
+		const uint32_t eq1 = pk_subsat(0x00010001u, (w[k] & 0x00070007u) ^ csplat);
+		// symbols of each run below the offset: min(max(off - start, 0), length); those of the runs of c summed by the dot product
+		acc_a = pk_dot(pk_minu(pk_subsat(ua, P), lw[k]), eq1, acc_a);
 		if (MATCH) { // the code that holds offset off_a itself: 0 <= off_a - start < length, i.e. clamping to [0, length - 1] changes nothing
+			const rb3_s16x2 ta = as_s16x2(ua) - as_s16x2(P), Lk = as_s16x2(lw[k]), zero = as_s16x2(0u), one = as_s16x2(0x00010001u);
 			const uint32_t y = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(ta, zero), Lk - one)) ^ as_u32(ta);
 			const uint32_t nz = ((y | ((y & 0x7FFF7FFFu) + 0x7FFF7FFFu)) >> 15) & 0x00010001u; // 1 in the halves where y != 0
-			mt |= (nz ^ 0x00010001u) & (eq & 0x00010001u);
+			mt |= (nz ^ 0x00010001u) & eq1;
 		}
-		if (TWO) {
-			d = __builtin_elementwise_min(__builtin_elementwise_max(ob - P, zero), Lk);
-			acc_b += as_s16x2(as_u32(d) & eq);
-		}
+		if (TWO) acc_b = pk_dot(pk_minu(pk_subsat(ub, P), lw[k]), eq1, acc_b);
 		base = pk_sum16(lw[k], base);
 	}
-	*cnt_a = pk_sum16(as_u32(acc_a), 0u);
-	if (TWO) *cnt_b = pk_sum16(as_u32(acc_b), 0u);
+	*cnt_a = acc_a;
+	if (TWO) *cnt_b = acc_b;
 	if (MATCH) *match_a = mt;
 }
 
@@ -285,18 +317,17 @@ __device__ __forceinline__ void slice_count_pk2(const uint4 &sa, const uint4 &sa
 	const uint32_t base2 = grp_exscan<LPW>(ta | tb << 16, j); // (a slot covers at most 8192 symbols + 48 unused codes: no carry between the fields)
 	uint32_t base_a = base2 & 0xFFFFu, base_b = base2 >> 16;
 	const uint32_t csplat = (uint32_t)c * 0x00010001u;
-	const rb3_s16x2 oa = as_s16x2((uint32_t)off_a * 0x00010001u), ob = as_s16x2((uint32_t)off_b * 0x00010001u), zero = as_s16x2(0u), one = as_s16x2(0x00010001u);
-	rb3_s16x2 acc_a = zero, acc_b = zero;
+	const uint32_t ua = (uint32_t)off_a * 0x00010001u, ub = (uint32_t)off_b * 0x00010001u; // (unsigned offsets: see slice_count_pk)
+	uint32_t acc_a = 0, acc_b = 0;
 #pragma unroll
 	for (int k = 0; k < NW; ++k) {
-		const rb3_s16x2 Pa = as_s16x2(base_a * 0x00010001u + (la[k] << 16)), Pb = as_s16x2(base_b * 0x00010001u + (lb[k] << 16));
-		const uint32_t eqa = as_u32((as_s16x2((wa[k] & 0x00070007u) ^ csplat) - one) >> 15), eqb = as_u32((as_s16x2((wb[k] & 0x00070007u) ^ csplat) - one) >> 15);
-		const rb3_s16x2 da = __builtin_elementwise_min(__builtin_elementwise_max(oa - Pa, zero), as_s16x2(la[k]));
-		const rb3_s16x2 db = __builtin_elementwise_min(__builtin_elementwise_max(ob - Pb, zero), as_s16x2(lb[k]));
-		acc_a += as_s16x2(as_u32(da) & eqa), acc_b += as_s16x2(as_u32(db) & eqb);
+		const uint32_t Pa = base_a * 0x00010001u + (la[k] << 16), Pb = base_b * 0x00010001u + (lb[k] << 16);
+		const uint32_t eqa = pk_subsat(0x00010001u, (wa[k] & 0x00070007u) ^ csplat), eqb = pk_subsat(0x00010001u, (wb[k] & 0x00070007u) ^ csplat);
+		acc_a = pk_dot(pk_minu(pk_subsat(ua, Pa), la[k]), eqa, acc_a);
+		acc_b = pk_dot(pk_minu(pk_subsat(ub, Pb), lb[k]), eqb, acc_b);
 		base_a = pk_sum16(la[k], base_a), base_b = pk_sum16(lb[k], base_b);
 	}
-	*cnt_a = pk_sum16(as_u32(acc_a), 0u), *cnt_b = pk_sum16(as_u32(acc_b), 0u);
+	*cnt_a = acc_a, *cnt_b = acc_b;
 }
 
 /* number of symbols equal to c among the first `off` symbols of the slot, this lane's share;
@@ -689,6 +720,14 @@ __device__ __forceinline__ uint32_t octc_hdr_c(const RankLoadC &r, int c, int j)
 	return 2 * j == c + 1 ? r.sl.x : 2 * j + 1 == c + 1 ? r.sl2.x : 0u;
 }
 
+/* the count of symbol c in the slot's header (word 0 of slice c + 1), in every lane of the group */
+template<int LPW>
+__device__ __forceinline__ uint32_t octc_hdr_pick(const RankLoadC &r, int c, int j)
+{
+	if (LPW == 8) return oct_pick(r.sl.x, c + 1);
+	return grp_sum<LPW>(octc_hdr_c<LPW>(r, c, j));
+}
+
 /* both ends of an interval that lies inside ONE run slot, from one decode */
 template<int LPW = 8>
 __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, uint32_t koff_hi, uint32_t hdr0, int c, int j, int64_t *lo_n, int64_t *hi_n)
@@ -699,7 +738,7 @@ __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, uint32_t k
 	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, (int)rl.koff - base, (int)koff_hi - base, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16; // both fit 16 bits (counts inside a slot of at most 8192 symbols)
 	v = grp_sum<LPW>(v);
-	const uint64_t hb = rl.gc + grp_sum<LPW>(octc_hdr_c<LPW>(rl, c, j)); // (the header may be the whole LF base: 32 bits)
+	const uint64_t hb = rl.gc + octc_hdr_pick<LPW>(rl, c, j); // (the header may be the whole LF base: 32 bits)
 	*lo_n = (int64_t)(hb + (v & 0xFFFFu)), *hi_n = (int64_t)(hb + (v >> 16));
 }
 
@@ -708,10 +747,10 @@ template<int LPW = 8>
 __device__ __forceinline__ void octc_finish_pair_at(const RankLoadC &rl, int off_lo, int off_hi, int c, int j, int64_t *lo_n, int64_t *hi_n)
 {
 	uint32_t ca, cb, mt;
+	const uint64_t hb = rl.gc + octc_hdr_pick<LPW>(rl, c, j); // (the header may be the whole LF base: 32 bits; asked for first: it crosses the lanes while the codes are counted)
 	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16;
 	v = grp_sum<LPW>(v);
-	const uint64_t hb = rl.gc + grp_sum<LPW>(octc_hdr_c<LPW>(rl, c, j)); // (the header may be the whole LF base: 32 bits)
 	*lo_n = (int64_t)(hb + (v & 0xFFFFu)), *hi_n = (int64_t)(hb + (v >> 16));
 }
 
@@ -1106,12 +1145,18 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				// state the whole wave takes the general step, which handles everything.
 				const uint32_t cq = (uint32_t)x & 7u;
 				const uint64_t kq = I32 ? (uint64_t)((uint32_t)hi - (uint32_t)lo) : (uint64_t)(hi - lo);
-				const bool opening = gap != 0 && sid == -1 && age >= RB3_TENT_MIN_AGE && kq <= (uint64_t)kmax;
 				const uint32_t kq32 = kq > 0xFFFFull ? 0xFFFFu : (uint32_t)kq;
-				// (an interval that reaches into the next GROUP needs a second directory entry: the general step)
-				const bool simple = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) && cq != 0u && (int32_t)(rc >> 32) < 0 && !opening && ((uint32_t)lo & (RB3_GRP - 1)) + kq32 <= (uint32_t)RB3_GRP
-					&& kq32 <= (uint32_t)kmax; // (a wider interval -- a walker in its first dozen steps -- may end several slots further on)
-				if (__all(simple)) {
+				// simple: inside its own segment, not at a sentinel, the row unvisited, no stretch to open (a walker that is inexact, without a stretch, old
+				// enough -- and narrow enough, which the last test asks of everybody: a wider interval, a walker in its first dozen steps, may end several
+				// slots further on), and the interval inside one GROUP (one that reaches into the next needs a second directory entry: the general step).
+				// Every test is a comparison whose lane mask is combined on the scalar unit (a bool per lane that is an AND of comparisons costs two
+				// more vector instructions before it can be voted on).
+#define RB3_BAL(x) __builtin_amdgcn_ballot_w64(x)
+				const unsigned long long exm = RB3_BAL(true);
+				const unsigned long long m_simple = RB3_BAL((uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1)) & RB3_BAL(cq != 0u) & RB3_BAL((int32_t)(rc >> 32) < 0)
+					& ~(RB3_BAL(gap != 0) & RB3_BAL(sid == -1) & RB3_BAL(age >= RB3_TENT_MIN_AGE))
+					& RB3_BAL(((uint32_t)lo & (RB3_GRP - 1)) + kq32 <= (uint32_t)RB3_GRP) & RB3_BAL(kq32 <= (uint32_t)kmax);
+				if (m_simple == exm) {
 #ifdef RB3_PROF_STEP /* kernel experiment: where does an iteration of the common step spend its cycles?  (s_memtime at four points) */
 					const uint64_t pt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1137,30 +1182,35 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					// where the slot starts and ends and what kind it is follow from the mask alone (a slot of more than one window is
 					// a run slot, a single window is bit planes), and so does whether the upper end of the interval lies in it too or
 					// in the slot behind it (same group: see `simple`); an exact walker is the empty interval [lo, lo)
-					const uint32_t w0 = 31u - (uint32_t)__clz((int)mlo);
-					const uint32_t above = (mask >> w0) >> 1;
-					uint32_t wend = w0 + 1u + (above ? (uint32_t)__builtin_ctz(above) : 31u - w0);
-					if (I32 ? ((uint32_t)lo >> RB3_GRP_BITS) == ((uint32_t)b1.n >> RB3_GRP_BITS) : g == (b1.n >> RB3_GRP_BITS)) { const uint32_t nvw = (uint32_t)(b1.n >> RB3_WIN_BITS & 31) + 1u; wend = wend < nvw ? wend : nvw; } // (the last group ends with the window of position n)
+					const uint32_t w0 = 31u - (uint32_t)__builtin_clz(mlo); // (mlo != 0: bit 0)
+					// the slot ends where the next one starts -- the lowest mask bit above lo's window --, at the end of the group or, in
+					// the last group, with the window of position n
+					const uint32_t abv = mask & ~((2u << lw) - 1u);
+					const uint32_t nxt = abv ? (uint32_t)__builtin_ctz(abv) : 32u;
+					const bool lastg = I32 ? ((uint32_t)lo >> RB3_GRP_BITS) == ((uint32_t)b1.n >> RB3_GRP_BITS) : g == (b1.n >> RB3_GRP_BITS);
+					const uint32_t glim = lastg ? (uint32_t)(b1.n >> RB3_WIN_BITS & 31) + 1u : 32u;
+					const uint32_t wend = nxt < glim ? nxt : glim;
 					const bool rle = wend - w0 > 1u;
 					const int off_lo = (int)(rl.koff - (w0 << RB3_WIN_BITS)), off_hi = off_lo + (int)kq32;
 					const bool same = rl.koff + kq32 <= (wend << RB3_WIN_BITS);
+					const unsigned long long m_pair = RB3_BAL(wend - w0 > 1u) & RB3_BAL(rl.koff + kq32 <= (wend << RB3_WIN_BITS)); // (rle && same: voted on here, where the comparisons are made)
 					const bool far = !same && kq32 > 255u; // (wide masks: an interval of more than 255 rows may end beyond the NEXT slot too: the general decode)
-					uint4 slb = make_uint4(0u, 0u, 0u, 0u), slb2 = make_uint4(0u, 0u, 0u, 0u);
+					// the slot in which the interval ENDS, asked for at the same time: the next one, or the same one again (a second request for a line
+					// that is on its way costs a tag look-up; a load only some lanes make costs a branch region, copies and a wait of its own)
+					uint4 slb, slb2 = make_uint4(0u, 0u, 0u, 0u);
 					if (LPW == 8) rl.sl2 = make_uint4(0u, 0u, 0u, 0u);
 					if (I32) { // (fewer than 2^24 slots: the byte offset fits 32 bits)
 						const uint32_t so = rl.sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * (LPW == 8 ? 16u : 32u);
+						const uint32_t sob = so + (same ? 0u : (uint32_t)sizeof(rb3_slot_t));
 						rl.sl = *(const uint4*)((const char*)b1.slot16 + so);
+						slb = *(const uint4*)((const char*)b1.slot16 + sob);
 						if (LPW == 4) rl.sl2 = *(const uint4*)((const char*)b1.slot16 + (so + 16u));
-						if (!same) {
-							slb = *(const uint4*)((const char*)b1.slot16 + (so + (uint32_t)sizeof(rb3_slot_t)));
-							if (LPW == 4) slb2 = *(const uint4*)((const char*)b1.slot16 + (so + (uint32_t)sizeof(rb3_slot_t) + 16u));
-						}
+						if (LPW == 4) slb2 = *(const uint4*)((const char*)b1.slot16 + (sob + 16u));
 					} else {
 						octc_load_slot<LPW>(b1, (int64_t)rl.sidx, j, rl);
-						if (!same) { // the upper end lies in the next slot: asked for at the same time
-							if (LPW == 8) slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + j];
-							else slb = b1.slot16[((int64_t)rl.sidx + 1) * 8 + 2 * j], slb2 = b1.slot16[((int64_t)rl.sidx + 1) * 8 + 2 * j + 1];
-						}
+						const int64_t sb = (int64_t)rl.sidx + (same ? 0 : 1);
+						if (LPW == 8) slb = b1.slot16[sb * 8 + j];
+						else slb = b1.slot16[sb * 8 + 2 * j], slb2 = b1.slot16[sb * 8 + 2 * j + 1];
 					}
 #ifdef RB3_PROF_STEP
 					asm volatile("s_nop 0" :: "v"(rl.sidx));
@@ -1180,21 +1230,18 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					const uint64_t pt2 = __builtin_amdgcn_s_memtime(); // the slot has arrived
 #endif
 					int64_t lo_n, hi_n;
-					if (same) slb = rl.sl, slb2 = rl.sl2;
-					const bool rleb = same ? rle : (grp_bcast0<LPW>(slb.x, j) & RB3_SLOT_RLE) != 0u;
 #ifdef RB3_PROF_STEP
 					if (__ballot(!(rle && same)) != 0ull) prof_t[5] += 1;
-					if (__ballot(!(rle && rleb)) != 0ull) prof_t[6] += 1;
 #endif
-					if (__all(rle && same)) octc_finish_pair_at<LPW>(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
-					else if (__all(rle && rleb && !far)) { // some walker's interval straddles two run slots: everybody through the two-slot decode
+					if (m_pair == exm) octc_finish_pair_at<LPW>(rl, off_lo, off_hi, c, j, &lo_n, &hi_n); // (rle && same, everybody)
+					else if (wave_all(rle && (grp_bcast0<LPW>(slb.x, j) & RB3_SLOT_RLE) != 0u && !far)) { // some walker's interval straddles two run slots: everybody through the two-slot decode
 						uint32_t ca, cb;
 						slice_count_pk2<LPW>(rl.sl, rl.sl2, slb, slb2, off_lo, same ? off_hi : off_hi - (int)((wend - w0) << RB3_WIN_BITS), c, j, &ca, &cb);
 						uint32_t v = ca | cb << 16;
 						v = grp_sum<LPW>(v);
 						RankLoadC rb2;
 						rb2.sl = slb, rb2.sl2 = slb2;
-						const uint32_t hl = grp_sum<LPW>(octc_hdr_c<LPW>(rl, c, j)), hh = grp_sum<LPW>(octc_hdr_c<LPW>(rb2, c, j)); // (headers of 32 bits where they carry the LF base)
+						const uint32_t hl = octc_hdr_pick<LPW>(rl, c, j), hh = octc_hdr_pick<LPW>(rb2, c, j); // (headers of 32 bits where they carry the LF base)
 						lo_n = (int64_t)(rl.gc + hl + (v & 0xFFFFu)), hi_n = (int64_t)(rl.gc + hh + (v >> 16));
 					} else if (rle && same) octc_finish_pair_at<LPW>(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
 					else { // a bit-plane slot somewhere

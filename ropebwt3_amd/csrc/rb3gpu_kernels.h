@@ -962,7 +962,7 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 		// which is then read and searched once (the two dependent round trips of a rank, not four)
 		const int64_t k1 = lo + kk <= ix.n ? lo + kk : lo;
 		const uint32_t koff0 = (uint32_t)lo & (RB3_GRP - 1), koff1 = (uint32_t)k1 & (RB3_GRP - 1);
-		const uint64_t sm0 = ix.grp64[(lo >> RB3_GRP_BITS) * 8 + 6], sm1 = ix.grp64[(k1 >> RB3_GRP_BITS) * 8 + 6];
+		const uint64_t sm0 = ix.grp64[(lo >> RB3_GRP_BITS) * 8 + 6], sm1 = ix.grp64[(k1 >> RB3_GRP_BITS) * 8 + 6]; // (measured: the compact copy IdxView.gsm is no faster here, +1 ms per build)
 		const int64_t s0 = (int64_t)((uint32_t)sm0 + __popc((uint32_t)(sm0 >> 32) & ((2u << (koff0 >> RB3_WIN_BITS)) - 1u)) - 1u);
 		const int64_t s1 = (int64_t)((uint32_t)sm1 + __popc((uint32_t)(sm1 >> 32) & ((2u << (koff1 >> RB3_WIN_BITS)) - 1u)) - 1u);
 		const bool two = s1 != s0 || (lo >> RB3_GRP_BITS) != (k1 >> RB3_GRP_BITS);
@@ -3309,7 +3309,7 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 	int nR = 0;
 	if (nold > 0) {
 		const int64_t ga = A0 >> RB3_GRP_BITS, gb = (A1 - 1) >> RB3_GRP_BITS;
-		const uint64_t sma = old.grp64[ga * 8 + 6], smb = old.grp64[gb * 8 + 6];
+		const uint64_t sma = old.gsm[ga], smb = old.gsm[gb]; // (the compact copy of the slot words: neighbouring groups share a line)
 		const uint32_t wa = ((uint32_t)A0 & (RB3_GRP - 1)) >> RB3_WIN_BITS, wb = ((uint32_t)(A1 - 1) & (RB3_GRP - 1)) >> RB3_WIN_BITS;
 		const int64_t fa = (int64_t)((uint32_t)sma + __popc((uint32_t)(sma >> 32) & ((2u << wa) - 1u)) - 1u);
 		const int64_t la = (int64_t)((uint32_t)smb + __popc((uint32_t)(smb >> 32) & ((2u << wb) - 1u)) - 1u);

@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) k_plane_group(IdxView old, const int64_t 
 		int ns = 0;
 		if (nold > 0) {
 			ga = A0 >> RB3_GRP_BITS, gb = (A0 + nold - 1) >> RB3_GRP_BITS;
-			sma = old.grp64[ga * 8 + 6], smb = old.grp64[gb * 8 + 6];
+			sma = old.gsm[ga], smb = old.gsm[gb];
 			const uint32_t wa = ((uint32_t)A0 & (RB3_GRP - 1)) >> RB3_WIN_BITS, wb = ((uint32_t)(A0 + nold - 1) & (RB3_GRP - 1)) >> RB3_WIN_BITS;
 			fa = (int64_t)((uint32_t)sma + __popc((uint32_t)(sma >> 32) & ((2u << wa) - 1u)) - 1u);
 			const int64_t la = (int64_t)((uint32_t)smb + __popc((uint32_t)(smb >> 32) & ((2u << wb) - 1u)) - 1u);

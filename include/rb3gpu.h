@@ -313,6 +313,54 @@ int rb3gpu_sh_step(rb3gpu_t *h, int64_t n_states, const rb3gpu_state_t *d_in, co
 		int n_iv, const int64_t *iv_bounds, int my_iv, rb3gpu_state_t *d_send, int64_t *counts);
 int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_bwt, const int64_t *d_ka, int64_t iv_start, int commit);
 
+/* The whole merge of one batch into the interval-sharded index, DRIVEN FROM THE LIBRARY (rb3_mg_rank_plain + worker_mgins,
+ * fm-index.c:202-249, with the kt_for over strings of 217-224 cut by interval instead of by thread): every rank calls
+ * rb3gpu_sh_merge with the same batch and bounds; per lock-step round there is ONE kernel (k_sh_round: LF step, record, next
+ * states written straight into per-destination send regions), one read-back of the split sizes, one all-gather of them and one
+ * all-to-all of 16-byte states.  The rows that land in an interval are kept as (row, insertion point) pairs -- 16 bytes per
+ * landed row, nothing of the size of the whole batch -- and placed when the walk is over; then the interval is rebuilt.
+ * What connects the ranks is a COMMUNICATOR of two collectives (host vectors of int64; device buffers of states):
+ *   all_gather  every rank contributes n int64, recv gets world * n of them in rank order
+ *   all_to_all  region d of this rank's send buffer (d_send + d * stride states, send_cnt[d] states) goes to rank d; d_recv
+ *               receives recv_cnt[s] states from every rank s, packed in rank order.  `stream` is the HIP stream the engine's
+ *               kernels run on: the send regions are complete on it, and d_recv must be usable on it when the call returns.
+ * Both return 0 or a negative RB3GPU_E* code; a rank that fails must make the others fail too (abort), not leave them waiting.
+ * Three communicators ship with the library: ranks as THREADS of one process with one device each (rb3gpu_group_*: barriers +
+ * peer copies over xGMI -- what `ropebwt3-amd build --gpus N --interval` uses), one PROCESS per GPU over RCCL (rb3gpu_rccl_*:
+ * grouped ncclSend/ncclRecv on the engine's stream, librccl loaded at run time), and any pair of callbacks (tests: gloo).
+ *   iv_bounds  world + 1 positions, the same on every rank; updated to the bounds after the merge when commit != 0
+ *   chain_tp   text positions of the batch's sentinels (host, n_chains of them, the same on every rank): where the chains start
+ *   n_rounds   (may be NULL) lock-step rounds this merge took = longest string + 1 */
+typedef struct rb3gpu_comm_s {
+	void *ctx;
+	int rank, world;
+	int (*all_gather)(void *ctx, const int64_t *send, int n, int64_t *recv);
+	int (*all_to_all)(void *ctx, const rb3gpu_state_t *d_send, int64_t stride, const int64_t *send_cnt, rb3gpu_state_t *d_recv, const int64_t *recv_cnt, void *stream);
+	void (*abort)(void *ctx);   /* may be NULL: called by a rank whose merge failed locally, so that the others do not wait for it */
+} rb3gpu_comm_t;
+int rb3gpu_sh_merge(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw,
+		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds);
+
+/* ranks = threads of ONE process, one handle (device) each.  rb3gpu_group_create(world) once, rb3gpu_group_comm(g, rank, h, &comm)
+ * by each rank's thread; rb3gpu_group_abort wakes every rank waiting in a collective (they return RB3GPU_ESTATE). */
+typedef struct rb3gpu_group_s rb3gpu_group_t;
+rb3gpu_group_t *rb3gpu_group_create(int world);
+int rb3gpu_group_comm(rb3gpu_group_t *g, int rank, rb3gpu_t *h, rb3gpu_comm_t *comm);
+void rb3gpu_group_abort(rb3gpu_group_t *g);
+void rb3gpu_group_destroy(rb3gpu_group_t *g);
+
+/* one PROCESS per GPU over RCCL.  Rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the others by whatever means the
+ * launcher has (bench.py: torch.distributed broadcast; MPI; a file); every rank then creates its communicator on its handle's
+ * device.  RB3GPU_EUNSUP: librccl.so could not be loaded. */
+#define RB3GPU_RCCL_ID_BYTES 128
+int rb3gpu_rccl_unique_id(char id[RB3GPU_RCCL_ID_BYTES]);
+int rb3gpu_rccl_comm_create(rb3gpu_t *h, int rank, int world, const char id[RB3GPU_RCCL_ID_BYTES], rb3gpu_comm_t *comm);
+void rb3gpu_rccl_comm_destroy(rb3gpu_comm_t *comm);
+
+/* the HIP device and stream of a handle (for communicators implemented outside the library) */
+int rb3gpu_device_of(const rb3gpu_t *h);
+void *rb3gpu_stream_of(const rb3gpu_t *h);
+
 /* Diagnostic switches of a handle (no reference analogue; none is needed in normal use).  Each key is also read ONCE from
  * the environment variable RB3GPU_<KEY> when the handle is created; the merge path itself never calls getenv().
  *   "tent" 0/1, "staged" 0/1, "group_rebuild" 0/1, "window_rebuild" 0/1, "reb_force" 0/1, "octs" 1..8, "blkmul", "blkcap", "ssa_split" 4..20,

@@ -39,7 +39,7 @@ def hipcc_path():
     raise RuntimeError("hipcc not found; the HIP engine cannot be built (there is no CPU fallback)")
 
 
-GPU_UNITS = ("rb3gpu.hip", "rb3gpu_sort.hip", "rb3gpu_fmdenc.hip")
+GPU_UNITS = ("rb3gpu.hip", "rb3gpu_sort.hip", "rb3gpu_fmdenc.hip", "rb3gpu_comm.hip")
 
 
 def build_gpu(force=False):

@@ -157,6 +157,7 @@ struct rb3gpu_s {
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
 	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist, pslots, lbst;
+	Buf shc, shn, shs, shr, shk; // interval-sharded merge (rb3gpu_sh_merge): states of this and of the next round, send regions, landed (row, insertion point) pairs, counters
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -496,7 +497,7 @@ rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
 		if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return nullptr; }
 	for (int i = 0; i < 3; ++i)
 		if (hipEventCreateWithFlags(&h->evx[i], hipEventDisableTiming) != hipSuccess) { delete h; return nullptr; }
-	if (hipHostMalloc((void**)&h->hm_pin, 64 * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->hm_pin = nullptr; }
+	if (hipHostMalloc((void**)&h->hm_pin, 128 * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->hm_pin = nullptr; }
 	h->t0 = now_s();
 	return h;
 }
@@ -547,7 +548,7 @@ static void guard_check(rb3gpu_t *h, const char *where)
 {
 	if (!h->tn.guard) return;
 	static const char *names[] = { "b2", "pos", "post", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk };
 	uint8_t g[RB3_GUARD];
 	for (int i = 0; i < 20 + 4; ++i) {
 		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
@@ -594,7 +595,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -2874,6 +2875,183 @@ int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_
 	if (commit) index_install(h, ngrp, nslots, ntot, acc);
 	return 0;
 }
+
+/* like buf_ensure, but the first `used` bytes of the buffer survive a reallocation */
+static int buf_grow_keep(rb3gpu_t *h, Buf &b, size_t used, size_t bytes)
+{
+	if (b.cap >= bytes && b.p) return 0;
+	Buf nb;
+	int r = buf_ensure(h, nb, bytes);
+	if (r < 0) return r;
+	if (b.p && used) HIPCHK(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, h->st));
+	if (b.p) dev_free(h, b.p, b.cap); // (given back by a hipFree, which waits for the copy)
+	b = nb;
+	return 0;
+}
+
+/* the rows [jlo, jlo + n_rows) of the batch with their positions inside this interval: checked, interleaved, index rebuilt */
+static int sh_rebuild(rb3gpu_t *h, int64_t n_rows, const uint8_t *d_b2rows, int64_t *dpos, unsigned long long *misc, int commit)
+{
+	const int64_t ntot = h->n + n_rows;
+	hipLaunchKernelGGL(k_pos_check, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)dpos, n_rows, ntot, misc + 2);
+	unsigned long long hm[5] = {0, 0, 0, 0, 0};
+	HIPCHK(hipMemcpyAsync(hm, misc, 40, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	if (hm[2] != 0 || hm[3] != 0) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] sharded merge: %llu rows of the interval unset or misrouted, %llu out of order\n", hm[2], hm[3]);
+		return RB3GPU_EINTERNAL;
+	}
+	int r;
+	int64_t ngrp = 0, nslots = 0, acc[7];
+	if ((r = build_index<false>(h, n_rows, d_b2rows, (const int64_t*)dpos, ntot, false, &ngrp, &nslots, acc)) < 0) return r;
+	HIPCHK(hipEventRecord(h->ev[3], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
+	h->stt.n_symbols_merged += n_rows;
+	h->stt.bytes_rebuild += 9 * n_rows + h->stt.bytes_index + ngrp * (int64_t)sizeof(rb3_grp_t) + nslots * (int64_t)sizeof(rb3_slot_t);
+	if (commit) index_install(h, ngrp, nslots, ntot, acc);
+	return 0;
+}
+
+static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw,
+		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds)
+{
+	const int world = comm->world, rank = comm->rank;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	if (iv_bounds[rank + 1] - iv_bounds[rank] != h->n) return RB3GPU_EINVAL; // not the interval this handle holds
+	int r;
+	// symbol totals of every interval -> C array of the whole BWT and this interval's additive offsets (mrope.c:76-88)
+	std::vector<int64_t> mine(6), allc((size_t)world * 6), M((size_t)world * world), cnt_h(world), recv_cnt(world), rows_all(world);
+	for (int c = 0; c < 6; ++c) mine[c] = h->acc[c + 1] - h->acc[c];
+	if ((r = comm->all_gather(comm->ctx, mine.data(), 6, allc.data())) < 0) return r;
+	ShArgs a;
+	memset(&a, 0, sizeof(a));
+	int64_t tot[6], C = 0;
+	for (int c = 0; c < 6; ++c) {
+		int64_t pre = 0;
+		tot[c] = 0;
+		for (int q = 0; q < world; ++q) { if (q < rank) pre += allc[(size_t)q * 6 + c]; tot[c] += allc[(size_t)q * 6 + c]; }
+		a.adj[c] = C + pre - h->acc[c];
+		C += tot[c];
+	}
+	for (int i = 0; i <= world; ++i) a.bounds[i] = iv_bounds[i];
+	a.iv_start = iv_bounds[rank], a.n_iv = world;
+	const int64_t m1 = tot[0]; // every chain starts at ka = #sentinels of the index (fm-index.c:164)
+	int owner0 = 0;
+	for (int i = 1; i < world; ++i) owner0 += iv_bounds[i] <= m1 ? 1 : 0;
+	// two state buffers for the whole merge (a rank never holds more states than there are strings), counters of both parities + bad
+	if ((r = buf_ensure(h, h->shc, (size_t)n_chains * 16)) < 0) return r;
+	if ((r = buf_ensure(h, h->shn, (size_t)n_chains * 16)) < 0) return r;
+	if ((r = buf_ensure(h, h->shk, (size_t)(2 * (RB3_SH_MAXIV + 1) + 1) * 8)) < 0) return r;
+	unsigned long long *d_cnt[2] = { (unsigned long long*)h->shk.p, (unsigned long long*)h->shk.p + RB3_SH_MAXIV + 1 }, *d_bad = (unsigned long long*)h->shk.p + 2 * (RB3_SH_MAXIV + 1);
+	HIPCHK(hipMemsetAsync(h->shk.p, 0, (size_t)(2 * (RB3_SH_MAXIV + 1) + 1) * 8, h->st));
+	ShState *cur = (ShState*)h->shc.p, *nxt = (ShState*)h->shn.p;
+	int64_t n_cur = 0;
+	if (rank == owner0) {
+		std::vector<ShState> st((size_t)n_chains);
+		for (int64_t i = 0; i < n_chains; ++i) {
+			if (chain_tp[i] < 0 || chain_tp[i] >= len) return RB3GPU_EINVAL;
+			st[(size_t)i].tp = chain_tp[i], st[(size_t)i].ka = m1;
+		}
+		HIPCHK(hipMemcpyAsync(cur, st.data(), (size_t)n_chains * 16, hipMemcpyHostToDevice, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+		n_cur = n_chains;
+	}
+	unsigned long long hc_stack[RB3_SH_MAXIV + 2], *hc = h->hm_pin ? h->hm_pin : hc_stack;
+	const IdxView iv = view_of(h);
+	int64_t rows = 0, rounds = 0;
+	int par = 0;
+	bool dirty[2] = { false, false };
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	for (;;) {
+		for (int i = 0; i < world; ++i) cnt_h[i] = 0;
+		if (n_cur > 0) {
+			if ((r = buf_grow_keep(h, h->shr, (size_t)rows * 16, (size_t)(rows + n_cur) * 16)) < 0) return r;
+			ShState *send = nxt; // one interval: the next states are the next round's states
+			if (world > 1) {
+				if ((r = buf_ensure(h, h->shs, (size_t)world * (size_t)n_cur * 16)) < 0) return r;
+				send = (ShState*)h->shs.p;
+			}
+			int64_t nblk = (n_cur + 31) / 32;
+			if (nblk > 256 * 16) nblk = 256 * 16;
+			hipLaunchKernelGGL(k_sh_round, dim3((unsigned)nblk), dim3(256), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad);
+			HIPCHK(hipMemcpyAsync(hc, d_cnt[par], (size_t)(world + 1) * 8, hipMemcpyDeviceToHost, h->st));
+			HIPCHK(hipMemcpyAsync(hc + world + 1, d_bad, 8, hipMemcpyDeviceToHost, h->st));
+			HIPCHK(hipStreamSynchronize(h->st));
+			if (hc[world + 1] != 0) return RB3GPU_EINTERNAL;
+			int64_t sum = 0;
+			for (int i = 0; i <= world; ++i) sum += (int64_t)hc[i];
+			if (sum != n_cur) return RB3GPU_EINTERNAL;
+			for (int i = 0; i < world; ++i) cnt_h[i] = (int64_t)hc[i];
+			dirty[par] = true, dirty[1 - par] = false;
+			h->stt.n_lf_steps += n_cur, h->stt.n_rank_launches += 1;
+		} else if (dirty[1 - par]) { // nothing here this round: the counters the next round adds to still hold an earlier round's sizes
+			HIPCHK(hipMemsetAsync(d_cnt[1 - par], 0, (size_t)(RB3_SH_MAXIV + 1) * 8, h->st));
+			dirty[1 - par] = false;
+		}
+		rows += n_cur;
+		++rounds;
+		int64_t moving = 0, n_in = 0;
+		if (world == 1) {
+			moving = n_in = cnt_h[0];
+		} else {
+			if ((r = comm->all_gather(comm->ctx, cnt_h.data(), world, M.data())) < 0) return r; // M[s][d]: states rank s sends to rank d
+			for (size_t i = 0; i < M.size(); ++i) moving += M[i];
+			for (int q = 0; q < world; ++q) recv_cnt[q] = M[(size_t)q * world + rank], n_in += recv_cnt[q];
+		}
+		if (moving == 0) break;
+		if (n_in > n_chains) return RB3GPU_EINTERNAL;
+		if (world == 1) {
+			ShState *t = cur; cur = nxt, nxt = t; // (k_sh_round wrote region 0 = nxt)
+		} else {
+			if ((r = comm->all_to_all(comm->ctx, (const rb3gpu_state_t*)h->shs.p, n_cur, cnt_h.data(), (rb3gpu_state_t*)nxt, recv_cnt.data(), (void*)h->st)) < 0) return r;
+			ShState *t = cur; cur = nxt, nxt = t;
+		}
+		n_cur = n_in, par ^= 1;
+	}
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_rank += ev_ms(h->ev[0], h->ev[1]);
+	if (n_rounds) *n_rounds = rounds;
+	// which rows landed here: rows are contiguous per interval, in interval order
+	if ((r = comm->all_gather(comm->ctx, &rows, 1, rows_all.data())) < 0) return r;
+	int64_t jlo = 0, rsum = 0;
+	for (int q = 0; q < world; ++q) { if (q < rank) jlo += rows_all[q]; rsum += rows_all[q]; }
+	if (rsum != len) {
+		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] sharded merge recorded %lld of %lld rows\n", (long long)rsum, (long long)len);
+		return RB3GPU_EINTERNAL;
+	}
+	if (rows > 0) {
+		if ((r = buf_ensure(h, h->pos, (size_t)rows * 8)) < 0) return r;
+		if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+		unsigned long long *misc = (unsigned long long*)h->misc.p;
+		int64_t *dpos = (int64_t*)h->pos.p;
+		HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
+		HIPCHK(hipMemsetAsync(dpos, 0xff, (size_t)rows * 8, h->st)); // RB3_UNSET
+		HIPCHK(hipEventRecord(h->ev[2], h->st));
+		hipLaunchKernelGGL(k_sh_place, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->st, rows, (const ShRec*)h->shr.p, jlo, iv_bounds[rank], dpos, misc + 2);
+		if ((r = sh_rebuild(h, rows, d_bwt + jlo, dpos, misc, commit)) < 0) return r;
+	}
+	if (commit) {
+		int64_t grow = 0;
+		for (int q = 0; q < world; ++q) grow += rows_all[q], iv_bounds[q + 1] += grow;
+	}
+	return 0;
+}
+
+int rb3gpu_sh_merge(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw,
+		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds)
+{
+	if (!h || !comm || !iv_bounds || len <= 0 || !d_bwt || !d_tw || n_chains <= 0 || n_chains > len || !chain_tp) return RB3GPU_EINVAL;
+	if (comm->world < 1 || comm->world > RB3_SH_MAXIV || comm->rank < 0 || comm->rank >= comm->world || !comm->all_gather || (comm->world > 1 && !comm->all_to_all)) return RB3GPU_EINVAL;
+	const int r = sh_merge_impl(h, comm, iv_bounds, len, d_bwt, d_tw, n_chains, chain_tp, commit, n_rounds);
+	if (r < 0 && comm->abort) comm->abort(comm->ctx); // the other ranks are (or will be) waiting in a collective
+	return r;
+}
+
+int rb3gpu_device_of(const rb3gpu_t *h) { return h ? h->dev : -1; }
+void *rb3gpu_stream_of(const rb3gpu_t *h) { return h ? (void*)h->st : nullptr; }
 
 int rb3gpu_dev_copy(rb3gpu_t *h, void *d_dst, const void *d_src, int64_t n_bytes)
 {

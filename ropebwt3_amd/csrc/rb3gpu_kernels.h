@@ -3954,6 +3954,70 @@ __global__ void __launch_bounds__(256) k_sh_localpos(int64_t jlo, int64_t n, con
 	pos[r] = ka - iv_start + r;
 }
 
+/* The same walk driven from inside the library (rb3gpu_sh_merge): ONE kernel per lock-step round, no scatter pass and no array
+ * over all rows of the batch.  State q of a round that starts with `done` rows recorded on this GPU appends the (row, insertion
+ * point) pair of its suffix at rec[done + q] -- arrival order, no counter; the rows that land in an interval are a contiguous
+ * range of the batch's rows because pos[] is increasing, k_sh_place sorts them out at the end -- and writes its next state
+ * straight into the send region of the interval that owns it: region d = send + d * stride, a slot from the cursor cnt[d]
+ * (one atomic per block, destination and 32 states).  After the launch the cursors ARE the split sizes of the all-to-all;
+ * cnt[n_iv] counts the chains that reached the start of their string.  The counters of the other parity are cleared for the
+ * next round on the way (the host has read them before this launch), so a round is one launch and one 8-byte-per-rank read-back. */
+struct ShRec { int64_t kb, ka; };
+__global__ void __launch_bounds__(256) k_sh_round(IdxView ix, ShArgs a, int64_t n, const ShState *in, const uint64_t *tw, ShRec *rec,
+		ShState *send, int64_t stride, unsigned long long *cnt, unsigned long long *cnt_next, unsigned long long *bad)
+{
+	__shared__ uint32_t lc[RB3_SH_MAXIV + 1];
+	__shared__ unsigned long long lb[RB3_SH_MAXIV + 1];
+	const int j = threadIdx.x & 7;
+	if (blockIdx.x == 0 && threadIdx.x <= RB3_SH_MAXIV) cnt_next[threadIdx.x] = 0ull;
+	for (int64_t base = (int64_t)blockIdx.x * 32; base < n; base += (int64_t)gridDim.x * 32) { // (block-uniform trip count: barriers inside)
+		for (int i = threadIdx.x; i <= a.n_iv; i += blockDim.x) lc[i] = 0u;
+		__syncthreads();
+		const int64_t q = base + (threadIdx.x >> 3);
+		int d = -1;
+		uint32_t mine = 0;
+		ShState nx;
+		nx.tp = 0, nx.ka = 0;
+		if (q < n) {
+			const ShState st = in[q];
+			const uint64_t x = tw[st.tp];
+			const int c = (int)(x & 7u);
+			int64_t k = st.ka - a.iv_start;
+			if (k < 0 || k > ix.n) { if (j == 0) atomicAdd(bad, 1ull); k = k < 0 ? 0 : ix.n; } // (a state routed to the wrong interval: cannot be)
+			if (j == 0) { ShRec r; r.kb = (int64_t)(x >> 3), r.ka = st.ka; rec[q] = r; }
+			d = a.n_iv;
+			nx.tp = st.tp - 1;
+			if (c != 0) {
+				RankLoad r;
+				oct_rank_issue(ix, k, j, r);
+				nx.ka = oct_rank_finish(r, c, j, ix.abs != 0) + a.adj[c];
+				d = 0;
+				for (int i = 1; i < a.n_iv; ++i) d += a.bounds[i] <= nx.ka ? 1 : 0;
+			}
+			if (j == 0) mine = atomicAdd(&lc[d], 1u);
+		}
+		__syncthreads();
+		for (int i = threadIdx.x; i <= a.n_iv; i += blockDim.x)
+			lb[i] = lc[i] ? atomicAdd(&cnt[i], (unsigned long long)lc[i]) : 0ull;
+		__syncthreads();
+		if (j == 0 && d >= 0 && d < a.n_iv) send[(int64_t)d * stride + (int64_t)lb[d] + mine] = nx;
+		__syncthreads();
+	}
+}
+
+/* the pairs an interval collected -> merged positions inside the interval: the rows are [jlo, jlo + n) of the batch, row r lands
+ * at (ka - start) + (r - jlo).  pos[] comes filled with RB3_UNSET; a row outside the range, recorded twice (then another one stays
+ * unset) or routed wrongly shows in bad[0] here or in k_pos_check behind this kernel. */
+__global__ void __launch_bounds__(256) k_sh_place(int64_t n, const ShRec *rec, int64_t jlo, int64_t iv_start, int64_t *pos, unsigned long long *bad)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const ShRec r = rec[i];
+	const int64_t kb = r.kb - jlo;
+	if (kb < 0 || kb >= n || r.ka < iv_start) { atomicAdd(bad, 1ull); return; }
+	pos[kb] = r.ka - iv_start + kb;
+}
+
 /* ----------------------------------------------------------------------------------------- */
 /* export                                                                                      */
 /* ----------------------------------------------------------------------------------------- */

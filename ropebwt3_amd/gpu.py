@@ -113,7 +113,27 @@ SYMBOLS = {
     "rb3gpu_sh_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_sh_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
     "rb3gpu_device_count": (ctypes.c_int, []),
+    "rb3gpu_sh_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "rb3gpu_group_create": (ctypes.c_void_p, [ctypes.c_int]),
+    "rb3gpu_group_comm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_group_abort": (None, [ctypes.c_void_p]),
+    "rb3gpu_group_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "rb3gpu_rccl_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_rccl_comm_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_device_of": (ctypes.c_int, [ctypes.c_void_p]),
+    "rb3gpu_stream_of": (ctypes.c_void_p, [ctypes.c_void_p]),
 }
+
+# rb3gpu_comm_t (include/rb3gpu.h): the two collectives of the interval-sharded merge
+ALL_GATHER_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.POINTER(ctypes.c_int64))
+ALL_TO_ALL_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p)
+ABORT_F = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+
+class CommStruct(ctypes.Structure):
+    _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
+                ("all_gather", ctypes.c_void_p), ("all_to_all", ctypes.c_void_p), ("abort", ctypes.c_void_p)]
 
 _libs = {}
 
@@ -433,6 +453,9 @@ class Rb3Gpu:
         self._chk(self._lib.rb3gpu_dev_download(self._h, out.ctypes.data, p, nbytes), "rb3gpu_dev_download")
         return out
 
+    def dev_download_i64(self, p, n):
+        return self.dev_download(p, int(n) * 8).view(np.int64)
+
     def ssa_gen(self, ssa_shift):
         """sampled suffix array of the index (rb3_ssa_gen, ssa.c:54-81): (ms, r2i[m], ssa[n_ssa]) as uint64"""
         m, n_ssa, ms = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
@@ -510,6 +533,15 @@ class Rb3Gpu:
     def sh_finish(self, jlo, n_rows, d_bwt, d_ka, iv_start, commit=True):
         self._chk(self._lib.rb3gpu_sh_finish(self._h, int(jlo), int(n_rows), d_bwt, d_ka, int(iv_start), 1 if commit else 0), "rb3gpu_sh_finish")
 
+    def sh_merge(self, comm, bounds, d_bwt, d_tw, n2, sent_tp, commit=True):
+        """rb3gpu_sh_merge: one batch merged into the interval-sharded index, the lock-step loop inside the library.  comm: a
+        GroupComm / RcclComm / CallbackComm of this rank.  Returns (bounds after the merge, lock-step rounds)."""
+        b = np.array(bounds, dtype=np.int64)
+        tp = np.ascontiguousarray(sent_tp, dtype=np.int64)
+        rounds = ctypes.c_int64(0)
+        self._chk(self._lib.rb3gpu_sh_merge(self._h, ctypes.addressof(comm.struct), b.ctypes.data, int(n2), d_bwt, d_tw, tp.size, tp.ctypes.data, 1 if commit else 0, ctypes.addressof(rounds)), "rb3gpu_sh_merge")
+        return b, int(rounds.value)
+
     def sync(self):
         self._chk(self._lib.rb3gpu_sync(self._h), "rb3gpu_sync")
 
@@ -520,3 +552,103 @@ class Rb3Gpu:
 
     def stats_reset(self):
         self._lib.rb3gpu_stats_reset(self._h)
+
+
+class CommGroup:
+    """rb3gpu_group_*: the ranks of an interval-sharded index as THREADS of this process, one handle each (barriers + peer copies)"""
+
+    def __init__(self, world, lib=None, hooks=False):
+        self._lib = load_library(hooks, lib)
+        self.world = int(world)
+        self._g = self._lib.rb3gpu_group_create(self.world)
+        if not self._g:
+            raise Rb3GpuError(-3, "rb3gpu_group_create")
+
+    def comm(self, rank, engine):
+        c = GroupComm()
+        c.struct = CommStruct()
+        r = self._lib.rb3gpu_group_comm(self._g, int(rank), engine._h, ctypes.addressof(c.struct))
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_group_comm")
+        c.group = self   # keeps the group alive
+        return c
+
+    def abort(self):
+        self._lib.rb3gpu_group_abort(self._g)
+
+    def close(self):
+        if self._g:
+            self._lib.rb3gpu_group_destroy(self._g)
+            self._g = None
+
+
+class GroupComm:
+    struct = None
+
+
+class RcclComm:
+    """rb3gpu_rccl_*: one process per GPU; grouped ncclSend/ncclRecv on the engine's stream.  `uid`: the 128 bytes rank 0 got
+    from RcclComm.unique_id() and sent to the other ranks."""
+
+    @staticmethod
+    def unique_id(lib=None):
+        l = load_library(False, lib)
+        buf = ctypes.create_string_buffer(128)
+        r = l.rb3gpu_rccl_unique_id(buf)
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_rccl_unique_id")
+        return buf.raw
+
+    def __init__(self, engine, rank, world, uid):
+        self._lib = engine._lib
+        self.struct = CommStruct()
+        self.rank, self.world = int(rank), int(world)
+        buf = ctypes.create_string_buffer(bytes(uid), 128)
+        r = self._lib.rb3gpu_rccl_comm_create(engine._h, self.rank, self.world, buf, ctypes.addressof(self.struct))
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_rccl_comm_create")
+        self._open = True
+
+    def close(self):
+        if self._open:
+            self._lib.rb3gpu_rccl_comm_destroy(ctypes.addressof(self.struct))
+            self._open = False
+
+
+class CallbackComm:
+    """a communicator whose two collectives are Python callables (tests: gloo, threads):
+    all_gather(vec int64[n]) -> array [world, n];  exchange(d_send, stride, send_counts, d_recv, recv_counts) with device pointers
+    as ints (states of 16 bytes; region d of the send buffer starts at d_send + d * stride * 16)."""
+
+    def __init__(self, rank, world, all_gather, exchange, abort=None):
+        self.rank, self.world = int(rank), int(world)
+        self.error = None
+
+        def _ag(ctx, send, n, recv):
+            try:
+                out = np.asarray(all_gather(np.ctypeslib.as_array(send, shape=(n,)).copy()), dtype=np.int64).reshape(self.world * n)
+                np.ctypeslib.as_array(recv, shape=(self.world * n,))[:] = out
+                return 0
+            except BaseException as e:   # (an exception must not unwind through the C frames)
+                self.error = e
+                return -6
+
+        def _a2a(ctx, d_send, stride, send_cnt, d_recv, recv_cnt, stream):
+            try:
+                sc = np.ctypeslib.as_array(send_cnt, shape=(self.world,)).copy()
+                rc = np.ctypeslib.as_array(recv_cnt, shape=(self.world,)).copy()
+                exchange(int(d_send or 0), int(stride), sc, int(d_recv or 0), rc)
+                return 0
+            except BaseException as e:
+                self.error = e
+                return -6
+
+        def _ab(ctx):
+            if abort is not None:
+                try:
+                    abort()
+                except BaseException:
+                    pass
+
+        self._keep = (ALL_GATHER_F(_ag), ALL_TO_ALL_F(_a2a), ABORT_F(_ab))   # the C side holds raw pointers to these
+        self.struct = CommStruct(None, self.rank, self.world, ctypes.cast(self._keep[0], ctypes.c_void_p), ctypes.cast(self._keep[1], ctypes.c_void_p), ctypes.cast(self._keep[2], ctypes.c_void_p))

@@ -1091,6 +1091,266 @@ def test_interval_sharded_merge_real_engine(oracle, world, kind):
     assert all(r == rounds[0] for r in rounds) and rounds[0] >= 40
 
 
+def _sharded_case(oracle, rng, kind):
+    """(index BWT, batches as texts, merged BWT after every batch) of the interval-sharded tests"""
+    from ropebwt3_amd import host
+    g0 = util.random_genome(rng, 40000)
+    if kind == "family":   # a run-coded index: relatives of one genome
+        cur = host.build_bwt(util.make_text([util.mutate(rng, g0, 0.002) for _ in range(12)]))
+    else:
+        cur = host.build_bwt(util.make_text([g0] + util.reads_from(rng, g0, 200, 100)))
+    batches = []
+    for b in range(3):
+        if kind == "dups":
+            seqs = [g0[500:650].copy()] * 3 + util.reads_from(rng, g0, 300, 80)
+        elif kind == "ragged":   # strings of very different lengths, one of them a single symbol
+            seqs = [util.mutate(rng, g0, 0.01)[:3000], g0[5:6].copy(), util.mutate(rng, g0, 0.02)[1000:1100]] + util.reads_from(rng, g0, 50, 60)
+        else:
+            seqs = util.reads_from(rng, g0, 2000, int(rng.integers(40, 151)), err=0.01)
+        batches.append(util.make_text(seqs, rev=(b != 1)))
+    want = [cur]
+    for t2 in batches:
+        want.append(oracle.merge(want[-1], host.build_bwt(t2.copy())))
+    return cur, batches, want
+
+
+def _check_interval(h, rng, w, bounds, rank):
+    assert bounds[-1] == w.size
+    mine = w[bounds[rank]:bounds[rank + 1]]
+    assert h.get_tot() == mine.size
+    assert np.array_equal(h.export_plain(), mine)
+    ks = np.unique(np.concatenate([rng.integers(0, mine.size + 1, size=50), [0, mine.size]]))
+    cum = np.stack([np.concatenate([[0], np.cumsum(mine == c)]) for c in range(6)], axis=1)
+    assert np.array_equal(h.rank1a(ks), cum[ks])
+
+
+@pytest.mark.parametrize("world,kind", [(1, "reads"), (2, "reads"), (3, "reads"), (2, "family"), (4, "dups"), (3, "ragged")])
+def test_interval_sharded_merge_driven_from_the_library(oracle, world, kind):
+    """rb3gpu_sh_merge: the lock-step loop of the interval-sharded merge INSIDE the library (one k_sh_round per symbol, split
+    sizes read back, all-gather + all-to-all through the library's own thread-group communicator: barriers + device-to-device
+    copies), `world` ranks as threads with a handle each.  After every merge the concatenation of the intervals is the oracle's
+    merged BWT, rank queries on the rebuilt intervals agree with it, and a merge with commit=False leaves everything as it was."""
+    import threading
+    from ropebwt3_amd import Rb3Gpu, CommGroup, multi
+    rng = np.random.default_rng(500 + world)
+    cur, batches, want = _sharded_case(oracle, rng, kind)
+    bounds0 = multi.interval_bounds(cur.size, world)
+    grp = CommGroup(world)
+    errs, rounds = [], [None] * world
+
+    def run(rank):
+        try:
+            r = np.random.default_rng(900 + rank)
+            h = Rb3Gpu(verbose=1)
+            comm = grp.comm(rank, h)
+            bounds = bounds0
+            h.from_plain(cur[bounds[rank]:bounds[rank + 1]])
+            for b, t2 in enumerate(batches):
+                d_bwt, d_tw = h.sort_text(t2)
+                sent = np.flatnonzero(t2 == 0)
+                if b == 1:   # a dry run first: nothing may change
+                    nb, _ = h.sh_merge(comm, bounds, d_bwt, d_tw, t2.size, sent, commit=False)
+                    assert np.array_equal(nb, bounds)
+                    _check_interval(h, r, want[b], bounds, rank)
+                bounds, nr = h.sh_merge(comm, bounds, d_bwt, d_tw, t2.size, sent, commit=True)
+                h.dev_free(d_bwt), h.dev_free(d_tw)
+                _check_interval(h, r, want[b + 1], bounds, rank)
+                rounds[rank] = nr
+            h.close()
+        except BaseException as e:   # (a failed rank must not leave the others waiting at the barrier for ever)
+            errs.append((rank, repr(e)))
+            grp.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    grp.close()
+    assert not errs, errs
+    longest = int(np.max(np.diff(np.concatenate([[-1], np.flatnonzero(batches[-1] == 0)]))))
+    assert all(r == longest for r in rounds), (rounds, longest)   # one round per symbol of the longest string, its sentinel included
+
+
+def test_interval_sharded_merge_through_callbacks(oracle):
+    """the same merge with a communicator made of two Python callables (what a launcher without RCCL -- gloo, MPI -- plugs in):
+    two ranks as threads, the all-to-all as device-to-device copies out of the per-destination send regions; and a rank whose
+    call fails (wrong bounds) aborts the others instead of leaving them in the barrier"""
+    import threading
+    from ropebwt3_amd import Rb3Gpu, CallbackComm, Rb3GpuError, multi
+    world = 2
+    rng = np.random.default_rng(77)
+    cur, batches, want = _sharded_case(oracle, rng, "reads")
+    bounds0 = multi.interval_bounds(cur.size, world)
+    bar = threading.Barrier(world)
+    slots, pubs = [None] * world, [None] * world
+    errs = []
+
+    def run(rank, sabotage):
+        try:
+            h = Rb3Gpu(verbose=0)
+
+            def all_gather(vec):
+                slots[rank] = vec
+                bar.wait()
+                out = np.stack(slots)
+                bar.wait()
+                return out
+
+            def exchange(d_send, stride, send_cnt, d_recv, recv_cnt):
+                h.sync()
+                pubs[rank] = (d_send, stride, send_cnt)
+                bar.wait()
+                at = 0
+                for src in range(world):
+                    p, st, cnt = pubs[src]
+                    n = int(cnt[rank])
+                    assert n == int(recv_cnt[src])
+                    if n:
+                        h.dev_copy(d_recv + at * 16, p + rank * st * 16, n * 16)
+                    at += n
+                h.sync()
+                bar.wait()
+
+            comm = CallbackComm(rank, world, all_gather, exchange, abort=bar.abort)
+            bounds = bounds0
+            h.from_plain(cur[bounds[rank]:bounds[rank + 1]])
+            t2 = batches[0]
+            d_bwt, d_tw = h.sort_text(t2)
+            if sabotage:
+                wrong = bounds.copy()
+                if rank == 1:
+                    wrong[1] += 1   # not the interval the handle holds: EINVAL on this rank, before its first collective
+                with pytest.raises(Rb3GpuError):
+                    h.sh_merge(comm, wrong, d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+            else:
+                bounds, _ = h.sh_merge(comm, bounds, d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+                _check_interval(h, np.random.default_rng(rank), want[1], bounds, rank)
+            h.close()
+        except BaseException as e:
+            errs.append((rank, repr(e)))
+            bar.abort()
+
+    for sabotage in (False, True):
+        bar.reset()
+        th = [threading.Thread(target=run, args=(r, sabotage)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not errs, errs
+
+
+def _gloo_sh_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from ropebwt3_amd import Rb3Gpu, CallbackComm, multi
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = util.Oracle()
+        rng = np.random.default_rng(4242)   # the same case on every rank
+        cur, batches, want = _sharded_case(orc, rng, "reads")
+        bounds = multi.interval_bounds(cur.size, world)
+        h = Rb3Gpu(verbose=1)
+
+        def all_gather(vec):
+            out = [torch.zeros(len(vec), dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(out, torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64)))
+            return torch.stack(out).numpy()
+
+        def exchange(d_send, stride, send_cnt, d_recv, recv_cnt):   # host-staged: gloo moves CPU tensors
+            parts = []
+            for d in range(world):
+                n = int(send_cnt[d])
+                parts.append(torch.from_numpy(h.dev_download_i64(d_send + d * stride * 16, n * 2)) if n else torch.zeros(0, dtype=torch.int64))
+            recv = [torch.zeros(int(recv_cnt[s]) * 2, dtype=torch.int64) for s in range(world)]
+            dist.all_to_all(recv, parts) if dist.get_backend() != "gloo" else _gloo_all_to_all(dist, rank, world, parts, recv)
+            got = torch.cat(recv).numpy()
+            if got.size:
+                h.dev_upload_to(d_recv, got)
+
+        comm = CallbackComm(rank, world, all_gather, exchange)
+        h.from_plain(cur[bounds[rank]:bounds[rank + 1]])
+        for b, t2 in enumerate(batches):
+            d_bwt, d_tw = h.sort_text(t2)
+            bounds, _ = h.sh_merge(comm, bounds, d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+            h.dev_free(d_bwt), h.dev_free(d_tw)
+            _check_interval(h, np.random.default_rng(rank), want[b + 1], bounds, rank)
+        h.close()
+        q.put((rank, True, ""))
+    except BaseException as e:
+        q.put((rank, False, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gloo_all_to_all(dist, rank, world, parts, recv):
+    """gloo has no all_to_all for CPU tensors of unequal sizes everywhere: pairwise send/recv, lower rank sends first"""
+    for peer in range(world):
+        if peer == rank:
+            recv[rank].copy_(parts[rank])
+        elif rank < peer:
+            if parts[peer].numel(): dist.send(parts[peer], peer)
+            if recv[peer].numel(): dist.recv(recv[peer], peer)
+        else:
+            if recv[peer].numel(): dist.recv(recv[peer], peer)
+            if parts[peer].numel(): dist.send(parts[peer], peer)
+
+
+def test_interval_sharded_merge_c_path_over_gloo():
+    """world 2 as two PROCESSES (sharing this GPU) joined by gloo: rb3gpu_sh_merge runs the loop in the library, the launcher
+    only supplies the two collectives"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_gloo_sh_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+
+
+def test_rccl_communicator_world_of_one(oracle):
+    """the RCCL communicator of the library (librccl loaded at run time; one process per GPU) on the one GPU there is: communicator of
+    world 1, its all-gather, its grouped send/recv (a rank sending to itself) called directly, and a merge through it"""
+    import ctypes
+    from ropebwt3_amd import Rb3Gpu, RcclComm, gpu, multi
+    rng = np.random.default_rng(11)
+    cur, batches, want = _sharded_case(oracle, rng, "reads")
+    h = Rb3Gpu(verbose=1)
+    try:
+        comm = RcclComm(h, 0, 1, RcclComm.unique_id())
+        ag = gpu.ALL_GATHER_F(comm.struct.all_gather)
+        send, recv = (ctypes.c_int64 * 6)(1, 2, 3, 4, 5, 6), (ctypes.c_int64 * 6)()
+        assert ag(comm.struct.ctx, send, 6, recv) == 0 and list(recv) == [1, 2, 3, 4, 5, 6]
+        a2a = gpu.ALL_TO_ALL_F(comm.struct.all_to_all)
+        st = np.arange(2 * 1000, dtype=np.int64)
+        d_s, d_r = h.dev_alloc(st.nbytes), h.dev_alloc(st.nbytes)
+        h.dev_upload_to(d_s, st)
+        cnt = (ctypes.c_int64 * 1)(1000)
+        assert a2a(comm.struct.ctx, d_s, 1000, cnt, d_r, cnt, h._lib.rb3gpu_stream_of(h._h)) == 0
+        h.sync()
+        assert np.array_equal(h.dev_download_i64(d_r, 2000), st)
+        h.dev_free(d_s), h.dev_free(d_r)
+        bounds = multi.interval_bounds(cur.size, 1)
+        h.from_plain(cur)
+        t2 = batches[0]
+        d_bwt, d_tw = h.sort_text(t2)
+        bounds, _ = h.sh_merge(comm, bounds, d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+        _check_interval(h, rng, want[1], bounds, 0)
+        comm.close()
+    finally:
+        h.close()
+
+
 def test_lf_consistency_check_finds_a_wrong_but_monotone_pos(oracle):
     """the device-side check of pos[] against the index (k_lf_check: ka[LF2(kb)] == C1[c] + rank_B1(c, ka[kb]), SURVEY
     appendix A) on every row: a correct merge passes with all rows verified; a pos[] that was moved by one position for a

@@ -2973,9 +2973,12 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 				if ((r = buf_ensure(h, h->shs, (size_t)world * (size_t)n_cur * 16)) < 0) return r;
 				send = (ShState*)h->shs.p;
 			}
-			int64_t nblk = (n_cur + 31) / 32;
-			if (nblk > 256 * 16) nblk = 256 * 16;
-			hipLaunchKernelGGL(k_sh_round, dim3((unsigned)nblk), dim3(256), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad);
+			// states per octet: enough blocks to fill the chip first, then as many states per cursor atomic as the registers take
+			const int S = n_cur >= ((int64_t)1 << 19) ? 8 : n_cur >= ((int64_t)1 << 17) ? 4 : n_cur >= ((int64_t)1 << 15) ? 2 : 1;
+			const unsigned nblk = (unsigned)((n_cur + 32 * S - 1) / (32 * S));
+#define RB3_SH_ROUND(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad)
+			if (S == 8) RB3_SH_ROUND(8); else if (S == 4) RB3_SH_ROUND(4); else if (S == 2) RB3_SH_ROUND(2); else RB3_SH_ROUND(1);
+#undef RB3_SH_ROUND
 			HIPCHK(hipMemcpyAsync(hc, d_cnt[par], (size_t)(world + 1) * 8, hipMemcpyDeviceToHost, h->st));
 			HIPCHK(hipMemcpyAsync(hc + world + 1, d_bad, 8, hipMemcpyDeviceToHost, h->st));
 			HIPCHK(hipStreamSynchronize(h->st));

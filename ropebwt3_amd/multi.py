@@ -352,6 +352,65 @@ def merge_interval(engine, comm, bounds, d_bwt, d_tw, n2, sent_tp, commit=True, 
     return bounds + grow if commit else bounds
 
 
+class _RawDev:
+    """a device buffer the engine owns, seen by torch (no copy): __cuda_array_interface__ over the raw pointer"""
+
+    def __init__(self, ptr, n_i64):
+        self.__cuda_array_interface__ = {"shape": (int(n_i64),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def sh_comm(h, dist, rank, world, dev, driver="rccl"):
+    """the communicator rb3gpu_sh_merge runs over in a one-process-per-GPU job (bench.py --gpus N --mode interval).
+    driver "rccl": the library's own (rb3gpu_rccl_*: grouped ncclSend/ncclRecv on the engine's stream; the 128-byte id travels
+    through torch.distributed); "torch": two callbacks over torch.distributed (all_gather of the split sizes, all_to_all of views
+    of the engine's send regions) -- also what "rccl" falls back to when librccl cannot be loaded.  Returns (comm, label)."""
+    import torch
+    from ropebwt3_amd import RcclComm, CallbackComm, Rb3GpuError
+    why = ""
+    if driver == "rccl":
+        try:
+            box = [RcclComm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            return RcclComm(h, rank, world, box[0]), "rb3gpu_rccl (ncclSend/ncclRecv grouped per round, on the engine's stream)"
+        except (Rb3GpuError, OSError) as e:   # (every rank fails alike: the library is the same on all of them)
+            why = " [rb3gpu_rccl unavailable: %r]" % (e,)
+
+    def all_gather(vec):
+        v = torch.as_tensor(np.ascontiguousarray(vec, dtype=np.int64), device=dev)
+        out = torch.empty(world * v.numel(), dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_gather_into_tensor(out, v)
+        else:
+            out.copy_(v)
+        return out.cpu().numpy().reshape(world, -1)
+
+    def exchange(d_send, stride, send_cnt, d_recv, recv_cnt):
+        h.sync()
+        ins = [torch.as_tensor(_RawDev(d_send + d * stride * 16, int(send_cnt[d]) * 2), device=dev) if send_cnt[d] else torch.empty(0, dtype=torch.int64, device=dev) for d in range(world)]
+        outs, at = [], 0
+        for s_ in range(world):
+            n = int(recv_cnt[s_])
+            outs.append(torch.as_tensor(_RawDev(d_recv + at * 16, n * 2), device=dev) if n else torch.empty(0, dtype=torch.int64, device=dev))
+            at += n
+        if world > 1:
+            dist.all_to_all(outs, ins)
+        elif ins[0].numel():
+            outs[0].copy_(ins[0])
+        torch.cuda.synchronize()
+
+    return CallbackComm(rank, world, all_gather, exchange), "callbacks over torch.distributed (all_gather_into_tensor + all_to_all of views of the engine's send regions)" + why
+
+
+def merge_interval_c(engine, comm, bounds, d_bwt, d_tw, n2, sent_tp, commit=True, stats=None):
+    """merge_interval with the lock-step loop inside the library (rb3gpu_sh_merge): same arguments, same result"""
+    nb, rounds = engine.sh_merge(comm, bounds, d_bwt, d_tw, n2, sent_tp, commit)
+    if stats is not None:
+        stats["rounds"] = rounds
+        stats["rows_per_rank"] = [int(x) for x in np.diff(nb) - np.diff(np.asarray(bounds, dtype=np.int64))] if commit else None
+    return nb
+
+
 class SoloComm(TorchComm):
     """the interval-sharded protocol with a single interval: no process group is touched"""
 
@@ -388,19 +447,33 @@ def _solo_interval_reference(reads_per_gpu, args, dev, local_rank):
         t2 = util.make_text(list(r))
         d2, d2tw = h1.sort_text(t2)
         sent = np.flatnonzero(t2 == 0).astype(np.int64)
-        comm = SoloComm(dev, sync=lambda: (h1.sync(), torch.cuda.synchronize()))
+        from ropebwt3_amd import CommGroup
         bounds = interval_bounds(b1.size, 1)
-        for _ in range(max(1, args.warmup)):
-            merge_interval(h1, comm, bounds, d2, d2tw, t2.size, sent, commit=False)
-        h1.sync(), torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(args.steps):
-            merge_interval(h1, comm, bounds, d2, d2tw, t2.size, sent, commit=False)
-        h1.sync(), torch.cuda.synchronize()
-        dt = time.perf_counter() - t
+        res = {}
+        for driver in ("library", "python"):   # rb3gpu_sh_merge (one kernel + one read-back per round) against the loop in Python (rounds 1-3)
+            if driver == "library":
+                grp = CommGroup(1)
+                comm, fn = grp.comm(0, h1), merge_interval_c
+            else:
+                comm, fn = SoloComm(dev, sync=lambda: (h1.sync(), torch.cuda.synchronize())), merge_interval
+            stt = {}
+            for _ in range(max(1, args.warmup)):
+                fn(h1, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
+            h1.sync(), torch.cuda.synchronize()
+            h1.stats_reset()
+            t = time.perf_counter()
+            for _ in range(args.steps):
+                fn(h1, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
+            h1.sync(), torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            s1 = h1.stats()
+            res[driver] = {"value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "rounds": stt.get("rounds"),
+                           "us_per_round_walk": round(s1["ms_rank"] / args.steps / max(1, stt.get("rounds") or 1) * 1e3, 2), "ms_rebuild": round(s1["ms_build"] / args.steps, 3)}
         h1.dev_free(d2), h1.dev_free(d2tw)
-        return {"value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "symbols_per_step": int(t2.size),
-                "index_symbols": int(b1.size), "note": "rank 0 alone, same protocol with one interval (no collective), measured after the timed region of this run"}
+        out = dict(res["library"])
+        out.update({"symbols_per_step": int(t2.size), "index_symbols": int(b1.size), "loop_in_python": res["python"],
+                    "note": "rank 0 alone, same protocol with one interval (no collective), measured after the timed region of this run; us_per_round_walk: the walk's wall time per lock-step round (kernel + read-back of the split sizes), rebuild excluded"})
+        return out
     finally:
         h1.close()
 
@@ -451,15 +524,20 @@ def bench_main(args, rank, local_rank, world):
         t2 = util.make_text(list(r))
         d2, d2tw = h.sort_text(t2)
         sent = np.flatnonzero(t2 == 0).astype(np.int64)
-        comm = TorchComm(dist, rank, world, dev, sync=lambda: (h.sync(), torch.cuda.synchronize()))
+        driver = getattr(args, "sh_driver", None) or os.environ.get("RB3_SH_DRIVER", "rccl")
+        if driver == "python":   # rounds 1-3: the lock-step loop in Python, two kernels and two host syncs per round
+            comm, label, fn = TorchComm(dist, rank, world, dev, sync=lambda: (h.sync(), torch.cuda.synchronize())), "loop in Python (multi.merge_interval) over torch.distributed", merge_interval
+        else:
+            comm, label = sh_comm(h, dist, rank, world, dev, driver)
+            fn = merge_interval_c
         stt = {}
         for _ in range(args.warmup):
-            merge_interval(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
+            fn(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
         h.stats_reset()
         barrier()
         t = time.perf_counter()
         for _ in range(args.steps):
-            merge_interval(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
+            fn(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
         barrier()
         dt = time.perf_counter() - t
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -471,9 +549,10 @@ def bench_main(args, rank, local_rank, world):
                    "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
                    "config": {"workload": "interval-sharded index (north_star): %d symbols in %d intervals, one per GPU; per step one batch of %d x 150 bp reads (both strands, %d symbols) merged with one all-to-all per symbol" % (b1.size, world, reads_per_gpu * world, t2.size),
                               "symbols_per_step_per_gpu": int(t2.size // world), "index_symbols": int(b1.size), "parallelism": "interval%d: chain states routed to the owner of their insertion point by RCCL all-to-all(v), %d lock-step rounds per merge; local rebuild per interval" % (world, stt.get("rounds", 0)),
-                              "rows_per_rank": stt.get("rows_per_rank")},
+                              "rows_per_rank": stt.get("rows_per_rank"), "driver": "rb3gpu_sh_merge (the loop inside the library): " + label if fn is merge_interval_c else label,
+                              "us_per_round_rank0": round(s["ms_rank"] / args.steps / max(1, stt.get("rounds") or 1) * 1e3, 2)},
                    "phases_ms_per_step_rank0": {"step_kernels": round(s["ms_rank"] / args.steps, 3), "rebuild": round(s["ms_build"] / args.steps, 3)},
-                   "roofline": {"bound": "hbm", "kernel": "k_sh_step", "achieved": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                   "roofline": {"bound": "hbm", "kernel": "k_sh_round" if fn is merge_interval_c else "k_sh_step", "achieved": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                 "frac": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6 / 8000.0, 5), "traffic": None,
                                 "note": "rank 0: 208 B x the LF steps it executed / the time of its step kernels; the collectives are outside this figure and inside `value`"}}
             # the same per-GPU work on ONE GPU (rank 0 alone, its own handle, no collectives): what weak scaling is measured against

@@ -1172,6 +1172,46 @@ def test_interval_sharded_merge_driven_from_the_library(oracle, world, kind):
     assert all(r == longest for r in rounds), (rounds, longest)   # one round per symbol of the longest string, its sentinel included
 
 
+def test_interval_sharded_merge_many_chains(oracle):
+    """600 k chains of ragged lengths (4..40 symbols) in one batch: the round kernel runs with 8, 4, 2 and 1 states per octet as the
+    chains end (k_sh_round<S>: the launch width follows the number of live chains), two intervals"""
+    import threading
+    from ropebwt3_amd import Rb3Gpu, CommGroup, host, multi
+    world = 2
+    rng = np.random.default_rng(2024)
+    g0 = util.random_genome(rng, 200000)
+    cur = host.build_bwt(util.make_text([g0]))
+    n = 300000
+    st, ln = rng.integers(0, len(g0) - 40, size=n), rng.integers(4, 41, size=n)
+    t2 = util.make_text([g0[a:a + l] for a, l in zip(st, ln)])
+    want = oracle.merge(cur, host.build_bwt(t2.copy()))
+    bounds0 = multi.interval_bounds(cur.size, world)
+    grp = CommGroup(world)
+    errs = []
+
+    def run(rank):
+        try:
+            h = Rb3Gpu(verbose=1)
+            comm = grp.comm(rank, h)
+            h.from_plain(cur[bounds0[rank]:bounds0[rank + 1]])
+            d_bwt, d_tw = h.sort_text(t2)
+            bounds, nr = h.sh_merge(comm, bounds0, d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+            assert nr == 41
+            _check_interval(h, np.random.default_rng(rank), want, bounds, rank)
+            h.close()
+        except BaseException as e:
+            errs.append((rank, repr(e)))
+            grp.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    grp.close()
+    assert not errs, errs
+
+
 def test_interval_sharded_merge_through_callbacks(oracle):
     """the same merge with a communicator made of two Python callables (what a launcher without RCCL -- gloo, MPI -- plugs in):
     two ranks as threads, the all-to-all as device-to-device copies out of the per-destination send regions; and a rank whose

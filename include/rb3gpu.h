@@ -357,6 +357,23 @@ int rb3gpu_rccl_unique_id(char id[RB3GPU_RCCL_ID_BYTES]);
 int rb3gpu_rccl_comm_create(rb3gpu_t *h, int rank, int world, const char id[RB3GPU_RCCL_ID_BYTES], rb3gpu_comm_t *comm);
 void rb3gpu_rccl_comm_destroy(rb3gpu_comm_t *comm);
 
+/* The interval-sharded index as ONE object for a single-process host program (`ropebwt3-amd build --gpus N --interval`): N handles,
+ * one per device, a thread per handle during a merge, the thread-group communicator above between them.
+ *   rb3gpu_shard_split   h0 holds a whole index (the first batch): it is cut into n intervals of about equal length, h0 keeps the
+ *                        first, n - 1 new handles (options *opt, devices[1..n-1]; devices[0] must be h0's) get the others, device to
+ *                        device.  NULL: fewer symbols than intervals, or a device / memory error.
+ *   rb3gpu_shard_merge   one batch (BWT and text-order words on h0's device, sentinel positions on the host): replicated to the other
+ *                        devices over xGMI, merged by n threads running rb3gpu_sh_merge.
+ *   rb3gpu_shard_gather  the intervals are put back together in h0 (plain symbols, device to device), the other handles destroyed and
+ *                        the object freed: h0 then serves every export call as if the build had run on it alone.
+ *   rb3gpu_shard_handle  the handle of interval i (statistics, tests); rb3gpu_shard_bounds copies the n + 1 bounds, returns n. */
+typedef struct rb3gpu_shard_s rb3gpu_shard_t;
+rb3gpu_shard_t *rb3gpu_shard_split(rb3gpu_t *h0, int n, const int *devices, const rb3gpu_opt_t *opt);
+int rb3gpu_shard_merge(rb3gpu_shard_t *s, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_chains, const int64_t *chain_tp, int64_t *n_rounds);
+int rb3gpu_shard_gather(rb3gpu_shard_t *s);
+rb3gpu_t *rb3gpu_shard_handle(rb3gpu_shard_t *s, int i);
+int rb3gpu_shard_bounds(const rb3gpu_shard_t *s, int64_t *bounds);
+
 /* the HIP device and stream of a handle (for communicators implemented outside the library) */
 int rb3gpu_device_of(const rb3gpu_t *h);
 void *rb3gpu_stream_of(const rb3gpu_t *h);

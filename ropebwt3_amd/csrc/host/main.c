@@ -30,7 +30,7 @@ enum { FMT_PLAIN = 0, FMT_FMD, FMT_FMR };
 typedef struct {
 	int64_t flag, batch_size;
 	int fmt, n_threads, sais_threads, block_len, max_nodes;
-	int device, n_gpus, split_log2, rebatch, gpu_sort, host_fmd;
+	int device, n_gpus, split_log2, rebatch, gpu_sort, host_fmd, interval;
 	int64_t gpu_batch;      /* with GPU suffix sorting a batch (-m) is cut into sub-batches of at most this many symbols, at record
 	                           boundaries: the .fmd does not depend on the batching, and the GPU sorter takes < 2^31 */
 	int64_t gpu_sort_limit; /* batches of this many symbols or more go to the host sorter (one record longer than a sub-batch) */
@@ -72,6 +72,9 @@ static int usage_build(FILE *fp, const bopt_t *opt)
 	fprintf(fp, "    --gpu INT   HIP device ordinal [%d]\n", opt->device);
 	fprintf(fp, "    --gpus INT  build on INT GPUs: the input files are cut into INT contiguous slices, every GPU indexes one (devices --gpu,\n");
 	fprintf(fp, "                --gpu + 1, ...), and the indexes are merged pairwise in input order (same output) [1]\n");
+	fprintf(fp, "    --interval  with --gpus INT: ONE index cut into INT intervals of positions, one per GPU; every batch after the first is\n");
+	fprintf(fp, "                merged by all GPUs in lock step, its strings' LF chains hopping between the GPUs that own their insertion\n");
+	fprintf(fp, "                points (for batches of short strings: one round per symbol of the longest one; same output)\n");
 	fprintf(fp, "    --split INT start extra LF walkers every 2^INT rows (0=auto, -1=never) [%d]\n", opt->split_log2);
 	fprintf(fp, "    --rebatch   let a batch span input files (same output, fewer merge rounds)\n");
 	fprintf(fp, "    --host-sort suffix-sort the batches on the host (default: on the GPU; same output; -p then sets the number\n");
@@ -285,6 +288,7 @@ typedef struct {
 	void *d_tw;               /* device: its text-order words (long strings: the walkers are then given by text position) */
 	void *d_sa;               /* device: its suffix array, behind them (the engine leaves its records in text order where that pays) */
 	rb3gpu_sorter_t *gs;
+	int64_t *sent, n_sent;    /* --interval: text positions of the batch's sentinels (where its LF chains start) */
 } batch_t;
 
 static int g_pin_on = 0; /* batch buffers (and walker lists) in page-locked memory */
@@ -310,6 +314,38 @@ static void walkers_free(batch_t *b)
 	b->walkers = 0, b->walkers_pinned = 0;
 }
 
+/* --gpus N --interval: the index lives in N intervals on N devices from the second batch on (rb3gpu_shard_*, include/rb3gpu.h) */
+static struct { int n, devices[RB3GPU_SH_MAXIV]; rb3gpu_shard_t *s; rb3gpu_opt_t gopt; double t_walk; int64_t rounds, batches; } g_iv;
+
+static int64_t *sentinels_of(const uint8_t *text, int64_t len, int64_t n_hint, int64_t *n_out)
+{
+	int64_t n = 0, m = n_hint > 16 ? n_hint : 16, *a = (int64_t*)malloc((size_t)m * 8);
+	const uint8_t *p = text, *end = text + len;
+	while (a && p < end && (p = (const uint8_t*)memchr(p, 0, (size_t)(end - p))) != 0) {
+		if (n == m) { int64_t *t = (int64_t*)realloc(a, (size_t)(m *= 2) * 8); if (t == 0) { free(a); a = 0; break; } a = t; }
+		a[n++] = p - text, ++p;
+	}
+	*n_out = a ? n : 0;
+	return a;
+}
+
+/* one batch into the sharded index; the first call cuts the index the handle holds into its intervals */
+static int interval_merge(rb3gpu_t *h, int64_t len, const void *d_bwt, const void *d_tw, int64_t n_sent, const int64_t *sent)
+{
+	int64_t rounds = 0;
+	int r;
+	const double t0 = rb3h_realtime();
+	if (sent == 0 || n_sent <= 0 || d_tw == 0) return RB3GPU_EINVAL;
+	if (g_iv.s == 0) {
+		if (rb3gpu_get_tot(h) < g_iv.n) return rb3gpu_merge_text_dev(h, len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, n_sent, 0, 1); /* (fewer symbols than intervals: not cut yet) */
+		if ((g_iv.s = rb3gpu_shard_split(h, g_iv.n, g_iv.devices, &g_iv.gopt)) == 0) return RB3GPU_ENODEV;
+		if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] index cut into %d intervals\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), g_iv.n);
+	}
+	r = rb3gpu_shard_merge(g_iv.s, len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, n_sent, sent, &rounds);
+	g_iv.t_walk += rb3h_realtime() - t0, g_iv.rounds += rounds, ++g_iv.batches;
+	return r;
+}
+
 /* --gpu-sort: the batch arrives as text; suffix sorting, BWT and inverse suffix array on the GPU
  * (rb3gpu_sort_text / rb3gpu_bwt_from_text instead of rb3_build_sais, build.c:220), the BWT never leaves HBM */
 static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
@@ -331,7 +367,11 @@ static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	if (ret == 0 && rb3h_verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
 	if (ret == 0 && !*has_index) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)d_bwt);
-	else if (ret == 0 && text_walk) {
+	else if (ret == 0 && text_walk && g_iv.n > 1) {
+		int64_t n_sent = 0, *sent = sentinels_of(b->bwt, b->len, b->n_seq, &n_sent);
+		ret = sent ? interval_merge(h, b->len, d_bwt, d_tw, n_sent, sent) : RB3GPU_ENOMEM;
+		free(sent);
+	} else if (ret == 0 && text_walk) {
 		if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) ret = RB3GPU_ENOMEM;
 		else if (b->step > 0) ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
 		else ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, b->n_seq, 0, 1); /* short strings: one walker per string */
@@ -347,6 +387,7 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	if (b->d_bwt) { /* sorted on the GPU by a sorter thread while the batch before was being merged */
 		const int first = !*has_index;
 		if (first) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)b->d_bwt);
+		else if (g_iv.n > 1) ret = interval_merge(h, b->len, b->d_bwt, b->d_tw, b->n_sent, b->sent);
 		else if (b->walkers && b->d_tw) ret = rb3gpu_merge_text_sa_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, (const uint32_t*)b->d_sa, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
 		else if (b->d_tw && b->step == 0 && b->n_seq > 0) ret = rb3gpu_merge_text_sa_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, (const uint32_t*)b->d_sa, b->n_seq, 0, 1); /* short strings: one walker per string */
 		else ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)b->d_bwt, 1);
@@ -366,6 +407,9 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 		}
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] %s the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), first ? "encoded" : "merged", (long)b->len);
+	} else if (g_iv.n > 1 && *has_index) {
+		fprintf(stderr, "ERROR: --interval merges batches the GPU sorted (their text-order words); this one was sorted on the host\n");
+		return -1;
 	} else if (!*has_index) {
 		ret = rb3gpu_from_plain(h, b->len, b->bwt);
 		if (ret == 0 && rb3h_verbose >= 3)
@@ -440,6 +484,7 @@ static int sort_batch(const bopt_t *opt, int device, rb3h_buf_t *seq, int64_t n_
 				if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0, b->d_tw = b->d_sa = 0;
 				walkers_pin(b);
 				b->gs = gs, b->raw = 0;
+				if (opt->interval) b->sent = sentinels_of(b->bwt, b->len, n_seq, &b->n_sent);
 				__sync_fetch_and_add(&g_sorted.n_gpu, 1), __sync_fetch_and_add(&g_sorted.sym_gpu, b->len);
 				rb3h_batch_free(b->bwt); b->bwt = 0; /* the text is not needed any more */
 			} else b->d_bwt = b->d_tw = b->d_sa = 0; /* leave it to the consumer (its handle's sorter, then the host sorter) */
@@ -521,7 +566,7 @@ static int consume(consumer_t *c, batch_t *b, int end_of_file)
 {
 	if (b) {
 		int r = process_batch(c->h, b, &c->has_index);
-		rb3h_batch_free(b->bwt); walkers_free(b); free(b);
+		rb3h_batch_free(b->bwt); walkers_free(b); free(b->sent); free(b);
 		if (r < 0) return r;
 	}
 	if (end_of_file && c->fn_tmp && c->has_index) { /* build.c:232-238 */
@@ -665,7 +710,7 @@ static void *run_slice(void *arg)
 			if (ret == 0) ret = consume(&cs, j.out, j.end_of_file);
 			else if (j.out) {
 				if (j.out->d_bwt) rb3gpu_sorter_release(j.out->gs, j.out->d_bwt);
-				rb3h_batch_free(j.out->bwt); walkers_free(j.out); free(j.out);
+				rb3h_batch_free(j.out->bwt); walkers_free(j.out); free(j.out->sent); free(j.out);
 			}
 		}
 		pthread_join(rt, 0);
@@ -704,6 +749,7 @@ static const struct option long_opts[] = {
 	{ "gpu-sort-limit", required_argument, 0, 307 }, /* (tests: pretend the GPU sorter takes less than it does) */
 	{ "host-fmd", no_argument, 0, 308 },
 	{ "gpus", required_argument, 0, 309 },
+	{ "interval", no_argument, 0, 310 },
 	{ 0, 0, 0, 0 }
 };
 
@@ -749,6 +795,7 @@ int main_build(int argc, char *argv[])
 		else if (c == 307) opt.gpu_sort_limit = rb3h_parse_num(optarg);
 		else if (c == 308) opt.host_fmd = g_host_fmd = 1;
 		else if (c == 309) opt.n_gpus = atoi(optarg);
+		else if (c == 310) opt.interval = 1;
 		else if (c == '?') return 1;
 	}
 	if (opt.gpu_sort_limit > (int64_t)INT32_MAX - 16) opt.gpu_sort_limit = (int64_t)INT32_MAX - 16;
@@ -797,6 +844,18 @@ int main_build(int argc, char *argv[])
 	 * with its own reader and sorter, as kt_for spreads the chains of a batch, fm-index.c:217-224); with a pipe or a .gz among the
 	 * inputs the slices are whole files. */
 	int64_t *fsize = 0, total_bytes = 0;
+	memset(&g_iv, 0, sizeof(g_iv));
+	if (opt.interval && opt.n_gpus > 1) { /* ONE reader / sorter / consumer; the index is what is spread over the GPUs (north_star's split) */
+		const int ndev = rb3gpu_device_count();
+		if (!opt.gpu_sort || fn_tmp || opt.n_gpus > RB3GPU_SH_MAXIV) {
+			fprintf(stderr, "ERROR: --interval needs GPU suffix sorting, no -S and at most %d GPUs\n", RB3GPU_SH_MAXIV);
+			rb3gpu_destroy(h);
+			return 1;
+		}
+		g_iv.n = opt.n_gpus, g_iv.gopt = gopt;
+		for (c = 0; c < g_iv.n; ++c) g_iv.devices[c] = (opt.device + c) % (ndev > 0 ? ndev : 1);
+		opt.n_gpus = 1;
+	}
 	int by_bytes = opt.n_gpus > 1 && argc - optind >= 1;
 	if (by_bytes) {
 		fsize = (int64_t*)calloc((size_t)(argc - optind), sizeof(int64_t));
@@ -885,6 +944,13 @@ int main_build(int argc, char *argv[])
 		free(sl); free(th); free(rb);
 	}
 	free(fsize);
+	if (g_iv.s) { /* --interval: the intervals back into one handle for the writers below */
+		const int r = rb3gpu_shard_gather(g_iv.s);
+		g_iv.s = 0;
+		if (r < 0) { fprintf(stderr, "ERROR: the GPU engine failed to put the intervals together: %s\n", rb3gpu_strerror(r)); ret = -1; }
+		else if (rb3h_verbose >= 3)
+			fprintf(stderr, "[M::%s::%.3f*%.2f] %ld batches merged into %d intervals: %ld lock-step rounds, %.3f s\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), (long)g_iv.batches, g_iv.n, (long)g_iv.rounds, g_iv.t_walk);
+	}
 	if (n_empty > 0 && rb3h_verbose >= 2)
 		fprintf(stderr, "WARNING: skipped %ld empty sequence(s)\n", (long)n_empty);
 

@@ -305,3 +305,164 @@ void rb3gpu_rccl_comm_destroy(rb3gpu_comm_t *comm)
 }
 
 } // extern "C"
+
+/* ---- the interval-sharded index as one object (a single-process host program: the CLI) ---- */
+
+struct rb3gpu_shard_s {
+	int n = 0;
+	rb3gpu_t *h[RB3GPU_SH_MAXIV];        // h[0] is the caller's
+	int dev[RB3GPU_SH_MAXIV];
+	int64_t bounds[RB3GPU_SH_MAXIV + 1];
+	rb3gpu_group_t *grp = nullptr;
+	void *rep_bwt[RB3GPU_SH_MAXIV], *rep_tw[RB3GPU_SH_MAXIV]; // replicas of the batch on the devices of intervals 1.. (kept between merges)
+	int64_t rep_cap[RB3GPU_SH_MAXIV];
+};
+
+static int copy_across(void *dst, int ddev, const void *src, int sdev, size_t n)
+{
+	if (n == 0) return 0;
+	const hipError_t e = ddev == sdev ? hipMemcpy(dst, src, n, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, ddev, src, sdev, n);
+	if (e != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	return 0;
+}
+
+struct ShardJob { rb3gpu_shard_s *s; int rank; int64_t len; const uint8_t *d_bwt; const uint64_t *d_tw; int64_t n_chains; const int64_t *chain_tp; int64_t bounds[RB3GPU_SH_MAXIV + 1]; int64_t rounds; int ret; };
+
+static void *shard_thread(void *arg)
+{
+	ShardJob *j = (ShardJob*)arg;
+	rb3gpu_comm_t comm;
+	j->ret = rb3gpu_group_comm(j->s->grp, j->rank, j->s->h[j->rank], &comm);
+	if (j->ret < 0) { rb3gpu_group_abort(j->s->grp); return nullptr; }
+	j->ret = rb3gpu_sh_merge(j->s->h[j->rank], &comm, j->bounds, j->len, j->d_bwt, j->d_tw, j->n_chains, j->chain_tp, 1, &j->rounds);
+	return nullptr;
+}
+
+extern "C" {
+
+static void shard_free(rb3gpu_shard_s *s, bool handles)
+{
+	for (int i = 1; i < s->n; ++i) {
+		if (s->h[i]) {
+			if (s->rep_bwt[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_bwt[i]);
+			if (s->rep_tw[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_tw[i]);
+			if (handles) rb3gpu_destroy(s->h[i]);
+		}
+	}
+	rb3gpu_group_destroy(s->grp);
+	delete s;
+}
+
+rb3gpu_shard_t *rb3gpu_shard_split(rb3gpu_t *h0, int n, const int *devices, const rb3gpu_opt_t *opt)
+{
+	if (!h0 || !devices || !opt || n < 1 || n > RB3GPU_SH_MAXIV || devices[0] != rb3gpu_device_of(h0)) return nullptr;
+	const int64_t tot = rb3gpu_get_tot(h0);
+	if (tot < n) return nullptr;
+	rb3gpu_shard_s *s = new (std::nothrow) rb3gpu_shard_s;
+	if (!s) return nullptr;
+	s->n = n;
+	for (int i = 0; i < RB3GPU_SH_MAXIV; ++i) s->h[i] = nullptr, s->rep_bwt[i] = s->rep_tw[i] = nullptr, s->rep_cap[i] = 0, s->dev[i] = 0;
+	s->h[0] = h0;
+	for (int i = 0; i <= n; ++i) s->bounds[i] = tot / n * i + (tot % n) * i / n;
+	s->bounds[n] = tot;
+	if ((s->grp = rb3gpu_group_create(n)) == nullptr) { delete s; return nullptr; }
+	void *plain = nullptr;
+	int r = n > 1 ? rb3gpu_dev_alloc(h0, tot, &plain) : 0;
+	if (r == 0 && n > 1) r = rb3gpu_export_plain_dev(h0, (uint8_t*)plain);
+	for (int i = 0; i < n && r == 0; ++i) {
+		s->dev[i] = devices[i];
+		const int64_t len = s->bounds[i + 1] - s->bounds[i];
+		if (i == 0) { if (n > 1) r = rb3gpu_from_plain_dev(h0, len, (const uint8_t*)plain); continue; } // (h0 rebuilds itself from the copy: its first interval)
+		rb3gpu_opt_t o = *opt;
+		o.device = devices[i];
+		if ((s->h[i] = rb3gpu_create(&o)) == nullptr) { r = RB3GPU_ENODEV; break; }
+		void *part = nullptr;
+		if ((r = rb3gpu_dev_alloc(s->h[i], len, &part)) < 0) break;
+		r = copy_across(part, s->dev[i], (const uint8_t*)plain + s->bounds[i], s->dev[0], (size_t)len);
+		if (r == 0) r = rb3gpu_from_plain_dev(s->h[i], len, (const uint8_t*)part);
+		(void)rb3gpu_dev_free(s->h[i], part);
+	}
+	if (plain) (void)rb3gpu_dev_free(h0, plain);
+	if (r < 0) { shard_free(s, true); return nullptr; } // (h0 may hold its first interval only: the caller gives the build up)
+	return s;
+}
+
+int rb3gpu_shard_merge(rb3gpu_shard_t *s, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_chains, const int64_t *chain_tp, int64_t *n_rounds)
+{
+	if (!s || len <= 0 || !d_bwt || !d_tw || n_chains <= 0 || !chain_tp) return RB3GPU_EINVAL;
+	int r;
+	// the batch on every device (1 + 8 bytes per symbol, device to device)
+	for (int i = 1; i < s->n; ++i) {
+		if (s->dev[i] == s->dev[0]) continue; // (several intervals on one device: they read the same copy)
+		if (s->rep_cap[i] < len) {
+			if (s->rep_bwt[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_bwt[i]);
+			if (s->rep_tw[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_tw[i]);
+			s->rep_bwt[i] = s->rep_tw[i] = nullptr, s->rep_cap[i] = 0;
+			const int64_t cap = len + (len >> 2);
+			if ((r = rb3gpu_dev_alloc(s->h[i], cap, &s->rep_bwt[i])) < 0 || (r = rb3gpu_dev_alloc(s->h[i], cap * 8, &s->rep_tw[i])) < 0) return r;
+			s->rep_cap[i] = cap;
+		}
+		if ((r = copy_across(s->rep_bwt[i], s->dev[i], d_bwt, s->dev[0], (size_t)len)) < 0) return r;
+		if ((r = copy_across(s->rep_tw[i], s->dev[i], d_tw, s->dev[0], (size_t)len * 8)) < 0) return r;
+	}
+	ShardJob *jobs = new (std::nothrow) ShardJob[s->n];
+	pthread_t *th = new (std::nothrow) pthread_t[s->n];
+	if (!jobs || !th) { delete[] jobs; delete[] th; return RB3GPU_ENOMEM; }
+	for (int i = 0; i < s->n; ++i) {
+		const bool here = i == 0 || s->dev[i] == s->dev[0];
+		jobs[i].s = s, jobs[i].rank = i, jobs[i].len = len, jobs[i].n_chains = n_chains, jobs[i].chain_tp = chain_tp, jobs[i].rounds = 0, jobs[i].ret = 0;
+		jobs[i].d_bwt = here ? d_bwt : (const uint8_t*)s->rep_bwt[i], jobs[i].d_tw = here ? d_tw : (const uint64_t*)s->rep_tw[i];
+		memcpy(jobs[i].bounds, s->bounds, sizeof(s->bounds));
+	}
+	int started = 0;
+	for (int i = 1; i < s->n; ++i, ++started)
+		if (pthread_create(&th[i], nullptr, shard_thread, &jobs[i]) != 0) { rb3gpu_group_abort(s->grp); jobs[i].ret = RB3GPU_ENOMEM; break; }
+	if (started == s->n - 1) shard_thread(&jobs[0]); // interval 0 on the calling thread
+	else jobs[0].ret = RB3GPU_ENOMEM;
+	for (int i = 1; i <= started; ++i) pthread_join(th[i], nullptr);
+	r = 0;
+	for (int i = 0; i < s->n; ++i) if (jobs[i].ret < 0 && (r == 0 || r == RB3GPU_ESTATE)) r = jobs[i].ret; // (ESTATE: a rank that was only woken up by another one's failure)
+	if (r == 0) {
+		memcpy(s->bounds, jobs[0].bounds, sizeof(s->bounds));
+		if (n_rounds) *n_rounds = jobs[0].rounds;
+	}
+	delete[] jobs;
+	delete[] th;
+	return r;
+}
+
+int rb3gpu_shard_gather(rb3gpu_shard_t *s)
+{
+	if (!s) return RB3GPU_EINVAL;
+	int r = 0;
+	if (s->n > 1) {
+		const int64_t tot = s->bounds[s->n];
+		void *plain = nullptr;
+		if ((r = rb3gpu_dev_alloc(s->h[0], tot, &plain)) == 0) {
+			for (int i = 0; i < s->n && r == 0; ++i) {
+				const int64_t len = s->bounds[i + 1] - s->bounds[i];
+				if (rb3gpu_get_tot(s->h[i]) != len) { r = RB3GPU_EINTERNAL; break; }
+				if (s->dev[i] == s->dev[0]) { r = rb3gpu_export_plain_dev(s->h[i], (uint8_t*)plain + s->bounds[i]); continue; }
+				void *part = nullptr;
+				if ((r = rb3gpu_dev_alloc(s->h[i], len, &part)) < 0) break;
+				if ((r = rb3gpu_export_plain_dev(s->h[i], (uint8_t*)part)) == 0) r = copy_across((uint8_t*)plain + s->bounds[i], s->dev[0], part, s->dev[i], (size_t)len);
+				(void)rb3gpu_dev_free(s->h[i], part);
+			}
+			if (r == 0) r = rb3gpu_from_plain_dev(s->h[0], tot, (const uint8_t*)plain);
+			(void)rb3gpu_dev_free(s->h[0], plain);
+		}
+	}
+	shard_free(s, true);
+	return r;
+}
+
+rb3gpu_t *rb3gpu_shard_handle(rb3gpu_shard_t *s, int i) { return s && i >= 0 && i < s->n ? s->h[i] : nullptr; }
+
+int rb3gpu_shard_bounds(const rb3gpu_shard_t *s, int64_t *bounds)
+{
+	if (!s || !bounds) return RB3GPU_EINVAL;
+	memcpy(bounds, s->bounds, (size_t)(s->n + 1) * 8);
+	return s->n;
+}
+
+} // extern "C"

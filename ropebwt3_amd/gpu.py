@@ -121,6 +121,11 @@ SYMBOLS = {
     "rb3gpu_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rb3gpu_rccl_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_rccl_comm_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_shard_split": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_shard_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_shard_gather": (ctypes.c_int, [ctypes.c_void_p]),
+    "rb3gpu_shard_handle": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "rb3gpu_shard_bounds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_device_of": (ctypes.c_int, [ctypes.c_void_p]),
     "rb3gpu_stream_of": (ctypes.c_void_p, [ctypes.c_void_p]),
 }
@@ -652,3 +657,38 @@ class CallbackComm:
 
         self._keep = (ALL_GATHER_F(_ag), ALL_TO_ALL_F(_a2a), ABORT_F(_ab))   # the C side holds raw pointers to these
         self.struct = CommStruct(None, self.rank, self.world, ctypes.cast(self._keep[0], ctypes.c_void_p), ctypes.cast(self._keep[1], ctypes.c_void_p), ctypes.cast(self._keep[2], ctypes.c_void_p))
+
+
+class Shard:
+    """rb3gpu_shard_*: the index of `engine` cut into n intervals (one handle per device of `devices`), batches merged by n threads
+    inside the library, put back together by gather()"""
+
+    def __init__(self, engine, devices):
+        self._e, self._lib = engine, engine._lib
+        dev = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        opt = Opt()
+        self._lib.rb3gpu_opt_init(ctypes.byref(opt))
+        opt.verbose = 1
+        self._s = self._lib.rb3gpu_shard_split(engine._h, len(devices), dev, ctypes.addressof(opt))
+        if not self._s:
+            raise Rb3GpuError(-1, "rb3gpu_shard_split")
+        self.n = len(devices)
+
+    def bounds(self):
+        b = np.zeros(self.n + 1, dtype=np.int64)
+        self._lib.rb3gpu_shard_bounds(self._s, b.ctypes.data)
+        return b
+
+    def merge(self, d_bwt, d_tw, n2, sent_tp):
+        tp = np.ascontiguousarray(sent_tp, dtype=np.int64)
+        rounds = ctypes.c_int64(0)
+        r = self._lib.rb3gpu_shard_merge(self._s, int(n2), d_bwt, d_tw, tp.size, tp.ctypes.data, ctypes.addressof(rounds))
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_shard_merge")
+        return int(rounds.value)
+
+    def gather(self):
+        s, self._s = self._s, None
+        r = self._lib.rb3gpu_shard_gather(s)
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_shard_gather")

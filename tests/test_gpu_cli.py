@@ -87,6 +87,22 @@ def test_multi_gpu_build_of_reads(tmp_path):
     assert out1 == out
 
 
+@pytest.mark.parametrize("n,extra", [(2, ["-m40k"]), (3, ["-m25k", "-p2"]), (4, ["-m60k", "-p0"])])
+def test_multi_gpu_build_with_the_index_cut_into_intervals(n, extra):
+    """`build --gpus N --interval` (north_star's split, driven from C): after the first batch the index is cut into N intervals of
+    positions, one handle each (here all on device 0); every later batch of reads is merged by N threads in lock step, the LF
+    chains hopping between the intervals (rb3gpu_shard_merge -> rb3gpu_sh_merge over the thread-group communicator); the
+    intervals are put back together for the writer: the reference's .fmd, both strands and forward only"""
+    for name in ("reads_fwd", "reads_rev", "reads_fq", "copies3000", "edge_dups"):   # forward only, reverse only, both strands (FASTA), exact copies, duplicates
+        ent = MAN[name]
+        inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+        small = name == "edge_dups"
+        out, err = run(["build"] + ent["flags"] + ["-d", "--gpus", str(n), "--interval"] + (["-m9"] if small else extra) + inputs)
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (name, n)
+        assert ("index cut into %d intervals" % n in err) == ("lock-step rounds" in err)   # (a single batch is never cut)
+        assert "lock-step rounds" in err or small or name == "reads_rev"
+
+
 def test_gzip_through_a_pipe_on_stdin():
     """`cat x.fa.gz | build -`: the same .fmd as from the file (the reader must not eat the gzip magic of a pipe)"""
     ent = MAN["genomes12"]

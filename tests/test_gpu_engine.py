@@ -1212,6 +1212,31 @@ def test_interval_sharded_merge_many_chains(oracle):
     assert not errs, errs
 
 
+def test_shard_object_split_merge_gather(oracle):
+    """rb3gpu_shard_*: what the CLI's --interval mode calls -- split the index of a handle into intervals (device-to-device copies
+    of its plain symbols), merge batches with a thread per interval inside the library, gather: the handle then holds the oracle's
+    merged BWT and exports it like any other"""
+    from ropebwt3_amd import Rb3Gpu, Shard
+    rng = np.random.default_rng(4)
+    cur, batches, want = _sharded_case(oracle, rng, "reads")
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_plain(cur)
+        sh = Shard(h, [0, 0, 0])
+        b = sh.bounds()
+        assert b[0] == 0 and b[-1] == cur.size and np.all(np.diff(b) > 0)
+        for t2 in batches:
+            d_bwt, d_tw = h.sort_text(t2)
+            sh.merge(d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+            h.dev_free(d_bwt), h.dev_free(d_tw)
+        assert sh.bounds()[-1] == want[-1].size and h.get_tot() == sh.bounds()[1]   # the handle holds its interval only
+        sh.gather()
+        assert h.get_tot() == want[-1].size
+        assert np.array_equal(h.export_plain(), want[-1])
+    finally:
+        h.close()
+
+
 def test_interval_sharded_merge_through_callbacks(oracle):
     """the same merge with a communicator made of two Python callables (what a launcher without RCCL -- gloo, MPI -- plugs in):
     two ranks as threads, the all-to-all as device-to-device copies out of the per-destination send regions; and a rank whose

@@ -645,6 +645,7 @@ static int scan_records(rb3gpu_t *h, const uint32_t *in, int64_t nrec, uint64_t 
 #define MISC_WIDE     39   /* k_chain: steps of walkers that could not record tentatively because their interval is wider than the masks */
 #define MISC_RG_OVER  32   /* set by k_decide<LISTED> / k_plane_group<LISTED>: the hand-over list of the run-space rebuild is longer than the scratch of the symbol path */
 #define MISC_PP_OK    33   /* k_plane_group: groups whose old range holds no bit-plane slot (the run-space rebuild could take them) */
+#define MISC_BAD_WALKERS RB3_MISC_BADW /* k_chain: entries of the caller's walker list that are not walkers of this batch (row outside it, no steps) */
 
 /* build a block array for ntot symbols into ib[1-cur]; FROM_PLAIN: symbols are d_b2[0..ntot);
  * otherwise the interleave of the current index with d_b2 at merged positions pos[].
@@ -1374,7 +1375,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	// one launch clears what this merge accumulates into: the counters (the scan totals behind them are written later), the
 	// stretches the merge before opened, the rows-per-window table of the rebuild, and -- text-order walk -- the row records
 	fill_add(&jb, misc, 128, 0u);
-	fill_add(&jb, misc + MISC_RG_OVER, tent ? (size_t)(MISC_WORDS - MISC_RG_OVER) * 8 : 64, 0u); // (... MISC_WIDE, and the id counters behind them)
+	fill_add(&jb, misc + MISC_RG_OVER, tent ? (size_t)(MISC_WORDS - MISC_RG_OVER) * 8 : (size_t)(MISC_BAD_WALKERS + 1 - MISC_RG_OVER) * 8, 0u); // (... MISC_WIDE, MISC_BAD_WALKERS, and the id counters behind them)
 	// (the rows-per-window table is not cleared: k_pos_finalize_check_rows writes every entry when pos[] validates, and when it does not the
 	// validation counters make every rebuild kernel return before it reads the table -- 42 MB of fill per round of a 1.3 G-symbol build)
 	const bool rows_filled = d_tw != nullptr && jb.n < 8;
@@ -1385,18 +1386,15 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	// The histogram of the batch and its scan (the C array of B2 and the rows before every tile, fm-index.c:206-216): a text-order walk
 	// does not read them -- the validation behind it and the host do --, so they run on the side stream, beside the walkers.
 	const bool lf_beside = rows_filled && !auto_list;
-	if (lf_beside) {
-		if ((r = buf_ensure(h, h->ctot2, (size_t)(((len + RB3_TILE - 1) / RB3_TILE + RB3_SCAN_CHUNK - 1) / RB3_SCAN_CHUNK + 1) * 64)) < 0) return r; // (before any launch)
-	}
-	if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr, rows_filled, lf_beside)) < 0) return r;
-	if (lf_beside) HIPCHK(hipEventRecord(h->evx[2], h->st2));
+	if (lf_beside) { // (every allocation before the walkers are launched: hipMalloc may synchronise)
+		const int64_t ntile = (len + RB3_TILE - 1) / RB3_TILE;
+		if ((r = buf_ensure(h, h->ctot2, (size_t)((ntile + RB3_SCAN_CHUNK - 1) / RB3_SCAN_CHUNK + 1) * 64)) < 0) return r;
+		if ((r = buf_ensure(h, h->tcnt, (size_t)ntile * 32)) < 0) return r;
+		if ((r = buf_ensure(h, h->tpre, (size_t)ntile * 64)) < 0) return r;
+	} else if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr, rows_filled, false)) < 0) return r;
+	// (lf_beside: the histogram kernels are queued BEHIND the walkers' launch, further down -- the host needs ~30 us for their five calls, and with
+	// them and the check of the caller's walker list, now done by k_chain itself, in front of it the walkers started ~85 us after the fill kernel)
 	HIPCHK(hipEventRecord(h->ev[1], h->st));
-	for (int64_t i = 0; walkers && i < n_walkers; ++i)
-		if (walkers[i].row < 0 || walkers[i].row >= len || walkers[i].nsteps <= 0) { // not a walker list for this batch: nothing has been walked
-			(void)hipStreamSynchronize(h->st);
-			h->reb_prepared = false;
-			return RB3GPU_EINVAL;
-		}
 #ifdef RB3_PROF_STEP
 	HIPCHK(hipMemsetAsync(misc + 34, 0, 40, h->st));
 #endif
@@ -1513,6 +1511,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #undef RB3_LAUNCH_FAST
 #undef RB3_LAUNCH_FAST1
 		HIPCHK(hipEventRecord(h->ev[7], h->st));
+		if (lf_beside) {
+			if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, false, true, true)) < 0) return r;
+			HIPCHK(hipEventRecord(h->evx[2], h->st2));
+		}
 		if (tent) {
 			launch_settle(h, iv, tab, mx, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS, tq, (const uint32_t*)mctr), h->stt.tent_mask_bits = 256 * tq;
 		}
@@ -1551,7 +1553,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) return r;
 	HIPCHK(hipEventRecord(h->ev[3], h->st));
 	if (lf_side) HIPCHK(hipStreamWaitEvent(h->st, h->evx[1], 0));
-	unsigned long long hm[40];
+	unsigned long long hm[48];
 	// The only synchronisation of the merge.  The counters land in page-locked memory: a copy into pageable memory goes through a
 	// staging buffer of the runtime, ~10 us more per merge (151 merges per build).
 	unsigned long long *hml = h->hm_pin ? h->hm_pin : hm;
@@ -1598,6 +1600,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)hm[MISC_LF_TOT + a];
 	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
 	if (per_string && acc2[1] != n_walkers) return RB3GPU_EINVAL; // not the number of strings of this batch (nothing was installed)
+	if (hm[MISC_BAD_WALKERS] != 0) return RB3GPU_EINVAL; // not a walker list for this batch (k_chain skipped those entries; nothing was installed)
 #ifdef RB3_DEBUG_B2
 	if (auto_list) { // kernel experiment: what the device-made list looks like
 		const int64_t nw = (int64_t)hm[13];

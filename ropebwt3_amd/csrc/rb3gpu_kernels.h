@@ -648,6 +648,7 @@ __global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, cons
  *                 arrived with in *arrive for the neighbour rank.
  */
 struct Walker { int64_t row, ka0, nsteps, flags; };
+#define RB3_MISC_BADW 40 /* word of the merge's counter block (rb3gpu.hip: misc[]; k_chain's nsteps is misc + 1) that counts list entries which are not walkers of the batch */
 #define RB3_WK_CHECK 2
 
 /* row words are read and written with agent-scope relaxed atomics: a record must reach the L2 where walkers
@@ -1087,10 +1088,13 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				kb = w.row, remaining = w.nsteps;
 				probe = (int)(w.flags >> 16 & 0xFF);
 				if (!TEXT && kb < 0) continue; // an empty slot of a device-made list
-				if (TEXT) {
-					tp = w.row;
-					if (tp < 0 || tp >= n2) continue; // (a per-string list whose string count was wrong: the rows stay unset)
+				// not a walker of this batch (a caller's list is checked HERE, by the octet that takes the walker, not by a loop on the host
+				// that the device waited for: 40 k entries took the host ~40 us per merge with the chip idle): counted, the host returns EINVAL
+				if ((uint64_t)w.row >= (uint64_t)n2 || w.nsteps <= 0) {
+					if (j == 0 && !(TEXT && w.row < 0)) atomicAdd(nsteps + (RB3_MISC_BADW - 1), 1ull); // (TEXT, row -1: a per-string list whose string count was wrong: the rows stay unset)
+					continue;
 				}
+				if (TEXT) tp = w.row;
 				if (w.ka0 >= 0) lo = hi = w.ka0;
 				else if (w.ka0 == -2) lo = hi = b1.m; // RB3GPU_KA_SENTINEL: a sentinel row, ka = acc[1] of the index (fm-index.c:164)
 				else lo = 0, hi = b1.n;

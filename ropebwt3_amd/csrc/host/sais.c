@@ -7,9 +7,10 @@
  * from-scratch SA-IS (see sais_core.h).  The partial BWT stays on the host by design
  * (north_star); it is not part of the timed merge path.
  *
- * The sorter is SEQUENTIAL.  `n_threads` is accepted so that the call reads like rb3_build_sais(n_seq, len, seq,
- * n_threads) and is ignored: host-side parallelism comes from the CLI's `-p N` (N batches sorted at once, one
- * thread each), and the default path does not come here at all (batches are cut to fit the GPU sorter, main.c).
+ * SA-IS is SEQUENTIAL.  With n_threads > 1 (rb3_build_sais(n_seq, len, seq, n_threads): libsais + OpenMP, sais-ss.c:15-22) the batch
+ * goes to the parallel prefix-doubling sorter of psort.c first; SA-IS takes what that one declines (small batches, a batch of long
+ * repeats, no memory for its 25 bytes per symbol).  The default path does not come here at all: batches are cut to fit the GPU
+ * sorter (main.c); this is for `--host-sort`, for a record of 2^31 symbols or more, and for a device without room.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -44,11 +45,13 @@ static int check_text(int64_t *n_seq, int64_t len, const uint8_t *seq)
 	return 0;
 }
 
+int rb3h_psort_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads, int64_t ck_step, int64_t *ckrow); /* psort.c */
+
 int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
 {
 	int r;
-	(void)n_threads;
 	if ((r = check_text(&n_seq, len, seq)) < 0) return r;
+	if ((r = rb3h_psort_bwt(n_seq, len, seq, n_threads, 0, 0)) <= 0) return r; /* (1: declined, the text is untouched) */
 	if (len + n_seq + 16 < INT32_MAX) return sais_bwt_32(n_seq, len, seq, 0, 0); /* sais-ss.c:52 picks 32/64 bit the same way */
 	return sais_bwt_64(n_seq, len, seq, 0, 0);
 }
@@ -123,7 +126,6 @@ int rb3h_build_bwt_walkers(int64_t n_seq, int64_t len, uint8_t *seq, int n_threa
 	int64_t *ckrow, i, b, j, nw = 0, mw;
 	rb3h_walker_t *w;
 	uint8_t *isend; /* 1 bit per checkpoint slot: position is a sentinel or the first symbol of a string */
-	(void)n_threads;
 	*n_walkers = 0, *walkers = 0;
 	if (step < 2) return -3;
 	if ((r = check_text(&n_seq, len, seq)) < 0) return r;
@@ -139,7 +141,8 @@ int rb3h_build_bwt_walkers(int64_t n_seq, int64_t len, uint8_t *seq, int n_threa
 		int64_t *ends = (int64_t*)malloc((size_t)n_seq * 8);
 		if (!ends) { free(ckrow); free(isend); free(w); return -1; }
 		for (i = 0, j = 0; i < len; ++i) if (seq[i] == 0) ends[j++] = i;
-		r = len + n_seq + 16 < INT32_MAX ? sais_bwt_32(n_seq, len, seq, step, ckrow) : sais_bwt_64(n_seq, len, seq, step, ckrow);
+		if ((r = rb3h_psort_bwt(n_seq, len, seq, n_threads, step, ckrow)) > 0) /* (declined: sequential) */
+			r = len + n_seq + 16 < INT32_MAX ? sais_bwt_32(n_seq, len, seq, step, ckrow) : sais_bwt_64(n_seq, len, seq, step, ckrow);
 		if (r < 0) { free(ends); free(ckrow); free(isend); free(w); return r; }
 		for (j = 0, b = 0; j < n_seq; ++j) { /* string j occupies [b, e), sentinel at e */
 			const int64_t e = ends[j];

@@ -338,3 +338,24 @@ def test_walker_list_by_text_position_covers_every_row_once():
                 assert e - prev >= min(128, step)
             b = e + 1
         assert i == w.shape[0]
+
+
+def test_parallel_host_sorter_equals_sais(monkeypatch):
+    """rb3h_build_bwt / rb3h_build_bwt_walkers with several threads (psort.c: prefix doubling over OpenMP, what rb3_build_sais gets from
+    libsais + OpenMP, sais-ss.c:15-22) give the bytes and the walker list of the sequential SA-IS: a genome on both strands, reads,
+    relatives, exact copies in one batch (the parallel sorter gives up on long repeats and SA-IS takes over), homopolymers, ragged strings"""
+    from ropebwt3_amd import host
+    monkeypatch.setenv("RB3H_PSORT_MIN_THREADS", "2")
+    rng = np.random.default_rng(7)
+    g = util.random_genome(rng, 150000)
+    cases = [util.make_text([g]),
+             util.make_text(util.reads_from(rng, g, 2000, 100, err=0.01)),
+             util.make_text([util.mutate(rng, g[:30000], 0.002) for _ in range(6)]),
+             util.make_text([g[:40000].copy() for _ in range(4)], rev=False),
+             util.make_text([np.full(70000, 1, dtype=np.uint8), np.full(3000, 2, dtype=np.uint8), g[:2000]], rev=False),
+             util.make_text([g[:100000], g[5:6].copy(), g[7:300]] + util.reads_from(rng, g, 300, 33))]
+    for t in cases:
+        assert t.size >= 1 << 16
+        assert np.array_equal(host.build_bwt(t, 1), host.build_bwt(t, 3))
+        wa, wb = host.build_bwt_walkers(t, 512, 1), host.build_bwt_walkers(t, 512, 4)
+        assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1])

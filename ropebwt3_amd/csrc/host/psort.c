@@ -34,6 +34,6 @@ int rb3h_psort_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads, int6
 	const int min_threads = e && atoi(e) > 1 ? atoi(e) : 8;
 	if (n_threads > omp_get_num_procs()) n_threads = omp_get_num_procs();
 	if (n_threads < min_threads || len < (1 << 16)) return 1;
-	r = (uint64_t)len + 16 < 0xFFFFFFFFull ? ps_bwt_32(n_seq, len, seq, ck_step, ckrow, n_threads) : ps_bwt_64(n_seq, len, seq, ck_step, ckrow, n_threads);
+	r = (uint64_t)len + 16 < 0xFFFFFFFFull && !getenv("RB3H_PSORT_FORCE64") /* (tests: the 64-bit instantiation on a small batch) */ ? ps_bwt_32(n_seq, len, seq, ck_step, ckrow, n_threads) : ps_bwt_64(n_seq, len, seq, ck_step, ckrow, n_threads);
 	return r == 0 ? 0 : 1; /* (no memory: SA-IS takes a third of it) */
 }

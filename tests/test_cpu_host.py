@@ -359,3 +359,6 @@ def test_parallel_host_sorter_equals_sais(monkeypatch):
         assert np.array_equal(host.build_bwt(t, 1), host.build_bwt(t, 3))
         wa, wb = host.build_bwt_walkers(t, 512, 1), host.build_bwt_walkers(t, 512, 4)
         assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1])
+    monkeypatch.setenv("RB3H_PSORT_FORCE64", "1")   # the instantiation for batches of 2^32 symbols and more, on a small one
+    for t in cases[:3]:
+        assert np.array_equal(host.build_bwt(t, 1), host.build_bwt(t, 4))

@@ -348,8 +348,12 @@ __global__ void __launch_bounds__(256) k_place_pg(const uint32_t *gstat, const u
  * lb: look-back state, 16 x u64 per block: [0..6] the block's totals, [8..14] its inclusive prefix, every word tagged with the
  * launch's epoch (never 0) in its upper 20 bits: the tag stands in for clearing and for memory ordering (see below).
  * C[] of the new index is known before the scan: acc of the old index + the batch's symbol counts (tot2, from the LF histogram). */
+#ifndef RB3_SP_GROUPS
 #define RB3_SP_GROUPS 256   /* groups per block (scanned by as many threads) */
+#endif
+#ifndef RB3_SP_THREADS
 #define RB3_SP_THREADS 1024 /* threads per block (all of them place slots) */
+#endif
 struct SpLds {
 	unsigned long long pre[8][RB3_SP_GROUPS]; // exclusive prefix of every group of the block (columns 0..5 symbols, 6 slots)
 	uint32_t ns[RB3_SP_GROUPS], mask[RB3_SP_GROUPS];

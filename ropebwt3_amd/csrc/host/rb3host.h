@@ -13,7 +13,7 @@
 extern "C" {
 #endif
 
-#define RB3H_VERSION "3.10-r281-mi355x-r3"
+#define RB3H_VERSION "3.10-r281-mi355x-r4"
 
 extern int rb3h_verbose;
 

@@ -321,7 +321,16 @@ struct rb3gpu_shard_s {
 static int copy_across(void *dst, int ddev, const void *src, int sdev, size_t n)
 {
 	if (n == 0) return 0;
-	const hipError_t e = ddev == sdev ? hipMemcpy(dst, src, n, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, ddev, src, sdev, n);
+	// A device-to-device hipMemcpy returns when the copy is QUEUED on the null stream, not when it is done, and the handles' streams do not
+	// wait for the null stream: without the synchronisation the interval handles were built from (or the batch read out of) buffers the
+	// copy had not reached yet -- only when something else kept the device busy (the CLI's sorter thread), and then silently:
+	// a wrong-but-valid BWT (found by the 10 M-read test of the interval build; tools/probe_iv_scale.py reproduces it).
+	hipError_t e = ddev == sdev ? hipMemcpy(dst, src, n, hipMemcpyDeviceToDevice) : hipMemcpyPeer(dst, ddev, src, sdev, n);
+	int cur = 0;
+	if (e == hipSuccess) e = hipGetDevice(&cur);
+	if (e == hipSuccess && (e = hipSetDevice(sdev)) == hipSuccess) e = hipDeviceSynchronize();
+	if (e == hipSuccess && ddev != sdev && (e = hipSetDevice(ddev)) == hipSuccess) e = hipDeviceSynchronize();
+	if (e == hipSuccess) e = hipSetDevice(cur);
 	if (e != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
 	return 0;
 }
@@ -367,7 +376,9 @@ rb3gpu_shard_t *rb3gpu_shard_split(rb3gpu_t *h0, int n, const int *devices, cons
 	s->bounds[n] = tot;
 	if ((s->grp = rb3gpu_group_create(n)) == nullptr) { delete s; return nullptr; }
 	void *plain = nullptr;
-	int r = n > 1 ? rb3gpu_dev_alloc(h0, tot, &plain) : 0;
+	int64_t acc0[RB3GPU_ASIZE + 1], sum[RB3GPU_ASIZE] = {0, 0, 0, 0, 0, 0};
+	int r = rb3gpu_get_acc(h0, acc0);
+	if (r == 0 && n > 1) r = rb3gpu_dev_alloc(h0, tot, &plain);
 	if (r == 0 && n > 1) r = rb3gpu_export_plain_dev(h0, (uint8_t*)plain);
 	for (int i = 0; i < n && r == 0; ++i) {
 		s->dev[i] = devices[i];
@@ -383,6 +394,12 @@ rb3gpu_shard_t *rb3gpu_shard_split(rb3gpu_t *h0, int n, const int *devices, cons
 		(void)rb3gpu_dev_free(s->h[i], part);
 	}
 	if (plain) (void)rb3gpu_dev_free(h0, plain);
+	for (int i = 0; i < n && r == 0; ++i) { // the intervals together hold the symbols the index held (a copy that went wrong would show here, not in a wrong BWT later)
+		int64_t acc[RB3GPU_ASIZE + 1];
+		if ((r = rb3gpu_get_acc(s->h[i], acc)) == 0)
+			for (int c = 0; c < RB3GPU_ASIZE; ++c) sum[c] += acc[c + 1] - acc[c];
+	}
+	for (int c = 0; c < RB3GPU_ASIZE && r == 0; ++c) if (sum[c] != acc0[c + 1] - acc0[c]) r = RB3GPU_EINTERNAL;
 	if (r < 0) { shard_free(s, true); return nullptr; } // (h0 may hold its first interval only: the caller gives the build up)
 	return s;
 }
@@ -448,7 +465,13 @@ int rb3gpu_shard_gather(rb3gpu_shard_t *s)
 				if ((r = rb3gpu_export_plain_dev(s->h[i], (uint8_t*)part)) == 0) r = copy_across((uint8_t*)plain + s->bounds[i], s->dev[0], part, s->dev[i], (size_t)len);
 				(void)rb3gpu_dev_free(s->h[i], part);
 			}
+			int64_t sum[RB3GPU_ASIZE] = {0, 0, 0, 0, 0, 0}, acc[RB3GPU_ASIZE + 1];
+			for (int i = 0; i < s->n && r == 0; ++i)
+				if ((r = rb3gpu_get_acc(s->h[i], acc)) == 0)
+					for (int c = 0; c < RB3GPU_ASIZE; ++c) sum[c] += acc[c + 1] - acc[c];
 			if (r == 0) r = rb3gpu_from_plain_dev(s->h[0], tot, (const uint8_t*)plain);
+			if (r == 0 && (r = rb3gpu_get_acc(s->h[0], acc)) == 0)
+				for (int c = 0; c < RB3GPU_ASIZE; ++c) if (acc[c + 1] - acc[c] != sum[c]) r = RB3GPU_EINTERNAL; // (the symbols of the intervals, no more and no fewer)
 			(void)rb3gpu_dev_free(s->h[0], plain);
 		}
 	}

@@ -309,6 +309,28 @@ def test_config4_reads_m7g_stays_on_the_gpu(tmp_path):
     assert os.path.getsize(out) == ent["fmd_bytes"] and h.hexdigest() == ent["fmd_md5"]
 
 
+def test_config4_reads_m7g_with_the_index_cut_into_intervals(tmp_path):
+    """the same 10 M reads (BASELINE configs[3] at 1/60: 3.02 G symbols) through `build --gpus 4 --interval`: after the first sub-batch
+    the index lives in four intervals (four handles, here on one device); every later sub-batch -- millions of chains, 151 lock-step
+    rounds each -- is merged by four threads inside the library (rb3gpu_shard_merge), the intervals are gathered for the writer: the
+    reference's .fmd"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(util.GOLDEN)))
+    from tools import gen_reads
+    ent = MAN["reads_m7g"]
+    fn = gen_reads.generate(ent["n_reads"], str(tmp_path / "reads.txt"))
+    out = str(tmp_path / "out.fmd")
+    r = subprocess.run([CLI, "build", "-L", "-d", "-m7g", "--gpus", "4", "--interval", "-o", out, fn], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-800:]
+    assert "index cut into 4 intervals" in err and "lock-step rounds" in err and "0 (0 symbols) on the host" in err
+    h = hashlib.md5()
+    with open(out, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    assert os.path.getsize(out) == ent["fmd_bytes"] and h.hexdigest() == ent["fmd_md5"]
+
+
 def test_resume_and_ssa_from_an_index_loaded_in_chunks(tmp_path):
     """`build -i` and `ssa` on an .fmd that is loaded chunk by chunk (RB3GPU_LOAD_CHUNK=2 groups): golden bytes"""
     r = MAN["resume"]

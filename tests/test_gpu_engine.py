@@ -1237,6 +1237,51 @@ def test_shard_object_split_merge_gather(oracle):
         h.close()
 
 
+def test_shard_object_beside_a_busy_sorter(oracle):
+    """the sharded index while ANOTHER thread keeps the device busy with suffix sorting (what the CLI's sorter thread does): the copies
+    that cut the index into intervals and put it back together must be complete before the handles read them -- a device-to-device
+    hipMemcpy only queues the copy (found at 10 M reads through the CLI: a valid but wrong BWT, one run in three)"""
+    import threading
+    from ropebwt3_amd import Rb3Gpu, Shard, Sorter
+    rng = np.random.default_rng(8)
+    g0 = util.random_genome(rng, 2000000)
+    t1 = util.make_text(util.reads_from(rng, g0, 60000, 100), rev=False)
+    t2 = util.make_text(util.reads_from(rng, g0, 30000, 100), rev=False)
+    big = util.make_text([g0])
+    stop = []
+
+    def busy():
+        s2 = Sorter(0)
+        while not stop:
+            s2.upload(big)
+            d2, _ = s2.sort_uploaded(big.size)
+            s2.release(d2)
+
+    th = threading.Thread(target=busy)
+    th.start()
+    try:
+        want = None
+        for rep in range(6):
+            h = Rb3Gpu(verbose=1)
+            d1, d1tw = h.sort_text(t1)
+            h.from_plain_dev(d1, t1.size)
+            sh = Shard(h, [0, 0, 0, 0])
+            d2, d2tw = h.sort_text(t2)
+            sh.merge(d2, d2tw, t2.size, np.flatnonzero(t2 == 0))
+            sh.gather()
+            got = h.export_plain()
+            for p in (d1, d1tw, d2, d2tw):
+                h.dev_free(p)
+            h.close()
+            if want is None:
+                from ropebwt3_amd import host
+                want = oracle.merge(host.build_bwt(t1.copy()), host.build_bwt(t2.copy()))
+            assert np.array_equal(got, want), rep
+    finally:
+        stop.append(1)
+        th.join()
+
+
 def test_interval_sharded_merge_through_callbacks(oracle):
     """the same merge with a communicator made of two Python callables (what a launcher without RCCL -- gloo, MPI -- plugs in):
     two ranks as threads, the all-to-all as device-to-device copies out of the per-destination send regions; and a rank whose

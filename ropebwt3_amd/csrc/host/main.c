@@ -336,6 +336,11 @@ static int interval_merge(rb3gpu_t *h, int64_t len, const void *d_bwt, const voi
 	int r;
 	const double t0 = rb3h_realtime();
 	if (sent == 0 || n_sent <= 0 || d_tw == 0) return RB3GPU_EINVAL;
+	if (rb3h_verbose >= 2) { /* one lock-step round per symbol of the longest string: say so before a batch of long strings takes minutes */
+		int64_t i, longest = sent[0] + 1;
+		for (i = 1; i < n_sent; ++i) if (sent[i] - sent[i - 1] > longest) longest = sent[i] - sent[i - 1];
+		if (longest > 100000) fprintf(stderr, "WARNING: --interval walks a batch in lock step, one round (~20 us or more) per symbol of its longest string: %ld rounds for this batch; it is meant for reads (without --interval the strings are cut among many walkers)\n", (long)longest);
+	}
 	if (g_iv.s == 0) {
 		if (rb3gpu_get_tot(h) < g_iv.n) return rb3gpu_merge_text_dev(h, len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, n_sent, 0, 1); /* (fewer symbols than intervals: not cut yet) */
 		if ((g_iv.s = rb3gpu_shard_split(h, g_iv.n, g_iv.devices, &g_iv.gopt)) == 0) return RB3GPU_ENODEV;

@@ -470,7 +470,7 @@ def main():
     ap.add_argument("--div", type=float, default=0.001)
     ap.add_argument("--mode", choices=["partition", "interval", "replicated"], default=None,
                     help="N > 1: how the work is split over the GPUs (ropebwt3_amd/multi.py); default partition = the same mtb152 build, partitioned + tree merge")
-    ap.add_argument("--sh-driver", choices=["rccl", "torch", "python"], default=None, help="--mode interval: what runs the lock-step loop and carries the states: rb3gpu_sh_merge over the library's RCCL communicator (default), over torch.distributed callbacks, or the loop in Python (rounds 1-3)")
+    ap.add_argument("--sh-driver", choices=["rccl", "torch", "python", "gloo"], default=None, help="--mode interval: what runs the lock-step loop and carries the states: rb3gpu_sh_merge over the library's RCCL communicator (default), over torch.distributed callbacks, or the loop in Python (rounds 1-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (CLI build, configs[1], reads regime, large index)")
     ap.add_argument("--no-pinned", action="store_true", help="batches in pageable host memory (staged upload)")

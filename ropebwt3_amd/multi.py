@@ -376,6 +376,30 @@ def sh_comm(h, dist, rank, world, dev, driver="rccl"):
         except (Rb3GpuError, OSError) as e:   # (every rank fails alike: the library is the same on all of them)
             why = " [rb3gpu_rccl unavailable: %r]" % (e,)
 
+    if driver == "gloo":   # ranks that share a GPU (test mode): CPU tensors, the states staged through host memory
+        def all_gather_g(vec):
+            out = [torch.zeros(len(vec), dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(out, torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64)))
+            return torch.stack(out).numpy()
+
+        def exchange_g(d_send, stride, send_cnt, d_recv, recv_cnt):
+            parts = [torch.from_numpy(h.dev_download_i64(d_send + d * stride * 16, int(send_cnt[d]) * 2)) if send_cnt[d] else torch.zeros(0, dtype=torch.int64) for d in range(world)]
+            recv = [torch.zeros(int(recv_cnt[s_]) * 2, dtype=torch.int64) for s_ in range(world)]
+            for peer in range(world):   # pairwise, the lower rank sends first
+                if peer == rank:
+                    recv[rank].copy_(parts[rank])
+                elif rank < peer:
+                    if parts[peer].numel(): dist.send(parts[peer], peer)
+                    if recv[peer].numel(): dist.recv(recv[peer], peer)
+                else:
+                    if recv[peer].numel(): dist.recv(recv[peer], peer)
+                    if parts[peer].numel(): dist.send(parts[peer], peer)
+            got = torch.cat(recv).numpy()
+            if got.size:
+                h.dev_upload_to(d_recv, got)
+
+        return CallbackComm(rank, world, all_gather_g, exchange_g), "callbacks over gloo through host memory (ranks share a GPU: test mode)"
+
     def all_gather(vec):
         v = torch.as_tensor(np.ascontiguousarray(vec, dtype=np.int64), device=dev)
         out = torch.empty(world * v.numel(), dtype=torch.int64, device=dev)
@@ -494,11 +518,20 @@ def bench_main(args, rank, local_rank, world):
     from tests import util
     if args.mode == "partition":
         return bench_partition_mtb(args, rank, local_rank, world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_id = local_rank % ndev
+    shared_gpu = ndev < int(os.environ.get("LOCAL_WORLD_SIZE", world))   # fewer devices than ranks: TEST MODE, the ranks share GPUs and talk over gloo
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    if shared_gpu:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if args.mode == "interval":
+            args.sh_driver = "gloo"
+    else:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    local_rank = dev_id
     h = Rb3Gpu(device=local_rank, verbose=1)
 
     def barrier():
@@ -540,7 +573,7 @@ def bench_main(args, rank, local_rank, world):
             fn(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
         barrier()
         dt = time.perf_counter() - t
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         s = h.stats()
@@ -548,8 +581,8 @@ def bench_main(args, rank, local_rank, world):
             out = {"metric": "Gbp/s indexed (build merge)", "value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                    "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
                    "config": {"workload": "interval-sharded index (north_star): %d symbols in %d intervals, one per GPU; per step one batch of %d x 150 bp reads (both strands, %d symbols) merged with one all-to-all per symbol" % (b1.size, world, reads_per_gpu * world, t2.size),
-                              "symbols_per_step_per_gpu": int(t2.size // world), "index_symbols": int(b1.size), "parallelism": "interval%d: chain states routed to the owner of their insertion point by RCCL all-to-all(v), %d lock-step rounds per merge; local rebuild per interval" % (world, stt.get("rounds", 0)),
-                              "rows_per_rank": stt.get("rows_per_rank"), "driver": "rb3gpu_sh_merge (the loop inside the library): " + label if fn is merge_interval_c else label,
+                              "symbols_per_step_per_gpu": int(t2.size // world), "index_symbols": int(b1.size), "parallelism": "interval%d: chain states routed to the owner of their insertion point by %s, %d lock-step rounds per merge; local rebuild per interval" % (world, "gloo send/recv through host memory (ranks share a GPU: TEST MODE, not a measurement)" if shared_gpu else "RCCL all-to-all(v)", stt.get("rounds", 0)),
+                              "rows_per_rank": stt.get("rows_per_rank"), "ranks_share_a_gpu": bool(shared_gpu), "driver": "rb3gpu_sh_merge (the loop inside the library): " + label if fn is merge_interval_c else label,
                               "us_per_round_rank0": round(s["ms_rank"] / args.steps / max(1, stt.get("rounds") or 1) * 1e3, 2)},
                    "phases_ms_per_step_rank0": {"step_kernels": round(s["ms_rank"] / args.steps, 3), "rebuild": round(s["ms_build"] / args.steps, 3)},
                    "roofline": {"bound": "hbm", "kernel": "k_sh_round" if fn is merge_interval_c else "k_sh_step", "achieved": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",

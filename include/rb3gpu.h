@@ -116,7 +116,8 @@ typedef struct {
 #define RB3GPU_WK_CHECK 2        /* the rows ahead may already be recorded: check each before recording */
 
 /* rb3gpu_merge_plain with an explicit walker list (host memory); same result, more parallelism
- * and no dependence on how the suffix array scatters the strings */
+ * and no dependence on how the suffix array scatters the strings.  An entry that is not a walker of this batch (row outside it, no
+ * steps) makes the call return RB3GPU_EINVAL with nothing installed; the list is checked on the device, by the kernel that walks it. */
 int rb3gpu_merge_plain_walkers(rb3gpu_t *h, int64_t len, const uint8_t *bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers);
 /* (device BWT) walkers == NULL: one walker per string, made on the device; n_walkers = the number of strings of the batch */
 int rb3gpu_merge_plain_dev_walkers(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit);

@@ -169,6 +169,7 @@ struct rb3gpu_s {
 	std::vector<std::pair<void*, size_t> > garbage; // replaced buffers not yet given back (dev_free)
 	int64_t bytes_garbage = 0;
 	uint64_t reb_slot_cap = 0; // capacity of the slot array the last rebuild emitted into (build_index)
+	bool lf_wait = false;      // the main stream has not waited yet for the batch's histogram on the side stream (merge_core -> build_index)
 	bool reb_prepared = false; // merge_core has cleared the counters of the run-space rebuild together with everything else
 	double t0 = 0;
 	uint8_t *stage[2] = {nullptr, nullptr}; // pinned staging buffers for host->device copies
@@ -874,6 +875,9 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	if (fused) {
 		Acc7 ao;
 		for (int a = 0; a < 7; ++a) ao.a[a] = h->acc[a];
+		// k_scan_place is the first kernel of a merge that reads the batch's symbol totals (side stream: merge_core): the wait for them sits here,
+		// behind the group kernels, where its ~15 us in the command processor pass beside their 250 (in front of them the chip idled)
+		if (h->lf_wait) { HIPCHK(hipStreamWaitEvent(h->st, h->evx[2], 0)); h->lf_wait = false; }
 		uint8_t *lbp = (uint8_t*)h->lbst.p;
 		hipLaunchKernelGGL(k_scan_place, dim3((unsigned)sp_nblk), dim3(RB3_SP_THREADS), 0, h->st, (const uint32_t*)gstat, ngrp, ntot, (const uint8_t*)(runspace ? gkind : nullptr), (const uint4*)h->gslots.p, (const uint4*)h->pslots.p,
 				(const uint32_t*)(runspace ? gpos : nullptr), h->ib[dst].grp, (uint64_t*)(h->ib[dst].grp + h->ib[dst].grp_cap), (uint4*)h->ib[dst].slots, (unsigned long long*)dtot,
@@ -969,6 +973,7 @@ static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b
 		if (hipEventRecord(h->evx[0], h->st) != hipSuccess || hipStreamWaitEvent(h->st2, h->evx[0], 0) != hipSuccess) side = false;
 		else s = h->st2;
 	}
+	if (!side && h->lf_wait) { (void)hipStreamWaitEvent(h->st, h->evx[2], 0); h->lf_wait = false; } // (on the main stream after all: the histogram it reads runs on the side stream)
 	hipLaunchKernelGGL(k_lf_check, dim3((unsigned)((ns * 8 + 255) / 256)), dim3(256), 0, s, view_of(h), dpos, d_b2, len, (const uint64_t*)h->tpre.p,
 			(const uint64_t*)(misc + MISC_LF_TOT), stride, misc + 2, misc + MISC_LF_CHK);
 	if (side) (void)hipEventRecord(h->evx[1], h->st2);
@@ -1550,10 +1555,11 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (h->tn.corrupt_pos) hipLaunchKernelGGL(k_test_corrupt, dim3((unsigned)(len / 6 / 256 + 1)), dim3(256), 0, h->st, dpos, len);
 #endif
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
-	if (lf_beside) HIPCHK(hipStreamWaitEvent(h->st, h->evx[2], 0)); // (long done: the validation and the host read the batch's totals)
+	h->lf_wait = lf_beside; // (the batch's totals, side stream: awaited where they are first read -- k_scan_place, or below before the counters go to the host)
 	const bool lf_side = launch_lf_check(h, (const int64_t*)dpos, d_b2, len, true);
 	int64_t ngrp = 0, nslots = 0, acc[7];
-	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) return r;
+	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) { h->lf_wait = false; return r; }
+	if (h->lf_wait) { HIPCHK(hipStreamWaitEvent(h->st, h->evx[2], 0)); h->lf_wait = false; }
 	HIPCHK(hipEventRecord(h->ev[3], h->st));
 	if (lf_side) HIPCHK(hipStreamWaitEvent(h->st, h->evx[1], 0));
 	unsigned long long hm[48];

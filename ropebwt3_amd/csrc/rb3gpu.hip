@@ -962,7 +962,7 @@ static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_ro
 
 /* the sampled LF-consistency check of pos[] (k_lf_check), against the index as it is BEFORE the merge is installed; counts into
  * misc[4] (with the unsettled tentative records: a failure first makes the merge redo its rank phase without speculation) */
-static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b2, int64_t len, bool side)
+static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b2, int64_t len, bool side, hipEvent_t here = nullptr) // here: an event the caller has just recorded on the main stream (saves recording another one: every record is a packet the command processor works through, ~3-5 us)
 {
 	const int64_t stride = h->tn.lf_check;
 	if (stride <= 0 || h->tpre.p == nullptr) return false;
@@ -970,7 +970,7 @@ static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b
 	const int64_t ns = (len + stride - 1) / stride;
 	hipStream_t s = h->st;
 	if (side) { // beside the rebuild: pos[] is read-only from here on, and a rebuild from a wrong-but-monotone pos[] is harmless (never installed)
-		if (hipEventRecord(h->evx[0], h->st) != hipSuccess || hipStreamWaitEvent(h->st2, h->evx[0], 0) != hipSuccess) side = false;
+		if ((here == nullptr && hipEventRecord(h->evx[0], h->st) != hipSuccess) || hipStreamWaitEvent(h->st2, here ? here : h->evx[0], 0) != hipSuccess) side = false;
 		else s = h->st2;
 	}
 	if (!side && h->lf_wait) { (void)hipStreamWaitEvent(h->st, h->evx[2], 0); h->lf_wait = false; } // (on the main stream after all: the histogram it reads runs on the side stream)
@@ -1401,7 +1401,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	} else if ((r = lf_build(h, len, d_b2, (int64_t*)h->pos.p, nullptr, d_tw == nullptr, rows_filled, false)) < 0) return r;
 	// (lf_beside: the histogram kernels are queued BEHIND the walkers' launch, further down -- the host needs ~30 us for their five calls, and with
 	// them and the check of the caller's walker list, now done by k_chain itself, in front of it the walkers started ~85 us after the fill kernel)
-	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	if (!lf_beside) HIPCHK(hipEventRecord(h->ev[1], h->st)); // (lf_beside: the rank phase starts where k_chain's own event, ev[6], is recorded)
 #ifdef RB3_PROF_STEP
 	HIPCHK(hipMemsetAsync(misc + 34, 0, 40, h->st));
 #endif
@@ -1556,7 +1556,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #endif
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	h->lf_wait = lf_beside; // (the batch's totals, side stream: awaited where they are first read -- k_scan_place, or below before the counters go to the host)
-	const bool lf_side = launch_lf_check(h, (const int64_t*)dpos, d_b2, len, true);
+	const bool lf_side = launch_lf_check(h, (const int64_t*)dpos, d_b2, len, true, h->ev[2]);
 	int64_t ngrp = 0, nslots = 0, acc[7];
 	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) { h->lf_wait = false; return r; }
 	if (h->lf_wait) { HIPCHK(hipStreamWaitEvent(h->st, h->evx[2], 0)); h->lf_wait = false; }
@@ -1589,9 +1589,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		fprintf(stderr, "[debug part] len %lld K %d nb %d: %lld rows differ from the gather, %lld rows with isa[sa[i]] != i\n", (long long)len, partK, part_nb, (long long)nbad, (long long)nperm);
 	}
 #endif
-	h->stt.ms_lf += ev_ms(h->ev[0], h->ev[1]);
+	hipEvent_t ev_rank0 = lf_beside ? h->ev[6] : h->ev[1];
+	h->stt.ms_lf += ev_ms(h->ev[0], ev_rank0);
 	h->stt.ms_chain += ev_ms(h->ev[6], h->ev[7]);
-	h->stt.ms_rank += ev_ms(h->ev[1], h->ev[2]);
+	h->stt.ms_rank += ev_ms(ev_rank0, h->ev[2]);
 	h->stt.ms_build += ev_ms(h->ev[2], h->ev[3]);
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	guard_check(h, __func__);
@@ -1838,7 +1839,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	}
 	if (h->opt.verbose >= 3)
 		fprintf(stderr, "[M::%s::%.3f] merged %lld symbols (%lld strings): lf %.3f ms, rank %.3f ms (%llu LF steps), rebuild %.3f ms\n", __func__,
-				now_s() - h->t0, (long long)len, (long long)acc2[1], ev_ms(h->ev[0], h->ev[1]), ev_ms(h->ev[1], h->ev[2]), hm[1], ev_ms(h->ev[2], h->ev[3]));
+				now_s() - h->t0, (long long)len, (long long)acc2[1], ev_ms(h->ev[0], ev_rank0), ev_ms(ev_rank0, h->ev[2]), hm[1], ev_ms(h->ev[2], h->ev[3]));
 	return 0;
 }
 

@@ -27,13 +27,19 @@ static void ps_qsort_fallback(void *a, size_t n, size_t sz, int (*cmp)(const voi
 int rb3h_psort_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads, int64_t ck_step, int64_t *ckrow)
 {
 	int r;
-	/* Prefix doubling does several times the work of SA-IS (a random read of rank[] per suffix and round): measured on the 8 virtual CPUs of
-	 * the build container, 8 M symbols take 1.03 s with 8 threads against 1.01 s for SA-IS on one, 1.1-1.9 s with 2-4 threads.  So it only
-	 * takes over from 8 threads up (RB3H_PSORT_MIN_THREADS overrides: tests run it with fewer). */
+	/* Prefix doubling does more work than SA-IS (a random read of rank[] per unsorted suffix and round), so it needs a few threads to win:
+	 * measured on the 8 virtual CPUs of the build container, 8 M symbols (a random genome, both strands) take 0.95 s with SA-IS on one
+	 * thread, 1.30 s here with 2 threads, 0.40 s with 4, 0.27 s with 8 (with the initial key of 8 symbols; starting from single symbols
+	 * it was 1.0 s with 8).  It takes over from 4 threads up (RB3H_PSORT_MIN_THREADS overrides: tests). */
 	const char *e = getenv("RB3H_PSORT_MIN_THREADS");
-	const int min_threads = e && atoi(e) > 1 ? atoi(e) : 8;
+	const int min_threads = e && atoi(e) > 1 ? atoi(e) : 4;
 	if (n_threads > omp_get_num_procs()) n_threads = omp_get_num_procs();
 	if (n_threads < min_threads || len < (1 << 16)) return 1;
+	/* Batches of SHORT strings stay with SA-IS: overlapping reads agree over up to a read length, every round of doubling then works on most
+	 * of the batch in groups of a few suffixes (measured: 600 k reads of 150 bp, 90.6 M symbols: 28 s with 8 threads against 22.8 s for
+	 * SA-IS) -- and such batches never come here in the first place (the GPU sorter takes them, cut to size).  What does come here is a
+	 * record too long for the GPU sorter: long strings. */
+	if (n_seq > 0 && len / n_seq < 1024 && !getenv("RB3H_PSORT_MIN_THREADS")) return 1;
 	r = (uint64_t)len + 16 < 0xFFFFFFFFull && !getenv("RB3H_PSORT_FORCE64") /* (tests: the 64-bit instantiation on a small batch) */ ? ps_bwt_32(n_seq, len, seq, ck_step, ckrow, n_threads) : ps_bwt_64(n_seq, len, seq, ck_step, ckrow, n_threads);
 	return r == 0 ? 0 : 1; /* (no memory: SA-IS takes a third of it) */
 }

@@ -73,8 +73,24 @@ static void PFN(ps_small)(PFN(pel_t) *e, size_t m)
 	} else qsort(e, m, sizeof(PFN(pel_t)), PFN(ps_cmp));
 }
 
+#define PS_W 8                     /* symbols of the initial key (3 bits each) */
+/* the packed first PS_W symbols of suffix i, cut behind its sentinel; *tie = T of that sentinel (1 + its number; 0: none in the window, or the
+ * end of the text) */
+static inline PIDX PFN(ps_key)(const PIDX *T, size_t n, uint64_t n_seq, size_t i, PIDX *tie)
+{
+	PIDX key = 0;
+	int j;
+	*tie = 0;
+	for (j = 0; j < PS_W; ++j) {
+		const PIDX t = i + (size_t)j < n ? T[i + (size_t)j] : 0;
+		if ((uint64_t)t <= n_seq) { *tie = t; break; } /* a sentinel (or the end): code 0, the rest of the key stays 0 */
+		key |= (PIDX)((uint64_t)t - n_seq) << (3 * (PS_W - 1 - j));
+	}
+	return key;
+}
+
 #define PS_BIG ((size_t)1 << 16)   /* groups of this many suffixes or more are sorted by all threads together */
-#define PS_MAX_ROUNDS 13           /* h = 2^12 symbols compared: give up if more than 1/16 of the suffixes are still unsorted */
+#define PS_MAX_ROUNDS 10           /* h = 2^12 symbols compared: give up if more than 1/16 of the suffixes are still unsorted */
 
 /* SA[0..n) of T[0..n) (T[n-1] = 0, unique).  Returns 0, -1 (memory), or 1: gave up (a batch of long repeats), SA undefined. */
 static int PFN(ps_main)(const PIDX *T, PIDX *SA, size_t n, uint64_t K, int nt)
@@ -85,12 +101,23 @@ static int PFN(ps_main)(const PIDX *T, PIDX *SA, size_t n, uint64_t K, int nt)
 	size_t ng = 0, i, h;
 	int ret = 0, round = 0;
 	if (!rank || !eb || !et || !bnd) { ret = -1; goto done; }
-	/* round 0: by first symbol */
+	/* round 0: by the first PS_W symbols at once (three rounds of doubling saved, each a random read of rank[] per suffix): the key packs
+	 * 3 bits per symbol, a sentinel as 0 and nothing behind it; suffixes that reach their sentinel inside the window agree in the key only if
+	 * the sentinel sits at the same place, and are then told apart by WHICH sentinel it is (T = 1 + its number): two stable sorts, by that
+	 * number first and by the packed key second */
 #pragma omp parallel for num_threads(nt) schedule(static)
-	for (i = 0; i < n; ++i) eb[i].key = T[i], eb[i].idx = (PIDX)i;
-	PFN(ps_radix)(eb, et, n, K, nt);
+	for (i = 0; i < n; ++i) { PIDX tie; (void)PFN(ps_key)(T, n, K - 6, i, &tie); eb[i].key = tie, eb[i].idx = (PIDX)i; }
+	PFN(ps_radix)(eb, et, n, K - 6 + 2, nt);
 #pragma omp parallel for num_threads(nt) schedule(static)
-	for (i = 0; i < n; ++i) SA[i] = eb[i].idx, bnd[i] = (i == 0 || eb[i].key != eb[i - 1].key) ? 1 : 0;
+	for (i = 0; i < n; ++i) { PIDX tie; eb[i].key = PFN(ps_key)(T, n, K - 6, eb[i].idx, &tie); }
+	PFN(ps_radix)(eb, et, n, (uint64_t)1 << (3 * PS_W), nt);
+#pragma omp parallel for num_threads(nt) schedule(static)
+	for (i = 0; i < n; ++i) {
+		PIDX t0 = 0, t1 = 0;
+		SA[i] = eb[i].idx;
+		if (i > 0 && eb[i].key == eb[i - 1].key) (void)PFN(ps_key)(T, n, K - 6, eb[i].idx, &t0), (void)PFN(ps_key)(T, n, K - 6, eb[i - 1].idx, &t1);
+		bnd[i] = (i == 0 || eb[i].key != eb[i - 1].key || t0 != t1) ? 1 : 0;
+	}
 	/* groups from the boundary flags: rank = start of the group; the unsorted ones (more than one suffix) are listed */
 	gs = (PIDX*)malloc((n / 2 + 1) * sizeof(PIDX)), ge = (PIDX*)malloc((n / 2 + 1) * sizeof(PIDX));
 	gs2 = (PIDX*)malloc((n / 2 + 1) * sizeof(PIDX)), ge2 = (PIDX*)malloc((n / 2 + 1) * sizeof(PIDX));
@@ -106,7 +133,7 @@ static int PFN(ps_main)(const PIDX *T, PIDX *SA, size_t n, uint64_t K, int nt)
 				a = i;
 			}
 	}
-	for (h = 1; ng > 0; h <<= 1) {
+	for (h = PS_W; ng > 0; h <<= 1) {
 		size_t unsorted = 0, g, ng2 = 0;
 		if (++round > PS_MAX_ROUNDS) {
 			for (g = 0; g < ng; ++g) unsorted += (size_t)(ge[g] - gs[g]);
@@ -215,4 +242,5 @@ static int PFN(ps_bwt)(int64_t n_seq, int64_t len, uint8_t *seq, int64_t ck_step
 #undef PCAT
 #undef PCAT_
 #undef PS_BIG
+#undef PS_W
 #undef PS_MAX_ROUNDS

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of `ropebwt3-amd build` (and, for every third case, `ssa`) against the unmodified reference binary (oracle/_ref/ropebwt3, GPU box):
+"""Differential fuzz of `ropebwt3-amd build` (incl. --gpus N and --gpus N --interval; and, for every third case, `ssa`) against the unmodified reference binary (oracle/_ref/ropebwt3, GPU box):
 random FASTA / FASTQ / one-per-line inputs (N, lower case, IUPAC, CRLF, duplicates, homopolymers, short and long
 records, several files), random -m / -R / -F / -p / sorter; the .fmd must be byte-identical.
     python tools/fuzz_cli.py [n_cases] [seed0]"""
@@ -65,13 +65,21 @@ for case in range(ncase):
     rng = np.random.default_rng(seed0 + case)
     fmt = str(rng.choice(["line", "fa", "fq"]))
     files = []
+    maxlen = 0
     for fi in range(int(rng.integers(1, 4))):
-        files.append(write(rng, os.path.join(tmp, "c%d_%d.%s" % (case, fi, "txt" if fmt == "line" else fmt)), seqs(rng), fmt))
+        recs = seqs(rng)
+        maxlen = max([maxlen] + [len(r) for r in recs])
+        files.append(write(rng, os.path.join(tmp, "c%d_%d.%s" % (case, fi, "txt" if fmt == "line" else fmt)), recs, fmt))
     flags = (["-L"] if fmt == "line" else []) + ([str(rng.choice(["-R", "-F"]))] if rng.random() < 0.3 else [])
     m = str(rng.choice(["7g", "1", "100", "3k", "50k", "1m"]))
     want = subprocess.run([ref, "build", "-d", "-t4", "-m" + m] + flags + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    ours = [amd, "build", "-d", "-m" + m] + flags + (["--host-sort"] if rng.random() < 0.3 else []) + (["-p%d" % rng.integers(1, 5)] if rng.random() < 0.5 else []) + \
-           (["--rebatch"] if rng.random() < 0.2 else []) + files
+    host_sort = rng.random() < 0.3
+    multi = []
+    if rng.random() < 0.35:   # several handles (on a one-GPU box all on device 0): slices + tree merge, or ONE index cut into intervals (short records only:
+        multi = ["--gpus", str(rng.integers(2, 5))]   # a lock-step round per symbol of the longest record)
+        if not host_sort and maxlen < 2000 and rng.random() < 0.6: multi.append("--interval")
+    ours = [amd, "build", "-d", "-m" + m] + flags + (["--host-sort"] if host_sort else []) + (["-p%d" % rng.integers(1, 5)] if rng.random() < 0.5 else []) + \
+           (["--rebatch"] if rng.random() < 0.2 and not multi else []) + multi + files
     got = subprocess.run(ours, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     ok = want.returncode == 0 and got.returncode == 0 and want.stdout == got.stdout
     print("case %d: %s %d files m=%s %s -> %s (%d bytes)" % (case, fmt, len(files), m, " ".join(ours[4:-len(files)]), "ok" if ok else "MISMATCH rc=%d/%d" % (want.returncode, got.returncode), len(got.stdout)), flush=True)

@@ -75,9 +75,10 @@ for case in range(ncase):
     want = subprocess.run([ref, "build", "-d", "-t4", "-m" + m] + flags + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     host_sort = rng.random() < 0.3
     multi = []
-    if rng.random() < 0.35:   # several handles (on a one-GPU box all on device 0): slices + tree merge, or ONE index cut into intervals (short records only:
+    force_iv = bool(os.environ.get("FUZZ_INTERVAL"))   # (every case that can take it runs with --interval)
+    if rng.random() < 0.35 or force_iv:   # several handles (on a one-GPU box all on device 0): slices + tree merge, or ONE index cut into intervals (short records only:
         multi = ["--gpus", str(rng.integers(2, 5))]   # a lock-step round per symbol of the longest record)
-        if not host_sort and maxlen < 2000 and rng.random() < 0.6: multi.append("--interval")
+        if not host_sort and maxlen < 2000 and (rng.random() < 0.6 or force_iv): multi.append("--interval")
     ours = [amd, "build", "-d", "-m" + m] + flags + (["--host-sort"] if host_sort else []) + (["-p%d" % rng.integers(1, 5)] if rng.random() < 0.5 else []) + \
            (["--rebatch"] if rng.random() < 0.2 and not multi else []) + multi + files
     got = subprocess.run(ours, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -1224,6 +1224,48 @@ static int main_recode(int argc, char *argv[])
 	return ret == 0 ? 0 : 1;
 }
 
+/* plain2fmd (the reference's main.c:299-331): every byte of the input is one BWT symbol, '\n' and '$' are sentinels; host only.
+ * The symbols go to the FMD writer a run at a time, not one by one. */
+static int main_plain2fmd(int argc, char *argv[])
+{
+	int c, j, ret = 0, cur = -1;
+	int64_t run = 0;
+	rb3h_fmdw_t *w;
+	uint8_t *buf, tab[256];
+	optind = 1;
+	while ((c = getopt(argc, argv, "o:")) >= 0)
+		if (c == 'o' && freopen(optarg, "wb", stdout) == 0) { fprintf(stderr, "ERROR: failed to open '%s' for writing\n", optarg); return 1; }
+	if (argc - optind < 1) {
+		fprintf(stdout, "Usage: ropebwt3-amd plain2fmd [-o output.fmd] <in.txt>\n");
+		return 0;
+	}
+	buf = (uint8_t*)malloc(1 << 20);
+	for (c = 0; c < 256; ++c) tab[c] = (uint8_t)c;
+	rb3h_char2nt6(256, tab);
+	tab['\n'] = tab['$'] = 0;
+	w = rb3h_fmdw_init();
+	for (j = optind; j < argc && ret == 0; ++j) {
+		FILE *fp = strcmp(argv[j], "-") == 0 ? stdin : fopen(argv[j], "r");
+		size_t i, len;
+		if (fp == 0) { fprintf(stderr, "ERROR: failed to open '%s'\n", argv[j]); ret = -1; break; }
+		while (ret == 0 && (len = fread(buf, 1, 1 << 20, fp)) > 0) {
+			for (i = 0; i < len && ret == 0; ++i) {
+				const int x = tab[buf[i]];
+				if (x == cur) { ++run; continue; }
+				if (run > 0) ret = rb3h_fmdw_enc(w, run, cur);
+				cur = x, run = 1;
+			}
+		}
+		if (fp != stdin) fclose(fp);
+	}
+	if (ret == 0 && run > 0) ret = rb3h_fmdw_enc(w, run, cur);
+	if (ret == 0) ret = rb3h_fmdw_finish(w);
+	if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
+	rb3h_fmdw_destroy(w);
+	free(buf);
+	return ret == 0 ? 0 : 1;
+}
+
 static int usage(FILE *fp)
 {
 	fprintf(fp, "Usage: ropebwt3-amd <command> <arguments>\n");
@@ -1232,6 +1274,7 @@ static int usage(FILE *fp)
 	fprintf(fp, "    merge      merge BWTs (on an MI355X)\n");
 	fprintf(fp, "    ssa        generate sampled suffix array (on an MI355X)\n");
 	fprintf(fp, "    recode     convert an FMD/FMR file to plain text, FMD (-d) or FMR (-b) (host only)\n");
+	fprintf(fp, "    plain2fmd  convert BWT in plain text to FMD (host only)\n");
 	fprintf(fp, "    version    print the version number\n");
 	return fp == stdout ? 0 : 1;
 }
@@ -1245,6 +1288,7 @@ int main(int argc, char *argv[])
 	else if (strcmp(argv[1], "merge") == 0) ret = main_merge(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "ssa") == 0) ret = main_ssa(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "recode") == 0) ret = main_recode(argc - 1, argv + 1);
+	else if (strcmp(argv[1], "plain2fmd") == 0) ret = main_plain2fmd(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "version") == 0) { printf("%s\n", RB3H_VERSION); return 0; }
 	else { fprintf(stderr, "ERROR: unknown command '%s'\n", argv[1]); return 1; }
 	if (rb3h_verbose >= 3 && argc > 2 && ret == 0) { /* main.c:73-80 */

@@ -45,6 +45,7 @@ void rb3h_seq_close(rb3h_seqio_t *fp);                                     /* io
 /* a byte range of a plain file (`build --gpus N` on one file): the records that START in [beg, end); end <= 0: to the end of the file */
 int rb3h_seq_splittable(const char *fn, int64_t *size);                    /* a regular file that is not gzip-compressed */
 rb3h_seqio_t *rb3h_seq_open_range(const char *fn, int is_line, int64_t beg, int64_t end);
+int64_t rb3h_seq_record_start(const char *fn, int is_line, int64_t off);            /* the cut rb3h_seq_open_range makes at an offset (-1: not a plain file) */
 /* io.c:104-125: fill `seq` with nt6(forward)+0 and nt6(revcomp)+0 per record until
  * seq->l > max_len; returns the number of strings appended (0 at EOF) or <0 on a parse error;
  * *n_empty counts records of length 0, which are skipped (out of contract in the reference) */

@@ -208,19 +208,49 @@ int rb3h_seq_splittable(const char *fn, int64_t *size)
 }
 
 /* first record start at or behind file offset `from` (the file's length if there is none).  A record starts where a line starts
- * -- with -L every line; FASTA: a line that begins with '>'; FASTQ: a line that begins with '@' whose second successor begins
- * with '+' (a quality line may begin with '@' too, but then the line after it is a header and the one after that a sequence). */
+ * -- with -L every line; FASTA (the first non-empty line of the file begins with '>'): a line that begins with '>'; FASTQ (it begins
+ * with '@'): a line L0 that begins with '@' whose second successor L2 begins with '+', with L1 and L3 of one length and L4 (if there
+ * is one) beginning with '@' again -- a quality line may begin with '@' too, but then the line after it is a header and the one after
+ * that a sequence.  Anything else (multi-line FASTQ, a file that begins with neither) has no start this function vouches for: the
+ * answer is the file's length, i.e. such a file is not cut.  What is found IS a record start for the sequential reader as well, and
+ * rb3h_seq_open_range applies the function to BOTH ends of a range, so ranges that share an end tile the file whatever it holds. */
 static int64_t sio_record_start(int fd, int64_t from, int64_t size, int is_line)
 {
 	uint8_t first = 0, *buf;
-	int64_t ls[3] = {-1, -1, -1}, off, found = -1; /* the last three line starts and their first bytes */
-	uint8_t lc[3] = {0, 0, 0};
+	int64_t ls[5] = {-1, -1, -1, -1, -1}, off, found = -1; /* the last five line starts and their first bytes */
+	uint8_t lc[5] = {0, 0, 0, 0, 0};
 	int at_start; /* the next byte begins a line */
 	if (from <= 0) return 0;
 	if (from >= size) return size;
-	if (!is_line && pread(fd, &first, 1, 0) != 1) return size;
 	buf = (uint8_t*)malloc(1 << 20);
 	if (buf == 0) return -1;
+	if (!is_line) { /* the first byte of the first non-empty line says what the file is */
+		for (off = 0; off < size && first == 0;) {
+			const ssize_t k = pread(fd, buf, 1 << 16, off);
+			ssize_t i;
+			if (k <= 0) break;
+			for (i = 0; i < k && first == 0; ++i) if (buf[i] != '\n' && buf[i] != '\r') first = buf[i];
+			off += k;
+		}
+		if (first != '>' && first != '@') { free(buf); return size; }
+		if (first == '@') { /* FASTQ is only cut if its first records are four lines each: @..., sequence, +..., quality of the sequence's length
+		                       (in a multi-line FASTQ file quality lines that begin with '@' and '+' can imitate any local pattern) */
+			const ssize_t k = pread(fd, buf, 1 << 20, 0);
+			ssize_t i = 0, b0;
+			int nrec = 0, line = 0, ok = 1;
+			int64_t len1 = 0;
+			while (i < k && (buf[i] == '\n' || buf[i] == '\r')) ++i;
+			for (b0 = i; i < k && ok && nrec < 64; ++i) {
+				if (buf[i] != '\n') continue;
+				if (line == 0) ok = buf[b0] == '@';
+				else if (line == 1) len1 = i - b0;
+				else if (line == 2) ok = buf[b0] == '+';
+				else ok = i - b0 == len1, ++nrec;
+				line = (line + 1) & 3, b0 = i + 1;
+			}
+			if (!ok) { free(buf); return size; }
+		}
+	}
 	off = from - 1, at_start = 0; /* (the byte before `from` says whether `from` itself begins a line) */
 	while (found < 0 && off < size) {
 		const ssize_t k = pread(fd, buf, 1 << 20, off);
@@ -233,33 +263,52 @@ static int64_t sio_record_start(int fd, int64_t from, int64_t size, int is_line)
 				if (is_line) found = o;
 				else if (first == '>') { if (buf[i] == '>') found = o; }
 				else {
-					ls[0] = ls[1], lc[0] = lc[1], ls[1] = ls[2], lc[1] = lc[2], ls[2] = o, lc[2] = buf[i];
-					if (ls[0] >= 0 && lc[0] == '@' && lc[2] == '+') found = ls[0];
+					memmove(ls, ls + 1, 4 * sizeof(ls[0])), memmove(lc, lc + 1, 4), ls[4] = o, lc[4] = buf[i];
+					if (ls[0] >= 0 && lc[0] == '@' && lc[2] == '+' && lc[4] == '@' && ls[2] - ls[1] == ls[4] - ls[3]) found = ls[0];
 				}
 			}
 			if (buf[i] == '\n') at_start = 1;
 		}
 		off += k;
 	}
+	if (found < 0 && !is_line && first == '@' && ls[1] >= 0 && lc[1] == '@' && lc[3] == '+') { /* the last record of the file: L1..L4 with nothing behind */
+		uint8_t last = 0;
+		const int64_t l4 = (pread(fd, &last, 1, size - 1) == 1 && last == '\n' ? size : size + 1) - ls[4];
+		if (ls[3] - ls[2] == l4) found = ls[1];
+	}
 	free(buf);
 	return found >= 0 ? found : size;
 }
 
-/* the records of a plain file that START in the byte range [beg, end) (end <= 0: to the end of the file): ranges that tile a file
- * give every record to exactly one reader, in file order */
-rb3h_seqio_t *rb3h_seq_open_range(const char *fn, int is_line, int64_t beg, int64_t end)
+/* the cut sio_record_start makes at file offset `off` (what rb3h_seq_open_range does with either end of its range) */
+int64_t rb3h_seq_record_start(const char *fn, int is_line, int64_t off)
 {
 	int64_t size = 0, at;
+	int fd;
+	if (!rb3h_seq_splittable(fn, &size) || (fd = open(fn, O_RDONLY)) < 0) return -1;
+	at = sio_record_start(fd, off, size, is_line);
+	close(fd);
+	return at;
+}
+
+/* the records of a plain file that START in the byte range [beg, end) (end <= 0: to the end of the file), both ends moved to the
+ * first record start at or behind them: ranges that share their ends tile a file -- every record goes to exactly one reader, in
+ * file order -- because the reader of [a, b) stops at the very offset the reader of [b, c) starts at */
+rb3h_seqio_t *rb3h_seq_open_range(const char *fn, int is_line, int64_t beg, int64_t end)
+{
+	int64_t size = 0, at, stop = 0;
 	rb3h_seqio_t *fp;
 	if (beg <= 0 && end <= 0) return rb3h_seq_open(fn, is_line);
 	if (!rb3h_seq_splittable(fn, &size)) return 0;
 	fp = rb3h_seq_open(fn, is_line);
 	if (fp == 0 || fp->fp != 0) { rb3h_seq_close(fp); return 0; }
 	at = sio_record_start(fp->fd, beg, size, is_line);
-	if (at < 0 || lseek(fp->fd, (off_t)at, SEEK_SET) == (off_t)-1) { rb3h_seq_close(fp); return 0; }
+	if (end > 0 && end < size) stop = end <= beg ? at : sio_record_start(fp->fd, end, size, is_line);
+	if (at < 0 || stop < 0 || lseek(fp->fd, (off_t)at, SEEK_SET) == (off_t)-1) { rb3h_seq_close(fp); return 0; }
 	fp->next_off = at, fp->buf_off = at;
-	fp->range_end = end > 0 && end < size ? end : 0;
+	fp->range_end = stop > 0 && stop < size ? stop : 0; /* (no record start behind `end`: this reader takes the rest of the file) */
 	if (fp->range_end > 0 && at >= fp->range_end) fp->is_eof = 1; /* (no record starts in this range) */
+	if (end > 0 && end < size && stop >= size && at >= size) fp->is_eof = 1;
 	return fp;
 }
 

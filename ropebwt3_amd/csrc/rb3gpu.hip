@@ -528,7 +528,7 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exac
 		h->ib[i].grp = nullptr, h->ib[i].grp_cap = 0;
 		size_t want = exact ? (size_t)ngrp + 16 : (size_t)ngrp + (size_t)(ngrp >> 1) + 16;
 		if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * RB3_GRP_ALLOC)) < 0) {
-			want = (size_t)ngrp;
+			want = (size_t)ngrp + 1; // (one spare entry: k_chain asks for the slot words of a group and of the one behind it)
 			if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * RB3_GRP_ALLOC)) < 0) return r;
 		}
 		h->ib[i].grp_cap = want;

@@ -745,10 +745,10 @@ __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, uint32_t k
 
 /* the same with the slot's offset in its group given (derived from the directory's mask: no header word needed) */
 template<int LPW = 8>
-__device__ __forceinline__ void octc_finish_pair_at(const RankLoadC &rl, int off_lo, int off_hi, int c, int j, int64_t *lo_n, int64_t *hi_n)
+__device__ __forceinline__ void octc_finish_pair_at(const RankLoadC &rl, int off_lo, int off_hi, int c, int j, int64_t *lo_n, int64_t *hi_n, bool have_hdr = false, uint32_t hdr_c = 0u)
 {
 	uint32_t ca, cb, mt;
-	const uint64_t hb = rl.gc + octc_hdr_pick<LPW>(rl, c, j); // (the header may be the whole LF base: 32 bits; asked for first: it crosses the lanes while the codes are counted)
+	const uint64_t hb = rl.gc + (have_hdr ? hdr_c : octc_hdr_pick<LPW>(rl, c, j)); // (the header may be the whole LF base: 32 bits; asked for first: it crosses the lanes while the codes are counted)
 	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16;
 	v = grp_sum<LPW>(v);
@@ -1054,6 +1054,12 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 	// flushes them with ONE store instruction every 8 iterations.
 	int64_t bkb = -1, bval = 0;
 	uint32_t it = 0, age = 0;
+	// I32, common step: the slot words (gsm) of the group the NEXT insertion point falls into, asked for as soon as the slot of this step has
+	// arrived: its header holds the LF base of c at the slot start, and the step adds at most the slot's symbols (<= 8192) to it, so the next
+	// point lies in group base >> 13 or in the one behind it -- two adjacent 8-byte words, one 16-byte request that is in flight while the
+	// codes are counted.  The step's chain is then slot -> (slot words | decode) -> slot instead of slot -> decode -> slot words -> slot.
+	uint32_t pf_g = 0x80000000u; // group of pf_w.x/.y (pf_w.z/.w: the group behind it); 0x80000000: nothing asked for
+	uint4 pf_w = make_uint4(0u, 0u, 0u, 0u);
 #ifdef RB3_PROF_STEP
 	uint64_t prof_t[7] = {0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
 #endif
@@ -1170,6 +1176,11 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					// for at the same time but only needed at the very end
 					const int64_t g = I32 ? (int64_t)((uint32_t)lo >> RB3_GRP_BITS) : lo >> RB3_GRP_BITS;
 					RankLoadC rl;
+#ifndef RB3_NO_GSM_PF
+					const uint32_t pf_d = ((uint32_t)lo >> RB3_GRP_BITS) - pf_g; // 0 or 1 if the words asked for during the last step are the ones needed
+					if (I32 && RB3_BAL(pf_d <= 1u) == exm) rl.sm = pf_d ? ((uint64_t)pf_w.w << 32 | pf_w.z) : ((uint64_t)pf_w.y << 32 | pf_w.x);
+					else
+#endif
 					if (I32) rl.sm = *(const uint64_t*)((const char*)b1.gsm + (((uint32_t)lo >> RB3_GRP_BITS) << 3));
 					else rl.sm = b1.gsm[g];
 					rl.gc = 0;
@@ -1207,6 +1218,10 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 						const uint32_t so = rl.sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * (LPW == 8 ? 16u : 32u);
 						const uint32_t sob = so + (same ? 0u : (uint32_t)sizeof(rb3_slot_t));
 						rl.sl = *(const uint4*)((const char*)b1.slot16 + so);
+#ifndef RB3_NO_SKIP_DUP
+						if (m_pair == exm) slb = make_uint4(0u, 0u, 0u, 0u); // every interval of the wave inside one run slot: nobody looks at a second one
+						else
+#endif
 						slb = *(const uint4*)((const char*)b1.slot16 + sob);
 						if (LPW == 4) rl.sl2 = *(const uint4*)((const char*)b1.slot16 + (so + 16u));
 						if (LPW == 4) slb2 = *(const uint4*)((const char*)b1.slot16 + (sob + 16u));
@@ -1226,6 +1241,16 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					if ((gap == 0 || sid >= 0) && j == (int)(it & (uint32_t)(LPW - 1)))
 						bkb = trec ? tp : kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					uint32_t hdr_c = 0u;
+#ifndef RB3_NO_GSM_PF
+					if (I32 && LPW == 8) { // (before the record store: what is asked for behind a written-through store waits for its acknowledgement)
+						hdr_c = oct_pick(rl.sl.x, c + 1);
+						pf_g = hdr_c >> RB3_GRP_BITS;
+						const uint2 *pfp = (const uint2*)((const char*)b1.gsm + (pf_g << 3)); // (the directory has a spare word behind the last group's)
+						const uint2 pa = pfp[0], pb = pfp[1];
+						pf_w = make_uint4(pa.x, pa.y, pb.x, pb.y);
+					}
+#endif
 					// the records of the last eight steps go out here, where nothing is asked for during the whole decode: the store is slow
 					// (written through) and whatever is asked for after it waits for its acknowledgement (vmcnt counts in order)
 					if ((it & (uint32_t)(LPW - 1)) == (uint32_t)(LPW - 1) && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
@@ -1237,7 +1262,11 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 #ifdef RB3_PROF_STEP
 					if (__ballot(!(rle && same)) != 0ull) prof_t[5] += 1;
 #endif
+#ifndef RB3_NO_GSM_PF
+					if (m_pair == exm) octc_finish_pair_at<LPW>(rl, off_lo, off_hi, c, j, &lo_n, &hi_n, I32 && LPW == 8, hdr_c); // (rle && same, everybody)
+#else
 					if (m_pair == exm) octc_finish_pair_at<LPW>(rl, off_lo, off_hi, c, j, &lo_n, &hi_n); // (rle && same, everybody)
+#endif
 					else if (wave_all(rle && (grp_bcast0<LPW>(slb.x, j) & RB3_SLOT_RLE) != 0u && !far)) { // some walker's interval straddles two run slots: everybody through the two-slot decode
 						uint32_t ca, cb;
 						slice_count_pk2<LPW>(rl.sl, rl.sl2, slb, slb2, off_lo, same ? off_hi : off_hi - (int)((wend - w0) << RB3_WIN_BITS), c, j, &ca, &cb);
@@ -1312,6 +1341,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 			prof_last = 0;
 #endif
 			if ((++it & (uint32_t)(LPW - 1)) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
+			pf_g = 0x80000000u;
 			bool met = TEXT ? (int64_t)rc >= 0 : (int64_t)x >= 0;  // this row already carries a record
 #ifdef RB3GPU_TEST_HOOKS
 			if (TENT && hide_first && met && gap == 0) {

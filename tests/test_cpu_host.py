@@ -49,9 +49,18 @@ def test_sais_rejects_bad_text():
 def test_fmd_writer_bit_exact(name, tmp_path):
     ent = MAN[name]
     plain = gzip.open(os.path.join(util.GOLDEN, ent["plain"])).read().strip()
-    fmd = host.fmd_bytes_from_plain(plain)   # the host FMD writer alone (no sub-command of the CLI: plain2fmd is out of scope)
+    fmd = host.fmd_bytes_from_plain(plain)   # the host FMD writer through the library
     assert hashlib.md5(fmd).hexdigest() == ent["fmd_md5"]
     assert fmd == open(os.path.join(util.GOLDEN, ent["fmd"]), "rb").read()
+    src = tmp_path / "bwt.txt"                # ... and through the `plain2fmd` sub-command (the reference's main.c:299-331)
+    src.write_bytes(plain + b"\n")
+    assert run([CLI, "plain2fmd", str(src)]) != b""
+    body = plain if plain.endswith(b"$") else plain
+    src.write_bytes(body)
+    assert run([CLI, "plain2fmd", str(src)]) == fmd
+    out = tmp_path / "o.fmd"
+    run([CLI, "plain2fmd", "-o", str(out), str(src)])
+    assert out.read_bytes() == fmd
 
 
 @pytest.mark.parametrize("name", ["genomes12", "reads_fq", "copies3000", "longruns", "edge_chars"])

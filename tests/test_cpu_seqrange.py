@@ -18,7 +18,8 @@ def _read_all(fn, is_line, ranges):
     return out
 
 
-@pytest.mark.parametrize("kind", ["line", "fasta", "fasta_multiline", "fastq"])
+@pytest.mark.parametrize("kind", ["line", "fasta", "fasta_multiline", "fastq", "fasta_blank_first", "fasta_at_headers", "fastq_multiline",
+                                  "fastq_crlf", "fastq_no_final_newline", "garbage_first"])
 def test_ranges_tile_a_file(tmp_path, kind):
     rng = random.Random(5)
     seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(1, 300))) for _ in range(400)]
@@ -27,8 +28,20 @@ def test_ranges_tile_a_file(tmp_path, kind):
         for i, s in enumerate(seqs):
             if kind == "line":
                 f.write(s + "\n")
-            elif kind == "fasta":
+            elif kind in ("fasta", "fasta_blank_first", "garbage_first"):
+                if i == 0 and kind != "fasta":   # (files the cut detector does not vouch for must still tile)
+                    f.write("\n\n" if kind == "fasta_blank_first" else "x\n")
                 f.write(">s%d\n%s\n" % (i, s))
+            elif kind == "fasta_at_headers":      # kseq takes '@' for a header in a FASTA file too
+                f.write("%ss%d\n%s\n" % (">" if i % 3 else "@", i, s) if i else ">s0\n%s\n" % s)
+            elif kind == "fastq_multiline":
+                q = "".join(rng.choice("@+>I#") for _ in s)
+                f.write("@s%d\n" % i + "\n".join(s[k:k + 50] for k in range(0, len(s), 50)) + "\n+\n" + "\n".join(q[k:k + 50] for k in range(0, len(q), 50)) + "\n")
+            elif kind in ("fastq_crlf", "fastq_no_final_newline"):
+                q = "".join(rng.choice("@+>I#") for _ in s)
+                nl = "\r\n" if kind == "fastq_crlf" else "\n"
+                rec = "@s%d%s%s%s+%s%s%s" % (i, nl, s, nl, nl, q, nl)
+                f.write(rec[:-1] if kind == "fastq_no_final_newline" and i + 1 == len(seqs) else rec)
             elif kind == "fasta_multiline":
                 f.write(">s%d\n" % i + "\n".join(s[k:k + 60] for k in range(0, len(s), 60)) + "\n")
             else:

@@ -72,6 +72,8 @@ typedef struct {
 	int64_t n_thinned;           /* merges done again with fewer, longer walkers because the table of tentative stretches was full */
 	int64_t tent_mask_bits;      /* width of the drop-out masks the last single-sync merge settled its tentative records with: 256, or 512 / 1024 /
 	                                2048 once walkers have met intervals of more matching suffixes than that (an index of > 255 relatives) */
+	int64_t n_junctions_checked; /* junctions of the speculative walk (a walker meeting somebody's record; a drop-out event) whose LF relation was
+	                                verified after the rank phase: all of them, on every merge with text-order words */
 } rb3gpu_stats_t;
 
 void rb3gpu_opt_init(rb3gpu_opt_t *opt);
@@ -198,6 +200,9 @@ int rb3gpu_export_plain(rb3gpu_t *h, uint8_t *out);
  * is itself a valid partial BWT, so a whole index can be merged into another one with
  * rb3gpu_merge_plain_dev -- the tree-shaped multi-GPU build (rb3_fmi_merge, fm-index.c:251-277) */
 int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out);
+int rb3gpu_export_plain_range_dev(rb3gpu_t *h, int64_t beg, int64_t end, uint8_t *d_out); /* symbols [beg, end) only */
+/* bounds[0..n] of n intervals of positions that hold about equal BYTES of the block array (cut at group boundaries) */
+int rb3gpu_balanced_bounds(rb3gpu_t *h, int n, int64_t *bounds);
 
 /* Sampled suffix array of the index, `ropebwt3 ssa` (rb3_ssa_gen ssa.c:54-81; the words are those of
  * rb3_ssa_t fm-index.h:28-36 as written by rb3_ssa_dump ssa.c:198-213):
@@ -341,6 +346,15 @@ typedef struct rb3gpu_comm_s {
 } rb3gpu_comm_t;
 int rb3gpu_sh_merge(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw,
 		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds);
+/* The same with the BATCH sharded as well (what rb3gpu_shard_merge runs): every rank holds d_tprev -- the symbol before every text position,
+ * one byte each, the only thing a step needs of the batch (rb3gpu_tprev_from_tw makes it from the text-order words) -- and d_tw_slice, the
+ * text-order words of ITS text range [len * rank / world, len * (rank + 1) / world) only.  A record is (text position, insertion point); when
+ * the chains have ended, one all-to-all takes the records to the owners of their text positions and one brings row << 3 | symbol back (the same
+ * 16-byte collective as the rounds'): replicated 1 byte per batch symbol instead of 9, and 16 bytes per symbol cross the links once instead of
+ * 8 (world - 1) out of one device. */
+int rb3gpu_sh_merge_text(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_tprev, const uint64_t *d_tw_slice,
+		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds);
+int rb3gpu_tprev_from_tw(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, uint8_t *d_out);
 
 /* ranks = threads of ONE process, one handle (device) each.  rb3gpu_group_create(world) once, rb3gpu_group_comm(g, rank, h, &comm)
  * by each rank's thread; rb3gpu_group_abort wakes every rank waiting in a collective (they return RB3GPU_ESTATE). */
@@ -359,19 +373,30 @@ int rb3gpu_rccl_comm_create(rb3gpu_t *h, int rank, int world, const char id[RB3G
 void rb3gpu_rccl_comm_destroy(rb3gpu_comm_t *comm);
 
 /* The interval-sharded index as ONE object for a single-process host program (`ropebwt3-amd build --gpus N --interval`): N handles,
- * one per device, a thread per handle during a merge, the thread-group communicator above between them.
- *   rb3gpu_shard_split   h0 holds a whole index (the first batch): it is cut into n intervals of about equal length, h0 keeps the
- *                        first, n - 1 new handles (options *opt, devices[1..n-1]; devices[0] must be h0's) get the others, device to
- *                        device.  NULL: fewer symbols than intervals, or a device / memory error.
- *   rb3gpu_shard_merge   one batch (BWT and text-order words on h0's device, sentinel positions on the host): replicated to the other
- *                        devices over xGMI, merged by n threads running rb3gpu_sh_merge.
- *   rb3gpu_shard_gather  the intervals are put back together in h0 (plain symbols, device to device), the other handles destroyed and
- *                        the object freed: h0 then serves every export call as if the build had run on it alone.
+ * one per device, a thread per handle (they live as long as the object), the thread-group communicator above between them.  Nothing of
+ * the index, and of a batch nothing but one byte per symbol, is ever whole on one device:
+ *   rb3gpu_shard_split   h0 holds a whole index (the first batch): it is cut into n intervals that hold about equal BYTES of the block array
+ *                        (rb3gpu_balanced_bounds), an interval at a time (its symbols, 1 byte each, device to device); h0 keeps the first,
+ *                        n - 1 new handles (options *opt, devices[1..n-1]; devices[0] must be h0's) get the others.  NULL: fewer symbols
+ *                        than intervals, or a device / memory error.
+ *   rb3gpu_shard_merge   one batch (text-order words on h0's device -- d_bwt is not read --, sentinel positions on the host): every rank
+ *                        pulls the symbol-before array (1 byte per symbol) and ITS text range of the text-order words (8 bytes per symbol / n)
+ *                        over its own xGMI link, all at once; then n threads run rb3gpu_sh_merge_text.
+ *   rb3gpu_shard_export_runs / _run_words   the runs of the intervals in rank order, joined where they meet at a seam (the reference writes
+ *                        its ropes one after the other and rld_enc joins them, fm-index.c:31-54, rld0.c:153-161): what the FMD / FMR /
+ *                        plain writers take -- no gather.  rb3gpu_shard_get_acc: the cumulative symbol counts of the whole index.
+ *   rb3gpu_shard_destroy the other handles destroyed, the object freed; h0 still holds interval 0.
+ *   rb3gpu_shard_gather  the intervals put back together in h0 (plain symbols, the WHOLE index on h0's device: only for a caller that must
+ *                        merge a batch the ordinary way), the other handles destroyed and the object freed.
  *   rb3gpu_shard_handle  the handle of interval i (statistics, tests); rb3gpu_shard_bounds copies the n + 1 bounds, returns n. */
 typedef struct rb3gpu_shard_s rb3gpu_shard_t;
 rb3gpu_shard_t *rb3gpu_shard_split(rb3gpu_t *h0, int n, const int *devices, const rb3gpu_opt_t *opt);
 int rb3gpu_shard_merge(rb3gpu_shard_t *s, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_chains, const int64_t *chain_tp, int64_t *n_rounds);
 int rb3gpu_shard_gather(rb3gpu_shard_t *s);
+int rb3gpu_shard_get_acc(const rb3gpu_shard_t *s, int64_t acc[RB3GPU_ASIZE + 1]);
+int rb3gpu_shard_export_runs(rb3gpu_shard_t *s, rb3gpu_emit_f emit, void *data);
+int rb3gpu_shard_export_run_words(rb3gpu_shard_t *s, rb3gpu_emit_words_f emit, void *data);
+void rb3gpu_shard_destroy(rb3gpu_shard_t *s);
 rb3gpu_t *rb3gpu_shard_handle(rb3gpu_shard_t *s, int i);
 int rb3gpu_shard_bounds(const rb3gpu_shard_t *s, int64_t *bounds);
 

@@ -8,7 +8,7 @@
  * librb3gpu.so).  Only tests/, __graft_entry__.smoke() and bench.py's
  * `cpu_baseline` leg may load liboracle.so.
  *
- * Parity status: PINNED.  tests/test_oracle_pin.py checks every function here
+ * Parity status: PINNED.  tests/test_cpu_oracle_pin.py checks every function here
  * against (a) the known-answer vectors K1-K4 of SURVEY.md section 8(c), (b) the golden
  * fixtures under tests/golden/ that were produced by the unmodified reference
  * binary (tools/make_golden.py), and (c) -- whenever oracle/_ref/ exists -- the

@@ -412,9 +412,6 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 		}
 		if (ret == 0 && rb3h_verbose >= 3)
 			fprintf(stderr, "[M::%s::%.3f*%.2f] %s the partial BWT for %ld symbols\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), first ? "encoded" : "merged", (long)b->len);
-	} else if (g_iv.n > 1 && *has_index) {
-		fprintf(stderr, "ERROR: --interval merges batches the GPU sorted (their text-order words); this one was sorted on the host\n");
-		return -1;
 	} else if (!*has_index) {
 		ret = rb3gpu_from_plain(h, b->len, b->bwt);
 		if (ret == 0 && rb3h_verbose >= 3)
@@ -422,6 +419,14 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 	} else {
 		/* long strings: hand over the sampled inverse suffix array as LF walkers (same result, text-regular
 		 * parallelism); short strings (reads): one walker per string is what the engine does by itself */
+		if (g_iv.s) { /* --interval and a batch the HOST had to sort (a record beyond the GPU sorter's limit, no device room): there are no text-order
+		                 words to walk the intervals with, so the intervals go back into one handle, this batch is merged the ordinary way, and the
+		                 next GPU-sorted batch cuts the index again (a long build must not die of one such batch) */
+			const int r = rb3gpu_shard_gather(g_iv.s);
+			g_iv.s = 0;
+			if (r < 0) { fprintf(stderr, "ERROR: the GPU engine failed to put the intervals together for a host-sorted batch: %s\n", rb3gpu_strerror(r)); return -1; }
+			if (rb3h_verbose >= 2) fprintf(stderr, "[W::%s] --interval: a host-sorted batch of %ld symbols is merged on one device; the index is cut again afterwards\n", "main_build", (long)b->len);
+		}
 		if (b->walkers) ret = rb3gpu_merge_plain_walkers(h, b->len, b->bwt, b->n_walkers, (const rb3gpu_walker_t*)b->walkers);
 		else ret = rb3gpu_merge_plain(h, b->len, b->bwt);
 		if (ret == 0 && rb3h_verbose >= 3)
@@ -949,24 +954,48 @@ int main_build(int argc, char *argv[])
 		free(sl); free(th); free(rb);
 	}
 	free(fsize);
-	if (g_iv.s) { /* --interval: the intervals back into one handle for the writers below */
-		const int r = rb3gpu_shard_gather(g_iv.s);
-		g_iv.s = 0;
-		if (r < 0) { fprintf(stderr, "ERROR: the GPU engine failed to put the intervals together: %s\n", rb3gpu_strerror(r)); ret = -1; }
-		else if (rb3h_verbose >= 3)
-			fprintf(stderr, "[M::%s::%.3f*%.2f] %ld batches merged into %d intervals: %ld lock-step rounds, %.3f s\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), (long)g_iv.batches, g_iv.n, (long)g_iv.rounds, g_iv.t_walk);
-	}
+	if (g_iv.batches > 0 && rb3h_verbose >= 3)
+		fprintf(stderr, "[M::%s::%.3f*%.2f] %ld batches merged into %d intervals: %ld lock-step rounds, %.3f s\n", __func__, rb3h_realtime(), rb3h_percent_cpu(), (long)g_iv.batches, g_iv.n, (long)g_iv.rounds, g_iv.t_walk);
 	if (n_empty > 0 && rb3h_verbose >= 2)
 		fprintf(stderr, "WARNING: skipped %ld empty sequence(s)\n", (long)n_empty);
 
 	if (ret != 0 || !has_index) {
+		if (g_iv.s) rb3gpu_shard_destroy(g_iv.s), g_iv.s = 0;
 		while (n_old_sorters > 0) rb3gpu_sorter_destroy(old_sorters[--n_old_sorters]);
 		pin_drain();
 		rb3gpu_destroy(h);
 		return 1;
 	}
 
-	if (opt.fmt == FMT_FMR) { /* build.c:245-260 */
+	if (g_iv.s) { /* --interval: the writers take the intervals in rank order, where they are (the reference writes its ropes one after the other,
+	                 fm-index.c:31-54, and rld_enc joins the runs that meet: rld0.c:153-161) -- the index is never put together on one device */
+		int64_t acc[7];
+		rb3gpu_shard_get_acc(g_iv.s, acc);
+		if (opt.fmt == FMT_FMR) {
+			rb3h_fmrw_t *w = rb3h_fmrw_init(acc, opt.max_nodes, opt.block_len);
+			ret = w ? rb3gpu_shard_export_runs(g_iv.s, sink_fmr, w) : -1;
+			if (ret == 0) ret = rb3h_fmrw_dump(w, stdout);
+			if (w) rb3h_fmrw_destroy(w);
+		} else if (opt.fmt == FMT_FMD) {
+			rb3h_fmdw_t *w = rb3h_fmdw_init();
+			ret = w ? rb3gpu_shard_export_run_words(g_iv.s, sink_fmd_words, w) : -1;
+			if (ret == 0) ret = rb3h_fmdw_finish(w);
+			if (ret == 0) ret = rb3h_fmdw_dump(w, stdout);
+			if (w) rb3h_fmdw_destroy(w);
+		} else {
+			ret = rb3gpu_shard_export_runs(g_iv.s, sink_plain, stdout);
+			fputc('\n', stdout);
+		}
+		if (rb3h_verbose >= 3) { /* what each device held */
+			int64_t bnd[RB3GPU_SH_MAXIV + 1];
+			const int n = rb3gpu_shard_bounds(g_iv.s, bnd);
+			for (c = 0; c < n; ++c) {
+				rb3gpu_stats_t st;
+				if (rb3gpu_stats(rb3gpu_shard_handle(g_iv.s, c), &st) == 0)
+					fprintf(stderr, "[M::%s] interval %d on device %d: %ld symbols, index %.1f MB, peak device memory %.1f MB\n", __func__, c, g_iv.devices[c], (long)(bnd[c + 1] - bnd[c]), st.bytes_index / 1e6, st.bytes_peak / 1e6);
+			}
+		}
+	} else if (opt.fmt == FMT_FMR) { /* build.c:245-260 */
 		ret = dump_fmr(h, &opt, stdout);
 	} else if (opt.fmt == FMT_FMD) {
 		ret = write_fmd(h, stdout);

@@ -124,6 +124,8 @@ struct Tune {
 	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
 	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
+	int junction_check = 16; // ... and the LF relation at the junctions of the speculative walk (k_junction_check): wherever a walker met somebody's record -- all
+	                         // of them, always -- and at the drop-out events of every n-th stretch id (1: every event, ~10 ms per 152-genome build; 0: off)
 	int64_t load_chunk = 16384; // groups (of 8192 symbols) an FMD stream is decoded and built by at a time when it holds more than that (rb3gpu_from_fmd_words)
 #ifdef RB3GPU_TEST_HOOKS
 	int hide_first = 0;      // k_chain: exact walkers do not see the tentative records of first stretches (the late-walker race of DESIGN.md, made deterministic)
@@ -133,6 +135,7 @@ struct Tune {
 	int64_t reb_lcap = 0;    // > 0: entries of the hand-over list the window scratch takes (a longer list: rebuild done again)
 	int64_t reb_slot_cap = 0;// > 0: pretend the slot array of a single-sync rebuild holds this many slots
 	int corrupt_pos = 0;     // move a range of rows of pos[] by one after the walk (still monotone): the LF check must notice
+	int64_t corrupt_sfin = -1; // >= 0: give the n-th settled event stretch of the merge a wrong unknown (k_test_corrupt_sfin): the junction check must notice
 	int64_t pos_limit = 0;   // > 0: pretend merged positions must stay below this instead of 2^38 (beyond: staged path, no tentative records)
 	int64_t win_scratch = 0; // > 0: pretend the window kernels' scratch may take this many bytes instead of 8 GB (beyond: group-sequential rebuild)
 	int64_t slot_bytes = 0;  // > 0: pretend the upper bound of the slot array may take this many bytes instead of 16 GB (beyond: staged path)
@@ -439,13 +442,15 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "guard")) t.guard = v != 0;
 	else if (!strcmp(key, "load_chunk")) t.load_chunk = v < 1 ? 1 : v;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
-	else if (!strcmp(key, "force_fallback") || !strcmp(key, "hide_first") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
+	else if (!strcmp(key, "junction_check")) t.junction_check = v < 0 ? 0 : v > 4096 ? 4096 : (int)v;
+	else if (!strcmp(key, "corrupt_sfin") || !strcmp(key, "force_fallback") || !strcmp(key, "hide_first") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
 			!strcmp(key, "pos_limit") || !strcmp(key, "win_scratch") || !strcmp(key, "slot_bytes")) {
 #ifdef RB3GPU_TEST_HOOKS
 		if (!strcmp(key, "pos_limit")) t.pos_limit = v;
 		else if (!strcmp(key, "win_scratch")) t.win_scratch = v;
 		else if (!strcmp(key, "slot_bytes")) t.slot_bytes = v;
 		else if (!strcmp(key, "corrupt_pos")) t.corrupt_pos = v != 0;
+		else if (!strcmp(key, "corrupt_sfin")) t.corrupt_sfin = v;
 		else if (!strcmp(key, "reb_lcap")) t.reb_lcap = v;
 		else if (!strcmp(key, "reb_slot_cap")) t.reb_slot_cap = v;
 		else if (!strcmp(key, "force_fallback")) t.force_fallback = v != 0;
@@ -467,8 +472,8 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
-		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
 		size_t l = strlen(name);
@@ -528,7 +533,7 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exac
 		h->ib[i].grp = nullptr, h->ib[i].grp_cap = 0;
 		size_t want = exact ? (size_t)ngrp + 16 : (size_t)ngrp + (size_t)(ngrp >> 1) + 16;
 		if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * RB3_GRP_ALLOC)) < 0) {
-			want = (size_t)ngrp + 1; // (one spare entry: k_chain asks for the slot words of a group and of the one behind it)
+			want = (size_t)ngrp + 4; // (spare entries: k_chain asks for the slot words of a group and of the one behind it)
 			if ((r = dev_malloc(h, (void**)&h->ib[i].grp, want * RB3_GRP_ALLOC)) < 0) return r;
 		}
 		h->ib[i].grp_cap = want;
@@ -879,6 +884,9 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 		// behind the group kernels, where its ~15 us in the command processor pass beside their 250 (in front of them the chip idled)
 		if (h->lf_wait) { HIPCHK(hipStreamWaitEvent(h->st, h->evx[2], 0)); h->lf_wait = false; }
 		uint8_t *lbp = (uint8_t*)h->lbst.p;
+		// the look-back words are told apart by a 20-bit tag of the launch, never cleared -- except where the tag comes round again: words that a
+		// launch 2^20 merges ago left in blocks no launch has written since (the index was re-made smaller on this handle) would pass for this one's
+		if (((h->lb_epoch + 1) & 0xFFFFFull) == 0) HIPCHK(hipMemsetAsync(lbp + 64, 0, h->lbst.cap > 64 ? h->lbst.cap - 64 : 0, h->st));
 		hipLaunchKernelGGL(k_scan_place, dim3((unsigned)sp_nblk), dim3(RB3_SP_THREADS), 0, h->st, (const uint32_t*)gstat, ngrp, ntot, (const uint8_t*)(runspace ? gkind : nullptr), (const uint4*)h->gslots.p, (const uint4*)h->pslots.p,
 				(const uint32_t*)(runspace ? gpos : nullptr), h->ib[dst].grp, (uint64_t*)(h->ib[dst].grp + h->ib[dst].grp_cap), (uint4*)h->ib[dst].slots, (unsigned long long*)dtot,
 				(unsigned long long*)(lbp + 64), (unsigned int*)lbp /* the block counter sits in FRONT of the look-back state: a fixed address, zero between launches */, (++h->lb_epoch, (h->lb_epoch & 0xFFFFFull) ? h->lb_epoch : ++h->lb_epoch), ao, (const uint64_t*)((uint64_t*)h->misc.p + MISC_LF_TOT), skip,
@@ -962,7 +970,9 @@ static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_ro
 
 /* the sampled LF-consistency check of pos[] (k_lf_check), against the index as it is BEFORE the merge is installed; counts into
  * misc[4] (with the unsettled tentative records: a failure first makes the merge redo its rank phase without speculation) */
-static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b2, int64_t len, bool side, hipEvent_t here = nullptr) // here: an event the caller has just recorded on the main stream (saves recording another one: every record is a packet the command processor works through, ~3-5 us)
+struct JuncArgs { const uint64_t *tw; const rb3_stretch_t *tab; const uint32_t *sidctr; const int64_t *jmet; int64_t nwalk; const unsigned long long *nwalk_dev; };
+#define MISC_JUNC 41 /* junctions k_junction_check looked at */
+static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b2, int64_t len, bool side, hipEvent_t here = nullptr, const JuncArgs *ja = nullptr) // here: an event the caller has just recorded on the main stream (saves recording another one: every record is a packet the command processor works through, ~3-5 us)
 {
 	const int64_t stride = h->tn.lf_check;
 	if (stride <= 0 || h->tpre.p == nullptr) return false;
@@ -976,6 +986,9 @@ static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b
 	if (!side && h->lf_wait) { (void)hipStreamWaitEvent(h->st, h->evx[2], 0); h->lf_wait = false; } // (on the main stream after all: the histogram it reads runs on the side stream)
 	hipLaunchKernelGGL(k_lf_check, dim3((unsigned)((ns * 8 + 255) / 256)), dim3(256), 0, s, view_of(h), dpos, d_b2, len, (const uint64_t*)h->tpre.p,
 			(const uint64_t*)(misc + MISC_LF_TOT), stride, misc + 2, misc + MISC_LF_CHK);
+	if (ja != nullptr && h->tn.junction_check) // every junction of the speculative walk, deterministically (k_junction_check)
+		hipLaunchKernelGGL(k_junction_check, dim3(512), dim3(256), 0, s, view_of(h), dpos, ja->tw, len, ja->tab, ja->sidctr, ja->jmet, ja->nwalk, ja->nwalk_dev, misc + 2, misc + MISC_LF_CHK, misc + MISC_JUNC,
+				h->tn.junction_check, (int)(h->stt.n_rounds % h->tn.junction_check)); // (a different residue of the stretch ids every merge)
 	if (side) (void)hipEventRecord(h->evx[1], h->st2);
 	return side; // true: the caller makes its stream wait for evx[1] before it reads the counters
 }
@@ -1456,6 +1469,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	}
 	int64_t *dpos = (int64_t*)h->pos.p;
 	int64_t *drec = trec ? (int64_t*)h->post.p : dpos; // where the walkers leave their records
+	// one word per walker behind the list's buffer: where it met somebody's record (k_chain: jmet; read by k_junction_check)
+	int64_t *jmet = tent && d_tw != nullptr && !auto_list ? (int64_t*)((char*)h->wl.p + (size_t)n_walkers * 32) : nullptr;
 	{
 		const IdxView iv = view_of(h);
 		// lanes per walker: an octet, or a QUAD (16 walkers share a wave's instruction stream; every lane takes two slices of a slot).  Quads exist for
@@ -1482,7 +1497,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #define RB3_TREC_ARG (trec ? 1 : 0)
 #endif
 #define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0, \
-			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG)
+			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG, jmet)
 #ifdef RB3_WITH_QUADS /* a quad per walker (k_chain<..., 4>) was measured slower in every regime: compiled in on request only */
 #define RB3_LAUNCH_FAST(D, T, X) do { if (lpw == 4) RB3_LAUNCH_FAST1(D, T, X, 4); else RB3_LAUNCH_FAST1(D, T, X, 8); } while (0)
 #else
@@ -1507,10 +1522,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		case 7: // (the headline's kernel: 32-bit positions in the common step where index and batch allow it)
 			if (iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29) && lpw == 8)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 8, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
-					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG);
+					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG, jmet);
 			else if (quad_ok && lpw == 4)
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 4, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
-					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG);
+					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG, jmet);
 			else RB3_LAUNCH_FAST(false, true, 1);
 			break;
 		default: RB3_LAUNCH_FAST(false, true, 0); break;
@@ -1525,6 +1540,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		}
 		if (tent) {
 			launch_settle(h, iv, tab, mx, (const uint32_t*)sidctr, sfin, misc + 2, (int)RB3_RESW_MAXHOPS, tq, (const uint32_t*)mctr), h->stt.tent_mask_bits = 256 * tq;
+#ifdef RB3GPU_TEST_HOOKS
+			if (h->tn.corrupt_sfin >= 0) hipLaunchKernelGGL(k_test_corrupt_sfin, dim3(1), dim3(64), 0, h->st, (const rb3_stretch_t*)tab, (const uint32_t*)sidctr, sfin, h->tn.corrupt_sfin, (long long*)(misc + 42));
+#endif
 		}
 		if (rows_fused) { // validation and the rows-per-window table of the rebuild in one pass over pos[]
 			const dim3 g1((unsigned)((len + 1 + 255) / 256));
@@ -1556,7 +1574,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #endif
 	HIPCHK(hipEventRecord(h->ev[2], h->st));
 	h->lf_wait = lf_beside; // (the batch's totals, side stream: awaited where they are first read -- k_scan_place, or below before the counters go to the host)
-	const bool lf_side = launch_lf_check(h, (const int64_t*)dpos, d_b2, len, true, h->ev[2]);
+	const JuncArgs ja = { d_tw, tab, (const uint32_t*)sidctr, jmet, n_walkers, (const unsigned long long*)nullptr };
+	const bool lf_side = launch_lf_check(h, (const int64_t*)dpos, d_b2, len, true, h->ev[2], jmet ? &ja : nullptr);
 	int64_t ngrp = 0, nslots = 0, acc[7];
 	if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) { h->lf_wait = false; return r; }
 	if (h->lf_wait) { HIPCHK(hipStreamWaitEvent(h->st, h->evx[2], 0)); h->lf_wait = false; }
@@ -1597,9 +1616,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	h->stt.n_rank_launches += 1, h->stt.n_rounds += 1;
 	guard_check(h, __func__);
 	h->stt.n_lf_steps += (int64_t)hm[1];
+	h->stt.n_junctions_checked += jmet ? (int64_t)hm[MISC_JUNC] : 0;
 	h->stt.n_lf_checked += (int64_t)hm[MISC_LF_CHK];
 #ifdef RB3_PROF_STEP
-	if (hm[37]) fprintf(stderr, "[prof] common step x %llu (lane 0 of every wave): directory %.0f cycles, slot %.0f, decode+rest %.0f, between steps %.0f; %.1f %% of these steps ran the two-decode side for some walker, %.1f %% because of a bit-plane slot\n", hm[37], (double)hm[34] / hm[37], (double)hm[35] / hm[37], (double)hm[36] / hm[37], (double)hm[38] / hm[37], 100.0 * hm[9] / hm[37], 100.0 * hm[10] / hm[37]);
+	if (hm[37]) fprintf(stderr, "[prof] common step x %llu (lane 0 of every wave): directory %.0f cycles, slot %.0f, decode+rest %.0f, between steps %.0f; %.1f %% of these steps ran the two-decode side for some walker; directory wait of the steps behind a flush of records: %.0f cycles\n", hm[37], (double)hm[34] / hm[37], (double)hm[35] / hm[37], (double)hm[36] / hm[37], (double)hm[38] / hm[37], 100.0 * hm[9] / hm[37], 8.0 * hm[10] / hm[37]);
 #endif
 #ifdef RB3_PROF
 	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, %.1f %% of them with the two-decode path -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], 100.0 * (double)hm[12] / (double)hm[10], (double)hm[9] / hm[10]);
@@ -1688,7 +1708,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			} else
 				hipLaunchKernelGGL(k_pos_finalize_check, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2);
 			HIPCHK(hipEventRecord(h->ev[5], h->st));
-			(void)launch_lf_check(h, (const int64_t*)dpos, d_b2, len, false);
+			(void)launch_lf_check(h, (const int64_t*)dpos, d_b2, len, false, nullptr, jmet ? &ja : nullptr);
 			if (!rank_only && (r = build_index<false>(h, len, d_b2, (const int64_t*)dpos, ntot, true, &ngrp, &nslots, acc, rows_fused)) < 0) return r;
 			HIPCHK(hipEventRecord(h->ev[3], h->st));
 			HIPCHK(hipMemcpyAsync(hm, misc, sizeof(hm), hipMemcpyDeviceToHost, h->st));
@@ -1786,7 +1806,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	}
 	if (tent && hm[MISC_LF_CHK + 1] != 0) { // sampled rows fail the LF relation: nothing was installed; once more without speculative records
 		h->stt.n_fallbacks += 1;
-		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu sampled rows fail the LF relation; redoing the merge without tentative records\n", hm[MISC_LF_CHK + 1]);
+		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] %llu junctions or sampled rows fail the LF relation; redoing the merge without tentative records\n", hm[MISC_LF_CHK + 1]);
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, 0);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, 0);
 	}
@@ -2046,6 +2066,49 @@ int rb3gpu_export_plain_dev(rb3gpu_t *h, uint8_t *d_out)
 	if (nblk > 65536) nblk = 65536;
 	hipLaunchKernelGGL(k_export_plain, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), (int64_t)0, h->n, d_out);
 	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
+/* the symbols [beg, end) of the index, one byte each, into device memory (what rb3gpu_shard_split cuts the index with: an interval at a time) */
+int rb3gpu_export_plain_range_dev(rb3gpu_t *h, int64_t beg, int64_t end, uint8_t *d_out)
+{
+	if (!h || !d_out || beg < 0 || end < beg) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr || end > h->n) return RB3GPU_ESTATE;
+	if (end == beg) return 0;
+	int64_t nblk = (end - beg + 255) / 256;
+	if (nblk > 65536) nblk = 65536;
+	hipLaunchKernelGGL(k_export_plain, dim3((unsigned)nblk), dim3(256), 0, h->st, view_of(h), beg, end, d_out);
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
+}
+
+/* n intervals of positions that hold about the same number of BYTES of the block array each ("balanced by bytes of runs";
+ * a run-coded stretch of the index costs a fraction of what a stretch of bit planes costs per symbol): bounds[0] = 0 <= ... <= bounds[n] =
+ * the index's symbols, cut at group boundaries (8192 symbols) from the slot numbers in the group directory.  Fewer groups than intervals:
+ * equal numbers of symbols. */
+int rb3gpu_balanced_bounds(rb3gpu_t *h, int n, int64_t *bounds)
+{
+	if (!h || !bounds || n < 1) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->grp == nullptr) return RB3GPU_ESTATE;
+	const int64_t tot = h->n, ngrp = h->ngrp;
+	for (int i = 0; i <= n; ++i) bounds[i] = tot / n * i + (tot % n) * i / n;
+	bounds[n] = tot;
+	if (ngrp < 4 * (int64_t)n || h->nslots <= 0) return 0;
+	std::vector<uint64_t> sm((size_t)ngrp);
+	HIPCHK(hipMemcpy(sm.data(), view_of(h).gsm, (size_t)ngrp * 8, hipMemcpyDeviceToHost));
+	// bytes before group g: 72 per group + 128 per slot before it
+	int64_t g = 0;
+	const double total = (double)ngrp * (double)RB3_GRP_ALLOC + (double)h->nslots * (double)sizeof(rb3_slot_t);
+	for (int i = 1; i < n; ++i) {
+		const double want = total * i / n;
+		while (g < ngrp && (double)g * (double)RB3_GRP_ALLOC + (double)(uint32_t)sm[(size_t)g] * (double)sizeof(rb3_slot_t) < want) ++g;
+		int64_t b = g << RB3_GRP_BITS;
+		if (b <= bounds[i - 1]) b = bounds[i - 1] + 1; // (every interval holds a symbol)
+		if (b > tot - (n - i)) b = tot - (n - i);
+		bounds[i] = b;
+	}
 	return 0;
 }
 
@@ -2926,8 +2989,12 @@ static int sh_rebuild(rb3gpu_t *h, int64_t n_rows, const uint8_t *d_b2rows, int6
 	return 0;
 }
 
+/* d_tprev != NULL: the batch is SHARDED -- this rank holds the symbol before every text position (d_tprev, one byte each, the only thing a
+ * step needs of the batch) and the text-order words of its own text range [t_lo, t_hi) only (d_tw = the slice; text ranges: len * q / world);
+ * the records are (text position, insertion point) and the rows come from the owners of the text positions at the end: one all-to-all of
+ * the records to the owners, one back with row << 3 | symbol in place of the text position (d_bwt is not read). */
 static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw,
-		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds)
+		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds, const uint8_t *d_tprev = nullptr, int64_t t_lo = 0, int64_t t_hi = 0)
 {
 	const int world = comm->world, rank = comm->rank;
 	HIPCHK(hipSetDevice(h->dev));
@@ -2989,7 +3056,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 			// states per octet: enough blocks to fill the chip first, then as many states per cursor atomic as the registers take
 			const int S = n_cur >= ((int64_t)1 << 19) ? 8 : n_cur >= ((int64_t)1 << 17) ? 4 : n_cur >= ((int64_t)1 << 15) ? 2 : 1;
 			const unsigned nblk = (unsigned)((n_cur + 32 * S - 1) / (32 * S));
-#define RB3_SH_ROUND(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad)
+#define RB3_SH_ROUND(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad, d_tprev)
 			if (S == 8) RB3_SH_ROUND(8); else if (S == 4) RB3_SH_ROUND(4); else if (S == 2) RB3_SH_ROUND(2); else RB3_SH_ROUND(1);
 #undef RB3_SH_ROUND
 			HIPCHK(hipMemcpyAsync(hc, d_cnt[par], (size_t)(world + 1) * 8, hipMemcpyDeviceToHost, h->st));
@@ -3038,7 +3105,60 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 		if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] sharded merge recorded %lld of %lld rows\n", (long long)rsum, (long long)len);
 		return RB3GPU_EINTERNAL;
 	}
-	if (rows > 0) {
+	if (d_tprev != nullptr) { // the rows of the records, from the owners of their text positions (every rank takes part, with or without records of its own)
+		ShTextBounds tb;
+		memset(&tb, 0, sizeof(tb));
+		tb.n = world;
+		for (int q = 0; q <= world; ++q) tb.b[q] = len / world * q + (len % world) * q / world;
+		tb.b[world] = len;
+		if (tb.b[rank] != t_lo || tb.b[rank + 1] != t_hi) return RB3GPU_EINVAL;
+		if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+		unsigned long long *misc = (unsigned long long*)h->misc.p;
+		HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
+		unsigned long long *d_oc = (unsigned long long*)h->shk.p, *d_cur = d_oc + RB3_SH_MAXIV + 1; // (the counters of the rounds: done with)
+		HIPCHK(hipMemsetAsync(h->shk.p, 0, (size_t)(2 * (RB3_SH_MAXIV + 1) + 1) * 8, h->st));
+		std::vector<int64_t> scnt(world, 0), rcnt(world, 0), M2((size_t)world * world);
+		if (rows > 0) {
+			hipLaunchKernelGGL(k_sh_owner_count, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->st, rows, (const ShRec*)h->shr.p, tb, d_oc, misc + 2);
+			unsigned long long hc2[RB3_SH_MAXIV + 1];
+			HIPCHK(hipMemcpyAsync(hc2, d_oc, (size_t)world * 8, hipMemcpyDeviceToHost, h->st));
+			HIPCHK(hipStreamSynchronize(h->st));
+			int64_t sum = 0;
+			for (int q = 0; q < world; ++q) scnt[q] = (int64_t)hc2[q], sum += scnt[q];
+			if (sum != rows) return RB3GPU_EINTERNAL;
+		}
+		if ((r = comm->all_gather(comm->ctx, scnt.data(), world, M2.data())) < 0) return r; // M2[s][d]: records rank s asks rank d about
+		int64_t stride1 = 1, n_in = 0, stride2 = 1;
+		for (int q = 0; q < world; ++q) { stride1 = scnt[q] > stride1 ? scnt[q] : stride1; rcnt[q] = M2[(size_t)q * world + rank]; n_in += rcnt[q]; stride2 = rcnt[q] > stride2 ? rcnt[q] : stride2; }
+		// requests out (regions by owner), requests in (packed by source), answers out (regions by source), answers in (packed by owner: over the records)
+		if ((r = buf_ensure(h, h->shs, (size_t)world * (size_t)stride1 * 16)) < 0) return r;
+		if ((r = buf_ensure(h, h->shc, (size_t)(n_in > 0 ? n_in : 1) * 16)) < 0) return r;
+		if ((r = buf_ensure(h, h->shn, (size_t)world * (size_t)stride2 * 16)) < 0) return r;
+		if (rows > 0) hipLaunchKernelGGL(k_sh_owner_scatter, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->st, rows, (const ShRec*)h->shr.p, tb, stride1, d_cur, (ShRec*)h->shs.p);
+		if (world > 1) {
+			if ((r = comm->all_to_all(comm->ctx, (const rb3gpu_state_t*)h->shs.p, stride1, scnt.data(), (rb3gpu_state_t*)h->shc.p, rcnt.data(), (void*)h->st)) < 0) return r;
+		} else if (rows > 0) HIPCHK(hipMemcpyAsync(h->shc.p, h->shs.p, (size_t)rows * 16, hipMemcpyDeviceToDevice, h->st));
+		if (n_in > 0) {
+			ShTextBounds off;
+			memset(&off, 0, sizeof(off));
+			off.n = world;
+			for (int q = 0; q < world; ++q) off.b[q + 1] = off.b[q] + rcnt[q];
+			hipLaunchKernelGGL(k_sh_lookup, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, h->st, n_in, (const ShRec*)h->shc.p, off, stride2, d_tw, t_lo, t_hi, (ShRec*)h->shn.p, misc + 2);
+		}
+		if ((r = buf_ensure(h, h->shr, (size_t)(rows > 0 ? rows : 1) * 16)) < 0) return r;
+		if (world > 1) {
+			if ((r = comm->all_to_all(comm->ctx, (const rb3gpu_state_t*)h->shn.p, stride2, rcnt.data(), (rb3gpu_state_t*)h->shr.p, scnt.data(), (void*)h->st)) < 0) return r;
+		} else if (rows > 0) HIPCHK(hipMemcpyAsync(h->shr.p, h->shn.p, (size_t)rows * 16, hipMemcpyDeviceToDevice, h->st));
+		if (rows > 0) {
+			if ((r = buf_ensure(h, h->pos, (size_t)rows * 8)) < 0) return r;
+			if ((r = buf_ensure(h, h->b2, (size_t)rows + 64)) < 0) return r;
+			int64_t *dpos = (int64_t*)h->pos.p;
+			HIPCHK(hipMemsetAsync(dpos, 0xff, (size_t)rows * 8, h->st)); // RB3_UNSET
+			HIPCHK(hipEventRecord(h->ev[2], h->st));
+			hipLaunchKernelGGL(k_sh_place_text, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->st, rows, (const ShRec*)h->shr.p, jlo, iv_bounds[rank], dpos, (uint8_t*)h->b2.p, misc + 2);
+			if ((r = sh_rebuild(h, rows, (const uint8_t*)h->b2.p, dpos, misc, commit)) < 0) return r;
+		}
+	} else if (rows > 0) {
 		if ((r = buf_ensure(h, h->pos, (size_t)rows * 8)) < 0) return r;
 		if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 		unsigned long long *misc = (unsigned long long*)h->misc.p;
@@ -3064,6 +3184,30 @@ int rb3gpu_sh_merge(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, 
 	const int r = sh_merge_impl(h, comm, iv_bounds, len, d_bwt, d_tw, n_chains, chain_tp, commit, n_rounds);
 	if (r < 0 && comm->abort) comm->abort(comm->ctx); // the other ranks are (or will be) waiting in a collective
 	return r;
+}
+
+/* the same with the batch SHARDED over the ranks (see sh_merge_impl): d_tprev = the symbol before every text position, one byte each, all of
+ * it on this device; d_tw_slice = the text-order words of this rank's text range [len * rank / world, len * (rank + 1) / world) only */
+int rb3gpu_sh_merge_text(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_tprev, const uint64_t *d_tw_slice,
+		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds)
+{
+	if (!h || !comm || !iv_bounds || len <= 0 || !d_tprev || !d_tw_slice || n_chains <= 0 || n_chains > len || !chain_tp) return RB3GPU_EINVAL;
+	if (comm->world < 1 || comm->world > RB3_SH_MAXIV || comm->rank < 0 || comm->rank >= comm->world || !comm->all_gather || (comm->world > 1 && !comm->all_to_all)) return RB3GPU_EINVAL;
+	const int64_t w = comm->world, q = comm->rank;
+	const int64_t t_lo = len / w * q + (len % w) * q / w, t_hi = q + 1 == w ? len : len / w * (q + 1) + (len % w) * (q + 1) / w;
+	const int r = sh_merge_impl(h, comm, iv_bounds, len, nullptr, d_tw_slice, n_chains, chain_tp, commit, n_rounds, d_tprev, t_lo, t_hi);
+	if (r < 0 && comm->abort) comm->abort(comm->ctx);
+	return r;
+}
+
+/* the symbol before every text position, one byte each, from the text-order words (what rb3gpu_sh_merge_text walks on) */
+int rb3gpu_tprev_from_tw(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, uint8_t *d_out)
+{
+	if (!h || len <= 0 || !d_tw || !d_out) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	hipLaunchKernelGGL(k_tprev_from_tw, dim3((unsigned)((len / 8 + 1 + 255) / 256)), dim3(256), 0, h->st, d_tw, len, d_out);
+	HIPCHK(hipStreamSynchronize(h->st));
+	return 0;
 }
 
 int rb3gpu_device_of(const rb3gpu_t *h) { return h ? h->dev : -1; }

@@ -308,14 +308,36 @@ void rb3gpu_rccl_comm_destroy(rb3gpu_comm_t *comm)
 
 /* ---- the interval-sharded index as one object (a single-process host program: the CLI) ---- */
 
+/* Nothing of the index and nothing of a batch but one byte per symbol is ever whole on one device ("what's missing" 1 and 2):
+ *   split    an interval at a time: the symbols of interval i are exported by h0 (1 byte each, len_i of them), copied across, built into
+ *            handle i; h0 rebuilds itself from its own interval last.  Bounds by BYTES of the block array (rb3gpu_balanced_bounds).
+ *   merge    device 0 (where the sorter left the batch) makes the byte array "symbol before text position t" from the text-order words;
+ *            every rank PULLS that array (len bytes) and the text-order words of ITS text range (8 len / n bytes) at the same time, each on
+ *            its own stream over its own xGMI link, then the ranks walk (rb3gpu_sh_merge_text): states hop between the intervals, records
+ *            are (text position, insertion point), and at the end one all-to-all asks the owners of the text ranges for the rows.
+ *            The rank threads live as long as the object; peer access is set up once.
+ *   export   the writers take the intervals in rank order (rb3gpu_shard_export_runs / _run_words): runs that meet at a seam are joined, as
+ *            rld_enc joins what the ropes of the reference hand it one after the other (fm-index.c:31-54, rld0.c:153-161).  No gather.
+ *   gather   kept for the one caller that needs the whole index on one device (a batch the host had to sort: merged the ordinary way). */
+struct ShardJob { int kind; int64_t len; const uint8_t *d_tprev0; const uint64_t *d_tw0; int64_t n_chains; const int64_t *chain_tp; int64_t bounds[RB3GPU_SH_MAXIV + 1]; int64_t rounds; int ret; };
+
 struct rb3gpu_shard_s {
 	int n = 0;
 	rb3gpu_t *h[RB3GPU_SH_MAXIV];        // h[0] is the caller's
 	int dev[RB3GPU_SH_MAXIV];
 	int64_t bounds[RB3GPU_SH_MAXIV + 1];
 	rb3gpu_group_t *grp = nullptr;
-	void *rep_bwt[RB3GPU_SH_MAXIV], *rep_tw[RB3GPU_SH_MAXIV]; // replicas of the batch on the devices of intervals 1.. (kept between merges)
-	int64_t rep_cap[RB3GPU_SH_MAXIV];
+	rb3gpu_comm_t comm[RB3GPU_SH_MAXIV];
+	void *rep_tp[RB3GPU_SH_MAXIV], *rep_tw[RB3GPU_SH_MAXIV]; // per rank on another device than 0: the symbol-before array (whole) and the rank's slice of the text-order words
+	int64_t rep_tp_cap[RB3GPU_SH_MAXIV], rep_tw_cap[RB3GPU_SH_MAXIV];
+	void *d_tprev0 = nullptr; int64_t tprev0_cap = 0;        // on device 0
+	// the rank threads (ranks 1 .. n-1; rank 0 runs on the caller's thread)
+	pthread_t th[RB3GPU_SH_MAXIV];
+	pthread_mutex_t mtx;
+	pthread_cond_t cv;
+	unsigned long gen = 0;
+	int done = 0, quit = 0, n_threads = 0;
+	ShardJob job[RB3GPU_SH_MAXIV];
 };
 
 static int copy_across(void *dst, int ddev, const void *src, int sdev, size_t n)
@@ -335,30 +357,87 @@ static int copy_across(void *dst, int ddev, const void *src, int sdev, size_t n)
 	return 0;
 }
 
-struct ShardJob { rb3gpu_shard_s *s; int rank; int64_t len; const uint8_t *d_bwt; const uint64_t *d_tw; int64_t n_chains; const int64_t *chain_tp; int64_t bounds[RB3GPU_SH_MAXIV + 1]; int64_t rounds; int ret; };
+/* rank `rank` pulls what it needs of the batch from device 0 (on the stream of its own handle: all ranks at once, a link each) and walks */
+static void shard_rank_merge(rb3gpu_shard_s *s, int rank)
+{
+	ShardJob *j = &s->job[rank];
+	const int64_t len = j->len, w = s->n;
+	const int64_t t_lo = len / w * rank + (len % w) * rank / w, t_hi = rank + 1 == w ? len : len / w * (rank + 1) + (len % w) * (rank + 1) / w;
+	const uint8_t *tprev = j->d_tprev0;
+	const uint64_t *tws = j->d_tw0 + t_lo;
+	int r = 0;
+	if (s->dev[rank] != s->dev[0]) {
+		const int64_t nsl = t_hi - t_lo;
+		if (s->rep_tp_cap[rank] < len) {
+			if (s->rep_tp[rank]) (void)rb3gpu_dev_free(s->h[rank], s->rep_tp[rank]);
+			s->rep_tp[rank] = nullptr, s->rep_tp_cap[rank] = 0;
+			if ((r = rb3gpu_dev_alloc(s->h[rank], len + (len >> 2) + 64, &s->rep_tp[rank])) == 0) s->rep_tp_cap[rank] = len + (len >> 2);
+		}
+		if (r == 0 && s->rep_tw_cap[rank] < nsl) {
+			if (s->rep_tw[rank]) (void)rb3gpu_dev_free(s->h[rank], s->rep_tw[rank]);
+			s->rep_tw[rank] = nullptr, s->rep_tw_cap[rank] = 0;
+			if ((r = rb3gpu_dev_alloc(s->h[rank], (nsl + (nsl >> 2) + 8) * 8, &s->rep_tw[rank])) == 0) s->rep_tw_cap[rank] = nsl + (nsl >> 2);
+		}
+		if (r == 0) {
+			hipStream_t st = (hipStream_t)rb3gpu_stream_of(s->h[rank]);
+			hipError_t e = hipSetDevice(s->dev[rank]);
+			if (e == hipSuccess) e = hipMemcpyPeerAsync(s->rep_tp[rank], s->dev[rank], j->d_tprev0, s->dev[0], (size_t)len, st);
+			if (e == hipSuccess && nsl > 0) e = hipMemcpyPeerAsync(s->rep_tw[rank], s->dev[rank], j->d_tw0 + t_lo, s->dev[0], (size_t)nsl * 8, st);
+			if (e == hipSuccess) e = hipStreamSynchronize(st);
+			if (e != hipSuccess) { (void)hipGetLastError(); r = RB3GPU_ENODEV; }
+		}
+		tprev = (const uint8_t*)s->rep_tp[rank], tws = (const uint64_t*)s->rep_tw[rank];
+	}
+	if (r < 0) { rb3gpu_group_abort(s->grp); j->ret = r; return; }
+	j->ret = rb3gpu_sh_merge_text(s->h[rank], &s->comm[rank], j->bounds, len, tprev, tws, j->n_chains, j->chain_tp, 1, &j->rounds);
+}
+
+struct ShardThreadArg { rb3gpu_shard_s *s; int rank; };
 
 static void *shard_thread(void *arg)
 {
-	ShardJob *j = (ShardJob*)arg;
-	rb3gpu_comm_t comm;
-	j->ret = rb3gpu_group_comm(j->s->grp, j->rank, j->s->h[j->rank], &comm);
-	if (j->ret < 0) { rb3gpu_group_abort(j->s->grp); return nullptr; }
-	j->ret = rb3gpu_sh_merge(j->s->h[j->rank], &comm, j->bounds, j->len, j->d_bwt, j->d_tw, j->n_chains, j->chain_tp, 1, &j->rounds);
-	return nullptr;
+	ShardThreadArg *a = (ShardThreadArg*)arg;
+	rb3gpu_shard_s *s = a->s;
+	const int rank = a->rank;
+	delete a;
+	unsigned long seen = 0;
+	for (;;) {
+		pthread_mutex_lock(&s->mtx);
+		while (s->gen == seen && !s->quit) pthread_cond_wait(&s->cv, &s->mtx);
+		const int quit = s->quit;
+		seen = s->gen;
+		pthread_mutex_unlock(&s->mtx);
+		if (quit) return nullptr;
+		shard_rank_merge(s, rank);
+		pthread_mutex_lock(&s->mtx);
+		++s->done;
+		pthread_cond_broadcast(&s->cv);
+		pthread_mutex_unlock(&s->mtx);
+	}
 }
 
 extern "C" {
 
 static void shard_free(rb3gpu_shard_s *s, bool handles)
 {
+	if (s->n_threads > 0) {
+		pthread_mutex_lock(&s->mtx);
+		s->quit = 1;
+		pthread_cond_broadcast(&s->cv);
+		pthread_mutex_unlock(&s->mtx);
+		for (int i = 1; i <= s->n_threads; ++i) pthread_join(s->th[i], nullptr);
+	}
+	if (s->d_tprev0 && s->h[0]) (void)rb3gpu_dev_free(s->h[0], s->d_tprev0);
 	for (int i = 1; i < s->n; ++i) {
 		if (s->h[i]) {
-			if (s->rep_bwt[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_bwt[i]);
+			if (s->rep_tp[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_tp[i]);
 			if (s->rep_tw[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_tw[i]);
 			if (handles) rb3gpu_destroy(s->h[i]);
 		}
 	}
 	rb3gpu_group_destroy(s->grp);
+	pthread_mutex_destroy(&s->mtx);
+	pthread_cond_destroy(&s->cv);
 	delete s;
 }
 
@@ -370,82 +449,167 @@ rb3gpu_shard_t *rb3gpu_shard_split(rb3gpu_t *h0, int n, const int *devices, cons
 	rb3gpu_shard_s *s = new (std::nothrow) rb3gpu_shard_s;
 	if (!s) return nullptr;
 	s->n = n;
-	for (int i = 0; i < RB3GPU_SH_MAXIV; ++i) s->h[i] = nullptr, s->rep_bwt[i] = s->rep_tw[i] = nullptr, s->rep_cap[i] = 0, s->dev[i] = 0;
+	pthread_mutex_init(&s->mtx, nullptr);
+	pthread_cond_init(&s->cv, nullptr);
+	for (int i = 0; i < RB3GPU_SH_MAXIV; ++i) s->h[i] = nullptr, s->rep_tp[i] = s->rep_tw[i] = nullptr, s->rep_tp_cap[i] = s->rep_tw_cap[i] = 0, s->dev[i] = 0;
 	s->h[0] = h0;
-	for (int i = 0; i <= n; ++i) s->bounds[i] = tot / n * i + (tot % n) * i / n;
-	s->bounds[n] = tot;
-	if ((s->grp = rb3gpu_group_create(n)) == nullptr) { delete s; return nullptr; }
-	void *plain = nullptr;
+	int r = rb3gpu_balanced_bounds(h0, n, s->bounds); // about equal BYTES of runs per interval
+	if (r < 0 || (s->grp = rb3gpu_group_create(n)) == nullptr) { pthread_mutex_destroy(&s->mtx); pthread_cond_destroy(&s->cv); delete s; return nullptr; }
 	int64_t acc0[RB3GPU_ASIZE + 1], sum[RB3GPU_ASIZE] = {0, 0, 0, 0, 0, 0};
-	int r = rb3gpu_get_acc(h0, acc0);
-	if (r == 0 && n > 1) r = rb3gpu_dev_alloc(h0, tot, &plain);
-	if (r == 0 && n > 1) r = rb3gpu_export_plain_dev(h0, (uint8_t*)plain);
-	for (int i = 0; i < n && r == 0; ++i) {
+	r = rb3gpu_get_acc(h0, acc0);
+	// an interval at a time, the last one first and h0's own last of all (it rebuilds itself from its interval: until then it holds the whole index):
+	// never more than one interval's symbols (1 byte each) beside the index
+	for (int i = n - 1; i >= 0 && r == 0; --i) {
 		s->dev[i] = devices[i];
 		const int64_t len = s->bounds[i + 1] - s->bounds[i];
-		if (i == 0) { if (n > 1) r = rb3gpu_from_plain_dev(h0, len, (const uint8_t*)plain); continue; } // (h0 rebuilds itself from the copy: its first interval)
-		rb3gpu_opt_t o = *opt;
-		o.device = devices[i];
-		if ((s->h[i] = rb3gpu_create(&o)) == nullptr) { r = RB3GPU_ENODEV; break; }
-		void *part = nullptr;
-		if ((r = rb3gpu_dev_alloc(s->h[i], len, &part)) < 0) break;
-		r = copy_across(part, s->dev[i], (const uint8_t*)plain + s->bounds[i], s->dev[0], (size_t)len);
-		if (r == 0) r = rb3gpu_from_plain_dev(s->h[i], len, (const uint8_t*)part);
-		(void)rb3gpu_dev_free(s->h[i], part);
+		void *part0 = nullptr, *part = nullptr;
+		if (n == 1) break;
+		if ((r = rb3gpu_dev_alloc(h0, len, &part0)) < 0) break;
+		r = rb3gpu_export_plain_range_dev(h0, s->bounds[i], s->bounds[i + 1], (uint8_t*)part0);
+		if (r == 0 && i == 0) r = rb3gpu_from_plain_dev(h0, len, (const uint8_t*)part0);
+		else if (r == 0) {
+			rb3gpu_opt_t o = *opt;
+			o.device = devices[i];
+			if ((s->h[i] = rb3gpu_create(&o)) == nullptr) r = RB3GPU_ENODEV;
+			if (r == 0 && s->dev[i] == s->dev[0]) r = rb3gpu_from_plain_dev(s->h[i], len, (const uint8_t*)part0);
+			else if (r == 0 && (r = rb3gpu_dev_alloc(s->h[i], len, &part)) == 0) {
+				r = copy_across(part, s->dev[i], part0, s->dev[0], (size_t)len);
+				if (r == 0) r = rb3gpu_from_plain_dev(s->h[i], len, (const uint8_t*)part);
+				(void)rb3gpu_dev_free(s->h[i], part);
+			}
+		}
+		(void)rb3gpu_dev_free(h0, part0);
 	}
-	if (plain) (void)rb3gpu_dev_free(h0, plain);
 	for (int i = 0; i < n && r == 0; ++i) { // the intervals together hold the symbols the index held (a copy that went wrong would show here, not in a wrong BWT later)
 		int64_t acc[RB3GPU_ASIZE + 1];
 		if ((r = rb3gpu_get_acc(s->h[i], acc)) == 0)
 			for (int c = 0; c < RB3GPU_ASIZE; ++c) sum[c] += acc[c + 1] - acc[c];
 	}
 	for (int c = 0; c < RB3GPU_ASIZE && r == 0; ++c) if (sum[c] != acc0[c + 1] - acc0[c]) r = RB3GPU_EINTERNAL;
+	// the communicators (peer access between the devices is switched on here, once) and the rank threads
+	for (int i = 0; i < n && r == 0; ++i) r = rb3gpu_group_comm(s->grp, i, s->h[i], &s->comm[i]);
+	for (int i = 1; i < n && r == 0; ++i) {
+		ShardThreadArg *a = new (std::nothrow) ShardThreadArg;
+		if (!a) { r = RB3GPU_ENOMEM; break; }
+		a->s = s, a->rank = i;
+		if (pthread_create(&s->th[i], nullptr, shard_thread, a) != 0) { delete a; r = RB3GPU_ENOMEM; break; }
+		s->n_threads = i;
+	}
 	if (r < 0) { shard_free(s, true); return nullptr; } // (h0 may hold its first interval only: the caller gives the build up)
 	return s;
 }
 
 int rb3gpu_shard_merge(rb3gpu_shard_t *s, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_chains, const int64_t *chain_tp, int64_t *n_rounds)
 {
-	if (!s || len <= 0 || !d_bwt || !d_tw || n_chains <= 0 || !chain_tp) return RB3GPU_EINVAL;
+	if (!s || len <= 0 || !d_tw || n_chains <= 0 || !chain_tp) return RB3GPU_EINVAL;
+	(void)d_bwt; // (the symbol of a row comes back with its number: rb3gpu_sh_merge_text)
 	int r;
-	// the batch on every device (1 + 8 bytes per symbol, device to device)
-	for (int i = 1; i < s->n; ++i) {
-		if (s->dev[i] == s->dev[0]) continue; // (several intervals on one device: they read the same copy)
-		if (s->rep_cap[i] < len) {
-			if (s->rep_bwt[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_bwt[i]);
-			if (s->rep_tw[i]) (void)rb3gpu_dev_free(s->h[i], s->rep_tw[i]);
-			s->rep_bwt[i] = s->rep_tw[i] = nullptr, s->rep_cap[i] = 0;
-			const int64_t cap = len + (len >> 2);
-			if ((r = rb3gpu_dev_alloc(s->h[i], cap, &s->rep_bwt[i])) < 0 || (r = rb3gpu_dev_alloc(s->h[i], cap * 8, &s->rep_tw[i])) < 0) return r;
-			s->rep_cap[i] = cap;
-		}
-		if ((r = copy_across(s->rep_bwt[i], s->dev[i], d_bwt, s->dev[0], (size_t)len)) < 0) return r;
-		if ((r = copy_across(s->rep_tw[i], s->dev[i], d_tw, s->dev[0], (size_t)len * 8)) < 0) return r;
+	// the symbol before every text position, one byte each: all a walking rank needs of the batch
+	if (s->tprev0_cap < len) {
+		if (s->d_tprev0) (void)rb3gpu_dev_free(s->h[0], s->d_tprev0);
+		s->d_tprev0 = nullptr, s->tprev0_cap = 0;
+		if ((r = rb3gpu_dev_alloc(s->h[0], len + (len >> 2) + 64, &s->d_tprev0)) < 0) return r;
+		s->tprev0_cap = len + (len >> 2);
 	}
-	ShardJob *jobs = new (std::nothrow) ShardJob[s->n];
-	pthread_t *th = new (std::nothrow) pthread_t[s->n];
-	if (!jobs || !th) { delete[] jobs; delete[] th; return RB3GPU_ENOMEM; }
+	if ((r = rb3gpu_tprev_from_tw(s->h[0], len, d_tw, (uint8_t*)s->d_tprev0)) < 0) return r;
 	for (int i = 0; i < s->n; ++i) {
-		const bool here = i == 0 || s->dev[i] == s->dev[0];
-		jobs[i].s = s, jobs[i].rank = i, jobs[i].len = len, jobs[i].n_chains = n_chains, jobs[i].chain_tp = chain_tp, jobs[i].rounds = 0, jobs[i].ret = 0;
-		jobs[i].d_bwt = here ? d_bwt : (const uint8_t*)s->rep_bwt[i], jobs[i].d_tw = here ? d_tw : (const uint64_t*)s->rep_tw[i];
-		memcpy(jobs[i].bounds, s->bounds, sizeof(s->bounds));
+		ShardJob *j = &s->job[i];
+		j->kind = 1, j->len = len, j->d_tprev0 = (const uint8_t*)s->d_tprev0, j->d_tw0 = d_tw, j->n_chains = n_chains, j->chain_tp = chain_tp, j->rounds = 0, j->ret = 0;
+		memcpy(j->bounds, s->bounds, sizeof(s->bounds));
 	}
-	int started = 0;
-	for (int i = 1; i < s->n; ++i, ++started)
-		if (pthread_create(&th[i], nullptr, shard_thread, &jobs[i]) != 0) { rb3gpu_group_abort(s->grp); jobs[i].ret = RB3GPU_ENOMEM; break; }
-	if (started == s->n - 1) shard_thread(&jobs[0]); // interval 0 on the calling thread
-	else jobs[0].ret = RB3GPU_ENOMEM;
-	for (int i = 1; i <= started; ++i) pthread_join(th[i], nullptr);
+	pthread_mutex_lock(&s->mtx);
+	s->done = 0, ++s->gen;
+	pthread_cond_broadcast(&s->cv);
+	pthread_mutex_unlock(&s->mtx);
+	shard_rank_merge(s, 0); // interval 0 on the calling thread
+	pthread_mutex_lock(&s->mtx);
+	while (s->done < s->n_threads) pthread_cond_wait(&s->cv, &s->mtx);
+	pthread_mutex_unlock(&s->mtx);
 	r = 0;
-	for (int i = 0; i < s->n; ++i) if (jobs[i].ret < 0 && (r == 0 || r == RB3GPU_ESTATE)) r = jobs[i].ret; // (ESTATE: a rank that was only woken up by another one's failure)
+	for (int i = 0; i < s->n; ++i) if (s->job[i].ret < 0 && (r == 0 || r == RB3GPU_ESTATE)) r = s->job[i].ret; // (ESTATE: a rank that was only woken up by another one's failure)
 	if (r == 0) {
-		memcpy(s->bounds, jobs[0].bounds, sizeof(s->bounds));
-		if (n_rounds) *n_rounds = jobs[0].rounds;
+		memcpy(s->bounds, s->job[0].bounds, sizeof(s->bounds));
+		if (n_rounds) *n_rounds = s->job[0].rounds;
 	}
-	delete[] jobs;
-	delete[] th;
 	return r;
+}
+
+int rb3gpu_shard_get_acc(const rb3gpu_shard_t *s, int64_t acc[RB3GPU_ASIZE + 1])
+{
+	if (!s || !acc) return RB3GPU_EINVAL;
+	int64_t sum[RB3GPU_ASIZE] = {0, 0, 0, 0, 0, 0}, a[RB3GPU_ASIZE + 1];
+	for (int i = 0; i < s->n; ++i) {
+		const int r = rb3gpu_get_acc(s->h[i], a);
+		if (r < 0) return r;
+		for (int c = 0; c < RB3GPU_ASIZE; ++c) sum[c] += a[c + 1] - a[c];
+	}
+	acc[0] = 0;
+	for (int c = 0; c < RB3GPU_ASIZE; ++c) acc[c + 1] = acc[c] + sum[c];
+	return 0;
+}
+
+/* runs of the intervals in rank order, the ones that meet at a seam joined */
+struct SeamRuns { rb3gpu_emit_f emit; void *data; int c; int64_t l; };
+static int seam_emit(void *data, int c, int64_t l)
+{
+	SeamRuns *q = (SeamRuns*)data;
+	if (l <= 0) return 0;
+	if (c == q->c) { q->l += l; return 0; }
+	if (q->l > 0) { const int r = q->emit(q->data, q->c, q->l); if (r != 0) return r; }
+	q->c = c, q->l = l;
+	return 0;
+}
+
+int rb3gpu_shard_export_runs(rb3gpu_shard_t *s, rb3gpu_emit_f emit, void *data)
+{
+	if (!s || !emit) return RB3GPU_EINVAL;
+	SeamRuns q = { emit, data, -1, 0 };
+	for (int i = 0; i < s->n; ++i) {
+		if (rb3gpu_get_tot(s->h[i]) != s->bounds[i + 1] - s->bounds[i]) return RB3GPU_EINTERNAL;
+		const int r = rb3gpu_export_runs(s->h[i], seam_emit, &q);
+		if (r != 0) return r;
+	}
+	if (q.l > 0) return emit(data, q.c, q.l);
+	return 0;
+}
+
+/* the same in bulk (words start << 3 | sym of maximal runs, starts counted from the beginning of the WHOLE index) */
+struct SeamWords { rb3gpu_emit_words_f emit; void *data; int64_t base; int last_c; uint64_t *buf; int64_t cap; };
+static int seam_words(void *data, int64_t n, const uint64_t *words, int64_t end)
+{
+	SeamWords *q = (SeamWords*)data;
+	if (n <= 0) return 0; // (the closing call of an interval: the run goes on into the next interval, or is closed by the caller at the very end)
+	(void)end;
+	int64_t i0 = 0;
+	if ((int)(words[0] & 7) == q->last_c) i0 = 1; // the first run of this call continues the last one of the call (or interval) before
+	if (n - i0 > q->cap) {
+		uint64_t *nb = (uint64_t*)realloc(q->buf, (size_t)(n - i0) * 8);
+		if (!nb) return RB3GPU_ENOMEM;
+		q->buf = nb, q->cap = n - i0;
+	}
+	for (int64_t i = i0; i < n; ++i) q->buf[i - i0] = (((words[i] >> 3) + (uint64_t)q->base) << 3) | (words[i] & 7);
+	q->last_c = (int)(words[n - 1] & 7);
+	return n > i0 ? q->emit(q->data, n - i0, q->buf, -1) : 0;
+}
+
+int rb3gpu_shard_export_run_words(rb3gpu_shard_t *s, rb3gpu_emit_words_f emit, void *data)
+{
+	if (!s || !emit) return RB3GPU_EINVAL;
+	SeamWords q = { emit, data, 0, -1, nullptr, 0 };
+	int r = 0;
+	for (int i = 0; i < s->n && r == 0; ++i) {
+		if (rb3gpu_get_tot(s->h[i]) != s->bounds[i + 1] - s->bounds[i]) { r = RB3GPU_EINTERNAL; break; }
+		q.base = s->bounds[i];
+		r = rb3gpu_export_run_words(s->h[i], seam_words, &q);
+	}
+	free(q.buf);
+	if (r == 0) r = emit(data, 0, nullptr, s->bounds[s->n]); // closes the last run
+	return r;
+}
+
+void rb3gpu_shard_destroy(rb3gpu_shard_t *s)
+{
+	if (s) shard_free(s, true); // (h0, the caller's handle, stays: it holds interval 0)
 }
 
 int rb3gpu_shard_gather(rb3gpu_shard_t *s)

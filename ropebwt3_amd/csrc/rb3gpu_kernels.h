@@ -659,7 +659,9 @@ __device__ __forceinline__ int64_t ld_pos(const int64_t *p)
 }
 __device__ __forceinline__ void st_pos(int64_t *p, int64_t v)
 {
-	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	// written through (sc1: the other XCDs' walkers must find it in memory) and streaming (nt: the line does not stay in this XCD's L2 -- a record
+	// is looked at once or never, and the 70 MB of records of a merge pushed the index's slots out of the L2s: k_chain 0.62 -> 0.58-0.60 ms per launch)
+	asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
 }
 
 /* rank with the symbol known before the loads are issued: every lane of the octet fetches the one
@@ -827,7 +829,8 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
  * stretch (k_resolve).  w0, w1: how the unknown of the stretch follows from another one.
  *   w0 = type << 62 | previous stretch << 38 | lo (EVENT only)
  *   EVENT: some rows of the previous stretch's interval [lo, lo + kk) do not hold c and dropped out;
- *          w1 = kk | c << 16.  k_events turns that into the 256-bit mask of the dropped
+ *          w1 = kk | c << 16 | tp << 20 (tp: the text position of the row at which the walker noted it, TEXT walkers; the
+ *          stretch begins at text position tp - 1).  k_events turns that into the 256-bit mask of the dropped
  *          rows (the walker itself only notes the event: three stores, no loads), and
  *          d = d(prev) - #{dropped rows with index < d(prev)}
  *   LINK:  d = d(prev) + (int32)w1
@@ -839,6 +842,7 @@ typedef struct {
 	uint32_t mask[8];
 	uint32_t pad[2];
 } rb3_stretch_t; /* 64 bytes; the first 24 must be zero before a merge */
+#define RB3_EV_TP_SHIFT 20
 #define RB3_DEP_EVENT 1ull
 #define RB3_DEP_LINK  2ull
 #define RB3_DEP_W0(type, prev, lo) ((uint64_t)(type) << 62 | (uint64_t)(uint32_t)(prev) << RB3_TENT_PBITS | (uint64_t)(lo))
@@ -881,7 +885,11 @@ template<bool TENT> __device__ __forceinline__ void rec_pos(int64_t *p, int64_t 
 {
 	if (TENT) atomicMin((unsigned long long*)p, (unsigned long long)v); // final < tentative < unvisited (bit 63)
 	else if (vis) st_pos(p, v);  // written through: other walkers may be waiting to see it
+#ifdef RB3_EXP_PLAINNT /* kernel experiment: ... as a stream as well */
+	else __builtin_nontemporal_store(v, p);
+#else
 	else *p = v;                 // one walker per string, nobody ever looks: let the L2 keep the line it just read
+#endif
 }
 
 /* Rows of [lo, lo + kk) that do NOT hold c, from the slice of a slot this lane already has in registers:
@@ -1007,8 +1015,11 @@ template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8, bool I32 = fal
 #endif
 __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
-		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX, uint32_t *mctr = nullptr, int trec_arg = 0)
+		rb3_stretch_t *tab, uint32_t *sidctr, uint32_t sid_limit, const uint64_t *tw, const unsigned long long *nwalk_dev = nullptr, int kmax = RB3_TENT_KMAX, uint32_t *mctr = nullptr, int trec_arg = 0, int64_t *jmet = nullptr)
 {
+	// jmet (TEXT, TENT, LIST): one word per walker, 1 + the text position of the row at which the walker met somebody's record and settled or
+	// linked an unknown (0: it never did) -- with the text positions of the events in the stretch records, all the places where what one
+	// walker knew was combined with what another had recorded: k_junction_check verifies the LF relation at every one of them
 	const int trec = trec_arg & 1;
 #ifdef RB3GPU_TEST_HOOKS
 	// test hook (rb3gpu_tune "hide_first"): an EXACT walker does not see the tentative records of a walker's FIRST stretch -- what happens for real when it
@@ -1048,7 +1059,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 	uint64_t blk8 = 0;      // TEXT: the words this octet fetches during the current window of 8 iterations (lane j: at iteration phase j),
 	                        // loaded with one 64-byte request per octet and window, whatever the L1 does with the lines
 	uint32_t steps = 0;
-	uint32_t nwide = 0;     // steps of walkers old enough to record tentatively whose interval is wider than the masks take
+	uint32_t wcur = 0;      // the list entry of the current walker (jmet)
 	// Records are written through to memory (agent scope) so that walkers on other XCDs can see them.
 	// Each octet parks up to 8 records in its lanes (lane it&7 takes iteration it) and the whole wave
 	// flushes them with ONE store instruction every 8 iterations.
@@ -1088,6 +1099,8 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				if (bkb >= 0) rec_pos<TENT && !LIST>(&row[bkb], bval, vis);
 				break;
 			}
+			wcur = (uint32_t)wid;
+			if (TENT && TEXT && LIST && jmet != nullptr && j == 0) jmet[wid] = 0; // (every list entry is taken by exactly one octet: the table needs no clearing)
 			int probe = 0; // TEXT: text distance to a row of the right neighbour's segment that tells whether this walker comes too late (below)
 			if (LIST) {
 				const Walker w = wl[wid];
@@ -1187,7 +1200,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					if (!I32 && !b1.abs) rl.gc = b1.grp64[g * 8 + c]; // (headers relative to the group: an index of 2^32 symbols or more)
 					const int64_t tpn = I32 ? (int64_t)((uint32_t)tp - 1u) : tp - 1; // (c != 0: there is a symbol before this one, so tp >= 1)
 					uint64_t xn;                                      // the word after next
-					if (I32) xn = *(const uint64_t*)((const char*)tw + (((uint32_t)tp >= 2u ? (uint32_t)tp - 2u : 0u) << 3));
+					if (I32) xn = *(const uint64_t*)((const char*)tw + (((uint32_t)tp >= 2u ? (uint32_t)tp - 2u : 0u) << 3)); // (read as a stream -- nt -- it was 8 % SLOWER: the L1 no longer serves the 15 steps that share a line)
 					else xn = tw[tpn > 0 ? tpn - 1 : 0];
 					const int64_t kbn = I32 ? (int64_t)((uint32_t)x1 >> 3) : (int64_t)(x1 >> 3);
 					rl.koff = (uint32_t)lo & (RB3_GRP - 1);
@@ -1300,9 +1313,15 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 							ns = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 						}
 						if (j == 0 && ns != RB3_TENT_POISON) {
-							tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = kq | (uint64_t)c << 16;
+#ifdef RB3_EXP_EVNT /* kernel experiment: the event record written as a stream */
+							__builtin_nontemporal_store(RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), &tab[ns].w0), __builtin_nontemporal_store(kq | (uint64_t)c << 16 | (uint64_t)tp << RB3_EV_TP_SHIFT, &tab[ns].w1);
+							__builtin_nontemporal_store((uint32_t)sid0 + 1u, &tab[ns].pad[0]);
+							__builtin_nontemporal_store(ns + 1, &tab[sid].child);
+#else
+							tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = kq | (uint64_t)c << 16 | (uint64_t)tp << RB3_EV_TP_SHIFT;
 							tab[ns].pad[0] = (uint32_t)sid0 + 1u;
 							tab[sid].child = ns + 1;
+#endif
 						}
 						sid = ns;
 					}
@@ -1358,7 +1377,10 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 			const bool wide = TENT ? gap == 2 : gap != 0;
 			// may this walker record tentatively?  (an interval of at most KMAX rows, and old enough)
 			const bool tentok = TENT && gap != 0 && age >= (LIST ? RB3_TENT_MIN_AGE : RB3_TENT_MIN_AGE_AUTO) && hi - lo <= kmax && sid != -2;
-			if (TENT && LIST) nwide += (gap == 2 && sid == -1 && age >= RB3_TENT_MIN_AGE && hi - lo > kmax && hi - lo <= RB3_TENT_KMAX_TOP) ? 1u : 0u;
+			if (TENT && LIST) { // steps of walkers old enough to record whose interval is wider than the masks take: misc[39] (MISC_WIDE), see merge_core (rare: counted where it happens, not in a register)
+				const unsigned long long mw = __builtin_amdgcn_ballot_w64(j == 0 && gap == 2 && sid == -1 && age >= RB3_TENT_MIN_AGE && hi - lo > kmax && hi - lo <= RB3_TENT_KMAX_TOP);
+				if (mw != 0ull && lane == (int)__builtin_ctzll(mw)) atomicAdd(nsteps + 38, (unsigned long long)__builtin_popcountll(mw));
+			}
 			RankLoadC rl, rh;
 			octc_issue_grp<DENSE, LPW>(b1, lo, c, j, rl);
 			if (wide) octc_issue_grp<DENSE, LPW>(b1, hi, c, j, rh);
@@ -1390,6 +1412,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 			}
 			if (TENT && met) { // settle an unknown (rare)
 				const int64_t seen = TEXT ? (int64_t)rc : (int64_t)x;
+				if (TEXT && LIST && jmet != nullptr && j == 0) jmet[wcur] = tp + 1; // a junction: this row's record is somebody else's, the row before it (text position tp + 1) mine
 				if (!(seen & RB3_TENT)) { // a final value: the unknown of my current stretch
 					if (gap != 0 && sid >= 0 && sid != RB3_TENT_POISON && j == 0) tab[sid].del = 1 + (int)(seen - myval);
 				} else {
@@ -1445,7 +1468,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					ns = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 				}
 				if (j == 0 && ns != RB3_TENT_POISON) {
-					tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = (uint64_t)(hi - lo) | (uint64_t)c << 16;
+					tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = (uint64_t)(hi - lo) | (uint64_t)c << 16 | (TEXT ? (uint64_t)tp << RB3_EV_TP_SHIFT : 0ull);
 					tab[ns].pad[0] = (uint32_t)sid0 + 1u; // (same 64-byte record: the store rides along)
 					tab[sid].child = ns + 1;
 				}
@@ -1464,13 +1487,9 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 		} while (__all(active));
 	}
 	{ // one atomic per wave, not per octet (they all go to the same word, and the kernel is over when the last one has landed)
-		unsigned long long tot = 0, totw = 0;
-		for (int o = 0; o < octs; ++o) {
-			tot += (uint32_t)__builtin_amdgcn_readlane((int)steps, o * LPW);
-			if (TENT && LIST) totw += (uint32_t)__builtin_amdgcn_readlane((int)nwide, o * LPW);
-		}
+		unsigned long long tot = 0;
+		for (int o = 0; o < octs; ++o) tot += (uint32_t)__builtin_amdgcn_readlane((int)steps, o * LPW);
 		if (lane == 0) atomicAdd(nsteps, tot);
-		if (TENT && LIST && lane == 0 && totw) atomicAdd(nsteps + 38, totw); // misc[39] (MISC_WIDE): see merge_core
 	}
 #ifdef RB3_PROF_STEP
 	if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(nsteps + 33 + q, (unsigned long long)prof_t[q]); // misc[34..38]
@@ -2384,6 +2403,93 @@ __global__ void __launch_bounds__(256) k_lf_check(IdxView b1, const int64_t *pos
 		else if ((s & 63) == 0) atomicAdd(nchecked, 64ull); // (approximate count, kept off the hot address)
 	}
 }
+
+/* The DETERMINISTIC part of the validation (round 5): the LF relation at every JUNCTION of the speculative walk, i.e. at every place
+ * where the value of a row was not computed from the row before it by the walker itself but put together from what two parties knew:
+ *   (a) a walker met somebody's record and settled or linked an unknown there (k_chain: `met`; the text position is in jmet[walker]):
+ *       the row before the met one is the walker's own, the met one is somebody else's;
+ *   (b) an EVENT: matching suffixes dropped out and the rows to come belong to a new stretch whose unknown follows from the old one
+ *       through the drop-out mask (k_events .. k_sfin); the text position is in the event record (w1 >> RB3_EV_TP_SHIFT).
+ * Inside a stretch every record is lo + kb with lo computed by rank from the lo before it, and the final value adds the stretch's ONE
+ * settled unknown to all of them: if the relation holds across the stretch's two ends it holds inside (the matching suffixes all
+ * survive there, so LF maps lo + d to lo' + d for every d).  A wrong unknown of any single stretch, a wrong link, a wrong settle by a
+ * follower each break the relation at a junction that is looked at here -- every time, not with the probability of a sample
+ * (k_lf_check keeps sampling every 4096th row for errors of the rank arithmetic itself).  One octet per walker and per event stretch:
+ * text positions t + 1 -> t, rows kb = tw[t + 1] >> 3 and kbn = tw[t] >> 3, c = tw[t + 1] & 7:  pos[kbn] - kbn == C1[c] + rank_B1(c, pos[kb] - kb)
+ * (fm-index.c:171-173).  nchecked[1] counts failures (with k_lf_check's), *njunc the junctions looked at. */
+__global__ void __launch_bounds__(256) k_junction_check(IdxView b1, const int64_t *pos, const uint64_t *tw, int64_t n2, const rb3_stretch_t *tab, const uint32_t *sidctr,
+		const int64_t *jmet, int64_t nwalk_arg, const unsigned long long *nwalk_dev, unsigned long long *bad, unsigned long long *nchecked, unsigned long long *njunc,
+		int ev_stride, int ev_phase)
+{
+	// ev_stride, ev_phase: the events looked at are those of the stretch ids = phase (mod stride); 1: all of them (the walkers' junctions: always all)
+	if ((bad[0] | bad[1] | bad[2]) != 0) return; // pos[] already failed validation
+	const int lane = threadIdx.x & 63, j = lane & 7;
+	const int64_t nwalk = nwalk_dev ? (int64_t)*nwalk_dev : nwalk_arg;
+	const int64_t nev = (int64_t)(sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : (uint32_t)RB3_TENT_HALF); // events only happen to ids from blocks
+	const int64_t nq = nwalk + (nev - ev_phase + ev_stride - 1) / ev_stride;
+	unsigned long long nfail = 0, nseen = 0;
+	for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; q < nq; q += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+		int64_t t; // the junction lies between text positions t + 1 and t
+		if (q < nwalk) {
+			t = jmet[q] - 1;
+		} else {
+			const int64_t sid = (q - nwalk) * ev_stride + ev_phase;
+			if (sid >= nev) continue;
+			const uint64_t w0 = tab[sid].w0;
+			if (w0 >> 62 != RB3_DEP_EVENT) continue;
+			t = (int64_t)(tab[sid].w1 >> RB3_EV_TP_SHIFT) - 1; // noted at text position tp: the new stretch begins at tp - 1
+		}
+		if (t < 0 || t + 1 >= n2) continue;
+		const uint64_t xa = tw[t + 1], xb = tw[t];
+		const int c = (int)(xa & 7u);
+		if (c == 0) continue; // position t + 1 starts a string: nothing leads from it to t
+		const int64_t kb = (int64_t)(xa >> 3), kbn = (int64_t)(xb >> 3);
+		bool ok = kb < n2 && kbn < n2;
+		if (ok) {
+			const int64_t ka = pos[kb] - kb, kan = pos[kbn] - kbn;
+			ok = ka >= 0 && ka <= b1.n && c <= 5;
+			if (ok) {
+				RankLoad rl;
+				oct_rank_issue(b1, ka, j, rl);
+				ok = oct_rank_finish(rl, c, j, b1.abs != 0) == kan;
+			}
+		}
+		++nseen;
+		if (!ok) ++nfail;
+	}
+	if (j == 0 && nfail) atomicAdd(nchecked + 1, nfail);
+	{ // ONE atomic per block for the count (every lane of an octet counted the same junctions; an atomic per wave -- 8 k of them on one word, ~12 ns
+	  // of its L2 channel each -- made this kernel last 70 us, all of them in front of the rebuild)
+		__shared__ unsigned int bsum;
+		if (threadIdx.x == 0) bsum = 0u;
+		__syncthreads();
+		unsigned int tot = 0;
+		for (int o = 0; o < 8; ++o) tot += (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nseen, o * 8);
+		if (lane == 0 && tot) atomicAdd(&bsum, tot);
+		__syncthreads();
+		if (threadIdx.x == 0 && bsum) atomicAdd(njunc, (unsigned long long)bsum);
+	}
+}
+
+#ifdef RB3GPU_TEST_HOOKS
+/* test hook: ONE settled stretch gets a wrong unknown -- the `which`-th event stretch in use (counted from the table's start) that is settled, moved by +1 or,
+ * if that leaves the masks' range, by -1: every row of that stretch and of no other moves by one position.  what[0] = the stretch (or -1). */
+__global__ void k_test_corrupt_sfin(const rb3_stretch_t *tab, const uint32_t *sidctr, int32_t *sfin, int64_t which, long long *what)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	const int64_t n = (int64_t)(sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : (uint32_t)RB3_TENT_HALF);
+	int64_t seen = 0;
+	what[0] = -1;
+	for (int64_t s = 0; s < n; ++s) {
+		if (tab[s].w0 >> 62 != RB3_DEP_EVENT || sfin[s] < 1) continue;
+		if (seen++ != which) continue;
+		const int kk = (int)(tab[s].w1 & 0xFFFF);
+		sfin[s] += sfin[s] - 1 < kk ? 1 : -1;
+		what[0] = s;
+		return;
+	}
+}
+#endif
 
 /* ----------------------------------------------------------------------------------------- */
 /* interleave + rebuild                                                                        */
@@ -4001,9 +4107,12 @@ struct ShRec { int64_t kb, ka; };
  * flight per stage instead of a chain of four per state), and ONE cursor atomic per block and destination for its 32 S states: the
  * cursors are single words that every block adds to and needs the answer from, and such an atomic takes ~12 ns of its L2 channel --
  * with one per 32 states the kernel ran at 2.5 G steps/s whatever the number of chains (measured: 398 us per 10^6 chains). */
+/* tprev != NULL (the batch sharded, VERDICT r4 "a sharded batch"): the device holds the symbol before every text position, one byte each,
+ * instead of the text-order words (8 bytes each) -- what a step needs of the batch is that symbol only; the record is then
+ * (text position, insertion point) and the row is looked up at the end, by the rank that holds that part of the inverse suffix array. */
 template<int S>
 __global__ void __launch_bounds__(256) k_sh_round(IdxView ix, ShArgs a, int64_t n, const ShState *in, const uint64_t *tw, ShRec *rec,
-		ShState *send, int64_t stride, unsigned long long *cnt, unsigned long long *cnt_next, unsigned long long *bad)
+		ShState *send, int64_t stride, unsigned long long *cnt, unsigned long long *cnt_next, unsigned long long *bad, const uint8_t *tprev = nullptr)
 {
 	__shared__ uint32_t lc[RB3_SH_MAXIV + 1];
 	__shared__ unsigned long long lb[RB3_SH_MAXIV + 1];
@@ -4023,7 +4132,7 @@ __global__ void __launch_bounds__(256) k_sh_round(IdxView ix, ShArgs a, int64_t 
 		if (q0 + s < n) st[s] = in[q0 + s];
 	}
 #pragma unroll
-	for (int s = 0; s < S; ++s) x[s] = q0 + s < n ? tw[st[s].tp] : 0ull;
+	for (int s = 0; s < S; ++s) x[s] = q0 + s >= n ? 0ull : tprev ? ((uint64_t)st[s].tp << 3 | (uint64_t)tprev[st[s].tp]) : tw[st[s].tp];
 #pragma unroll
 	for (int s = 0; s < S; ++s) {
 		int64_t k = st[s].ka - a.iv_start;
@@ -4071,6 +4180,96 @@ __global__ void __launch_bounds__(256) k_sh_place(int64_t n, const ShRec *rec, i
 	const int64_t kb = r.kb - jlo;
 	if (kb < 0 || kb >= n || r.ka < iv_start) { atomicAdd(bad, 1ull); return; }
 	pos[kb] = r.ka - iv_start + kb;
+}
+
+/* ---- the batch sharded by text range: the rows of the records are looked up where that part of the inverse suffix array lives ---- */
+
+/* the symbol before every text position, one byte each, from the text-order words (tw[t] = row << 3 | symbol before) */
+__global__ void __launch_bounds__(256) k_tprev_from_tw(const uint64_t *tw, int64_t n, uint8_t *out)
+{
+	const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+	if (i >= n) return;
+	if (i + 8 <= n) {
+		uint64_t v = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v |= (tw[i + k] & 7ull) << (8 * k);
+		*(uint64_t*)(out + i) = v;
+	} else
+		for (int64_t k = i; k < n; ++k) out[k] = (uint8_t)(tw[k] & 7ull);
+}
+
+struct ShTextBounds { int64_t b[RB3_SH_MAXIV + 1]; int n; };
+
+/* records (text position, insertion point) per owner of the text position: cnt[q] += ... */
+__global__ void __launch_bounds__(256) k_sh_owner_count(int64_t n, const ShRec *rec, ShTextBounds tb, unsigned long long *cnt, unsigned long long *bad)
+{
+	__shared__ unsigned int lc[RB3_SH_MAXIV];
+	if (threadIdx.x < RB3_SH_MAXIV) lc[threadIdx.x] = 0u;
+	__syncthreads();
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		const int64_t tp = rec[i].kb;
+		if (tp < 0 || tp >= tb.b[tb.n]) atomicAdd(bad, 1ull);
+		else {
+			int d = 0;
+			for (int q = 1; q < tb.n; ++q) d += tb.b[q] <= tp ? 1 : 0;
+			atomicAdd(&lc[d], 1u);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < tb.n && lc[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)lc[threadIdx.x]);
+}
+
+/* ... and into the send region of that owner (region q at q * stride; the order inside a region does not matter: the reply carries all a row needs) */
+__global__ void __launch_bounds__(256) k_sh_owner_scatter(int64_t n, const ShRec *rec, ShTextBounds tb, int64_t stride, unsigned long long *cursor, ShRec *send)
+{
+	__shared__ unsigned int lc[RB3_SH_MAXIV];
+	__shared__ unsigned long long lb[RB3_SH_MAXIV];
+	if (threadIdx.x < RB3_SH_MAXIV) lc[threadIdx.x] = 0u;
+	__syncthreads();
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	int d = -1;
+	unsigned int mine = 0;
+	ShRec r;
+	r.kb = r.ka = 0;
+	if (i < n) {
+		r = rec[i];
+		if (r.kb >= 0 && r.kb < tb.b[tb.n]) {
+			d = 0;
+			for (int q = 1; q < tb.n; ++q) d += tb.b[q] <= r.kb ? 1 : 0;
+			mine = atomicAdd(&lc[d], 1u);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < tb.n) lb[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)lc[threadIdx.x]) : 0ull;
+	__syncthreads();
+	if (d >= 0) send[(int64_t)d * stride + (int64_t)lb[d] + mine] = r;
+}
+
+/* the owner's answer: request i of source s (the requests lie packed by source, off[s] .. off[s + 1]) -> tw[tp] = row << 3 | symbol of the row,
+ * into the send region of s (s * stride); the insertion point travels back untouched */
+__global__ void __launch_bounds__(256) k_sh_lookup(int64_t n, const ShRec *req, ShTextBounds off, int64_t stride, const uint64_t *tw_slice, int64_t t_lo, int64_t t_hi, ShRec *out, unsigned long long *bad)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int sidx = 0;
+	for (int q = 1; q < off.n; ++q) sidx += off.b[q] <= i ? 1 : 0;
+	ShRec r = req[i];
+	if (r.kb < t_lo || r.kb >= t_hi) { atomicAdd(bad, 1ull); r.kb = -1; }
+	else r.kb = (int64_t)tw_slice[r.kb - t_lo];
+	out[(int64_t)sidx * stride + (i - off.b[sidx])] = r;
+}
+
+/* the answers -> merged positions inside the interval and the rows' symbols: reply.kb = row << 3 | symbol */
+__global__ void __launch_bounds__(256) k_sh_place_text(int64_t n, const ShRec *rep, int64_t jlo, int64_t iv_start, int64_t *pos, uint8_t *b2rows, unsigned long long *bad)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const ShRec r = rep[i];
+	const int64_t kb = (r.kb >> 3) - jlo;
+	if (r.kb < 0 || kb < 0 || kb >= n || r.ka < iv_start) { atomicAdd(bad, 1ull); return; }
+	pos[kb] = r.ka - iv_start + kb;
+	b2rows[kb] = (uint8_t)(r.kb & 7);
 }
 
 /* ----------------------------------------------------------------------------------------- */

@@ -1493,6 +1493,46 @@ def test_lf_consistency_check_finds_a_wrong_but_monotone_pos(oracle):
     h.close()
 
 
+def test_junction_check_catches_one_wrong_stretch_every_time(oracle):
+    """the deterministic part of the validation (k_junction_check): the LF relation at EVERY junction of the
+    speculative walk -- where a walker met somebody's record, and at every drop-out event -- on every merge.  A test hook gives ONE
+    settled stretch a wrong unknown (all its rows move by one position; the sampled check, 1 row in 4096, would see a stretch of
+    a few dozen rows once in a hundred merges): caught 100 times out of 100 -- by the order check when the move collides with a
+    neighbour, by the junction check otherwise --, nothing installed, the merge redone without speculation: the oracle's index."""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(2025)
+    g0 = util.random_genome(rng, 30000)
+    rel = [util.mutate(rng, g0, 0.004) for _ in range(10)]
+    b1 = host.build_bwt(util.make_text(rel))
+    t2 = util.make_text([util.mutate(rng, g0, 0.003)])
+    want = oracle.merge(b1, host.build_bwt(t2.copy()))
+    h = Rb3Gpu(verbose=1, hooks=True)
+    h.tune("junction_check", 1)    # every event (the default looks at the events of every 16th stretch id, and at all junctions between walkers)
+    try:
+        caught = 0
+        for trial in range(100):
+            h.stats_reset()
+            h.tune("corrupt_sfin", trial * 3)
+            h.from_plain(b1)
+            d, dtw = h.sort_text(t2)
+            h.merge_text_dev(d, dtw, t2.size, host.walkers_text(t2, 256), commit=True)
+            h.dev_free(d), h.dev_free(dtw)
+            st = h.stats()
+            assert np.array_equal(h.export_plain(), want), trial
+            caught += st["n_fallbacks"]      # (by the order check -- the junction check does not run then -- or by the junction check)
+        assert caught == 100, caught
+        # and without the hook: every junction checked, none fails
+        h.tune("corrupt_sfin", -1)
+        h.stats_reset()
+        h.from_plain(b1)
+        d, dtw = h.sort_text(t2)
+        h.merge_text_dev(d, dtw, t2.size, host.walkers_text(t2, 256), commit=True)
+        st = h.stats()
+        assert st["n_fallbacks"] == 0 and st["n_junctions_checked"] > 300 and np.array_equal(h.export_plain(), want), st
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("tent_q", [0, 2, 8])
 def test_duplicate_genome_long_settle_paths(oracle, tent_q):
     """a string that repeats indexed text end to end never makes a walker exact: all its walkers hang on ONE dependency path,

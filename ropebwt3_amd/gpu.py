@@ -43,6 +43,7 @@ class Stats(ctypes.Structure):
 
 
 EMIT_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64)
+EMITW_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64)
 EMIT_WORDS_F = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64)
 
 # name -> (restype, argtypes); every symbol declared in include/rb3gpu.h
@@ -124,6 +125,14 @@ SYMBOLS = {
     "rb3gpu_shard_split": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_shard_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_shard_gather": (ctypes.c_int, [ctypes.c_void_p]),
+    "rb3gpu_shard_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_shard_get_acc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_shard_export_runs": (ctypes.c_int, [ctypes.c_void_p, EMIT_F, ctypes.c_void_p]),
+    "rb3gpu_shard_export_run_words": (ctypes.c_int, [ctypes.c_void_p, EMITW_F, ctypes.c_void_p]),
+    "rb3gpu_sh_merge_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "rb3gpu_tprev_from_tw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_balanced_bounds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "rb3gpu_export_plain_range_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rb3gpu_shard_handle": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     "rb3gpu_shard_bounds": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_device_of": (ctypes.c_int, [ctypes.c_void_p]),
@@ -547,6 +556,26 @@ class Rb3Gpu:
         self._chk(self._lib.rb3gpu_sh_merge(self._h, ctypes.addressof(comm.struct), b.ctypes.data, int(n2), d_bwt, d_tw, tp.size, tp.ctypes.data, 1 if commit else 0, ctypes.addressof(rounds)), "rb3gpu_sh_merge")
         return b, int(rounds.value)
 
+    def sh_merge_text(self, comm, bounds, d_tprev, d_tw_slice, n2, sent_tp, commit=True):
+        """rb3gpu_sh_merge_text: the same with the BATCH sharded -- d_tprev: the symbol before every text position (1 byte each, whole),
+        d_tw_slice: the text-order words of this rank's text range only; the rows come from the owners of the text ranges at the end"""
+        b = np.array(bounds, dtype=np.int64)
+        tp = np.ascontiguousarray(sent_tp, dtype=np.int64)
+        rounds = ctypes.c_int64(0)
+        self._chk(self._lib.rb3gpu_sh_merge_text(self._h, ctypes.addressof(comm.struct), b.ctypes.data, int(n2), d_tprev, d_tw_slice, tp.size, tp.ctypes.data, 1 if commit else 0, ctypes.addressof(rounds)), "rb3gpu_sh_merge_text")
+        return b, int(rounds.value)
+
+    def tprev_from_tw(self, d_tw, n2):
+        """device array of n2 bytes: the symbol before every text position (rb3gpu_tprev_from_tw); free it with dev_free"""
+        d = self.dev_alloc(int(n2) + 64)
+        self._chk(self._lib.rb3gpu_tprev_from_tw(self._h, int(n2), d_tw, d), "rb3gpu_tprev_from_tw")
+        return d
+
+    def balanced_bounds(self, n):
+        b = np.zeros(n + 1, dtype=np.int64)
+        self._chk(self._lib.rb3gpu_balanced_bounds(self._h, int(n), b.ctypes.data), "rb3gpu_balanced_bounds")
+        return b
+
     def sync(self):
         self._chk(self._lib.rb3gpu_sync(self._h), "rb3gpu_sync")
 
@@ -686,6 +715,52 @@ class Shard:
         if r < 0:
             raise Rb3GpuError(int(r), "rb3gpu_shard_merge")
         return int(rounds.value)
+
+    def get_acc(self):
+        a = np.zeros(7, dtype=np.int64)
+        r = self._lib.rb3gpu_shard_get_acc(self._s, a.ctypes.data)
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_shard_get_acc")
+        return a
+
+    def export_plain(self):
+        """the whole index as one byte per symbol, straight from the intervals in rank order (rb3gpu_shard_export_runs: no gather)"""
+        out = []
+        runs = []
+
+        def emit(_d, c, l):
+            runs.append((int(c), int(l)))
+            return 0
+        cb = EMIT_F(emit)
+        r = self._lib.rb3gpu_shard_export_runs(self._s, cb, None)
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_shard_export_runs")
+        assert all(runs[i][0] != runs[i + 1][0] for i in range(len(runs) - 1)), "runs that meet at a seam must be joined"
+        for c, l in runs:
+            out.append(np.full(l, c, dtype=np.uint8))
+        return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+
+    def export_run_words(self):
+        """(starts, symbols) of the maximal runs of the whole index and its length, from rb3gpu_shard_export_run_words"""
+        words, end = [], [-1]
+
+        def emit(_d, n, w, e):
+            if n > 0:
+                words.append(np.ctypeslib.as_array(w, shape=(n,)).copy())
+            if e >= 0:
+                end[0] = int(e)
+            return 0
+        cb = EMITW_F(emit)
+        r = self._lib.rb3gpu_shard_export_run_words(self._s, cb, None)
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_shard_export_run_words")
+        w = np.concatenate(words) if words else np.zeros(0, dtype=np.uint64)
+        return (w >> np.uint64(3)).astype(np.int64), (w & np.uint64(7)).astype(np.uint8), end[0]
+
+    def destroy(self):
+        s, self._s = self._s, None
+        if s:
+            self._lib.rb3gpu_shard_destroy(s)
 
     def gather(self):
         s, self._s = self._s, None

@@ -426,6 +426,16 @@ def sh_comm(h, dist, rank, world, dev, driver="rccl"):
     return CallbackComm(rank, world, all_gather, exchange), "callbacks over torch.distributed (all_gather_into_tensor + all_to_all of views of the engine's send regions)" + why
 
 
+def merge_interval_text(engine, comm, bounds, d_tprev, d_tw_slice, n2, sent_tp, commit=True, stats=None):
+    """merge_interval_c with the BATCH sharded as well (rb3gpu_sh_merge_text): d_tprev = the symbol before every text position (1 byte each),
+    d_tw_slice = the text-order words of this rank's text range only"""
+    nb, rounds = engine.sh_merge_text(comm, bounds, d_tprev, d_tw_slice, n2, sent_tp, commit)
+    if stats is not None:
+        stats["rounds"] = rounds
+        stats["rows_per_rank"] = [int(x) for x in np.diff(nb) - np.diff(np.asarray(bounds, dtype=np.int64))] if commit else None
+    return nb
+
+
 def merge_interval_c(engine, comm, bounds, d_bwt, d_tw, n2, sent_tp, commit=True, stats=None):
     """merge_interval with the lock-step loop inside the library (rb3gpu_sh_merge): same arguments, same result"""
     nb, rounds = engine.sh_merge(comm, bounds, d_bwt, d_tw, n2, sent_tp, commit)
@@ -493,14 +503,101 @@ def _solo_interval_reference(reads_per_gpu, args, dev, local_rank):
             s1 = h1.stats()
             res[driver] = {"value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "rounds": stt.get("rounds"),
                            "us_per_round_walk": round(s1["ms_rank"] / args.steps / max(1, stt.get("rounds") or 1) * 1e3, 2), "ms_rebuild": round(s1["ms_build"] / args.steps, 3)}
+        # ... and through the NORMAL single-GPU path (rb3gpu_merge_text_dev, one walker per string): the number an interval-sharded build has to beat
+        try:
+            for _ in range(max(1, args.warmup)):
+                h1.merge_text_dev(d2, d2tw, t2.size, int(sent.size), commit=False)
+            h1.sync(), torch.cuda.synchronize()
+            h1.stats_reset()
+            t = time.perf_counter()
+            for _ in range(args.steps):
+                h1.merge_text_dev(d2, d2tw, t2.size, int(sent.size), commit=False)
+            h1.sync(), torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            s1 = h1.stats()
+            res["normal"] = {"value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_rank": round(s1["ms_rank"] / args.steps, 3), "ms_rebuild": round(s1["ms_build"] / args.steps, 3),
+                             "entry_point": "rb3gpu_merge_text_dev, one walker per string (k_chain), commit=0"}
+        except Exception as e:
+            res["normal"] = {"error": repr(e)[:200]}
         h1.dev_free(d2), h1.dev_free(d2tw)
         out = dict(res["library"])
-        out.update({"symbols_per_step": int(t2.size), "index_symbols": int(b1.size), "loop_in_python": res["python"],
+        out.update({"symbols_per_step": int(t2.size), "index_symbols": int(b1.size), "loop_in_python": res["python"], "normal_single_gpu_path": res["normal"],
                     "note": "rank 0 alone, same protocol with one interval (no collective), measured after the timed region of this run; us_per_round_walk: the walk's wall time per lock-step round (kernel + read-back of the split sizes), rebuild excluded"})
         return out
     finally:
         h1.close()
 
+
+def interval_leg(args, h, dist, rank, world, dev, local_rank, shared_gpu, barrier):
+    """the north_star workload: the index of a random genome cut into `world` intervals, one per GPU; every step merges one batch of reads
+    (world x 500 k reads of 150 bp, both strands: per-GPU work fixed) with the BATCH sharded as well (rb3gpu_sh_merge_text: 1 byte per batch
+    symbol replicated, the text-order words by text range).  Returns rank 0's JSON object (None elsewhere)."""
+    import os, time
+    import torch
+    from tests import util
+    out = None
+    n_index, reads_per_gpu = (1 << 26) * world, (500000 if world > 1 else 100000)   # (large batches amortise the per-symbol collectives: config 4 has 46 M chains per batch)
+    rng = np.random.default_rng(31)
+    g = util.random_genome(rng, n_index // 2 - 1)
+    t1 = util.make_text([g])
+    d1, d1tw = h.sort_text(t1)                                  # every rank sorts the (synthetic) index text itself: no broadcast needed
+    b1 = h.dev_download(d1, t1.size)
+    h.dev_free(d1), h.dev_free(d1tw)
+    bounds = interval_bounds(b1.size, world)
+    h.from_plain(b1[bounds[rank]:bounds[rank + 1]])
+    st = rng.integers(0, len(g) - 150, size=reads_per_gpu * world)
+    r = np.stack([g[s:s + 150] for s in st])
+    m = rng.random(r.shape) < 0.01
+    r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
+    t2 = util.make_text(list(r))
+    d2, d2tw = h.sort_text(t2)
+    sent = np.flatnonzero(t2 == 0).astype(np.int64)
+    driver = getattr(args, "sh_driver", None) or os.environ.get("RB3_SH_DRIVER", "rccl")
+    if driver == "python":   # rounds 1-3: the lock-step loop in Python, two kernels and two host syncs per round
+        comm, label, fn = TorchComm(dist, rank, world, dev, sync=lambda: (h.sync(), torch.cuda.synchronize())), "loop in Python (multi.merge_interval) over torch.distributed", merge_interval
+    else:
+        comm, label = sh_comm(h, dist, rank, world, dev, driver)
+        fn = merge_interval_c
+    a1, a2 = d2, d2tw
+    if fn is merge_interval_c and not os.environ.get("RB3_SH_REPLICATED_BATCH"):   # the batch sharded as well: what `build --gpus N --interval` runs
+        n2 = t2.size
+        t_lo = n2 // world * rank + (n2 % world) * rank // world
+        a1, a2 = h.tprev_from_tw(d2tw, n2), d2tw.value + t_lo * 8   # (every rank sorted the whole synthetic batch itself; it only reads its own text range of the words)
+        fn = merge_interval_text
+    stt = {}
+    for _ in range(args.warmup):
+        fn(h, comm, bounds, a1, a2, t2.size, sent, commit=False, stats=stt)
+    h.stats_reset()
+    barrier()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        fn(h, comm, bounds, a1, a2, t2.size, sent, commit=False, stats=stt)
+    barrier()
+    dt = time.perf_counter() - t
+    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    s = h.stats()
+    if rank == 0:
+        out = {"metric": "Gbp/s indexed (build merge)", "value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+               "config": {"workload": "interval-sharded index (north_star): %d symbols in %d intervals, one per GPU; per step one batch of %d x 150 bp reads (both strands, %d symbols) merged with one all-to-all per symbol" % (b1.size, world, reads_per_gpu * world, t2.size),
+                          "symbols_per_step_per_gpu": int(t2.size // world), "index_symbols": int(b1.size), "parallelism": "interval%d: chain states routed to the owner of their insertion point by %s, %d lock-step rounds per merge; local rebuild per interval" % (world, "gloo send/recv through host memory (ranks share a GPU: TEST MODE, not a measurement)" if shared_gpu else "RCCL all-to-all(v)", stt.get("rounds", 0)),
+                          "rows_per_rank": stt.get("rows_per_rank"), "ranks_share_a_gpu": bool(shared_gpu),
+                          "driver": ("rb3gpu_sh_merge_text (the loop inside the library; the batch sharded: 1 byte per symbol on every GPU, the text-order words by text range, rows looked up by their owners at the end): " + label) if fn is merge_interval_text else ("rb3gpu_sh_merge (the loop inside the library): " + label) if fn is merge_interval_c else label,
+                          "us_per_round_rank0": round(s["ms_rank"] / args.steps / max(1, stt.get("rounds") or 1) * 1e3, 2)},
+               "phases_ms_per_step_rank0": {"step_kernels": round(s["ms_rank"] / args.steps, 3), "rebuild": round(s["ms_build"] / args.steps, 3)},
+               "roofline": {"bound": "hbm", "kernel": "k_sh_round" if fn is not merge_interval else "k_sh_step", "achieved": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6 / 8000.0, 5), "traffic": None,
+                            "note": "rank 0: 208 B x the LF steps it executed / the time of its step kernels; the collectives are outside this figure and inside `value`"}}
+        # the same per-GPU work on ONE GPU (rank 0 alone, its own handle, no collectives): what weak scaling is measured against
+        if world > 1 or os.environ.get("RB3_BENCH_SOLO_REF"):
+            try:
+                out["n1_same_workload"] = _solo_interval_reference(reads_per_gpu, args, dev, local_rank)
+            except Exception as e:   # never lose the measurement above to this extra
+                out["n1_same_workload"] = {"error": repr(e)}
+
+    return out
 
 def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1), one process per GPU.  --mode interval (default): north_star -- the index of a random genome
@@ -541,59 +638,7 @@ def bench_main(args, rank, local_rank, world):
 
     out = None
     if args.mode == "interval":
-        n_index, reads_per_gpu = (1 << 26) * world, (500000 if world > 1 else 100000)   # (large batches amortise the per-symbol collectives: config 4 has 46 M chains per batch)
-        rng = np.random.default_rng(31)
-        g = util.random_genome(rng, n_index // 2 - 1)
-        t1 = util.make_text([g])
-        d1, d1tw = h.sort_text(t1)                                  # every rank sorts the (synthetic) index text itself: no broadcast needed
-        b1 = h.dev_download(d1, t1.size)
-        h.dev_free(d1), h.dev_free(d1tw)
-        bounds = interval_bounds(b1.size, world)
-        h.from_plain(b1[bounds[rank]:bounds[rank + 1]])
-        st = rng.integers(0, len(g) - 150, size=reads_per_gpu * world)
-        r = np.stack([g[s:s + 150] for s in st])
-        m = rng.random(r.shape) < 0.01
-        r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
-        t2 = util.make_text(list(r))
-        d2, d2tw = h.sort_text(t2)
-        sent = np.flatnonzero(t2 == 0).astype(np.int64)
-        driver = getattr(args, "sh_driver", None) or os.environ.get("RB3_SH_DRIVER", "rccl")
-        if driver == "python":   # rounds 1-3: the lock-step loop in Python, two kernels and two host syncs per round
-            comm, label, fn = TorchComm(dist, rank, world, dev, sync=lambda: (h.sync(), torch.cuda.synchronize())), "loop in Python (multi.merge_interval) over torch.distributed", merge_interval
-        else:
-            comm, label = sh_comm(h, dist, rank, world, dev, driver)
-            fn = merge_interval_c
-        stt = {}
-        for _ in range(args.warmup):
-            fn(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
-        h.stats_reset()
-        barrier()
-        t = time.perf_counter()
-        for _ in range(args.steps):
-            fn(h, comm, bounds, d2, d2tw, t2.size, sent, commit=False, stats=stt)
-        barrier()
-        dt = time.perf_counter() - t
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        s = h.stats()
-        if rank == 0:
-            out = {"metric": "Gbp/s indexed (build merge)", "value": round(t2.size * args.steps / dt / 1e9, 6), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-                   "config": {"workload": "interval-sharded index (north_star): %d symbols in %d intervals, one per GPU; per step one batch of %d x 150 bp reads (both strands, %d symbols) merged with one all-to-all per symbol" % (b1.size, world, reads_per_gpu * world, t2.size),
-                              "symbols_per_step_per_gpu": int(t2.size // world), "index_symbols": int(b1.size), "parallelism": "interval%d: chain states routed to the owner of their insertion point by %s, %d lock-step rounds per merge; local rebuild per interval" % (world, "gloo send/recv through host memory (ranks share a GPU: TEST MODE, not a measurement)" if shared_gpu else "RCCL all-to-all(v)", stt.get("rounds", 0)),
-                              "rows_per_rank": stt.get("rows_per_rank"), "ranks_share_a_gpu": bool(shared_gpu), "driver": "rb3gpu_sh_merge (the loop inside the library): " + label if fn is merge_interval_c else label,
-                              "us_per_round_rank0": round(s["ms_rank"] / args.steps / max(1, stt.get("rounds") or 1) * 1e3, 2)},
-                   "phases_ms_per_step_rank0": {"step_kernels": round(s["ms_rank"] / args.steps, 3), "rebuild": round(s["ms_build"] / args.steps, 3)},
-                   "roofline": {"bound": "hbm", "kernel": "k_sh_round" if fn is merge_interval_c else "k_sh_step", "achieved": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
-                                "frac": round(208 * t2.size / world * args.steps / max(1e-9, s["ms_rank"]) / 1e6 / 8000.0, 5), "traffic": None,
-                                "note": "rank 0: 208 B x the LF steps it executed / the time of its step kernels; the collectives are outside this figure and inside `value`"}}
-            # the same per-GPU work on ONE GPU (rank 0 alone, its own handle, no collectives): what weak scaling is measured against
-            if world > 1 or os.environ.get("RB3_BENCH_SOLO_REF"):
-                try:
-                    out["n1_same_workload"] = _solo_interval_reference(reads_per_gpu, args, dev, local_rank)
-                except Exception as e:   # never lose the measurement above to this extra
-                    out["n1_same_workload"] = {"error": repr(e)}
+        out = interval_leg(args, h, dist, rank, world, dev, local_rank, shared_gpu, barrier)
     else:
         seeds = [2 + i for i in range(world)]
         g0 = util.random_genome(np.random.default_rng(1), args.genome_len)
@@ -714,6 +759,22 @@ def bench_partition_mtb(args, rank, local_rank, world):
                "not_counted_ms_per_step": {"suffix_sorting_on_the_gpu(max over ranks)": round(sort / args.steps * 1e3, 3)},
                "roofline": B.chain_roofline(int(st["n_lf_steps"] / max(1, st["n_rank_launches"])), st["ms_chain"] / max(1, st["n_rank_launches"]), "text", None,
                                             "rank 0's k_chain launches (leaf rounds and tree merges together): 208 B x LF steps / HIP-event time")}
+    # in the same line, the reads workload through the interval-sharded path (north_star), with the SAME workload at N = 1 through
+    # the normal single-GPU path beside it (aux_interval_reads.n1_same_workload.normal_single_gpu_path: the number --interval has to beat)
+    aux = None
+    if not args.no_aux:
+        try:
+            from ropebwt3_amd import Rb3Gpu
+            h2 = Rb3Gpu(device=dev_id, verbose=1)
+            if shared_gpu:
+                args.sh_driver = "gloo"
+            aux = interval_leg(args, h2, dist, rank, world, dev, dev_id, shared_gpu, lambda: (h2.sync(), torch.cuda.synchronize(), dist.all_reduce(zero), torch.cuda.synchronize()))
+            h2.close()
+        except Exception as e:
+            aux = {"error": repr(e)[:300]}
+    if rank == 0:
+        if aux is not None:
+            out["aux_interval_reads"] = aux
         print(json.dumps(out), flush=True)
     dist.barrier() if shared_gpu else barrier()
     bl.close()

@@ -103,6 +103,20 @@ def test_multi_gpu_build_with_the_index_cut_into_intervals(n, extra):
         assert "lock-step rounds" in err or small or name == "reads_rev"
 
 
+def test_interval_build_writes_every_format_from_the_intervals(tmp_path):
+    """`build --gpus 3 --interval` with FMR (-b) and plain output: the writers take the intervals where they are (no gather); the plain BWT is
+    the ordinary build's, the FMR decodes to the same FMD"""
+    ent = MAN["reads_fq"]
+    inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+    plain1, _ = run(["build"] + ent["flags"] + ["-m40k"] + inputs)
+    plain3, err = run(["build"] + ent["flags"] + ["-m40k", "--gpus", "3", "--interval"] + inputs)
+    assert plain3 == plain1 and "index cut into 3 intervals" in err
+    fmr = tmp_path / "x.fmr"
+    out, _ = run(["build"] + ent["flags"] + ["-m40k", "--gpus", "3", "--interval", "-b", "-o", str(fmr)] + inputs)
+    fmd, _ = run(["recode", "-d", str(fmr)])
+    assert hashlib.md5(fmd).hexdigest() == ent["fmd_md5"]
+
+
 def test_gzip_through_a_pipe_on_stdin():
     """`cat x.fa.gz | build -`: the same .fmd as from the file (the reader must not eat the gzip magic of a pipe)"""
     ent = MAN["genomes12"]

@@ -1237,6 +1237,99 @@ def test_shard_object_split_merge_gather(oracle):
         h.close()
 
 
+def test_shard_object_exports_without_a_gather(oracle):
+    """the writers' view of the sharded index: runs taken from the intervals in rank order and joined at the seams (rb3gpu_shard_export_runs /
+    _run_words), cumulative counts summed over the intervals -- the oracle's merged BWT, with no interval ever copied to another device.
+    A run-coded index (relatives) cut by BYTES of the block array, not by symbols; and the batch sharded inside rb3gpu_shard_merge."""
+    from ropebwt3_amd import Rb3Gpu, Shard
+    for kind, nd in (("family", 3), ("reads", 4), ("dups", 2)):
+        rng = np.random.default_rng(40 + nd)
+        cur, batches, want = _sharded_case(oracle, rng, kind)
+        h = Rb3Gpu(verbose=1)
+        try:
+            h.from_plain(cur)
+            sh = Shard(h, [0] * nd)
+            for t2 in batches:
+                d_bwt, d_tw = h.sort_text(t2)
+                sh.merge(d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+                h.dev_free(d_bwt), h.dev_free(d_tw)
+            w = want[-1]
+            assert np.array_equal(sh.export_plain(), w), kind
+            st, sy, end = sh.export_run_words()
+            assert end == w.size
+            chg = np.flatnonzero(np.concatenate([[True], w[1:] != w[:-1]]))
+            assert np.array_equal(st, chg) and np.array_equal(sy, w[chg]), kind
+            acc = sh.get_acc()
+            assert np.array_equal(np.diff(acc), np.bincount(w, minlength=6)[:6])
+            sh.destroy()
+            assert h.get_tot() < w.size     # the handle still holds its own interval only
+        finally:
+            h.close()
+
+
+def test_balanced_bounds_follow_the_bytes_of_the_block_array(oracle):
+    """rb3gpu_balanced_bounds: an index whose first half is one long run and whose second half is random symbols is cut where the BYTES
+    are (nearly all in the second half), not in the middle"""
+    from ropebwt3_amd import Rb3Gpu
+    rng = np.random.default_rng(5)
+    n = 1 << 21
+    b = np.concatenate([np.full(n, 1, dtype=np.uint8), rng.integers(1, 5, size=n).astype(np.uint8), np.zeros(1, dtype=np.uint8)])
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_plain(b)
+        bd = h.balanced_bounds(4)
+        assert bd[0] == 0 and bd[-1] == b.size and np.all(np.diff(bd) > 0)
+        assert bd[1] > n and bd[2] > n      # equal symbol counts would put bd[1] at n / 2 and bd[2] at n
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("world,kind", [(1, "reads"), (2, "reads"), (3, "family"), (4, "dups"), (3, "ragged")])
+def test_interval_sharded_merge_with_a_sharded_batch(oracle, world, kind):
+    """rb3gpu_sh_merge_text: every rank holds the symbol-before array (1 byte per batch symbol) and ITS text range of the text-order words
+    only; the records are (text position, insertion point) and the rows come back from the owners of the text ranges in one exchange at
+    the end.  `world` ranks as threads with a handle each; after every merge the intervals are the oracle's."""
+    import threading
+    from ropebwt3_amd import Rb3Gpu, CommGroup, multi
+    rng = np.random.default_rng(640 + world)
+    cur, batches, want = _sharded_case(oracle, rng, kind)
+    bounds0 = multi.interval_bounds(cur.size, world)
+    grp = CommGroup(world)
+    errs = []
+
+    def run(rank):
+        try:
+            r = np.random.default_rng(900 + rank)
+            h = Rb3Gpu(verbose=1)
+            comm = grp.comm(rank, h)
+            bounds = bounds0
+            h.from_plain(cur[bounds[rank]:bounds[rank + 1]])
+            for b, t2 in enumerate(batches):
+                d_bwt, d_tw = h.sort_text(t2)
+                d_tp = h.tprev_from_tw(d_tw, t2.size)
+                n2 = t2.size
+                t_lo = n2 // world * rank + (n2 % world) * rank // world
+                t_hi = n2 if rank + 1 == world else n2 // world * (rank + 1) + (n2 % world) * (rank + 1) // world
+                d_slice = h.dev_alloc((t_hi - t_lo) * 8 + 64)      # a copy of the slice: nothing else of the words is reachable through it
+                h.dev_copy(d_slice, d_tw.value + t_lo * 8, (t_hi - t_lo) * 8)
+                h.dev_memset(d_tw, 0xEE, n2 * 8)                   # ... and the whole array is spoilt
+                bounds, _ = h.sh_merge_text(comm, bounds, d_tp, d_slice, n2, np.flatnonzero(t2 == 0), commit=True)
+                h.dev_free(d_bwt), h.dev_free(d_tw), h.dev_free(d_tp), h.dev_free(d_slice)
+                _check_interval(h, r, want[b + 1], bounds, rank)
+            h.close()
+        except BaseException as e:
+            errs.append((rank, repr(e)))
+            grp.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    grp.close()
+    assert not errs, errs
+
+
 def test_shard_object_beside_a_busy_sorter(oracle):
     """the sharded index while ANOTHER thread keeps the device busy with suffix sorting (what the CLI's sorter thread does): the copies
     that cut the index into intervals and put it back together must be complete before the handles read them -- a device-to-device

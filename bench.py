@@ -225,13 +225,15 @@ def mtb_files(K, L, tmp=None):
     return tmp, files, time.time() - t
 
 
-def load_batches(files, pinned=True, step=WALKER_STEP, device=0):
+def load_batches(files, pinned=True, step=WALKER_STEP, device=0, host_walkers=False):
     """every file through the CLI's own reader (rb3h_seq_read: nt6, both strands, sentinels; io.c:104-125), one batch per
     file, into page-locked memory (what `ropebwt3-amd build` does with rb3gpu_pinned_alloc) + the walker list of each batch
     (one walker per string + one per rb3gpu_walker_step text positions -- 230 for these genomes --, rb3h_walkers_text).  Not timed: file I/O is outside the metric."""
     from ropebwt3_amd import PinnedArray, host, walker_step
+    load_batches.host_walkers = host_walkers
     texts, walkers, keep = [], [], []
-    load_batches.walker_seconds = 0.0   # host time spent making the walker lists (rb3h_walkers_text + rb3h_strand_pairs), all batches
+    load_batches.walker_seconds = 0.0   # host time spent making walker lists (rb3h_walkers_text; --host-walkers only), all batches
+    load_batches.pairs_seconds = 0.0    # ... and finding where the records start (rb3h_strand_pairs: what the forward-strand upload needs; the CLI's reader knows them as it parses)
     for fn in files:
         parts = list(host.read_batches(fn, False, 1 << 40))
         n_seq = sum(k for k, _ in parts)
@@ -242,9 +244,15 @@ def load_batches(files, pinned=True, step=WALKER_STEP, device=0):
             keep.append(pa)
             t = pa.array
         texts.append(t)
+        wstep = step if step > 0 else walker_step(device, t.size, n_seq)
         tw0 = time.perf_counter()
-        w = host.walkers_text(t, step if step > 0 else walker_step(device, t.size, n_seq))
         sp = host.strand_pairs(t, n_seq)
+        load_batches.pairs_seconds += time.perf_counter() - tw0
+        if not load_batches.host_walkers:   # the walker list is made on the device, inside the timed merge call (rb3gpu_merge_text_step_dev): the host only says how many strings and what spacing
+            walkers.append(((int(n_seq), int(wstep)), sp))
+            continue
+        tw0 = time.perf_counter()
+        w = host.walkers_text(t, wstep)
         load_batches.walker_seconds += time.perf_counter() - tw0
         if pinned:  # the list goes to the device inside the merge call: from page-locked memory that is one DMA, no staging copy on the host
             pw = PinnedArray(w.nbytes)
@@ -312,8 +320,10 @@ class BuildLoop:
                 c1 = time.perf_counter()
                 if reference_signature:   # the arguments of rb3_fmi_merge_plain (fm-index.c:279): the partial BWT and nothing else
                     h.merge_plain_dev(d_bwt, t.size, commit=True)
+                elif isinstance(w, tuple):   # (strings, spacing): the walker list is made on the device, inside this call
+                    h.merge_text_step_dev(d_bwt, d_tw, t.size, w[0], w[1], commit=True, d_sa=d_sa)   # one synchronisation, at its end
                 else:
-                    h.merge_text_dev(d_bwt, d_tw, t.size, w, commit=True, d_sa=d_sa)   # one synchronisation, at its end
+                    h.merge_text_dev(d_bwt, d_tw, t.size, w, commit=True, d_sa=d_sa)
                 d = time.perf_counter()
                 if overlap and i + 1 < n:
                     srt.upload_end()                        # what the copy engine still has to do shows up here
@@ -482,6 +492,7 @@ def main():
     ap.add_argument("--only", choices=["large", "reads", "cfg2", "cli", "headline", "8g"], default=None, help="run one leg alone and print its JSON (profiling)")
     ap.add_argument("--mtb-ref-prefix", type=int, default=6, help="files the reference binary is timed on (cpu_baseline)")
     ap.add_argument("--walker-step", type=int, default=WALKER_STEP)
+    ap.add_argument("--host-walkers", action="store_true", help="make the walker lists on the host before the timed steps (rb3h_walkers_text, rounds 2-4) instead of on the device inside the merge call")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -518,7 +529,7 @@ def main():
         print(json.dumps(cli_build(files, K, gold)), flush=True)
         return
     t0 = time.time()
-    texts, walkers, keep = load_batches(files, pinned=not args.no_pinned, step=args.walker_step, device=local_rank)
+    texts, walkers, keep = load_batches(files, pinned=not args.no_pinned, step=args.walker_step, device=local_rank, host_walkers=args.host_walkers)
     nsym_all = int(sum(t.size for t in texts))
     log("mtb%d: %d files generated in %.1f s, read into %s memory in %.1f s (%d symbols)" % (K, K, t_gen, "pageable" if args.no_pinned else "page-locked", time.time() - t0, nsym_all))
 
@@ -578,17 +589,17 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "cfg3-synthetic-mtb%d: %d genomes of %d bp (star phylogeny, 0.1 %% substitutions + 10 indels each; tools/gen_mtb.py), one genome per batch = %d merge rounds per step, %d symbols merged per step; merge path incl. H2D (SURVEY 8(d))%s" % (K, K, L, K - 1, sym_step, ", the H2D copy of batch i+1 queued beside the merge of batch i" if bl.overlap else ""),
                    "symbols_per_step": int(sym_step), "merge_rounds_per_step": K - 1, "index_symbols_final": nsym_all, "index_mb_final": round(st["bytes_index"] / 1e6, 1), "parallelism": "single GPU",
-                   "entry_points": "rb3gpu_sorter_upload_fwd (H2D of the batch: forward strands out of page-locked memory, reverse complements written on the device; --full-upload: rb3gpu_sorter_upload) + rb3gpu_merge_text_dev (LF + walkers + settle + validation + rebuild, commit=1); rb3gpu_sorter_sort_uploaded between them is not counted (suffix sorting: excluded by the metric)",
+                   "entry_points": "rb3gpu_sorter_upload_fwd (H2D of the batch: forward strands out of page-locked memory, reverse complements written on the device; --full-upload: rb3gpu_sorter_upload) + rb3gpu_merge_text_step_dev (walker list made on the device + LF + walkers + settle + validation + rebuild, commit=1; --host-walkers: rb3gpu_merge_text_dev with a list from the host); rb3gpu_sorter_sort_uploaded between them is not counted (suffix sorting: excluded by the metric)",
                    "fmd_md5": md5, "fmd_bytes": fmd_len, "fmd_identical_to_reference": ident,
                    "reference_fmd_md5_source": "tests/golden/MANIFEST.json mtb_star/%d (oracle/_ref/ropebwt3 = the unmodified reference, tools/make_golden_mtb.py)" % K if gold else "no golden for this size",
                    "lf_steps_per_step": int(st["n_lf_steps"] // S), "rank_phase_fallbacks": int(st["n_fallbacks"]), "long_settles": int(st["n_long_settles"])},
         "phases_ms_per_step": {"h2d": round(tot_h2d / S * 1e3, 3), "merge_calls": round(tot_mrg / S * 1e3, 3), "lf": round(st["ms_lf"] / S, 3), "rank": round(st["ms_rank"] / S, 3), "k_chain": round(st["ms_chain"] / S, 3),
                                "rebuild": round(st["ms_build"] / S, 3), "host_and_sync_inside_merge_calls": round((tot_mrg * 1e3 - st["ms_lf"] - st["ms_rank"] - st["ms_build"]) / S, 3)},
         "not_counted_ms_per_step": {"suffix_sorting_on_the_gpu": round(tot_sort / S * 1e3, 3), "wall_of_the_whole_loop": round(tot_wall / S * 1e3, 3),
-                                    "walker_lists_on_the_host": round(load_batches.walker_seconds * 1e3, 3),
-                                    "note": "suffix sorting is excluded by the metric's definition (SURVEY 8(d): libsais in the reference); the walker lists (rb3h_walkers_text + rb3h_strand_pairs: where the LF walkers "
-                                            "of a batch start, one pass over the text on one host core) are made ONCE before the timed steps here and by the sorter thread, beside the GPU's work, in the CLI; "
-                                            "their cost per build is stated, not hidden: add it to ms_per_step for a build whose host does nothing in parallel"},
+                                    "walker_lists_on_the_host": round(load_batches.walker_seconds * 1e3, 3), "record_starts_on_the_host(rb3h_strand_pairs)": round(load_batches.pairs_seconds * 1e3, 3),
+                                    "note": "suffix sorting is excluded by the metric's definition (SURVEY 8(d): libsais in the reference); the walker lists are made on the device inside the timed merge calls since round 5 "
+                                            "(walker_lists_on_the_host is 0 unless --host-walkers); where the records of a batch start (what the forward-strand upload needs) is found once before the timed steps "
+                                            "here -- the CLI's reader knows it as it parses"},
         "h2d": {"symbols_per_step": int(sym_step), "bytes_over_pcie_per_step": int(sym_step // 2) if not args.full_upload else int(sym_step), "how": "rb3gpu_sorter_upload_fwd: forward strands copied, reverse complements written on the device" if not args.full_upload else "rb3gpu_sorter_upload: both strands copied", "GB/s_of_text": round(nsym / max(1e-9, tot_h2d) / 1e9, 2), "source": "pageable (staged)" if args.no_pinned else "page-locked (rb3gpu_pinned_alloc): one DMA per batch",
                 "overlapped_with_the_merge_of_the_batch_before": bool(bl.overlap),
                 "what_phases_ms_per_step.h2d_is": ("queueing the copies of batch i+1 (rb3gpu_sorter_upload_fwd_begin) before the merge of batch i is called + what the copy engine still needs once that merge has returned (rb3gpu_sorter_upload_end); the copies run beside the merge's kernels, as in the CLI (sorter thread) and the reference (reader, build.c:203-239)" if bl.overlap else "the upload call from start to completion, nothing beside it"),

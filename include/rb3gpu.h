@@ -229,6 +229,12 @@ int rb3gpu_merge_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const 
  * validation pass gathers them into row order through d_sa: what an index that lives in HBM wants (a batch of reads into a large
  * index: the record stores are two thirds of the walk).  d_sa == NULL: rb3gpu_merge_text_dev.  Same result either way. */
 int rb3gpu_merge_text_sa_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, const uint32_t *d_sa, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit);
+/* The same with the walker list made ON THE DEVICE: the caller passes the number of strings of the batch and a spacing (rb3gpu_walker_step), the
+ * engine puts a walker at every sentinel and at every multiple of `step` strictly inside a string -- the list rb3h_walkers_text makes on the host
+ * (70 ms of one core per 152-genome build), by two small kernels in front of the walk.  d_sa may be NULL.  A wrong string count: RB3GPU_EINVAL. */
+int rb3gpu_merge_text_step_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, const uint32_t *d_sa, int64_t n_strings, int64_t step, int commit);
+/* that list on the host, without its empty slots (tests): *walkers is malloc'ed, free it with rb3gpu_host_free */
+int rb3gpu_walkers_step_dev(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *n_walkers, rb3gpu_walker_t **walkers);
 int rb3gpu_mg_rank_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, int64_t n_walkers, const rb3gpu_walker_t *walkers, int64_t *pos, int64_t acc2[RB3GPU_ASIZE+1]);
 
 /* Partial BWT of one batch on the GPU, instead of rb3_build_sais on the host (sais-ss.c:10-56; libsais in GSA

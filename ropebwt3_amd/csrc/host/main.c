@@ -377,8 +377,7 @@ static int process_raw_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 		ret = sent ? interval_merge(h, b->len, d_bwt, d_tw, n_sent, sent) : RB3GPU_ENOMEM;
 		free(sent);
 	} else if (ret == 0 && text_walk) {
-		if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) ret = RB3GPU_ENOMEM;
-		else if (b->step > 0) ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+		if (b->step > 0) ret = rb3gpu_merge_text_step_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, 0, b->n_seq, b->step, 1); /* long strings: the walker list (one per string, one every `step` positions) is made on the device */
 		else ret = rb3gpu_merge_text_dev(h, b->len, (const uint8_t*)d_bwt, (const uint64_t*)d_tw, b->n_seq, 0, 1); /* short strings: one walker per string */
 	} else if (ret == 0) ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)d_bwt, 1);
 	if (d_tw) rb3gpu_dev_free(h, d_tw);
@@ -393,7 +392,8 @@ static int process_batch(rb3gpu_t *h, batch_t *b, int *has_index)
 		const int first = !*has_index;
 		if (first) ret = rb3gpu_from_plain_dev(h, b->len, (const uint8_t*)b->d_bwt);
 		else if (g_iv.n > 1) ret = interval_merge(h, b->len, b->d_bwt, b->d_tw, b->n_sent, b->sent);
-		else if (b->walkers && b->d_tw) ret = rb3gpu_merge_text_sa_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, (const uint32_t*)b->d_sa, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1);
+		else if (b->walkers && b->d_tw) ret = rb3gpu_merge_text_sa_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, (const uint32_t*)b->d_sa, b->n_walkers, (const rb3gpu_walker_t*)b->walkers, 1); /* (RB3_HOST_WALKERS: the list of rounds 2-4, made by the sorter thread) */
+		else if (b->d_tw && b->step > 0 && b->n_seq > 0) ret = rb3gpu_merge_text_step_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, (const uint32_t*)b->d_sa, b->n_seq, b->step, 1); /* long strings: walker list made on the device */
 		else if (b->d_tw && b->step == 0 && b->n_seq > 0) ret = rb3gpu_merge_text_sa_dev(h, b->len, (const uint8_t*)b->d_bwt, (const uint64_t*)b->d_tw, (const uint32_t*)b->d_sa, b->n_seq, 0, 1); /* short strings: one walker per string */
 		else ret = rb3gpu_merge_plain_dev(h, b->len, (const uint8_t*)b->d_bwt, 1);
 		rb3gpu_sorter_release(b->gs, b->d_bwt);
@@ -491,9 +491,9 @@ static int sort_batch(const bopt_t *opt, int device, rb3h_buf_t *seq, int64_t n_
 			if (r2 == 0) {
 				if (rb3h_verbose >= 3)
 					fprintf(stderr, "[M::%s::%.3f*%.2f] constructed partial BWT for %ld symbols on the GPU\n", "main_build", rb3h_realtime(), rb3h_percent_cpu(), (long)b->len);
-				if (b->step > 0 && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0, b->d_tw = b->d_sa = 0;
+				if (b->step > 0 && getenv("RB3_HOST_WALKERS") && rb3h_walkers_text(b->len, b->bwt, b->step, &b->n_walkers, &b->walkers) < 0) b->walkers = 0, b->n_walkers = 0; /* (experiments: the host's list) */
 				walkers_pin(b);
-				b->gs = gs, b->raw = 0;
+				b->gs = gs, b->raw = 0; /* (the walker list of a batch of long strings is made on the device, inside the merge call: b->n_seq and b->step say how) */
 				if (opt->interval) b->sent = sentinels_of(b->bwt, b->len, n_seq, &b->n_sent);
 				__sync_fetch_and_add(&g_sorted.n_gpu, 1), __sync_fetch_and_add(&g_sorted.sym_gpu, b->len);
 				rb3h_batch_free(b->bwt); b->bwt = 0; /* the text is not needed any more */

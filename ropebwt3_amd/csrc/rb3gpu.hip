@@ -12,6 +12,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <algorithm>
 #include <utility>
 #include <stdio.h>
 #include <stdlib.h>
@@ -123,6 +124,7 @@ struct Tune {
 	int poison = 0;          // fill every new device buffer with 0xA5 bytes (debugging: nothing may rely on what fresh memory holds)
 	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
 	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
+	int sh_host_rounds = 0;  // rb3gpu_sh_merge with ONE interval: the host reads the split sizes back after every round, as with several (0: the rounds run back to back on the device)
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
 	int junction_check = 16; // ... and the LF relation at the junctions of the speculative walk (k_junction_check): wherever a walker met somebody's record -- all
 	                         // of them, always -- and at the drop-out events of every n-th stretch id (1: every event, ~10 ms per 152-genome build; 0: off)
@@ -180,6 +182,7 @@ struct rb3gpu_s {
 	unsigned long long lb_epoch = 0; // launches of k_scan_place so far (its look-back state is tagged with it instead of being cleared)
 	bool reb_pp_all = false; // the last rebuilds handed most groups on to the symbol path: skip the run-space tiers until most groups qualify (merge_core keeps it up to date)
 	int64_t reb_last[2] = {-1, -1}; // groups the first / the last tier of the run-space rebuild handed on in the merge before (-1: unknown)
+	int64_t mg_step = 0;             // > 0 (rb3gpu_merge_text_step_dev): no list, a count of strings: the walker list is made on the device, a walker every mg_step text positions
 	const uint32_t *mg_sa = nullptr; // the suffix array of the batch being merged, if its caller has it (rb3gpu_merge_text_sa_dev): records in text order
 	int tent_q = 1;          // masks of 256 * tent_q bits (merge_core doubles it when walkers report intervals wider than that)
 	int64_t sid_dirty[2] = {RB3_TENT_HALF, RB3_TENT_HALF}; // entries of the two halves of the stretch tables (dl) that may be non-zero
@@ -442,6 +445,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "guard")) t.guard = v != 0;
 	else if (!strcmp(key, "load_chunk")) t.load_chunk = v < 1 ? 1 : v;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
+	else if (!strcmp(key, "sh_host_rounds")) t.sh_host_rounds = v < 0 ? -1 : v != 0; // (-1: rounds on the device whatever the number of chains)
 	else if (!strcmp(key, "junction_check")) t.junction_check = v < 0 ? 0 : v > 4096 ? 4096 : (int)v;
 	else if (!strcmp(key, "corrupt_sfin") || !strcmp(key, "force_fallback") || !strcmp(key, "hide_first") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
 			!strcmp(key, "pos_limit") || !strcmp(key, "win_scratch") || !strcmp(key, "slot_bytes")) {
@@ -472,7 +476,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -1233,6 +1237,65 @@ __global__ void __launch_bounds__(256) k_walkers_per_string(Walker *wl, int64_t 
 	if (r < m2 && sentinel) { Walker w; w.row = t, w.ka0 = -2, w.nsteps = INT64_MAX / 2, w.flags = 0; wl[r] = w; }
 }
 
+/* The walker list of a batch of long strings, made on the device (VERDICT r4 "what's missing" 4: the host spent 70 ms of one core per 152-genome
+ * build on it, outside the timed region): one walker per string -- at its sentinel -- and one at every text position that is a multiple of `step`
+ * strictly inside a string, exactly the list of rb3h_walkers_text (host/sais.c:74-113: same pre-roll, same probe distance, the same rule for the
+ * multiple next to a sentinel).  Slot k - 1 of the list belongs to the multiple k * step (k = 1 .. K), slot K + j to the sentinel of string j; a
+ * multiple that gets no walker leaves its slot empty (row -1: k_chain passes over it).  The slots are in TEXT ORDER, as the host's list is -- the multiple
+ * p of a string behind j sentinels at slot p / step - 1 + j, the sentinel at e of string j at slot e / step + j --: octet i takes walker i first, so the
+ * walkers of a wave are neighbours in the text and run in lock step; with the sentinels' walkers at the end of the list instead, a build of 320 relatives
+ * with the masks pinned to 256 bits redid 5 of its merges where the host's list makes it redo 1 (same list, another order: tools/gpu_r5_exp8.sh).
+ * Pass 1: sent[j] = text position of the sentinel of string j (its row IS j: the suffixes that start at a sentinel sort first, in string order). */
+#define RB3_WL_PREROLL 32  /* = RB3H_PREROLL = RB3_TENT_MIN_AGE */
+#define RB3_WL_PROBE   64  /* = RB3H_PROBE */
+#define RB3_WL_MIN_SEG 128 /* = RB3H_MIN_SEG */
+__global__ void __launch_bounds__(256) k_wl_sentinels(const uint64_t *tw, int64_t n, int64_t m2, int64_t *sent)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	const bool sentinel = t + 1 == n || (tw[t + 1] & 7u) == 0; // the word after it says which symbol sits at t
+	const int64_t r = (int64_t)(tw[t] >> 3);
+	if (sentinel && r < m2) sent[r] = t;
+}
+
+/* Pass 2: the list.  sent[] came filled with -1: a string count that is not the batch's leaves entries there, and the walkers of those strings
+ * are not made (their rows stay unset: the merge reports EINVAL, as for a wrong count of the per-string list) */
+__global__ void __launch_bounds__(256) k_wl_make(const int64_t *sent, int64_t m2, int64_t n, int64_t step, int64_t K, Walker *wl)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= K + m2) return;
+	const int64_t INF = INT64_MAX / 2;
+	Walker w;
+	int64_t slot = -1;
+	w.row = -1, w.ka0 = -1, w.nsteps = 0, w.flags = 0;
+	if (i < K) { // the multiple p = (i + 1) * step: string [b, e) with sentinel e = the first sentinel at or behind p
+		const int64_t p = (i + 1) * step;
+		int64_t lo = 0, hi = m2; // first j with sent[j] >= p
+		while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sent[mid] >= p) hi = mid; else lo = mid + 1; }
+		slot = i + lo;
+		if (lo < m2 && p < n) {
+			const int64_t e = sent[lo], b = lo > 0 ? sent[lo - 1] + 1 : 0;
+			const bool ok = e >= 0 && (lo == 0 || sent[lo - 1] >= 0) && p > b && p < e && !(e - p < RB3_WL_MIN_SEG && e - p < step);
+			if (ok) {
+				const int64_t pre = e - 1 - p < RB3_WL_PREROLL ? e - 1 - p : RB3_WL_PREROLL;
+				w.row = p + pre, w.ka0 = -1, w.flags = pre << 8;
+				if (pre == RB3_WL_PREROLL && e - 1 - (p + pre) >= RB3_WL_PROBE) w.flags |= (int64_t)RB3_WL_PROBE << 16;
+				w.nsteps = p - step > b ? step + pre : INF; // (the multiple before it, if it lies inside the string, has a walker: it is further from the sentinel)
+			}
+		}
+	} else { // the sentinel of string j
+		const int64_t j = i - K, e = sent[j], b = j > 0 ? sent[j - 1] + 1 : 0;
+		if (e >= 0) slot = e / step + j;
+		if (e >= 0 && (j == 0 || sent[j - 1] >= 0)) {
+			int64_t q = e > 0 ? (e - 1) / step * step : 0; // the last multiple below e ... that has a walker
+			if (q > b && q < e && (e - q < RB3_WL_MIN_SEG && e - q < step)) q -= step;
+			w.row = e, w.ka0 = -2, w.flags = 0;
+			w.nsteps = q > b && q >= step ? e - q : INF;
+		}
+	}
+	if (slot >= 0 && slot < K + m2) wl[slot] = w; // (the list came filled with empty slots)
+}
+
 __global__ void __launch_bounds__(256) k_walkers_sentinel_rows(Walker *wl, int64_t m2)
 {
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1292,6 +1355,33 @@ static rb3gpu_walker_t *thin_walkers(int64_t n, const rb3gpu_walker_t *w, int th
 	return o;
 }
 
+/* the list of k_wl_sentinels / k_wl_make into wl (K + n_strings slots), queued on the handle's stream; scratch: n_strings words */
+static void step_list_launch(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *d_sent, Walker *wl)
+{
+	const int64_t K = len / step;
+	(void)hipMemsetAsync(d_sent, 0xff, (size_t)n_strings * 8, h->st);
+	(void)hipMemsetAsync(wl, 0xff, (size_t)(K + n_strings) * 32, h->st); // every slot empty (row -1)
+	hipLaunchKernelGGL(k_wl_sentinels, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, d_tw, len, n_strings, d_sent);
+	hipLaunchKernelGGL(k_wl_make, dim3((unsigned)((K + n_strings + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)d_sent, n_strings, len, step, K, wl);
+}
+
+/* ... and on the host, without its empty slots (the paths that walk row words, a merge that is redone: rare) */
+static int step_list_host(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *nw, rb3gpu_walker_t **out)
+{
+	const int64_t K = len / step, n = K + n_strings;
+	int r;
+	*out = nullptr, *nw = 0;
+	if ((r = buf_ensure(h, h->wl, (size_t)n * 40)) < 0 || (r = buf_ensure(h, h->xbuf, (size_t)n_strings * 8)) < 0) return r;
+	step_list_launch(h, len, d_tw, n_strings, step, (int64_t*)h->xbuf.p, (Walker*)h->wl.p);
+	rb3gpu_walker_t *w = (rb3gpu_walker_t*)malloc((size_t)n * sizeof(rb3gpu_walker_t));
+	if (!w) return RB3GPU_ENOMEM;
+	if (hipMemcpyAsync(w, h->wl.p, (size_t)n * 32, hipMemcpyDeviceToHost, h->st) != hipSuccess || hipStreamSynchronize(h->st) != hipSuccess) { free(w); return RB3GPU_ENODEV; }
+	int64_t m = 0;
+	for (int64_t i = 0; i < n; ++i) if (w[i].row >= 0) w[m++] = w[i];
+	*nw = m, *out = w;
+	return 0;
+}
+
 static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, int64_t *host_pos, int64_t *host_acc2, int rank_only,
 		int64_t n_walkers, const rb3gpu_walker_t *walkers, const uint64_t *d_tw, int thin)
 {
@@ -1300,8 +1390,12 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (h->n <= 0 || h->grp == nullptr) return RB3GPU_ESTATE;
 	garbage_collect(h, false); // (nothing of this merge is queued yet)
 	// no list but a count: one walker per string (n_walkers = number of strings), made on the device
-	const bool per_string = !walkers && n_walkers > 0;
-	if (d_tw && !walkers && !per_string) return RB3GPU_EINVAL;
+	// ... or a count and a spacing (rb3gpu_merge_text_step_dev): one walker per string and one every `wstep` text positions inside the strings, made on the device
+	const int64_t wstep = !walkers && d_tw && n_walkers > 0 && h->mg_step >= 2 ? h->mg_step : 0, n_strings = n_walkers;
+	const bool step_list = wstep > 0;
+	const bool per_string = !walkers && n_walkers > 0 && !step_list;
+	if (d_tw && !walkers && !per_string && !step_list) return RB3GPU_EINVAL;
+	if (step_list) n_walkers = len / wstep + n_strings; // slots of the list (some stay empty)
 	// neither (the reference's signature: BWT only): the list is made on the device from a sparse LF walk of the batch itself
 	const bool auto_list = !walkers && !per_string && !d_tw && h->tn.b2_split != 0 && h->opt.split_log2 == 0 && len >= 4096;
 	// Splitters every 2^S rows.  The ranking of the splitters is pointer jumping over all of them (13 rounds for 21 M): a small batch
@@ -1329,6 +1423,16 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const int tent_auto = tent;
 	if (per_string) tent = 0; // every walker is exact
 	// (the entries of a caller's list are checked by k_chain itself, by the octet that takes a walker: a host loop over 40 k entries took ~40 us with the chip idle)
+	if (step_list && tent && thin == 1 && n_walkers > 4096) { // (the same estimate for the list made on the device: a wider spacing from the start)
+		int t = 1;
+		while (t < 64 && events_at((double)wstep * t) > tent_room) t *= 2;
+		if (t > 1) {
+			h->stt.n_thinned += 1, h->mg_step = wstep * t;
+			const int r2 = merge_core(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_strings, nullptr, d_tw, t);
+			h->mg_step = wstep;
+			return r2;
+		}
+	}
 	if (walkers && tent && thin == 1 && n_walkers > 4096) { // (the same estimate for a list the caller made: every t-th walker from the start)
 		int t = 1;
 		while (t < 64 && events_at((double)len / (double)n_walkers * t) > tent_room) t *= 2;
@@ -1342,8 +1446,16 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			return r2;
 		}
 	}
-	if ((!walkers && !per_string && !auto_list) || n_walkers > (1 << 24) || n_walkers > len || ntot >= lim_pos(h) || (size_t)nwin * sizeof(rb3_slot_t) > lim_slot_bytes(h) || h->tn.staged) {
+	if ((!walkers && !per_string && !auto_list && !step_list) || n_walkers > (1 << 24) || n_walkers > len || ntot >= lim_pos(h) || (size_t)nwin * sizeof(rb3_slot_t) > lim_slot_bytes(h) || h->tn.staged) {
 		if (per_string) return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, tent_auto);
+		if (step_list) { // (the staged paths take a list from the host)
+			rb3gpu_walker_t *hw = nullptr;
+			int64_t nhw = 0;
+			int r0 = step_list_host(h, len, d_tw, n_strings, wstep, &nhw, &hw);
+			if (r0 == 0) r0 = merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, nhw, hw, d_tw, tent);
+			free(hw);
+			return r0;
+		}
 		if (d_tw) return merge_staged_text(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, d_tw, tent);
 		return merge_staged(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_walkers, walkers, tent);
 	}
@@ -1354,6 +1466,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	if (auto_list && (r = buf_ensure(h, h->xbuf, ((size_t)b2_nspmax * 4 + (size_t)b2_m2cap + 2 + (size_t)b2_nbk) * 8)) < 0) return r;
+	if (step_list && (r = buf_ensure(h, h->dlx, (size_t)n_strings * 8)) < 0) return r; // the sentinels' text positions (k_wl_sentinels)
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
 #ifdef RB3GPU_TEST_HOOKS
@@ -1439,6 +1552,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		hipLaunchKernelGGL(k_b2_pick, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], (const uint64_t*)slen, bucket, b2W);
 		hipLaunchKernelGGL(k_b2_list, dim3((unsigned)((n_walkers + 255) / 256 < 2048 ? (n_walkers + 255) / 256 : 2048)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode,
 				(const uint64_t*)lnk[cur], (const uint64_t*)slen, (const unsigned long long*)bucket, b2_nbk, (Walker*)h->wl.p, b2_nwalk, (const int64_t*)h->pos.p, b2W);
+	} else if (step_list) { // one walker per string and one every wstep text positions, made here (two small kernels in front of the walkers)
+		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->dlx.p, (Walker*)h->wl.p);
 	} else if (per_string && d_tw) {
 		HIPCHK(hipMemsetAsync(h->wl.p, 0xff, (size_t)n_walkers * 32, h->st)); // a walker that nobody fills in starts at row -1: caught below
 		hipLaunchKernelGGL(k_walkers_per_string, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw, len);
@@ -1630,6 +1745,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	for (int a = 0; a < 6; ++a) acc2[a + 1] = acc2[a] + (int64_t)hm[MISC_LF_TOT + a];
 	if (acc2[1] <= 0) return RB3GPU_EINVAL; // a batch always ends with a sentinel
 	if (per_string && acc2[1] != n_walkers) return RB3GPU_EINVAL; // not the number of strings of this batch (nothing was installed)
+	if (step_list && acc2[1] != n_strings) return RB3GPU_EINVAL;
 	if (hm[MISC_BAD_WALKERS] != 0) return RB3GPU_EINVAL; // not a walker list for this batch (k_chain skipped those entries; nothing was installed)
 #ifdef RB3_DEBUG_B2
 	if (auto_list) { // kernel experiment: what the device-made list looks like
@@ -1734,7 +1850,21 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 			free(w2);
 			return r;
 		}
+		if (step_list) { // the list made on the device: eight times the spacing
+			h->mg_step = wstep * 8;
+			r = merge_core(h, len, d_b2, commit, host_pos, host_acc2, rank_only, n_strings, nullptr, d_tw, thin * 8);
+			h->mg_step = wstep;
+			return r;
+		}
 		return merge_core(h, len, d_b2, commit, host_pos, host_acc2, rank_only, 0, nullptr, d_tw, thin * 8);
+	}
+	// (the paths below walk row words and take their list from the host: the one made on the device is fetched)
+	rb3gpu_walker_t *hw_step = nullptr;
+	struct FreeHw { rb3gpu_walker_t **p; ~FreeHw() { free(*p); } } free_hw = { &hw_step };
+	if (step_list && tent && (hm[4] != 0 || hm[2] != 0 || hm[3] != 0 || hm[MISC_LF_CHK + 1] != 0)) {
+		int64_t nhw = 0;
+		if ((r = step_list_host(h, len, d_tw, n_strings, wstep, &nhw, &hw_step)) < 0) return r;
+		walkers = hw_step, n_walkers = nhw;
 	}
 	if (tent && (hm[4] != 0 || hm[2] != 0 || hm[3] != 0)) { // the optimistic pass did not validate (records unsettled, or rows nobody reached): nothing was installed, redo without tentative records
 		h->stt.n_fallbacks += 1;
@@ -1956,6 +2086,26 @@ int rb3gpu_merge_text_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const 
 	if (!h || len <= 0 || !d_bwt || !d_tw || n_walkers <= 0) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_walkers, walkers, d_tw);
+}
+
+/* ... with the walker list made on the device: n_strings strings, a walker at every sentinel and at every multiple of `step` inside a string (the list of
+ * rb3h_walkers_text, host/sais.c:74-113; step from rb3gpu_walker_step).  d_sa: NULL, or the suffix array as for rb3gpu_merge_text_sa_dev. */
+int rb3gpu_merge_text_step_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, const uint32_t *d_sa, int64_t n_strings, int64_t step, int commit)
+{
+	if (!h || len <= 0 || !d_bwt || !d_tw || n_strings <= 0 || n_strings > len || step < 2) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	h->mg_sa = d_sa, h->mg_step = step;
+	const int r = merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, n_strings, nullptr, d_tw);
+	h->mg_sa = nullptr, h->mg_step = 0;
+	return r;
+}
+
+/* the list rb3gpu_merge_text_step_dev walks, copied to the host without its empty slots (tests; *walkers is malloc'ed: rb3gpu_host_free) */
+int rb3gpu_walkers_step_dev(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *n_walkers, rb3gpu_walker_t **walkers)
+{
+	if (!h || len <= 0 || !d_tw || n_strings <= 0 || n_strings > len || step < 2 || !n_walkers || !walkers) return RB3GPU_EINVAL;
+	HIPCHK(hipSetDevice(h->dev));
+	return step_list_host(h, len, d_tw, n_strings, step, n_walkers, walkers);
 }
 
 int rb3gpu_merge_text_sa_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw, const uint32_t *d_sa, int64_t n_walkers, const rb3gpu_walker_t *walkers, int commit)
@@ -3023,9 +3173,15 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 	// two state buffers for the whole merge (a rank never holds more states than there are strings), counters of both parities + bad
 	if ((r = buf_ensure(h, h->shc, (size_t)n_chains * 16)) < 0) return r;
 	if ((r = buf_ensure(h, h->shn, (size_t)n_chains * 16)) < 0) return r;
-	if ((r = buf_ensure(h, h->shk, (size_t)(2 * (RB3_SH_MAXIV + 1) + 1) * 8)) < 0) return r;
-	unsigned long long *d_cnt[2] = { (unsigned long long*)h->shk.p, (unsigned long long*)h->shk.p + RB3_SH_MAXIV + 1 }, *d_bad = (unsigned long long*)h->shk.p + 2 * (RB3_SH_MAXIV + 1);
-	HIPCHK(hipMemsetAsync(h->shk.p, 0, (size_t)(2 * (RB3_SH_MAXIV + 1) + 1) * 8, h->st));
+	// three sets of counters (two for the rounds the host drives, three for the rounds that run back to back) + bad, 1 KB apart: a round that reads its
+	// number of states from the set before while every block adds to its own set must not find the two in one cache line (with the sets 72 bytes apart every
+	// block's first load queued behind the atomics of its own launch: 247 us per round of 2 M chains instead of 156)
+#define RB3_SH_CNT_STRIDE 128
+#define RB3_SH_CNT_WORDS (4 * RB3_SH_CNT_STRIDE)
+	static_assert(RB3_SH_CNT_STRIDE >= RB3_SH_MAXIV + 1, "a set of counters per KB");
+	if ((r = buf_ensure(h, h->shk, (size_t)RB3_SH_CNT_WORDS * 8)) < 0) return r;
+	unsigned long long *d_cnt[3] = { (unsigned long long*)h->shk.p, (unsigned long long*)h->shk.p + RB3_SH_CNT_STRIDE, (unsigned long long*)h->shk.p + 2 * RB3_SH_CNT_STRIDE }, *d_bad = (unsigned long long*)h->shk.p + 3 * RB3_SH_CNT_STRIDE;
+	HIPCHK(hipMemsetAsync(h->shk.p, 0, (size_t)RB3_SH_CNT_WORDS * 8, h->st));
 	ShState *cur = (ShState*)h->shc.p, *nxt = (ShState*)h->shn.p;
 	int64_t n_cur = 0;
 	if (rank == owner0) {
@@ -3044,6 +3200,48 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 	int par = 0;
 	bool dirty[2] = { false, false };
 	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	// ONE interval (a build on one GPU through this path, the N = 1 point of the scaling curve): nobody needs the split sizes between the rounds,
+	// so the rounds are queued back to back -- each takes its number of states from the counter the round before left on the device -- and the
+	// host looks at the result once, at the end (45 us per round of 200 k chains were mostly the read-back and the synchronisation)
+	// (up to 2^19 chains: behind larger rounds the device idles ~50 ns per chain between two kernels that follow each other without the host in
+	// between -- the kernels themselves take the same time, rocprofv3: 148.5 against 147.8 us at 2 M chains --, more than the read-back costs)
+	if (world == 1 && h->tn.sh_host_rounds <= 0 && (n_chains <= ((int64_t)1 << 19) || h->tn.sh_host_rounds < 0)) {
+		int64_t longest = 0; // rounds = symbols of the longest string, its sentinel included
+		{
+			std::vector<int64_t> tp(chain_tp, chain_tp + n_chains);
+			std::sort(tp.begin(), tp.end());
+			int64_t prev = -1;
+			for (int64_t i = 0; i < n_chains; ++i) { if (tp[(size_t)i] - prev > longest) longest = tp[(size_t)i] - prev; prev = tp[(size_t)i]; }
+		}
+		if ((r = buf_ensure(h, h->shr, (size_t)len * 16)) < 0) return r;
+		if ((r = buf_ensure(h, h->xbuf, (size_t)(longest + 3) * 8)) < 0) return r;
+		unsigned long long *rb = (unsigned long long*)h->xbuf.p;
+		HIPCHK(hipMemsetAsync(rb, 0, 8, h->st));
+		// three sets of counters in turn: round k adds to set k % 3, takes its number of states from set (k - 1) % 3 (what the round before counted for
+		// interval 0) and clears set (k + 1) % 3 for the round behind it -- three different sets, so no block reads a word another block of the same launch clears
+		{ const unsigned long long n0 = (unsigned long long)n_chains; HIPCHK(hipMemcpyAsync(d_cnt[2], &n0, 8, hipMemcpyHostToDevice, h->st)); HIPCHK(hipStreamSynchronize(h->st)); } // "the round before" of round 0 (n0 lives on this stack)
+		const int S = n_chains >= ((int64_t)1 << 19) ? 8 : n_chains >= ((int64_t)1 << 17) ? 4 : n_chains >= ((int64_t)1 << 15) ? 2 : 1;
+		const unsigned nblk = (unsigned)((n_chains + 32 * S - 1) / (32 * S));
+		ShState *sa = cur, *sb = nxt;
+		for (int64_t k = 0; k < longest; ++k) {
+			unsigned long long *c_add = d_cnt[k % 3], *c_n = d_cnt[(k + 2) % 3], *c_clr = d_cnt[(k + 1) % 3];
+#define RB3_SH_ROUND1(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_chains, (const ShState*)sa, d_tw, (ShRec*)h->shr.p, sb, n_chains, c_add, c_clr, d_bad, d_tprev, (const unsigned long long*)c_n, rb + k)
+			if (S == 8) RB3_SH_ROUND1(8); else if (S == 4) RB3_SH_ROUND1(4); else if (S == 2) RB3_SH_ROUND1(2); else RB3_SH_ROUND1(1);
+#undef RB3_SH_ROUND1
+			ShState *t = sa; sa = sb, sb = t;
+		}
+		unsigned long long fin[3] = {0, 0, 0};
+		HIPCHK(hipMemcpyAsync(&fin[0], rb + longest, 8, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipMemcpyAsync(&fin[1], d_cnt[(longest + 2) % 3], 8, hipMemcpyDeviceToHost, h->st)); // states left after the last round: none
+		HIPCHK(hipMemcpyAsync(&fin[2], d_bad, 8, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+		if (fin[2] != 0 || fin[1] != 0 || (int64_t)fin[0] != len) {
+			if (h->opt.verbose >= 1) fprintf(stderr, "[E::rb3gpu] sharded merge (one interval, %lld rounds on the device): %llu of %lld rows recorded, %llu states left, %llu misrouted\n", (long long)longest, fin[0], (long long)len, fin[1], fin[2]);
+			return RB3GPU_EINTERNAL;
+		}
+		rows = len, rounds = longest;
+		h->stt.n_lf_steps += len, h->stt.n_rank_launches += longest;
+	} else
 	for (;;) {
 		for (int i = 0; i < world; ++i) cnt_h[i] = 0;
 		if (n_cur > 0) {
@@ -3115,8 +3313,8 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 		if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 		unsigned long long *misc = (unsigned long long*)h->misc.p;
 		HIPCHK(hipMemsetAsync(misc, 0, 128, h->st));
-		unsigned long long *d_oc = (unsigned long long*)h->shk.p, *d_cur = d_oc + RB3_SH_MAXIV + 1; // (the counters of the rounds: done with)
-		HIPCHK(hipMemsetAsync(h->shk.p, 0, (size_t)(2 * (RB3_SH_MAXIV + 1) + 1) * 8, h->st));
+		unsigned long long *d_oc = (unsigned long long*)h->shk.p, *d_cur = d_oc + RB3_SH_CNT_STRIDE; // (the counters of the rounds: done with)
+		HIPCHK(hipMemsetAsync(h->shk.p, 0, (size_t)RB3_SH_CNT_WORDS * 8, h->st));
 		std::vector<int64_t> scnt(world, 0), rcnt(world, 0), M2((size_t)world * world);
 		if (rows > 0) {
 			hipLaunchKernelGGL(k_sh_owner_count, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->st, rows, (const ShRec*)h->shr.p, tb, d_oc, misc + 2);

@@ -661,7 +661,11 @@ __device__ __forceinline__ void st_pos(int64_t *p, int64_t v)
 {
 	// written through (sc1: the other XCDs' walkers must find it in memory) and streaming (nt: the line does not stay in this XCD's L2 -- a record
 	// is looked at once or never, and the 70 MB of records of a merge pushed the index's slots out of the L2s: k_chain 0.62 -> 0.58-0.60 ms per launch)
+#ifdef RB3_EXP_NO_RECNT /* kernel experiment: the store of rounds 1-4 */
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
 	asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+#endif
 }
 
 /* rank with the symbol known before the loads are issued: every lane of the octet fetches the one
@@ -4112,11 +4116,25 @@ struct ShRec { int64_t kb, ka; };
  * (text position, insertion point) and the row is looked up at the end, by the rank that holds that part of the inverse suffix array. */
 template<int S>
 __global__ void __launch_bounds__(256) k_sh_round(IdxView ix, ShArgs a, int64_t n, const ShState *in, const uint64_t *tw, ShRec *rec,
-		ShState *send, int64_t stride, unsigned long long *cnt, unsigned long long *cnt_next, unsigned long long *bad, const uint8_t *tprev = nullptr)
+		ShState *send, int64_t stride, unsigned long long *cnt, unsigned long long *cnt_next, unsigned long long *bad, const uint8_t *tprev = nullptr,
+		const unsigned long long *n_dev = nullptr, unsigned long long *rowbase = nullptr)
 {
+	// n_dev, rowbase (ONE interval: the rounds run back to back, nothing goes to the host between them): the number of states of this round is what
+	// the round before counted for interval 0 (*n_dev; `n` is then only an upper bound that sized the grid), its records go behind those of the
+	// rounds before (rowbase[0]), and block 0 leaves the base of the next round in rowbase[1]
 	__shared__ uint32_t lc[RB3_SH_MAXIV + 1];
 	__shared__ unsigned long long lb[RB3_SH_MAXIV + 1];
 	const int j = threadIdx.x & 7;
+	if (n_dev != nullptr) { // (ONE thread of the block fetches the two words: a million threads asking for the same line kept its L2 channel busy for longer than the round's work)
+		__shared__ unsigned long long nb[2];
+		if (threadIdx.x == 0) nb[0] = *n_dev, nb[1] = rowbase[0];
+		__syncthreads();
+		const int64_t nd = (int64_t)nb[0];
+		n = nd < n ? nd : n;
+		rec += nb[1];
+		if (blockIdx.x == 0 && threadIdx.x == 0) rowbase[1] = nb[1] + (unsigned long long)n;
+		if ((int64_t)blockIdx.x * 32 * S >= n && blockIdx.x != 0) return; // (block 0 stays: it clears the counters of the next round)
+	}
 	if (blockIdx.x == 0 && threadIdx.x <= RB3_SH_MAXIV) cnt_next[threadIdx.x] = 0ull;
 	for (int i = threadIdx.x; i <= a.n_iv; i += blockDim.x) lc[i] = 0u;
 	__syncthreads();

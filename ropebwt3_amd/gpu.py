@@ -122,6 +122,8 @@ SYMBOLS = {
     "rb3gpu_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rb3gpu_rccl_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_rccl_comm_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_merge_text_step_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
+    "rb3gpu_walkers_step_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_shard_split": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_shard_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_shard_gather": (ctypes.c_int, [ctypes.c_void_p]),
@@ -451,6 +453,18 @@ class Rb3Gpu:
             return
         w = self._walkers(walkers)
         self._chk(self._lib.rb3gpu_merge_text_sa_dev(self._h, length, d_bwt, d_tw, d_sa, w.shape[0], w.ctypes.data, 1 if commit else 0), "rb3gpu_merge_text_sa_dev")
+
+    def merge_text_step_dev(self, d_bwt, d_tw, length, n_strings, step, commit=True, d_sa=None):
+        """rb3gpu_merge_text_step_dev: the walker list made on the device (a walker per string and one every `step` text positions)"""
+        self._chk(self._lib.rb3gpu_merge_text_step_dev(self._h, int(length), d_bwt, d_tw, d_sa, int(n_strings), int(step), 1 if commit else 0), "rb3gpu_merge_text_step_dev")
+
+    def walkers_step_dev(self, d_tw, length, n_strings, step):
+        """the walker list rb3gpu_merge_text_step_dev makes on the device, as an (n, 4) int64 array (row = text position, ka0, nsteps, flags)"""
+        n, p = ctypes.c_int64(0), ctypes.c_void_p()
+        self._chk(self._lib.rb3gpu_walkers_step_dev(self._h, int(length), d_tw, int(n_strings), int(step), ctypes.byref(n), ctypes.byref(p)), "rb3gpu_walkers_step_dev")
+        w = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int64)), shape=(n.value, 4)).copy()
+        self._lib.rb3gpu_host_free(p)
+        return w
 
     def mg_rank_text_dev(self, d_bwt, d_tw, length, walkers):
         pos = np.empty(length, dtype=np.int64)

@@ -1586,6 +1586,39 @@ def test_lf_consistency_check_finds_a_wrong_but_monotone_pos(oracle):
     h.close()
 
 
+def test_walker_list_made_on_the_device(oracle):
+    """rb3gpu_merge_text_step_dev: the walker list of a batch of long strings made by two kernels in front of the walk (VERDICT r4 "missing" 4) is the
+    list of rb3h_walkers_text entry for entry -- strings of every length around the spacing, a string shorter than the pre-roll, multiples that fall on
+    sentinels and next to them --, a merge through it gives the oracle's index, and a wrong string count is an error, not a wrong index."""
+    from ropebwt3_amd import Rb3Gpu, Rb3GpuError, host
+    rng = np.random.default_rng(77)
+    g0 = util.random_genome(rng, 50000)
+    b1 = host.build_bwt(util.make_text([g0, util.mutate(rng, g0, 0.01)]))
+    h = Rb3Gpu(verbose=1)
+    try:
+        for step in (64, 100, 256, 1000):
+            lens = [1, 2, 31, 32, 33, step - 1, step, step + 1, 2 * step, 2 * step + 127, 2 * step + 129, 3 * step - 1, 5000, 12345, 7]
+            seqs = [util.mutate(rng, g0, 0.003)[o:o + l] for o, l in zip(rng.integers(0, 30000, size=len(lens)), lens)]
+            t2 = util.make_text(seqs)
+            n_str = int((t2 == 0).sum())
+            d, dtw = h.sort_text(t2)
+            wd = h.walkers_step_dev(dtw, t2.size, n_str, step)
+            wh = np.asarray(host.walkers_text(t2, step)).reshape(-1, 4)
+            assert wd.shape == wh.shape, (step, wd.shape, wh.shape)
+            assert np.array_equal(wd, wh), step      # entry for entry, in text order
+            want = oracle.merge(b1, host.build_bwt(t2.copy()))
+            h.from_plain(b1)
+            h.merge_text_step_dev(d, dtw, t2.size, n_str, step)
+            assert np.array_equal(h.export_plain(), want), step
+            h.from_plain(b1)
+            with pytest.raises(Rb3GpuError):
+                h.merge_text_step_dev(d, dtw, t2.size, n_str - 1, step)
+            assert np.array_equal(h.export_plain(), b1)      # nothing was installed
+            h.dev_free(d), h.dev_free(dtw)
+    finally:
+        h.close()
+
+
 def test_junction_check_catches_one_wrong_stretch_every_time(oracle):
     """the deterministic part of the validation (k_junction_check): the LF relation at EVERY junction of the
     speculative walk -- where a walker met somebody's record, and at every drop-out event -- on every merge.  A test hook gives ONE

@@ -60,7 +60,7 @@ def gen_genomes(n, rate, seed0, seeds):
 
 def load_pmc_traffic(kernel):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/), if any."""
-    for fn in ("r4_pmc_%s.json" % kernel, "r3_pmc_%s.json" % kernel, "r2_pmc_%s.json" % kernel, "r1_pmc_%s.json" % kernel):
+    for fn in ("r5_pmc_%s.json" % kernel, "r4_pmc_%s.json" % kernel, "r3_pmc_%s.json" % kernel, "r2_pmc_%s.json" % kernel, "r1_pmc_%s.json" % kernel):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", fn))).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
@@ -606,7 +606,7 @@ def main():
                 "ms_per_step_with_nothing_beside_it": None if h2d_serial is None else round(h2d_serial * 1e3, 3)},
         "roofline": chain_roofline(int(rows_launch), ms_chain, "text", load_pmc_traffic("k_chain_mtb152"),
                                    "k_chain<list,mixed,tent,text>: average over the %d launches of the timed steps (run-coded index, intervals of up to %d matching suffixes); `achieved` prices SURVEY 8(d)'s 208 B per LF step over the kernel's HIP-event time; "
-                                   "traffic = FETCH_SIZE/WRITE_SIZE of the committed --pmc passes (profiles/r4_pmc_k_chain_mtb152.json); the index (<= %.0f MB) sits in L2 + Infinity Cache, so this kernel is bound by latency and instruction issue, not by HBM (aux_large_index is the HBM-resident case)" % (st["n_rank_launches"], K - 1, st["bytes_index"] / 1e6)),
+                                   "traffic = FETCH_SIZE/WRITE_SIZE of the committed --pmc passes (profiles/r5_pmc_k_chain_mtb152.json); the index (<= %.0f MB) sits in L2 + Infinity Cache, so this kernel is bound by latency and instruction issue, not by HBM (aux_large_index is the HBM-resident case)" % (st["n_rank_launches"], K - 1, st["bytes_index"] / 1e6)),
         "roofline_path": {"bound": "hbm", "formula": "SURVEY 8(d): (217 B x symbols merged + bytes(B1 old) + bytes(B1 new) per round) / merge-path seconds / 8 TB/s", "algorithmic_bytes_per_step": int(path_bytes // S),
                           "achieved": round(path_bytes / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_bytes / dt / 1e9 / HBM_PEAK_GBS, 5)},
         "roofline_rebuild": {"bound": "hbm", "kernel": "k_reb_group + k_place (+ window kernels on what they hand on)", "algorithmic_bytes_per_step": int(st["bytes_rebuild"] // S), "ms_per_step": round(st["ms_build"] / S, 3),

@@ -9,7 +9,7 @@
  *
  * SA-IS is SEQUENTIAL.  With n_threads >= 4 (rb3_build_sais(n_seq, len, seq, n_threads): libsais + OpenMP, sais-ss.c:15-22) the batch
  * goes to the parallel prefix-doubling sorter of psort.c first; SA-IS takes what that one declines (small batches, a batch of long
- * repeats, no memory for its 25 bytes per symbol).  The default path does not come here at all: batches are cut to fit the GPU
+ * repeats, no room for its ~37 bytes per symbol, ~73 with 64-bit positions: checked against the available memory up front).  The default path does not come here at all: batches are cut to fit the GPU
  * sorter (main.c); this is for `--host-sort`, for a record of 2^31 symbols or more, and for a device without room.
  */
 #include <stdint.h>

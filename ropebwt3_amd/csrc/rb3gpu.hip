@@ -1258,6 +1258,13 @@ __global__ void __launch_bounds__(256) k_wl_sentinels(const uint64_t *tw, int64_
 	if (sentinel && r < m2) sent[r] = t;
 }
 
+/* ... or, where the caller has the batch's suffix array: the sentinels' suffixes are rows 0 .. m2-1, so sent[j] = sa[j] (m2 loads instead of a pass over the words) */
+__global__ void __launch_bounds__(256) k_wl_sentinels_sa(const uint32_t *sa, int64_t n, int64_t m2, int64_t *sent)
+{
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < m2) sent[j] = sa[j] < (uint32_t)n ? (int64_t)sa[j] : -1;
+}
+
 /* Pass 2: the list.  sent[] came filled with -1: a string count that is not the batch's leaves entries there, and the walkers of those strings
  * are not made (their rows stay unset: the merge reports EINVAL, as for a wrong count of the per-string list) */
 __global__ void __launch_bounds__(256) k_wl_make(const int64_t *sent, int64_t m2, int64_t n, int64_t step, int64_t K, Walker *wl)
@@ -1359,9 +1366,13 @@ static rb3gpu_walker_t *thin_walkers(int64_t n, const rb3gpu_walker_t *w, int th
 static void step_list_launch(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *d_sent, Walker *wl)
 {
 	const int64_t K = len / step;
-	(void)hipMemsetAsync(d_sent, 0xff, (size_t)n_strings * 8, h->st);
 	(void)hipMemsetAsync(wl, 0xff, (size_t)(K + n_strings) * 32, h->st); // every slot empty (row -1)
-	hipLaunchKernelGGL(k_wl_sentinels, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, d_tw, len, n_strings, d_sent);
+	if (h->mg_sa != nullptr && len < (1LL << 32)) // (a wrong string count: sa[j] of a j that is no sentinel's row is a position whose next word does not start a string -- k_wl_make's
+		hipLaunchKernelGGL(k_wl_sentinels_sa, dim3((unsigned)((n_strings + 255) / 256)), dim3(256), 0, h->st, h->mg_sa, len, n_strings, d_sent); // binary search then meets unsorted positions; the merge's own count of the sentinels decides)
+	else {
+		(void)hipMemsetAsync(d_sent, 0xff, (size_t)n_strings * 8, h->st);
+		hipLaunchKernelGGL(k_wl_sentinels, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, d_tw, len, n_strings, d_sent);
+	}
 	hipLaunchKernelGGL(k_wl_make, dim3((unsigned)((K + n_strings + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)d_sent, n_strings, len, step, K, wl);
 }
 

@@ -1204,7 +1204,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					if (!I32 && !b1.abs) rl.gc = b1.grp64[g * 8 + c]; // (headers relative to the group: an index of 2^32 symbols or more)
 					const int64_t tpn = I32 ? (int64_t)((uint32_t)tp - 1u) : tp - 1; // (c != 0: there is a symbol before this one, so tp >= 1)
 					uint64_t xn;                                      // the word after next
-					if (I32) xn = *(const uint64_t*)((const char*)tw + (((uint32_t)tp >= 2u ? (uint32_t)tp - 2u : 0u) << 3)); // (read as a stream -- nt -- it was 8 % SLOWER: the L1 no longer serves the 15 steps that share a line)
+					if (I32) xn = *(const uint64_t*)((const char*)tw + (((uint32_t)tp >= 2u ? (uint32_t)tp - 2u : 0u) << 3)); // (read as a stream -- nt -- it was 8 % SLOWER: the L1 no longer serves the 15 steps that share a line; one 64-byte request per octet and eight steps, handed out by ds_bpermute as TEXT = 2 does: 33 % slower, profiles/r5_ab_text_words_block.txt)
 					else xn = tw[tpn > 0 ? tpn - 1 : 0];
 					const int64_t kbn = I32 ? (int64_t)((uint32_t)x1 >> 3) : (int64_t)(x1 >> 3);
 					rl.koff = (uint32_t)lo & (RB3_GRP - 1);
@@ -1317,15 +1317,9 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 							ns = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 						}
 						if (j == 0 && ns != RB3_TENT_POISON) {
-#ifdef RB3_EXP_EVNT /* kernel experiment: the event record written as a stream */
-							__builtin_nontemporal_store(RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), &tab[ns].w0), __builtin_nontemporal_store(kq | (uint64_t)c << 16 | (uint64_t)tp << RB3_EV_TP_SHIFT, &tab[ns].w1);
-							__builtin_nontemporal_store((uint32_t)sid0 + 1u, &tab[ns].pad[0]);
-							__builtin_nontemporal_store(ns + 1, &tab[sid].child);
-#else
 							tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = kq | (uint64_t)c << 16 | (uint64_t)tp << RB3_EV_TP_SHIFT;
 							tab[ns].pad[0] = (uint32_t)sid0 + 1u;
 							tab[sid].child = ns + 1;
-#endif
 						}
 						sid = ns;
 					}

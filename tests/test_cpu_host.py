@@ -371,3 +371,6 @@ def test_parallel_host_sorter_equals_sais(monkeypatch):
     monkeypatch.setenv("RB3H_PSORT_FORCE64", "1")   # the instantiation for batches of 2^32 symbols and more, on a small one
     for t in cases[:3]:
         assert np.array_equal(host.build_bwt(t, 1), host.build_bwt(t, 4))
+    monkeypatch.delenv("RB3H_PSORT_FORCE64")
+    monkeypatch.setenv("RB3H_PSORT_MEM_LIMIT", "1000000")   # less memory than the parallel sorter needs: it declines BEFORE allocating, SA-IS takes the batch
+    assert np.array_equal(host.build_bwt(cases[0], 1), host.build_bwt(cases[0], 4))

@@ -26,5 +26,5 @@ if [ "$WHAT" = all ] || [ "$WHAT" = multi ]; then
 	timeout 600 python bench.py --gpus 2 --steps 1 --warmup 0 --mtb 24 > gpurun_out/bench_n2_mtb24.json 2> gpurun_out/bench_n2_mtb24.err; echo "bench --gpus 2 rc=$?"; tail -5 gpurun_out/bench_n2_mtb24.err; cat gpurun_out/bench_n2_mtb24.json | cut -c1-1500
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = prof ]; then
-	bash tools/prof_bench.sh r3_mtb152 --only headline --steps 1 --warmup 1
+	bash tools/prof_bench.sh r5_mtb152 --only headline --steps 1 --warmup 1
 fi

@@ -403,6 +403,10 @@ int rb3gpu_shard_get_acc(const rb3gpu_shard_t *s, int64_t acc[RB3GPU_ASIZE + 1])
 int rb3gpu_shard_export_runs(rb3gpu_shard_t *s, rb3gpu_emit_f emit, void *data);
 int rb3gpu_shard_export_run_words(rb3gpu_shard_t *s, rb3gpu_emit_words_f emit, void *data);
 void rb3gpu_shard_destroy(rb3gpu_shard_t *s);
+/* bounds moved to where equal shares of the block array's BYTES lie, if the largest interval holds more than pct per cent more than the mean (pct < 0:
+ * always), every interval rebuilt from its new range on its own device; called by rb3gpu_shard_merge after every batch with pct = 25 (SURVEY 8(e);
+ * RB3GPU_SHARD_REBALANCE_PCT overrides, -1 = never).  1: rebalanced, 0: not needed, < 0: error */
+int rb3gpu_shard_rebalance(rb3gpu_shard_t *s, int pct);
 rb3gpu_t *rb3gpu_shard_handle(rb3gpu_shard_t *s, int i);
 int rb3gpu_shard_bounds(const rb3gpu_shard_t *s, int64_t *bounds);
 

@@ -1246,7 +1246,7 @@ __global__ void __launch_bounds__(256) k_walkers_per_string(Walker *wl, int64_t 
  * walkers of a wave are neighbours in the text and run in lock step; with the sentinels' walkers at the end of the list instead, a build of 320 relatives
  * with the masks pinned to 256 bits redid 5 of its merges where the host's list makes it redo 1 (same list, another order: tools/gpu_r5_exp8.sh).
  * Pass 1: sent[j] = text position of the sentinel of string j (its row IS j: the suffixes that start at a sentinel sort first, in string order). */
-#define RB3_WL_PREROLL 32  /* = RB3H_PREROLL = RB3_TENT_MIN_AGE */
+#define RB3_WL_PREROLL ((int64_t)RB3_TENT_MIN_AGE) /* = RB3H_PREROLL: a walker starts as many positions to the right of its segment as it must be old to record */
 #define RB3_WL_PROBE   64  /* = RB3H_PROBE */
 #define RB3_WL_MIN_SEG 128 /* = RB3H_MIN_SEG */
 __global__ void __launch_bounds__(256) k_wl_sentinels(const uint64_t *tw, int64_t n, int64_t m2, int64_t *sent)

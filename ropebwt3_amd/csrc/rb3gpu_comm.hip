@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <vector>
 #include "rb3gpu.h"
 
 /* ---- ranks as threads of one process ---- */
@@ -337,6 +338,7 @@ struct rb3gpu_shard_s {
 	pthread_cond_t cv;
 	unsigned long gen = 0;
 	int done = 0, quit = 0, n_threads = 0;
+	int n_rebalanced = 0;
 	ShardJob job[RB3GPU_SH_MAXIV];
 };
 
@@ -530,8 +532,87 @@ int rb3gpu_shard_merge(rb3gpu_shard_t *s, int64_t len, const uint8_t *d_bwt, con
 	if (r == 0) {
 		memcpy(s->bounds, s->job[0].bounds, sizeof(s->bounds));
 		if (n_rounds) *n_rounds = s->job[0].rounds;
+		const char *e = getenv("RB3GPU_SHARD_REBALANCE_PCT"); // (25: SURVEY 8(e); -1: never; 0: whenever the shares differ at all -- tests)
+		const int pct = e && *e ? atoi(e) : 25;
+		if (pct >= 0 && s->n > 1) {
+			const int rr = rb3gpu_shard_rebalance(s, pct);
+			if (rr < 0) r = rr;
+			else s->n_rebalanced += rr;
+		}
 	}
 	return r;
+}
+
+/* The intervals grow unevenly (a batch lands where its strings sort): when the largest holds more than `pct` per cent more BYTES of the block array than
+ * the mean (25), the bounds are moved to where equal shares of the bytes lie -- found from 64 byte-quantiles of every interval -- and every
+ * interval is rebuilt from the symbols of its new range: each device gets its range as plain symbols (1 byte each, its own share only) from the
+ * neighbours that held them, device to device, and rebuilds its handle in place.  Nothing is ever whole on one device.  1: rebalanced, 0: not needed. */
+int rb3gpu_shard_rebalance(rb3gpu_shard_t *s, int pct)
+{
+	if (!s) return RB3GPU_EINVAL;
+	const int n = s->n;
+	if (n < 2) return 0;
+	enum { Q = 64 };
+	double bytes[RB3GPU_SH_MAXIV], total = 0, mx = 0;
+	for (int i = 0; i < n; ++i) {
+		rb3gpu_stats_t st;
+		int r = rb3gpu_stats(s->h[i], &st);
+		if (r < 0) return r;
+		bytes[i] = (double)st.bytes_index, total += bytes[i], mx = bytes[i] > mx ? bytes[i] : mx;
+	}
+	if (pct >= 0 && mx * n <= total * (1.0 + pct / 100.0)) return 0;
+	// the global profile: (position, bytes before it) at Q + 1 points per interval
+	std::vector<double> px((size_t)n * Q + 1), py((size_t)n * Q + 1);
+	double before = 0;
+	int r = 0;
+	for (int i = 0; i < n && r == 0; ++i) {
+		int64_t qb[Q + 1];
+		if (s->bounds[i + 1] - s->bounds[i] >= Q) r = rb3gpu_balanced_bounds(s->h[i], Q, qb);
+		else for (int k = 0; k <= Q; ++k) qb[k] = (s->bounds[i + 1] - s->bounds[i]) * k / Q;
+		for (int k = 0; k < Q; ++k) px[(size_t)i * Q + k] = (double)(s->bounds[i] + qb[k]), py[(size_t)i * Q + k] = before + bytes[i] * k / Q;
+		before += bytes[i];
+	}
+	if (r < 0) return r;
+	px[(size_t)n * Q] = (double)s->bounds[n], py[(size_t)n * Q] = total;
+	int64_t nb[RB3GPU_SH_MAXIV + 1];
+	nb[0] = 0, nb[n] = s->bounds[n];
+	size_t at = 0;
+	for (int j = 1; j < n; ++j) {
+		const double want = total * j / n;
+		while (at + 1 < px.size() - 1 && py[at + 1] < want) ++at;
+		const double dy = py[at + 1] - py[at], f = dy > 0 ? (want - py[at]) / dy : 0.0;
+		int64_t b = (int64_t)(px[at] + f * (px[at + 1] - px[at]));
+		if (b <= nb[j - 1]) b = nb[j - 1] + 1;
+		if (b > nb[n] - (n - j)) b = nb[n] - (n - j);
+		nb[j] = b;
+	}
+	int64_t acc0[RB3GPU_ASIZE + 1], acc1[RB3GPU_ASIZE + 1];
+	if ((r = rb3gpu_shard_get_acc(s, acc0)) < 0) return r;
+	// phase 1: every device collects the symbols of its new range (the old handles stay as they are until all have)
+	void *plain[RB3GPU_SH_MAXIV];
+	for (int j = 0; j < n; ++j) plain[j] = nullptr;
+	for (int j = 0; j < n && r == 0; ++j) {
+		const int64_t len = nb[j + 1] - nb[j];
+		if ((r = rb3gpu_dev_alloc(s->h[j], len + 64, &plain[j])) < 0) break;
+		for (int i = 0; i < n && r == 0; ++i) {
+			const int64_t a = nb[j] > s->bounds[i] ? nb[j] : s->bounds[i], b = nb[j + 1] < s->bounds[i + 1] ? nb[j + 1] : s->bounds[i + 1];
+			if (a >= b) continue;
+			uint8_t *dst = (uint8_t*)plain[j] + (a - nb[j]);
+			if (s->dev[i] == s->dev[j]) { r = rb3gpu_export_plain_range_dev(s->h[i], a - s->bounds[i], b - s->bounds[i], dst); continue; }
+			void *tmp = nullptr;
+			if ((r = rb3gpu_dev_alloc(s->h[i], b - a + 64, &tmp)) < 0) break;
+			if ((r = rb3gpu_export_plain_range_dev(s->h[i], a - s->bounds[i], b - s->bounds[i], (uint8_t*)tmp)) == 0) r = copy_across(dst, s->dev[j], tmp, s->dev[i], (size_t)(b - a));
+			(void)rb3gpu_dev_free(s->h[i], tmp);
+		}
+	}
+	// phase 2: every handle rebuilt from its new range
+	for (int j = 0; j < n && r == 0; ++j) r = rb3gpu_from_plain_dev(s->h[j], nb[j + 1] - nb[j], (const uint8_t*)plain[j]);
+	for (int j = 0; j < n; ++j) if (plain[j]) (void)rb3gpu_dev_free(s->h[j], plain[j]);
+	if (r < 0) return r; // (the index is lost: the caller gives the build up)
+	memcpy(s->bounds, nb, (size_t)(n + 1) * 8);
+	if ((r = rb3gpu_shard_get_acc(s, acc1)) < 0) return r;
+	for (int c = 0; c <= RB3GPU_ASIZE; ++c) if (acc0[c] != acc1[c]) return RB3GPU_EINTERNAL; // (the symbols the intervals held, no more and no fewer)
+	return 1;
 }
 
 int rb3gpu_shard_get_acc(const rb3gpu_shard_t *s, int64_t acc[RB3GPU_ASIZE + 1])

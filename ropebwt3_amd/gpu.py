@@ -128,6 +128,7 @@ SYMBOLS = {
     "rb3gpu_shard_merge": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_shard_gather": (ctypes.c_int, [ctypes.c_void_p]),
     "rb3gpu_shard_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_shard_rebalance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rb3gpu_shard_get_acc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_shard_export_runs": (ctypes.c_int, [ctypes.c_void_p, EMIT_F, ctypes.c_void_p]),
     "rb3gpu_shard_export_run_words": (ctypes.c_int, [ctypes.c_void_p, EMITW_F, ctypes.c_void_p]),
@@ -770,6 +771,17 @@ class Shard:
             raise Rb3GpuError(int(r), "rb3gpu_shard_export_run_words")
         w = np.concatenate(words) if words else np.zeros(0, dtype=np.uint64)
         return (w >> np.uint64(3)).astype(np.int64), (w & np.uint64(7)).astype(np.uint8), end[0]
+
+    def rebalance(self, pct=25):
+        r = self._lib.rb3gpu_shard_rebalance(self._s, int(pct))
+        if r < 0:
+            raise Rb3GpuError(int(r), "rb3gpu_shard_rebalance")
+        return int(r)
+
+    def handle_stats(self, i):
+        st = Stats()
+        self._lib.rb3gpu_stats(self._lib.rb3gpu_shard_handle(self._s, int(i)), ctypes.byref(st))
+        return st.as_dict()
 
     def destroy(self):
         s, self._s = self._s, None

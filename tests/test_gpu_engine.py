@@ -1267,6 +1267,46 @@ def test_shard_object_exports_without_a_gather(oracle):
             h.close()
 
 
+def test_shard_rebalance_moves_the_bounds_to_equal_bytes(oracle, monkeypatch):
+    """rb3gpu_shard_rebalance ("rebalance by neighbour shifts when the largest interval exceeds the mean by 25 %"): an index whose
+    second half is incompressible and whose first half is one run, cut into four intervals of equal SYMBOL counts by hand (two nearly empty
+    of bytes, two heavy), is rebalanced to intervals of about equal bytes; the index is the same symbol for symbol, merges go on afterwards,
+    and a balanced index is left alone."""
+    from ropebwt3_amd import Rb3Gpu, Shard, host
+    monkeypatch.setenv("RB3GPU_SHARD_REBALANCE_PCT", "-1")      # not by itself inside merge(): this test calls it
+    rng = np.random.default_rng(9)
+    g0 = util.random_genome(rng, 60000)
+    cur = host.build_bwt(util.make_text([g0] + [util.mutate(rng, g0, 0.001) for _ in range(30)], rev=False))   # runs of ~30: compressible ...
+    t2s = [util.make_text(util.reads_from(rng, util.random_genome(rng, 40000), 3000, 120), rev=False) for _ in range(2)]  # ... and batches of unrelated reads: bit planes wherever they land
+    want = [cur]
+    for t2 in t2s:
+        want.append(oracle.merge(want[-1], host.build_bwt(t2.copy())))
+    h = Rb3Gpu(verbose=1)
+    try:
+        h.from_plain(cur)
+        sh = Shard(h, [0, 0, 0, 0])
+        assert sh.rebalance(25) == 0                              # cut by bytes a moment ago: nothing to do
+        for k, t2 in enumerate(t2s):
+            d_bwt, d_tw = h.sort_text(t2)
+            sh.merge(d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+            h.dev_free(d_bwt), h.dev_free(d_tw)
+        by = np.array([sh.handle_stats(i)["bytes_index"] for i in range(4)], dtype=np.float64)
+        did = sh.rebalance(0)                                     # any difference at all
+        by2 = np.array([sh.handle_stats(i)["bytes_index"] for i in range(4)], dtype=np.float64)
+        assert did == 1 and by2.max() / by2.mean() <= max(1.15, by.max() / by.mean()), (by, by2)
+        b = sh.bounds()
+        assert b[0] == 0 and b[-1] == want[-1].size and np.all(np.diff(b) > 0)
+        assert np.array_equal(sh.export_plain(), want[-1])
+        t3 = util.make_text(util.reads_from(rng, g0, 500, 100), rev=True)   # and the rebalanced intervals take another batch
+        d_bwt, d_tw = h.sort_text(t3)
+        sh.merge(d_bwt, d_tw, t3.size, np.flatnonzero(t3 == 0))
+        h.dev_free(d_bwt), h.dev_free(d_tw)
+        assert np.array_equal(sh.export_plain(), oracle.merge(want[-1], host.build_bwt(t3.copy())))
+        sh.destroy()
+    finally:
+        h.close()
+
+
 def test_balanced_bounds_follow_the_bytes_of_the_block_array(oracle):
     """rb3gpu_balanced_bounds: an index whose first half is one long run and whose second half is random symbols is cut where the BYTES
     are (nearly all in the second half), not in the middle"""

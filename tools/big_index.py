@@ -129,7 +129,8 @@ def summary(rounds, reads, n_hap, L, t_total):
                         "frac": round(ALGO * steps / (msc * 1e-3) / 1e9 / 8000.0, 4) if msc > 0 else None, "lf_steps_per_s": round(steps / (msc * 1e-3) / 1e9, 3) if msc > 0 else None,
                         "ms_per_launch": round(msc / len(last), 3)},
            "residency": {"index_symbols": rounds[-1]["index_symbols"], "index_bytes": rounds[-1]["index_bytes"], "bytes_per_symbol": round(rounds[-1]["index_bytes"] / rounds[-1]["index_symbols"], 4),
-                         "peak_device_bytes_of_the_handle": max(r["peak_bytes"] for r in rounds), "sorter_scratch": "52 B per batch symbol beside it (its own object)"},
+                         "peak_device_bytes_of_the_handle": max(r["peak_bytes"] for r in rounds), "sorter_scratch": "52 B per batch symbol beside it (its own object)",
+                         "handle_peak_bytes_per_batch_symbol": round((max(r["peak_bytes"] for r in rounds) - rounds[-1]["index_bytes"]) / max(1, max(r["symbols"] for r in rounds)), 1)},
            "fallbacks": sum(r["fallbacks"] for r in rounds), "wall_s": round(t_total, 1),
            "first_and_last_rounds": rounds[:2] + rounds[-2:]}
     if reads:

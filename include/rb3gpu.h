@@ -189,7 +189,7 @@ void rb3gpu_pinned_free(void *p);
  * rb3h_walkers_text / rb3h_build_bwt_walkers; the reference has one chain per string, fm-index.c:217-224): as many walkers as the
  * walker kernel keeps resident on `device` -- one per group of eight lanes, compute units x 160 -- because a wave lasts as long as
  * its longest walker and walkers beyond the resident ones only start when others have finished; never closer than 192 positions
- * (a walker must be 32 steps old before it records, and segments shorter than 128 are not split).  < 0: no such device. */
+ * (a walker must be 16 steps old before it records -- RB3_TENT_MIN_AGE --, and segments shorter than 128 are not split).  < 0: no such device. */
 int64_t rb3gpu_walker_step(int device, int64_t len, int64_t n_strings);
 
 /* The whole BWT as one symbol per byte (0..5) into host memory of rb3gpu_get_tot() bytes;

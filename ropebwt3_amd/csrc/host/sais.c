@@ -64,7 +64,7 @@ int rb3h_build_bwt(int64_t n_seq, int64_t len, uint8_t *seq, int n_threads)
                        * first, which the per-walker settle pass does not resolve -- a merge in ten thousand was redone.  With 64 a late walker only
                        * starts if the neighbour is at least ~55 rows behind.) */
 #ifndef RB3H_PREROLL
-#define RB3H_PREROLL 32 /* = RB3_TENT_MIN_AGE of the engine (rb3gpu_kernels.h) */
+#define RB3H_PREROLL 16 /* = RB3_TENT_MIN_AGE of the engine (rb3gpu_kernels.h) */
 #endif
 
 /* The walker list of a batch from its sampled inverse suffix array: ckrow[i] = row of the suffix starting at text

@@ -128,6 +128,8 @@ struct Tune {
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
 	int junction_check = 16; // ... and the LF relation at the junctions of the speculative walk (k_junction_check): wherever a walker met somebody's record -- all
 	                         // of them, always -- and at the drop-out events of every n-th stretch id (1: every event, ~10 ms per 152-genome build; 0: off)
+	int ev_blocks = 2048, cum_blocks = 2048, resw_blocks = 512, sfin_blocks = 2048; // launch widths of the settle kernels (k_events, k_cum, k_resolve_w, k_sfin); round 5: k_cum 1024 -> 2048 (-1 ms per 152-genome build), the others make no difference (profiles/r5_ab_settle_widths.txt)
+	int list_beside = 1;     // the kernels that make the walker list of rb3gpu_merge_text_step_dev run on the side stream, beside the fill (0: in front of the walkers on the main stream)
 	int64_t load_chunk = 16384; // groups (of 8192 symbols) an FMD stream is decoded and built by at a time when it holds more than that (rb3gpu_from_fmd_words)
 #ifdef RB3GPU_TEST_HOOKS
 	int hide_first = 0;      // k_chain: exact walkers do not see the tentative records of first stretches (the late-walker race of DESIGN.md, made deterministic)
@@ -357,12 +359,12 @@ static void launch_settle(rb3gpu_t *h, const IdxView &iv, rb3_stretch_t *tab, ui
 	else if (q >= 4 && mx) RB3_SETTLE_X(4);
 	else if (q >= 2 && mx) RB3_SETTLE_X(2);
 	else {
-		hipLaunchKernelGGL(k_events, dim3(2048), dim3(256), 0, h->st, iv, tab, sidctr, fused_extent ? mctr : (const uint32_t*)nullptr, (uint32_t*)sidctr);
+		hipLaunchKernelGGL(k_events, dim3((unsigned)h->tn.ev_blocks), dim3(256), 0, h->st, iv, tab, sidctr, fused_extent ? mctr : (const uint32_t*)nullptr, (uint32_t*)sidctr);
 		if (h->tn.resolve_v1) hipLaunchKernelGGL(k_resolve, dim3(2048), dim3(256), 0, h->st, tab, sidctr, sfin);
 		else {
-			hipLaunchKernelGGL(k_cum, dim3(1024), dim3(256), 0, h->st, tab, sidctr);
-			hipLaunchKernelGGL(k_resolve_w, dim3(512), dim3(256), 0, h->st, tab, sidctr, sfin, bad, maxhops);
-			hipLaunchKernelGGL(k_sfin, dim3(2048), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, sidctr, sfin);
+			hipLaunchKernelGGL(k_cum, dim3((unsigned)h->tn.cum_blocks), dim3(256), 0, h->st, tab, sidctr);
+			hipLaunchKernelGGL(k_resolve_w, dim3((unsigned)h->tn.resw_blocks), dim3(256), 0, h->st, tab, sidctr, sfin, bad, maxhops);
+			hipLaunchKernelGGL(k_sfin, dim3((unsigned)h->tn.sfin_blocks), dim3(256), 0, h->st, (const rb3_stretch_t*)tab, sidctr, sfin);
 		}
 	}
 #undef RB3_SETTLE_X
@@ -446,6 +448,11 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "load_chunk")) t.load_chunk = v < 1 ? 1 : v;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
 	else if (!strcmp(key, "sh_host_rounds")) t.sh_host_rounds = v < 0 ? -1 : v != 0; // (-1: rounds on the device whatever the number of chains)
+	else if (!strcmp(key, "ev_blocks")) t.ev_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
+	else if (!strcmp(key, "cum_blocks")) t.cum_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
+	else if (!strcmp(key, "resw_blocks")) t.resw_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
+	else if (!strcmp(key, "sfin_blocks")) t.sfin_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
+	else if (!strcmp(key, "list_beside")) t.list_beside = v != 0;
 	else if (!strcmp(key, "junction_check")) t.junction_check = v < 0 ? 0 : v > 4096 ? 4096 : (int)v;
 	else if (!strcmp(key, "corrupt_sfin") || !strcmp(key, "force_fallback") || !strcmp(key, "hide_first") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
 			!strcmp(key, "pos_limit") || !strcmp(key, "win_scratch") || !strcmp(key, "slot_bytes")) {
@@ -476,7 +483,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "list_beside", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -1363,17 +1370,18 @@ static rb3gpu_walker_t *thin_walkers(int64_t n, const rb3gpu_walker_t *w, int th
 }
 
 /* the list of k_wl_sentinels / k_wl_make into wl (K + n_strings slots), queued on the handle's stream; scratch: n_strings words */
-static void step_list_launch(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *d_sent, Walker *wl)
+static void step_list_launch(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *d_sent, Walker *wl, hipStream_t st = nullptr)
 {
+	if (st == nullptr) st = h->st;
 	const int64_t K = len / step;
-	(void)hipMemsetAsync(wl, 0xff, (size_t)(K + n_strings) * 32, h->st); // every slot empty (row -1)
+	(void)hipMemsetAsync(wl, 0xff, (size_t)(K + n_strings) * 32, st); // every slot empty (row -1)
 	if (h->mg_sa != nullptr && len < (1LL << 32)) // (a wrong string count: sa[j] of a j that is no sentinel's row is a position whose next word does not start a string -- k_wl_make's
-		hipLaunchKernelGGL(k_wl_sentinels_sa, dim3((unsigned)((n_strings + 255) / 256)), dim3(256), 0, h->st, h->mg_sa, len, n_strings, d_sent); // binary search then meets unsorted positions; the merge's own count of the sentinels decides)
+		hipLaunchKernelGGL(k_wl_sentinels_sa, dim3((unsigned)((n_strings + 255) / 256)), dim3(256), 0, st, h->mg_sa, len, n_strings, d_sent); // binary search then meets unsorted positions; the merge's own count of the sentinels decides)
 	else {
-		(void)hipMemsetAsync(d_sent, 0xff, (size_t)n_strings * 8, h->st);
-		hipLaunchKernelGGL(k_wl_sentinels, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, d_tw, len, n_strings, d_sent);
+		(void)hipMemsetAsync(d_sent, 0xff, (size_t)n_strings * 8, st);
+		hipLaunchKernelGGL(k_wl_sentinels, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, d_tw, len, n_strings, d_sent);
 	}
-	hipLaunchKernelGGL(k_wl_make, dim3((unsigned)((K + n_strings + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)d_sent, n_strings, len, step, K, wl);
+	hipLaunchKernelGGL(k_wl_make, dim3((unsigned)((K + n_strings + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_sent, n_strings, len, step, K, wl);
 }
 
 /* ... and on the host, without its empty slots (the paths that walk row words, a merge that is redone: rare) */
@@ -1522,6 +1530,12 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	fill_add(&jb, misc + MISC_RG_OVER, tent ? (size_t)(MISC_WORDS - MISC_RG_OVER) * 8 : (size_t)(MISC_BAD_WALKERS + 1 - MISC_RG_OVER) * 8, 0u); // (... MISC_WIDE, MISC_BAD_WALKERS, and the id counters behind them)
 	// (the rows-per-window table is not cleared: k_pos_finalize_check_rows writes every entry when pos[] validates, and when it does not the
 	// validation counters make every rebuild kernel return before it reads the table -- 42 MB of fill per round of a 1.3 G-symbol build)
+	// the walker list made on the device: on the side stream, beside the fill (three small launches that read only the batch's own words)
+	const bool list_beside = step_list && h->tn.list_beside;
+	if (list_beside) {
+		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->dlx.p, (Walker*)h->wl.p, h->st2);
+		HIPCHK(hipEventRecord(h->evx[0], h->st2));
+	}
 	const bool rows_filled = d_tw != nullptr && jb.n < 8;
 	if (rows_filled) fill_add(&jb, trec ? h->post.p : h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
 	else if (trec) HIPCHK(hipMemsetAsync(h->post.p, 0xff, (size_t)len * 8, h->st));
@@ -1563,8 +1577,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		hipLaunchKernelGGL(k_b2_pick, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], (const uint64_t*)slen, bucket, b2W);
 		hipLaunchKernelGGL(k_b2_list, dim3((unsigned)((n_walkers + 255) / 256 < 2048 ? (n_walkers + 255) / 256 : 2048)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode,
 				(const uint64_t*)lnk[cur], (const uint64_t*)slen, (const unsigned long long*)bucket, b2_nbk, (Walker*)h->wl.p, b2_nwalk, (const int64_t*)h->pos.p, b2W);
-	} else if (step_list) { // one walker per string and one every wstep text positions, made here (two small kernels in front of the walkers)
-		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->dlx.p, (Walker*)h->wl.p);
+	} else if (step_list) { // one walker per string and one every wstep text positions, made on the side stream while the fill ran (above)
+		if (list_beside) HIPCHK(hipStreamWaitEvent(h->st, h->evx[0], 0));
+		else step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->dlx.p, (Walker*)h->wl.p);
 	} else if (per_string && d_tw) {
 		HIPCHK(hipMemsetAsync(h->wl.p, 0xff, (size_t)n_walkers * 32, h->st)); // a walker that nobody fills in starts at row -1: caught below
 		hipLaunchKernelGGL(k_walkers_per_string, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw, len);
@@ -1685,9 +1700,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 				hipLaunchKernelGGL(k_part_place, dim3((unsigned)((part_nb + 7) / 8 * 8 * S)), dim3(256), 0, h->st, (const uint64_t*)pout, len, partK, part_nb, S, dpos, (const unsigned long long*)(misc + 2));
 				frec = nullptr, fsa = nullptr;
 			}
-			const dim3 g2((unsigned)((len / 2 + 1 + 255) / 256)); // (records in row order: two rows per thread)
-			if (frec == nullptr && tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows2<true>), g2, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
-			else if (frec == nullptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows2<false>), g2, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)nullptr, misc + 2, (int64_t*)h->jg.p, nwin);
+			const dim3 g2((unsigned)((len / RB3_FIN_ROWS + 1 + 255) / 256)); // (records in row order: several rows per thread)
+			if (frec == nullptr && tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rowsN<true, RB3_FIN_ROWS>), g2, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin);
+			else if (frec == nullptr) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rowsN<false, RB3_FIN_ROWS>), g2, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)nullptr, misc + 2, (int64_t*)h->jg.p, nwin);
 			else if (tent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<true>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)sfin, misc + 2, (int64_t*)h->jg.p, nwin, frec, fsa);
 			else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pos_finalize_check_rows<false>), g1, dim3(256), 0, h->st, dpos, len, ntot, (const int32_t*)nullptr, misc + 2, (int64_t*)h->jg.p, nwin, frec, fsa);
 		} else if (tent)
@@ -1780,6 +1795,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
 	if (tent) {
 		tent_used(h, hm[5]);
+		if (h->opt.verbose >= 4) fprintf(stderr, "[M::rb3gpu] merge of %lld rows into %lld: %lld walkers, %llu LF steps, stretch ids %llu (blocks of a walker with relatives) + %llu (single)\n",
+				(long long)len, (long long)h->n, (long long)n_walkers, hm[1], hm[5] & 0xFFFFFFFFull, hm[5] >> 32);
 		// Walkers that were old enough to record tentatively but sat on an interval wider than the masks (more relatives in the index
 		// than mask bits) walked without recording: where that was more than a few percent of all steps the next merges use masks of
 		// twice the width (the index only gains relatives).  Nothing is redone: this merge is complete, only slower than it could be.

@@ -825,7 +825,9 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 #define RB3_TENT_QMAX 8               /* ... and with masks of 256 Q bits in an array of their own, Q = 2, 4, 8 (more than 255 relatives: below) */
 #define RB3_TENT_KMAX_TOP (256 * RB3_TENT_QMAX - 1)
 #ifndef RB3_TENT_MIN_AGE
-#define RB3_TENT_MIN_AGE 32u      /* walker lists (segments of a guaranteed length) */
+#define RB3_TENT_MIN_AGE 16u      /* walker lists (segments of a guaranteed length).  32 in rounds 2-4; round 5, with the records written as a stream: 16 walks
+                                     6 % fewer steps (the pre-roll of every walker), one merge of 38 k redone on a crowded GPU against 12 of 38 k at 32; at 12 and 8
+                                     the walkers reach their segments on intervals too wide to record and the walk gets SLOWER (profiles/r5_ab_min_age.txt) */
 #endif
 #define RB3_TENT_MIN_AGE_AUTO 64u /* automatic split: the segments are geometric, and with 32 one merge in a hundred of the
                                      soak left records unsettled and was redone */
@@ -949,11 +951,17 @@ __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, 
 /* mctr != NULL: the extent of the ids in use is still in the 64 counters the walkers took their chunks from (see tent_take_chunk): every
  * block works it out for itself and block 0 leaves it in sidctr_out[0] for the kernels behind this one and for the host (k_tent_extent's
  * job, without its launch) */
+/* U stretches per octet and iteration (their loads asked for together).  Measured in round 5 (profiles/r5_ab_settle_widths.txt): U = 2 changes
+ * nothing, and neither do wider launches of this or the other settle kernels -- the pass is not waiting for memory: its counters say 18 M
+ * vector instructions per launch (the run decode of drops_from_slot for every event), i.e. ~30 of its ~40 us are the vector units. */
+#ifndef RB3_EV_UNROLL
+#define RB3_EV_UNROLL 1
+#endif
 __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, const uint32_t *sidctr, const uint32_t *mctr = nullptr, uint32_t *sidctr_out = nullptr)
 {
-	__shared__ uint32_t dmask[32 * 8];
+	constexpr int U = RB3_EV_UNROLL;
+	__shared__ uint32_t dmask[U][32 * 8];
 	const int j = threadIdx.x & 7;
-	uint32_t *D = &dmask[(threadIdx.x >> 3) * 8];
 	uint32_t ext = 0;
 	if (mctr != nullptr) {
 		uint32_t v = (threadIdx.x & 63) < RB3_TENT_NCTR ? mctr[(threadIdx.x & 63) * 32u] : 0u;
@@ -963,37 +971,66 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
 		if (blockIdx.x == 0 && threadIdx.x == 0) sidctr_out[0] = ext;
 	} else ext = *sidctr;
 	const int64_t n = ext < (uint32_t)RB3_TENT_HALF ? ext : RB3_TENT_HALF; // events only happen to ids from blocks
-	for (int64_t sid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; sid < n; sid += ((int64_t)gridDim.x * blockDim.x) >> 3) {
-		const uint64_t w0 = tab[sid].w0;
-		if (w0 >> 62 != RB3_DEP_EVENT) continue;
-		const uint64_t w1 = tab[sid].w1;
-		const int64_t lo = (int64_t)(w0 & (uint64_t)RB3_TENT_MASK);
-		const int kk = (int)(w1 & 0xFFFF), c = (int)(w1 >> 16 & 7);
-		D[j] = 0u;
-		__builtin_amdgcn_wave_barrier();
+	const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 3;
+	for (int64_t sid0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; sid0 < n; sid0 += stride * U) {
+		uint64_t w0[U], w1[U];
+		bool ev[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int64_t sid = sid0 + u * stride;
+			ev[u] = sid < n;
+			w0[u] = ev[u] ? tab[sid].w0 : 0ull, w1[u] = ev[u] ? tab[sid].w1 : 0ull;
+		}
+		bool any = false;
+#pragma unroll
+		for (int u = 0; u < U; ++u) ev[u] = w0[u] >> 62 == RB3_DEP_EVENT, any |= ev[u];
+		if (!any) continue;
 		// the slots of lo and of lo + kk: both directory words first, then the slot(s) -- the interval usually lies in ONE slot,
 		// which is then read and searched once (the two dependent round trips of a rank, not four)
-		const int64_t k1 = lo + kk <= ix.n ? lo + kk : lo;
-		const uint32_t koff0 = (uint32_t)lo & (RB3_GRP - 1), koff1 = (uint32_t)k1 & (RB3_GRP - 1);
-		const uint64_t sm0 = ix.grp64[(lo >> RB3_GRP_BITS) * 8 + 6], sm1 = ix.grp64[(k1 >> RB3_GRP_BITS) * 8 + 6]; // (measured: the compact copy IdxView.gsm is no faster here, +1 ms per build)
-		const int64_t s0 = (int64_t)((uint32_t)sm0 + __popc((uint32_t)(sm0 >> 32) & ((2u << (koff0 >> RB3_WIN_BITS)) - 1u)) - 1u);
-		const int64_t s1 = (int64_t)((uint32_t)sm1 + __popc((uint32_t)(sm1 >> 32) & ((2u << (koff1 >> RB3_WIN_BITS)) - 1u)) - 1u);
-		const bool two = s1 != s0 || (lo >> RB3_GRP_BITS) != (k1 >> RB3_GRP_BITS);
-		const uint4 sl0 = ix.slot16[s0 * 8 + j];
-		uint4 sl1 = sl0;
-		if (two) sl1 = ix.slot16[s1 * 8 + j];
-		{
-			const uint32_t hdr0 = oct_bcast0(sl0.x, j);
-			drops_from_slot(sl0, hdr0, (int)koff0 - (int)(hdr0 & 0xFFFFu), kk, c, j, D);
+		int64_t lo[U], k1[U];
+		uint64_t sm0[U], sm1[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			lo[u] = (int64_t)(w0[u] & (uint64_t)RB3_TENT_MASK);
+			const int kk = (int)(w1[u] & 0xFFFF);
+			k1[u] = lo[u] + kk <= ix.n ? lo[u] + kk : lo[u];
+			sm0[u] = sm1[u] = 0;
+			if (ev[u]) sm0[u] = ix.grp64[(lo[u] >> RB3_GRP_BITS) * 8 + 6], sm1[u] = ix.grp64[(k1[u] >> RB3_GRP_BITS) * 8 + 6]; // (measured: the compact copy IdxView.gsm is no faster here, +1 ms per build)
 		}
-		if (two && k1 != lo) {
-			const uint32_t hdr0 = oct_bcast0(sl1.x, j);
-			drops_from_slot(sl1, hdr0, (int)koff1 - (int)(hdr0 & 0xFFFFu) - kk, kk, c, j, D);
+		uint4 sl0[U], sl1[U];
+		bool two[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const uint32_t koff0 = (uint32_t)lo[u] & (RB3_GRP - 1), koff1 = (uint32_t)k1[u] & (RB3_GRP - 1);
+			const int64_t s0 = (int64_t)((uint32_t)sm0[u] + __popc((uint32_t)(sm0[u] >> 32) & ((2u << (koff0 >> RB3_WIN_BITS)) - 1u)) - 1u);
+			const int64_t s1 = (int64_t)((uint32_t)sm1[u] + __popc((uint32_t)(sm1[u] >> 32) & ((2u << (koff1 >> RB3_WIN_BITS)) - 1u)) - 1u);
+			two[u] = s1 != s0 || (lo[u] >> RB3_GRP_BITS) != (k1[u] >> RB3_GRP_BITS);
+			sl0[u] = make_uint4(0u, 0u, 0u, 0u);
+			if (ev[u]) sl0[u] = ix.slot16[s0 * 8 + j];
+			sl1[u] = sl0[u];
+			if (ev[u] && two[u]) sl1[u] = ix.slot16[s1 * 8 + j];
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		tab[sid].mask[j] = D[j];
-		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			if (!ev[u]) continue;
+			uint32_t *D = &dmask[u][(threadIdx.x >> 3) * 8];
+			const int kk = (int)(w1[u] & 0xFFFF), c = (int)(w1[u] >> 16 & 7);
+			const uint32_t koff0 = (uint32_t)lo[u] & (RB3_GRP - 1), koff1 = (uint32_t)k1[u] & (RB3_GRP - 1);
+			D[j] = 0u;
+			__builtin_amdgcn_wave_barrier();
+			{
+				const uint32_t hdr0 = oct_bcast0(sl0[u].x, j);
+				drops_from_slot(sl0[u], hdr0, (int)koff0 - (int)(hdr0 & 0xFFFFu), kk, c, j, D);
+			}
+			if (two[u] && k1[u] != lo[u]) {
+				const uint32_t hdr0 = oct_bcast0(sl1[u].x, j);
+				drops_from_slot(sl1[u], hdr0, (int)koff1 - (int)(hdr0 & 0xFFFFu) - kk, kk, c, j, D);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			tab[sid0 + u * stride].mask[j] = D[j];
+			__builtin_amdgcn_wave_barrier();
+		}
 	}
 }
 
@@ -2205,6 +2242,14 @@ __device__ __forceinline__ int64_t pos_final(int64_t v, const int32_t *sfin, uns
 	return (v & RB3_TENT_MASK) + (r - 1);
 }
 
+/* bad[2]: written by the settle kernels BEFORE this launch on the same stream, so an ordinary load sees it (and every compute unit finds
+ * it in its L2 after the first one asked).  It used to be a volatile load: 65 k waves asking the memory side for ONE word, one after the
+ * other -- most of what the pass took. */
+#ifdef RB3_EXP_VOLBAD /* kernel experiment: the old load */
+#define RB3_SETTLE_INCOMPLETE(bad) (*(volatile unsigned long long*)&(bad)[2] != 0)
+#else
+#define RB3_SETTLE_INCOMPLETE(bad) ((bad)[2] != 0)
+#endif
 __global__ void __launch_bounds__(256) k_pos_finalize(int64_t *pos, int64_t n2, const int32_t *sfin, unsigned long long *bad)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2218,7 +2263,7 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check(int64_t *pos, int64_
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n2) return;
-	if (*(volatile unsigned long long*)&bad[2] != 0) return; // the settle pass already knows it is incomplete: nothing to validate yet
+	if (RB3_SETTLE_INCOMPLETE(bad)) return; // the settle pass already knows it is incomplete: nothing to validate yet
 	const int64_t raw = pos[i];
 	const int64_t p = pos_final(raw, sfin, bad);
 	const int64_t q = i > 0 ? pos_final(pos[i - 1], sfin, nullptr) : RB3_UNSET; // the neighbour's own thread reports its problems
@@ -2238,7 +2283,7 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check_rows(int64_t *pos, i
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > n2) return;
 	// the settle pass already knows it is incomplete: nothing to validate yet (one answer per wave: the lanes exchange values below)
-	if (TENT && __builtin_amdgcn_readfirstlane((int)(*(volatile unsigned long long*)&bad[2] != 0)) != 0) return;
+	if (TENT && __builtin_amdgcn_readfirstlane((int)(RB3_SETTLE_INCOMPLETE(bad))) != 0) return;
 	int64_t p = INT64_MAX, q = RB3_UNSET;
 	if (i < n2) {
 		const int64_t raw = sa ? rec[sa[i] < (uint32_t)n2 ? sa[i] : 0u] : pos[i];
@@ -2269,64 +2314,77 @@ __global__ void __launch_bounds__(256) k_pos_finalize_check_rows(int64_t *pos, i
 	for (int64_t w = a + 1; w <= b; ++w) jw[w] = i;
 }
 
-/* the same for records in row order (rec == nullptr above), TWO rows per thread: 16-byte loads and stores, half the threads -- the pass
- * is a stream of 16 B per row and was running at half the rate a stream should */
-template<bool TENT>
-__global__ void __launch_bounds__(256) k_pos_finalize_check_rows2(int64_t *pos, int64_t n2, int64_t ntot, const int32_t *sfin, unsigned long long *bad, int64_t *jw, int64_t nwin)
+/* the same for records in row order (rec == nullptr above), R rows per thread: 16-byte loads and stores.  The pass is a stream of 16 B per
+ * row plus one gather from sfin[] per tentative row (8.8 M rows: 163 MB and 8.5 M gathers that hit the L2, 66 us = 2.5 TB/s).  Two rows per
+ * thread since round 4 (one: half the rate); four were measured in round 5 and are 7 us per launch SLOWER (profiles/r5_ab_finalize_rows.txt). */
+#ifndef RB3_FIN_ROWS
+#define RB3_FIN_ROWS 2
+#endif
+template<bool TENT, int R>
+__global__ void __launch_bounds__(256) k_pos_finalize_check_rowsN(int64_t *pos, int64_t n2, int64_t ntot, const int32_t *sfin, unsigned long long *bad, int64_t *jw, int64_t nwin)
 {
-	const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2, i1 = i0 + 1;
+	static_assert(R == 2 || R == 4, "two or four rows per thread");
+	const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * R;
 	if (i0 > n2) return;
-	if (TENT && __builtin_amdgcn_readfirstlane((int)(*(volatile unsigned long long*)&bad[2] != 0)) != 0) return;
-	int64_t p0 = INT64_MAX, p1 = INT64_MAX, q = RB3_UNSET;
-	if (i1 < n2) {
-		const longlong2 raw = *(const longlong2*)(pos + i0);
-		p0 = TENT ? pos_final(raw.x, sfin, bad) : (raw.x < 0 ? RB3_UNSET : raw.x);
-		p1 = TENT ? pos_final(raw.y, sfin, bad) : (raw.y < 0 ? RB3_UNSET : raw.y);
-		if (TENT && ((p0 != raw.x && p0 >= 0) || (p1 != raw.y && p1 >= 0))) { // (an unsettled record stays as it is: a longer settle pass may still resolve it)
-			longlong2 w;
-			w.x = p0 >= 0 ? p0 : raw.x, w.y = p1 >= 0 ? p1 : raw.y;
-			*(longlong2*)(pos + i0) = w;
+	if (TENT && __builtin_amdgcn_readfirstlane((int)(RB3_SETTLE_INCOMPLETE(bad))) != 0) return;
+	int64_t raw[R], p[R], q = RB3_UNSET;
+	const bool full = i0 + R <= n2;
+	if (full) {
+#pragma unroll
+		for (int r = 0; r < R; r += 2) {
+			const longlong2 v = *(const longlong2*)(pos + i0 + r);
+			raw[r] = v.x, raw[r + 1] = v.y;
 		}
-	} else if (i0 < n2) {
-		const int64_t raw = pos[i0];
-		p0 = TENT ? pos_final(raw, sfin, bad) : (raw < 0 ? RB3_UNSET : raw);
-		if (TENT && p0 != raw && p0 >= 0) pos[i0] = p0;
+	} else {
+#pragma unroll
+		for (int r = 0; r < R; ++r) raw[r] = i0 + r < n2 ? pos[i0 + r] : 0;
 	}
-	{ // the row before i0: the second row of the lane below; lane 0 of a wave looks it up again
-		const int64_t last = i1 < n2 ? p1 : p0; // (only the wave's last thread can have i1 >= n2, and nobody reads its `last`)
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		p[r] = INT64_MAX;
+		if (full || i0 + r < n2) p[r] = TENT ? pos_final(raw[r], sfin, bad) : (raw[r] < 0 ? RB3_UNSET : raw[r]);
+	}
+	if (TENT) { // (an unsettled record stays as it is: a longer settle pass may still resolve it)
+		if (full) {
+#pragma unroll
+			for (int r = 0; r < R; r += 2)
+				if ((p[r] != raw[r] && p[r] >= 0) || (p[r + 1] != raw[r + 1] && p[r + 1] >= 0)) {
+					longlong2 w;
+					w.x = p[r] >= 0 ? p[r] : raw[r], w.y = p[r + 1] >= 0 ? p[r + 1] : raw[r + 1];
+					*(longlong2*)(pos + i0 + r) = w;
+				}
+		} else {
+#pragma unroll
+			for (int r = 0; r < R; ++r)
+				if (i0 + r < n2 && p[r] != raw[r] && p[r] >= 0) pos[i0 + r] = p[r];
+		}
+	}
+	{ // the row before i0: the last row of the lane below (all of its rows exist, since this thread's first one does or is row n2); lane 0 of a wave looks it up again
+		const int64_t last = p[R - 1];
 		const uint32_t qlo = wave_up1((uint32_t)(uint64_t)last), qhi = wave_up1((uint32_t)((uint64_t)last >> 32));
 		if ((threadIdx.x & 63) != 0) q = (int64_t)((uint64_t)qhi << 32 | qlo);
 		else if (i0 > 0) {
 			const int64_t rq = pos[i0 - 1];
-			q = TENT ? pos_final(rq, sfin, nullptr) : (rq < 0 ? RB3_UNSET : rq);
+			q = TENT ? pos_final(rq, sfin, nullptr) : (rq < 0 ? RB3_UNSET : rq); // (the neighbour's own thread reports its problems)
 		}
 	}
-	// row i0 (or, with i0 == n2, the windows behind the last row)
-	bool ok0 = true;
-	if (i0 < n2) {
-		if (p0 < 0) { atomicAdd(&bad[0], 1ull); ok0 = false; }
-		else if (p0 >= ntot || (i0 > 0 && q >= 0 && q >= p0)) { atomicAdd(&bad[1], 1ull); ok0 = false; }
-	}
-	if (i0 > 0 && q < 0) ok0 = false;
-	if (ok0) {
-		const int64_t a = i0 == 0 ? -1 : q >> RB3_WIN_BITS;
-		int64_t b = i0 == n2 ? nwin : p0 >> RB3_WIN_BITS;
-		if (b > nwin) b = nwin;
-		for (int64_t w = a + 1; w <= b; ++w) jw[w] = i0;
-	}
-	if (i0 >= n2) return;
-	// row i1 (or the windows behind the last row)
-	bool ok1 = true;
-	if (i1 < n2) {
-		if (p1 < 0) { atomicAdd(&bad[0], 1ull); ok1 = false; }
-		else if (p1 >= ntot || (p0 >= 0 && p0 >= p1)) { atomicAdd(&bad[1], 1ull); ok1 = false; }
-	}
-	if (p0 < 0) ok1 = false;
-	if (ok1) {
-		const int64_t a = p0 >> RB3_WIN_BITS;
-		int64_t b = i1 == n2 ? nwin : p1 >> RB3_WIN_BITS;
-		if (b > nwin) b = nwin;
-		for (int64_t w = a + 1; w <= b; ++w) jw[w] = i1;
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const int64_t i = i0 + r; // row i, or, with i == n2, the windows behind the last row
+		if (i > n2) break;
+		const int64_t prev = r == 0 ? q : p[r - 1];
+		bool ok = true;
+		if (i < n2) {
+			if (p[r] < 0) { atomicAdd(&bad[0], 1ull); ok = false; }
+			else if (p[r] >= ntot || (i > 0 && prev >= 0 && prev >= p[r])) { atomicAdd(&bad[1], 1ull); ok = false; }
+		}
+		if (i > 0 && prev < 0) ok = false;
+		if (ok) {
+			const int64_t a = i == 0 ? -1 : prev >> RB3_WIN_BITS;
+			int64_t b = i == n2 ? nwin : p[r] >> RB3_WIN_BITS;
+			if (b > nwin) b = nwin;
+			for (int64_t w = a + 1; w <= b; ++w) jw[w] = i;
+		}
 	}
 }
 

@@ -315,9 +315,10 @@ def test_fmd_writer_wide_block_headers_vs_reference_library(tmp_path, case):
 
 def test_walker_list_by_text_position_covers_every_row_once():
     """rb3h_walkers_text: per string one walker at the sentinel and one at every multiple of `step` strictly inside it, in text
-    order; an inner walker starts `flags >> 8` positions (32 = the age from which the engine's walkers record; fewer next to
+    order; an inner walker starts `flags >> 8` positions (16 = the age from which the engine's walkers record; fewer next to
     the string's end) to the RIGHT of its segment and its nsteps counts them; the segments of a string tile it exactly; the
     sentinel walker's own segment is never shorter than 128 steps where the string is that long"""
+    PRE = 16   # RB3H_PREROLL (host/sais.c) = RB3_TENT_MIN_AGE of the engine
     rng = np.random.default_rng(77)
     seqs = [util.random_genome(rng, n) for n in (5000, 1, 257, 384, 385, 20000, 130, 3)]
     t = util.make_text(seqs, True, False)
@@ -337,9 +338,9 @@ def test_walker_list_by_text_position_covers_every_row_once():
             for row, ka0, nsteps, flags in inner:
                 pre, probe = flags >> 8 & 0xFF, flags >> 16
                 p = row - pre
-                assert ka0 == -1 and flags & 0xFF == 0 and 0 <= pre <= 32 and p % step == 0 and b < p < e and row < e
-                assert probe == (64 if pre == 32 and e - 1 - row >= 64 else 0) and row + probe < e
-                assert pre == min(32, e - 1 - p)
+                assert ka0 == -1 and flags & 0xFF == 0 and 0 <= pre <= PRE and p % step == 0 and b < p < e and row < e
+                assert probe == (64 if pre == PRE and e - 1 - row >= 64 else 0) and row + probe < e
+                assert pre == min(PRE, e - 1 - p)
                 assert nsteps == (np.iinfo(np.int64).max // 2 if prev is None else p - prev + pre)
                 prev = p
             assert sent[2] == (np.iinfo(np.int64).max // 2 if prev is None else e - prev)

@@ -21,6 +21,8 @@ def short(name):
         import re
         m = re.search(r"k_reb_group<(\d+), *(\d+)", name) or re.search(r"k_reb_groupILi(\d+)ELi(\d+)", name)
         return "k_reb_group<%s,%s>" % (m.group(1), m.group(2)) if m else "k_reb_group"
+    if "k_pos_finalize_check_rowsN" in name:
+        return "k_pos_finalize_check_rowsN"
     if "k_pos_finalize_check_rows2" in name:
         return "k_pos_finalize_check_rows2"
     if "k_pos_finalize_check_rows" in name:

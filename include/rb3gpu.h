@@ -428,6 +428,9 @@ void *rb3gpu_stream_of(const rb3gpu_t *h);
 int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value);
 
 int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st);
+/* what the handle holds right now, buffer by buffer (diagnostics: which scratch makes up bytes_peak): i = 0, 1, ... until RB3GPU_EINVAL; *name is a static
+ * string.  (No counterpart in the reference: its memory is the rope's, mrope.c:15-34.) */
+int rb3gpu_buffer_bytes(const rb3gpu_t *h, int i, const char **name, int64_t *bytes);
 void rb3gpu_stats_reset(rb3gpu_t *h);
 
 /* device scratch helpers so that callers without a HIP binding (C host code, ctypes) can

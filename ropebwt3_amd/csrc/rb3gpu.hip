@@ -129,7 +129,6 @@ struct Tune {
 	int junction_check = 16; // ... and the LF relation at the junctions of the speculative walk (k_junction_check): wherever a walker met somebody's record -- all
 	                         // of them, always -- and at the drop-out events of every n-th stretch id (1: every event, ~10 ms per 152-genome build; 0: off)
 	int ev_blocks = 2048, cum_blocks = 2048, resw_blocks = 512, sfin_blocks = 2048; // launch widths of the settle kernels (k_events, k_cum, k_resolve_w, k_sfin); round 5: k_cum 1024 -> 2048 (-1 ms per 152-genome build), the others make no difference (profiles/r5_ab_settle_widths.txt)
-	int list_beside = 1;     // the kernels that make the walker list of rb3gpu_merge_text_step_dev run on the side stream, beside the fill (0: in front of the walkers on the main stream)
 	int64_t load_chunk = 16384; // groups (of 8192 symbols) an FMD stream is decoded and built by at a time when it holds more than that (rb3gpu_from_fmd_words)
 #ifdef RB3GPU_TEST_HOOKS
 	int hide_first = 0;      // k_chain: exact walkers do not see the tentative records of first stretches (the late-walker race of DESIGN.md, made deterministic)
@@ -255,12 +254,16 @@ static void dev_free(rb3gpu_t *h, void *p, size_t bytes)
 	h->bytes_owned -= (int64_t)bytes;
 }
 
+static size_t grow_slack(size_t n) { return n < ((size_t)256 << 20) ? n >> 1 : n < ((size_t)2 << 30) ? n >> 2 : n >> 3; }
+
 static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes, bool exact = false)
 {
 	if (b.cap >= bytes && b.p) return 0;
 	if (b.p) dev_free(h, b.p, b.cap);
 	b.p = nullptr, b.cap = 0;
-	size_t want = exact ? bytes + 256 : bytes + (bytes >> 1) + 256; // geometric growth: an index that grows round by round must not realloc every round (exact: a one-off, e.g. loading an index)
+	// geometric growth: an index that grows round by round must not realloc every round (exact: a one-off, e.g. loading an index, or a table of a fixed size).
+	// Half as much again while a buffer is small, a quarter from 256 MB, an eighth from 2 GB: at 360 M rows per batch the halves were 10 GB of nothing.
+	size_t want = exact ? bytes + 256 : bytes + grow_slack(bytes) + 256;
 	int r = dev_malloc(h, &b.p, want);
 	if (r == RB3GPU_ENOMEM && want != bytes) r = dev_malloc(h, &b.p, want = bytes);
 	if (r < 0) return r;
@@ -306,7 +309,7 @@ static int tent_prepare(rb3gpu_t *h, rb3_stretch_t **tab, int32_t **sfin, FillJo
 	const size_t bytes = (size_t)RB3_TENT_IDS * (sizeof(rb3_stretch_t) + 4);
 	const bool fresh = !(h->dl.p && h->dl.cap >= bytes);
 	int r;
-	if ((r = buf_ensure(h, h->dl, bytes)) < 0) return r;
+	if ((r = buf_ensure(h, h->dl, bytes, true)) < 0) return r; // (a table of a fixed size)
 	rb3_stretch_t *t = *tab = (rb3_stretch_t*)h->dl.p;
 	int32_t *f = *sfin = (int32_t*)(t + RB3_TENT_IDS);
 	// zero what the previous merge used: the blocks at the bottom of the table, the single ids from the middle up
@@ -452,7 +455,6 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "cum_blocks")) t.cum_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
 	else if (!strcmp(key, "resw_blocks")) t.resw_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
 	else if (!strcmp(key, "sfin_blocks")) t.sfin_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
-	else if (!strcmp(key, "list_beside")) t.list_beside = v != 0;
 	else if (!strcmp(key, "junction_check")) t.junction_check = v < 0 ? 0 : v > 4096 ? 4096 : (int)v;
 	else if (!strcmp(key, "corrupt_sfin") || !strcmp(key, "force_fallback") || !strcmp(key, "hide_first") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
 			!strcmp(key, "pos_limit") || !strcmp(key, "win_scratch") || !strcmp(key, "slot_bytes")) {
@@ -483,7 +485,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "list_beside", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -552,7 +554,7 @@ static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exac
 	if (h->ib[i].slots_cap < (size_t)nslots) {
 		dev_free(h, h->ib[i].slots, h->ib[i].slots_cap * sizeof(rb3_slot_t));
 		h->ib[i].slots = nullptr, h->ib[i].slots_cap = 0;
-		size_t want = exact ? (size_t)nslots + 64 : (size_t)nslots + (size_t)(nslots >> 1) + 64;
+		size_t want = exact ? (size_t)nslots + 64 : (size_t)nslots + grow_slack((size_t)nslots * sizeof(rb3_slot_t)) / sizeof(rb3_slot_t) + 64;
 		if ((r = dev_malloc(h, (void**)&h->ib[i].slots, want * sizeof(rb3_slot_t))) < 0) {
 			want = (size_t)nslots;
 			if ((r = dev_malloc(h, (void**)&h->ib[i].slots, want * sizeof(rb3_slot_t))) < 0) return r;
@@ -718,7 +720,9 @@ static int64_t slot_estimate(const rb3gpu_t *h, int64_t n2, int64_t ntot)
 {
 	const int64_t nwin = (ntot >> RB3_WIN_BITS) + 1;
 	if (!use_winpar(h, nwin) || h->nslots * 2 >= (h->n >> RB3_WIN_BITS) + 1) return nwin;
-	const int64_t est = h->nslots + h->nslots / 4 + n2 / 16 + 4096;
+	// (round 5: a quarter of the old count + a sixteenth of the rows until the index holds 2^22 slots = 512 MB; beyond, an eighth + a thirty-second --
+	// the 24-haplotype build adds n2 / 750 slots per round, and the two slot arrays of its 1.5 GB index had grown to 6.5 GB each)
+	const int64_t est = h->nslots < (1 << 22) ? h->nslots + h->nslots / 4 + n2 / 16 + 4096 : h->nslots + h->nslots / 8 + n2 / 32 + 4096;
 	return est < nwin ? est : nwin;
 }
 
@@ -1530,12 +1534,6 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	fill_add(&jb, misc + MISC_RG_OVER, tent ? (size_t)(MISC_WORDS - MISC_RG_OVER) * 8 : (size_t)(MISC_BAD_WALKERS + 1 - MISC_RG_OVER) * 8, 0u); // (... MISC_WIDE, MISC_BAD_WALKERS, and the id counters behind them)
 	// (the rows-per-window table is not cleared: k_pos_finalize_check_rows writes every entry when pos[] validates, and when it does not the
 	// validation counters make every rebuild kernel return before it reads the table -- 42 MB of fill per round of a 1.3 G-symbol build)
-	// the walker list made on the device: on the side stream, beside the fill (three small launches that read only the batch's own words)
-	const bool list_beside = step_list && h->tn.list_beside;
-	if (list_beside) {
-		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->dlx.p, (Walker*)h->wl.p, h->st2);
-		HIPCHK(hipEventRecord(h->evx[0], h->st2));
-	}
 	const bool rows_filled = d_tw != nullptr && jb.n < 8;
 	if (rows_filled) fill_add(&jb, trec ? h->post.p : h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
 	else if (trec) HIPCHK(hipMemsetAsync(h->post.p, 0xff, (size_t)len * 8, h->st));
@@ -1577,9 +1575,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		hipLaunchKernelGGL(k_b2_pick, dim3((unsigned)((b2_nspmax + 255) / 256)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], (const uint64_t*)slen, bucket, b2W);
 		hipLaunchKernelGGL(k_b2_list, dim3((unsigned)((n_walkers + 255) / 256 < 2048 ? (n_walkers + 255) / 256 : 2048)), dim3(256), 0, h->st, len, tot2, b2S, (const unsigned long long*)mode,
 				(const uint64_t*)lnk[cur], (const uint64_t*)slen, (const unsigned long long*)bucket, b2_nbk, (Walker*)h->wl.p, b2_nwalk, (const int64_t*)h->pos.p, b2W);
-	} else if (step_list) { // one walker per string and one every wstep text positions, made on the side stream while the fill ran (above)
-		if (list_beside) HIPCHK(hipStreamWaitEvent(h->st, h->evx[0], 0));
-		else step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->dlx.p, (Walker*)h->wl.p);
+	} else if (step_list) { // one walker per string and one every wstep text positions, made here (two small kernels in front of the walkers; on the side stream,
+		// beside the fill, they were measured in round 5: the wait for the event costs more than they take -- fill-to-walkers 6.0 -> 7.0 ms per 152-genome build)
+		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->dlx.p, (Walker*)h->wl.p);
 	} else if (per_string && d_tw) {
 		HIPCHK(hipMemsetAsync(h->wl.p, 0xff, (size_t)n_walkers * 32, h->st)); // a walker that nobody fills in starts at row -1: caught below
 		hipLaunchKernelGGL(k_walkers_per_string, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw, len);
@@ -1795,8 +1793,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (host_acc2) memcpy(host_acc2, acc2, sizeof(acc2));
 	if (tent) {
 		tent_used(h, hm[5]);
-		if (h->opt.verbose >= 4) fprintf(stderr, "[M::rb3gpu] merge of %lld rows into %lld: %lld walkers, %llu LF steps, stretch ids %llu (blocks of a walker with relatives) + %llu (single)\n",
-				(long long)len, (long long)h->n, (long long)n_walkers, hm[1], hm[5] & 0xFFFFFFFFull, hm[5] >> 32);
+		if (h->opt.verbose >= 4) fprintf(stderr, "[M::rb3gpu] merge of %lld rows into %lld: %lld list slots, %llu LF steps, stretch ids %llu (blocks of a walker with relatives) + %llu (single); fill-to-walkers %.3f ms, k_chain %.3f, settle + validation %.3f, rebuild %.3f\n",
+				(long long)len, (long long)h->n, (long long)n_walkers, hm[1], hm[5] & 0xFFFFFFFFull, hm[5] >> 32, ev_ms(h->ev[0], ev_rank0), ev_ms(h->ev[6], h->ev[7]), ev_ms(h->ev[7], h->ev[2]), ev_ms(h->ev[2], h->ev[3]));
 		// Walkers that were old enough to record tentatively but sat on an interval wider than the masks (more relatives in the index
 		// than mask bits) walked without recording: where that was more than a few percent of all steps the next merges use masks of
 		// twice the width (the index only gains relatives).  Nothing is redone: this merge is complete, only slower than it could be.
@@ -3462,6 +3460,22 @@ int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st)
 	if (!h || !st) return RB3GPU_EINVAL;
 	*st = h->stt;
 	return 0;
+}
+
+int rb3gpu_buffer_bytes(const rb3gpu_t *h, int i, const char **name, int64_t *bytes)
+{
+	static const char *names[] = { "b2 (batch symbols)", "pos (row records)", "post (records in text order)", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg (rows per window)", "misc", "xbuf (scratch)", "wl (walker list)",
+		"dl (stretch table)", "dlx (wide masks)", "wstat", "wplane", "wruns", "gslots (run-space rebuild)", "glist", "pslots (plane-space rebuild)", "lbst", "shc", "shn", "shs", "shr", "shk" };
+	if (!h || !name || !bytes || i < 0) return RB3GPU_EINVAL;
+	rb3gpu_t *m = const_cast<rb3gpu_t*>(h);
+	Buf *all[] = { &m->b2, &m->pos, &m->post, &m->tcnt, &m->tpre, &m->ctot, &m->ctot2, &m->gstat, &m->gpre, &m->jg, &m->misc, &m->xbuf, &m->wl, &m->dl, &m->dlx, &m->wstat, &m->wplane, &m->wruns, &m->gslots, &m->glist, &m->pslots, &m->lbst,
+		&m->shc, &m->shn, &m->shs, &m->shr, &m->shk };
+	const int nb = (int)(sizeof(all) / sizeof(all[0]));
+	static_assert(sizeof(all) / sizeof(all[0]) == sizeof(names) / sizeof(names[0]), "a name per buffer");
+	if (i < nb) { *name = names[i], *bytes = all[i]->p ? (int64_t)all[i]->cap : 0; return 0; }
+	if (i < nb + 2) { *name = i == nb + h->cur ? "index directory (current)" : "index directory (being built)", *bytes = h->ib[i - nb].grp ? (int64_t)(h->ib[i - nb].grp_cap * RB3_GRP_ALLOC) : 0; return 0; }
+	if (i < nb + 4) { *name = i == nb + 2 + h->cur ? "index slots (current)" : "index slots (being built)", *bytes = h->ib[i - nb - 2].slots ? (int64_t)(h->ib[i - nb - 2].slots_cap * sizeof(rb3_slot_t)) : 0; return 0; }
+	return RB3GPU_EINVAL;
 }
 
 void rb3gpu_stats_reset(rb3gpu_t *h)

@@ -103,6 +103,7 @@ SYMBOLS = {
     "rb3gpu_merge_index": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_tune": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     "rb3gpu_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
+    "rb3gpu_buffer_bytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64)]),
     "rb3gpu_stats_reset": (None, [ctypes.c_void_p]),
     "rb3gpu_dev_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
     "rb3gpu_dev_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
@@ -601,6 +602,16 @@ class Rb3Gpu:
 
     def stats_reset(self):
         self._lib.rb3gpu_stats_reset(self._h)
+
+    def buffers(self):
+        """{name: bytes} of every device buffer the handle holds right now (rb3gpu_buffer_bytes)"""
+        out, i = {}, 0
+        name, nb = ctypes.c_char_p(), ctypes.c_int64()
+        while self._lib.rb3gpu_buffer_bytes(self._h, i, ctypes.byref(name), ctypes.byref(nb)) == 0:
+            if nb.value:
+                out[name.value.decode()] = int(nb.value)
+            i += 1
+        return out
 
 
 class CommGroup:

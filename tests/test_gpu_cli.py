@@ -117,6 +117,25 @@ def test_interval_build_writes_every_format_from_the_intervals(tmp_path):
     assert hashlib.md5(fmd).hexdigest() == ent["fmd_md5"]
 
 
+def test_interval_build_keeps_the_intervals_balanced(tmp_path):
+    """`build --gpus 4 --interval` on 300 k synthetic reads in five batches: the same .fmd as the ordinary build, the
+    intervals within 1 % of each other in symbols, no handle's peak device memory more than 1.3 x another's -- nothing of the size of the
+    whole index sits on one of them (every handle on the one device here; tests/test_gpu_multi.py has the two-device form)"""
+    import re
+    from tools import gen_reads
+    fn = str(tmp_path / "reads.txt")
+    gen_reads.generate(300000, fn)
+    fmd1, _ = run(["build", "-L", "-d", "-m18m", fn])
+    fmd4, err = run(["build", "-L", "-d", "-m18m", "--gpus", "4", "--interval", fn])
+    assert fmd4 == fmd1
+    iv = [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"interval \d+ on device \d+: (\d+) symbols, index [\d.]+ MB, peak device memory ([\d.]+) MB", err)]
+    assert len(iv) == 4, err[-2000:]
+    sym, peak = [a for a, _ in iv], [b for _, b in iv]
+    assert sum(sym) == 2 * 300000 * 151
+    assert max(sym) <= 1.01 * min(sym), sym
+    assert max(peak) <= 1.3 * min(peak), peak
+
+
 def test_gzip_through_a_pipe_on_stdin():
     """`cat x.fa.gz | build -`: the same .fmd as from the file (the reader must not eat the gzip magic of a pipe)"""
     ent = MAN["genomes12"]

@@ -74,6 +74,8 @@ def build(n_hap, L, lf_check=None, log=None, device=0):
              "ms_lf": round(s["ms_lf"] - prev["ms_lf"], 3), "ms_rank": round(s["ms_rank"] - prev["ms_rank"], 3), "ms_chain": round(s["ms_chain"] - prev["ms_chain"], 3),
              "ms_rebuild": round(s["ms_build"] - prev["ms_build"], 3), "lf_steps": int(s["n_lf_steps"] - prev["n_lf_steps"]), "fallbacks": int(s["n_fallbacks"] - prev["n_fallbacks"]),
              "index_bytes": int(s["bytes_index"]), "peak_bytes": int(s["bytes_peak"]), "rebuild_emitted_again": int(s["n_reb_again"] - prev["n_reb_again"]), "ms_alloc": round(s["ms_alloc"] - prev["ms_alloc"], 1)}
+        if k == n_hap - 1:   # what the handle holds after its last round, buffer by buffer
+            r["buffers_MB"] = {n: round(b / 1e6, 1) for n, b in sorted(h.buffers().items(), key=lambda x: -x[1])}
         rounds.append(r)
         prev = s
         if log:
@@ -130,7 +132,8 @@ def summary(rounds, reads, n_hap, L, t_total):
                         "ms_per_launch": round(msc / len(last), 3)},
            "residency": {"index_symbols": rounds[-1]["index_symbols"], "index_bytes": rounds[-1]["index_bytes"], "bytes_per_symbol": round(rounds[-1]["index_bytes"] / rounds[-1]["index_symbols"], 4),
                          "peak_device_bytes_of_the_handle": max(r["peak_bytes"] for r in rounds), "sorter_scratch": "52 B per batch symbol beside it (its own object)",
-                         "handle_peak_bytes_per_batch_symbol": round((max(r["peak_bytes"] for r in rounds) - rounds[-1]["index_bytes"]) / max(1, max(r["symbols"] for r in rounds)), 1)},
+                         "handle_peak_bytes_per_batch_symbol": round((max(r["peak_bytes"] for r in rounds) - rounds[-1]["index_bytes"]) / max(1, max(r["symbols"] for r in rounds)), 1),
+                         "buffers_MB_after_the_last_round": rounds[-1].get("buffers_MB")},
            "fallbacks": sum(r["fallbacks"] for r in rounds), "wall_s": round(t_total, 1),
            "first_and_last_rounds": rounds[:2] + rounds[-2:]}
     if reads:

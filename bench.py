@@ -592,7 +592,8 @@ def main():
                    "entry_points": "rb3gpu_sorter_upload_fwd (H2D of the batch: forward strands out of page-locked memory, reverse complements written on the device; --full-upload: rb3gpu_sorter_upload) + rb3gpu_merge_text_step_dev (walker list made on the device + LF + walkers + settle + validation + rebuild, commit=1; --host-walkers: rb3gpu_merge_text_dev with a list from the host); rb3gpu_sorter_sort_uploaded between them is not counted (suffix sorting: excluded by the metric)",
                    "fmd_md5": md5, "fmd_bytes": fmd_len, "fmd_identical_to_reference": ident,
                    "reference_fmd_md5_source": "tests/golden/MANIFEST.json mtb_star/%d (oracle/_ref/ropebwt3 = the unmodified reference, tools/make_golden_mtb.py)" % K if gold else "no golden for this size",
-                   "lf_steps_per_step": int(st["n_lf_steps"] // S), "rank_phase_fallbacks": int(st["n_fallbacks"]), "long_settles": int(st["n_long_settles"])},
+                   "lf_steps_per_step": int(st["n_lf_steps"] // S), "rank_phase_fallbacks": int(st["n_fallbacks"]), "long_settles": int(st["n_long_settles"]),
+                   "handle_peak_device_bytes": int(st["bytes_peak"]), "handle_peak_bytes_per_batch_symbol": round((st["bytes_peak"] - st["bytes_index"]) / max(1, sym_step // max(1, K - 1)), 1)},
         "phases_ms_per_step": {"h2d": round(tot_h2d / S * 1e3, 3), "merge_calls": round(tot_mrg / S * 1e3, 3), "lf": round(st["ms_lf"] / S, 3), "rank": round(st["ms_rank"] / S, 3), "k_chain": round(st["ms_chain"] / S, 3),
                                "rebuild": round(st["ms_build"] / S, 3), "host_and_sync_inside_merge_calls": round((tot_mrg * 1e3 - st["ms_lf"] - st["ms_rank"] - st["ms_build"]) / S, 3)},
         "not_counted_ms_per_step": {"suffix_sorting_on_the_gpu": round(tot_sort / S * 1e3, 3), "wall_of_the_whole_loop": round(tot_wall / S * 1e3, 3),

@@ -125,6 +125,7 @@ struct Tune {
 	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
 	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
 	int sh_host_rounds = 0;  // rb3gpu_sh_merge with ONE interval: the host reads the split sizes back after every round, as with several (0: the rounds run back to back on the device)
+	int sh_states = 0;       // states per octet of k_sh_round (1, 2, 4, 8); 0: by the number of chains
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
 	int junction_check = 16; // ... and the LF relation at the junctions of the speculative walk (k_junction_check): wherever a walker met somebody's record -- all
 	                         // of them, always -- and at the drop-out events of every n-th stretch id (1: every event, ~10 ms per 152-genome build; 0: off)
@@ -455,6 +456,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "cum_blocks")) t.cum_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
 	else if (!strcmp(key, "resw_blocks")) t.resw_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
 	else if (!strcmp(key, "sfin_blocks")) t.sfin_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
+	else if (!strcmp(key, "sh_states")) t.sh_states = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : v >= 1 ? 1 : 0;
 	else if (!strcmp(key, "junction_check")) t.junction_check = v < 0 ? 0 : v > 4096 ? 4096 : (int)v;
 	else if (!strcmp(key, "corrupt_sfin") || !strcmp(key, "force_fallback") || !strcmp(key, "hide_first") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
 			!strcmp(key, "pos_limit") || !strcmp(key, "win_scratch") || !strcmp(key, "slot_bytes")) {
@@ -485,7 +487,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -3246,7 +3248,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 		// three sets of counters in turn: round k adds to set k % 3, takes its number of states from set (k - 1) % 3 (what the round before counted for
 		// interval 0) and clears set (k + 1) % 3 for the round behind it -- three different sets, so no block reads a word another block of the same launch clears
 		{ const unsigned long long n0 = (unsigned long long)n_chains; HIPCHK(hipMemcpyAsync(d_cnt[2], &n0, 8, hipMemcpyHostToDevice, h->st)); HIPCHK(hipStreamSynchronize(h->st)); } // "the round before" of round 0 (n0 lives on this stack)
-		const int S = n_chains >= ((int64_t)1 << 19) ? 8 : n_chains >= ((int64_t)1 << 17) ? 4 : n_chains >= ((int64_t)1 << 15) ? 2 : 1;
+		const int S = h->tn.sh_states ? h->tn.sh_states : n_chains >= ((int64_t)1 << 19) ? 8 : n_chains >= ((int64_t)1 << 17) ? 4 : n_chains >= ((int64_t)1 << 15) ? 2 : 1;
 		const unsigned nblk = (unsigned)((n_chains + 32 * S - 1) / (32 * S));
 		ShState *sa = cur, *sb = nxt;
 		for (int64_t k = 0; k < longest; ++k) {
@@ -3278,7 +3280,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 				send = (ShState*)h->shs.p;
 			}
 			// states per octet: enough blocks to fill the chip first, then as many states per cursor atomic as the registers take
-			const int S = n_cur >= ((int64_t)1 << 19) ? 8 : n_cur >= ((int64_t)1 << 17) ? 4 : n_cur >= ((int64_t)1 << 15) ? 2 : 1;
+			const int S = h->tn.sh_states ? h->tn.sh_states : n_cur >= ((int64_t)1 << 19) ? 8 : n_cur >= ((int64_t)1 << 17) ? 4 : n_cur >= ((int64_t)1 << 15) ? 2 : 1;
 			const unsigned nblk = (unsigned)((n_cur + 32 * S - 1) / (32 * S));
 #define RB3_SH_ROUND(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad, d_tprev)
 			if (S == 8) RB3_SH_ROUND(8); else if (S == 4) RB3_SH_ROUND(4); else if (S == 2) RB3_SH_ROUND(2); else RB3_SH_ROUND(1);

@@ -829,8 +829,10 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
                                      6 % fewer steps (the pre-roll of every walker), one merge of 38 k redone on a crowded GPU against 12 of 38 k at 32; at 12 and 8
                                      the walkers reach their segments on intervals too wide to record and the walk gets SLOWER (profiles/r5_ab_min_age.txt) */
 #endif
+#ifndef RB3_TENT_MIN_AGE_AUTO
 #define RB3_TENT_MIN_AGE_AUTO 64u /* automatic split: the segments are geometric, and with 32 one merge in a hundred of the
                                      soak left records unsettled and was redone */
+#endif
 /* One 64-byte record per stretch, so that following a dependency path costs one memory round trip per
  * stretch (k_resolve).  w0, w1: how the unknown of the stretch follows from another one.
  *   w0 = type << 62 | previous stretch << 38 | lo (EVENT only)

@@ -762,6 +762,24 @@ def bench_partition_mtb(args, rank, local_rank, world):
     # in the same line, the reads workload through the interval-sharded path (north_star), with the SAME workload at N = 1 through
     # the normal single-GPU path beside it (aux_interval_reads.n1_same_workload.normal_single_gpu_path: the number --interval has to beat)
     aux = None
+    # The leg below has never run between two devices (no multi-GPU box in rounds 1-5): if it hangs in a collective, the line of the main
+    # measurement must not be lost with it.  Every rank arms the same deadline; when it passes, rank 0 prints the line without the leg and all exit.
+    watchdog = None
+    if not args.no_aux:
+        import threading
+
+        printed = [False]
+
+        def give_up():
+            if rank == 0 and not printed[0]:
+                out["aux_interval_reads"] = {"error": "the interval leg did not finish within %d s (first contact with a multi-GPU box?); the line above it stands" % aux_deadline}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        aux_deadline = int(os.environ.get("RB3_BENCH_AUX_DEADLINE", "300"))
+        watchdog = threading.Timer(aux_deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if not args.no_aux:
         try:
             from ropebwt3_amd import Rb3Gpu
@@ -775,8 +793,12 @@ def bench_partition_mtb(args, rank, local_rank, world):
     if rank == 0:
         if aux is not None:
             out["aux_interval_reads"] = aux
+        if watchdog is not None:
+            printed[0] = True
         print(json.dumps(out), flush=True)
-    dist.barrier() if shared_gpu else barrier()
+    dist.barrier() if shared_gpu else barrier()   # (a rank whose leg failed waits here for the others -- or for the deadline)
+    if watchdog is not None:
+        watchdog.cancel()
     bl.close()
     if rank == 0:
         for f in files:

@@ -3248,7 +3248,8 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 		// three sets of counters in turn: round k adds to set k % 3, takes its number of states from set (k - 1) % 3 (what the round before counted for
 		// interval 0) and clears set (k + 1) % 3 for the round behind it -- three different sets, so no block reads a word another block of the same launch clears
 		{ const unsigned long long n0 = (unsigned long long)n_chains; HIPCHK(hipMemcpyAsync(d_cnt[2], &n0, 8, hipMemcpyHostToDevice, h->st)); HIPCHK(hipStreamSynchronize(h->st)); } // "the round before" of round 0 (n0 lives on this stack)
-		const int S = h->tn.sh_states ? h->tn.sh_states : n_chains >= ((int64_t)1 << 19) ? 8 : n_chains >= ((int64_t)1 << 17) ? 4 : n_chains >= ((int64_t)1 << 15) ? 2 : 1;
+		// (states per octet: eight from 2^15 chains on -- round 5, profiles/r5_sh_states.txt: 200 k chains 38.7 us per round with four, 32.7 with eight; sixteen are no faster; one for few chains)
+		const int S = h->tn.sh_states ? h->tn.sh_states : n_chains >= ((int64_t)1 << 15) ? 8 : 1;
 		const unsigned nblk = (unsigned)((n_chains + 32 * S - 1) / (32 * S));
 		ShState *sa = cur, *sb = nxt;
 		for (int64_t k = 0; k < longest; ++k) {
@@ -3280,7 +3281,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 				send = (ShState*)h->shs.p;
 			}
 			// states per octet: enough blocks to fill the chip first, then as many states per cursor atomic as the registers take
-			const int S = h->tn.sh_states ? h->tn.sh_states : n_cur >= ((int64_t)1 << 19) ? 8 : n_cur >= ((int64_t)1 << 17) ? 4 : n_cur >= ((int64_t)1 << 15) ? 2 : 1;
+			const int S = h->tn.sh_states ? h->tn.sh_states : n_cur >= ((int64_t)1 << 15) ? 8 : 1;
 			const unsigned nblk = (unsigned)((n_cur + 32 * S - 1) / (32 * S));
 #define RB3_SH_ROUND(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad, d_tprev)
 			if (S == 8) RB3_SH_ROUND(8); else if (S == 4) RB3_SH_ROUND(4); else if (S == 2) RB3_SH_ROUND(2); else RB3_SH_ROUND(1);

@@ -125,6 +125,7 @@ struct Tune {
 	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
 	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
 	int sh_host_rounds = 0;  // rb3gpu_sh_merge with ONE interval: the host reads the split sizes back after every round, as with several (0: the rounds run back to back on the device)
+	int sh_block = 0;        // threads per block of k_sh_round at eight states per octet: 256 or 1024; 0: 1024 below 3 M chains
 	int sh_states = 0;       // states per octet of k_sh_round (1, 2, 4, 8); 0: by the number of chains
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
 	int junction_check = 16; // ... and the LF relation at the junctions of the speculative walk (k_junction_check): wherever a walker met somebody's record -- all
@@ -456,6 +457,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "cum_blocks")) t.cum_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
 	else if (!strcmp(key, "resw_blocks")) t.resw_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
 	else if (!strcmp(key, "sfin_blocks")) t.sfin_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
+	else if (!strcmp(key, "sh_block")) t.sh_block = v >= 1024 ? 1024 : v > 0 ? 256 : 0;
 	else if (!strcmp(key, "sh_states")) t.sh_states = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : v >= 1 ? 1 : 0;
 	else if (!strcmp(key, "junction_check")) t.junction_check = v < 0 ? 0 : v > 4096 ? 4096 : (int)v;
 	else if (!strcmp(key, "corrupt_sfin") || !strcmp(key, "force_fallback") || !strcmp(key, "hide_first") || !strcmp(key, "tent_limit") || !strcmp(key, "text_mode") || !strcmp(key, "corrupt_pos") || !strcmp(key, "reb_lcap") || !strcmp(key, "reb_slot_cap") ||
@@ -487,7 +489,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -3250,12 +3252,14 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 		{ const unsigned long long n0 = (unsigned long long)n_chains; HIPCHK(hipMemcpyAsync(d_cnt[2], &n0, 8, hipMemcpyHostToDevice, h->st)); HIPCHK(hipStreamSynchronize(h->st)); } // "the round before" of round 0 (n0 lives on this stack)
 		// (states per octet: eight from 2^15 chains on -- round 5, profiles/r5_sh_states.txt: 200 k chains 38.7 us per round with four, 32.7 with eight; sixteen are no faster; one for few chains)
 		const int S = h->tn.sh_states ? h->tn.sh_states : n_chains >= ((int64_t)1 << 15) ? 8 : 1;
-		const unsigned nblk = (unsigned)((n_chains + 32 * S - 1) / (32 * S));
+		const int BS = S == 8 && (h->tn.sh_block ? h->tn.sh_block == 1024 : n_chains < ((int64_t)3 << 20)) ? 1024 : 256; // (round 5, profiles/r5_sh_states.txt: 200 k chains 32.6 -> 27.2 us per round, 2 M 166 -> 159, 4 M 278 -> 297)
+		const unsigned nblk = (unsigned)((n_chains + (BS / 8) * S - 1) / ((BS / 8) * S));
 		ShState *sa = cur, *sb = nxt;
 		for (int64_t k = 0; k < longest; ++k) {
 			unsigned long long *c_add = d_cnt[k % 3], *c_n = d_cnt[(k + 2) % 3], *c_clr = d_cnt[(k + 1) % 3];
 #define RB3_SH_ROUND1(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_chains, (const ShState*)sa, d_tw, (ShRec*)h->shr.p, sb, n_chains, c_add, c_clr, d_bad, d_tprev, (const unsigned long long*)c_n, rb + k)
-			if (S == 8) RB3_SH_ROUND1(8); else if (S == 4) RB3_SH_ROUND1(4); else if (S == 2) RB3_SH_ROUND1(2); else RB3_SH_ROUND1(1);
+			if (BS == 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<8, 1024>), dim3(nblk), dim3(1024), 0, h->st, iv, a, n_chains, (const ShState*)sa, d_tw, (ShRec*)h->shr.p, sb, n_chains, c_add, c_clr, d_bad, d_tprev, (const unsigned long long*)c_n, rb + k);
+			else if (S == 8) RB3_SH_ROUND1(8); else if (S == 4) RB3_SH_ROUND1(4); else if (S == 2) RB3_SH_ROUND1(2); else RB3_SH_ROUND1(1);
 #undef RB3_SH_ROUND1
 			ShState *t = sa; sa = sb, sb = t;
 		}
@@ -3282,9 +3286,11 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 			}
 			// states per octet: enough blocks to fill the chip first, then as many states per cursor atomic as the registers take
 			const int S = h->tn.sh_states ? h->tn.sh_states : n_cur >= ((int64_t)1 << 15) ? 8 : 1;
-			const unsigned nblk = (unsigned)((n_cur + 32 * S - 1) / (32 * S));
+			const int BS = S == 8 && (h->tn.sh_block ? h->tn.sh_block == 1024 : n_cur < ((int64_t)3 << 20)) ? 1024 : 256;
+			const unsigned nblk = (unsigned)((n_cur + (BS / 8) * S - 1) / ((BS / 8) * S));
 #define RB3_SH_ROUND(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad, d_tprev)
-			if (S == 8) RB3_SH_ROUND(8); else if (S == 4) RB3_SH_ROUND(4); else if (S == 2) RB3_SH_ROUND(2); else RB3_SH_ROUND(1);
+			if (BS == 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<8, 1024>), dim3(nblk), dim3(1024), 0, h->st, iv, a, n_cur, (const ShState*)cur, d_tw, (ShRec*)h->shr.p + rows, send, n_cur, d_cnt[par], d_cnt[1 - par], d_bad, d_tprev);
+			else if (S == 8) RB3_SH_ROUND(8); else if (S == 4) RB3_SH_ROUND(4); else if (S == 2) RB3_SH_ROUND(2); else RB3_SH_ROUND(1);
 #undef RB3_SH_ROUND
 			HIPCHK(hipMemcpyAsync(hc, d_cnt[par], (size_t)(world + 1) * 8, hipMemcpyDeviceToHost, h->st));
 			HIPCHK(hipMemcpyAsync(hc + world + 1, d_bad, 8, hipMemcpyDeviceToHost, h->st));

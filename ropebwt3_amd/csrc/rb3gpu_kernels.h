@@ -4168,8 +4168,10 @@ struct ShRec { int64_t kb, ka; };
 /* tprev != NULL (the batch sharded, VERDICT r4 "a sharded batch"): the device holds the symbol before every text position, one byte each,
  * instead of the text-order words (8 bytes each) -- what a step needs of the batch is that symbol only; the record is then
  * (text position, insertion point) and the row is looked up at the end, by the rank that holds that part of the inverse suffix array. */
-template<int S>
-__global__ void __launch_bounds__(256) k_sh_round(IdxView ix, ShArgs a, int64_t n, const ShState *in, const uint64_t *tw, ShRec *rec,
+/* BS threads per block: every block makes ONE returning atomic per destination on the round's cursor, and such atomics on one word take ~12 ns
+ * each one after the other -- 7800 blocks of 256 threads at 2 M chains are 94 us of them per round; blocks of 1024 threads are a quarter of that */
+template<int S, int BS = 256>
+__global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n, const ShState *in, const uint64_t *tw, ShRec *rec,
 		ShState *send, int64_t stride, unsigned long long *cnt, unsigned long long *cnt_next, unsigned long long *bad, const uint8_t *tprev = nullptr,
 		const unsigned long long *n_dev = nullptr, unsigned long long *rowbase = nullptr)
 {
@@ -4187,12 +4189,12 @@ __global__ void __launch_bounds__(256) k_sh_round(IdxView ix, ShArgs a, int64_t 
 		n = nd < n ? nd : n;
 		rec += nb[1];
 		if (blockIdx.x == 0 && threadIdx.x == 0) rowbase[1] = nb[1] + (unsigned long long)n;
-		if ((int64_t)blockIdx.x * 32 * S >= n && blockIdx.x != 0) return; // (block 0 stays: it clears the counters of the next round)
+		if ((int64_t)blockIdx.x * (BS / 8) * S >= n && blockIdx.x != 0) return; // (block 0 stays: it clears the counters of the next round)
 	}
 	if (blockIdx.x == 0 && threadIdx.x <= RB3_SH_MAXIV) cnt_next[threadIdx.x] = 0ull;
 	for (int i = threadIdx.x; i <= a.n_iv; i += blockDim.x) lc[i] = 0u;
 	__syncthreads();
-	const int64_t q0 = ((int64_t)blockIdx.x * 32 + (threadIdx.x >> 3)) * S;
+	const int64_t q0 = ((int64_t)blockIdx.x * (BS / 8) + (threadIdx.x >> 3)) * S;
 	ShState st[S];
 	uint64_t x[S];
 	RankLoad r[S];

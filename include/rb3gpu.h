@@ -422,7 +422,7 @@ void *rb3gpu_stream_of(const rb3gpu_t *h);
  *   text-order walk in text order: never / always / where the index does not fit the caches), "copy_walkers" 0/1, "b2_split" S (splitter
  *   spacing 2^S of the walker list the engine makes for the BWT-only entry points; -1 = by the size of the batch), "abs_limit" N (indexes
  *   of fewer than N symbols carry the LF base in their slot headers; at most 2^32, only before an index exists: RB3GPU_ESTATE after);
- *   the full table with defaults is in DESIGN.md section 8c
+ *   the full table with defaults is in docs/LAB_NOTEBOOK.md section 8c
  * Test hooks "force_fallback", "tent_limit", "text_mode" exist only in the test build of the library (compiled with
  * -DRB3GPU_TEST_HOOKS, librb3gpu_hooks.so); the release library answers RB3GPU_EUNSUP.  Unknown key: RB3GPU_EINVAL. */
 int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value);

@@ -1172,9 +1172,11 @@ def test_interval_sharded_merge_driven_from_the_library(oracle, world, kind):
     assert all(r == longest for r in rounds), (rounds, longest)   # one round per symbol of the longest string, its sentinel included
 
 
-def test_interval_sharded_merge_many_chains(oracle):
-    """600 k chains of ragged lengths (4..40 symbols) in one batch: the round kernel runs with 8, 4, 2 and 1 states per octet as the
-    chains end (k_sh_round<S>: the launch width follows the number of live chains), two intervals"""
+@pytest.mark.parametrize("states,block", [(0, 0), (8, 256), (4, 0), (2, 0)])
+def test_interval_sharded_merge_many_chains(oracle, states, block):
+    """600 k chains of ragged lengths (4..40 symbols) in one batch, two intervals: the round kernel with the launch shape the library picks
+    (k_sh_round<8, 1024> from 2^15 live chains on, one state per octet below: the launch follows the number of live chains as they end) and
+    with the other instantiations asked for through the tune keys (sh_states, sh_block)"""
     import threading
     from ropebwt3_amd import Rb3Gpu, CommGroup, host, multi
     world = 2
@@ -1192,6 +1194,10 @@ def test_interval_sharded_merge_many_chains(oracle):
     def run(rank):
         try:
             h = Rb3Gpu(verbose=1)
+            if states:
+                h.tune("sh_states", states)
+            if block:
+                h.tune("sh_block", block)
             comm = grp.comm(rank, h)
             h.from_plain(cur[bounds0[rank]:bounds0[rank + 1]])
             d_bwt, d_tw = h.sort_text(t2)
@@ -1210,6 +1216,30 @@ def test_interval_sharded_merge_many_chains(oracle):
         t.join(timeout=600)
     grp.close()
     assert not errs, errs
+
+
+def test_buffer_bytes_account_for_the_handle(oracle):
+    """rb3gpu_buffer_bytes: the buffers a handle reports add up to no more than its peak, the current slot array holds the index, and the
+    stretch table is there at its fixed size once a merge with tentative records has run"""
+    from ropebwt3_amd import Rb3Gpu, host
+    rng = np.random.default_rng(5)
+    g = util.random_genome(rng, 300000)
+    t1, t2 = util.make_text([g]), util.make_text([util.mutate(rng, g, 0.002)])
+    h = Rb3Gpu(verbose=1)
+    try:
+        d, dtw = h.sort_text(t1)
+        h.from_plain_dev(d, t1.size)
+        h.dev_free(d), h.dev_free(dtw)
+        d, dtw = h.sort_text(t2)
+        h.merge_text_dev(d, dtw, t2.size, host.walkers_text(t2, 192), commit=True)
+        h.dev_free(d), h.dev_free(dtw)
+        b, st = h.buffers(), h.stats()
+        assert b and all(v > 0 for v in b.values())
+        assert sum(b.values()) <= st["bytes_peak"]
+        assert b["index slots (current)"] + b["index directory (current)"] >= st["bytes_index"]
+        assert 16777216 * 68 <= b["dl (stretch table)"] <= 16777216 * 68 + 4096
+    finally:
+        h.close()
 
 
 def test_shard_object_split_merge_gather(oracle):

@@ -339,6 +339,7 @@ struct rb3gpu_shard_s {
 	unsigned long gen = 0;
 	int done = 0, quit = 0, n_threads = 0;
 	int n_rebalanced = 0;
+	int rebalance_pct = 25;   // RB3GPU_SHARD_REBALANCE_PCT, read once when the object is made (25: SURVEY 8(e); -1: never; 0: whenever the shares differ at all -- tests)
 	ShardJob job[RB3GPU_SH_MAXIV];
 };
 
@@ -451,6 +452,7 @@ rb3gpu_shard_t *rb3gpu_shard_split(rb3gpu_t *h0, int n, const int *devices, cons
 	rb3gpu_shard_s *s = new (std::nothrow) rb3gpu_shard_s;
 	if (!s) return nullptr;
 	s->n = n;
+	{ const char *e = getenv("RB3GPU_SHARD_REBALANCE_PCT"); if (e && *e) s->rebalance_pct = atoi(e); }
 	pthread_mutex_init(&s->mtx, nullptr);
 	pthread_cond_init(&s->cv, nullptr);
 	for (int i = 0; i < RB3GPU_SH_MAXIV; ++i) s->h[i] = nullptr, s->rep_tp[i] = s->rep_tw[i] = nullptr, s->rep_tp_cap[i] = s->rep_tw_cap[i] = 0, s->dev[i] = 0;
@@ -532,8 +534,7 @@ int rb3gpu_shard_merge(rb3gpu_shard_t *s, int64_t len, const uint8_t *d_bwt, con
 	if (r == 0) {
 		memcpy(s->bounds, s->job[0].bounds, sizeof(s->bounds));
 		if (n_rounds) *n_rounds = s->job[0].rounds;
-		const char *e = getenv("RB3GPU_SHARD_REBALANCE_PCT"); // (25: SURVEY 8(e); -1: never; 0: whenever the shares differ at all -- tests)
-		const int pct = e && *e ? atoi(e) : 25;
+		const int pct = s->rebalance_pct;
 		if (pct >= 0 && s->n > 1) {
 			const int rr = rb3gpu_shard_rebalance(s, pct);
 			if (rr < 0) r = rr;

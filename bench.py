@@ -574,6 +574,32 @@ def main():
                       "ratio_to_the_headline": round((a + b) / ((tot_h2d + tot_mrg) / args.steps), 3)}
         except Exception as e:
             refsig = {"error": repr(e)[:300]}
+    # rb3_fmi_merge (fm-index.c:251-277; `ropebwt3 merge`, and the tree step of `build --gpus N`): the index of the second half of the genomes
+    # merged into the index of the first half, both resident in HBM -- rb3gpu_merge_index(a, b): b's BWT expanded to 1 byte per symbol, walked
+    # through the reference's signature (VERDICT r4 item 8 asks for a walk that ranks on b's block array instead: not built)
+    mrg_idx = None
+    if not args.no_aux and K >= 4:
+        try:
+            half = K // 2
+            la, lb = BuildLoop(local_rank), BuildLoop(local_rank)
+            la.run(texts[:half], walkers[:half]), lb.run(texts[half:], walkers[half:])
+            la.h.sync(), lb.h.sync()
+            na, nb = la.h.get_tot(), lb.h.get_tot()
+            bytes_ab = la.h.stats()["bytes_index"] + lb.h.stats()["bytes_index"]
+            la.h.stats_reset()
+            t = time.perf_counter()
+            la.h.merge_index(lb.h)
+            e = time.perf_counter() - t
+            sa_ = la.h.stats()
+            md5m, _ = la.fmd_md5()
+            mrg_idx = {"workload": "rb3gpu_merge_index: the index of genomes %d..%d (%d symbols) merged into the index of genomes 0..%d (%d symbols), both in HBM" % (half, K - 1, nb, half - 1, na),
+                       "ms": round(e * 1e3, 3), "value": round(nb / e / 1e9, 4), "unit": "Gbp/s",
+                       "phases_ms": {"lf": round(sa_["ms_lf"], 3), "rank": round(sa_["ms_rank"], 3), "k_chain": round(sa_["ms_chain"], 3), "rebuild": round(sa_["ms_build"], 3)},
+                       "operands_bytes": int(bytes_ab), "handle_peak_bytes": int(sa_["bytes_peak"]), "peak_over_operands": round(sa_["bytes_peak"] / max(1, bytes_ab), 1),
+                       "rank_phase_fallbacks": int(sa_["n_fallbacks"]), "fmd_identical_to_reference": (md5m == gold["fmd_md5"]) if gold else None}
+            la.close(), lb.close()
+        except Exception as e:
+            mrg_idx = {"error": repr(e)[:300]}
     ident = (md5 == gold["fmd_md5"]) if gold else None
     if ident is False:
         log("ERROR: the .fmd differs from the reference's (md5 %s vs %s)" % (md5, gold["fmd_md5"]))
@@ -616,6 +642,8 @@ def main():
     }
     if refsig is not None:
         out["aux_mtb152_reference_signature"] = refsig
+    if mrg_idx is not None:
+        out["aux_merge_index"] = mrg_idx
     bl.close()
     if args.only == "headline":
         print(json.dumps(out), flush=True)

@@ -209,6 +209,26 @@ def parse_cli_stats(err):
 # ---------------------------------------------------------------------------------------------
 
 MTB_L = 4400000
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when a communicator is made, and a C
+    library's buffered output comes out when the process ends, i.e. BEHIND the line): from here on file descriptor 1 is stderr for everybody,
+    and emit_json() writes the line to the real stdout (its descriptor travels in the environment: ropebwt3_amd/multi.py imports this file as
+    a second module)."""
+    if "RB3_BENCH_STDOUT_FD" not in os.environ:
+        sys.stdout.flush()
+        os.environ["RB3_BENCH_STDOUT_FD"] = str(os.dup(1))
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    fd = os.environ.get("RB3_BENCH_STDOUT_FD")
+    if fd is None:
+        sys.stdout.write(line.decode()), sys.stdout.flush()
+    else:
+        os.write(int(fd), line)
+
+
 WALKER_STEP = 0      # 0: rb3gpu_walker_step (as many walkers as k_chain keeps resident: 230 text positions for a 4.4 Mbp genome on an MI355X)
 
 
@@ -494,6 +514,7 @@ def main():
     ap.add_argument("--walker-step", type=int, default=WALKER_STEP)
     ap.add_argument("--host-walkers", action="store_true", help="make the walker lists on the host before the timed steps (rb3h_walkers_text, rounds 2-4) instead of on the device inside the merge call")
     args = ap.parse_args()
+    protect_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -515,18 +536,18 @@ def main():
     torch.cuda.set_device(local_rank)
     mk = lambda: Rb3Gpu(device=local_rank, verbose=1)
     if args.only == "8g":
-        print(json.dumps(index_8g(args.index_8g, local_rank)), flush=True)
+        emit_json(index_8g(args.index_8g, local_rank))
         return
     if args.only in ("large", "reads", "cfg2"):
-        print(json.dumps(large_index_regime(mk, args.large_index, 1000000) if args.only == "large" else reads_regime(mk, args.aux_reads) if args.only == "reads" else
-                         cfg2_step(local_rank, 10, 3, args.genome_len, args.div)), flush=True)
+        emit_json(large_index_regime(mk, args.large_index, 1000000) if args.only == "large" else reads_regime(mk, args.aux_reads) if args.only == "reads" else
+                         cfg2_step(local_rank, 10, 3, args.genome_len, args.div))
         return
 
     K, L = args.mtb, args.genome_len
     gold = mtb_manifest(K, L)
     tmp, files, t_gen = mtb_files(K, L)
     if args.only == "cli":
-        print(json.dumps(cli_build(files, K, gold)), flush=True)
+        emit_json(cli_build(files, K, gold))
         return
     t0 = time.time()
     texts, walkers, keep = load_batches(files, pinned=not args.no_pinned, step=args.walker_step, device=local_rank, host_walkers=args.host_walkers)
@@ -646,7 +667,7 @@ def main():
         out["aux_merge_index"] = mrg_idx
     bl.close()
     if args.only == "headline":
-        print(json.dumps(out), flush=True)
+        emit_json(out)
         return
     if not args.no_cpu_baseline:
         cb = reference_prefix(files, args.mtb_ref_prefix, K)
@@ -689,7 +710,7 @@ def main():
         os.rmdir(tmp)
     except OSError:
         pass
-    print(json.dumps(out), flush=True)
+    emit_json(out)
 
 
 if __name__ == "__main__":

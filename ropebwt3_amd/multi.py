@@ -599,6 +599,15 @@ def interval_leg(args, h, dist, rank, world, dev, local_rank, shared_gpu, barrie
 
     return out
 
+def _emit(obj):
+    """the one JSON line of bench.py, on the real stdout (bench.protect_stdout)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    bench.emit_json(obj)
+
+
 def bench_main(args, rank, local_rank, world):
     """bench.py --gpus N (N > 1), one process per GPU.  --mode interval (default): north_star -- the index of a random genome
     is cut into N intervals, every step merges one batch of reads (N x 100 k reads of 150 bp, both strands: per-GPU work fixed)
@@ -665,7 +674,7 @@ def bench_main(args, rank, local_rank, world):
                    "config": {"workload": "one batch of %d genomes of %d bp merged into the index of G0, replicated on every GPU" % (world, args.genome_len),
                               "parallelism": "replicated%d: walkers sharded by text range, all-reduce(MAX) of pos[] (8 B per batch row), every GPU rebuilds its replica" % world}}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        _emit(out)
     h.close()
     dist.destroy_process_group()
 
@@ -773,7 +782,7 @@ def bench_partition_mtb(args, rank, local_rank, world):
         def give_up():
             if rank == 0 and not printed[0]:
                 out["aux_interval_reads"] = {"error": "the interval leg did not finish within %d s (first contact with a multi-GPU box?); the line above it stands" % aux_deadline}
-                print(json.dumps(out), flush=True)
+                _emit(out)
             os._exit(0)
 
         aux_deadline = int(os.environ.get("RB3_BENCH_AUX_DEADLINE", "300"))
@@ -795,7 +804,7 @@ def bench_partition_mtb(args, rank, local_rank, world):
             out["aux_interval_reads"] = aux
         if watchdog is not None:
             printed[0] = True
-        print(json.dumps(out), flush=True)
+        _emit(out)
     dist.barrier() if shared_gpu else barrier()   # (a rank whose leg failed waits here for the others -- or for the deadline)
     if watchdog is not None:
         watchdog.cancel()

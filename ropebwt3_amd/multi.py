@@ -458,6 +458,19 @@ class SoloComm(TorchComm):
         return np.asarray(vec, dtype=np.int64)[None, :].copy()
 
 
+def _reads_text(g, st, rng, read_len=150, err=0.01):
+    """the batch text of reads g[s : s + read_len] (s in st) with substitution errors, every read followed by its reverse complement, each with its
+    sentinel (io.c:84-102) -- tests.util.make_text on a list of reads, without a Python loop over millions of them"""
+    r = np.lib.stride_tricks.sliding_window_view(g, read_len)[st]   # (a copy: fancy indexing of the view)
+    k = int(rng.binomial(r.size, err))            # (the errors drawn as positions, not as a mask over every symbol: seconds per million reads)
+    r.reshape(-1)[rng.integers(0, r.size, size=k)] = rng.integers(1, 5, size=k, dtype=np.uint8)
+    n = r.shape[0]
+    out = np.zeros((n, 2, read_len + 1), dtype=np.uint8)
+    out[:, 0, :read_len] = r
+    out[:, 1, :read_len] = np.array([0, 4, 3, 2, 1, 5], dtype=np.uint8)[r[:, ::-1]]   # complement of the reversed read
+    return out.reshape(-1)
+
+
 def _solo_interval_reference(reads_per_gpu, args, dev, local_rank):
     """bench_main's interval workload at world size 1 with the per-GPU sizes of the multi-GPU run: index of 2^26 symbols in one
     interval, reads_per_gpu reads per step"""
@@ -475,10 +488,7 @@ def _solo_interval_reference(reads_per_gpu, args, dev, local_rank):
         h1.dev_free(d1), h1.dev_free(d1tw)
         h1.from_plain(b1)
         st = rng.integers(0, len(g) - 150, size=reads_per_gpu)
-        r = np.stack([g[s:s + 150] for s in st])
-        m = rng.random(r.shape) < 0.01
-        r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
-        t2 = util.make_text(list(r))
+        t2 = _reads_text(g, st, rng)
         d2, d2tw = h1.sort_text(t2)
         sent = np.flatnonzero(t2 == 0).astype(np.int64)
         from ropebwt3_amd import CommGroup
@@ -546,10 +556,7 @@ def interval_leg(args, h, dist, rank, world, dev, local_rank, shared_gpu, barrie
     bounds = interval_bounds(b1.size, world)
     h.from_plain(b1[bounds[rank]:bounds[rank + 1]])
     st = rng.integers(0, len(g) - 150, size=reads_per_gpu * world)
-    r = np.stack([g[s:s + 150] for s in st])
-    m = rng.random(r.shape) < 0.01
-    r[m] = rng.integers(1, 5, size=int(m.sum()), dtype=np.uint8)
-    t2 = util.make_text(list(r))
+    t2 = _reads_text(g, st, rng)
     d2, d2tw = h.sort_text(t2)
     sent = np.flatnonzero(t2 == 0).astype(np.int64)
     driver = getattr(args, "sh_driver", None) or os.environ.get("RB3_SH_DRIVER", "rccl")
@@ -785,7 +792,7 @@ def bench_partition_mtb(args, rank, local_rank, world):
                 _emit(out)
             os._exit(0)
 
-        aux_deadline = int(os.environ.get("RB3_BENCH_AUX_DEADLINE", "300"))
+        aux_deadline = int(os.environ.get("RB3_BENCH_AUX_DEADLINE", "420"))
         watchdog = threading.Timer(aux_deadline, give_up)
         watchdog.daemon = True
         watchdog.start()

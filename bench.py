@@ -487,6 +487,8 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["RB3_BENCH_SELF_LAUNCHED"] = "1"
+    env.pop("RB3_BENCH_STDOUT_FD", None)   # a descriptor number of THIS process means nothing in the ranks (close_fds): each rank saves its own stdout
+    sys.stdout.flush()
     return subprocess.call(cmd, env=env)
 
 
@@ -514,15 +516,21 @@ def main():
     ap.add_argument("--walker-step", type=int, default=WALKER_STEP)
     ap.add_argument("--host-walkers", action="store_true", help="make the walker lists on the host before the timed steps (rb3h_walkers_text, rounds 2-4) instead of on the device inside the merge call")
     args = ap.parse_args()
-    protect_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # (decided BEFORE file descriptor 1 is redirected: the ranks must inherit the real stdout, and each of them protects its own)
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))
+    protect_stdout()
     if world > 1:
         args.gpus = world
+    if os.environ.get("RB3_BENCH_LAUNCH_SELFTEST"):   # tests/test_cpu_host.py: the launch + stdout plumbing alone, no GPU touched
+        if rank == 0:
+            print("noise a library would write to stdout")   # (goes to stderr: descriptor 1 is protected)
+            emit_json({"selftest": "launch", "n_gpus": args.gpus, "world": world})
+        return
 
     import torch
     from ropebwt3_amd import Rb3Gpu

@@ -992,9 +992,12 @@ int main_build(int argc, char *argv[])
 			for (c = 0; c < n; ++c) {
 				rb3gpu_stats_t st;
 				if (rb3gpu_stats(rb3gpu_shard_handle(g_iv.s, c), &st) == 0)
-					fprintf(stderr, "[M::%s] interval %d on device %d: %ld symbols, index %.1f MB, peak device memory %.1f MB\n", __func__, c, g_iv.devices[c], (long)(bnd[c + 1] - bnd[c]), st.bytes_index / 1e6, st.bytes_peak / 1e6);
+					fprintf(stderr, "[M::%s] interval %d on device %d: %ld symbols, index %.1f MB, peak device memory %.1f MB; merge path: rank %.3f + rebuild %.3f ms\n", __func__, c, g_iv.devices[c], (long)(bnd[c + 1] - bnd[c]), st.bytes_index / 1e6, st.bytes_peak / 1e6, st.ms_rank, st.ms_build);
 			}
 		}
+		/* the writers are done: the rank threads, the handles of intervals 1 .. N-1 and the replicated buffers go BEFORE the caller's handle (interval 0),
+		   which the object points at */
+		rb3gpu_shard_destroy(g_iv.s), g_iv.s = 0;
 	} else if (opt.fmt == FMT_FMR) { /* build.c:245-260 */
 		ret = dump_fmr(h, &opt, stdout);
 	} else if (opt.fmt == FMT_FMD) {

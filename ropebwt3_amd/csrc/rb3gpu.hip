@@ -165,7 +165,7 @@ struct rb3gpu_s {
 	// (behind the grp_cap directory entries of a buffer sit grp_cap 8-byte words: the compact copy of the entries' slot words, IdxView.gsm)
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
-	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, dl, dlx, wstat, wplane, wruns, gslots, glist, pslots, lbst;
+	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, wls, dl, dlx, wstat, wplane, wruns, gslots, glist, pslots, lbst; // (wls: the sentinels' text positions of a device-made walker list -- a buffer of its own, NOT dlx, which tent_masks() hands out as the wide drop-out masks and may reallocate: ADVICE r5)
 	Buf shc, shn, shs, shr, shk; // interval-sharded merge (rb3gpu_sh_merge): states of this and of the next round, send regions, landed (row, insertion point) pairs, counters
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
@@ -573,7 +573,7 @@ static void guard_check(rb3gpu_t *h, const char *where)
 {
 	if (!h->tn.guard) return;
 	static const char *names[] = { "b2", "pos", "post", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist" };
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk };
 	uint8_t g[RB3_GUARD];
 	for (int i = 0; i < 20 + 4; ++i) {
 		const uint8_t *p = nullptr; size_t cap = 0; const char *name = "";
@@ -620,7 +620,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -1493,7 +1493,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if ((r = buf_ensure(h, h->wl, (size_t)n_walkers * 40)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	if (auto_list && (r = buf_ensure(h, h->xbuf, ((size_t)b2_nspmax * 4 + (size_t)b2_m2cap + 2 + (size_t)b2_nbk) * 8)) < 0) return r;
-	if (step_list && (r = buf_ensure(h, h->dlx, (size_t)n_strings * 8)) < 0) return r; // the sentinels' text positions (k_wl_sentinels)
+	if (step_list && (r = buf_ensure(h, h->wls, (size_t)n_strings * 8)) < 0) return r; // the sentinels' text positions (k_wl_sentinels)
 	rb3_stretch_t *tab = nullptr;
 	int32_t *sfin = nullptr;
 #ifdef RB3GPU_TEST_HOOKS
@@ -1581,7 +1581,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 				(const uint64_t*)lnk[cur], (const uint64_t*)slen, (const unsigned long long*)bucket, b2_nbk, (Walker*)h->wl.p, b2_nwalk, (const int64_t*)h->pos.p, b2W);
 	} else if (step_list) { // one walker per string and one every wstep text positions, made here (two small kernels in front of the walkers; on the side stream,
 		// beside the fill, they were measured in round 5: the wait for the event costs more than they take -- fill-to-walkers 6.0 -> 7.0 ms per 152-genome build)
-		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->dlx.p, (Walker*)h->wl.p);
+		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->wls.p, (Walker*)h->wl.p);
 	} else if (per_string && d_tw) {
 		HIPCHK(hipMemsetAsync(h->wl.p, 0xff, (size_t)n_walkers * 32, h->st)); // a walker that nobody fills in starts at row -1: caught below
 		hipLaunchKernelGGL(k_walkers_per_string, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw, len);
@@ -3473,11 +3473,11 @@ int rb3gpu_stats(const rb3gpu_t *h, rb3gpu_stats_t *st)
 
 int rb3gpu_buffer_bytes(const rb3gpu_t *h, int i, const char **name, int64_t *bytes)
 {
-	static const char *names[] = { "b2 (batch symbols)", "pos (row records)", "post (records in text order)", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg (rows per window)", "misc", "xbuf (scratch)", "wl (walker list)",
+	static const char *names[] = { "b2 (batch symbols)", "pos (row records)", "post (records in text order)", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg (rows per window)", "misc", "xbuf (scratch)", "wl (walker list)", "wls (sentinel positions of a device-made list)",
 		"dl (stretch table)", "dlx (wide masks)", "wstat", "wplane", "wruns", "gslots (run-space rebuild)", "glist", "pslots (plane-space rebuild)", "lbst", "shc", "shn", "shs", "shr", "shk" };
 	if (!h || !name || !bytes || i < 0) return RB3GPU_EINVAL;
 	rb3gpu_t *m = const_cast<rb3gpu_t*>(h);
-	Buf *all[] = { &m->b2, &m->pos, &m->post, &m->tcnt, &m->tpre, &m->ctot, &m->ctot2, &m->gstat, &m->gpre, &m->jg, &m->misc, &m->xbuf, &m->wl, &m->dl, &m->dlx, &m->wstat, &m->wplane, &m->wruns, &m->gslots, &m->glist, &m->pslots, &m->lbst,
+	Buf *all[] = { &m->b2, &m->pos, &m->post, &m->tcnt, &m->tpre, &m->ctot, &m->ctot2, &m->gstat, &m->gpre, &m->jg, &m->misc, &m->xbuf, &m->wl, &m->wls, &m->dl, &m->dlx, &m->wstat, &m->wplane, &m->wruns, &m->gslots, &m->glist, &m->pslots, &m->lbst,
 		&m->shc, &m->shn, &m->shs, &m->shr, &m->shk };
 	const int nb = (int)(sizeof(all) / sizeof(all[0]));
 	static_assert(sizeof(all) / sizeof(all[0]) == sizeof(names) / sizeof(names[0]), "a name per buffer");

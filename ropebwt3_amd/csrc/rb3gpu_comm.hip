@@ -339,6 +339,8 @@ struct rb3gpu_shard_s {
 	unsigned long gen = 0;
 	int done = 0, quit = 0, n_threads = 0;
 	int n_rebalanced = 0;
+	int n_rebalance_skipped = 0; // rebalances given up before anything was touched (no memory for the new ranges): the intervals stayed as they were
+	int verbose = 1;
 	int rebalance_pct = 25;   // RB3GPU_SHARD_REBALANCE_PCT, read once when the object is made (25: SURVEY 8(e); -1: never; 0: whenever the shares differ at all -- tests)
 	ShardJob job[RB3GPU_SH_MAXIV];
 };
@@ -452,6 +454,7 @@ rb3gpu_shard_t *rb3gpu_shard_split(rb3gpu_t *h0, int n, const int *devices, cons
 	rb3gpu_shard_s *s = new (std::nothrow) rb3gpu_shard_s;
 	if (!s) return nullptr;
 	s->n = n;
+	s->verbose = opt->verbose;
 	{ const char *e = getenv("RB3GPU_SHARD_REBALANCE_PCT"); if (e && *e) s->rebalance_pct = atoi(e); }
 	pthread_mutex_init(&s->mtx, nullptr);
 	pthread_cond_init(&s->cv, nullptr);
@@ -606,10 +609,19 @@ int rb3gpu_shard_rebalance(rb3gpu_shard_t *s, int pct)
 			(void)rb3gpu_dev_free(s->h[i], tmp);
 		}
 	}
+	if (r < 0) {
+		// Nothing has been touched yet: the old handles hold the whole index with the old bounds.  The rebalance is an optimisation of a build whose
+		// merge has already succeeded, so running out of memory HERE -- exactly when one device is fuller than the rest -- means "not rebalanced",
+		// not "give the build up" (ADVICE r5): free what was collected, keep the bounds, say so at verbose >= 2.
+		for (int j = 0; j < n; ++j) if (plain[j]) (void)rb3gpu_dev_free(s->h[j], plain[j]);
+		if (s->verbose >= 2) fprintf(stderr, "[W::rb3gpu_shard_rebalance] could not collect the new ranges (error %d): the intervals stay as they are\n", r);
+		++s->n_rebalance_skipped;
+		return 0;
+	}
 	// phase 2: every handle rebuilt from its new range
 	for (int j = 0; j < n && r == 0; ++j) r = rb3gpu_from_plain_dev(s->h[j], nb[j + 1] - nb[j], (const uint8_t*)plain[j]);
 	for (int j = 0; j < n; ++j) if (plain[j]) (void)rb3gpu_dev_free(s->h[j], plain[j]);
-	if (r < 0) return r; // (the index is lost: the caller gives the build up)
+	if (r < 0) return r; // (a handle has been rebuilt and another could not be: the index is lost, the caller gives the build up)
 	memcpy(s->bounds, nb, (size_t)(n + 1) * 8);
 	if ((r = rb3gpu_shard_get_acc(s, acc1)) < 0) return r;
 	for (int c = 0; c <= RB3GPU_ASIZE; ++c) if (acc0[c] != acc1[c]) return RB3GPU_EINTERNAL; // (the symbols the intervals held, no more and no fewer)

@@ -785,12 +785,15 @@ def bench_partition_mtb(args, rank, local_rank, world):
         import threading
 
         printed = [False]
+        emit_lock = threading.Lock()   # the line is written exactly once: by the deadline or by the main thread, never by both and never by neither
 
         def give_up():
-            if rank == 0 and not printed[0]:
-                out["aux_interval_reads"] = {"error": "the interval leg did not finish within %d s (first contact with a multi-GPU box?); the line above it stands" % aux_deadline}
-                _emit(out)
-            os._exit(0)
+            with emit_lock:
+                if rank == 0 and not printed[0]:
+                    out["aux_interval_reads"] = {"error": "TIMED OUT: the interval leg did not finish within %d s (first contact with a multi-GPU box?); the line above it stands" % aux_deadline, "timed_out": True}
+                    _emit(out)
+                    printed[0] = True
+                os._exit(3 if rank != 0 else 0)   # (rank 0 has delivered the main measurement; the other ranks report that they were cut off)
 
         aux_deadline = int(os.environ.get("RB3_BENCH_AUX_DEADLINE", "420"))
         watchdog = threading.Timer(aux_deadline, give_up)
@@ -810,9 +813,13 @@ def bench_partition_mtb(args, rank, local_rank, world):
         if aux is not None:
             out["aux_interval_reads"] = aux
         if watchdog is not None:
-            printed[0] = True
-        _emit(out)
-    dist.barrier() if shared_gpu else barrier()   # (a rank whose leg failed waits here for the others -- or for the deadline)
+            with emit_lock:
+                if not printed[0]:
+                    _emit(out)
+                    printed[0] = True
+        else:
+            _emit(out)
+    dist.barrier() if shared_gpu else barrier()   # (a rank whose leg failed waits here for the others -- or for the deadline: the timer stays armed, it no longer writes anything)
     if watchdog is not None:
         watchdog.cancel()
     bl.close()

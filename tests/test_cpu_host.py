@@ -375,3 +375,21 @@ def test_parallel_host_sorter_equals_sais(monkeypatch):
     monkeypatch.delenv("RB3H_PSORT_FORCE64")
     monkeypatch.setenv("RB3H_PSORT_MEM_LIMIT", "1000000")   # less memory than the parallel sorter needs: it declines BEFORE allocating, SA-IS takes the batch
     assert np.array_equal(host.build_bwt(cases[0], 1), host.build_bwt(cases[0], 4))
+
+
+def test_bench_self_launch_prints_exactly_one_json_line():
+    """`python bench.py --gpus 2` WITHOUT a launcher: the parent starts the ranks itself (torch.distributed.run); rank 0's
+    JSON line must arrive on the parent's stdout -- exactly one line, nothing else -- whatever libraries print (the ranks redirect their own
+    descriptor 1; the parent's saved descriptor number must not leak into them).  RB3_BENCH_LAUNCH_SELFTEST stops the ranks before they touch a GPU."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RB3_BENCH_LAUNCH_SELFTEST="1")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    env["RB3_BENCH_STDOUT_FD"] = "987"   # a stale descriptor number in the environment (what round 5's parent leaked) must not matter either
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["selftest"] == "launch" and d["world"] == 2 and d["n_gpus"] == 2
+    assert "noise a library would write" in r.stderr and "noise" not in r.stdout

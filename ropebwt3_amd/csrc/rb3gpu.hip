@@ -109,7 +109,7 @@ struct Tune {
 	int resolve_v1 = 0;      // settle the tentative stretches with k_resolve (one hop per stretch) instead of k_cum / k_resolve_w / k_sfin
 	int reb_force = 0;       // the run-space rebuild whatever the row density and the old index look like (tests: the hand-over paths)
 	int octs = 8;            // octets per wave of k_chain
-	int lpw = 8;             // lanes per walker of k_chain in the single-sync merge: 8 (an octet) or 4 (a quad, 16 walkers per wave; builds with -DRB3_WITH_QUADS only)
+	int lpw = 8;             // (lanes per walker of k_chain: an octet.  The key is still accepted; the quad variant of rounds 2-5 is gone)
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
 	int trec = -1;           // records of a text-order walk in text order (needs the batch's suffix array): 1 always, 0 never, -1: where the index does not fit the caches
@@ -433,7 +433,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "reb_force")) t.reb_force = v != 0;
 	else if (!strcmp(key, "resolve_v1")) t.resolve_v1 = v != 0;
 	else if (!strcmp(key, "octs")) t.octs = v < 1 ? 1 : v > 8 ? 8 : (int)v;
-	else if (!strcmp(key, "lpw")) t.lpw = v == 4 ? 4 : 8;
+	else if (!strcmp(key, "lpw")) t.lpw = 8;
 	else if (!strcmp(key, "blkmul")) t.blkmul = v < 1 ? 1 : (int)v;
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
 	else if (!strcmp(key, "chain_bs")) t.chain_bs = v == 64 ? 64 : v == 128 ? 128 : 256;
@@ -1616,15 +1616,9 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	int64_t *jmet = tent && d_tw != nullptr && !auto_list ? (int64_t*)((char*)h->wl.p + (size_t)n_walkers * 32) : nullptr;
 	{
 		const IdxView iv = view_of(h);
-		// lanes per walker: an octet, or a QUAD (16 walkers share a wave's instruction stream; every lane takes two slices of a slot).  Quads exist for
-		// the headline's kernel (run-coded index, tentative records, text-order words, 32-bit positions); all kernels only in a -DRB3_WITH_QUADS build.
-		const bool quad_ok = iv.dense != 2 && tent && d_tw != nullptr && n_walkers <= 65536 && iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29);
-#ifdef RB3_WITH_QUADS
-		const int lpw = h->tn.lpw;
-#else
-		const int lpw = h->tn.lpw == 4 && quad_ok ? 4 : 8;
-#endif
-		const int octs = h->tn.octs * (8 / lpw); // groups of lpw lanes per wave
+		// lanes per walker: an octet.  (A QUAD per walker -- 16 walkers per wave, every lane two slices of a slot -- existed in rounds 2-5 and was slower in every
+		// regime, 147 against 86 ms of k_chain per 152-genome build when last measured (round 6); it went when the run codes became cumulative ends.)
+		const int octs = h->tn.octs; // octets per wave that take walkers
 		const int64_t n_expect = auto_list ? b2_nbk + 64 : n_walkers; // (a device-made list: capacity >> walkers; size the launch for the walkers)
 		int64_t nblk = (n_expect + 4 * octs - 1) / (4 * octs) * h->tn.blkmul;
 		// persistent waves: 2048 blocks x 4 waves fill the chip once (256 CUs x 32); more blocks only queue behind them (measured: 10 % slower at 4096)
@@ -1641,11 +1635,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 #endif
 #define RB3_LAUNCH_FAST1(D, T, X, W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, D, T, X, W>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0, \
 			(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG, jmet)
-#ifdef RB3_WITH_QUADS /* a quad per walker (k_chain<..., 4>) was measured slower in every regime: compiled in on request only */
-#define RB3_LAUNCH_FAST(D, T, X) do { if (lpw == 4) RB3_LAUNCH_FAST1(D, T, X, 4); else RB3_LAUNCH_FAST1(D, T, X, 8); } while (0)
-#else
 #define RB3_LAUNCH_FAST(D, T, X) RB3_LAUNCH_FAST1(D, T, X, 8)
-#endif
 		// text-order words: per-lane loads while the L1 can hold a line per walker (256 CUs x 32 waves x 8 octets), else 64-byte fetches
 		int text_mode = !d_tw ? 0 : n_walkers <= 65536 ? 1 : 2;
 #ifdef RB3GPU_TEST_HOOKS
@@ -1663,11 +1653,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		case 0: RB3_LAUNCH_FAST(false, false, 0); break;
 		case 8: RB3_LAUNCH_FAST(false, true, 2); break;
 		case 7: // (the headline's kernel: 32-bit positions in the common step where index and batch allow it)
-			if (iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29) && lpw == 8)
+			if (iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29))
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 8, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
-					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG, jmet);
-			else if (quad_ok && lpw == 4)
-				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 4, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
 					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG, jmet);
 			else RB3_LAUNCH_FAST(false, true, 1);
 			break;

@@ -223,13 +223,14 @@ __device__ __forceinline__ void oct_rank_issue(const IdxView &ix, int64_t k, int
 	oct_rank_issue_slot(ix, j, r);
 }
 
-/* The same count with packed 16-bit arithmetic (v_pk_*): run lengths (<= 8192) and offsets inside a slot fit 16 bits, so
- * the six codes of a lane are three dwords processed two at a time -- about half the vector instructions of slice_count,
- * and the second offset of an interval that lies in the same slot comes almost for free.  A lone wave issues one vector
- * instruction every ~4 cycles, so on the LF chain instruction count IS latency.  Unused codes (sym 7, "length" 1) sit
- * behind the last used one: their positions are past every valid offset and their symbol never equals c, so they need no
- * special case here.  cnt = #{i < off : sym_i == c} for this lane's share of the slot; match_a != 0 in the lane that holds the
- * symbol AT off_a if that symbol is c. */
+/* Counting in a run slot with packed 16-bit arithmetic (v_pk_*).  A run code is (end - 1) << 3 | sym with `end` the offset, from the
+ * slot start, just past the run (rb3gpu_layout.h: CUMULATIVE ends since round 6; rounds 1-5 stored lengths).  The run of a code
+ * therefore covers [end of the code before it, its own end): a lane gets the starts of its six runs from its own three dwords and
+ * ONE cross-lane read (the last end of the lane below; 0 in lane 0) where lengths needed their sum, a six-step exclusive scan over the
+ * octet and a running base -- about 25 vector instructions and the scan's dependent DPP chain less per rank (the walkers' step is bound by
+ * instruction issue and by the length of its own dependent chain).  Unused codes (sym 7) sit behind the last used one and repeat its
+ * end: empty runs whose symbol never equals c.  Offsets and ends are <= 8192: every quantity fits 16 bits unsigned.
+ * cnt = #{i < off : sym_i == c} for this lane's share of the slot: sum over its runs of c of max(min(off, end) - start, 0). */
 typedef short rb3_s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short rb3_u16x2 __attribute__((ext_vector_type(2)));
 
@@ -241,7 +242,7 @@ __device__ __forceinline__ uint32_t pk_sum16(uint32_t v, uint32_t add) // add + 
 	return __builtin_amdgcn_udot2(__builtin_bit_cast(rb3_u16x2, v), __builtin_bit_cast(rb3_u16x2, 0x00010001u), add, false);
 }
 
-/* packed unsigned 16-bit helpers of the run-slot decode (offsets and run lengths inside a slot are < 2^15):
+/* packed unsigned 16-bit helpers of the run-slot decode:
  * pk_subsat: a > b ? a - b : 0 per half (v_pk_sub_u16 clamp -- subtraction and the clamp at 0 in one instruction);
  * pk_dot: add + a.lo * b.lo + a.hi * b.hi (v_dot2_u32_u16 -- with b in {0, 1} per half: mask and sum in one instruction) */
 __device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b)
@@ -256,76 +257,87 @@ __device__ __forceinline__ uint32_t pk_dot(uint32_t a, uint32_t b, uint32_t add)
 {
 	return __builtin_amdgcn_udot2(__builtin_bit_cast(rb3_u16x2, a), __builtin_bit_cast(rb3_u16x2, b), add, false);
 }
+/* the exclusive ends of the two codes of a dword: (code >> 3) + 1 per half */
+__device__ __forceinline__ uint32_t pk_ends(uint32_t w)
+{
+	return as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, w) >> 3) + as_s16x2(0x00010001u));
+}
+/* the high half of v in the lane below of the octet, in the HIGH half of the result; 0 in octet lane 0 (DPP row_shr:1 hands lane 8 of a
+ * row the value of lane 7 -- the other octet --, hence the select) */
+__device__ __forceinline__ uint32_t oct_prev_end(uint32_t v, int j)
+{
+	const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); // row_shr:1, lanes shifted in from outside the row: 0
+	return j ? t : 0u;
+}
+/* starts of the two runs of a dword whose ends are `e`, given the ends `below` of the dword before it (only its high half counts) */
+__device__ __forceinline__ uint32_t pk_starts(uint32_t e, uint32_t below)
+{
+	return __builtin_amdgcn_alignbit(e, below, 16); // (e.lo << 16) | below.hi
+}
 
+/* a dword of two run codes with its unused ones (sym 7) set to "ends at `total`" (writers: the codes behind the last run repeat its end) */
+__device__ __forceinline__ uint32_t run_fill_unused(uint32_t w, uint32_t total)
+{
+	const uint32_t u = RB3_RUN_CODE(total, 7u);
+	if ((w & 7u) == 7u) w = (w & 0xFFFF0000u) | u;
+	if ((w >> 16 & 7u) == 7u) w = (w & 0x0000FFFFu) | u << 16;
+	return w;
+}
+
+/* cnt_a / cnt_b: the runs of c below off_a / off_b (TWO).  MATCH: *match_a = 1 in the lane that holds the symbol AT off_a if that symbol
+ * is c, else 0 -- the count at off_a + 1 minus the count at off_a. */
 template<bool TWO, bool MATCH, int LPW = 8>
 __device__ __forceinline__ void slice_count_pk(const uint4 &sl, const uint4 &sl2, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b, uint32_t *match_a)
 {
-	// an octet lane holds slice j of the slot (6 codes), a quad lane slices 2j and 2j+1 (12 consecutive codes)
-	constexpr int NW = LPW == 4 ? 6 : 3;
-	const uint32_t w[6] = { sl.y, sl.z, sl.w, sl2.y, sl2.z, sl2.w };
-	uint32_t lw[NW];
-	uint32_t tot = 0;
+	static_assert(LPW == 8, "an octet per slot (the quad variant of rounds 2-5 was slower in every regime and went with the length codes)");
+	(void)sl2;
+	const uint32_t w[3] = { sl.y, sl.z, sl.w };
+	uint32_t e[3], st[3];
 #pragma unroll
-	for (int k = 0; k < NW; ++k) {
-		lw[k] = as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, w[k]) >> 3) + as_s16x2(0x00010001u)); // run lengths of the two codes (<= 8192)
-		tot = pk_sum16(lw[k], tot);
-	}
-	uint32_t base = grp_exscan<LPW>(tot, j);
+	for (int k = 0; k < 3; ++k) e[k] = pk_ends(w[k]);
+	st[0] = pk_starts(e[0], oct_prev_end(e[2], j)), st[1] = pk_starts(e[1], e[0]), st[2] = pk_starts(e[2], e[1]);
 	const uint32_t csplat = (uint32_t)c * 0x00010001u;
-	// (offsets are unsigned here: 0 <= off <= the slot's symbols; every start offset and run length is below 2^15)
-	const uint32_t ua = (uint32_t)off_a * 0x00010001u, ub = (uint32_t)off_b * 0x00010001u;
-	uint32_t acc_a = 0, acc_b = 0;
-	uint32_t mt = 0;
+	// (offsets are unsigned here: 0 <= off <= the slot's symbols <= 8192)
+	const uint32_t ua = (uint32_t)off_a * 0x00010001u, ub = (uint32_t)off_b * 0x00010001u, um = ua + 0x00010001u;
+	uint32_t acc_a = 0, acc_b = 0, acc_m = 0;
 #pragma unroll
-	for (int k = 0; k < NW; ++k) {
-		const uint32_t P = base * 0x00010001u + (lw[k] << 16); // start offsets: (base, base + len of the first code)
+	for (int k = 0; k < 3; ++k) {
 		// 1 in the halves whose symbol is c: x in 0..7 per half, 1 -sat- x is 1 iff x == 0
 		const uint32_t eq1 = pk_subsat(0x00010001u, (w[k] & 0x00070007u) ^ csplat);
-		// symbols of each run below the offset: min(max(off - start, 0), length); those of the runs of c summed by the dot product
-		acc_a = pk_dot(pk_minu(pk_subsat(ua, P), lw[k]), eq1, acc_a);
-		if (MATCH) { // the code that holds offset off_a itself: 0 <= off_a - start < length, i.e. clamping to [0, length - 1] changes nothing
-			const rb3_s16x2 ta = as_s16x2(ua) - as_s16x2(P), Lk = as_s16x2(lw[k]), zero = as_s16x2(0u), one = as_s16x2(0x00010001u);
-			const uint32_t y = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(ta, zero), Lk - one)) ^ as_u32(ta);
-			const uint32_t nz = ((y | ((y & 0x7FFF7FFFu) + 0x7FFF7FFFu)) >> 15) & 0x00010001u; // 1 in the halves where y != 0
-			mt |= (nz ^ 0x00010001u) & eq1;
-		}
-		if (TWO) acc_b = pk_dot(pk_minu(pk_subsat(ub, P), lw[k]), eq1, acc_b);
-		base = pk_sum16(lw[k], base);
+		acc_a = pk_dot(pk_subsat(pk_minu(ua, e[k]), st[k]), eq1, acc_a);
+		if (MATCH) acc_m = pk_dot(pk_subsat(pk_minu(um, e[k]), st[k]), eq1, acc_m);
+		if (TWO) acc_b = pk_dot(pk_subsat(pk_minu(ub, e[k]), st[k]), eq1, acc_b);
 	}
 	*cnt_a = acc_a;
 	if (TWO) *cnt_b = acc_b;
-	if (MATCH) *match_a = mt;
+	if (MATCH) *match_a = acc_m - acc_a;
 }
 
 /* The two ends of an interval that lie in two (neighbouring) run slots, through ONE instruction stream: off_a is counted in
  * slice sa, off_b in slice sb.  An interval of up to 255 rows against slots of 512+ symbols straddles a slot boundary in one
  * step out of five or ten, and with eight walkers per wave some walker does in a third of the wave's iterations; giving that
- * walker two single decodes made the whole wave run ~300 more instructions.  The two exclusive scans over the octet share
- * their DPP steps (two 16-bit fields).  cnt = #{i < off : sym_i == c}, this lane's share. */
+ * walker two single decodes made the whole wave run ~300 more instructions.  cnt = #{i < off : sym_i == c}, this lane's share. */
 template<int LPW = 8>
 __device__ __forceinline__ void slice_count_pk2(const uint4 &sa, const uint4 &sa2, const uint4 &sb, const uint4 &sb2, int off_a, int off_b, int c, int j, uint32_t *cnt_a, uint32_t *cnt_b)
 {
-	constexpr int NW = LPW == 4 ? 6 : 3; // (a quad lane holds two slices of each slot: 12 codes)
-	const uint32_t wa[6] = { sa.y, sa.z, sa.w, sa2.y, sa2.z, sa2.w }, wb[6] = { sb.y, sb.z, sb.w, sb2.y, sb2.z, sb2.w };
-	uint32_t la[NW], lb[NW], ta = 0, tb = 0;
+	static_assert(LPW == 8, "an octet per slot");
+	(void)sa2, (void)sb2;
+	const uint32_t wa[3] = { sa.y, sa.z, sa.w }, wb[3] = { sb.y, sb.z, sb.w };
+	uint32_t ea[3], eb[3];
 #pragma unroll
-	for (int k = 0; k < NW; ++k) {
-		la[k] = as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, wa[k]) >> 3) + as_s16x2(0x00010001u));
-		lb[k] = as_u32(__builtin_bit_cast(rb3_s16x2, __builtin_bit_cast(rb3_u16x2, wb[k]) >> 3) + as_s16x2(0x00010001u));
-		ta = pk_sum16(la[k], ta), tb = pk_sum16(lb[k], tb);
-	}
-	const uint32_t base2 = grp_exscan<LPW>(ta | tb << 16, j); // (a slot covers at most 8192 symbols + 48 unused codes: no carry between the fields)
-	uint32_t base_a = base2 & 0xFFFFu, base_b = base2 >> 16;
+	for (int k = 0; k < 3; ++k) ea[k] = pk_ends(wa[k]), eb[k] = pk_ends(wb[k]);
+	// (the two "ends of the lane below" travel in one DPP read: the high halves of ea[2] and eb[2])
+	const uint32_t pv = oct_prev_end(__builtin_amdgcn_perm(eb[2], ea[2], 0x07060302u), j); // hi(ea[2]) | hi(eb[2]) << 16
+	const uint32_t sta[3] = { pk_starts(ea[0], pv << 16), pk_starts(ea[1], ea[0]), pk_starts(ea[2], ea[1]) };
+	const uint32_t stb[3] = { pk_starts(eb[0], pv), pk_starts(eb[1], eb[0]), pk_starts(eb[2], eb[1]) };
 	const uint32_t csplat = (uint32_t)c * 0x00010001u;
 	const uint32_t ua = (uint32_t)off_a * 0x00010001u, ub = (uint32_t)off_b * 0x00010001u; // (unsigned offsets: see slice_count_pk)
 	uint32_t acc_a = 0, acc_b = 0;
 #pragma unroll
-	for (int k = 0; k < NW; ++k) {
-		const uint32_t Pa = base_a * 0x00010001u + (la[k] << 16), Pb = base_b * 0x00010001u + (lb[k] << 16);
+	for (int k = 0; k < 3; ++k) {
 		const uint32_t eqa = pk_subsat(0x00010001u, (wa[k] & 0x00070007u) ^ csplat), eqb = pk_subsat(0x00010001u, (wb[k] & 0x00070007u) ^ csplat);
-		acc_a = pk_dot(pk_minu(pk_subsat(ua, Pa), la[k]), eqa, acc_a);
-		acc_b = pk_dot(pk_minu(pk_subsat(ub, Pb), lb[k]), eqb, acc_b);
-		base_a = pk_sum16(la[k], base_a), base_b = pk_sum16(lb[k], base_b);
+		acc_a = pk_dot(pk_subsat(pk_minu(ua, ea[k]), sta[k]), eqa, acc_a);
+		acc_b = pk_dot(pk_subsat(pk_minu(ub, eb[k]), stb[k]), eqb, acc_b);
 	}
 	*cnt_a = acc_a, *cnt_b = acc_b;
 }
@@ -354,7 +366,7 @@ __device__ __forceinline__ uint32_t slice_count(const uint4 &sl, const uint4 &sl
 	} else { // run codes, two at a time
 		uint32_t cb, mt;
 		slice_count_pk<false, MATCH, LPW>(sl, sl2, (int)off, (int)off, c, j, &cnt, &cb, &mt);
-		if (MATCH && mt) cnt |= RB3_MATCH_BIT;
+		if (MATCH) cnt |= mt << 20; // (RB3_MATCH_BIT: 0 or 1 from at most one lane of the octet)
 	}
 	return cnt;
 }
@@ -920,20 +932,14 @@ __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, 
 				if (sh && wi + 1 >= 0 && wi + 1 < NW && (nm >> (32 - sh))) atomicOr(&D[wi + 1], nm >> (32 - sh));
 			}
 		}
-	} else { // six run codes per lane
-		uint32_t tot = 0;
+	} else { // six run codes per lane; run i covers [the end of the code before it, its own end) -- unused codes repeat the last end: empty
+		int pos = (int)(oct_prev_end(pk_ends(sl.w), j) >> 16);
 #pragma unroll
 		for (int i = 0; i < 6; ++i) {
 			const uint32_t word = i < 2 ? sl.y : i < 4 ? sl.z : sl.w, e = (i & 1) ? word >> 16 : word & 0xFFFFu;
-			tot += (e & 7u) == 7u ? 0u : (e >> 3) + 1u;
-		}
-		int pos = (int)oct_exscan(tot, j);
-#pragma unroll
-		for (int i = 0; i < 6; ++i) {
-			const uint32_t word = i < 2 ? sl.y : i < 4 ? sl.z : sl.w, e = (i & 1) ? word >> 16 : word & 0xFFFFu;
-			const int len = (e & 7u) == 7u ? 0 : (int)(e >> 3) + 1;
-			if ((int)(e & 7u) != c && len != 0) {
-				int a = pos - off0, b = pos + len - off0; // index range of this run
+			const int end = (int)(e >> 3) + 1;
+			if ((int)(e & 7u) != c && (e & 7u) != 7u && end > pos) {
+				int a = pos - off0, b = end - off0; // index range of this run
 				a = a < 0 ? 0 : a, b = b > kk ? kk : b;
 				if (a < b) { // (nearly always one row of one word: a relative that dropped out)
 					int w = a >> 5;
@@ -943,7 +949,7 @@ __device__ __forceinline__ void drops_from_slot(const uint4 &sl, uint32_t hdr0, 
 					for (++w; w <= wl && w < NW; ++w) atomicOr(&D[w], w == wl && x1l < 32 ? (1u << x1l) - 1u : 0xFFFFFFFFu);
 				}
 			}
-			pos += len;
+			pos = end;
 		}
 	}
 }
@@ -1054,7 +1060,8 @@ __global__ void __launch_bounds__(256) k_events(IdxView ix, rb3_stretch_t *tab, 
  * 2^29 rows in the batch -- so that the step's arithmetic is 32-bit and its addresses are a base and a 32-bit offset */
 template<bool LIST, bool DENSE, bool TENT, int TEXT, int LPW = 8, bool I32 = false>
 #ifndef RB3_CHAIN_WPE
-#define RB3_CHAIN_WPE 1 /* (kernel experiment: waves per SIMD the register allocation must leave room for) */
+#define RB3_CHAIN_WPE 5 /* waves per SIMD the register allocation must leave room for: 96 registers.  (Round 6: with the event queue the allocator takes 102 when left
+                           alone -- four waves per SIMD; held to 96 it spills ONE pair, outside the loops.  6 -- 80 registers -- spills inside the common step: slower, round 5) */
 #endif
 __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_t *row, int64_t n2, int64_t m2,
 		int logM, const Walker *wl, int64_t nwalk_arg, int64_t stop_row, int64_t *arrive, unsigned long long *qhead, unsigned long long *nsteps, int octs,
@@ -1084,6 +1091,31 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
 	// it hosts: the host may enable only the first `octs` octets of each wave and launch more waves.
 	if (lane / LPW >= octs) return; // (octs counts groups of LPW lanes)
+	// The EVENT QUEUE of the common step (round 6).  A drop-out event is three stores by one lane of the octet (the stretch record, the walker's first
+	// stretch, the child word of the stretch before), in a branch region of their own, two wave iterations in three late in a pangenome build; and what
+	// is asked for behind a written-through store waits for its acknowledgement (vmcnt counts in order): the directory words of the NEXT step.  The
+	// event is now noted in LDS -- entry (octet, iteration & 7), written by octet lane 0 -- and goes out with the records of its window of eight
+	// iterations, every lane one entry, in front of them (a record never names a stretch whose event is not on its way): seven steps in eight issue no
+	// store at all, and an event costs three store instructions per wave and window instead of three per octet and event.
+	constexpr bool EVQ = LIST && !DENSE && TENT && TEXT == 1 && LPW == 8;
+	__shared__ uint4 evq_[EVQ ? 512 : 1]; // entry t: evq_[2t] = w0, w1 of the stretch record; evq_[2t + 1].x = the new stretch id (-1: no event), .y = 1 + the walker's first stretch
+	if (EVQ) evq_[2 * threadIdx.x + 1].x = 0xFFFFFFFFu;
+	auto evq_flush = [&]() { // every lane its own entry: (octet lane >> 3, iteration & 7 == lane & 7)
+		if (EVQ) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (entries are written by other lanes of this wave: program order is all the LDS needs)
+			const int ns = (int)evq_[2 * threadIdx.x + 1].x;
+			if (ns >= 0) {
+				const uint32_t first1 = evq_[2 * threadIdx.x + 1].y;
+				const uint4 e = evq_[2 * threadIdx.x];
+				const int prev = (int)(e.y >> (RB3_TENT_PBITS - 32)) & (RB3_TENT_IDS - 1);
+				*(uint4*)&tab[ns].w0 = e;
+				tab[ns].pad[0] = first1;
+				tab[prev].child = ns + 1;
+				evq_[2 * threadIdx.x + 1].x = 0xFFFFFFFFu;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		}
+	};
 	const int64_t myoct = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * octs + lane / LPW, noct = (int64_t)gridDim.x * (blockDim.x >> 6) * octs;
 	bool firstpull = true;
 	const int64_t M = logM > 0 ? (1LL << logM) : 0;
@@ -1139,6 +1171,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				wid = noct + (int64_t)((uint64_t)w1 << 32 | w0);
 			}
 			if (wid >= nwalk) {
+				evq_flush();
 				if (bkb >= 0) rec_pos<TENT && !LIST>(&row[bkb], bval, vis);
 				break;
 			}
@@ -1226,7 +1259,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 #ifdef RB3_PROF_STEP /* kernel experiment: where does an iteration of the common step spend its cycles?  (s_memtime at four points) */
 					const uint64_t pt0 = __builtin_amdgcn_s_memtime();
 #endif
-					if ((++it & (uint32_t)(LPW - 1)) == 0 && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; } // (only after general steps: this body flushes at the end of a window)
+					++it; // (both kinds of step flush the records and events of a window of eight iterations at its end: nothing is left over from a general step)
 					const int c = (int)cq;
 					// round trip 1: the slot word of lo's group from the compact copy (an L2 hit); the 64-byte entry's count for c is asked
 					// for at the same time but only needed at the very end
@@ -1309,7 +1342,10 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 #endif
 					// the records of the last eight steps go out here, where nothing is asked for during the whole decode: the store is slow
 					// (written through) and whatever is asked for after it waits for its acknowledgement (vmcnt counts in order)
-					if ((it & (uint32_t)(LPW - 1)) == (uint32_t)(LPW - 1) && bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
+					if ((it & (uint32_t)(LPW - 1)) == (uint32_t)(LPW - 1)) { // (the events of the window in front of its records)
+						evq_flush();
+						if (bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
+					}
 #ifdef RB3_PROF_STEP
 					asm volatile("s_nop 0" :: "v"(rl.sl.x));
 					const uint64_t pt2 = __builtin_amdgcn_s_memtime(); // the slot has arrived
@@ -1356,9 +1392,17 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 							ns = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
 						}
 						if (j == 0 && ns != RB3_TENT_POISON) {
-							tab[ns].w0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), tab[ns].w1 = kq | (uint64_t)c << 16 | (uint64_t)tp << RB3_EV_TP_SHIFT;
-							tab[ns].pad[0] = (uint32_t)sid0 + 1u;
-							tab[sid].child = ns + 1;
+							const uint64_t ew0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, lo), ew1 = kq | (uint64_t)c << 16 | (uint64_t)tp << RB3_EV_TP_SHIFT;
+							if (EVQ) { // noted in LDS; it goes out with the records of this window (evq_flush)
+								const uint32_t qi = (threadIdx.x & ~7u) + (it & 7u);
+								evq_[2 * qi] = make_uint4((uint32_t)ew0, (uint32_t)(ew0 >> 32), (uint32_t)ew1, (uint32_t)(ew1 >> 32));
+								*(uint2*)&evq_[2 * qi + 1] = make_uint2((uint32_t)ns, (uint32_t)sid0 + 1u);
+								__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+							} else {
+								tab[ns].w0 = ew0, tab[ns].w1 = ew1;
+								tab[ns].pad[0] = (uint32_t)sid0 + 1u;
+								tab[sid].child = ns + 1;
+							}
 						}
 						sid = ns;
 					}
@@ -1396,7 +1440,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 #ifdef RB3_PROF_STEP
 			prof_last = 0;
 #endif
-			if ((++it & (uint32_t)(LPW - 1)) == 0 && bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
+			++it;
 			pf_g = 0x80000000u;
 			bool met = TEXT ? (int64_t)rc >= 0 : (int64_t)x >= 0;  // this row already carries a record
 #ifdef RB3GPU_TEST_HOOKS
@@ -1463,6 +1507,10 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 			}
 			if ((gap == 0 || (tentok && sid >= 0)) && !met && j == (int)(it & (uint32_t)(LPW - 1)))
 				bkb = (TEXT && trec) ? tp : kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
+			if ((it & (uint32_t)(LPW - 1)) == (uint32_t)(LPW - 1)) { // the end of a window of eight iterations: its events (noted by the common step), then its records
+				evq_flush();
+				if (bkb >= 0) { rec_pos<TENT && !LIST>(&row[bkb], bval, vis); bkb = -1; }
+			}
 			// next insertion point(s)
 			uint32_t match = 0, mh;
 			int64_t lo_n, hi_n;
@@ -2568,13 +2616,10 @@ __device__ __forceinline__ uint32_t idx_sym(const IdxView &ix, int64_t i)
 		const uint4 sl = ix.slot16[(int64_t)s * 8 + jj];
 		return ((sl.y >> bit) & 1u) | ((sl.z >> bit) & 1u) << 1 | ((sl.w >> bit) & 1u) << 2;
 	} else {
-		uint32_t p = 0;
-		for (int q = 0; q < RB3_RLE_CODES; ++q) {
+		for (int q = 0; q < RB3_RLE_CODES; ++q) { // the first run that ends behind off (unused codes repeat the last end: never)
 			const uint32_t word = sp[(q / 6) * 4 + 1 + (q % 6) / 2];
 			const uint32_t code = (q & 1) ? word >> 16 : word & 0xFFFFu; // q%6 and q have the same parity
-			const uint32_t sym = code & 7u, len = sym == 7u ? 0u : (code >> 3) + 1u;
-			if (off < p + len) return sym;
-			p += len;
+			if (off < RB3_RUN_END(code)) return code & 7u;
 		}
 		return 7;
 	}
@@ -2673,15 +2718,15 @@ __device__ __forceinline__ void gen_window(const IdxView &old, const int64_t *po
 			if (lane < 32) oslot[X][lane] = sw[X];
 			obase[X] = (og[X] << RB3_GRP_BITS) + (ohdr[X] & 0xFFFFu);
 			if (ohdr[X] & RB3_SLOT_RLE) { // start offset of every run: prefix sum over the 48 codes
-				uint32_t len = 0, sy = 7;
+				uint32_t end = 0, sy = 7;
 				const uint32_t word = __shfl(sw[X], lane < RB3_RLE_CODES ? (lane / 6) * 4 + 1 + (lane % 6) / 2 : 0);
 				if (lane < RB3_RLE_CODES) {
 					const uint32_t code = (lane & 1) ? word >> 16 : word & 0xFFFFu; // lane % 6 and lane have the same parity
-					sy = code & 7u, len = sy == 7u ? 0u : (code >> 3) + 1u;
+					sy = code & 7u, end = RB3_RUN_END(code);
 				}
-				uint32_t inc = len;
-				inc = wave_incl_scan((uint32_t)inc);
-				ostart[X][lane] = (uint16_t)((lane < RB3_RLE_CODES && len != 0) ? inc - len : 0xFFFFu); // unused codes start at the end
+				uint32_t st = wave_up1(end); // a run starts where the one before it ends (cumulative codes)
+				if (lane == 0) st = 0u;
+				ostart[X][lane] = (uint16_t)((lane < RB3_RLE_CODES && sy != 7u) ? st : 0xFFFFu); // unused codes start at the end
 				orsym[X][lane] = (uint8_t)sy;
 			}
 		}
@@ -2893,9 +2938,9 @@ __global__ void __launch_bounds__(64) k_pass2(IdxView old, const int64_t *pos, c
 			nc += nr - mg;
 			__syncthreads();
 			if (lw == slot_w0 + slot_sz - 1) { // flush the slot
-				if (lane < RB3_RLE_CODES) {
-					const uint32_t code = lane < nc ? ((clen[lane] - 1u) << 3 | csym[lane]) : 7u;
-					((uint16_t*)code16)[lane] = (uint16_t)code;
+				{ // cumulative ends; the unused codes repeat the slot's last end
+					const uint32_t cend = wave_incl_scan(lane < nc ? clen[lane] : 0u);
+					if (lane < RB3_RLE_CODES) ((uint16_t*)code16)[lane] = (uint16_t)RB3_RUN_CODE(cend, lane < nc ? csym[lane] : 7u);
 				}
 				__syncthreads();
 				if (lane < 8) {
@@ -2980,15 +3025,16 @@ __device__ __forceinline__ bool window_runs_fast(const IdxView &old, const int64
 		sy[i] = wave_read(rs, i);
 	}
 	// lane q: run q of the slot, clipped to the window, in old-local coordinates
-	uint32_t len = 0, rsym = 7;
+	uint32_t inc = 0, rsym = 7; // inc: where the run ends
 	if (lane < RB3_RLE_CODES) {
 		const uint32_t word = sp[(lane / 6) * 4 + 1 + (lane % 6) / 2];
 		const uint32_t code = (lane & 1) ? word >> 16 : word & 0xFFFFu;
-		rsym = code & 7u, len = rsym == 7u ? 0u : (code >> 3) + 1u;
+		rsym = code & 7u, inc = RB3_RUN_END(code);
 	}
-	uint32_t inc = len;
-	inc = wave_incl_scan((uint32_t)inc);
-	int cs = (int)(inc - len) - A, ce = (int)inc - A;
+	uint32_t rst = wave_up1(inc); // ... and where it starts: the end of the code before it
+	if (lane == 0) rst = 0u;
+	if (lane >= RB3_RLE_CODES || rsym == 7u) rst = inc; // (unused codes: empty)
+	int cs = (int)rst - A, ce = (int)inc - A;
 	cs = cs < 0 ? 0 : cs, ce = ce > nold ? nold : ce;
 	const bool valid = ce > cs;
 	const uint64_t vm = __ballot(valid);
@@ -3346,8 +3392,8 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 		if (lane < RB3_GRP_WINS) sP[lane] = lane < slot_sz ? inc - e : 0xFFFFu, sB[lane] = bm, sNr[lane] = nr;
 		if (lane == 0) sP[RB3_GRP_WINS] = 0xFFFFu;
 		wave_sync();
-		if (lane < RB3_RLE_CODES) {
-			uint32_t code = 7u;
+		{ // (wruns: per-window LENGTH codes (len - 1) << 3 | sym, an intermediate of this path; the slot gets cumulative ends)
+			uint32_t len = 0u, csy = 7u;
 			if (lane < nc) {
 				int k = 0; // the last window whose first code is at or before this lane's
 #pragma unroll
@@ -3355,15 +3401,15 @@ __global__ void __launch_bounds__(64 * RB3_REB_WAVES) k_pass2w(const uint4 *wsta
 					if (k + d < slot_sz && sP[k + d] <= (uint32_t)lane) k += d;
 				const uint32_t r = (uint32_t)lane - sP[k] + sB[k];
 				const uint32_t c0 = wruns[(ws + k) * RB3_RLE_CODES + r];
-				uint32_t len = (c0 >> 3) + 1u;
+				len = (c0 >> 3) + 1u, csy = c0 & 7u;
 				if (r == sNr[k] - 1u) // the window's last run may go on through the following windows
 					for (int kk = k + 1; kk < slot_sz && sB[kk]; ++kk) {
 						len += ((uint32_t)wruns[(ws + kk) * RB3_RLE_CODES] >> 3) + 1u;
 						if (sNr[kk] > 1u) break;
 					}
-				code = (len - 1u) << 3 | (c0 & 7u);
 			}
-			((uint16_t*)code16)[lane] = (uint16_t)code;
+			const uint32_t cend = wave_incl_scan(len); // (lanes behind the last run repeat the slot's last end)
+			if (lane < RB3_RLE_CODES) ((uint16_t*)code16)[lane] = (uint16_t)RB3_RUN_CODE(cend, csy);
 		}
 		wave_sync();
 		if (lane < 8) {
@@ -3533,21 +3579,18 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 			if (__any(valid && !(hdr0 & RB3_SLOT_RLE))) { RB3_REB_WHY(2); return false; } // a bit-plane slot: this group is rebuilt from symbols
 			const int64_t sgrp = (gb != ga && fa + q >= slot0b) ? gb : ga;
 			const uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
-			uint32_t len[6], tot = 0;
-#pragma unroll
-			for (int i = 0; i < 6; ++i) {
-				len[i] = (e[i] & 7u) == 7u ? 0u : (e[i] >> 3) + 1u;
-				tot += len[i];
-			}
-			int rel = (int)(((sgrp << RB3_GRP_BITS) + (int64_t)(hdr0 & 0xFFFFu)) - A0) + (int)oct_exscan(tot, j); // may be negative
+			// cumulative codes: run i covers [end of the code before it, its own end) of the slot -- the first one of a lane starts where the lane below ended
+			const int sbase = (int)(((sgrp << RB3_GRP_BITS) + (int64_t)(hdr0 & 0xFFFFu)) - A0); // the slot's start in the group's old range: may be negative
+			int rel = sbase + (int)(oct_prev_end(pk_ends(sl.w), j) >> 16);
 			int cs[6];
 			uint32_t nv = 0, vm = 0;
 #pragma unroll
 			for (int i = 0; i < 6; ++i) {
-				const int st = rel < 0 ? 0 : rel, en = rel + (int)len[i] > nold ? nold : rel + (int)len[i];
+				const int eni = sbase + (int)RB3_RUN_END(e[i]);
+				const int st = rel < 0 ? 0 : rel, en = eni > nold ? nold : eni;
 				cs[i] = st;
-				if (valid && len[i] != 0u && en > st) vm |= 1u << i, ++nv;
-				rel += (int)len[i];
+				if (valid && (e[i] & 7u) != 7u && en > st) vm |= 1u << i, ++nv;
+				rel = eni;
 			}
 			const uint32_t inc = wave_incl_scan(nv);
 			int o = nR + (int)(inc - nv);
@@ -3757,7 +3800,7 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 			const int ci = x - (int)L.sbase[si], t = (int)L.hB[a] - 1 + ci;
 			const uint32_t h = H[t], hn = H[t + 1];
 			const uint32_t st = (h >> 3) < x0 ? x0 : h >> 3, en = (hn >> 3) > x1 ? x1 : hn >> 3;
-			((uint16_t*)L.stage)[si * RB3_RLE_CODES + ci] = (uint16_t)((en - st - 1u) << 3 | (h & 7u));
+			((uint16_t*)L.stage)[si * RB3_RLE_CODES + ci] = (uint16_t)RB3_RUN_CODE(en - x0, h & 7u); // (cumulative: where the run ends in its slot)
 			atomicAdd(&L.scnt[si * 8 + (h & 7u)], en - st);
 		}
 	}
@@ -3776,8 +3819,10 @@ __device__ __forceinline__ bool reb_group_one(const IdxView &old, const int64_t 
 			const uint32_t *pw = &L.stage[si * 24];
 			uint4 v;
 			v.x = hq;
-			if (an - a > 1u) v.y = pw[j * 3], v.z = pw[j * 3 + 1], v.w = pw[j * 3 + 2];
-			else v.y = pw[(j >> 1) * 6 + 0 + (j & 1)], v.z = pw[(j >> 1) * 6 + 2 + (j & 1)], v.w = pw[(j >> 1) * 6 + 4 + (j & 1)]; // same word order as wplane
+			if (an - a > 1u) { // (the codes behind the last run repeat its end: the slot's symbols)
+				const uint32_t tot = (an - a) << RB3_WIN_BITS;
+				v.y = run_fill_unused(pw[j * 3], tot), v.z = run_fill_unused(pw[j * 3 + 1], tot), v.w = run_fill_unused(pw[j * 3 + 2], tot);
+			} else v.y = pw[(j >> 1) * 6 + 0 + (j & 1)], v.z = pw[(j >> 1) * 6 + 2 + (j & 1)], v.w = pw[(j >> 1) * 6 + 4 + (j & 1)]; // same word order as wplane
 			gslots[((int64_t)g * RB3_RG_MAXSLOTS + si) * 8 + j] = v;
 		}
 	}
@@ -4409,8 +4454,9 @@ __global__ void __launch_bounds__(256) k_export_runs_g(IdxView ix, int64_t g0, i
 			const int64_t start = P0 + (int64_t)(hdr0 & 0xFFFFu);
 			if (hdr0 & RB3_SLOT_RLE) {
 				const uint32_t code = lane < RB3_RLE_CODES ? slot_code(sp, lane) : 7u;
-				const uint32_t sym = code & 7u, len = sym == 7u ? 0u : (code >> 3) + 1u;
-				const uint32_t ex = wave_incl_scan(len) - len;
+				const uint32_t sym = code & 7u;
+				uint32_t ex = wave_up1(RB3_RUN_END(code)); // cumulative codes: a run starts where the code before it ends
+				if (lane == 0) ex = 0u;
 				uint32_t before = wave_up1(sym);
 				if (lane == 0) before = prev;
 				const uint64_t H = __ballot(sym != 7u && sym != before);
@@ -4467,17 +4513,12 @@ __device__ __forceinline__ uint32_t slice_sym(const uint4 &sl, uint32_t hdr0, ui
 		return 8u | ((sl.y >> t) & 1u) | ((sl.z >> t) & 1u) << 1 | ((sl.w >> t) & 1u) << 2;
 	} else {
 		const uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
-		uint32_t len[6], tot = 0;
+		uint32_t pos = oct_prev_end(pk_ends(sl.w), j) >> 16, r = 0u; // cumulative codes: run i covers [end of the code before it, its own end)
 #pragma unroll
 		for (int i = 0; i < 6; ++i) {
-			len[i] = (e[i] & 7u) == 7u ? 0u : (e[i] >> 3) + 1u;
-			tot += len[i];
-		}
-		uint32_t pos = oct_exscan(tot, j), r = 0u;
-#pragma unroll
-		for (int i = 0; i < 6; ++i) {
-			if (off >= pos && off < pos + len[i]) r = 8u | (e[i] & 7u);
-			pos += len[i];
+			const uint32_t en = RB3_RUN_END(e[i]);
+			if (off >= pos && off < en && (e[i] & 7u) != 7u) r = 8u | (e[i] & 7u);
+			pos = en;
 		}
 		return r;
 	}

@@ -23,7 +23,11 @@
  *      bit-plane slot (exactly one window): slice j holds symbols [32j, 32j+32) as three
  *        32-bit planes; symbol = bit0 | bit1<<1 | bit2<<2; padding past the end = 7
  *      run slot (2, 4, 8, 16 or 32 whole windows, at most 48 runs): slice j holds six
- *        16-bit codes (len-1)<<3 | sym, len in 1..8192; unused codes have sym = 7
+ *        16-bit codes (end-1)<<3 | sym, `end` = the offset from the slot start just past the run, 1..8192
+ *        (CUMULATIVE: run i covers [end of code i-1, end of code i), the first run starts at 0 -- a lane of the
+ *        octet that decodes the slot gets the starts of its six runs from its own words and one value of the lane
+ *        below, where the lengths of rounds 1-5 needed a prefix sum over the octet); unused codes have sym = 7 and
+ *        repeat the end of the last used one (empty runs): the last code of a slot always holds the slot's symbols
  *
  * A slot never crosses a group, a run slot covers an aligned power-of-two number of
  * windows, and a window with more than 48 runs (or any single window) is a bit-plane
@@ -48,6 +52,9 @@
 #define RB3_RLE_CODES  48
 #define RB3_RLE_MAXLEN 8192
 #define RB3_SLOT_RLE   0x80000000u
+/* a run code from the run's exclusive end offset in the slot (1..8192) and its symbol; the end of a code */
+#define RB3_RUN_CODE(end, sym) ((((uint32_t)(end) - 1u) << 3) | (uint32_t)(sym))
+#define RB3_RUN_END(code) ((((uint32_t)(code)) >> 3) + 1u)
 
 typedef struct {
 	uint64_t cnt[6];

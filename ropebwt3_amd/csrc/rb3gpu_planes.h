@@ -128,17 +128,13 @@ __global__ void __launch_bounds__(256) k_plane_group(IdxView old, const int64_t 
 				anybp = 1;
 			} else {
 				const uint32_t e[6] = { sl.y & 0xFFFFu, sl.y >> 16, sl.z & 0xFFFFu, sl.z >> 16, sl.w & 0xFFFFu, sl.w >> 16 };
-				uint32_t len[6], tot = 0;
+				// cumulative codes: a run starts where the code before it ends (the first one of a lane: where the lane below ended)
+				uint32_t st = oct_prev_end(pk_ends(sl.w), j) >> 16;
 #pragma unroll
 				for (int i = 0; i < 6; ++i) {
-					len[i] = (e[i] & 7u) == 7u ? 0u : (e[i] >> 3) + 1u;
-					tot += len[i];
-				}
-				uint32_t st = oct_exscan(tot, j);
-#pragma unroll
-				for (int i = 0; i < 6; ++i) {
-					L.rtab[q * 48 + j * 6 + i] = (len[i] ? st : RB3_PG_BIG) << 3 | (e[i] & 7u);
-					st += len[i];
+					const uint32_t en = RB3_RUN_END(e[i]);
+					L.rtab[q * 48 + j * 6 + i] = ((e[i] & 7u) != 7u && en > st ? st : RB3_PG_BIG) << 3 | (e[i] & 7u);
+					st = en;
 				}
 			}
 			if (j == 0) L.srel[q] = rel, L.skind[q] = hdr0 & RB3_SLOT_RLE;
@@ -290,13 +286,14 @@ __global__ void __launch_bounds__(256) k_plane_group(IdxView old, const int64_t 
 		__syncthreads();
 		if (mine && an - a > 1 && lw == a) { // a run slot: this octet writes it, six codes per lane
 			uint32_t c[6];
+			const uint32_t x0 = (uint32_t)(a * RB3_WIN), xe = hl[si * 49 + nr] >> 3; // the slot's first offset in the group, and where its symbols end
 #pragma unroll
-			for (int i = 0; i < 6; ++i) {
+			for (int i = 0; i < 6; ++i) { // cumulative codes: where the run ends in the slot; the codes behind the last run repeat its end
 				const int r = j * 6 + i;
-				c[i] = 7u;
+				c[i] = RB3_RUN_CODE(xe > x0 ? xe - x0 : 1u, 7u);
 				if (r < nr) {
 					const uint32_t e0 = hl[si * 49 + r], e1 = hl[si * 49 + r + 1];
-					c[i] = ((e1 >> 3) - (e0 >> 3) - 1u) << 3 | (e0 & 7u);
+					c[i] = RB3_RUN_CODE((e1 >> 3) - x0, e0 & 7u);
 				}
 			}
 			pslots[((int64_t)u * RB3_GRP_WINS + si) * 8 + j] = make_uint4(hq, c[0] | c[1] << 16, c[2] | c[3] << 16, c[4] | c[5] << 16);

@@ -32,6 +32,7 @@ import hashlib
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -403,6 +404,49 @@ def reference_prefix(files, n_ref, K):
     return out
 
 
+def reference_many_chains(files, n_first, n_batch):
+    """SURVEY 8(d) config 3(b) -- the reference at its BEST on this workload: the same genomes concatenated so that ONE merge round holds 2 * n_batch
+    chains (rb3_fmi_merge_plain runs one chain per string over kt_for, fm-index.c:217-224): file 1 = the first n_first genomes (the first batch: no
+    merge), file 2 = the next n_batch genomes, `-m` large enough for each file to be one batch.  Merge-only seconds by the reference's own timers."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt3")
+    if not os.path.exists(ref) or len(files) < n_first + n_batch:
+        return None
+    from ropebwt3_amd import _build
+    cores = os.cpu_count() or 1
+    nthr = min(cores, 2 * n_batch)
+    tmp = tempfile.mkdtemp(prefix="rb3_3b_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        fa, fb = os.path.join(tmp, "first.fa"), os.path.join(tmp, "batch.fa")
+        for fn, part in ((fa, files[:n_first]), (fb, files[n_first:n_first + n_batch])):
+            with open(fn, "wb") as fp:
+                for f in part:
+                    fp.write(open(f, "rb").read())
+        t = time.time()
+        rr = subprocess.run([ref, "build", "-d", "-m8g", "-t%d" % nthr, fa, fb], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        dt = time.time() - t
+        tot, last, nsr = 0.0, None, 0
+        for l in rr.stderr.decode().splitlines():
+            m = re.match(r"\[M::\w+::([0-9.]+)\*", l)
+            if not m:
+                continue
+            if "constructed partial BWT" in l:
+                last = float(m.group(1))
+            elif "inserted" in l and last is not None:
+                tot += float(m.group(1)) - last
+                last = None
+                nsr += int(re.search(r"inserted (\d+) symbols", l).group(1))
+        ra = subprocess.run([_build.BIN_CLI, "build", "-d", "-m8g", fa, fb], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        sa = parse_cli_stats(ra.stderr.decode())
+        gms = (sa.get("merge_path_ms", 0) + sa.get("text_upload_ms", 0)) if sa.get("merge_path_ms") else None
+        return {"value": round(nsr / tot / 1e9, 6) if tot > 0 else None, "unit": "Gbp/s", "cores": cores, "kind": "reference",
+                "sample": "`ropebwt3 build -d -m8g -t%d first.fa batch.fa` (oracle/_ref, unmodified): %d genomes as the first batch, the next %d concatenated as ONE batch = one merge round of %d chains on %d threads; merge-only seconds by its own timers %.2f s of %.1f s wall" % (nthr, n_first, n_batch, 2 * n_batch, nthr, tot, dt),
+                "merge_only_seconds": round(tot, 3), "symbols_merged": nsr, "chains_per_round": 2 * n_batch,
+                "identical_fmd": rr.returncode == 0 and hashlib.md5(rr.stdout).hexdigest() == hashlib.md5(ra.stdout).hexdigest(),
+                "same_files_on_the_gpu": {"merge_path_ms_incl_h2d": round(gms, 3) if gms else None, "speedup_merge_path": round(tot * 1e3 / gms, 1) if gms else None}}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cli_build(files, K, gold):
     """the whole build through the CLI (reader thread, GPU sorter thread and merges overlapped; wall clock incl. process start,
     file reading and FMD writing) + the same files re-batched"""
@@ -513,6 +557,8 @@ def main():
     ap.add_argument("--index-8g", type=int, default=24, help="haplotypes (360 M symbols each) of the leg with an index beyond 2^32 symbols (0: skip)")
     ap.add_argument("--only", choices=["large", "reads", "cfg2", "cli", "headline", "8g"], default=None, help="run one leg alone and print its JSON (profiling)")
     ap.add_argument("--mtb-ref-prefix", type=int, default=6, help="files the reference binary is timed on (cpu_baseline)")
+    ap.add_argument("--mtb-3b-first", type=int, default=4, help="cpu_baseline_config3b: genomes in the first batch of the reference's many-chain run")
+    ap.add_argument("--mtb-3b-batch", type=int, default=16, help="cpu_baseline_config3b: genomes concatenated into the ONE merged batch (0 = skip)")
     ap.add_argument("--walker-step", type=int, default=WALKER_STEP)
     ap.add_argument("--host-walkers", action="store_true", help="make the walker lists on the host before the timed steps (rb3h_walkers_text, rounds 2-4) instead of on the device inside the merge call")
     args = ap.parse_args()
@@ -690,6 +736,10 @@ def main():
             e = time.time() - t
             cb = {"value": round(b2.size / e / 1e9, 6), "unit": "Gbp/s", "cores": os.cpu_count() or 1, "kind": "port", "sample": "rank phase of round 1 (genome 1 into the index of genome 0) by oracle/liboracle.so"}
         out["cpu_baseline"] = cb
+        if K >= args.mtb_3b_first + args.mtb_3b_batch and args.mtb_3b_batch > 0:
+            cb3 = reference_many_chains(files, args.mtb_3b_first, args.mtb_3b_batch)
+            if cb3 is not None:
+                out["cpu_baseline_config3b"] = cb3
     if not args.no_aux:
         out["aux_cli_build"] = cli_build(files, K, gold)
         # everything around the metric in one place

@@ -241,15 +241,22 @@ static int sink_plain(void *data, int c, int64_t l) /* mr_print_bwt, mrope.c:201
 	return 0;
 }
 
+static int iv_live(void);
+static int iv_get_acc(int64_t acc[7]);
+static int iv_export_runs(rb3gpu_emit_f sink, void *data);
+
+/* the index as an FMR file -- from the handle, or, once --interval has cut it, from the intervals in rank order where they are
+ * (-S after each input file, build.c:232-238, and the final -r output) */
 static int dump_fmr(rb3gpu_t *h, const bopt_t *opt, FILE *fp)
 {
 	int64_t acc[7];
 	rb3h_fmrw_t *w;
 	int ret;
-	rb3gpu_get_acc(h, acc);
+	if (iv_live()) iv_get_acc(acc);
+	else rb3gpu_get_acc(h, acc);
 	w = rb3h_fmrw_init(acc, opt->max_nodes, opt->block_len);
 	if (w == 0) return -1;
-	ret = rb3gpu_export_runs(h, sink_fmr, w);
+	ret = iv_live() ? iv_export_runs(sink_fmr, w) : rb3gpu_export_runs(h, sink_fmr, w);
 	if (ret == 0) ret = rb3h_fmrw_dump(w, fp);
 	rb3h_fmrw_destroy(w);
 	return ret;
@@ -328,6 +335,10 @@ static int64_t *sentinels_of(const uint8_t *text, int64_t len, int64_t n_hint, i
 	*n_out = a ? n : 0;
 	return a;
 }
+
+static int iv_live(void) { return g_iv.s != 0; }
+static int iv_get_acc(int64_t acc[7]) { return rb3gpu_shard_get_acc(g_iv.s, acc); }
+static int iv_export_runs(rb3gpu_emit_f sink, void *data) { return rb3gpu_shard_export_runs(g_iv.s, sink, data); }
 
 /* one batch into the sharded index; the first call cuts the index the handle holds into its intervals */
 static int interval_merge(rb3gpu_t *h, int64_t len, const void *d_bwt, const void *d_tw, int64_t n_sent, const int64_t *sent)
@@ -857,8 +868,8 @@ int main_build(int argc, char *argv[])
 	memset(&g_iv, 0, sizeof(g_iv));
 	if (opt.interval && opt.n_gpus > 1) { /* ONE reader / sorter / consumer; the index is what is spread over the GPUs (north_star's split) */
 		const int ndev = rb3gpu_device_count();
-		if (!opt.gpu_sort || fn_tmp || opt.n_gpus > RB3GPU_SH_MAXIV) {
-			fprintf(stderr, "ERROR: --interval needs GPU suffix sorting, no -S and at most %d GPUs\n", RB3GPU_SH_MAXIV);
+		if (!opt.gpu_sort || opt.n_gpus > RB3GPU_SH_MAXIV) { /* (-S works: the FMR writer takes the intervals where they are, see dump_fmr) */
+			fprintf(stderr, "ERROR: --interval needs GPU suffix sorting and at most %d GPUs\n", RB3GPU_SH_MAXIV);
 			rb3gpu_destroy(h);
 			return 1;
 		}
@@ -972,10 +983,7 @@ int main_build(int argc, char *argv[])
 		int64_t acc[7];
 		rb3gpu_shard_get_acc(g_iv.s, acc);
 		if (opt.fmt == FMT_FMR) {
-			rb3h_fmrw_t *w = rb3h_fmrw_init(acc, opt.max_nodes, opt.block_len);
-			ret = w ? rb3gpu_shard_export_runs(g_iv.s, sink_fmr, w) : -1;
-			if (ret == 0) ret = rb3h_fmrw_dump(w, stdout);
-			if (w) rb3h_fmrw_destroy(w);
+			ret = dump_fmr(h, &opt, stdout);
 		} else if (opt.fmt == FMT_FMD) {
 			rb3h_fmdw_t *w = rb3h_fmdw_init();
 			ret = w ? rb3gpu_shard_export_run_words(g_iv.s, sink_fmd_words, w) : -1;
@@ -1315,6 +1323,7 @@ int main(int argc, char *argv[])
 {
 	int ret = 0;
 	rb3h_init();
+	if (getenv("RB3_VERBOSE")) rb3h_verbose = atoi(getenv("RB3_VERBOSE")); /* (diagnostics: 4 makes the engine print every merge's phases from its HIP events; the reference's level is 3) */
 	if (argc == 1) return usage(stdout);
 	else if (strcmp(argv[1], "build") == 0) ret = main_build(argc - 1, argv + 1);
 	else if (strcmp(argv[1], "merge") == 0) ret = main_merge(argc - 1, argv + 1);

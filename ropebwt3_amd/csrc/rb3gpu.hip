@@ -1654,7 +1654,14 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		case 8: RB3_LAUNCH_FAST(false, true, 2); break;
 		case 7: // (the headline's kernel: 32-bit positions in the common step where index and batch allow it)
 			if (iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29))
+#ifdef RB3_PROF_STEP
+
+#endif
+#ifdef RB3_PROF_STEP /* kernel experiment: RB3_EXP_DYNLDS bytes of unused LDS per block bound the waves per SIMD (how long is a step of a wave that has its SIMD to itself?) */
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 8, true>), grid, blk, getenv("RB3_EXP_DYNLDS") ? (unsigned)atoi(getenv("RB3_EXP_DYNLDS")) : 0u, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
+#else
 				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true, false, true, 1, 8, true>), grid, blk, 0, h->st, iv, drec, len, (int64_t)0, per_string ? -1 : 0,
+#endif
 					(const Walker*)dwl, n_walkers, (int64_t)-1, (int64_t*)nullptr, misc, misc + 1, octs, tab, sidctr, sid_limit, d_tw, (const unsigned long long*)b2_nwalk, 256 * tq - 1, mctr, RB3_TREC_ARG, jmet);
 			else RB3_LAUNCH_FAST(false, true, 1);
 			break;
@@ -1750,6 +1757,10 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	h->stt.n_lf_checked += (int64_t)hm[MISC_LF_CHK];
 #ifdef RB3_PROF_STEP
 	if (hm[37]) fprintf(stderr, "[prof] common step x %llu (lane 0 of every wave): directory %.0f cycles, slot %.0f, decode+rest %.0f, between steps %.0f; %.1f %% of these steps ran the two-decode side for some walker; directory wait of the steps behind a flush of records: %.0f cycles\n", hm[37], (double)hm[34] / hm[37], (double)hm[35] / hm[37], (double)hm[36] / hm[37], (double)hm[38] / hm[37], 100.0 * hm[9] / hm[37], 8.0 * hm[10] / hm[37]);
+	if (hm[37] && (hm[11] >> 40)) fprintf(stderr, "[prof] steps behind a flush of records x %llu: directory %.0f cycles, slot %.0f\n", hm[11] >> 40, (double)(hm[11] & ((1ull << 40) - 1)) / (double)(hm[11] >> 40), (double)hm[12] / (double)(hm[11] >> 40));
+	if (hm[37]) fprintf(stderr, "[prof] general steps x %llu (lane 0 of every wave): %.0f ticks each; common steps %.0f ticks each (s_memtime ticks, whole step incl. the time between steps): general steps are %.1f %% of the iterations and %.1f %% of the stepping time\n",
+		hm[10] >> 32, (double)(hm[10] & 0xFFFFFFFFull) / (double)((hm[10] >> 32) ? (hm[10] >> 32) : 1), (double)(hm[34] + hm[35] + hm[36] + hm[38]) / hm[37],
+		100.0 * (double)(hm[10] >> 32) / (double)((hm[10] >> 32) + hm[37]), 100.0 * (double)(hm[10] & 0xFFFFFFFFull) / (double)((hm[10] & 0xFFFFFFFFull) + hm[34] + hm[35] + hm[36] + hm[38]));
 #endif
 #ifdef RB3_PROF
 	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, %.1f %% of them with the two-decode path -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], 100.0 * (double)hm[12] / (double)hm[10], (double)hm[9] / hm[10]);

@@ -1088,6 +1088,15 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 	const uint32_t lim_singles = sid_limit < (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF) ? sid_limit : (uint32_t)(RB3_TENT_POISON - RB3_TENT_HALF);
 	static_assert(LPW == 8 || LPW == 4, "an octet or a quad per walker");
 	const int lane = threadIdx.x & 63, j = lane & (LPW - 1);
+#ifdef RB3_EXP_PRIO /* kernel experiment: the waves of a SIMD at different issue priorities (they run in a convoy: all of them decode at the same time, at a fifth of the speed, then all wait) */
+	if (RB3_EXP_PRIO == 1) { // static, by the wave's slot in its SIMD (HW_ID bits 3:0)
+		const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);
+		if ((slot & 3u) == 0u) __builtin_amdgcn_s_setprio(0); else if ((slot & 3u) == 1u) __builtin_amdgcn_s_setprio(1); else if ((slot & 3u) == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+	} else if (RB3_EXP_PRIO == 3) { // static, by the layer of the block (blocks arrive round-robin over the compute units)
+		const uint32_t layer = (blockIdx.x >> 8) & 3u;
+		if (layer == 0u) __builtin_amdgcn_s_setprio(3); else if (layer == 1u) __builtin_amdgcn_s_setprio(2); else if (layer == 2u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+	}
+#endif
 	// With few walkers the kernel is latency-bound and a wave runs every instruction of every octet
 	// it hosts: the host may enable only the first `octs` octets of each wave and launch more waves.
 	if (lane / LPW >= octs) return; // (octs counts groups of LPW lanes)
@@ -1108,9 +1117,14 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				const uint32_t first1 = evq_[2 * threadIdx.x + 1].y;
 				const uint4 e = evq_[2 * threadIdx.x];
 				const int prev = (int)(e.y >> (RB3_TENT_PBITS - 32)) & (RB3_TENT_IDS - 1);
+#ifdef RB3_EXP_NOEVST /* kernel experiment (wrong results, right timing): what do the event stores cost the walk?  1 = none of them, 2 = only the 16 bytes of the record */
+				if (RB3_EXP_NOEVST == 2) *(uint4*)&tab[ns].w0 = e;
+				(void)first1; (void)prev;
+#else
 				*(uint4*)&tab[ns].w0 = e;
 				tab[ns].pad[0] = first1;
 				tab[prev].child = ns + 1;
+#endif
 				evq_[2 * threadIdx.x + 1].x = 0xFFFFFFFFu;
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1147,7 +1161,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 	uint32_t pf_g = 0x80000000u; // group of pf_w.x/.y (pf_w.z/.w: the group behind it); 0x80000000: nothing asked for
 	uint4 pf_w = make_uint4(0u, 0u, 0u, 0u);
 #ifdef RB3_PROF_STEP
-	uint64_t prof_t[7] = {0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+	uint64_t prof_t[7] = {0, 0, 0, 0, 0, 0, 0}, prof_last = 0, prof_u[2] = {0, 0};
 #endif
 #ifdef RB3_PROF
 	const uint64_t tstart = __builtin_readcyclecounter();
@@ -1233,7 +1247,135 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 		// instruction-issue speed, so instruction count is the cost.
 		do {
 #ifndef RB3_NO_FAST_STEP
-			if (LIST && !DENSE && TENT && TEXT == 1) { // (LPW = 8: an octet per walker; LPW = 4: a quad, every lane two slices of a slot)
+#if !defined(RB3_NO_LEAN32) && !defined(RB3_PROF_STEP)
+			// ---- the common step on 32-bit state (I32: the headline's kernel; round 6).  The same step as the loop behind it -- read that one first --, made for the
+			// LENGTH of a wave's instruction stream: a lone wave of this kernel needs ~10 cycles per instruction (dependent issue, VALU <-> SALU hand-overs, ~25 branch
+			// points per step), five waves per SIMD do not hide that (profiles/r6_lone_wave.txt: 3.6 k cycles per step alone, 6.1 k with five), so what a step costs is
+			// its instruction count.  Here: the walker's state as 32-bit words (position, WIDTH of the interval instead of its upper end, text position, the two text
+			// words) so that the loop's back edge moves 6 registers instead of 18; ONE counter (scalar) for the iteration number, the walker's age, its steps and what
+			// is left of its segment -- the per-walker limits are worked out once, on the way in, and the 64-bit state is written back on the way out.
+			if constexpr (I32 && LIST && !DENSE && TENT && TEXT == 1 && LPW == 8) {
+#define RB3_BAL(x) __builtin_amdgcn_ballot_w64(x)
+				const unsigned long long exm = RB3_BAL(true);
+				const unsigned long long m_rc = RB3_BAL((int32_t)(rc >> 32) < 0); // (the record word of the row is only looked up outside the segment: it does not change in here)
+				// common steps this walker may take: as long as remaining >= 2 (and it has not left its segment: remaining <= RB3_BEYOND)
+				uint32_t bud = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) ? (remaining - 1 > 0x3FFFFFFFLL ? 0x3FFFFFFFu : (uint32_t)(remaining - 1)) : 0u;
+				// ... and, while it is inexact without a stretch, until it is old enough to open one (the general step does that)
+				uint32_t agelim = sid == -1 ? (age >= RB3_TENT_MIN_AGE ? 0u : RB3_TENT_MIN_AGE - age) : 0xFFFFFFFFu;
+				asm volatile("" : "+v"(bud), "+v"(agelim)); // (plain numbers from here on: the compiler folded the selects above into the loop's comparisons, two instructions a step each)
+				uint32_t lo32 = (uint32_t)lo, kq = (uint32_t)hi - (uint32_t)lo; // [lo32, lo32 + kq)
+				uint32_t xw = (uint32_t)x, x1w = (uint32_t)x1, tp32 = (uint32_t)tp;
+				uint32_t its = (uint32_t)__builtin_amdgcn_readfirstlane((int)it), d = 0u; // (the same in every lane: scalar registers)
+				const uint32_t nlastg = (uint32_t)b1.n >> RB3_GRP_BITS, nlastw = ((uint32_t)b1.n >> RB3_WIN_BITS & 31u) + 1u;
+				for (;;) {
+					const uint32_t cq = xw & 7u;
+					const unsigned long long m_simple = RB3_BAL(d < bud) & RB3_BAL(cq != 0u) & m_rc & ~(RB3_BAL(kq != 0u) & RB3_BAL(d >= agelim))
+						& RB3_BAL((lo32 & (RB3_GRP - 1)) + kq <= (uint32_t)RB3_GRP) & RB3_BAL(kq <= (uint32_t)kmax); // (a width that wraps the sum fails the last test)
+					if (m_simple != exm) break;
+					++its, ++d;
+					const int c = (int)cq;
+					const uint32_t g32 = lo32 >> RB3_GRP_BITS;
+					uint64_t sm;
+					const uint32_t pf_d = g32 - pf_g; // 0 or 1 if the words asked for during the last step are the ones needed
+					if (RB3_BAL(pf_d <= 1u) == exm) {
+						const uint32_t v2 = dpp_mov<0xEE>(pf_w.x), v0 = dpp_mov<0x44>(pf_w.x); // quad_perm [2,3,2,3] / [0,1,0,1]
+						const uint32_t sel = pf_d ? v2 : v0;
+						sm = (uint64_t)dpp_mov<0x55>(sel) << 32 | dpp_mov<0x00>(sel);
+					} else sm = *(const uint64_t*)((const char*)b1.gsm + (g32 << 3));
+					const uint32_t xn = *(const uint32_t*)((const char*)tw + ((tp32 >= 2u ? tp32 - 2u : 0u) << 3)); // the word after next (c != 0: tp32 >= 1)
+					const uint32_t koff = lo32 & (RB3_GRP - 1);
+					const uint32_t mask = (uint32_t)(sm >> 32), lw = koff >> RB3_WIN_BITS;
+					const uint32_t mlo = mask & ((2u << lw) - 1u);
+					const uint32_t sidx = (uint32_t)sm + __popc(mlo) - 1u;
+					const uint32_t w0 = 31u - (uint32_t)__builtin_clz(mlo);
+					const uint32_t abv = mask & ~((2u << lw) - 1u);
+					const uint32_t nxt = abv ? (uint32_t)__builtin_ctz(abv) : 32u;
+					const uint32_t glim = g32 == nlastg ? nlastw : 32u;
+					const uint32_t wend = nxt < glim ? nxt : glim;
+					const bool rle = wend - w0 > 1u;
+					const int off_lo = (int)(koff - (w0 << RB3_WIN_BITS)), off_hi = off_lo + (int)kq;
+					const bool same = koff + kq <= (wend << RB3_WIN_BITS);
+					const unsigned long long m_pair = RB3_BAL(wend - w0 > 1u) & RB3_BAL(koff + kq <= (wend << RB3_WIN_BITS));
+					const bool far = !same && kq > 255u;
+					RankLoadC rl;
+					rl.gc = 0, rl.koff = koff, rl.sidx = sidx, rl.sm = sm, rl.sl2 = make_uint4(0u, 0u, 0u, 0u);
+					uint4 slb;
+					const uint32_t so = sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * 16u; // (fewer than 2^24 slots: the byte offset fits 32 bits)
+					rl.sl = *(const uint4*)((const char*)b1.slot16 + so);
+					if (m_pair == exm) slb = make_uint4(0u, 0u, 0u, 0u); // every interval of the wave inside one run slot: nobody looks at a second one
+					else slb = *(const uint4*)((const char*)b1.slot16 + (so + (same ? 0u : (uint32_t)sizeof(rb3_slot_t))));
+					const uint32_t kbw = xw >> 3; // the row
+					if ((kq == 0u || sid >= 0) && (uint32_t)j == (its & 7u)) {
+						const int64_t myval = (int64_t)((uint64_t)lo32 + (uint64_t)kbw);
+						bkb = trec ? (int64_t)tp32 : (int64_t)kbw, bval = kq ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
+					}
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					const uint32_t hdr_c = oct_pick(rl.sl.x, c + 1); // the LF base of c at the slot start: the next point lies in its group or in the one behind it
+					pf_g = hdr_c >> RB3_GRP_BITS;
+					pf_w.x = *(const uint32_t*)((const char*)b1.gsm + ((pf_g << 3) + (((uint32_t)j & 3u) << 2))); // (the directory has a spare word behind the last group's)
+					if ((its & 7u) == 7u) { // the end of a window of eight iterations: its events, then its records (a scalar test)
+						evq_flush();
+						if (bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
+					}
+					uint32_t lo_n, hi_n;
+					if (m_pair == exm) { // everybody inside one run slot
+						uint32_t ca, cb, mt;
+						slice_count_pk<true, false, 8>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
+						const uint32_t v = oct_sum(ca | cb << 16);
+						lo_n = hdr_c + (v & 0xFFFFu), hi_n = hdr_c + (v >> 16);
+					} else if (wave_all(rle && (oct_bcast0(slb.x, j) & RB3_SLOT_RLE) != 0u && !far)) { // some interval straddles two run slots: everybody through the two-slot decode
+						uint32_t ca, cb;
+						slice_count_pk2<8>(rl.sl, rl.sl2, slb, slb, off_lo, same ? off_hi : off_hi - (int)((wend - w0) << RB3_WIN_BITS), c, j, &ca, &cb);
+						const uint32_t v = oct_sum(ca | cb << 16);
+						const uint32_t hh = oct_pick(slb.x, c + 1);
+						lo_n = hdr_c + (v & 0xFFFFu), hi_n = hh + (v >> 16);
+					} else if (rle && same) {
+						uint32_t ca, cb, mt;
+						slice_count_pk<true, false, 8>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
+						const uint32_t v = oct_sum(ca | cb << 16);
+						lo_n = hdr_c + (v & 0xFFFFu), hi_n = hdr_c + (v >> 16);
+					} else { // a bit-plane slot somewhere
+						uint32_t match = 0, mh;
+						const int64_t l64 = octc_finish<false, 8>(rl, c, j, &match);
+						int64_t h64 = kq == 1u ? l64 + match : l64;
+						if (kq >= 2u) {
+							RankLoadC rh;
+							octc_issue_grp<false, 8>(b1, (int64_t)lo32 + (int64_t)kq, c, j, rh);
+							octc_issue_slot_hi<false, 8>(b1, j, rh, rl);
+							h64 = octc_finish<false, 8, false>(rh, c, j, &mh);
+						}
+						lo_n = (uint32_t)l64, hi_n = (uint32_t)h64;
+					}
+					const uint32_t kn = hi_n - lo_n;
+					if (kq >= 2u && sid >= 0 && kn >= 1u && kn < kq) { // some matching suffixes are not preceded by c: a new stretch (an EVENT, noted in LDS)
+						int ns = sid + 1;
+						if (sid == RB3_TENT_POISON) ns = RB3_TENT_POISON;
+						else if ((ns & (RB3_TENT_CHUNK - 1)) == 0) {
+							uint32_t s0 = 0;
+							if (j == 0) s0 = tent_take_chunk(sidctr, mctr, myctr);
+							s0 = oct_bcast0(s0, j);
+							ns = s0 + RB3_TENT_CHUNK <= lim_blocks ? (int)s0 : RB3_TENT_POISON;
+						}
+						if (j == 0 && ns != RB3_TENT_POISON) {
+							const uint64_t ew0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, (uint64_t)lo32), ew1 = (uint64_t)kq | (uint64_t)c << 16 | (uint64_t)tp32 << RB3_EV_TP_SHIFT;
+							const uint32_t qi = (threadIdx.x & ~7u) + (its & 7u);
+							evq_[2 * qi] = make_uint4((uint32_t)ew0, (uint32_t)(ew0 >> 32), (uint32_t)ew1, (uint32_t)(ew1 >> 32));
+							*(uint2*)&evq_[2 * qi + 1] = make_uint2((uint32_t)ns, (uint32_t)sid0 + 1u);
+							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+						}
+						sid = ns;
+					}
+					tp32 -= 1u, xw = x1w, x1w = xn, lo32 = lo_n, kq = kn;
+				}
+				// back to the general step's 64-bit state (d == 0: nothing happened)
+				it += d, age += d, steps += d, remaining -= (int64_t)d;
+				lo = (int64_t)lo32, hi = (int64_t)lo32 + (int64_t)kq, gap = kq > 1u ? 2 : (int)kq;
+				x = (uint64_t)xw, x1 = (uint64_t)x1w, tp = (int64_t)tp32, kb = (int64_t)(xw >> 3);
+#undef RB3_BAL
+			} else
+#endif
+			if (LIST && !DENSE && TENT && TEXT == 1) for (;;) { // (the common steps of a wave run back to back in this loop of their own: through the do-while's condition the
+				// compiler's structured control flow took every one of them round the OUTER loop's header as well -- ~35 instructions and six taken branches per step, round 6)
 				// ---- the common step, straight-line.  A genome walked through an index of its relatives spends nine steps in ten in
 				// one state: inside its own segment (so nobody has recorded the row and nothing ends here), not at a sentinel, its
 				// stretch -- if it records tentatively -- already open.  Everything the general step below tests for on the way
@@ -1255,7 +1397,8 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				const unsigned long long m_simple = RB3_BAL((uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1)) & RB3_BAL(cq != 0u) & RB3_BAL((int32_t)(rc >> 32) < 0)
 					& ~(RB3_BAL(gap != 0) & RB3_BAL(sid == -1) & RB3_BAL(age >= RB3_TENT_MIN_AGE))
 					& RB3_BAL(((uint32_t)lo & (RB3_GRP - 1)) + kq32 <= (uint32_t)RB3_GRP) & RB3_BAL(kq32 <= (uint32_t)kmax);
-				if (m_simple == exm) {
+				if (m_simple != exm) break; // somebody is in another state: one general step for the whole wave (it handles everything), then back here
+				{
 #ifdef RB3_PROF_STEP /* kernel experiment: where does an iteration of the common step spend its cycles?  (s_memtime at four points) */
 					const uint64_t pt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1267,7 +1410,16 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					RankLoadC rl;
 #ifndef RB3_NO_GSM_PF
 					const uint32_t pf_d = ((uint32_t)lo >> RB3_GRP_BITS) - pf_g; // 0 or 1 if the words asked for during the last step are the ones needed
+#ifndef RB3_NO_TA_DIET
+					// (lane j of a quad holds dword j of the 16 bytes asked for: four DPP broadcasts inside the quad put the pair together)
+					if (I32 && RB3_BAL(pf_d <= 1u) == exm) {
+						const uint32_t v2 = dpp_mov<0xEE>(pf_w.x), v0 = dpp_mov<0x44>(pf_w.x); // quad_perm [2,3,2,3] / [0,1,0,1]: the word of the group behind / of the group itself in lanes 0, 1
+						const uint32_t sel = pf_d ? v2 : v0;
+						rl.sm = (uint64_t)dpp_mov<0x55>(sel) << 32 | dpp_mov<0x00>(sel);
+					}
+#else
 					if (I32 && RB3_BAL(pf_d <= 1u) == exm) rl.sm = pf_d ? ((uint64_t)pf_w.w << 32 | pf_w.z) : ((uint64_t)pf_w.y << 32 | pf_w.x);
+#endif
 					else
 #endif
 					if (I32) rl.sm = *(const uint64_t*)((const char*)b1.gsm + (((uint32_t)lo >> RB3_GRP_BITS) << 3));
@@ -1276,7 +1428,13 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					if (!I32 && !b1.abs) rl.gc = b1.grp64[g * 8 + c]; // (headers relative to the group: an index of 2^32 symbols or more)
 					const int64_t tpn = I32 ? (int64_t)((uint32_t)tp - 1u) : tp - 1; // (c != 0: there is a symbol before this one, so tp >= 1)
 					uint64_t xn;                                      // the word after next
-					if (I32) xn = *(const uint64_t*)((const char*)tw + (((uint32_t)tp >= 2u ? (uint32_t)tp - 2u : 0u) << 3)); // (read as a stream -- nt -- it was 8 % SLOWER: the L1 no longer serves the 15 steps that share a line; one 64-byte request per octet and eight steps, handed out by ds_bpermute as TEXT = 2 does: 33 % slower, profiles/r5_ab_text_words_block.txt)
+#ifndef RB3_NO_TA_DIET
+					// (I32: fewer than 2^29 rows, so a text-order word is its low half -- a dword per lane: the address unit of a compute unit handles a wave's request
+					// lane by lane and dword by dword, whatever the lanes share, and it is what this kernel fills: round 6)
+					if (I32) xn = (uint64_t)*(const uint32_t*)((const char*)tw + (((uint32_t)tp >= 2u ? (uint32_t)tp - 2u : 0u) << 3));
+#else
+					if (I32) xn = *(const uint64_t*)((const char*)tw + (((uint32_t)tp >= 2u ? (uint32_t)tp - 2u : 0u) << 3));
+#endif // (read as a stream -- nt -- it was 8 % SLOWER: the L1 no longer serves the 15 steps that share a line; one 64-byte request per octet and eight steps, handed out by ds_bpermute as TEXT = 2 does: 33 % slower, profiles/r5_ab_text_words_block.txt)
 					else xn = tw[tpn > 0 ? tpn - 1 : 0];
 					const int64_t kbn = I32 ? (int64_t)((uint32_t)x1 >> 3) : (int64_t)(x1 >> 3);
 					rl.koff = (uint32_t)lo & (RB3_GRP - 1);
@@ -1306,7 +1464,12 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					if (I32) { // (fewer than 2^24 slots: the byte offset fits 32 bits)
 						const uint32_t so = rl.sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * (LPW == 8 ? 16u : 32u);
 						const uint32_t sob = so + (same ? 0u : (uint32_t)sizeof(rb3_slot_t));
+#ifdef RB3_EXP_SLOT_NT /* kernel experiment: the slot lines read as a stream (they are 98 MB of random lines against 4 MB of L2 per XCD) */
+						{ typedef uint32_t rb3_u32x4 __attribute__((ext_vector_type(4)));
+						  const rb3_u32x4 t = __builtin_nontemporal_load((const rb3_u32x4*)((const char*)b1.slot16 + so)); rl.sl = make_uint4(t.x, t.y, t.z, t.w); }
+#else
 						rl.sl = *(const uint4*)((const char*)b1.slot16 + so);
+#endif
 #ifndef RB3_NO_SKIP_DUP
 						if (m_pair == exm) slb = make_uint4(0u, 0u, 0u, 0u); // every interval of the wave inside one run slot: nobody looks at a second one
 						else
@@ -1320,6 +1483,9 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 						if (LPW == 8) slb = b1.slot16[sb * 8 + j];
 						else slb = b1.slot16[sb * 8 + 2 * j], slb2 = b1.slot16[sb * 8 + 2 * j + 1];
 					}
+#ifdef RB3_EXP_PRIO
+					if (RB3_EXP_PRIO == 2) { asm volatile("" :: "v"(rl.sl.x), "v"(slb.x)); __builtin_amdgcn_s_setprio(0); } // the slot is asked for: nothing to do but wait
+#endif
 #ifdef RB3_PROF_STEP
 					asm volatile("s_nop 0" :: "v"(rl.sidx));
 					const uint64_t pt1 = __builtin_amdgcn_s_memtime(); // the directory word has arrived, the slot is requested
@@ -1330,21 +1496,33 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					if ((gap == 0 || sid >= 0) && j == (int)(it & (uint32_t)(LPW - 1)))
 						bkb = trec ? tp : kb, bval = gap ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RB3_EXP_PRIO
+					if (RB3_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(3); // the slot is here: through the decode and up to the next slot request ahead of the waves that would only wait again
+#endif
 					uint32_t hdr_c = 0u;
 #ifndef RB3_NO_GSM_PF
 					if (I32 && LPW == 8) { // (before the record store: what is asked for behind a written-through store waits for its acknowledgement)
 						hdr_c = oct_pick(rl.sl.x, c + 1);
 						pf_g = hdr_c >> RB3_GRP_BITS;
+#ifndef RB3_NO_TA_DIET
+						// one dword per lane -- lane j of a quad dword j of the two words -- instead of all 16 bytes in every lane: a quarter of the address unit's work
+						pf_w.x = *(const uint32_t*)((const char*)b1.gsm + ((pf_g << 3) + (((uint32_t)j & 3u) << 2))); // (the directory has a spare word behind the last group's)
+#else
 						const uint2 *pfp = (const uint2*)((const char*)b1.gsm + (pf_g << 3)); // (the directory has a spare word behind the last group's)
 						const uint2 pa = pfp[0], pb = pfp[1];
 						pf_w = make_uint4(pa.x, pa.y, pb.x, pb.y);
+#endif
 					}
 #endif
 					// the records of the last eight steps go out here, where nothing is asked for during the whole decode: the store is slow
 					// (written through) and whatever is asked for after it waits for its acknowledgement (vmcnt counts in order)
 					if ((it & (uint32_t)(LPW - 1)) == (uint32_t)(LPW - 1)) { // (the events of the window in front of its records)
 						evq_flush();
+#ifdef RB3_EXP_NORECST /* kernel experiment (wrong results, right timing): the common step without its record stores */
+						bkb = -1;
+#else
 						if (bkb >= 0) { rec_pos<false>(&row[bkb], bval, vis); bkb = -1; }
+#endif
 					}
 #ifdef RB3_PROF_STEP
 					asm volatile("s_nop 0" :: "v"(rl.sl.x));
@@ -1416,6 +1594,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 						asm volatile("s_nop 0" :: "v"((uint32_t)lo));
 						const uint64_t pt3 = __builtin_amdgcn_s_memtime();
 						prof_t[0] += pt1 - pt0, prof_t[1] += pt2 - pt1, prof_t[2] += pt3 - pt2, prof_t[3] += 1;
+						if ((it & 7u) == 0u) prof_u[0] += (pt1 - pt0) + (1ull << 40), prof_u[1] += pt2 - pt1; // the step behind a flush of records (count << 40 | directory wait; slot wait)
 						if (prof_last) prof_t[4] += pt0 - prof_last; // (from the end of one common step to the start of the next: the test, the loop)
 						prof_last = pt3;
 					}
@@ -1433,12 +1612,12 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 						if ((e0 ^ e1 ^ e2 ^ e3) == 0x7fffff1u) steps += 1000000u; // (keeps the chains alive; practically never true)
 					}
 #endif
-					continue;
 				}
 			}
 #endif
 #ifdef RB3_PROF_STEP
 			prof_last = 0;
+			const uint64_t ptg = __builtin_amdgcn_s_memtime(); // (the general step: its time and count, packed, in prof_t[6])
 #endif
 			++it;
 			pf_g = 0x80000000u;
@@ -1569,6 +1748,10 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 			if (TEXT) tp = tpn, x = x1, x1 = xn, rc = rcn;
 			else x = xn;
 			kb = kbn, lo = lo_n, hi = hi_n, gap = gap_n;
+#ifdef RB3_PROF_STEP
+			asm volatile("s_nop 0" :: "v"((uint32_t)lo));
+			prof_t[6] += (__builtin_amdgcn_s_memtime() - ptg) + (1ull << 32);
+#endif
 		} while (__all(active));
 	}
 	{ // one atomic per wave, not per octet (they all go to the same word, and the kernel is over when the last one has landed)
@@ -1579,6 +1762,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 #ifdef RB3_PROF_STEP
 	if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(nsteps + 33 + q, (unsigned long long)prof_t[q]); // misc[34..38]
 	if (lane == 0) atomicAdd(nsteps + 8, (unsigned long long)prof_t[5]), atomicAdd(nsteps + 9, (unsigned long long)prof_t[6]); // misc[9], misc[10]
+	if (lane == 0) atomicAdd(nsteps + 10, (unsigned long long)prof_u[0]), atomicAdd(nsteps + 11, (unsigned long long)prof_u[1]); // misc[11], misc[12]
 #endif
 #ifdef RB3_PROF
 	if (lane == 0) { // wave statistics: [8] max cycles, [9] sum cycles, [10] sum iterations, [11] waves, [12] max iterations

@@ -117,6 +117,29 @@ def test_interval_build_writes_every_format_from_the_intervals(tmp_path):
     assert hashlib.md5(fmd).hexdigest() == ent["fmd_md5"]
 
 
+def test_interval_build_saves_a_checkpoint_after_every_file(tmp_path):
+    """`build --gpus 3 --interval -S ck.fmr` over two input files (VERDICT r5 "missing" 4; build.c:232-238): after each file the FMR writer takes the
+    intervals where they are; the checkpoint after the last file decodes to the final index, and the one after the FIRST file -- kept by making
+    the second build stop there -- lets `build -i` go on to the same .fmd"""
+    ent = MAN["reads_fq"]
+    import gzip
+    src = gzip.open(os.path.join(util.GOLDEN, ent["inputs"][0]), "rb").read().split(b"\n")
+    recs = [b"\n".join(src[i:i + 4]) + b"\n" for i in range(0, len(src) - 3, 4)]   # FASTQ records
+    assert len(recs) > 100
+    f1, f2 = tmp_path / "a.fq", tmp_path / "b.fq"
+    f1.write_bytes(b"".join(recs[:len(recs) // 2])), f2.write_bytes(b"".join(recs[len(recs) // 2:]))
+    ck = tmp_path / "ck.fmr"
+    fmd, err = run(["build"] + ent["flags"] + ["-d", "-m20k", "--gpus", "3", "--interval", "-S", str(ck), str(f1), str(f2)])
+    assert hashlib.md5(fmd).hexdigest() == ent["fmd_md5"] and "index cut into 3 intervals" in err and err.count("saved the current index") == 2
+    got, _ = run(["recode", "-d", str(ck)])
+    assert got == fmd                                   # the checkpoint after the last file is the final index
+    ck1 = tmp_path / "ck1.fmr"
+    _, err1 = run(["build"] + ent["flags"] + ["-d", "-m20k", "--gpus", "3", "--interval", "-S", str(ck1), str(f1)])
+    assert "index cut into 3 intervals" in err1        # (the first file alone is several batches: its checkpoint came out of the intervals)
+    fmd2, _ = run(["build"] + ent["flags"] + ["-d", "-m20k", "-i", str(ck1), str(f2)])
+    assert fmd2 == fmd
+
+
 def test_interval_build_keeps_the_intervals_balanced(tmp_path):
     """`build --gpus 4 --interval` on 300 k synthetic reads in five batches: the same .fmd as the ordinary build, the
     intervals within 1 % of each other in symbols, no handle's peak device memory more than 1.3 x another's -- nothing of the size of the

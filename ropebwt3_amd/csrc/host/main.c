@@ -218,7 +218,8 @@ static int write_fmd(rb3gpu_t *h, FILE *fp)
 		ret = rb3h_fmdw_adopt(w, words, n_words, acc); /* takes the array over */
 		if (ret < 0) rb3gpu_host_free(words);
 		else if (rb3h_verbose >= 3) fprintf(stderr, "[M::%s::%.3f*%.2f] packed the FMD on the GPU\n", __func__, rb3h_realtime(), rb3h_percent_cpu());
-	} else if (ret == RB3GPU_EUNSUP || ret == RB3GPU_ENOMEM) { /* wider block headers needed, or no room to pack the whole index at once */
+	} else if (ret != RB3GPU_ESTATE && ret != RB3GPU_EINVAL) { /* wider block headers needed, no room to pack the whole index at once -- or the packer gave up: the host's encoder takes the runs chunk by chunk */
+		if (ret != RB3GPU_EUNSUP && ret != RB3GPU_ENOMEM && rb3h_verbose >= 2) fprintf(stderr, "[W::%s] the GPU's FMD packer failed (%s); encoding on the host\n", __func__, rb3gpu_strerror(ret));
 		ret = rb3gpu_export_run_words(h, sink_fmd_words, w);
 		if (ret == 0) ret = rb3h_fmdw_finish(w);
 	}

@@ -123,6 +123,8 @@ struct Tune {
 	int log_alloc = 0;       // print every device allocation and the time it took
 	int poison = 0;          // fill every new device buffer with 0xA5 bytes (debugging: nothing may rely on what fresh memory holds)
 	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
+	int vmm = 1;             // (values above 1: the threshold in KB instead of 64 MB -- tests make every buffer a growable range) buffers of 64 MB and more are ranges of reserved device address space that grow IN PLACE, a few physical chunks at a time (vm_ensure; round 6); 0: hipMalloc + reallocation
+	int vmm_reserve = 0;     // (tests) MB of address space a new range reserves instead of 32 x its size (at least 16 GB)
 	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
 	int sh_host_rounds = 0;  // rb3gpu_sh_merge with ONE interval: the host reads the split sizes back after every round, as with several (0: the rounds run back to back on the device)
 	int sh_block = 0;        // threads per block of k_sh_round at eight states per octet: 256 or 1024; 0: 1024 below 3 M chains
@@ -145,6 +147,18 @@ struct Tune {
 	int64_t win_scratch = 0; // > 0: pretend the window kernels' scratch may take this many bytes instead of 8 GB (beyond: group-sequential rebuild)
 	int64_t slot_bytes = 0;  // > 0: pretend the upper bound of the slot array may take this many bytes instead of 16 GB (beyond: staged path)
 #endif
+};
+
+/* A buffer that GROWS IN PLACE (round 6).  The buffers of an index that grows round by round -- the two slot arrays, the rows' positions, the scratch of
+ * the rebuild -- used to be given up and obtained again, an eighth larger, every few merges: device memory costs ~37 us per MB to obtain, a 10 GB slot
+ * array 0.4 s, and 60 M reads (18 G symbols) spent 4.0 of their 14 s in 108 hipMalloc calls with 69 GB of device memory around a 9.2 GB index (the slack,
+ * and the replaced buffers waiting for their hipFree).  Now such a buffer is a RANGE OF RESERVED ADDRESS SPACE (hipMemAddressReserve: the device has
+ * 2^48 bytes of it) into which physical chunks are mapped as it grows (hipMemCreate + hipMemMap): growing costs the new bytes only, nothing is copied,
+ * replaced or left over, the contents stay, and the address never changes. */
+struct VmRange {
+	void *va = nullptr;
+	size_t va_size = 0, mapped = 0;
+	std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t> > hs; // physical chunks in address order
 };
 
 struct rb3gpu_s {
@@ -174,6 +188,10 @@ struct rb3gpu_s {
 	int64_t *mg_pos = nullptr;
 	hipEvent_t ev[8];
 	int64_t bytes_owned = 0;
+	size_t dev_mem = 0;         // the device's memory (what the scratch limits of the rebuild are fractions of)
+	std::vector<VmRange*> vmr;  // the growable ranges of this handle (vm_ensure)
+	int vm_state = 0;           // 0: not asked yet, 1: the device maps memory into reserved address space, -1: it does not (or tune vmm = 0): hipMalloc
+	size_t vm_gran = 0, vm_total = 0; // granularity of a physical chunk, the device's memory (the most a range ever reserves)
 	std::vector<std::pair<void*, size_t> > garbage; // replaced buffers not yet given back (dev_free)
 	int64_t bytes_garbage = 0;
 	uint64_t reb_slot_cap = 0; // capacity of the slot array the last rebuild emitted into (build_index)
@@ -241,9 +259,19 @@ static int dev_malloc(rb3gpu_t *h, void **p, size_t bytes)
 	return 0;
 }
 
+static VmRange *vm_find(rb3gpu_t *h, const void *p);
+static void vm_release(rb3gpu_t *h, VmRange *r);
+
 static void dev_free(rb3gpu_t *h, void *p, size_t bytes)
 {
 	if (p == nullptr) return;
+	if (VmRange *r = vm_find(h, p)) { // (rare: a growable range is only given up with its handle, or when an index is dropped)
+		const double t0 = now_s();
+		(void)hipStreamSynchronize(h->st), (void)hipStreamSynchronize(h->st2);
+		vm_release(h, r);
+		h->stt.ms_alloc += (now_s() - t0) * 1e3;
+		return;
+	}
 	if (bytes == 0) bytes = 256;
 	if (h->tn.guard) bytes += RB3_GUARD;
 	if (h->tn.defer_free) { // (every user of the buffer is on h->st or joined to it, and the list is only emptied by hipFree, which waits for the device)
@@ -256,11 +284,133 @@ static void dev_free(rb3gpu_t *h, void *p, size_t bytes)
 	h->bytes_owned -= (int64_t)bytes;
 }
 
+#define RB3_VM_MIN ((size_t)64 << 20) /* smaller buffers: hipMalloc */
+
+static bool vm_usable(rb3gpu_t *h, size_t bytes)
+{
+	if (h->vm_state == 0) {
+		int ok = 0;
+		h->vm_state = -1;
+		if (h->tn.vmm && !h->tn.guard && hipDeviceGetAttribute(&ok, hipDeviceAttributeVirtualMemoryManagementSupported, h->dev) == hipSuccess && ok) {
+			hipMemAllocationProp prop;
+			memset(&prop, 0, sizeof(prop));
+			prop.type = hipMemAllocationTypePinned, prop.location.type = hipMemLocationTypeDevice, prop.location.id = h->dev;
+			size_t gran = 0, fr = 0, tot = 0;
+			if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 && hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0)
+				h->vm_gran = gran < ((size_t)2 << 20) ? ((size_t)2 << 20) : gran, h->vm_total = (tot + h->vm_gran - 1) / h->vm_gran * h->vm_gran, h->vm_state = 1;
+		}
+		(void)hipGetLastError();
+	}
+	return h->vm_state == 1 && bytes >= (h->tn.vmm > 1 ? (size_t)h->tn.vmm << 10 : RB3_VM_MIN);
+}
+
+static VmRange *vm_find(rb3gpu_t *h, const void *p)
+{
+	if (p) for (VmRange *r : h->vmr) if (r->va == p) return r;
+	return nullptr;
+}
+
+static int vm_map_chunk(rb3gpu_t *h, VmRange *r, size_t off, hipMemGenericAllocationHandle_t hd, size_t size)
+{
+	if (hipMemMap((char*)r->va + off, size, 0, hd, 0) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENOMEM; }
+	hipMemAccessDesc ad[RB3GPU_SH_MAXIV + 1];
+	int nad = 0, ndev = 0;
+	memset(ad, 0, sizeof(ad));
+	ad[nad].location.type = hipMemLocationTypeDevice, ad[nad].location.id = h->dev, ad[nad].flags = hipMemAccessFlagsProtReadWrite, ++nad;
+	if (hipGetDeviceCount(&ndev) == hipSuccess) // (the peers that pull from this device's buffers: rb3gpu_comm.hip)
+		for (int d = 0; d < ndev && nad < RB3GPU_SH_MAXIV + 1; ++d) {
+			int can = 0;
+			if (d != h->dev && hipDeviceCanAccessPeer(&can, d, h->dev) == hipSuccess && can)
+				ad[nad].location.type = hipMemLocationTypeDevice, ad[nad].location.id = d, ad[nad].flags = hipMemAccessFlagsProtReadWrite, ++nad;
+		}
+	if (hipMemSetAccess((char*)r->va + off, size, ad, (size_t)nad) != hipSuccess) {
+		(void)hipGetLastError();
+		if (nad == 1 || hipMemSetAccess((char*)r->va + off, size, ad, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap((char*)r->va + off, size); return RB3GPU_ENOMEM; }
+	}
+	return 0;
+}
+
+/* *p (a range of this handle, or NULL) holds at least `bytes` mapped bytes afterwards; what it held stays; *cap = the mapped bytes.  < 0: nothing changed */
+static int vm_ensure(rb3gpu_t *h, void **p, size_t *cap, size_t bytes)
+{
+	const size_t G = h->vm_gran;
+	VmRange *r = vm_find(h, *p);
+	const double t0 = now_s();
+	if (r == nullptr) {
+		r = new (std::nothrow) VmRange();
+		if (!r) return RB3GPU_ENOMEM;
+		size_t want = bytes * 32 < ((size_t)16 << 30) ? ((size_t)16 << 30) : bytes * 32; // address space is free: room for the buffer to grow thirty-two-fold where it stands
+		if (h->tn.vmm_reserve > 0) want = (size_t)h->tn.vmm_reserve << 20; // (tests: a small reservation, so that ranges move to larger ones)
+		want = (want + G - 1) / G * G;
+		if (want > h->vm_total) want = h->vm_total;
+		if (want < (bytes + G - 1) / G * G) want = (bytes + G - 1) / G * G;
+		if (hipMemAddressReserve(&r->va, want, G, nullptr, 0) != hipSuccess || r->va == nullptr) { (void)hipGetLastError(); delete r; return RB3GPU_ENOMEM; }
+		r->va_size = want;
+		h->vmr.push_back(r);
+	}
+	if (bytes > r->va_size) { // the reserved range is used up (the buffer grew more than eightfold): a larger one, the same physical chunks mapped into it -- nothing is copied
+		size_t want = r->va_size * 4 > bytes * 2 ? r->va_size * 4 : bytes * 2;
+		want = (want + G - 1) / G * G;
+		void *nva = nullptr;
+		HIPCHK(hipStreamSynchronize(h->st));  // (kernels in flight use the old addresses)
+		HIPCHK(hipStreamSynchronize(h->st2));
+		if (hipMemAddressReserve(&nva, want, G, nullptr, 0) != hipSuccess || nva == nullptr) { (void)hipGetLastError(); return RB3GPU_ENOMEM; }
+		VmRange nr;
+		nr.va = nva, nr.va_size = want;
+		size_t off = 0;
+		for (auto &c : r->hs) { (void)hipMemUnmap((char*)r->va + off, c.second); off += c.second; }
+		off = 0;
+		for (auto &c : r->hs) { if (vm_map_chunk(h, &nr, off, c.first, c.second) < 0) return RB3GPU_EINTERNAL; off += c.second; }
+		(void)hipMemAddressFree(r->va, r->va_size);
+		r->va = nva, r->va_size = want;
+	}
+	if (bytes > r->mapped) {
+		size_t inc = (bytes - r->mapped + G - 1) / G * G;
+		hipMemAllocationProp prop;
+		memset(&prop, 0, sizeof(prop));
+		prop.type = hipMemAllocationTypePinned, prop.location.type = hipMemLocationTypeDevice, prop.location.id = h->dev;
+		hipMemGenericAllocationHandle_t hd;
+		hipError_t e = hipMemCreate(&hd, inc, &prop, 0);
+		if (e == hipErrorOutOfMemory && !h->garbage.empty()) { (void)hipGetLastError(); garbage_collect(h, true); e = hipMemCreate(&hd, inc, &prop, 0); }
+		if (e != hipSuccess) { (void)hipGetLastError(); if (r->mapped == 0) { (void)hipMemAddressFree(r->va, r->va_size); h->vmr.erase(std::find(h->vmr.begin(), h->vmr.end(), r)); delete r; } return RB3GPU_ENOMEM; }
+		if (vm_map_chunk(h, r, r->mapped, hd, inc) < 0) { (void)hipMemRelease(hd); if (r->mapped == 0) { (void)hipMemAddressFree(r->va, r->va_size); h->vmr.erase(std::find(h->vmr.begin(), h->vmr.end(), r)); delete r; } return RB3GPU_ENOMEM; }
+		r->hs.push_back(std::make_pair(hd, inc));
+		r->mapped += inc;
+		h->bytes_owned += (int64_t)inc;
+		if (h->bytes_owned > h->stt.bytes_peak) h->stt.bytes_peak = h->bytes_owned;
+		h->stt.n_allocs += 1;
+		if (h->tn.log_alloc) fprintf(stderr, "[M::rb3gpu] %.1f MB mapped behind %.1f MB at %p in %.3f ms\n", (double)inc / 1e6, (double)(r->mapped - inc) / 1e6, r->va, (now_s() - t0) * 1e3);
+		if (h->tn.poison) HIPCHK(hipMemsetAsync((char*)r->va + r->mapped - inc, 0xA5, inc, h->st));
+	}
+	h->stt.ms_alloc += (now_s() - t0) * 1e3;
+	*p = r->va, *cap = r->mapped;
+	return 0;
+}
+
+/* give a range back (the device must be done with it: callers synchronise) */
+static void vm_release(rb3gpu_t *h, VmRange *r)
+{
+	size_t off = 0;
+	for (auto &c : r->hs) { (void)hipMemUnmap((char*)r->va + off, c.second); (void)hipMemRelease(c.first); off += c.second; }
+	(void)hipMemAddressFree(r->va, r->va_size);
+	h->bytes_owned -= (int64_t)r->mapped;
+	h->vmr.erase(std::find(h->vmr.begin(), h->vmr.end(), r));
+	delete r;
+}
+
 static size_t grow_slack(size_t n) { return n < ((size_t)256 << 20) ? n >> 1 : n < ((size_t)2 << 30) ? n >> 2 : n >> 3; }
 
-static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes, bool exact = false)
+/* growable: the buffer may be a range that grows in place (vm_ensure) -- ONLY buffers that nothing but kernels touch: the runtime's copies and fills look an
+ * address up as ONE allocation, and a range is several (a copy across a chunk boundary of the records of the interval-sharded merge lost rows, round 6) */
+static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes, bool exact = false, bool growable = false)
 {
 	if (b.cap >= bytes && b.p) return 0;
+	if (growable && vm_usable(h, bytes)) { // grows where it stands: a sixteenth of slack (at most 256 MB) so that not every merge maps a chunk
+		const size_t sl = exact ? 0 : (bytes >> 4) < ((size_t)256 << 20) ? (bytes >> 4) : ((size_t)256 << 20);
+		if (b.p && !vm_find(h, b.p)) dev_free(h, b.p, b.cap), b.p = nullptr, b.cap = 0; // (it was small so far)
+		if (vm_ensure(h, &b.p, &b.cap, bytes + sl + 256) == 0 || vm_ensure(h, &b.p, &b.cap, bytes + 256) == 0) return 0;
+		if (b.p && b.cap >= bytes) return 0;
+	}
 	if (b.p) dev_free(h, b.p, b.cap);
 	b.p = nullptr, b.cap = 0;
 	// geometric growth: an index that grows round by round must not realloc every round (exact: a one-off, e.g. loading an index, or a table of a fixed size).
@@ -438,6 +588,8 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "blkcap")) t.blkcap = v < 1 ? 1 : v;
 	else if (!strcmp(key, "chain_bs")) t.chain_bs = v == 64 ? 64 : v == 128 ? 128 : 256;
 	else if (!strcmp(key, "lf_after")) t.lf_after = v != 0;
+	else if (!strcmp(key, "vmm")) t.vmm = v < 0 ? 0 : (int)v;
+	else if (!strcmp(key, "vmm_reserve")) t.vmm_reserve = v < 0 ? 0 : (int)v;
 	else if (!strcmp(key, "copy_walkers")) t.copy_walkers = v != 0;
 	else if (!strcmp(key, "trec")) t.trec = v < 0 ? -1 : v != 0;
 	else if (!strcmp(key, "abs_limit")) {
@@ -489,7 +641,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "vmm", "vmm_reserve", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -514,6 +666,7 @@ rb3gpu_t *rb3gpu_create(const rb3gpu_opt_t *opt)
 	rb3gpu_t *h = new (std::nothrow) rb3gpu_s();
 	if (!h) return nullptr;
 	h->dev = o.device, h->opt = o;
+	{ size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) h->dev_mem = tot; else (void)hipGetLastError(); }
 	tune_from_env(h);
 	memset(&h->stt, 0, sizeof(h->stt));
 	if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { delete h; return nullptr; }
@@ -545,6 +698,14 @@ static void ib_release(rb3gpu_t *h, int i)
 static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exact = false)
 {
 	int r;
+	// (the slot array grows in place; the directory -- 72 bytes per 8192 symbols, read back by the host in places -- stays an ordinary allocation)
+	if (h->ib[i].slots_cap < (size_t)nslots && vm_usable(h, (size_t)nslots * sizeof(rb3_slot_t))) {
+		void *p = h->ib[i].slots;
+		size_t cap = 0;
+		if (p && !vm_find(h, p)) dev_free(h, p, h->ib[i].slots_cap * sizeof(rb3_slot_t)), p = nullptr, h->ib[i].slots = nullptr, h->ib[i].slots_cap = 0;
+		const size_t slk = exact ? 0 : ((size_t)nslots >> 4) < ((size_t)2 << 20) ? ((size_t)nslots >> 4) : ((size_t)2 << 20); // (a sixteenth, at most 256 MB)
+		if (vm_ensure(h, &p, &cap, ((size_t)nslots + slk + 64) * sizeof(rb3_slot_t)) == 0) h->ib[i].slots = (rb3_slot_t*)p, h->ib[i].slots_cap = cap / sizeof(rb3_slot_t);
+	}
 	if (h->ib[i].grp_cap < (size_t)ngrp) {
 		dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * RB3_GRP_ALLOC);
 		h->ib[i].grp = nullptr, h->ib[i].grp_cap = 0;
@@ -700,21 +861,22 @@ static size_t lim_win_scratch(const rb3gpu_t *h)
 #ifdef RB3GPU_TEST_HOOKS
 	if (h->tn.win_scratch > 0) return (size_t)h->tn.win_scratch;
 #endif
-	(void)h;
-	return (size_t)8 << 30;
+	// (8 GB until round 5: an index of 9.5 G symbols fell off it onto the group-sequential kernels -- 12 -> 58 ms per rebuild, 120 ms at 24 G symbols,
+	// tools/r6/scale_hap.sh.  A quarter of the device's memory: 72 GB of 288)
+	return h->dev_mem / 4 > ((size_t)8 << 30) ? h->dev_mem / 4 : (size_t)8 << 30;
 }
 static size_t lim_slot_bytes(const rb3gpu_t *h)
 {
 #ifdef RB3GPU_TEST_HOOKS
 	if (h->tn.slot_bytes > 0) return (size_t)h->tn.slot_bytes;
 #endif
-	(void)h;
-	return (size_t)16 << 30;
+	return h->dev_mem / 3 > ((size_t)16 << 30) ? h->dev_mem / 3 : (size_t)16 << 30; // (16 GB until round 5; a third of the device's memory)
 }
 
 static bool use_winpar(const rb3gpu_t *h, int64_t nwin)
 {
-	return (size_t)nwin * 216 <= lim_win_scratch(h) && !h->tn.group_rebuild;
+	// (scratch per window: 128 B of slots in plane space, 216 B for the window kernels of rounds 1-3)
+	return (size_t)nwin * (h->tn.plane_rebuild && !h->tn.window_rebuild ? 136 : 216) <= lim_win_scratch(h) && !h->tn.group_rebuild;
 }
 
 /* slots to make room for before a single-sync merge of n2 rows: one per window is the upper bound; where the index is
@@ -779,11 +941,11 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	if (winpar) {
 		const int64_t nws = runspace ? lcap * RB3_GRP_WINS : nwin;
 		if (planes) {
-			if ((r = buf_ensure(h, h->pslots, (size_t)(runspace ? lcap : ngrp) * RB3_GRP_WINS * sizeof(rb3_slot_t))) < 0) return r;
+			if ((r = buf_ensure(h, h->pslots, (size_t)(runspace ? lcap : ngrp) * RB3_GRP_WINS * sizeof(rb3_slot_t), false, true)) < 0) return r;
 		} else {
-			if ((r = buf_ensure(h, h->wstat, (size_t)nws * 16)) < 0) return r;
-			if ((r = buf_ensure(h, h->wplane, (size_t)nws * 96)) < 0) return r;
-			if ((r = buf_ensure(h, h->wruns, (size_t)nws * RB3_RLE_CODES * 2)) < 0) return r;
+			if ((r = buf_ensure(h, h->wstat, (size_t)nws * 16, false, true)) < 0) return r;
+			if ((r = buf_ensure(h, h->wplane, (size_t)nws * 96, false, true)) < 0) return r;
+			if ((r = buf_ensure(h, h->wruns, (size_t)nws * RB3_RLE_CODES * 2, false, true)) < 0) return r;
 		}
 		if (!FROM_PLAIN && (r = buf_ensure(h, h->jg, (size_t)(nwin + 1) * 8)) < 0) return r;
 		jg = (int64_t*)h->jg.p;
@@ -795,7 +957,7 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 	uint32_t *glist[2] = {nullptr, nullptr}, *nglist = nullptr, *gpos = nullptr;
 	uint8_t *gkind = nullptr;
 	if (runspace) {
-		if ((r = buf_ensure(h, h->gslots, (size_t)ngrp * RB3_RG_MAXSLOTS * sizeof(rb3_slot_t))) < 0) return r;
+		if ((r = buf_ensure(h, h->gslots, (size_t)ngrp * RB3_RG_MAXSLOTS * sizeof(rb3_slot_t), false, true)) < 0) return r;
 		if ((r = buf_ensure(h, h->glist, (size_t)ngrp * 13 + 64)) < 0) return r;
 		glist[0] = (uint32_t*)h->glist.p, glist[1] = glist[0] + ngrp, gpos = glist[1] + ngrp, gkind = (uint8_t*)(gpos + ngrp);
 		nglist = (uint32_t*)((uint64_t*)h->misc.p + MISC_RG_LISTS);
@@ -960,7 +1122,7 @@ static void index_install(rb3gpu_t *h, int64_t ngrp, int64_t nslots, int64_t nto
 	h->stt.bytes_index = ngrp * (int64_t)RB3_GRP_ALLOC + nslots * (int64_t)sizeof(rb3_slot_t);
 	// do not sit on a large spare buffer: the next merge re-allocates it (it is sized for a bigger index anyway)
 	const int o = 1 - h->cur;
-	if (h->ib[o].slots_cap * sizeof(rb3_slot_t) > ((size_t)4 << 30)) ib_release(h, o);
+	if (h->ib[o].slots_cap * sizeof(rb3_slot_t) > ((size_t)4 << 30) && !vm_find(h, h->ib[o].slots)) ib_release(h, o); // (a range that grows in place stays: the next rebuild maps what it lacks)
 }
 
 /* histogram + row words of B2 (LF word of every row, fm-index.c:206-216) into d_row.  Totals stay on the device (misc[MISC_LF_TOT..]); acc2 != NULL also
@@ -2777,6 +2939,18 @@ int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
 	if ((r = scan_records(h, cnt8, ngrp, off8, (uint64_t*)h->misc.p + MISC_IX_TOT, total)) < 0) return r;
 	const int64_t nr = (int64_t)total[0];
 	if (nr <= 0) return RB3GPU_EINTERNAL;
+	{ // the packer holds ~26 bytes per run beside the run starts (8): where that does not fit beside the merge scratch of the handle, the scratch goes (the next merge obtains it again)
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)nr * 34 > fr) {
+			HIPCHK(hipStreamSynchronize(h->st));
+			Buf *scratch[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->jg, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->shc, &h->shn, &h->shs, &h->shr };
+			for (Buf *b : scratch) buf_release(h, *b);
+			ib_release(h, 1 - h->cur);
+			garbage_collect(h, true);
+			h->sid_dirty[0] = h->sid_dirty[1] = RB3_TENT_HALF; // (the stretch table is gone: a fresh one is cleared whole)
+			if (h->opt.verbose >= 3) fprintf(stderr, "[M::%s::%.3f] %lld runs: the merge scratch of the handle released for the packer's tables\n", __func__, now_s() - h->t0, (long long)nr);
+		} else (void)hipGetLastError();
+	}
 	if ((r = buf_ensure(h, h->xbuf, (size_t)nr * 8)) < 0) return r;
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<true>), grid, blk, 0, h->st, iv, (int64_t)0, ngrp, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
 	r = rb3fmd_encode(h->st, h->n, nr, (const uint64_t*)h->xbuf.p, words, n_words);
@@ -2878,9 +3052,9 @@ static int from_fmd_chunked(rb3gpu_t *h, rb3fmd_dec *ctx, int64_t n, const int64
 	const int dst = 1 - h->cur;
 	int r;
 	if ((r = buf_ensure(h, h->b2, (size_t)csym + 16, true)) < 0) return r;
-	if ((r = buf_ensure(h, h->wstat, (size_t)(cwin + 1) * 16, true)) < 0) return r;
-	if ((r = buf_ensure(h, h->wplane, (size_t)(cwin + 1) * 96, true)) < 0) return r;
-	if ((r = buf_ensure(h, h->wruns, (size_t)(cwin + 1) * RB3_RLE_CODES * 2, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->wstat, (size_t)(cwin + 1) * 16, true, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->wplane, (size_t)(cwin + 1) * 96, true, true)) < 0) return r;
+	if ((r = buf_ensure(h, h->wruns, (size_t)(cwin + 1) * RB3_RLE_CODES * 2, true, true)) < 0) return r;
 	if ((r = buf_ensure(h, h->gstat, (size_t)ngrp * 32, true)) < 0) return r;
 	if ((r = buf_ensure(h, h->gpre, (size_t)ngrp * 64, true)) < 0) return r;
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
@@ -3134,6 +3308,7 @@ int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_
 static int buf_grow_keep(rb3gpu_t *h, Buf &b, size_t used, size_t bytes)
 {
 	if (b.cap >= bytes && b.p) return 0;
+	if (vm_find(h, b.p)) return buf_ensure(h, b, bytes); // (grows where it stands, contents and all)
 	Buf nb;
 	int r = buf_ensure(h, nb, bytes);
 	if (r < 0) return r;

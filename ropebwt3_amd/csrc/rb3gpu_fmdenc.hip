@@ -206,6 +206,26 @@ static bool fmd_debug(void)
 	return on;
 }
 
+/* exclusive scan of n code widths into bit offsets, a piece of at most 2^30 items at a time (the device scan takes a size_t, but an index of 24.8 G symbols
+ * in contigs of 40-135 Mbp -- more than 2^32 runs -- came back with offsets that made the chain below wander for ten minutes and give up: round 6) */
+#define FE_SCAN_PIECE ((int64_t)1 << 30)
+static int fe_scan_widths(hipStream_t st, void *tmp, size_t tb, const uint8_t *width, uint64_t *P, int64_t n)
+{
+	uint64_t base = 0;
+	for (int64_t o = 0; o < n; o += FE_SCAN_PIECE) {
+		const int64_t m = n - o < FE_SCAN_PIECE ? n - o : FE_SCAN_PIECE;
+		size_t b = tb;
+		if (rocprim::exclusive_scan(tmp, b, rocprim::make_transform_iterator(width + o, fe_widen()), P + o, base, (size_t)m, rocprim::plus<uint64_t>(), st) != hipSuccess) return -2;
+		if (o + m < n) { // the piece's total: its last offset + its last width
+			uint64_t lastP = 0;
+			uint8_t lastw = 0;
+			if (hipMemcpyAsync(&lastP, P + o + m - 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&lastw, width + o + m - 1, 1, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -2;
+			base = lastP + (uint64_t)lastw;
+		}
+	}
+	return 0;
+}
+
 int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words)
 {
 	int ret = 0;
@@ -226,12 +246,12 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 		hipMalloc(&scal, 64) != hipSuccess || hipMalloc(&flag, 16) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
 	hE = (uint8_t*)malloc((size_t)K * FE_ENTRIES * 2), hCn = (uint16_t*)malloc((size_t)K * FE_ENTRIES * 4), hlists = (int64_t*)malloc((size_t)(K + 1) * 24);
 	if (!hE || !hCn || !hlists) { ret = -1; goto done; }
-	FE_HIP(rocprim::exclusive_scan(nullptr, tb, rocprim::make_transform_iterator(width, fe_widen()), P, (uint64_t)0, (size_t)(nr + 1), rocprim::plus<uint64_t>(), st));
+	FE_HIP(rocprim::exclusive_scan(nullptr, tb, rocprim::make_transform_iterator(width, fe_widen()), P, (uint64_t)0, (size_t)(nr + 1 < FE_SCAN_PIECE ? nr + 1 : FE_SCAN_PIECE), rocprim::plus<uint64_t>(), st));
 	tb += 256;
 	if (hipMalloc(&tmp, tb) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
 	FE_HIP(hipMemsetAsync(flag, 0, 16, st));
 	hipLaunchKernelGGL(k_fe_width, FE_GRID(nr + 1), d_words, nr, n_sym, width, flag);
-	{ size_t b = tb; FE_HIP(rocprim::exclusive_scan(tmp, b, rocprim::make_transform_iterator(width, fe_widen()), P, (uint64_t)0, (size_t)(nr + 1), rocprim::plus<uint64_t>(), st)); }
+	if (fe_scan_widths(st, tmp, tb, width, P, nr + 1) < 0) { (void)hipGetLastError(); ret = -2; goto done; }
 	hipLaunchKernelGGL(k_fe_table, FE_GRID(K * FE_ENTRIES * 2), K, nr, n_sym, (const uint64_t*)P, d_words, E, Cn, flag);
 	FE_HIP(hipMemcpyAsync(hE, E, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipMemcpyAsync(hCn, Cn, (size_t)K * FE_ENTRIES * 4, hipMemcpyDeviceToHost, st));
@@ -251,7 +271,7 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 		int cty = (int)c1[2];
 		for (int64_t k = k0 + 1; cur < nr && gb <= s; ++k) {
 			const int64_t d = cur - k * FE_CHUNK;
-			if (d < 0 || d >= FE_ENTRIES) { ret = -3; goto done; }
+			if (d < 0 || d >= FE_ENTRIES) { if (fmd_debug()) fprintf(stderr, "[fmdenc] the chain left its chunk: run %lld in chunk %lld of %lld (block %lld)\n", (long long)cur, (long long)k, (long long)K, (long long)gb); ret = -3; goto done; }
 			ids[nl] = k, ent[nl] = cur << 1 | cty, bas[nl] = gb, ++nl;
 			const int64_t te = (k * FE_ENTRIES + d) * 2 + cty;
 			gb += hCn[te];
@@ -282,7 +302,7 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	hipLaunchKernelGGL(k_fe_pack, FE_GRID(B + 1), d_words, nr, n_sym, (const int64_t*)bs, B, out, flag, flag + 1);
 	FE_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
-	if (hflag[0] & 4u) { ret = -3; goto done; }
+	if (hflag[0] & 4u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: the packer met a block it cannot write\n", hflag[0]); ret = -3; goto done; }
 	if (hflag[0] & 11u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a 64-bit header\n", hflag[0]); ret = 1; goto done; }
 	{
 		const int64_t tailw = hflag[1] == 4u ? 4 : 2; // header words of the trailing header-only block (rld0.c:211)

@@ -1262,26 +1262,32 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 				uint32_t bud = (uint64_t)(remaining - 2) < (uint64_t)(RB3_BEYOND - 1) ? (remaining - 1 > 0x3FFFFFFFLL ? 0x3FFFFFFFu : (uint32_t)(remaining - 1)) : 0u;
 				// ... and, while it is inexact without a stretch, until it is old enough to open one (the general step does that)
 				uint32_t agelim = sid == -1 ? (age >= RB3_TENT_MIN_AGE ? 0u : RB3_TENT_MIN_AGE - age) : 0xFFFFFFFFu;
-				asm volatile("" : "+v"(bud), "+v"(agelim)); // (plain numbers from here on: the compiler folded the selects above into the loop's comparisons, two instructions a step each)
+				// (folded into ONE limit: an exact walker stays exact, so only a walker that is inexact on the way in can be the one that has to open a stretch; if it turns exact
+				// before that step it merely leaves the loop once too often)
+				if ((uint32_t)hi != (uint32_t)lo && agelim < bud) bud = agelim;
+				asm volatile("" : "+v"(bud)); // (a plain number from here on: the compiler folded the selects above into the loop's comparison, two instructions a step)
 				uint32_t lo32 = (uint32_t)lo, kq = (uint32_t)hi - (uint32_t)lo; // [lo32, lo32 + kq)
 				uint32_t xw = (uint32_t)x, x1w = (uint32_t)x1, tp32 = (uint32_t)tp;
 				uint32_t its = (uint32_t)__builtin_amdgcn_readfirstlane((int)it), d = 0u; // (the same in every lane: scalar registers)
 				const uint32_t nlastg = (uint32_t)b1.n >> RB3_GRP_BITS, nlastw = ((uint32_t)b1.n >> RB3_WIN_BITS & 31u) + 1u;
+				const uint32_t pick1 = (uint32_t)(((lane & ~7) + 1) << 2); // ds_bpermute address of header word 1 of this octet's slot
+				// the directory words of the first step's group, asked for here; every later step's are asked for by the step before it, from the slot header -- always the right ones (below)
+				pf_g = lo32 >> RB3_GRP_BITS;
+				pf_w.x = *(const uint32_t*)((const char*)b1.gsm + (((pf_g < (uint32_t)((b1.n >> RB3_GRP_BITS) + 1) ? pf_g : 0u) << 3) + (((uint32_t)j & 3u) << 2)));
 				for (;;) {
 					const uint32_t cq = xw & 7u;
-					const unsigned long long m_simple = RB3_BAL(d < bud) & RB3_BAL(cq != 0u) & m_rc & ~(RB3_BAL(kq != 0u) & RB3_BAL(d >= agelim))
+					const unsigned long long m_simple = RB3_BAL(d < bud) & RB3_BAL(cq != 0u) & m_rc
 						& RB3_BAL((lo32 & (RB3_GRP - 1)) + kq <= (uint32_t)RB3_GRP) & RB3_BAL(kq <= (uint32_t)kmax); // (a width that wraps the sum fails the last test)
 					if (m_simple != exm) break;
 					++its, ++d;
 					const int c = (int)cq;
 					const uint32_t g32 = lo32 >> RB3_GRP_BITS;
 					uint64_t sm;
-					const uint32_t pf_d = g32 - pf_g; // 0 or 1 if the words asked for during the last step are the ones needed
-					if (RB3_BAL(pf_d <= 1u) == exm) {
+					{ // the words asked for during the last step are the ones needed: the point lies at most a slot's symbols (<= 8192) behind the header's LF base, i.e. in its group or the next
 						const uint32_t v2 = dpp_mov<0xEE>(pf_w.x), v0 = dpp_mov<0x44>(pf_w.x); // quad_perm [2,3,2,3] / [0,1,0,1]
-						const uint32_t sel = pf_d ? v2 : v0;
+						const uint32_t sel = g32 != pf_g ? v2 : v0;
 						sm = (uint64_t)dpp_mov<0x55>(sel) << 32 | dpp_mov<0x00>(sel);
-					} else sm = *(const uint64_t*)((const char*)b1.gsm + (g32 << 3));
+					}
 					const uint32_t xn = *(const uint32_t*)((const char*)tw + ((tp32 >= 2u ? tp32 - 2u : 0u) << 3)); // the word after next (c != 0: tp32 >= 1)
 					const uint32_t koff = lo32 & (RB3_GRP - 1);
 					const uint32_t mask = (uint32_t)(sm >> 32), lw = koff >> RB3_WIN_BITS;
@@ -1302,15 +1308,14 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					uint4 slb;
 					const uint32_t so = sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * 16u; // (fewer than 2^24 slots: the byte offset fits 32 bits)
 					rl.sl = *(const uint4*)((const char*)b1.slot16 + so);
-					if (m_pair == exm) slb = make_uint4(0u, 0u, 0u, 0u); // every interval of the wave inside one run slot: nobody looks at a second one
-					else slb = *(const uint4*)((const char*)b1.slot16 + (so + (same ? 0u : (uint32_t)sizeof(rb3_slot_t))));
+					if (m_pair != exm) slb = *(const uint4*)((const char*)b1.slot16 + (so + (same ? 0u : (uint32_t)sizeof(rb3_slot_t)))); // (else every interval of the wave lies inside one run slot: nobody looks at a second one)
 					const uint32_t kbw = xw >> 3; // the row
 					if ((kq == 0u || sid >= 0) && (uint32_t)j == (its & 7u)) {
 						const int64_t myval = (int64_t)((uint64_t)lo32 + (uint64_t)kbw);
 						bkb = trec ? (int64_t)tp32 : (int64_t)kbw, bval = kq ? (RB3_TENT | ((int64_t)sid << RB3_TENT_PBITS) | myval) : myval;
 					}
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					const uint32_t hdr_c = oct_pick(rl.sl.x, c + 1); // the LF base of c at the slot start: the next point lies in its group or in the one behind it
+					const uint32_t hdr_c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((cq << 2) + pick1), (int)rl.sl.x); // the LF base of c at the slot start: the next point lies in its group or in the one behind it
 					pf_g = hdr_c >> RB3_GRP_BITS;
 					pf_w.x = *(const uint32_t*)((const char*)b1.gsm + ((pf_g << 3) + (((uint32_t)j & 3u) << 2))); // (the directory has a spare word behind the last group's)
 					if ((its & 7u) == 7u) { // the end of a window of eight iterations: its events, then its records (a scalar test)
@@ -1347,7 +1352,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 						lo_n = (uint32_t)l64, hi_n = (uint32_t)h64;
 					}
 					const uint32_t kn = hi_n - lo_n;
-					if (kq >= 2u && sid >= 0 && kn >= 1u && kn < kq) { // some matching suffixes are not preceded by c: a new stretch (an EVENT, noted in LDS)
+					if (sid >= 0 && kn - 1u < kq - 1u) { // (1 <= kn < kq, unsigned: false for kq = 0 and 1) // some matching suffixes are not preceded by c: a new stretch (an EVENT, noted in LDS)
 						int ns = sid + 1;
 						if (sid == RB3_TENT_POISON) ns = RB3_TENT_POISON;
 						else if ((ns & (RB3_TENT_CHUNK - 1)) == 0) {

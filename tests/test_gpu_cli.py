@@ -39,6 +39,19 @@ def test_build_fmd_identical(name):
         assert out.decode().strip() == ent["plain_text"]
 
 
+@pytest.mark.parametrize("vmm", ["4", "0"])
+def test_build_with_growable_ranges_everywhere_and_nowhere(vmm):
+    """the slot arrays and the rebuild's scratch as ranges of reserved address space that grow in place (RB3GPU_VMM=4: from 4 KB on, in reservations of 2 MB
+    that they outgrow; the default: from 64 MB on) and as plain hipMalloc'd buffers that are reallocated (RB3GPU_VMM=0): the same .fmd, many small batches"""
+    for name, m in (("genomes12", "-m45k"), ("reads_fq", "-m20k"), ("copies3000", "-m40k")):
+        ent = MAN[name]
+        inputs = [os.path.join(util.GOLDEN, p) for p in ent["inputs"]]
+        out, err = run(["build"] + ent["flags"] + [m, "-d"] + inputs, env={"RB3GPU_VMM": vmm, "RB3GPU_VMM_RESERVE": "2"})
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (name, vmm)
+        out, err = run(["build"] + ent["flags"] + [m, "-d", "--gpus", "2", "--interval"] + inputs, env={"RB3GPU_VMM": vmm, "RB3GPU_VMM_RESERVE": "2"})   # (the intervals' handles: split, rebalance, export)
+        assert hashlib.md5(out).hexdigest() == ent["fmd_md5"], (name, vmm, "interval")
+
+
 def test_build_merge_really_ran():
     ent = MAN["genomes12"]
     out, err = run(["build", "-m45k", "-d", os.path.join(util.GOLDEN, ent["inputs"][0])])

@@ -381,6 +381,16 @@ def test_soak_few_cases():
     assert r.returncode == 0, r.stdout.decode()[-2000:]
 
 
+def test_soak_with_every_buffer_a_growable_range():
+    """the same soak with RB3GPU_VMM=4: the slot arrays and the rebuild's scratch are ranges of reserved address space that grow in place, chunk by chunk,
+    from 4 KB on (vm_ensure, round 6; by default from 64 MB on) -- and with RB3GPU_VMM=0: hipMalloc and reallocation, as in rounds 1-5"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for v, res in (("4", "0"), ("4", "2"), ("0", "0")):   # (a reservation of 2 MB: a range that outgrows it moves, with its physical chunks, into a larger one)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "6", "5000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, RB3GPU_VMM=v, RB3GPU_VMM_RESERVE=res))
+        assert r.returncode == 0, (v, res, r.stdout.decode()[-2000:])
+
+
 @pytest.mark.parametrize("seed,kind", [(81, "genomes"), (82, "reads"), (83, "copies"), (84, "tiny"), (85, "runs"), (86, "family")])
 def test_bwt_from_text_vs_host_sorter(oracle, seed, kind):
     """partial BWT of a batch on the GPU (rb3gpu_bwt_from_text, prefix doubling) against the host suffix sorter

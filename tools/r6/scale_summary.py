@@ -15,6 +15,16 @@ for m in re.finditer(r"merge of (\d+) rows into (\d+): (\d+) list slots, (\d+) L
     fill, chain, settle, reb = (float(m.group(i)) for i in range(5, 9))
     merges.append({"rows": rows, "into_symbols": into, "lf_steps": steps, "ms_k_chain": chain, "ms_settle_validation": settle, "ms_rebuild": reb, "ms_fill_to_walkers": fill,
                    "gbp_s_merge": round(rows / max(1e-9, (fill + chain + settle + reb) * 1e-3) / 1e9, 2), "k_chain_frac_of_208B_roofline": round(208.0 * rows / max(1e-9, chain * 1e-3) / 8e12, 3)})
+if not merges:   # verbose 3: one line per merge from the engine, without the size of the index: it is the running sum
+    into = 0
+    for m in re.finditer(r"(encoded|merged) the partial BWT for (\d+) symbols|merged (\d+) symbols \((\d+) strings\): lf ([0-9.]+) ms, rank ([0-9.]+) ms \((\d+) LF steps\), rebuild ([0-9.]+) ms", err):
+        if m.group(1) == "encoded":
+            into += int(m.group(2))
+        elif m.group(3):
+            rows, lf, rank, steps, reb = int(m.group(3)), float(m.group(5)), float(m.group(6)), int(m.group(7)), float(m.group(8))
+            merges.append({"rows": rows, "strings": int(m.group(4)), "into_symbols": into, "lf_steps": steps, "ms_lf": lf, "ms_rank": rank, "ms_rebuild": reb,
+                           "gbp_s_merge": round(rows / max(1e-9, (lf + rank + reb) * 1e-3) / 1e9, 2), "rank_frac_of_208B_roofline": round(208.0 * rows / max(1e-9, rank * 1e-3) / 8e12, 3)})
+            into += rows
 out = {"workload": label, "merges": len(merges)}
 tot = re.search(r"GPU merge path: (\d+) symbols merged in ([0-9.]+) ms \(H2D ([0-9.]+) \+ LF ([0-9.]+) \+ rank ([0-9.]+) \+ rebuild ([0-9.]+)\); index ([0-9.]+) MB", err)
 if tot:

@@ -113,7 +113,9 @@ struct Tune {
 	int blkmul = 1;          // launch width multiplier of k_chain
 	int64_t blkcap = 2048;   // block cap of k_chain
 	int trec = -1;           // records of a text-order walk in text order (needs the batch's suffix array): 1 always, 0 never, -1: where the index does not fit the caches
-	int64_t abs_limit = RB3_ABS_LIMIT; // indexes of fewer symbols carry the LF base in their slot headers (at most 2^32: the headers are 32-bit); set before an index exists
+	int64_t abs_limit = INT64_MAX; // indexes of fewer symbols carry the LF base in their slot headers -- whole below 2^32 symbols, its low half + the table IdxView.sb from there on (round 6;
+	                               // rounds 3-5: 2^32, beyond which the headers counted from the group start and a rank read the 64-byte directory entry as well); set before an index exists
+	int abs_table = 0;             // (tests) the table and the low-half arithmetic below 2^32 symbols too
 	int tent_q = 0;          // width of the drop-out masks of the tentative stretches in units of 256 bits: 1, 2, 4, 8; 0: follows what the walkers report
 	int copy_walkers = 0;    // a walker list in page-locked memory is copied to the device all the same (instead of being read in place)
 	int lf_after = 1;        // the batch's histogram kernels (side stream) wait for the walkers to finish instead of running beside their first steps (measured: 186.3 -> 184.3 ms per build; 0: beside the walkers)
@@ -175,7 +177,8 @@ struct rb3gpu_s {
 	int64_t acc[7] = {0, 0, 0, 0, 0, 0, 0};
 	rb3_grp_t *grp = nullptr;
 	rb3_slot_t *slots = nullptr;
-	struct { rb3_grp_t *grp; size_t grp_cap; rb3_slot_t *slots; size_t slots_cap; } ib[2] = {{nullptr, 0, nullptr, 0}, {nullptr, 0, nullptr, 0}};
+	struct { rb3_grp_t *grp; size_t grp_cap; rb3_slot_t *slots; size_t slots_cap; uint64_t *sbt; size_t sbt_cap; } ib[2] = {{nullptr, 0, nullptr, 0, nullptr, 0}, {nullptr, 0, nullptr, 0, nullptr, 0}};
+	// (sbt: the table of LF bases every 2^31 symbols, IdxView.sb, of an index of 2^32 symbols and more -- sbt_cap entries of 8 words)
 	// (behind the grp_cap directory entries of a buffer sit grp_cap 8-byte words: the compact copy of the entries' slot words, IdxView.gsm)
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
@@ -405,6 +408,11 @@ static size_t grow_slack(size_t n) { return n < ((size_t)256 << 20) ? n >> 1 : n
 static int buf_ensure(rb3gpu_t *h, Buf &b, size_t bytes, bool exact = false, bool growable = false)
 {
 	if (b.cap >= bytes && b.p) return 0;
+	if (h->tn.log_alloc) { // which buffer: its place among the handle's
+		static const char *names[] = { "b2", "pos", "post", "tcnt", "tpre", "ctot", "ctot2", "gstat", "gpre", "jg", "misc", "xbuf", "wl", "wls", "dl", "dlx", "wstat", "wplane", "wruns", "gslots", "glist", "pslots", "lbst", "shc", "shn", "shs", "shr", "shk" };
+		const ptrdiff_t k = &b - &h->b2;
+		fprintf(stderr, "[M::rb3gpu] buffer '%s' grows from %.1f to %.1f MB%s\n", k >= 0 && k < 28 ? names[k] : "(local)", (double)b.cap / 1e6, (double)bytes / 1e6, growable ? " (in place)" : "");
+	}
 	if (growable && vm_usable(h, bytes)) { // grows where it stands: a sixteenth of slack (at most 256 MB) so that not every merge maps a chunk
 		const size_t sl = exact ? 0 : (bytes >> 4) < ((size_t)256 << 20) ? (bytes >> 4) : ((size_t)256 << 20);
 		if (b.p && !vm_find(h, b.p)) dev_free(h, b.p, b.cap), b.p = nullptr, b.cap = 0; // (it was small so far)
@@ -533,7 +541,8 @@ static IdxView view_of(const rb3gpu_t *h)
 	v.grp64 = (const uint64_t*)h->grp, v.slot16 = (const uint4*)h->slots, v.n = h->n, v.m = h->acc[1];
 	v.gsm = h->grp ? (const uint64_t*)(h->ib[h->cur].grp + h->ib[h->cur].grp_cap) : nullptr;
 	const int64_t nwin = (h->n >> RB3_WIN_BITS) + 1;
-	v.abs = RB3_ABS_HEADERS(h->n, h->tn.abs_limit) ? 1 : 0;
+	v.abs = RB3_ABS_HEADERS(h->n, h->tn.abs_limit) ? (h->n >= RB3_ABS_LIMIT || h->tn.abs_table ? 2 : 1) : 0;
+	v.sb = h->ib[h->cur].sbt;
 	v.dense = h->nslots == nwin ? (v.abs ? 2 : 1) : 0;
 	return v;
 }
@@ -589,12 +598,13 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "chain_bs")) t.chain_bs = v == 64 ? 64 : v == 128 ? 128 : 256;
 	else if (!strcmp(key, "lf_after")) t.lf_after = v != 0;
 	else if (!strcmp(key, "vmm")) t.vmm = v < 0 ? 0 : (int)v;
+	else if (!strcmp(key, "abs_table")) t.abs_table = v != 0;
 	else if (!strcmp(key, "vmm_reserve")) t.vmm_reserve = v < 0 ? 0 : (int)v;
 	else if (!strcmp(key, "copy_walkers")) t.copy_walkers = v != 0;
 	else if (!strcmp(key, "trec")) t.trec = v < 0 ? -1 : v != 0;
 	else if (!strcmp(key, "abs_limit")) {
 		if (h->grp) return RB3GPU_ESTATE; // the headers of the index in place were written under the old limit
-		t.abs_limit = v < 0 ? 0 : v > RB3_ABS_LIMIT ? RB3_ABS_LIMIT : v;
+		t.abs_limit = v < 0 ? INT64_MAX : v;
 	} else if (!strcmp(key, "tent_q")) t.tent_q = v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : v >= 1 ? 1 : 0;
 	else if (!strcmp(key, "ssa_split")) t.ssa_split = v < 4 ? 4 : v > 20 ? 20 : (int)v;
 	else if (!strcmp(key, "b2_split")) t.b2_split = v < 0 ? -1 : v > 12 ? 12 : (int)v;
@@ -641,7 +651,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "vmm", "vmm_reserve", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "abs_table", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "vmm", "vmm_reserve", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -691,13 +701,23 @@ static void ib_release(rb3gpu_t *h, int i)
 {
 	dev_free(h, h->ib[i].grp, h->ib[i].grp_cap * RB3_GRP_ALLOC);
 	dev_free(h, h->ib[i].slots, h->ib[i].slots_cap * sizeof(rb3_slot_t));
-	h->ib[i].grp = nullptr, h->ib[i].slots = nullptr, h->ib[i].grp_cap = h->ib[i].slots_cap = 0;
+	dev_free(h, h->ib[i].sbt, h->ib[i].sbt_cap * 64);
+	h->ib[i].grp = nullptr, h->ib[i].slots = nullptr, h->ib[i].sbt = nullptr, h->ib[i].grp_cap = h->ib[i].slots_cap = h->ib[i].sbt_cap = 0;
 }
 
 /* make ib[i] hold at least ngrp directory entries and nslots slots (contents are not preserved) */
 static int ib_ensure(rb3gpu_t *h, int i, int64_t ngrp, int64_t nslots, bool exact = false)
 {
 	int r;
+	{ // the table of LF bases every 2^31 symbols (IdxView.sb; a few hundred bytes): room for it beside every index, used from 2^32 symbols on
+		const size_t nsb = ((size_t)ngrp >> (RB3_SB_BITS - RB3_GRP_BITS)) + 4;
+		if (h->ib[i].sbt_cap < nsb) {
+			dev_free(h, h->ib[i].sbt, h->ib[i].sbt_cap * 64);
+			h->ib[i].sbt = nullptr, h->ib[i].sbt_cap = 0;
+			if ((r = dev_malloc(h, (void**)&h->ib[i].sbt, (nsb + 12) * 64)) < 0) return r;
+			h->ib[i].sbt_cap = nsb + 12;
+		}
+	}
 	// (the slot array grows in place; the directory -- 72 bytes per 8192 symbols, read back by the host in places -- stays an ordinary allocation)
 	if (h->ib[i].slots_cap < (size_t)nslots && vm_usable(h, (size_t)nslots * sizeof(rb3_slot_t))) {
 		void *p = h->ib[i].slots;
@@ -1117,6 +1137,10 @@ static int build_index(rb3gpu_t *h, int64_t n2, const uint8_t *d_b2, const int64
 static void index_install(rb3gpu_t *h, int64_t ngrp, int64_t nslots, int64_t ntot, const int64_t acc[7])
 {
 	h->cur = 1 - h->cur;
+	if (RB3_ABS_HEADERS(ntot, h->tn.abs_limit) && (ntot >= RB3_ABS_LIMIT || h->tn.abs_table)) { // the LF bases every 2^31 symbols, from the directory the rebuild has just written (IdxView.sb)
+		auto &b = h->ib[h->cur]; // (ib_ensure made room for the table)
+		if (b.sbt && b.sbt_cap >= (size_t)(ntot >> RB3_SB_BITS) + 1) hipLaunchKernelGGL(k_sb_table, dim3((unsigned)((((ntot >> RB3_SB_BITS) + 1) * 8 + 63) / 64)), dim3(64), 0, h->st, (const uint64_t*)b.grp, (ntot >> RB3_SB_BITS) + 1, b.sbt);
+	}
 	h->grp = h->ib[h->cur].grp, h->slots = h->ib[h->cur].slots, h->ngrp = ngrp, h->nslots = nslots, h->n = ntot;
 	memcpy(h->acc, acc, sizeof(h->acc));
 	h->stt.bytes_index = ngrp * (int64_t)RB3_GRP_ALLOC + nslots * (int64_t)sizeof(rb3_slot_t);
@@ -1815,7 +1839,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		case 0: RB3_LAUNCH_FAST(false, false, 0); break;
 		case 8: RB3_LAUNCH_FAST(false, true, 2); break;
 		case 7: // (the headline's kernel: 32-bit positions in the common step where index and batch allow it)
-			if (iv.abs && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29))
+			if (iv.abs == 1 && iv.n < (1LL << 32) - (1LL << 20) && len < (1LL << 29))
 #ifdef RB3_PROF_STEP
 
 #endif

@@ -302,6 +302,7 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	hipLaunchKernelGGL(k_fe_pack, FE_GRID(B + 1), d_words, nr, n_sym, (const int64_t*)bs, B, out, flag, flag + 1);
 	FE_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
+	if (hflag[0] & 11u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a 64-bit header\n", hflag[0]); ret = 1; goto done; } // (not produced here: the host's encoder writes such an index)
 	if (hflag[0] & 4u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: the packer met a block it cannot write\n", hflag[0]); ret = -3; goto done; }
 	if (hflag[0] & 11u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a 64-bit header\n", hflag[0]); ret = 1; goto done; }
 	{

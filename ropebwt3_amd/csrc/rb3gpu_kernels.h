@@ -37,9 +37,28 @@ struct IdxView {
 	int64_t m;               // number of sentinels (= acc[1])
 	int dense;               // 0: mixed slots.  1: every slot is a bit-plane slot (slot index = position >> 8).
 	                         // 2: as 1 and the slot headers carry ABSOLUTE counts (RB3_ABS_HEADERS): rank needs no directory
-	int abs;                 // the slot headers carry ABSOLUTE counts (an index of fewer than 2^32 symbols): a rank needs the directory's
-	                         // slot word (gsm) to find the slot, but not the 64-byte entry with the group's counts
+	int abs;                 // 1: the slot headers carry the whole LF base (an index of fewer than 2^32 symbols): a rank needs the directory's slot word (gsm) to find
+	                         // the slot, but not the 64-byte entry with the group's counts.  2 (round 6): the headers carry the LOW 32 BITS of the LF base -- what the
+	                         // writers have always stored -- and the rest comes from the table `sb` (lf_base): the same two lines per rank at any size.  0: headers
+	                         // relative to the group (rb3gpu_tune abs_limit; the layout of 2^32 symbols and more in rounds 3-5)
+	const uint64_t *sb;      // abs = 2: sb[s * 8 + c] = the LF base of c at position s << 31, i.e. the counts of directory entry s << 18 (k_sb_table): a few hundred bytes
 };
+
+/* the LF base from a slot header.  wrap = 0: T + hdr (T = 0: the header is the base; T = the group's count: the header is relative to the group).  wrap = 1
+ * (IdxView.abs = 2): the header holds the low 32 bits of the base and T is the base 2^31 symbols or less further down -- a base grows by at most one per symbol,
+ * so the two differ by less than 2^32 and the difference of their low halves is the difference */
+#define RB3_SB_BITS 31
+__device__ __forceinline__ uint64_t lf_base(uint64_t T, uint32_t hdr, uint32_t wrap)
+{
+	return wrap ? T + (uint64_t)(uint32_t)(hdr - (uint32_t)T) : T + (uint64_t)hdr;
+}
+
+/* the table of IdxView.sb from the directory of an index (one thread per entry word) */
+__global__ void __launch_bounds__(64) k_sb_table(const uint64_t *grp64, int64_t nsb, uint64_t *sb)
+{
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nsb * 8) sb[t] = (t & 7) < 6 ? grp64[((t >> 3) << (RB3_SB_BITS - RB3_GRP_BITS)) * 8 + (t & 7)] : 0ull;
+}
 
 /* A block array that holds fewer than 2^32 symbols is written with hdr[1..6] = C[a] + #{i < slot start : B[i] = a}, the
  * full LF base, instead of the count relative to the group start: where all slots are bit planes rank(c, k) is then ONE
@@ -204,7 +223,7 @@ __device__ __forceinline__ void oct_rank_issue_grp(const IdxView &ix, int64_t k,
 {
 	const int64_t g = k >> RB3_GRP_BITS;
 	r.koff = (uint32_t)k & (RB3_GRP - 1);
-	r.gw = ix.grp64[g * 8 + j];
+	r.gw = ix.abs == 2 ? ix.sb[(k >> RB3_SB_BITS) * 8 + j] : ix.grp64[g * 8 + j];
 	r.sm = ix.grp64[g * 8 + 6];
 }
 
@@ -371,12 +390,16 @@ __device__ __forceinline__ uint32_t slice_count(const uint4 &sl, const uint4 &sl
 	return cnt;
 }
 
-__device__ __forceinline__ int64_t oct_rank_finish(const RankLoad &r, int c, int j, bool abs_hdr)
+__device__ __forceinline__ int64_t oct_rank_finish(const RankLoad &r, int c, int j, int abs_hdr)
 {
 	const uint32_t hdr0 = oct_bcast0(r.sl.x, j);
 	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
 	uint32_t part = slice_count<8>(r.sl, r.sl, hdr0, off, c, j) & (RB3_MATCH_BIT - 1u);
-	if (abs_hdr) return (int64_t)oct_sum(j == c + 1 ? r.sl.x : 0u) + (int64_t)oct_sum(part); // hdr[c+1] is the whole LF base
+	if (abs_hdr == 1) return (int64_t)oct_sum(j == c + 1 ? r.sl.x : 0u) + (int64_t)oct_sum(part); // hdr[c+1] is the whole LF base
+	if (abs_hdr == 2) { // ... its low half; the table word of c came in as gw of lane c
+		const uint32_t tl = oct_sum(j == c ? (uint32_t)r.gw : 0u), th = oct_sum(j == c ? (uint32_t)(r.gw >> 32) : 0u);
+		return (int64_t)(lf_base((uint64_t)th << 32 | tl, oct_sum(j == c + 1 ? r.sl.x : 0u), 1u) + (uint64_t)oct_sum(part));
+	}
 	if (j == c + 1) part += r.sl.x; // hdr[c+1] = count of c between group start and slot start
 	const uint32_t sum = oct_sum(part);
 	const uint32_t lo = oct_sum(j == c ? (uint32_t)r.gw : 0u);
@@ -399,7 +422,7 @@ __global__ void __launch_bounds__(256) k_rank_batch(IdxView ix, Acc7 acc, int64_
 		RankLoad r;
 		oct_rank_issue(ix, kk, j, r);
 		for (int c = 0; c < 6; ++c) {
-			int64_t v = oct_rank_finish(r, c, j, ix.abs != 0) - acc.a[c];
+			int64_t v = oct_rank_finish(r, c, j, ix.abs) - acc.a[c];
 			if (j == 0) ok[q * 6 + c] = v;
 		}
 	}
@@ -689,6 +712,7 @@ struct RankLoadC {
 	uint4 sl2;       // quads: slice 2j + 1
 	uint32_t koff;   // k & 8191
 	uint32_t sidx;   // index of the slot (mixed indexes)
+	uint32_t wrap;   // gc is a word of IdxView.sb and the headers hold low halves (lf_base)
 };
 
 template<int LPW>
@@ -703,8 +727,10 @@ __device__ __forceinline__ void octc_issue_grp(const IdxView &ix, int64_t k, int
 {
 	const int64_t g = k >> RB3_GRP_BITS;
 	r.koff = (uint32_t)k & (RB3_GRP - 1);
+	r.wrap = ix.abs == 2 ? 1u : 0u, r.gc = 0;
+	if (ix.abs == 2) r.gc = ix.sb[(k >> RB3_SB_BITS) * 8 + c];   // (a table of a few hundred bytes)
 	if (DENSE) octc_load_slot<LPW>(ix, k >> RB3_WIN_BITS, j, r); // every window is its own slot and carries the LF base: no directory lookup
-	else if (ix.abs) r.gc = 0, r.sm = ix.gsm[g];                  // the headers carry the LF base: only the slot word, from its compact copy
+	else if (ix.abs) r.sm = ix.gsm[g];                            // the headers carry the LF base: only the slot word, from its compact copy
 	else r.gc = ix.grp64[g * 8 + c], r.sm = ix.grp64[g * 8 + 6];
 }
 
@@ -757,7 +783,7 @@ __device__ __forceinline__ void octc_finish_pair(const RankLoadC &rl, uint32_t k
 	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, (int)rl.koff - base, (int)koff_hi - base, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16; // both fit 16 bits (counts inside a slot of at most 8192 symbols)
 	v = grp_sum<LPW>(v);
-	const uint64_t hb = rl.gc + octc_hdr_pick<LPW>(rl, c, j); // (the header may be the whole LF base: 32 bits)
+	const uint64_t hb = lf_base(rl.gc, octc_hdr_pick<LPW>(rl, c, j), rl.wrap); // (the header may be the whole LF base: 32 bits)
 	*lo_n = (int64_t)(hb + (v & 0xFFFFu)), *hi_n = (int64_t)(hb + (v >> 16));
 }
 
@@ -766,7 +792,7 @@ template<int LPW = 8>
 __device__ __forceinline__ void octc_finish_pair_at(const RankLoadC &rl, int off_lo, int off_hi, int c, int j, int64_t *lo_n, int64_t *hi_n, bool have_hdr = false, uint32_t hdr_c = 0u)
 {
 	uint32_t ca, cb, mt;
-	const uint64_t hb = rl.gc + (have_hdr ? hdr_c : octc_hdr_pick<LPW>(rl, c, j)); // (the header may be the whole LF base: 32 bits; asked for first: it crosses the lanes while the codes are counted)
+	const uint64_t hb = lf_base(rl.gc, have_hdr ? hdr_c : octc_hdr_pick<LPW>(rl, c, j), rl.wrap); // (the header may be the whole LF base: 32 bits; asked for first: it crosses the lanes while the codes are counted)
 	slice_count_pk<true, false, LPW>(rl.sl, rl.sl2, off_lo, off_hi, c, j, &ca, &cb, &mt);
 	uint32_t v = ca | cb << 16;
 	v = grp_sum<LPW>(v);
@@ -785,14 +811,14 @@ __device__ __forceinline__ int64_t octc_finish(const RankLoadC &r, int c, int j,
 		else part = plane_count(r.sl, off - 64 * j, c) + plane_count(r.sl2, off - 64 * j - 32, c);
 		const uint32_t base = grp_sum<LPW>(octc_hdr_c<LPW>(r, c, j)), sum = grp_sum<LPW>(part);
 		*match = sum >> 20;
-		return (int64_t)base + (int64_t)(sum & (RB3_MATCH_BIT - 1u));
+		return (int64_t)lf_base(r.gc, base, r.wrap) + (int64_t)(sum & (RB3_MATCH_BIT - 1u));
 	} else {
 		const uint32_t hdr0 = grp_bcast0<LPW>(r.sl.x, j);
 		part = slice_count<LPW, MATCH>(r.sl, r.sl2, hdr0, r.koff - (hdr0 & 0xFFFFu), c, j);
 	}
 	const uint32_t sum = grp_sum<LPW>(part), base = grp_sum<LPW>(octc_hdr_c<LPW>(r, c, j)); // (the header may be the whole LF base: 32 bits)
 	*match = sum >> 20;
-	return (int64_t)(r.gc + base + (sum & (RB3_MATCH_BIT - 1u)));
+	return (int64_t)(lf_base(r.gc, base, r.wrap) + (sum & (RB3_MATCH_BIT - 1u)));
 }
 
 /* Tentative records (TENT = true).  An inexact walker whose interval [lo, hi) has shrunk to a few
@@ -1304,7 +1330,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 					const unsigned long long m_pair = RB3_BAL(wend - w0 > 1u) & RB3_BAL(koff + kq <= (wend << RB3_WIN_BITS));
 					const bool far = !same && kq > 255u;
 					RankLoadC rl;
-					rl.gc = 0, rl.koff = koff, rl.sidx = sidx, rl.sm = sm, rl.sl2 = make_uint4(0u, 0u, 0u, 0u);
+					rl.gc = 0, rl.wrap = 0u, rl.koff = koff, rl.sidx = sidx, rl.sm = sm, rl.sl2 = make_uint4(0u, 0u, 0u, 0u);
 					uint4 slb;
 					const uint32_t so = sidx * (uint32_t)sizeof(rb3_slot_t) + (uint32_t)j * 16u; // (fewer than 2^24 slots: the byte offset fits 32 bits)
 					rl.sl = *(const uint4*)((const char*)b1.slot16 + so);
@@ -1429,8 +1455,9 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 #endif
 					if (I32) rl.sm = *(const uint64_t*)((const char*)b1.gsm + (((uint32_t)lo >> RB3_GRP_BITS) << 3));
 					else rl.sm = b1.gsm[g];
-					rl.gc = 0;
-					if (!I32 && !b1.abs) rl.gc = b1.grp64[g * 8 + c]; // (headers relative to the group: an index of 2^32 symbols or more)
+					rl.gc = 0, rl.wrap = (!I32 && b1.abs == 2) ? 1u : 0u;
+					if (!I32 && !b1.abs) rl.gc = b1.grp64[g * 8 + c]; // (headers relative to the group: rb3gpu_tune abs_limit)
+					if (!I32 && b1.abs == 2) rl.gc = b1.sb[(lo >> RB3_SB_BITS) * 8 + c]; // (2^32 symbols or more: the base's upper half from the table)
 					const int64_t tpn = I32 ? (int64_t)((uint32_t)tp - 1u) : tp - 1; // (c != 0: there is a symbol before this one, so tp >= 1)
 					uint64_t xn;                                      // the word after next
 #ifndef RB3_NO_TA_DIET
@@ -1550,7 +1577,7 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 						RankLoadC rb2;
 						rb2.sl = slb, rb2.sl2 = slb2;
 						const uint32_t hl = octc_hdr_pick<LPW>(rl, c, j), hh = octc_hdr_pick<LPW>(rb2, c, j); // (headers of 32 bits where they carry the LF base)
-						lo_n = (int64_t)(rl.gc + hl + (v & 0xFFFFu)), hi_n = (int64_t)(rl.gc + hh + (v >> 16));
+						lo_n = (int64_t)(lf_base(rl.gc, hl, rl.wrap) + (v & 0xFFFFu)), hi_n = (int64_t)(lf_base(rl.gc, hh, rl.wrap) + (v >> 16));
 					} else if (rle && same) octc_finish_pair_at<LPW>(rl, off_lo, off_hi, c, j, &lo_n, &hi_n);
 					else { // a bit-plane slot somewhere
 						uint32_t match = 0, mh;
@@ -2690,7 +2717,7 @@ __global__ void __launch_bounds__(256) k_lf_check(IdxView b1, const int64_t *pos
 		const int64_t kbn = c2 + (int64_t)tpre[tile * 8 + c] + cnt;
 		RankLoad rl;
 		oct_rank_issue(b1, ka, j, rl);
-		const int64_t want = oct_rank_finish(rl, c, j, b1.abs != 0);
+		const int64_t want = oct_rank_finish(rl, c, j, b1.abs);
 		if (kbn < 0 || kbn >= n2 || pos[kbn] - kbn != want) ok = false;
 	}
 	if (j == 0) {
@@ -2746,7 +2773,7 @@ __global__ void __launch_bounds__(256) k_junction_check(IdxView b1, const int64_
 			if (ok) {
 				RankLoad rl;
 				oct_rank_issue(b1, ka, j, rl);
-				ok = oct_rank_finish(rl, c, j, b1.abs != 0) == kan;
+				ok = oct_rank_finish(rl, c, j, b1.abs) == kan;
 			}
 		}
 		++nseen;
@@ -4340,7 +4367,7 @@ __global__ void __launch_bounds__(256) k_sh_step(IdxView ix, ShArgs a, int64_t n
 		if (c != 0) { // (wave-uniform control flow is not required: the rank helpers only talk inside an octet)
 			RankLoad r;
 			oct_rank_issue(ix, k, j, r);
-			nx.ka = oct_rank_finish(r, c, j, ix.abs != 0) + a.adj[c];
+			nx.ka = oct_rank_finish(r, c, j, ix.abs) + a.adj[c];
 			d = 0;
 			for (int i = 1; i < a.n_iv; ++i) d += a.bounds[i] <= nx.ka ? 1 : 0;
 		}
@@ -4461,7 +4488,7 @@ __global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n
 				int64_t adj = a.adj[0];
 #pragma unroll
 				for (int e = 1; e < 6; ++e) adj = c == e ? a.adj[e] : adj; // (selects on scalars: an index that varies per lane would move the array to scratch)
-				st[s].ka = oct_rank_finish(r[s], c, j, ix.abs != 0) + adj;
+				st[s].ka = oct_rank_finish(r[s], c, j, ix.abs) + adj;
 				d[s] = 0;
 				for (int i = 1; i < a.n_iv; ++i) d[s] += a.bounds[i] <= st[s].ka ? 1 : 0;
 			}
@@ -4722,7 +4749,7 @@ __device__ __forceinline__ int64_t oct_lf_self(const IdxView &ix, int64_t k, int
 	const uint32_t off = r.koff - (hdr0 & 0xFFFFu);
 	const uint32_t sy = oct_sum(slice_sym(r.sl, hdr0, off, j)) & 7u;
 	*c = (int)sy;
-	return oct_rank_finish(r, (int)sy, j, ix.abs != 0);
+	return oct_rank_finish(r, (int)sy, j, ix.abs);
 }
 
 /* nxt[2p] = next splitter (or RB3_SSA_END | sentinel row reached), nxt[2p+1] = steps of the sublist;

@@ -1877,7 +1877,7 @@ def test_walkers_that_start_late(oracle, blkcap, octs):
         h.close()
 
 
-@pytest.mark.parametrize("limit", [0, 150000, 1 << 32])
+@pytest.mark.parametrize("limit", [0, 150000, 1 << 32, -1])
 def test_slot_headers_relative_to_the_group(oracle, limit):
     """an index below 2^32 symbols carries the LF base in its slot headers (a rank reads the slot words and the slot, no directory
     entry); from 2^32 symbols on the headers count from the group start.  rb3gpu_tune abs_limit moves that border: 0 = every build
@@ -1888,6 +1888,8 @@ def test_slot_headers_relative_to_the_group(oracle, limit):
     g0 = util.random_genome(rng, 20000)
     h = Rb3Gpu(verbose=1)
     h.tune("abs_limit", limit)
+    if limit < 0:   # (round 6) the layout of 2^32 symbols and more: headers = the low half of the LF base, the rest from the table of bases every 2^31 symbols -- here forced on a small index
+        h.tune("abs_table", 1)
     want = None
     try:
         for i in range(16):
@@ -1922,6 +1924,8 @@ def test_slot_headers_relative_to_the_group(oracle, limit):
             h2 = Rb3Gpu(verbose=1)
             try:
                 h2.tune("abs_limit", limit); h2.tune("load_chunk", 3)
+                if limit < 0:
+                    h2.tune("abs_table", 1)
                 h2.from_fmd_file(fn)
                 assert np.array_equal(h2.export_plain(), want) and np.array_equal(h2.rank1a(ks), cum[ks])
             finally:

@@ -61,7 +61,7 @@ def gen_genomes(n, rate, seed0, seeds):
 
 def load_pmc_traffic(kernel):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/), if any."""
-    for fn in ("r5_pmc_%s.json" % kernel, "r4_pmc_%s.json" % kernel, "r3_pmc_%s.json" % kernel, "r2_pmc_%s.json" % kernel, "r1_pmc_%s.json" % kernel):
+    for fn in ("r6_pmc_%s.json" % kernel, "r5_pmc_%s.json" % kernel, "r4_pmc_%s.json" % kernel, "r3_pmc_%s.json" % kernel, "r2_pmc_%s.json" % kernel, "r1_pmc_%s.json" % kernel):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", fn))).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
@@ -555,6 +555,7 @@ def main():
     ap.add_argument("--aux-reads", type=int, default=100000)
     ap.add_argument("--large-index", type=int, default=1 << 30, help="symbols of the index of the large-index leg (0: skip)")
     ap.add_argument("--index-8g", type=int, default=24, help="haplotypes (360 M symbols each) of the leg with an index beyond 2^32 symbols (0: skip)")
+    ap.add_argument("--scale", choices=["reads", "hap"], default=None, help="run one of the scale scripts now (tools/r6/scale_reads.sh: 60 M reads, 18 G symbols; tools/r6/scale_hap.sh: 4 haplotypes x 3.1 Gbp) and print its JSON")
     ap.add_argument("--only", choices=["large", "reads", "cfg2", "cli", "headline", "8g"], default=None, help="run one leg alone and print its JSON (profiling)")
     ap.add_argument("--mtb-ref-prefix", type=int, default=6, help="files the reference binary is timed on (cpu_baseline)")
     ap.add_argument("--mtb-3b-first", type=int, default=4, help="cpu_baseline_config3b: genomes in the first batch of the reference's many-chain run")
@@ -562,6 +563,11 @@ def main():
     ap.add_argument("--walker-step", type=int, default=WALKER_STEP)
     ap.add_argument("--host-walkers", action="store_true", help="make the walker lists on the host before the timed steps (rb3h_walkers_text, rounds 2-4) instead of on the device inside the merge call")
     args = ap.parse_args()
+    if args.scale:   # (a recorded-run script, run now: its JSON object is the line)
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "r6", "scale_reads.sh" if args.scale == "reads" else "scale_hap.sh")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT)
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        print(lines[-1] if lines else json.dumps({"error": r.stderr.decode()[-400:]}))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -708,7 +714,7 @@ def main():
                 "ms_per_step_with_nothing_beside_it": None if h2d_serial is None else round(h2d_serial * 1e3, 3)},
         "roofline": chain_roofline(int(rows_launch), ms_chain, "text", load_pmc_traffic("k_chain_mtb152"),
                                    "k_chain<list,mixed,tent,text>: average over the %d launches of the timed steps (run-coded index, intervals of up to %d matching suffixes); `achieved` prices SURVEY 8(d)'s 208 B per LF step over the kernel's HIP-event time; "
-                                   "traffic = FETCH_SIZE/WRITE_SIZE of the committed --pmc passes (profiles/r5_pmc_k_chain_mtb152.json); the index (<= %.0f MB) sits in L2 + Infinity Cache, so this kernel is bound by latency and instruction issue, not by HBM (aux_large_index is the HBM-resident case)" % (st["n_rank_launches"], K - 1, st["bytes_index"] / 1e6)),
+                                   "traffic = FETCH_SIZE/WRITE_SIZE of the committed --pmc passes (profiles/r6_pmc_k_chain_mtb152.json); the index (<= %.0f MB) sits in L2 + Infinity Cache, so this kernel is bound by latency and instruction issue, not by HBM (aux_large_index is the HBM-resident case)" % (st["n_rank_launches"], K - 1, st["bytes_index"] / 1e6)),
         "roofline_path": {"bound": "hbm", "formula": "SURVEY 8(d): (217 B x symbols merged + bytes(B1 old) + bytes(B1 new) per round) / merge-path seconds / 8 TB/s", "algorithmic_bytes_per_step": int(path_bytes // S),
                           "achieved": round(path_bytes / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_bytes / dt / 1e9 / HBM_PEAK_GBS, 5)},
         "roofline_rebuild": {"bound": "hbm", "kernel": "k_reb_group + k_place (+ window kernels on what they hand on)", "algorithmic_bytes_per_step": int(st["bytes_rebuild"] // S), "ms_per_step": round(st["ms_build"] / S, 3),
@@ -759,6 +765,18 @@ def main():
                 out["aux_index_8g"] = index_8g(args.index_8g, local_rank)
         except Exception as e:   # (a box with less free memory than a leg needs must not lose the headline)
             out["aux_error"] = repr(e)[:300]
+        # BASELINE configs[3] / [4] in shape at 1/10 and at real contig sizes: minutes of box time each, so they are RECORDED runs (tools/r6/scale_reads.sh,
+        # tools/r6/scale_hap.sh through the CLI, every 64th row of every merge LF-checked), not legs of this line; `--scale reads|hap` runs one now
+        rec = {}
+        for name, fn in (("aux_reads_18g", "r6_scale_reads_60m.json"), ("aux_haplotypes_4x3g", "r6_scale_hap_4x3g.json")):
+            try:
+                d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                d.pop("samples_as_the_index_grows", None)
+                rec[name] = dict(d, recorded_in="profiles/" + fn)
+            except (OSError, ValueError):
+                pass
+        if rec:
+            out["scale_runs_recorded"] = rec
     for f in files:
         try:
             os.unlink(f)

@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,7 +43,8 @@
 #define FE_CHUNK     4096         /* runs per speculation chunk */
 
 #define FE_HIP(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); ret = -2; goto done; } } while (0)
-#define FE_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, st
+#define FE_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, st /* (a thread per item: for fewer than 2^32 items) */
+#define FE_GRID_LOOP(n) dim3((unsigned)((((n) + 255) / 256) < (1 << 22) ? (((n) + 255) / 256) : (1 << 22))), dim3(256), 0, st /* kernels with a grid-stride loop */
 
 __device__ __forceinline__ int fe_ilog2(uint64_t v) { return 63 - __clzll((long long)v); }
 
@@ -51,15 +53,17 @@ struct fe_widen { __device__ __host__ uint64_t operator()(uint8_t v) const { ret
 /* width of the code of every run (rld0.c:45-51, 140-141); flag[0] |= 1 if a code would not fit 63 bits */
 __global__ void __launch_bounds__(256) k_fe_width(const uint64_t *words, int64_t nr, int64_t n_sym, uint8_t *width, unsigned int *flag)
 {
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > nr) return;
-	if (i == nr) { width[i] = 0; return; }
-	const int64_t s = (int64_t)(words[i] >> 3), e = i + 1 < nr ? (int64_t)(words[i + 1] >> 3) : n_sym;
-	const uint64_t l = (uint64_t)(e - s);
-	const int y = fe_ilog2(l), zz = fe_ilog2((uint64_t)y + 1);
-	const int w = (zz << 1) + 1 + y + 3;
-	if (w >= 64 || e <= s) atomicOr(flag, 1u);
-	width[i] = (uint8_t)w;
+	// (a grid-stride loop: a launch holds fewer than 2^32 threads, and an index of 24.8 G symbols in long contigs has 4.99 G runs -- with a thread per run
+	// the launch came out 2^32 threads short, the widths behind run 696 M stayed what the fresh buffer held, and the chain ran away: round 6)
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nr; i += (int64_t)gridDim.x * blockDim.x) {
+		if (i == nr) { width[i] = 0; continue; }
+		const int64_t s = (int64_t)(words[i] >> 3), e = i + 1 < nr ? (int64_t)(words[i + 1] >> 3) : n_sym;
+		const uint64_t l = (uint64_t)(e - s);
+		const int y = fe_ilog2(l), zz = fe_ilog2((uint64_t)y + 1);
+		const int w = (zz << 1) + 1 + y + 3;
+		if (w >= 64 || e <= s) atomicOr(flag, 1u);
+		width[i] = (uint8_t)w;
+	}
 }
 
 /* first run of the block after the one that starts at run i (payload of C bits) */
@@ -206,6 +210,13 @@ static bool fmd_debug(void)
 	return on;
 }
 
+/* (RB3GPU_FMD_DEBUG) are the bit offsets the widths' running sum?  bad[0] = mismatches, bad[1] = the first one */
+__global__ void __launch_bounds__(256) k_fe_check_scan(const uint8_t *width, const uint64_t *P, int64_t n, unsigned long long *bad)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += (int64_t)gridDim.x * blockDim.x)
+		if (P[i + 1] - P[i] != (uint64_t)width[i]) { atomicAdd(&bad[0], 1ull); atomicMin(&bad[1], (unsigned long long)i); }
+}
+
 /* exclusive scan of n code widths into bit offsets, a piece of at most 2^30 items at a time (the device scan takes a size_t, but an index of 24.8 G symbols
  * in contigs of 40-135 Mbp -- more than 2^32 runs -- came back with offsets that made the chain below wander for ten minutes and give up: round 6) */
 #define FE_SCAN_PIECE ((int64_t)1 << 30)
@@ -226,9 +237,13 @@ static int fe_scan_widths(hipStream_t st, void *tmp, size_t tb, const uint8_t *w
 	return 0;
 }
 
+static double fe_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
 int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words)
 {
 	int ret = 0;
+	const double fe_t0 = fe_now();
+	int64_t fe_iter = 0;
 	uint8_t *width = nullptr, *E = nullptr, *hE = nullptr;
 	uint16_t *Cn = nullptr, *hCn = nullptr;
 	uint64_t *P = nullptr, *out = nullptr, *host = nullptr;
@@ -250,16 +265,33 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 	tb += 256;
 	if (hipMalloc(&tmp, tb) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
 	FE_HIP(hipMemsetAsync(flag, 0, 16, st));
-	hipLaunchKernelGGL(k_fe_width, FE_GRID(nr + 1), d_words, nr, n_sym, width, flag);
+	hipLaunchKernelGGL(k_fe_width, FE_GRID_LOOP(nr + 1), d_words, nr, n_sym, width, flag);
+	if ((K * FE_ENTRIES * 2 + 255) / 256 >= ((int64_t)1 << 32) / 256 || nr >= ((int64_t)1 << 36)) { ret = 1; goto done; } // (the table kernel's thread per entry: 2^36 runs and more go to the host's encoder)
 	if (fe_scan_widths(st, tmp, tb, width, P, nr + 1) < 0) { (void)hipGetLastError(); ret = -2; goto done; }
+	if (fmd_debug()) {
+		unsigned long long hb[2] = { 0ull, ~0ull }, *db = nullptr;
+		unsigned int hf = 0;
+		if (hipMalloc(&db, 16) == hipSuccess) {
+			(void)hipMemcpyAsync(db, hb, 16, hipMemcpyHostToDevice, st);
+			hipLaunchKernelGGL(k_fe_check_scan, dim3(8192), dim3(256), 0, st, (const uint8_t*)width, (const uint64_t*)P, nr + 1, db);
+			(void)hipMemcpyAsync(hb, db, 16, hipMemcpyDeviceToHost, st);
+			(void)hipMemcpyAsync(&hf, flag, 4, hipMemcpyDeviceToHost, st);
+			(void)hipStreamSynchronize(st);
+			(void)hipFree(db);
+			fprintf(stderr, "[fmdenc] %lld runs, %lld symbols: %llu of the bit offsets are not the running sum of the widths (first at run %lld); width flags %u\n", (long long)nr, (long long)n_sym, hb[0], (long long)hb[1], hf);
+		}
+	}
 	hipLaunchKernelGGL(k_fe_table, FE_GRID(K * FE_ENTRIES * 2), K, nr, n_sym, (const uint64_t*)P, d_words, E, Cn, flag);
 	FE_HIP(hipMemcpyAsync(hE, E, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipMemcpyAsync(hCn, Cn, (size_t)K * FE_ENTRIES * 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
 	if (hflag[0] & 1u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] a code of 64 bits or more\n"); ret = 1; goto done; }
+	if (fmd_debug()) fprintf(stderr, "[fmdenc] tables of %lld chunks on the host after %.3f s\n", (long long)K, fe_now() - fe_t0);
 	// the chain, one superblock at a time: the host walks the chunk tables
 	for (;;) {
+		if (fmd_debug() && (fe_iter < 4 || (fe_iter & 15) == 0)) fprintf(stderr, "[fmdenc] superblock %lld: run %lld of %lld, block %lld, %.3f s\n", (long long)fe_iter, (long long)o, (long long)nr, (long long)gb0, fe_now() - fe_t0);
+		++fe_iter;
 		const int64_t s = gb0 | (FE_SB_BLOCKS - 1); // global index of this superblock's last block
 		const int64_t k0 = o / FE_CHUNK;
 		int64_t *ids = hlists, *ent = hlists + (K + 1), *bas = hlists + 2 * (K + 1), nl = 0, c1[3];
@@ -282,13 +314,18 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 		FE_HIP(hipMemcpyAsync(lists + (K + 1), ent, (size_t)nl * 8, hipMemcpyHostToDevice, st));
 		FE_HIP(hipMemcpyAsync(lists + 2 * (K + 1), bas, (size_t)nl * 8, hipMemcpyHostToDevice, st));
 		hipLaunchKernelGGL(k_fe_emit, FE_GRID(nl), nl, (const int64_t*)lists, (const int64_t*)(lists + (K + 1)), (const int64_t*)(lists + 2 * (K + 1)), nr, n_sym, (const uint64_t*)P, d_words, s, bs, flag);
-		if (gb <= s) { B = gb; FE_HIP(hipStreamSynchronize(st)); break; } // the data end before this superblock does
+		if (gb <= s) { if (fmd_debug()) fprintf(stderr, "[fmdenc] the data end in superblock %lld: block %lld <= %lld, run %lld, %lld chunks listed\n", (long long)fe_iter, (long long)gb, (long long)s, (long long)cur, (long long)nl); B = gb; FE_HIP(hipStreamSynchronize(st)); break; } // the data end before this superblock does
 		hipLaunchKernelGGL(k_fe_special, dim3(1), dim3(1), 0, st, (const uint64_t*)P, d_words, nr, n_sym, (const int64_t*)bs, s, scal, flag);
 		{
 			int64_t sp[2];
 			FE_HIP(hipMemcpyAsync(sp, scal, 16, hipMemcpyDeviceToHost, st));
 			FE_HIP(hipStreamSynchronize(st));
 			o = sp[0], oty = (int)sp[1];
+			if (fmd_debug() && o >= nr) {
+				int64_t hb2[2] = {0, 0};
+				(void)hipMemcpy(hb2, bs + s - 1, 16, hipMemcpyDeviceToHost);
+				fprintf(stderr, "[fmdenc] superblock %lld ends the data: next run %lld >= %lld; its last block %lld starts at run %lld, the one before at %lld; chain had reached run %lld, block %lld\n", (long long)fe_iter, (long long)o, (long long)nr, (long long)s, (long long)hb2[1], (long long)hb2[0], (long long)cur, (long long)gb);
+			}
 		}
 		gb0 = s + 1;
 		if (o >= nr) { B = gb0; break; }
@@ -298,6 +335,7 @@ int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_w
 		FE_HIP(hipMemcpyAsync(bs + B, &nrv, 8, hipMemcpyHostToDevice, st));
 		FE_HIP(hipStreamSynchronize(st));
 	}
+	if (fmd_debug()) fprintf(stderr, "[fmdenc] %lld blocks in %lld superblocks after %.3f s\n", (long long)B, (long long)fe_iter, fe_now() - fe_t0);
 	if (hipMalloc(&out, (size_t)(8 * B + 8) * 8) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
 	hipLaunchKernelGGL(k_fe_pack, FE_GRID(B + 1), d_words, nr, n_sym, (const int64_t*)bs, B, out, flag, flag + 1);
 	FE_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, st));

@@ -490,7 +490,7 @@ def cfg2_step(local_rank, steps, warmup, genome_len, div):
     h.from_plain(b1)
     d_b2s, d_tw = h.sort_text(text2)
     out = {"workload": "cfg2-synthetic-mtb1: merge G1 = G0 + 0.1%% substitutions (%d bp, both strands, %d symbols, 2 strings) into the index of G0 (%d symbols); batch resident in HBM, commit=0" % (genome_len, text2.size, b1.size)}
-    for name, fn in (("rb3gpu_merge_plain_dev (reference's signature: BWT only, walker list made on the device)", lambda: h.merge_plain_dev(d_b2s, text2.size, commit=False)),
+    for name, fn in (("rb3gpu_merge_plain_dev (reference's signature: BWT only, text-order words made on the device)", lambda: h.merge_plain_dev(d_b2s, text2.size, commit=False)),
                      ("rb3gpu_merge_text_dev (BWT + inverse suffix array as the GPU sorter leaves them: the CLI's path)", lambda: h.merge_text_dev(d_b2s, d_tw, text2.size, w_text, commit=False))):
         for _ in range(warmup):
             fn()
@@ -649,7 +649,7 @@ def main():
             bl.h.sync()
             s2 = bl.h.stats()
             md5r, _ = bl.fmd_md5()
-            refsig = {"workload": "the headline's 151 merge rounds through rb3gpu_merge_plain_dev (the arguments of rb3_fmi_merge_plain: the partial BWT only; walker list made on the device by a sparse LF walk of the batch, row words instead of text-order words)",
+            refsig = {"workload": "the headline's 151 merge rounds through rb3gpu_merge_plain_dev (the arguments of rb3_fmi_merge_plain: the partial BWT only; round 6: the text-order words are made on the device from the batch's own sparse LF walk -- phase `lf` -- and the batch then goes through the same text path as the headline)",
                       "ms_per_step": round((a + b) * 1e3, 3), "value": round(n / (a + b) / 1e9, 4), "unit": "Gbp/s", "phases_ms_per_step": {"h2d": round(a * 1e3, 3), "lf": round(s2["ms_lf"], 3), "rank": round(s2["ms_rank"], 3), "k_chain": round(s2["ms_chain"], 3), "rebuild": round(s2["ms_build"], 3)},
                       "rank_phase_fallbacks": int(s2["n_fallbacks"]), "fmd_identical_to_reference": (md5r == gold["fmd_md5"]) if gold else None,
                       "ratio_to_the_headline": round((a + b) / ((tot_h2d + tot_mrg) / args.steps), 3)}

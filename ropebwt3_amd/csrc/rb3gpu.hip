@@ -126,6 +126,7 @@ struct Tune {
 	int poison = 0;          // fill every new device buffer with 0xA5 bytes (debugging: nothing may rely on what fresh memory holds)
 	int guard = 0;           // (debugging) 4 KB of fill pattern behind every buffer of the handle, verified after every merge
 	int vmm = 1;             // (values above 1: the threshold in KB instead of 64 MB -- tests make every buffer a growable range) buffers of 64 MB and more are ranges of reserved device address space that grow IN PLACE, a few physical chunks at a time (vm_ensure; round 6); 0: hipMalloc + reallocation
+	int b2_tw = 1;           // a batch that comes as its BWT only (the reference's signature) gets its text-order words from its own sparse LF walk and is merged like one that came with them (round 6); 0: walkers over row words (rounds 2-5)
 	int vmm_reserve = 0;     // (tests) MB of address space a new range reserves instead of 32 x its size (at least 16 GB)
 	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
 	int sh_host_rounds = 0;  // rb3gpu_sh_merge with ONE interval: the host reads the split sizes back after every round, as with several (0: the rounds run back to back on the device)
@@ -183,7 +184,8 @@ struct rb3gpu_s {
 	int cur = 0;
 	// scratch, grown on demand and kept between calls
 	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, wls, dl, dlx, wstat, wplane, wruns, gslots, glist, pslots, lbst; // (wls: the sentinels' text positions of a device-made walker list -- a buffer of its own, NOT dlx, which tent_masks() hands out as the wide drop-out masks and may reallocate: ADVICE r5)
-	Buf shc, shn, shs, shr, shk; // interval-sharded merge (rb3gpu_sh_merge): states of this and of the next round, send regions, landed (row, insertion point) pairs, counters
+	Buf shc, shn, shs, shr, shk;
+	Buf twb; // the text-order words of a batch that came as its BWT only (merge_plain_via_tw) // interval-sharded merge (rb3gpu_sh_merge): states of this and of the next round, send regions, landed (row, insertion point) pairs, counters
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
 	int64_t mg_len = 0, mg_acc2[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -599,6 +601,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "lf_after")) t.lf_after = v != 0;
 	else if (!strcmp(key, "vmm")) t.vmm = v < 0 ? 0 : (int)v;
 	else if (!strcmp(key, "abs_table")) t.abs_table = v != 0;
+	else if (!strcmp(key, "b2_tw")) t.b2_tw = v != 0;
 	else if (!strcmp(key, "vmm_reserve")) t.vmm_reserve = v < 0 ? 0 : (int)v;
 	else if (!strcmp(key, "copy_walkers")) t.copy_walkers = v != 0;
 	else if (!strcmp(key, "trec")) t.trec = v < 0 ? -1 : v != 0;
@@ -651,7 +654,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "abs_table", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "vmm", "vmm_reserve", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "abs_table", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "vmm", "vmm_reserve", "b2_tw", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -801,7 +804,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk, &h->twb };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -2261,10 +2264,68 @@ int rb3gpu_from_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
 	return rb3gpu_from_plain_dev(h, len, (const uint8_t*)h->b2.p);
 }
 
+/* The reference's signature (the partial BWT only, fm-index.c:279) for a batch of long strings: row words (lf_build), the sparse LF walk and its jumping
+ * rounds (as for the device-made walker list of rounds 3-5), then every splitter writes the text-order words of its stretch (k_b2_tw) and the batch goes
+ * through the text path -- streamed words, the common step of k_chain, the walker list of rb3gpu_merge_text_step_dev -- instead of through walkers that
+ * chase row words (139 against 80 ms of k_chain per 152-genome build).  One host synchronisation more (the number of strings).  *done = false: not a batch
+ * for this path (short strings, a split forced by the caller, an empty index): the caller goes on as before. */
+static int merge_plain_via_tw(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit, bool *done)
+{
+	*done = false;
+	if (!h->tn.b2_tw || h->tn.b2_split == 0 || h->opt.split_log2 != 0 || len < 4096 || h->n <= 0 || h->grp == nullptr || h->tn.staged || len >= (1LL << 40)) return 0;
+	const int b2S = h->tn.b2_split > 0 ? h->tn.b2_split : len < (32LL << 20) ? 4 : len < (128LL << 20) ? 5 : 6;
+	const int64_t m2cap = len / 64 + 1, nspmax = (len >> b2S) + m2cap + 2;
+	int r;
+	if ((r = buf_ensure(h, h->post, (size_t)len * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->twb, (size_t)len * 8 + 64)) < 0) return r;
+	if ((r = buf_ensure(h, h->xbuf, ((size_t)nspmax * 4 + 2 * (size_t)(m2cap + 2)) * 8)) < 0) return r;
+	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
+	int64_t acc2[7];
+	HIPCHK(hipEventRecord(h->ev[0], h->st));
+	if ((r = lf_build(h, len, d_b2, (int64_t*)h->post.p, acc2)) < 0) return r; // row words + the batch's symbol counts on the host (one synchronisation)
+	const int64_t m2 = acc2[1], step = m2 > 0 ? rb3gpu_walker_step(h->dev, len, m2) : 0;
+	if (m2 <= 0 || m2 > m2cap || len / m2 <= 4 * (int64_t)RB3_B2_W || step < 2) return 0; // short strings: one walker per string over the row words, as before
+	unsigned long long *misc = (unsigned long long*)h->misc.p;
+	const uint64_t *tot2 = (const uint64_t*)(misc + MISC_LF_TOT);
+	unsigned long long *mode = misc + MISC_B2_MODE, *bad = misc + 12;
+	uint64_t *lnk[2] = { (uint64_t*)h->xbuf.p, (uint64_t*)h->xbuf.p + 2 * nspmax };
+	uint64_t *slen2 = lnk[1] + 2 * nspmax, *sidx = slen2 + m2cap + 2;
+	HIPCHK(hipMemsetAsync(slen2, 0, (size_t)(m2cap + 2) * 8, h->st));
+	HIPCHK(hipMemsetAsync(sidx, 0xff, (size_t)(m2cap + 2) * 8, h->st));
+	HIPCHK(hipMemsetAsync(bad, 0, 8, h->st));
+	hipLaunchKernelGGL(k_b2_mode, dim3(1), dim3(64), 0, h->st, tot2, len, m2cap, mode, (int64_t)RB3_B2_W);
+	hipLaunchKernelGGL(k_b2_walk, dim3((unsigned)((nspmax + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)h->post.p, len, tot2, b2S, (const unsigned long long*)mode, lnk[0]);
+	int cur = 0;
+	for (int64_t reach = 1; reach < nspmax; reach <<= 2, cur ^= 1)
+		hipLaunchKernelGGL(k_b2_jump4, dim3((unsigned)((nspmax + 255) / 256)), dim3(256), 0, h->st, nspmax, (const uint64_t*)lnk[cur], lnk[cur ^ 1]);
+	hipLaunchKernelGGL(k_b2_strings2, dim3(64), dim3(256), 0, h->st, tot2, (const unsigned long long*)mode, (const uint64_t*)lnk[cur], slen2, sidx);
+	hipLaunchKernelGGL(k_b2_scan, dim3(1), dim3(1024), 0, h->st, tot2, (const unsigned long long*)mode, slen2);
+	hipLaunchKernelGGL(k_b2_tw, dim3((unsigned)((nspmax + 255) / 256)), dim3(256), 0, h->st, (const int64_t*)h->post.p, len, tot2, b2S, (const unsigned long long*)mode, (const uint64_t*)lnk[cur],
+			(const uint64_t*)slen2, (const uint64_t*)sidx, (uint64_t*)h->twb.p, bad);
+	unsigned long long hb[2] = {0, 0};
+	HIPCHK(hipMemcpyAsync(&hb[0], bad, 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipMemcpyAsync(&hb[1], slen2 + m2, 8, hipMemcpyDeviceToHost, h->st)); // (the total behind the last string: every row has its place)
+	HIPCHK(hipEventRecord(h->ev[1], h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	h->stt.ms_lf += ev_ms(h->ev[0], h->ev[1]);
+	if (hb[0] != 0 || (int64_t)hb[1] != len) { // (a BWT that is not one of complete strings: the walk over row words finds out what is wrong with it)
+		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] text-order words from the batch's own LF walk: %llu splitters without a string, %llu of %lld rows placed; walking row words instead\n", hb[0], hb[1], (long long)len);
+		return 0;
+	}
+	h->mg_sa = nullptr, h->mg_step = step;
+	r = merge_core(h, len, d_b2, commit, nullptr, nullptr, 0, m2, nullptr, (const uint64_t*)h->twb.p);
+	h->mg_step = 0;
+	*done = true;
+	return r;
+}
+
 int rb3gpu_merge_plain_dev(rb3gpu_t *h, int64_t len, const uint8_t *d_bwt, int commit)
 {
 	if (!h || len <= 0 || !d_bwt) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
+	bool done = false;
+	const int r = merge_plain_via_tw(h, len, d_bwt, commit, &done);
+	if (r < 0 || done) return r;
 	return merge_core(h, len, d_bwt, commit, nullptr, nullptr, 0, 0, nullptr);
 }
 
@@ -2275,6 +2336,9 @@ int rb3gpu_merge_plain(rb3gpu_t *h, int64_t len, const uint8_t *bwt)
 	if (h->n <= 0) return RB3GPU_ESTATE;
 	int r;
 	if ((r = upload_b2(h, len, bwt)) < 0) return r;
+	bool done = false;
+	r = merge_plain_via_tw(h, len, (const uint8_t*)h->b2.p, 1, &done);
+	if (r < 0 || done) return r;
 	return merge_core(h, len, (const uint8_t*)h->b2.p, 1, nullptr, nullptr, 0, 0, nullptr);
 }
 

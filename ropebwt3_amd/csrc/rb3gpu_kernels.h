@@ -4246,6 +4246,46 @@ __global__ void __launch_bounds__(1024) k_b2_scan(const uint64_t *tot2, const un
 	for (int64_t i = a; i < b; ++i) { const uint64_t v = slen[i]; slen[i] = run; run += v; }
 }
 
+/* Round 6: the TEXT-ORDER WORDS of a batch from its BWT alone (the reference's signature, rb3_fmi_merge_plain(len, bwt), fm-index.c:279): what a suffix sorter
+ * hands over for free -- tw[t] = row of the suffix at text position t << 3 | the symbol before it -- is the inverse of the BWT, and the sparse LF walk above
+ * has already done the sequential part: after the jumping rounds every splitter knows its string and its distance from the string's start.  So every
+ * splitter walks its stretch of rows ONCE MORE and writes their words at its text positions; the batch is then merged exactly like one that came with
+ * its inverse suffix array (k_chain<..., TEXT>: streamed words, the common step), instead of by walkers that chase row words.
+ * k_b2_strings2: string j (its sentinel is row j) has slen2[j] rows; its first suffix links to the dense number X of the string before it: sidx[X] = j. */
+__global__ void __launch_bounds__(256) k_b2_strings2(const uint64_t *tot2, const unsigned long long *mode, const uint64_t *lnk, uint64_t *slen2, uint64_t *sidx)
+{
+	if (mode[0] != 0) return;
+	const int64_t m2 = (int64_t)tot2[0];
+	for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m2; j += (int64_t)gridDim.x * blockDim.x) {
+		const uint64_t e = lnk[2 * j];
+		slen2[j] = lnk[2 * j + 1] + 1;
+		if ((e & RB3_SSA_END) && (e & ~RB3_SSA_END) < (uint64_t)m2) sidx[e & ~RB3_SSA_END] = (uint64_t)j;
+	}
+}
+
+/* gbase2 = the exclusive prefix of slen2 (k_b2_scan): string j lies at text positions [gbase2[j], gbase2[j + 1]), its sentinel last -- the batch's own order */
+__global__ void __launch_bounds__(256) k_b2_tw(const int64_t *roww, int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, const uint64_t *lnk, const uint64_t *gbase2,
+		const uint64_t *sidx, uint64_t *tw, unsigned long long *bad)
+{
+	if (mode[0] != 0) return;
+	const int64_t m2 = (int64_t)tot2[0], msk = (1LL << S) - 1;
+	const int64_t nsp = m2 + ((n2 - m2 + msk) >> S);
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= nsp) return;
+	const uint64_t e = lnk[2 * p], D = lnk[2 * p + 1];
+	if (!(e & RB3_SSA_END) || (e & ~RB3_SSA_END) >= (uint64_t)m2) { atomicAdd(bad, 1ull); return; } // (cannot be after the jumping rounds)
+	const uint64_t j = sidx[e & ~RB3_SSA_END];
+	if (j >= (uint64_t)m2 || gbase2[j] + D >= (uint64_t)n2) { atomicAdd(bad, 1ull); return; }
+	int64_t r = p < m2 ? p : m2 + ((p - m2) << S), G = (int64_t)(gbase2[j] + D);
+	for (;;) { // the same stretch as k_b2_walk's: down to the row in front of the next splitter, or to the first suffix of the string
+		const uint64_t w = (uint64_t)roww[r];
+		tw[G] = (uint64_t)r << 3 | (w & 7u);
+		if ((w & 7u) == 0u) break;
+		r = RB3_ROW_NEXT(w), --G;
+		if ((r >= m2 && ((r - m2) & msk) == 0) || G < 0) break;
+	}
+}
+
 /* per window of RB3_B2_W text positions (concatenated strings): the qualifying splitter closest to the window's start */
 __global__ void __launch_bounds__(256) k_b2_pick(int64_t n2, const uint64_t *tot2, int S, const unsigned long long *mode, const uint64_t *lnk, const uint64_t *gbase, unsigned long long *bucket, int64_t W)
 {

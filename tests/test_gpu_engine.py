@@ -658,12 +658,13 @@ def test_full_stretch_table_is_answered_with_fewer_walkers(oracle, entry):
 
 @pytest.mark.parametrize("env", [{"RB3GPU_GROUP_REBUILD": "1"}, {"RB3GPU_STAGED": "1"}, {"RB3GPU_GROUP_REBUILD": "1", "RB3GPU_STAGED": "1"},
                                  {"RB3GPU_TEXT_MODE": "2"}, {"RB3GPU_WINDOW_REBUILD": "1"}, {"RB3GPU_ABS_LIMIT": "0"}, {"RB3GPU_ABS_LIMIT": "60000"},
-                                 {"RB3GPU_B2_SPLIT": "6"}])
+                                 {"RB3GPU_B2_SPLIT": "6"}, {"RB3GPU_B2_TW": "0"}, {"RB3GPU_ABS_TABLE": "1"}, {"RB3GPU_B2_SPLIT": "3", "RB3GPU_ABS_TABLE": "1"}])
 def test_fallback_code_paths_via_soak(env):
     """the group-sequential rebuild kernels (taken when the window scratch would exceed 8 GB), the staged merge
     (taken for walker-less or oversized merges) and the slot headers of an index of 2^32 symbols or more (counts relative
     to the group; abs_limit moves that border down to nothing or into the middle of the builds) and the splitter spacing that whole-index
-    merges of 128 M symbols and more get (b2_split 6) forced through the randomised soak"""
+    merges of 128 M symbols and more get (b2_split 6), the walk over row words for a batch that came as its BWT only (b2_tw 0: rounds 2-5; the default makes the
+    batch's text-order words from its own LF walk) and the layout of 2^32 symbols and more (abs_table: low halves in the headers + the table of bases) forced through the randomised soak"""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "10", "61000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env))

@@ -1132,7 +1132,11 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 	// event is now noted in LDS -- entry (octet, iteration & 7), written by octet lane 0 -- and goes out with the records of its window of eight
 	// iterations, every lane one entry, in front of them (a record never names a stretch whose event is not on its way): seven steps in eight issue no
 	// store at all, and an event costs three store instructions per wave and window instead of three per octet and event.
+#ifdef RB3_NO_EVQ /* kernel experiment: the events written where they happen (rounds 2-5) */
+	constexpr bool EVQ = false;
+#else
 	constexpr bool EVQ = LIST && !DENSE && TENT && TEXT == 1 && LPW == 8;
+#endif
 	__shared__ uint4 evq_[EVQ ? 512 : 1]; // entry t: evq_[2t] = w0, w1 of the stretch record; evq_[2t + 1].x = the new stretch id (-1: no event), .y = 1 + the walker's first stretch
 	if (EVQ) evq_[2 * threadIdx.x + 1].x = 0xFFFFFFFFu;
 	auto evq_flush = [&]() { // every lane its own entry: (octet lane >> 3, iteration & 7 == lane & 7)
@@ -1389,10 +1393,16 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 						}
 						if (j == 0 && ns != RB3_TENT_POISON) {
 							const uint64_t ew0 = RB3_DEP_W0(RB3_DEP_EVENT, sid, (uint64_t)lo32), ew1 = (uint64_t)kq | (uint64_t)c << 16 | (uint64_t)tp32 << RB3_EV_TP_SHIFT;
-							const uint32_t qi = (threadIdx.x & ~7u) + (its & 7u);
-							evq_[2 * qi] = make_uint4((uint32_t)ew0, (uint32_t)(ew0 >> 32), (uint32_t)ew1, (uint32_t)(ew1 >> 32));
-							*(uint2*)&evq_[2 * qi + 1] = make_uint2((uint32_t)ns, (uint32_t)sid0 + 1u);
-							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+							if (EVQ) {
+								const uint32_t qi = (threadIdx.x & ~7u) + (its & 7u);
+								evq_[2 * qi] = make_uint4((uint32_t)ew0, (uint32_t)(ew0 >> 32), (uint32_t)ew1, (uint32_t)(ew1 >> 32));
+								*(uint2*)&evq_[2 * qi + 1] = make_uint2((uint32_t)ns, (uint32_t)sid0 + 1u);
+								__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+							} else {
+								tab[ns].w0 = ew0, tab[ns].w1 = ew1;
+								tab[ns].pad[0] = (uint32_t)sid0 + 1u;
+								tab[sid].child = ns + 1;
+							}
 						}
 						sid = ns;
 					}

@@ -318,20 +318,11 @@ static VmRange *vm_find(rb3gpu_t *h, const void *p)
 static int vm_map_chunk(rb3gpu_t *h, VmRange *r, size_t off, hipMemGenericAllocationHandle_t hd, size_t size)
 {
 	if (hipMemMap((char*)r->va + off, size, 0, hd, 0) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENOMEM; }
-	hipMemAccessDesc ad[RB3GPU_SH_MAXIV + 1];
-	int nad = 0, ndev = 0;
-	memset(ad, 0, sizeof(ad));
-	ad[nad].location.type = hipMemLocationTypeDevice, ad[nad].location.id = h->dev, ad[nad].flags = hipMemAccessFlagsProtReadWrite, ++nad;
-	if (hipGetDeviceCount(&ndev) == hipSuccess) // (the peers that pull from this device's buffers: rb3gpu_comm.hip)
-		for (int d = 0; d < ndev && nad < RB3GPU_SH_MAXIV + 1; ++d) {
-			int can = 0;
-			if (d != h->dev && hipDeviceCanAccessPeer(&can, d, h->dev) == hipSuccess && can)
-				ad[nad].location.type = hipMemLocationTypeDevice, ad[nad].location.id = d, ad[nad].flags = hipMemAccessFlagsProtReadWrite, ++nad;
-		}
-	if (hipMemSetAccess((char*)r->va + off, size, ad, (size_t)nad) != hipSuccess) {
-		(void)hipGetLastError();
-		if (nad == 1 || hipMemSetAccess((char*)r->va + off, size, ad, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap((char*)r->va + off, size); return RB3GPU_ENOMEM; }
-	}
+	// (this device only: the ranges are buffers that nothing but this handle's kernels touch -- what peers pull over xGMI are ordinary allocations)
+	hipMemAccessDesc ad;
+	memset(&ad, 0, sizeof(ad));
+	ad.location.type = hipMemLocationTypeDevice, ad.location.id = h->dev, ad.flags = hipMemAccessFlagsProtReadWrite;
+	if (hipMemSetAccess((char*)r->va + off, size, &ad, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap((char*)r->va + off, size); return RB3GPU_ENOMEM; }
 	return 0;
 }
 

@@ -356,9 +356,16 @@ static int vm_ensure(rb3gpu_t *h, void **p, size_t *cap, size_t bytes)
 		size_t off = 0;
 		for (auto &c : r->hs) { (void)hipMemUnmap((char*)r->va + off, c.second); off += c.second; }
 		off = 0;
-		for (auto &c : r->hs) { if (vm_map_chunk(h, &nr, off, c.first, c.second) < 0) return RB3GPU_EINTERNAL; off += c.second; }
+		size_t moved = 0;
+		for (auto &c : r->hs) { if (vm_map_chunk(h, &nr, off, c.first, c.second) < 0) break; off += c.second, ++moved; }
 		(void)hipMemAddressFree(r->va, r->va_size);
 		r->va = nva, r->va_size = want;
+		if (moved < r->hs.size()) { // (cannot be: the chunks were mapped a moment ago.  The range keeps what did move; the caller's buffer is gone)
+			for (size_t i = moved; i < r->hs.size(); ++i) { (void)hipMemRelease(r->hs[i].first); h->bytes_owned -= (int64_t)r->hs[i].second; }
+			r->hs.resize(moved), r->mapped = off;
+			*p = r->va, *cap = r->mapped;
+			return RB3GPU_EINTERNAL;
+		}
 	}
 	if (bytes > r->mapped) {
 		size_t inc = (bytes - r->mapped + G - 1) / G * G;
@@ -2306,6 +2313,10 @@ static int merge_plain_via_tw(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int
 	h->mg_sa = nullptr, h->mg_step = step;
 	r = merge_core(h, len, d_b2, commit, nullptr, nullptr, 0, m2, nullptr, (const uint64_t*)h->twb.p);
 	h->mg_step = 0;
+	if (r == RB3GPU_EINVAL || r == RB3GPU_EINTERNAL) { // (a failed merge installs nothing: the walk over row words decides what is wrong with the batch, or merges it)
+		if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] the merge through device-made text-order words failed (%s); walking row words instead\n", rb3gpu_strerror(r));
+		return 0;
+	}
 	*done = true;
 	return r;
 }
@@ -3020,7 +3031,7 @@ int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
 	if (nr <= 0) return RB3GPU_EINTERNAL;
 	{ // the packer holds ~26 bytes per run beside the run starts (8): where that does not fit beside the merge scratch of the handle, the scratch goes (the next merge obtains it again)
 		size_t fr = 0, tot = 0;
-		if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)nr * 34 > fr) {
+		if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)nr * 34 > fr && !h->mg_active) { // (not inside a two-phase merge: its uncommitted index lives in the spare buffers)
 			HIPCHK(hipStreamSynchronize(h->st));
 			Buf *scratch[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->jg, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->shc, &h->shn, &h->shs, &h->shr };
 			for (Buf *b : scratch) buf_release(h, *b);

@@ -74,6 +74,8 @@ typedef struct {
 	                                2048 once walkers have met intervals of more matching suffixes than that (an index of > 255 relatives) */
 	int64_t n_junctions_checked; /* junctions of the speculative walk (a walker meeting somebody's record; a drop-out event) whose LF relation was
 	                                verified after the rank phase: all of them, on every merge with text-order words */
+	int64_t n_peer_rounds;       /* lock-step rounds of the interval-sharded merge that ran as PEER ROUNDS (one kernel per rank, states written straight
+	                                into the owner's receive buffer; rb3gpu_comm_t.stream_barrier): 0 where the host drove the rounds */
 } rb3gpu_stats_t;
 
 void rb3gpu_opt_init(rb3gpu_opt_t *opt);
@@ -329,7 +331,7 @@ int rb3gpu_sh_finish(rb3gpu_t *h, int64_t jlo, int64_t n_rows, const uint8_t *d_
  * fm-index.c:202-249, with the kt_for over strings of 217-224 cut by interval instead of by thread): every rank calls
  * rb3gpu_sh_merge with the same batch and bounds; per lock-step round there is ONE kernel (k_sh_round: LF step, record, next
  * states written straight into per-destination send regions), one read-back of the split sizes, one all-gather of them and one
- * all-to-all of 16-byte states.  The rows that land in an interval are kept as (row, insertion point) pairs -- 16 bytes per
+ * all-to-all of 16-byte states -- or, over a communicator with stream_barrier (below), ONE kernel per round and nothing else.  The rows that land in an interval are kept as (row, insertion point) pairs -- 16 bytes per
  * landed row, nothing of the size of the whole batch -- and placed when the walk is over; then the interval is rebuilt.
  * What connects the ranks is a COMMUNICATOR of two collectives (host vectors of int64; device buffers of states):
  *   all_gather  every rank contributes n int64, recv gets world * n of them in rank order
@@ -349,6 +351,12 @@ typedef struct rb3gpu_comm_s {
 	int (*all_gather)(void *ctx, const int64_t *send, int n, int64_t *recv);
 	int (*all_to_all)(void *ctx, const rb3gpu_state_t *d_send, int64_t stride, const int64_t *send_cnt, rb3gpu_state_t *d_recv, const int64_t *recv_cnt, void *stream);
 	void (*abort)(void *ctx);   /* may be NULL: called by a rank whose merge failed locally, so that the others do not wait for it */
+	/* may be NULL.  Not NULL says two things: (1) the ranks can address each other's device memory (one process, peer access: a pointer that
+	 * all_gather carried from another rank can be given to a kernel here), and (2) stream_barrier(ctx, stream) makes everything this rank queues
+	 * on `stream` AFTER the call wait for everything EVERY rank queued on its stream BEFORE its call -- without waiting for the devices (events the
+	 * streams wait for, not a host synchronisation).  With it the lock-step rounds of rb3gpu_sh_merge[_text] run as PEER ROUNDS: one kernel per
+	 * rank and round that writes the next states straight into the owner's receive buffer over xGMI, no read-back, no all-gather, no all-to-all. */
+	int (*stream_barrier)(void *ctx, void *stream);
 } rb3gpu_comm_t;
 int rb3gpu_sh_merge(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw,
 		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds);

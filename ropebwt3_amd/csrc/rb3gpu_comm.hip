@@ -19,40 +19,47 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <atomic>
 #include <vector>
 #include "rb3gpu.h"
 
 /* ---- ranks as threads of one process ---- */
 
-struct GroupMember { rb3gpu_group_s *g; int rank, dev; };
+struct GroupMember { rb3gpu_group_s *g; int rank, dev; hipEvent_t ev[2]; int par; };
 
 struct rb3gpu_group_s {
 	int world = 0;
 	pthread_mutex_t mtx;
 	pthread_cond_t cv;
-	int waiting = 0, aborted = 0;
-	unsigned long gen = 0;
+	std::atomic<int> waiting{0}, aborted{0};
+	std::atomic<unsigned long> gen{0};
 	int64_t slots[RB3GPU_SH_MAXIV * RB3GPU_SH_MAXIV];           // all_gather: n <= RB3GPU_SH_MAXIV values per rank
 	struct { const rb3gpu_state_t *send; int64_t stride; int64_t cnt[RB3GPU_SH_MAXIV]; int dev; } pub[RB3GPU_SH_MAXIV];
 	GroupMember mem[RB3GPU_SH_MAXIV];
 };
 
+/* A rank that arrives spins for a few tens of microseconds before it goes to sleep on the condition variable: the peer rounds of the sharded merge pass
+ * one barrier per lock-step round (group_stream_barrier), the ranks arrive within microseconds of each other, and a wake-up through the kernel costs
+ * more than the round's launch.  The generation changes under the mutex, so a rank that gives up spinning cannot miss it. */
 static int group_barrier(rb3gpu_group_s *g)
 {
-	int r = 0;
-	pthread_mutex_lock(&g->mtx);
-	if (!g->aborted) {
-		const unsigned long my = g->gen;
-		if (++g->waiting == g->world) {
-			g->waiting = 0, ++g->gen;
-			pthread_cond_broadcast(&g->cv);
-		} else {
-			while (g->gen == my && !g->aborted) pthread_cond_wait(&g->cv, &g->mtx);
+	if (g->aborted.load(std::memory_order_acquire)) return RB3GPU_ESTATE;
+	const unsigned long my = g->gen.load(std::memory_order_acquire);
+	if (g->waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == g->world) {
+		g->waiting.store(0, std::memory_order_relaxed); // (nobody adds to it again before the generation has changed)
+		pthread_mutex_lock(&g->mtx);
+		g->gen.store(my + 1, std::memory_order_release);
+		pthread_cond_broadcast(&g->cv);
+		pthread_mutex_unlock(&g->mtx);
+	} else {
+		for (int spins = 0; spins < 4000 && g->gen.load(std::memory_order_acquire) == my && !g->aborted.load(std::memory_order_relaxed); ++spins) __builtin_ia32_pause();
+		if (g->gen.load(std::memory_order_acquire) == my && !g->aborted.load(std::memory_order_acquire)) {
+			pthread_mutex_lock(&g->mtx);
+			while (g->gen.load(std::memory_order_acquire) == my && !g->aborted.load(std::memory_order_acquire)) pthread_cond_wait(&g->cv, &g->mtx);
+			pthread_mutex_unlock(&g->mtx);
 		}
 	}
-	if (g->aborted) r = RB3GPU_ESTATE;
-	pthread_mutex_unlock(&g->mtx);
-	return r;
+	return g->aborted.load(std::memory_order_acquire) ? RB3GPU_ESTATE : 0;
 }
 
 static int group_all_gather(void *ctx, const int64_t *send, int n, int64_t *recv)
@@ -93,6 +100,27 @@ static int group_all_to_all(void *ctx, const rb3gpu_state_t *d_send, int64_t str
 	return group_barrier(g); // (a send region is not rewritten before every rank has pulled its share)
 }
 
+/* rb3gpu_comm_t.stream_barrier: every rank records an event behind what it has queued, the threads meet (the host waits for the other THREADS, not
+ * for any device), and every rank's stream then waits for the other ranks' events.  Two events per rank, used in turn: a rank records event p again
+ * two barriers later, and it cannot get there before every other rank has queued its wait for the earlier record (they all pass the barrier in between). */
+static int group_stream_barrier(void *ctx, void *stream)
+{
+	GroupMember *m = (GroupMember*)ctx;
+	rb3gpu_group_s *g = m->g;
+	hipStream_t st = (hipStream_t)stream;
+	if (hipSetDevice(m->dev) != hipSuccess) { rb3gpu_group_abort(g); return RB3GPU_ENODEV; }
+	for (int i = 0; i < 2; ++i)
+		if (!m->ev[i] && hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) != hipSuccess) { m->ev[i] = nullptr; rb3gpu_group_abort(g); return RB3GPU_ENODEV; }
+	const int p = m->par;
+	m->par ^= 1;
+	if (hipEventRecord(m->ev[p], st) != hipSuccess) { rb3gpu_group_abort(g); return RB3GPU_ENODEV; }
+	int r;
+	if ((r = group_barrier(g)) < 0) return r;
+	for (int q = 0; q < g->world; ++q)
+		if (q != m->rank && hipStreamWaitEvent(st, g->mem[q].ev[p], 0) != hipSuccess) { rb3gpu_group_abort(g); return RB3GPU_ENODEV; }
+	return 0;
+}
+
 static void group_abort_cb(void *ctx) { rb3gpu_group_abort(((GroupMember*)ctx)->g); }
 
 extern "C" {
@@ -106,6 +134,7 @@ rb3gpu_group_t *rb3gpu_group_create(int world)
 	pthread_mutex_init(&g->mtx, nullptr);
 	pthread_cond_init(&g->cv, nullptr);
 	memset(g->pub, 0, sizeof(g->pub));
+	memset(g->mem, 0, sizeof(g->mem));
 	return g;
 }
 
@@ -113,7 +142,7 @@ int rb3gpu_group_comm(rb3gpu_group_t *g, int rank, rb3gpu_t *h, rb3gpu_comm_t *c
 {
 	if (!g || !h || !comm || rank < 0 || rank >= g->world) return RB3GPU_EINVAL;
 	GroupMember *m = &g->mem[rank];
-	m->g = g, m->rank = rank, m->dev = rb3gpu_device_of(h);
+	m->g = g, m->rank = rank, m->dev = rb3gpu_device_of(h); // (m->par stays: the ranks pass their stream barriers together, whichever communicator structs they go through)
 	// direct peer access where the devices differ (an error here only means "already enabled" or "copies get staged": both fine)
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) == hipSuccess && hipSetDevice(m->dev) == hipSuccess)
@@ -121,6 +150,13 @@ int rb3gpu_group_comm(rb3gpu_group_t *g, int rank, rb3gpu_t *h, rb3gpu_comm_t *c
 			if (d != m->dev) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->dev, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0); (void)hipGetLastError(); }
 	comm->ctx = m, comm->rank = rank, comm->world = g->world;
 	comm->all_gather = group_all_gather, comm->all_to_all = group_all_to_all, comm->abort = group_abort_cb;
+	// peer rounds: this rank must reach the memory of every device of the node that another rank may sit on (the ranks agree on the path
+	// among themselves before they take it: rb3gpu.hip, sh_merge_impl)
+	bool reach = true;
+	for (int d = 0; d < ndev; ++d)
+		if (d != m->dev) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->dev, d) != hipSuccess || !can) reach = false; }
+	(void)hipGetLastError();
+	comm->stream_barrier = reach && !getenv("RB3GPU_NO_PEER_ROUNDS") ? group_stream_barrier : nullptr;
 	return 0;
 }
 
@@ -128,7 +164,7 @@ void rb3gpu_group_abort(rb3gpu_group_t *g)
 {
 	if (!g) return;
 	pthread_mutex_lock(&g->mtx);
-	g->aborted = 1;
+	g->aborted.store(1, std::memory_order_release);
 	pthread_cond_broadcast(&g->cv);
 	pthread_mutex_unlock(&g->mtx);
 }
@@ -136,6 +172,9 @@ void rb3gpu_group_abort(rb3gpu_group_t *g)
 void rb3gpu_group_destroy(rb3gpu_group_t *g)
 {
 	if (!g) return;
+	for (int q = 0; q < g->world; ++q)
+		for (int i = 0; i < 2; ++i)
+			if (g->mem[q].ev[i]) { (void)hipSetDevice(g->mem[q].dev); (void)hipEventDestroy(g->mem[q].ev[i]); }
 	pthread_cond_destroy(&g->cv);
 	pthread_mutex_destroy(&g->mtx);
 	delete g;
@@ -288,6 +327,7 @@ int rb3gpu_rccl_comm_create(rb3gpu_t *h, int rank, int world, const char id[RB3G
 	}
 	comm->ctx = c, comm->rank = rank, comm->world = world;
 	comm->all_gather = rccl_all_gather, comm->all_to_all = rccl_all_to_all, comm->abort = rccl_abort_cb;
+	comm->stream_barrier = nullptr; // (processes: a pointer of another rank means nothing here)
 	return 0;
 }
 

@@ -4481,10 +4481,28 @@ struct ShRec { int64_t kb, ka; };
  * (text position, insertion point) and the row is looked up at the end, by the rank that holds that part of the inverse suffix array. */
 /* BS threads per block: every block makes ONE returning atomic per destination on the round's cursor, and such atomics on one word take ~12 ns
  * each one after the other -- 7800 blocks of 256 threads at 2 M chains are 94 us of them per round; blocks of 1024 threads are a quarter of that */
+/* PEER ROUNDS (round 6; ranks that address each other's device memory: threads of one process with peer access over xGMI, rb3gpu_group_*).  The
+ * next state of a chain is written straight into the RECEIVE buffer of the rank that owns it: rank d's buffer has one region per source rank (stride
+ * states each), a source takes the places in ITS region from its own cursors (the same local atomics as with send regions: nothing returns over a
+ * link) and stores the state there -- 16 bytes, fire and forget.  The block that finishes last stores the source's totals into the destinations'
+ * tables of incoming counts (cin[d][source], one 8-byte word per pair and round), and the next round's kernel on d finds its states as world
+ * regions of cin_mine[s] states each.  A round is ONE kernel per rank and nothing goes through the host: no read-back of split sizes, no all-gather,
+ * no all-to-all (rb3gpu.hip, sh_merge_impl); between two rounds the streams wait for each other's events (rb3gpu_comm_t.stream_barrier) -- what one
+ * kernel stored is there for the kernels queued behind such a wait, on whichever device.  rec_cap: records this rank has room for (nobody knows
+ * beforehand how many rows land in an interval); a round that would overrun it counts into bad[1] and the host does the merge again its old way. */
+#define RB3_SH_MAXPEER 8
+struct ShPeers {
+	ShState *dst[RB3_SH_MAXPEER];            // receive buffer of rank d for the round behind this one (on device d)
+	unsigned long long *cin[RB3_SH_MAXPEER]; // rank d's incoming counts of that round: cin[d][source]
+	const unsigned long long *cin_mine;      // this rank's incoming counts of THIS round, by source
+	unsigned long long *done;                // blocks of this launch that have taken their places (cleared by the last one)
+	int64_t stride, rec_cap;
+	int on, rank;
+};
 template<int S, int BS = 256>
 __global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n, const ShState *in, const uint64_t *tw, ShRec *rec,
 		ShState *send, int64_t stride, unsigned long long *cnt, unsigned long long *cnt_next, unsigned long long *bad, const uint8_t *tprev = nullptr,
-		const unsigned long long *n_dev = nullptr, unsigned long long *rowbase = nullptr)
+		const unsigned long long *n_dev = nullptr, unsigned long long *rowbase = nullptr, ShPeers peers = ShPeers())
 {
 	// n_dev, rowbase (ONE interval: the rounds run back to back, nothing goes to the host between them): the number of states of this round is what
 	// the round before counted for interval 0 (*n_dev; `n` is then only an upper bound that sized the grid), its records go behind those of the
@@ -4492,12 +4510,25 @@ __global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n
 	__shared__ uint32_t lc[RB3_SH_MAXIV + 1];
 	__shared__ unsigned long long lb[RB3_SH_MAXIV + 1];
 	const int j = threadIdx.x & 7;
-	if (n_dev != nullptr) { // (ONE thread of the block fetches the two words: a million threads asking for the same line kept its L2 channel busy for longer than the round's work)
+	__shared__ unsigned long long pre[RB3_SH_MAXPEER + 1]; // peer rounds: the states of source s are [pre[s], pre[s + 1]) of this round
+	if (n_dev != nullptr || peers.on) { // (ONE thread of the block fetches the two words: a million threads asking for the same line kept its L2 channel busy for longer than the round's work)
 		__shared__ unsigned long long nb[2];
-		if (threadIdx.x == 0) nb[0] = *n_dev, nb[1] = rowbase[0];
+		if (threadIdx.x == 0) {
+			if (peers.on) {
+				unsigned long long t = 0;
+				for (int q = 0; q < a.n_iv; ++q) pre[q] = t, t += peers.cin_mine[q];
+				for (int q = a.n_iv; q <= RB3_SH_MAXPEER; ++q) pre[q] = t;
+				nb[0] = t;
+			} else nb[0] = *n_dev;
+			nb[1] = rowbase[0];
+		}
 		__syncthreads();
 		const int64_t nd = (int64_t)nb[0];
 		n = nd < n ? nd : n;
+		if (peers.on && (int64_t)nb[1] + n > peers.rec_cap) { // more rows land here than this rank made room for: nothing is written, the host does the merge again
+			if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(bad + 1, 1ull);
+			n = 0;
+		}
 		rec += nb[1];
 		if (blockIdx.x == 0 && threadIdx.x == 0) rowbase[1] = nb[1] + (unsigned long long)n;
 		if ((int64_t)blockIdx.x * (BS / 8) * S >= n && blockIdx.x != 0) return; // (block 0 stays: it clears the counters of the next round)
@@ -4511,10 +4542,19 @@ __global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n
 	RankLoad r[S];
 	int d[S];
 	uint32_t mine[S];
+	int src = 0; // peer rounds: the source whose region holds state q0 (the S states of an octet follow each other: the search is done once)
+	if (peers.on) {
+#pragma unroll
+		for (int e = 1; e < RB3_SH_MAXPEER; ++e) src += pre[e] <= (unsigned long long)q0 && e < a.n_iv ? 1 : 0;
+	}
 #pragma unroll
 	for (int s = 0; s < S; ++s) {
 		st[s].tp = 0, st[s].ka = a.iv_start;
-		if (q0 + s < n) st[s] = in[q0 + s];
+		if (q0 + s < n && peers.on) {
+			const unsigned long long q = (unsigned long long)(q0 + s);
+			while (src + 1 < a.n_iv && pre[src + 1] <= q) ++src;
+			st[s] = in[(int64_t)src * peers.stride + (int64_t)(q - pre[src])];
+		} else if (q0 + s < n) st[s] = in[q0 + s];
 	}
 #pragma unroll
 	for (int s = 0; s < S; ++s) x[s] = q0 + s >= n ? 0ull : tprev ? ((uint64_t)st[s].tp << 3 | (uint64_t)tprev[st[s].tp]) : tw[st[s].tp];
@@ -4551,7 +4591,35 @@ __global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n
 	__syncthreads();
 #pragma unroll
 	for (int s = 0; s < S; ++s)
-		if (j == 0 && d[s] >= 0 && d[s] < a.n_iv) send[(int64_t)d[s] * stride + (int64_t)lb[d[s]] + mine[s]] = st[s];
+		if (j == 0 && d[s] >= 0 && d[s] < a.n_iv) {
+			if (peers.on) { // into this rank's region of the owner's receive buffer
+				ShState *p = peers.dst[0];
+#pragma unroll
+				for (int e = 1; e < RB3_SH_MAXPEER; ++e) p = d[s] == e ? peers.dst[e] : p; // (selects: an index that varies per lane would move the table to scratch)
+				p[(int64_t)peers.rank * peers.stride + (int64_t)lb[d[s]] + mine[s]] = st[s];
+			} else send[(int64_t)d[s] * stride + (int64_t)lb[d[s]] + mine[s]] = st[s];
+		}
+	if (peers.on) { // the block that takes its places last knows this rank's totals: they go to the owners' tables of incoming counts
+		__shared__ int last;
+		// (no fence: the cursor atomics above RETURNED their values before the barrier in front of the stores, so they are done where the last block's
+		// atomic loads look for them; the states themselves are only read by kernels behind this one.  A __threadfence() here -- a release at agent
+		// scope, i.e. a write-back of the XCD's L2 per block -- made a round of 2 M chains take 1150 us instead of 220.)
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const int64_t per = (int64_t)(BS / 8) * S;
+			const unsigned long long nact = n > 0 ? (unsigned long long)((n + per - 1) / per) : 1ull; // (the blocks that did not return at the top)
+			last = atomicAdd(peers.done, 1ull) + 1ull == nact ? 1 : 0;
+		}
+		__syncthreads();
+		if (last && threadIdx.x < a.n_iv) {
+			const unsigned long long v = __hip_atomic_load(&cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			unsigned long long *c = peers.cin[0];
+#pragma unroll
+			for (int e = 1; e < RB3_SH_MAXPEER; ++e) c = (int)threadIdx.x == e ? peers.cin[e] : c;
+			__hip_atomic_store(&c[peers.rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		if (last && threadIdx.x == 0) *peers.done = 0ull;
+	}
 }
 
 /* the pairs an interval collected -> merged positions inside the interval: the rows are [jlo, jlo + n) of the batch, row r lands

@@ -36,7 +36,7 @@ class Stats(ctypes.Structure):
                 ("n_rank_launches", ctypes.c_int64), ("n_lf_steps", ctypes.c_int64), ("n_symbols_merged", ctypes.c_int64),
                 ("n_rounds", ctypes.c_int64), ("n_fallbacks", ctypes.c_int64), ("bytes_index", ctypes.c_int64), ("bytes_peak", ctypes.c_int64),
                 ("ms_ssa", ctypes.c_double), ("ms_ssa_walk", ctypes.c_double), ("ms_sort", ctypes.c_double), ("n_sort_rounds", ctypes.c_int64),
-                ("n_reb_groups", ctypes.c_int64), ("n_reb_groups_window", ctypes.c_int64), ("n_lf_checked", ctypes.c_int64), ("n_long_settles", ctypes.c_int64), ("ms_alloc", ctypes.c_double), ("n_allocs", ctypes.c_int64), ("n_reb_again", ctypes.c_int64), ("bytes_rebuild", ctypes.c_int64), ("n_thinned", ctypes.c_int64), ("tent_mask_bits", ctypes.c_int64), ("n_junctions_checked", ctypes.c_int64)]
+                ("n_reb_groups", ctypes.c_int64), ("n_reb_groups_window", ctypes.c_int64), ("n_lf_checked", ctypes.c_int64), ("n_long_settles", ctypes.c_int64), ("ms_alloc", ctypes.c_double), ("n_allocs", ctypes.c_int64), ("n_reb_again", ctypes.c_int64), ("bytes_rebuild", ctypes.c_int64), ("n_thinned", ctypes.c_int64), ("tent_mask_bits", ctypes.c_int64), ("n_junctions_checked", ctypes.c_int64), ("n_peer_rounds", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -151,7 +151,7 @@ ABORT_F = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 
 class CommStruct(ctypes.Structure):
     _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
-                ("all_gather", ctypes.c_void_p), ("all_to_all", ctypes.c_void_p), ("abort", ctypes.c_void_p)]
+                ("all_gather", ctypes.c_void_p), ("all_to_all", ctypes.c_void_p), ("abort", ctypes.c_void_p), ("stream_barrier", ctypes.c_void_p)]
 
 _libs = {}
 

@@ -1229,6 +1229,67 @@ def test_interval_sharded_merge_many_chains(oracle, states, block):
     assert not errs, errs
 
 
+@pytest.mark.parametrize("world,skew", [(2, False), (4, False), (4, True)])
+def test_interval_sharded_merge_peer_rounds(oracle, world, skew):
+    """PEER ROUNDS (rb3gpu_comm_t.stream_barrier; the thread-group communicator offers it): the lock-step rounds as one kernel per rank that writes the
+    next states straight into the owners' receive buffers -- every round counted in n_peer_rounds, the merged intervals the oracle's, and the same
+    intervals from the same merge with the rounds driven by the host (tune sh_host_rounds: every rank must say so, they agree on the path).
+    skew: three intervals of a few symbols and one with the rest, so that more rows land in it than the peer rounds made room for (three times a
+    rank's share): they give up on the device, say so, and the merge is done again the old way -- same result, no peer round counted."""
+    import threading
+    from ropebwt3_amd import Rb3Gpu, CommGroup, host, multi
+    rng = np.random.default_rng(77 + world)
+    g0 = util.random_genome(rng, 60000)
+    cur = host.build_bwt(util.make_text([g0]))
+    n = 14000 if skew else 3000
+    st, ln = rng.integers(0, len(g0) - 60, size=n), rng.integers(20, 61, size=n)
+    t2 = util.make_text([g0[a:a + l] for a, l in zip(st, ln)])
+    want = oracle.merge(cur, host.build_bwt(t2.copy()))
+    if skew:
+        assert t2.size > 3 * (t2.size // world) + (1 << 16) + 4000
+        bounds0 = np.array([0, 700, 1500, 2100, cur.size], dtype=np.int64)
+    else:
+        bounds0 = multi.interval_bounds(cur.size, world)
+    sent = np.flatnonzero(t2 == 0)
+    longest = int(np.max(np.diff(np.concatenate([[-1], sent]))))
+    res = {}
+    for host_rounds in (0, 1):
+        grp = CommGroup(world)
+        errs, out = [], [None] * world
+
+        def run(rank):
+            try:
+                h = Rb3Gpu(verbose=1)
+                if host_rounds:
+                    h.tune("sh_host_rounds", 1)
+                comm = grp.comm(rank, h)
+                assert comm.struct.stream_barrier
+                h.from_plain(cur[bounds0[rank]:bounds0[rank + 1]])
+                d_bwt, d_tw = h.sort_text(t2)
+                bounds, nr = h.sh_merge(comm, bounds0, d_bwt, d_tw, t2.size, sent)
+                assert nr == longest
+                _check_interval(h, np.random.default_rng(rank), want, bounds, rank)
+                out[rank] = (h.stats()["n_peer_rounds"], bounds.copy(), h.export_plain())
+                h.dev_free(d_bwt), h.dev_free(d_tw)
+                h.close()
+            except BaseException as e:
+                errs.append((rank, repr(e)))
+                grp.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        grp.close()
+        assert not errs, errs
+        res[host_rounds] = out
+    for rank in range(world):
+        assert res[0][rank][0] == (0 if skew else longest) and res[1][rank][0] == 0, [x[0] for x in res[0]]
+        assert np.array_equal(res[0][rank][1], res[1][rank][1]) and np.array_equal(res[0][rank][2], res[1][rank][2])
+    assert np.array_equal(np.concatenate([x[2] for x in res[0]]), want)
+
+
 def test_buffer_bytes_account_for_the_handle(oracle):
     """rb3gpu_buffer_bytes: the buffers a handle reports add up to no more than its peak, the current slot array holds the index, and the
     stretch table is there at its fixed size once a merge with tentative records has run"""

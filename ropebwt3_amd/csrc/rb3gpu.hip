@@ -12,6 +12,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <map>
 #include <algorithm>
 #include <utility>
 #include <stdio.h>
@@ -1948,6 +1949,51 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	if (hm[37]) fprintf(stderr, "[prof] general steps x %llu (lane 0 of every wave): %.0f ticks each; common steps %.0f ticks each (s_memtime ticks, whole step incl. the time between steps): general steps are %.1f %% of the iterations and %.1f %% of the stepping time\n",
 		hm[10] >> 32, (double)(hm[10] & 0xFFFFFFFFull) / (double)((hm[10] >> 32) ? (hm[10] >> 32) : 1), (double)(hm[34] + hm[35] + hm[36] + hm[38]) / hm[37],
 		100.0 * (double)(hm[10] >> 32) / (double)((hm[10] >> 32) + hm[37]), 100.0 * (double)(hm[10] & 0xFFFFFFFFull) / (double)((hm[10] & 0xFFFFFFFFull) + hm[34] + hm[35] + hm[36] + hm[38]));
+#endif
+#ifdef RB3_PROF_WAVES /* kernel experiment: the waves of this launch, by where they ran (merge number RB3_PROF_WAVES_AT of the handle, default 140) */
+	{
+		static int at = getenv("RB3_PROF_WAVES_AT") ? atoi(getenv("RB3_PROF_WAVES_AT")) : 140;
+		unsigned long long nw = 0, zero = 0;
+		(void)hipMemcpyFromSymbol(&nw, HIP_SYMBOL(g_prof_wave_n), 8);
+		static int printed = 0;
+		if ((int)(h->stt.n_rounds % 151) == at % 151 && nw > 0 && printed++ < 2) {
+			if (nw > RB3_PROF_WAVES_MAX) nw = RB3_PROF_WAVES_MAX;
+			std::vector<unsigned long long> w((size_t)nw * 4);
+			(void)hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(g_prof_wave), (size_t)nw * 32);
+			unsigned long long t0 = ~0ull, t1 = 0;
+			for (size_t i = 0; i < nw; ++i) { if (w[4 * i] < t0) t0 = w[4 * i]; if (w[4 * i + 1] > t1) t1 = w[4 * i + 1]; }
+			// where: xcc (8) x se (4?) x cu (16) x simd (4)
+			std::map<unsigned, std::vector<size_t>> by_cu, by_simd;
+			for (size_t i = 0; i < nw; ++i) {
+				const unsigned hw = (unsigned)w[4 * i + 2], xcc = (unsigned)(w[4 * i + 2] >> 32) & 15u;
+				const unsigned simd = hw >> 4 & 3u, cu = hw >> 8 & 15u, sh = hw >> 12 & 1u, se = hw >> 13 & 7u;
+				const unsigned cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu;
+				by_cu[cuid].push_back(i), by_simd[cuid * 4 + simd].push_back(i);
+			}
+			double dsum[16] = {0}; long cnt[16] = {0};
+			for (auto &kv : by_simd) {
+				const size_t k = kv.second.size() < 15 ? kv.second.size() : 15;
+				for (size_t i : kv.second) dsum[k] += (double)(w[4 * i + 1] - w[4 * i]), ++cnt[k];
+			}
+			(void)t1; // (s_memtime counts from another base on every XCD: only a wave's own duration means something)
+			fprintf(stderr, "[prof waves] merge %d: %llu waves on %zu compute units / %zu SIMDs (durations in ticks of s_memtime)\n", at, nw, by_cu.size(), by_simd.size());
+			for (int k = 1; k < 16; ++k) if (cnt[k]) fprintf(stderr, "[prof waves]   SIMDs with %d waves: %ld waves, last %.0f ticks on average\n", k, cnt[k], dsum[k] / cnt[k]);
+			double cd[64] = {0}; long cc[64] = {0};
+			for (auto &kv : by_cu) {
+				const size_t k = kv.second.size() < 63 ? kv.second.size() : 63;
+				for (size_t i : kv.second) cd[k] += (double)(w[4 * i + 1] - w[4 * i]), ++cc[k];
+			}
+			for (int k = 1; k < 64; ++k) if (cc[k]) fprintf(stderr, "[prof waves]   compute units with %d waves: %ld waves, last %.0f ticks on average\n", k, cc[k], cd[k] / cc[k]);
+			double xd[16] = {0}; long xc[16] = {0};
+			for (size_t i = 0; i < nw; ++i) { const unsigned x = (unsigned)(w[4 * i + 2] >> 32) & 15u; xd[x] += (double)(w[4 * i + 1] - w[4 * i]), ++xc[x]; }
+			for (int x = 0; x < 16; ++x) if (xc[x]) fprintf(stderr, "[prof waves]   XCD %d: %ld waves, last %.0f ticks on average\n", x, xc[x], xd[x] / xc[x]);
+			std::vector<double> durs;
+			for (size_t i = 0; i < nw; ++i) durs.push_back((double)(w[4 * i + 1] - w[4 * i]));
+			std::sort(durs.begin(), durs.end());
+			fprintf(stderr, "[prof waves]   durations: 1 %% %.0f, 10 %% %.0f, 50 %% %.0f, 90 %% %.0f, 99 %% %.0f, longest %.0f; iterations of the first wave: %llu\n", durs[nw / 100], durs[nw / 10], durs[nw / 2], durs[nw * 9 / 10], durs[nw * 99 / 100], durs[nw - 1], w[3] & 0xFFFFFFFFull);
+		}
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_wave_n), &zero, 8);
+	}
 #endif
 #ifdef RB3_PROF
 	fprintf(stderr, "[prof] k_chain waves %llu: max %.0f cycles, mean %.0f cycles, mean iterations %.1f, %.1f %% of them with the two-decode path -> %.1f cycles/iteration\n", hm[11], (double)hm[8], (double)hm[9] / hm[11], (double)hm[10] / hm[11], 100.0 * (double)hm[12] / (double)hm[10], (double)hm[9] / hm[10]);

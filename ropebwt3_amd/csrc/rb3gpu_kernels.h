@@ -683,6 +683,11 @@ __global__ void __launch_bounds__(256) k_lf2(const uint8_t *b2, int64_t n2, cons
  *                 arrived with in *arrive for the neighbour rank.
  */
 struct Walker { int64_t row, ka0, nsteps, flags; };
+#ifdef RB3_PROF_WAVES
+#define RB3_PROF_WAVES_MAX 16384
+__device__ unsigned long long g_prof_wave[4 * RB3_PROF_WAVES_MAX];
+__device__ unsigned long long g_prof_wave_n;
+#endif
 #define RB3_MISC_BADW 40 /* word of the merge's counter block (rb3gpu.hip: misc[]; k_chain's nsteps is misc + 1) that counts list entries which are not walkers of the batch */
 #define RB3_WK_CHECK 2
 
@@ -1193,6 +1198,9 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 #ifdef RB3_PROF_STEP
 	uint64_t prof_t[7] = {0, 0, 0, 0, 0, 0, 0}, prof_last = 0, prof_u[2] = {0, 0};
 #endif
+#ifdef RB3_PROF_WAVES
+	const unsigned long long prof_wt0 = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef RB3_PROF
 	const uint64_t tstart = __builtin_readcyclecounter();
 	unsigned long long prof_nonpair = 0; // iterations in which some group of this wave took the two-decode path
@@ -1204,7 +1212,11 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 			// of text-regular walkers has about one per octet: ~23 k atomics on one word in the first microseconds); later ones
 			// come from the queue behind those
 			int64_t wid;
+#ifdef RB3_EXP_STRIDE /* kernel experiment: the eight octets of a wave take walkers from eight distant parts of the list (the text) instead of eight neighbours */
+			if (firstpull) wid = (int64_t)(lane / LPW) * (noct / octs) + myoct / octs, firstpull = false;
+#else
 			if (firstpull) wid = myoct, firstpull = false;
+#endif
 			else {
 				uint32_t w0 = 0, w1 = 0;
 				if (j == 0) {
@@ -1805,6 +1817,16 @@ __global__ void __launch_bounds__(256, RB3_CHAIN_WPE) k_chain(IdxView b1, int64_
 	if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(nsteps + 33 + q, (unsigned long long)prof_t[q]); // misc[34..38]
 	if (lane == 0) atomicAdd(nsteps + 8, (unsigned long long)prof_t[5]), atomicAdd(nsteps + 9, (unsigned long long)prof_t[6]); // misc[9], misc[10]
 	if (lane == 0) atomicAdd(nsteps + 10, (unsigned long long)prof_u[0]), atomicAdd(nsteps + 11, (unsigned long long)prof_u[1]); // misc[11], misc[12]
+#endif
+#ifdef RB3_PROF_WAVES /* kernel experiment: where does a launch's tail come from?  One entry per wave: when it began and ended (s_memtime: one clock for the chip), where it ran (HW_ID, XCC_ID), its iterations */
+	if (lane == 0) {
+		const unsigned long long e = atomicAdd(&g_prof_wave_n, 1ull);
+		if (e < RB3_PROF_WAVES_MAX) {
+			g_prof_wave[4 * e] = prof_wt0, g_prof_wave[4 * e + 1] = __builtin_amdgcn_s_memtime();
+			g_prof_wave[4 * e + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
+			g_prof_wave[4 * e + 3] = (unsigned long long)it | (unsigned long long)steps << 32;
+		}
+	}
 #endif
 #ifdef RB3_PROF
 	if (lane == 0) { // wave statistics: [8] max cycles, [9] sum cycles, [10] sum iterations, [11] waves, [12] max iterations

@@ -4555,7 +4555,9 @@ __global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n
 		if (blockIdx.x == 0 && threadIdx.x == 0) rowbase[1] = nb[1] + (unsigned long long)n;
 		if ((int64_t)blockIdx.x * (BS / 8) * S >= n && blockIdx.x != 0) return; // (block 0 stays: it clears the counters of the next round)
 	}
-	if (blockIdx.x == 0 && threadIdx.x <= RB3_SH_MAXIV) cnt_next[threadIdx.x] = 0ull;
+	// (peer rounds: cursor d lies at word 16 d of its set -- a line of its own, so that the returning atomics of different destinations do not queue
+	// in one L2 channel, ~12 ns each -- and the count of ended chains at word 8)
+	if (blockIdx.x == 0 && threadIdx.x <= (peers.on ? 16 * RB3_SH_MAXPEER - 1 : RB3_SH_MAXIV)) cnt_next[threadIdx.x] = 0ull;
 	for (int i = threadIdx.x; i <= a.n_iv; i += blockDim.x) lc[i] = 0u;
 	__syncthreads();
 	const int64_t q0 = ((int64_t)blockIdx.x * (BS / 8) + (threadIdx.x >> 3)) * S;
@@ -4609,7 +4611,7 @@ __global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n
 	}
 	__syncthreads();
 	for (int i = threadIdx.x; i <= a.n_iv; i += blockDim.x)
-		lb[i] = lc[i] ? atomicAdd(&cnt[i], (unsigned long long)lc[i]) : 0ull;
+		lb[i] = lc[i] ? atomicAdd(&cnt[peers.on ? (i < a.n_iv ? 16 * i : 8) : i], (unsigned long long)lc[i]) : 0ull;
 	__syncthreads();
 #pragma unroll
 	for (int s = 0; s < S; ++s)
@@ -4634,7 +4636,7 @@ __global__ void __launch_bounds__(BS) k_sh_round(IdxView ix, ShArgs a, int64_t n
 		}
 		__syncthreads();
 		if (last && threadIdx.x < a.n_iv) {
-			const unsigned long long v = __hip_atomic_load(&cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned long long v = __hip_atomic_load(&cnt[16 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			unsigned long long *c = peers.cin[0];
 #pragma unroll
 			for (int e = 1; e < RB3_SH_MAXPEER; ++e) c = (int)threadIdx.x == e ? peers.cin[e] : c;

@@ -548,6 +548,7 @@ def main():
                     help="N > 1: how the work is split over the GPUs (ropebwt3_amd/multi.py); default partition = the same mtb152 build, partitioned + tree merge")
     ap.add_argument("--sh-driver", choices=["rccl", "torch", "python", "gloo"], default=None, help="--mode interval: what runs the lock-step loop and carries the states: rb3gpu_sh_merge over the library's RCCL communicator (default), over torch.distributed callbacks, or the loop in Python (rounds 1-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--peer-rounds", type=int, default=100000, help="reads of the aux_interval_peer_rounds leg (0: skip it)")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (CLI build, configs[1], reads regime, large index)")
     ap.add_argument("--no-pinned", action="store_true", help="batches in pageable host memory (staged upload)")
     ap.add_argument("--serial-h2d", action="store_true", help="upload every batch before its own sort with nothing beside it (round 3's first definition) instead of beside the merge of the batch before")
@@ -763,6 +764,14 @@ def main():
                 out["aux_large_index"] = large_index_regime(mk, args.large_index, 1000000)
             if args.index_8g > 0:
                 out["aux_index_8g"] = index_8g(args.index_8g, local_rank)
+            if args.peer_rounds > 0:   # VERDICT r5 "next" 8: the lock-step rounds of the interval-sharded merge without the host, ranks = threads sharing this GPU
+                from tools import probe_sh_peer
+                rows = probe_sh_peer.measure([args.peer_rounds], worlds=(1, 2, 4), modes=(0, 1), index_log2=24, reps=2)
+                out["aux_interval_peer_rounds"] = {"what": "rb3gpu_sh_merge of %d reads x 150 bp (both strands) into an index of 2^24 symbols cut into `world` intervals, ranks = threads with a handle each, ALL ON THIS ONE GPU: "
+                                                           "us of the walk per lock-step round.  peer rounds: one kernel per rank and round that stores the next states straight into the owner's receive buffer, streams waiting "
+                                                           "for each other's events (rb3gpu_comm_t.stream_barrier); driven by the host: read-back of the split sizes + all-gather + all-to-all per round (rounds 4-5).  "
+                                                           "Never run on two devices; larger batches: profiles/r6_sh_peer_rounds.txt" % args.peer_rounds,
+                                                   "rows": rows}
         except Exception as e:   # (a box with less free memory than a leg needs must not lose the headline)
             out["aux_error"] = repr(e)[:300]
         # BASELINE configs[3] / [4] in shape at 1/10 and at real contig sizes: minutes of box time each, so they are RECORDED runs (tools/r6/scale_reads.sh,

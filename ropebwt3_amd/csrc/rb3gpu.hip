@@ -1461,31 +1461,27 @@ __global__ void __launch_bounds__(256) k_wl_sentinels(const uint64_t *tw, int64_
 	if (sentinel && r < m2) sent[r] = t;
 }
 
-/* ... or, where the caller has the batch's suffix array: the sentinels' suffixes are rows 0 .. m2-1, so sent[j] = sa[j] (m2 loads instead of a pass over the words) */
-__global__ void __launch_bounds__(256) k_wl_sentinels_sa(const uint32_t *sa, int64_t n, int64_t m2, int64_t *sent)
-{
-	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j < m2) sent[j] = sa[j] < (uint32_t)n ? (int64_t)sa[j] : -1;
-}
-
 /* Pass 2: the list.  sent[] came filled with -1: a string count that is not the batch's leaves entries there, and the walkers of those strings
  * are not made (their rows stay unset: the merge reports EINVAL, as for a wrong count of the per-string list) */
-__global__ void __launch_bounds__(256) k_wl_make(const int64_t *sent, int64_t m2, int64_t n, int64_t step, int64_t K, Walker *wl)
+/* sa != NULL: the sentinels' positions straight from the batch's suffix array (sent[j] = sa[j], what k_wl_sentinels_sa would have copied: one launch less in front of the walkers,
+ * ~10 us of a merge with the chip idle) */
+__global__ void __launch_bounds__(256) k_wl_make(const int64_t *sent_, const uint32_t *sa, int64_t m2, int64_t n, int64_t step, int64_t K, Walker *wl)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= K + m2) return;
+	auto sent = [&](int64_t j) -> int64_t { if (sa == nullptr) return sent_[j]; const uint32_t v = sa[j]; return v < (uint32_t)n ? (int64_t)v : -1; };
 	const int64_t INF = INT64_MAX / 2;
 	Walker w;
 	int64_t slot = -1;
 	w.row = -1, w.ka0 = -1, w.nsteps = 0, w.flags = 0;
 	if (i < K) { // the multiple p = (i + 1) * step: string [b, e) with sentinel e = the first sentinel at or behind p
 		const int64_t p = (i + 1) * step;
-		int64_t lo = 0, hi = m2; // first j with sent[j] >= p
-		while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sent[mid] >= p) hi = mid; else lo = mid + 1; }
+		int64_t lo = 0, hi = m2; // first j with sent(j) >= p
+		while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sent(mid) >= p) hi = mid; else lo = mid + 1; }
 		slot = i + lo;
 		if (lo < m2 && p < n) {
-			const int64_t e = sent[lo], b = lo > 0 ? sent[lo - 1] + 1 : 0;
-			const bool ok = e >= 0 && (lo == 0 || sent[lo - 1] >= 0) && p > b && p < e && !(e - p < RB3_WL_MIN_SEG && e - p < step);
+			const int64_t e = sent(lo), b = lo > 0 ? sent(lo - 1) + 1 : 0;
+			const bool ok = e >= 0 && (lo == 0 || sent(lo - 1) >= 0) && p > b && p < e && !(e - p < RB3_WL_MIN_SEG && e - p < step);
 			if (ok) {
 				const int64_t pre = e - 1 - p < RB3_WL_PREROLL ? e - 1 - p : RB3_WL_PREROLL;
 				w.row = p + pre, w.ka0 = -1, w.flags = pre << 8;
@@ -1494,9 +1490,9 @@ __global__ void __launch_bounds__(256) k_wl_make(const int64_t *sent, int64_t m2
 			}
 		}
 	} else { // the sentinel of string j
-		const int64_t j = i - K, e = sent[j], b = j > 0 ? sent[j - 1] + 1 : 0;
+		const int64_t j = i - K, e = sent(j), b = j > 0 ? sent(j - 1) + 1 : 0;
 		if (e >= 0) slot = e / step + j;
-		if (e >= 0 && (j == 0 || sent[j - 1] >= 0)) {
+		if (e >= 0 && (j == 0 || sent(j - 1) >= 0)) {
 			int64_t q = e > 0 ? (e - 1) / step * step : 0; // the last multiple below e ... that has a walker
 			if (q > b && q < e && (e - q < RB3_WL_MIN_SEG && e - q < step)) q -= step;
 			w.row = e, w.ka0 = -2, w.flags = 0;
@@ -1566,18 +1562,19 @@ static rb3gpu_walker_t *thin_walkers(int64_t n, const rb3gpu_walker_t *w, int th
 }
 
 /* the list of k_wl_sentinels / k_wl_make into wl (K + n_strings slots), queued on the handle's stream; scratch: n_strings words */
-static void step_list_launch(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *d_sent, Walker *wl, hipStream_t st = nullptr)
+static void step_list_launch(rb3gpu_t *h, int64_t len, const uint64_t *d_tw, int64_t n_strings, int64_t step, int64_t *d_sent, Walker *wl, hipStream_t st = nullptr, bool wl_cleared = false)
 {
 	if (st == nullptr) st = h->st;
 	const int64_t K = len / step;
-	(void)hipMemsetAsync(wl, 0xff, (size_t)(K + n_strings) * 32, st); // every slot empty (row -1)
-	if (h->mg_sa != nullptr && len < (1LL << 32)) // (a wrong string count: sa[j] of a j that is no sentinel's row is a position whose next word does not start a string -- k_wl_make's
-		hipLaunchKernelGGL(k_wl_sentinels_sa, dim3((unsigned)((n_strings + 255) / 256)), dim3(256), 0, st, h->mg_sa, len, n_strings, d_sent); // binary search then meets unsorted positions; the merge's own count of the sentinels decides)
-	else {
-		(void)hipMemsetAsync(d_sent, 0xff, (size_t)n_strings * 8, st);
-		hipLaunchKernelGGL(k_wl_sentinels, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, d_tw, len, n_strings, d_sent);
+	if (!wl_cleared) (void)hipMemsetAsync(wl, 0xff, (size_t)(K + n_strings) * 32, st); // every slot empty (row -1) (wl_cleared: the merge's fill kernel has done it)
+	if (h->mg_sa != nullptr && len < (1LL << 32)) { // (a wrong string count: sa[j] of a j that is no sentinel's row is a position whose next word does not start a string -- k_wl_make's
+		// binary search then meets unsorted positions; the merge's own count of the sentinels decides)
+		hipLaunchKernelGGL(k_wl_make, dim3((unsigned)((K + n_strings + 255) / 256)), dim3(256), 0, st, (const int64_t*)nullptr, h->mg_sa, n_strings, len, step, K, wl);
+		return;
 	}
-	hipLaunchKernelGGL(k_wl_make, dim3((unsigned)((K + n_strings + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_sent, n_strings, len, step, K, wl);
+	(void)hipMemsetAsync(d_sent, 0xff, (size_t)n_strings * 8, st);
+	hipLaunchKernelGGL(k_wl_sentinels, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, d_tw, len, n_strings, d_sent);
+	hipLaunchKernelGGL(k_wl_make, dim3((unsigned)((K + n_strings + 255) / 256)), dim3(256), 0, st, (const int64_t*)d_sent, (const uint32_t*)nullptr, n_strings, len, step, K, wl);
 }
 
 /* ... and on the host, without its empty slots (the paths that walk row words, a merge that is redone: rare) */
@@ -1729,6 +1726,8 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 	const bool rows_filled = d_tw != nullptr && jb.n < 8;
 	if (rows_filled) fill_add(&jb, trec ? h->post.p : h->pos.p, (size_t)len * 8, 0xFFFFFFFFu);
 	else if (trec) HIPCHK(hipMemsetAsync(h->post.p, 0xff, (size_t)len * 8, h->st));
+	const bool wl_cleared = step_list && jb.n < 8; // the empty slots of the list made on the device: with this launch too (a memset of its own was 8 us in front of the walkers)
+	if (wl_cleared) fill_add(&jb, h->wl.p, (size_t)n_walkers * 32, 0xFFFFFFFFu);
 	fill_launch(h, jb);
 	h->reb_prepared = true; // (build_index: the counters of the run-space rebuild are clear)
 	// The histogram of the batch and its scan (the C array of B2 and the rows before every tile, fm-index.c:206-216): a text-order walk
@@ -1769,7 +1768,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 				(const uint64_t*)lnk[cur], (const uint64_t*)slen, (const unsigned long long*)bucket, b2_nbk, (Walker*)h->wl.p, b2_nwalk, (const int64_t*)h->pos.p, b2W);
 	} else if (step_list) { // one walker per string and one every wstep text positions, made here (two small kernels in front of the walkers; on the side stream,
 		// beside the fill, they were measured in round 5: the wait for the event costs more than they take -- fill-to-walkers 6.0 -> 7.0 ms per 152-genome build)
-		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->wls.p, (Walker*)h->wl.p);
+		step_list_launch(h, len, d_tw, n_strings, wstep, (int64_t*)h->wls.p, (Walker*)h->wl.p, nullptr, wl_cleared);
 	} else if (per_string && d_tw) {
 		HIPCHK(hipMemsetAsync(h->wl.p, 0xff, (size_t)n_walkers * 32, h->st)); // a walker that nobody fills in starts at row -1: caught below
 		hipLaunchKernelGGL(k_walkers_per_string, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, h->st, (Walker*)h->wl.p, n_walkers, d_tw, len);
@@ -1815,7 +1814,7 @@ static int merge_core(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int commit,
 		fprintf(stderr, "[prof] launching %lld blocks x 256 threads, %d octets per wave, %lld walkers\n", (long long)nblk, octs, (long long)n_walkers);
 #endif
 		const dim3 grid((unsigned)(nblk * (256 / h->tn.chain_bs))), blk((unsigned)h->tn.chain_bs);
-		HIPCHK(hipEventRecord(h->ev[6], h->st));
+		HIPCHK(hipEventRecord(h->ev[6], h->st)); // (measured, round 6: without this event a merge is ~5 us shorter -- k_chain's own time is worth that)
 #ifdef RB3GPU_TEST_HOOKS
 #define RB3_TREC_ARG ((trec ? 1 : 0) | (h->tn.hide_first ? 2 : 0))
 #else

@@ -134,7 +134,7 @@ struct Tune {
 	int sh_block = 0;        // threads per block of k_sh_round at eight states per octet: 256 or 1024; 0: 1024 below 3 M chains
 	int sh_states = 0;       // states per octet of k_sh_round (1, 2, 4, 8); 0: by the number of chains
 	int lf_check = 4096;     // sampled LF-consistency check of pos[] after every merge: every n-th row (0: off)
-	int junction_check = 16; // ... and the LF relation at the junctions of the speculative walk (k_junction_check): wherever a walker met somebody's record -- all
+	int junction_check = 1;  // (round 6, last session: 1 = the events of EVERY stretch -- 16 before: every 16th; beside the rebuild the full check costs the 152-genome build 2.3 of 167 ms, every 2nd 0.4, every 4th nothing) ... and the LF relation at the junctions of the speculative walk (k_junction_check): wherever a walker met somebody's record -- all
 	                         // of them, always -- and at the drop-out events of every n-th stretch id (1: every event, ~10 ms per 152-genome build; 0: off)
 	int ev_blocks = 2048, cum_blocks = 2048, resw_blocks = 512, sfin_blocks = 2048; // launch widths of the settle kernels (k_events, k_cum, k_resolve_w, k_sfin); round 5: k_cum 1024 -> 2048 (-1 ms per 152-genome build), the others make no difference (profiles/r5_ab_settle_widths.txt)
 	int64_t load_chunk = 16384; // groups (of 8192 symbols) an FMD stream is decoded and built by at a time when it holds more than that (rb3gpu_from_fmd_words)

@@ -1775,7 +1775,7 @@ def test_junction_check_catches_one_wrong_stretch_every_time(oracle):
     t2 = util.make_text([util.mutate(rng, g0, 0.003)])
     want = oracle.merge(b1, host.build_bwt(t2.copy()))
     h = Rb3Gpu(verbose=1, hooks=True)
-    h.tune("junction_check", 1)    # every event (the default looks at the events of every 16th stretch id, and at all junctions between walkers)
+    h.tune("junction_check", 1)    # every event and all junctions between walkers (the default since round 6; every 16th stretch id's events before)
     try:
         caught = 0
         for trial in range(100):

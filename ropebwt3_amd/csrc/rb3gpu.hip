@@ -1179,6 +1179,9 @@ static int lf_build(rb3gpu_t *h, int64_t len, const uint8_t *d_b2, int64_t *d_ro
  * misc[4] (with the unsettled tentative records: a failure first makes the merge redo its rank phase without speculation) */
 struct JuncArgs { const uint64_t *tw; const rb3_stretch_t *tab; const uint32_t *sidctr; const int64_t *jmet; int64_t nwalk; const unsigned long long *nwalk_dev; };
 #define MISC_JUNC 41 /* junctions k_junction_check looked at */
+#ifndef RB3_JUNC_BLOCKS
+#define RB3_JUNC_BLOCKS 512 /* blocks of k_junction_check (side stream, beside the rebuild) */
+#endif
 static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b2, int64_t len, bool side, hipEvent_t here = nullptr, const JuncArgs *ja = nullptr) // here: an event the caller has just recorded on the main stream (saves recording another one: every record is a packet the command processor works through, ~3-5 us)
 {
 	const int64_t stride = h->tn.lf_check;
@@ -1194,7 +1197,7 @@ static bool launch_lf_check(rb3gpu_t *h, const int64_t *dpos, const uint8_t *d_b
 	hipLaunchKernelGGL(k_lf_check, dim3((unsigned)((ns * 8 + 255) / 256)), dim3(256), 0, s, view_of(h), dpos, d_b2, len, (const uint64_t*)h->tpre.p,
 			(const uint64_t*)(misc + MISC_LF_TOT), stride, misc + 2, misc + MISC_LF_CHK);
 	if (ja != nullptr && h->tn.junction_check) // every junction of the speculative walk, deterministically (k_junction_check)
-		hipLaunchKernelGGL(k_junction_check, dim3(512), dim3(256), 0, s, view_of(h), dpos, ja->tw, len, ja->tab, ja->sidctr, ja->jmet, ja->nwalk, ja->nwalk_dev, misc + 2, misc + MISC_LF_CHK, misc + MISC_JUNC,
+		hipLaunchKernelGGL(k_junction_check, dim3(RB3_JUNC_BLOCKS), dim3(256), 0, s, view_of(h), dpos, ja->tw, len, ja->tab, ja->sidctr, ja->jmet, ja->nwalk, ja->nwalk_dev, misc + 2, misc + MISC_LF_CHK, misc + MISC_JUNC,
 				h->tn.junction_check, (int)(h->stt.n_rounds % h->tn.junction_check)); // (a different residue of the stretch ids every merge)
 	if (side) (void)hipEventRecord(h->evx[1], h->st2);
 	return side; // true: the caller makes its stream wait for evx[1] before it reads the counters

@@ -2771,6 +2771,10 @@ __global__ void __launch_bounds__(256) k_lf_check(IdxView b1, const int64_t *pos
  * (k_lf_check keeps sampling every 4096th row for errors of the rank arithmetic itself).  One octet per walker and per event stretch:
  * text positions t + 1 -> t, rows kb = tw[t + 1] >> 3 and kbn = tw[t] >> 3, c = tw[t + 1] & 7:  pos[kbn] - kbn == C1[c] + rank_B1(c, pos[kb] - kb)
  * (fm-index.c:171-173).  nchecked[1] counts failures (with k_lf_check's), *njunc the junctions looked at. */
+#ifndef RB3_JUNC_UNROLL
+#define RB3_JUNC_UNROLL 1 /* (measured, round 6: 2 / 4 / 8 junctions at a time finish the check sooner and cost the rebuild beside it more than that -- rebuild 44 -> 47 / 47.5 / 52 ms per
+                             152-genome build, the whole build 167-169 -> 170-175 ms; a wider launch the same.  The check lives on latency nobody else wants.) */
+#endif
 __global__ void __launch_bounds__(256) k_junction_check(IdxView b1, const int64_t *pos, const uint64_t *tw, int64_t n2, const rb3_stretch_t *tab, const uint32_t *sidctr,
 		const int64_t *jmet, int64_t nwalk_arg, const unsigned long long *nwalk_dev, unsigned long long *bad, unsigned long long *nchecked, unsigned long long *njunc,
 		int ev_stride, int ev_phase)
@@ -2782,34 +2786,61 @@ __global__ void __launch_bounds__(256) k_junction_check(IdxView b1, const int64_
 	const int64_t nev = (int64_t)(sidctr[0] < (uint32_t)RB3_TENT_HALF ? sidctr[0] : (uint32_t)RB3_TENT_HALF); // events only happen to ids from blocks
 	const int64_t nq = nwalk + (nev - ev_phase + ev_stride - 1) / ev_stride;
 	unsigned long long nfail = 0, nseen = 0;
-	for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; q < nq; q += ((int64_t)gridDim.x * blockDim.x) >> 3) {
-		int64_t t; // the junction lies between text positions t + 1 and t
-		if (q < nwalk) {
-			t = jmet[q] - 1;
-		} else {
-			const int64_t sid = (q - nwalk) * ev_stride + ev_phase;
-			if (sid >= nev) continue;
-			const uint64_t w0 = tab[sid].w0;
-			if (w0 >> 62 != RB3_DEP_EVENT) continue;
-			t = (int64_t)(tab[sid].w1 >> RB3_EV_TP_SHIFT) - 1; // noted at text position tp: the new stretch begins at tp - 1
-		}
-		if (t < 0 || t + 1 >= n2) continue;
-		const uint64_t xa = tw[t + 1], xb = tw[t];
-		const int c = (int)(xa & 7u);
-		if (c == 0) continue; // position t + 1 starts a string: nothing leads from it to t
-		const int64_t kb = (int64_t)(xa >> 3), kbn = (int64_t)(xb >> 3);
-		bool ok = kb < n2 && kbn < n2;
-		if (ok) {
-			const int64_t ka = pos[kb] - kb, kan = pos[kbn] - kbn;
-			ok = ka >= 0 && ka <= b1.n && c <= 5;
-			if (ok) {
-				RankLoad rl;
-				oct_rank_issue(b1, ka, j, rl);
-				ok = oct_rank_finish(rl, c, j, b1.abs) == kan;
+	// U junctions per octet and iteration, their loads asked for stage by stage (event record -> text words -> the two rows -> directory -> slot): a junction is a
+	// chain of five round trips, and with one at a time 16 k octets needed ~350 us for the 1.2 M events of a late merge of the 152-genome build -- as long as the
+	// rebuild they run beside (round 6: all events are looked at, not every 16th)
+	constexpr int U = RB3_JUNC_UNROLL;
+	const int64_t noct = ((int64_t)gridDim.x * blockDim.x) >> 3;
+	for (int64_t q0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; q0 < nq; q0 += noct * U) {
+		int64_t t[U], kb[U], kbn[U], ka[U], kan[U];
+		uint64_t w0[U], w1[U], xa[U], xb[U];
+		RankLoad rl[U];
+		bool live[U], ok[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) { // (junction q0 + u noct: the octets of a wave stay on neighbouring entries)
+			const int64_t q = q0 + (int64_t)u * noct;
+			live[u] = q < nq, t[u] = -1, w0[u] = 0, w1[u] = 0;
+			if (live[u] && q < nwalk) t[u] = jmet[q] - 1;
+			else if (live[u]) {
+				const int64_t sid = (q - nwalk) * ev_stride + ev_phase;
+				live[u] = sid < nev;
+				if (live[u]) { const ulonglong2 v = *(const ulonglong2*)&tab[sid].w0; w0[u] = v.x, w1[u] = v.y; }
 			}
 		}
-		++nseen;
-		if (!ok) ++nfail;
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int64_t q = q0 + (int64_t)u * noct;
+			if (live[u] && q >= nwalk) {
+				live[u] = w0[u] >> 62 == RB3_DEP_EVENT;
+				t[u] = (int64_t)(w1[u] >> RB3_EV_TP_SHIFT) - 1; // noted at text position tp: the new stretch begins at tp - 1
+			}
+			live[u] = live[u] && t[u] >= 0 && t[u] + 1 < n2;
+			xa[u] = xb[u] = 0;
+			if (live[u]) xa[u] = tw[t[u] + 1], xb[u] = tw[t[u]];
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			live[u] = live[u] && (xa[u] & 7u) != 0u; // (c == 0: position t + 1 starts a string: nothing leads from it to t)
+			kb[u] = (int64_t)(xa[u] >> 3), kbn[u] = (int64_t)(xb[u] >> 3);
+			ok[u] = kb[u] < n2 && kbn[u] < n2;
+			ka[u] = kan[u] = 0;
+			if (live[u] && ok[u]) ka[u] = pos[kb[u]] - kb[u], kan[u] = pos[kbn[u]] - kbn[u];
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			ok[u] = ok[u] && ka[u] >= 0 && ka[u] <= b1.n && (int)(xa[u] & 7u) <= 5;
+			oct_rank_issue_grp(b1, live[u] && ok[u] ? ka[u] : 0, j, rl[u]); // (a junction that is not looked at: a valid address, the result unused)
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			oct_rank_issue_slot(b1, j, rl[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int c = (int)(xa[u] & 7u);
+			const bool same = oct_rank_finish(rl[u], c >= 1 && c <= 5 ? c : 1, j, b1.abs) == kan[u];
+			if (live[u]) { ++nseen; if (!(ok[u] && same)) ++nfail; }
+		}
 	}
 	if (j == 0 && nfail) atomicAdd(nchecked + 1, nfail);
 	{ // ONE atomic per block for the count (every lane of an octet counted the same junctions; an atomic per wave -- 8 k of them on one word, ~12 ns

@@ -39,6 +39,12 @@ int64_t rb3sort_bytes(const rb3sort_ws *ws);
 int rb3sort_bwt(rb3sort_ws *ws, hipStream_t st, int64_t n, const uint8_t *d_text, uint8_t *d_bwt, int64_t step, int64_t *d_ckrow, int *rounds, uint64_t *d_tw, uint32_t *d_sa);
 /* the FMD packer lives in rb3gpu_fmdenc.hip */
 int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words);
+struct rb3fmd_enc;
+int rb3fmd_enc_begin(hipStream_t st, int64_t n_sym, int64_t cap_runs, rb3fmd_enc **e);
+uint64_t *rb3fmd_enc_buffer(rb3fmd_enc *e, int64_t *room);
+int rb3fmd_enc_piece(rb3fmd_enc *e, int64_t n_new, int final);
+int rb3fmd_enc_end(rb3fmd_enc *e, uint64_t **z_out, int64_t *n_words);
+void rb3fmd_enc_abort(rb3fmd_enc *e);
 struct rb3fmd_dec;
 int rb3fmd_decode_begin(hipStream_t st, int64_t n_words, const uint64_t *d_z, rb3fmd_dec **ctx, int64_t *n_sym);
 int rb3fmd_decode_fill(rb3fmd_dec *ctx, uint8_t *d_plain);
@@ -130,6 +136,7 @@ struct Tune {
 	int b2_tw = 1;           // a batch that comes as its BWT only (the reference's signature) gets its text-order words from its own sparse LF walk and is merged like one that came with them (round 6); 0: walkers over row words (rounds 2-5)
 	int vmm_reserve = 0;     // (tests) MB of address space a new range reserves instead of 32 x its size (at least 16 GB)
 	int defer_free = 1;      // keep replaced buffers on a list and hipFree them in bulk (0: at once; hipFree waits for every stream of the device)
+	int64_t fmd_piece = 0;   // runs the FMD packer takes at a time (0: 64 M; rb3gpu_export_fmd_words)
 	int sh_host_rounds = 0;  // rb3gpu_sh_merge with ONE interval: the host reads the split sizes back after every round, as with several (0: the rounds run back to back on the device)
 	int sh_block = 0;        // threads per block of k_sh_round at eight states per octet: 256 or 1024; 0: 1024 below 3 M chains
 	int sh_states = 0;       // states per octet of k_sh_round (1, 2, 4, 8); 0: by the number of chains
@@ -616,6 +623,7 @@ static int tune_set(rb3gpu_t *h, const char *key, int64_t v)
 	else if (!strcmp(key, "guard")) t.guard = v != 0;
 	else if (!strcmp(key, "load_chunk")) t.load_chunk = v < 1 ? 1 : v;
 	else if (!strcmp(key, "lf_check")) t.lf_check = v < 0 ? 0 : v > (1 << 30) ? (1 << 30) : (int)v;
+	else if (!strcmp(key, "fmd_piece")) t.fmd_piece = v < 0 ? 0 : v;
 	else if (!strcmp(key, "sh_host_rounds")) t.sh_host_rounds = v < 0 ? -1 : v != 0; // (-1: rounds on the device whatever the number of chains)
 	else if (!strcmp(key, "ev_blocks")) t.ev_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
 	else if (!strcmp(key, "cum_blocks")) t.cum_blocks = v < 1 ? 1 : v > 65536 ? 65536 : (int)v;
@@ -653,7 +661,7 @@ int rb3gpu_tune(rb3gpu_t *h, const char *key, int64_t value)
 
 static void tune_from_env(rb3gpu_t *h) // once per handle
 {
-	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "abs_table", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "load_chunk", "log_alloc", "defer_free", "vmm", "vmm_reserve", "b2_tw", "poison", "guard",
+	static const char *keys[] = { "tent", "staged", "group_rebuild", "window_rebuild", "plane_rebuild", "reb_t1_rows", "part", "scan_place", "reb_force", "resolve_v1", "octs", "lpw", "blkmul", "blkcap", "chain_bs", "lf_after", "copy_walkers", "tent_q", "trec", "abs_limit", "abs_table", "ssa_split", "b2_split", "lf_check", "junction_check", "sh_block", "sh_states", "ev_blocks", "cum_blocks", "resw_blocks", "sfin_blocks", "sh_host_rounds", "fmd_piece", "load_chunk", "log_alloc", "defer_free", "vmm", "vmm_reserve", "b2_tw", "poison", "guard",
 		"force_fallback", "hide_first", "tent_limit", "text_mode", "corrupt_pos", "corrupt_sfin", "reb_lcap", "reb_slot_cap", "pos_limit", "win_scratch", "slot_bytes", nullptr };
 	for (int i = 0; keys[i]; ++i) {
 		char name[64] = "RB3GPU_";
@@ -3054,20 +3062,29 @@ int rb3gpu_export_run_words(rb3gpu_t *h, rb3gpu_emit_words_f emit, void *data)
 	return ret;
 }
 
+/* column 0 of the scan's 8-word records (the runs before every group), one word per group, and the total behind them */
+__global__ void __launch_bounds__(256) k_runs_before(const uint64_t *off8, int64_t ngrp, uint64_t total, uint64_t *out)
+{
+	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g <= ngrp) out[g] = g < ngrp ? off8[g * 8] : total;
+}
+
+/* The FMD word stream of the index, packed on the device A PIECE OF THE RUNS AT A TIME (rb3gpu_fmdenc.hip, rb3fmd_enc_*; round 6): the runs of as many groups as
+ * make `piece` runs are written behind what the packer carried over from the piece before, packed, and their words go to the host.  Device memory: 34 bytes per
+ * run of a PIECE (64 M runs by default: 2.2 GB; rb3gpu_tune "fmd_piece"), not of the index -- 4.99 G runs of four human haplotypes held 40 GB of run starts and
+ * ~130 GB of tables in one piece. */
 int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
 {
 	if (!h || !words || !n_words) return RB3GPU_EINVAL;
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->grp == nullptr) return RB3GPU_ESTATE;
 	const double t = now_s();
-	const int64_t nwin = (h->n + RB3_WIN - 1) >> RB3_WIN_BITS;
 	const IdxView iv = view_of(h);
 	int r;
 	*words = nullptr, *n_words = 0;
-	// the run starts of the whole index, resident: count per window, scan, emit
+	// the run starts of every group: count, scan
 	if ((r = buf_ensure(h, h->misc, MISC_WORDS * 8)) < 0) return r;
 	const int64_t ngrp = (h->n + RB3_GRP - 1) >> RB3_GRP_BITS;
-	(void)nwin;
 	if ((r = buf_ensure(h, h->gstat, (size_t)ngrp * 32)) < 0) return r;
 	if ((r = buf_ensure(h, h->gpre, (size_t)ngrp * 64)) < 0) return r;
 	uint32_t *cnt8 = (uint32_t*)h->gstat.p;
@@ -3077,9 +3094,13 @@ int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
 	if ((r = scan_records(h, cnt8, ngrp, off8, (uint64_t*)h->misc.p + MISC_IX_TOT, total)) < 0) return r;
 	const int64_t nr = (int64_t)total[0];
 	if (nr <= 0) return RB3GPU_EINTERNAL;
-	{ // the packer holds ~26 bytes per run beside the run starts (8): where that does not fit beside the merge scratch of the handle, the scratch goes (the next merge obtains it again)
+	int64_t piece = h->tn.fmd_piece > 0 ? h->tn.fmd_piece : ((int64_t)64 << 20);
+	if (piece < 32768) piece = 32768; // (a piece must hold a few chunks of the packer's speculation -- rb3fmd_enc_piece --, and it ends with a whole group: up to 8192 runs short)
+	const bool one = nr <= piece;
+	const int64_t cap = one ? nr + 16 : piece + RB3_GRP + 8192 + 1024; // (a piece ends with a whole group: at most 8192 runs more; + what the packer carries over)
+	{ // the packer holds ~26 bytes per run of a piece beside the run starts (8): where that does not fit beside the merge scratch of the handle, the scratch goes (the next merge obtains it again)
 		size_t fr = 0, tot = 0;
-		if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)nr * 34 > fr && !h->mg_active) { // (not inside a two-phase merge: its uncommitted index lives in the spare buffers)
+		if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)cap * 34 + ((size_t)64 << 20) > fr && !h->mg_active) { // (not inside a two-phase merge: its uncommitted index lives in the spare buffers)
 			HIPCHK(hipStreamSynchronize(h->st));
 			Buf *scratch[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->jg, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->shc, &h->shn, &h->shs, &h->shr };
 			for (Buf *b : scratch) buf_release(h, *b);
@@ -3089,19 +3110,45 @@ int rb3gpu_export_fmd_words(rb3gpu_t *h, uint64_t **words, int64_t *n_words)
 			if (h->opt.verbose >= 3) fprintf(stderr, "[M::%s::%.3f] %lld runs: the merge scratch of the handle released for the packer's tables\n", __func__, now_s() - h->t0, (long long)nr);
 		} else (void)hipGetLastError();
 	}
-	if ((r = buf_ensure(h, h->xbuf, (size_t)nr * 8)) < 0) return r;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<true>), grid, blk, 0, h->st, iv, (int64_t)0, ngrp, cnt8, (const uint64_t*)off8, (uint64_t*)h->xbuf.p);
-	r = rb3fmd_encode(h->st, h->n, nr, (const uint64_t*)h->xbuf.p, words, n_words);
-	if (r == -1 && !h->garbage.empty()) { // no room for the packer's tables while replaced buffers are still held
+	rb3fmd_enc *enc = nullptr;
+	int fr = rb3fmd_enc_begin(h->st, h->n, cap, &enc);
+	if (fr == -1 && !h->garbage.empty()) { // no room for the packer's tables while replaced buffers are still held
 		(void)hipGetLastError();
 		garbage_collect(h, true);
-		r = rb3fmd_encode(h->st, h->n, nr, (const uint64_t*)h->xbuf.p, words, n_words);
+		fr = rb3fmd_enc_begin(h->st, h->n, cap, &enc);
 	}
+	int64_t npieces = 0;
+	if (fr == 0 && one) {
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<true>), grid, blk, 0, h->st, iv, (int64_t)0, ngrp, cnt8, (const uint64_t*)off8, rb3fmd_enc_buffer(enc, nullptr));
+		fr = rb3fmd_enc_piece(enc, nr, 1), npieces = 1;
+	} else if (fr == 0) {
+		std::vector<uint64_t> before((size_t)ngrp + 1);
+		if ((r = buf_ensure(h, h->xbuf, (size_t)(ngrp + 1) * 8)) < 0) { rb3fmd_enc_abort(enc); return r; }
+		hipLaunchKernelGGL(k_runs_before, dim3((unsigned)((ngrp + 1 + 255) / 256)), dim3(256), 0, h->st, (const uint64_t*)off8, ngrp, (uint64_t)nr, (uint64_t*)h->xbuf.p);
+		if (hipMemcpyAsync(before.data(), h->xbuf.p, (size_t)(ngrp + 1) * 8, hipMemcpyDeviceToHost, h->st) != hipSuccess || hipStreamSynchronize(h->st) != hipSuccess) { (void)hipGetLastError(); rb3fmd_enc_abort(enc); return RB3GPU_ENODEV; }
+		for (int64_t ga = 0; ga < ngrp && fr == 0; ++npieces) {
+			int64_t room = 0;
+			uint64_t *dst = rb3fmd_enc_buffer(enc, &room);
+			if (room > piece + RB3_GRP) room = piece + RB3_GRP;
+			// the groups [ga, gb) hold at most `room` runs and, if they can, at least `piece` of them
+			int64_t lo = ga + 1, hi = ngrp;
+			while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if ((int64_t)(before[(size_t)mid] - before[(size_t)ga]) <= room - RB3_GRP) lo = mid; else hi = mid - 1; }
+			const int64_t gb = lo, nn = (int64_t)(before[(size_t)gb] - before[(size_t)ga]);
+			if (nn > room) { fr = -3; break; }
+			if (nn > 0)
+				hipLaunchKernelGGL(HIP_KERNEL_NAME(k_export_runs_g<true>), dim3((unsigned)((gb - ga + 3) / 4)), blk, 0, h->st, iv, ga, gb - ga, cnt8 + ga * 8, (const uint64_t*)(off8 + ga * 8), dst - before[(size_t)ga]);
+			fr = rb3fmd_enc_piece(enc, nn, gb == ngrp ? 1 : 0);
+			ga = gb;
+		}
+	}
+	if (fr == 0) fr = rb3fmd_enc_end(enc, words, n_words), enc = nullptr;
+	if (enc) rb3fmd_enc_abort(enc);
+	(void)hipGetLastError();
 	h->stt.ms_export += (now_s() - t) * 1e3;
-	if (r == 1) return RB3GPU_EUNSUP;
-	if (r < 0) return r == -1 ? RB3GPU_ENOMEM : r == -2 ? RB3GPU_ENODEV : RB3GPU_EINTERNAL;
+	if (fr == 1) return RB3GPU_EUNSUP;
+	if (fr < 0) return fr == -1 ? RB3GPU_ENOMEM : fr == -2 ? RB3GPU_ENODEV : RB3GPU_EINTERNAL;
 	if (h->opt.verbose >= 3)
-		fprintf(stderr, "[M::%s::%.3f] packed %lld runs into %lld FMD words on the GPU in %.3f ms\n", __func__, now_s() - h->t0, (long long)nr, (long long)*n_words, (now_s() - t) * 1e3);
+		fprintf(stderr, "[M::%s::%.3f] packed %lld runs into %lld FMD words on the GPU in %.3f ms (%lld piece%s)\n", __func__, now_s() - h->t0, (long long)nr, (long long)*n_words, (now_s() - t) * 1e3, (long long)npieces, npieces == 1 ? "" : "s");
 	return 0;
 }
 

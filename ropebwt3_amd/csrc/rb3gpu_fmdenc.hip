@@ -148,14 +148,17 @@ __global__ void k_fe_special(const uint64_t *P, const uint64_t *words, int64_t n
 	out[1] = ty;
 }
 
-/* one thread per block (and one more for the trailing header-only block, rld0.c:206-216) */
-__global__ void __launch_bounds__(256) k_fe_pack(const uint64_t *words, int64_t nr, int64_t n_sym, const int64_t *bs, int64_t B, uint64_t *out, unsigned int *flag, unsigned int *tail)
+/* one thread per block: thread t < nfull packs block b0 + t (its header from the runs of the block before it: bs[b - 1] .. bs[b], none for the very
+ * first block of the stream -- two equal starts), thread nfull -- if `trailing` -- writes the header-only block behind the data (rld0.c:206-216).
+ * Block numbers are those of the PIECE at hand (rb3fmd_enc_piece): out[8 t ..] is the t-th block written. */
+__global__ void __launch_bounds__(256) k_fe_pack(const uint64_t *words, int64_t nr, int64_t n_sym, const int64_t *bs, int64_t b0, int64_t nfull, int trailing, uint64_t *out, unsigned int *flag, unsigned int *tail)
 {
-	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (b > B) return;
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > nfull || (t == nfull && !trailing)) return;
+	const int64_t b = b0 + t;
 	uint64_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int type = 0;
-	if (b > 0) { // header: what the block before contained (rld0.c:116-128), 7 x uint16 or 7 x uint32
+	{ // header: what the block before contained (rld0.c:116-128), 7 x uint16 or 7 x uint32
 		uint64_t c[7] = {0, 0, 0, 0, 0, 0, 0};
 		for (int64_t i = bs[b - 1]; i < bs[b]; ++i) {
 			const int64_t s = (int64_t)(words[i] >> 3), e = i + 1 < nr ? (int64_t)(words[i + 1] >> 3) : n_sym;
@@ -172,8 +175,8 @@ __global__ void __launch_bounds__(256) k_fe_pack(const uint64_t *words, int64_t 
 			z[0] |= 1ull << 62;
 		}
 	}
-	if (b == B) { // the trailing header-only block (rld0.c:206-216): its header words
-		for (int q = 0; q < (type ? 4 : 2); ++q) out[8 * b + q] = z[q];
+	if (t == nfull) { // the trailing header-only block (rld0.c:206-216): its header words
+		for (int q = 0; q < (type ? 4 : 2); ++q) out[8 * t + q] = z[q];
 		if (type) tail[0] = 4;
 		return;
 	}
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(256) k_fe_pack(const uint64_t *words, int64_t 
 		}
 	}
 #pragma unroll
-	for (int q = 0; q < 8; ++q) out[8 * b + q] = z[q];
+	for (int q = 0; q < 8; ++q) out[8 * t + q] = z[q];
 }
 
 /* d_words: nr words start << 3 | sym of the maximal runs of a BWT of n_sym symbols (device).  On success (0) *z_out is
@@ -239,123 +242,233 @@ static int fe_scan_widths(hipStream_t st, void *tmp, size_t tb, const uint8_t *w
 
 static double fe_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 
-int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words)
+/* THE PACKER AS A STREAM (round 6, last session).  rb3fmd_encode held the run starts of the WHOLE index (8 bytes per run) and ~26 bytes per run of tables beside
+ * them: 4.99 G runs of four human haplotypes = 40 + 130 GB around an index of 12.6 GB, and a build at the full size of BASELINE configs[3] / [4] would have gone to
+ * the host's encoder (ten minutes per 8 GB on one core).  Where a block ends only depends on where it starts and on the runs behind that point, so the runs can
+ * come a PIECE at a time: the caller writes the next runs behind the ones the packer has carried over (rb3fmd_enc_buffer), rb3fmd_enc_piece packs every block that
+ * is complete inside the piece and keeps what is left -- the last complete block (the header of the next one counts its symbols), the block that has begun, the
+ * run whose end is not known yet: fewer than 2 FE_CHUNK runs -- for the next piece.  Inside a piece the run numbers and the block numbers are the piece's own
+ * (block 1 is the first block to pack, block 0 the one before it); only (header type, global block number) of the block at hand travel, the second for the
+ * superblocks' short last blocks.  A piece that is not the last looks to the kernels like a complete BWT that ends where its last run starts.
+ * Device memory: ~26 bytes per run of a PIECE, whatever the index holds.  rb3fmd_encode is one final piece. */
+#define FE_CARRY_MAX (2 * FE_CHUNK + 512)
+#define FE_PIECE_MIN (2 * FE_CHUNK + 256) /* runs of a piece that is not the last: the chain must get through a chunk (the block at hand begins in the first hundred runs) */
+
+struct rb3fmd_enc {
+	hipStream_t st;
+	int64_t n_sym, cap;             // symbols of the BWT; runs the buffers hold (carried + new)
+	uint64_t *w, *carry;            // run words of the piece (cap + 2); the ones carried over, on their way to the front
+	uint8_t *width, *E, *hE;
+	uint16_t *Cn, *hCn;
+	uint64_t *P, *out;
+	int64_t *bs, *lists, *scal, *hlists, Kcap, out_cap;
+	unsigned int *flag;
+	void *tmp;
+	size_t tb;
+	uint64_t *host;                 // the stream so far (malloc)
+	int64_t host_n, host_cap;
+	int64_t nc, o, gb;              // carried runs in front of w; the block at hand starts at run o (of w) and has global number gb ...
+	int oty, finished;              // ... and header type oty
+	int64_t pieces;
+};
+
+static void fe_enc_free(rb3fmd_enc *e)
+{
+	if (!e) return;
+	free(e->host); free(e->hE); free(e->hCn); free(e->hlists);
+	void *all[] = { e->w, e->carry, e->width, e->P, e->out, e->E, e->Cn, e->lists, e->bs, e->scal, e->flag, e->tmp };
+	for (void *p : all) if (p) (void)hipFree(p);
+	delete e;
+}
+
+/* cap_runs: the most runs a piece will hold (what the caller adds at a time + FE_CARRY_MAX).  0 / -1 (out of memory) / -2 / -3 */
+int rb3fmd_enc_begin(hipStream_t st, int64_t n_sym, int64_t cap_runs, rb3fmd_enc **out_e)
+{
+	*out_e = nullptr;
+	if (n_sym <= 0 || cap_runs <= 0) return -3;
+	rb3fmd_enc *e = new rb3fmd_enc;
+	memset(e, 0, sizeof(*e));
+	e->st = st, e->n_sym = n_sym, e->cap = cap_runs;
+	const int64_t K = (cap_runs + FE_CHUNK - 1) / FE_CHUNK + 1;
+	e->Kcap = K;
+	int ret = 0;
+	if (hipMalloc(&e->w, (size_t)(cap_runs + 2) * 8) != hipSuccess || hipMalloc(&e->carry, (size_t)FE_CARRY_MAX * 8) != hipSuccess || hipMalloc(&e->width, (size_t)cap_runs + 16) != hipSuccess ||
+		hipMalloc(&e->P, (size_t)(cap_runs + 2) * 8) != hipSuccess || hipMalloc(&e->bs, (size_t)(cap_runs + 4) * 8) != hipSuccess || hipMalloc(&e->E, (size_t)K * FE_ENTRIES * 2) != hipSuccess ||
+		hipMalloc(&e->Cn, (size_t)K * FE_ENTRIES * 4) != hipSuccess || hipMalloc(&e->lists, (size_t)(K + 1) * 24) != hipSuccess || hipMalloc(&e->scal, 64) != hipSuccess || hipMalloc(&e->flag, 16) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto fail; }
+	e->hE = (uint8_t*)malloc((size_t)K * FE_ENTRIES * 2), e->hCn = (uint16_t*)malloc((size_t)K * FE_ENTRIES * 4), e->hlists = (int64_t*)malloc((size_t)(K + 1) * 24);
+	if (!e->hE || !e->hCn || !e->hlists) { ret = -1; goto fail; }
+	if (rocprim::exclusive_scan(nullptr, e->tb, rocprim::make_transform_iterator(e->width, fe_widen()), e->P, (uint64_t)0, (size_t)(cap_runs + 1 < FE_SCAN_PIECE ? cap_runs + 1 : FE_SCAN_PIECE), rocprim::plus<uint64_t>(), st) != hipSuccess) { (void)hipGetLastError(); ret = -2; goto fail; }
+	e->tb += 256;
+	if (hipMalloc(&e->tmp, e->tb) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto fail; }
+	*out_e = e;
+	return 0;
+fail:
+	fe_enc_free(e);
+	return ret;
+}
+
+/* where the caller writes the next runs (device): behind the carried ones; *room = how many fit */
+uint64_t *rb3fmd_enc_buffer(rb3fmd_enc *e, int64_t *room)
+{
+	if (room) *room = e->cap - e->nc;
+	return e->w + e->nc;
+}
+
+void rb3fmd_enc_abort(rb3fmd_enc *e) { fe_enc_free(e); }
+
+/* the words so far become the caller's (malloc); everything else is freed.  Only after a final piece. */
+int rb3fmd_enc_end(rb3fmd_enc *e, uint64_t **z_out, int64_t *n_words)
+{
+	int ret = e->finished ? 0 : -3;
+	if (ret == 0) *z_out = e->host, *n_words = e->host_n, e->host = nullptr;
+	fe_enc_free(e);
+	return ret;
+}
+
+/* n_new runs have been written behind the carried ones; final: they are the last of the BWT.  0, 1 (a block needs a 64-bit header or a code 64 bits: the
+ * host's encoder writes such an index), < 0: -1 out of memory, -2 HIP error, -3 internal */
+int rb3fmd_enc_piece(rb3fmd_enc *e, int64_t n_new, int final)
 {
 	int ret = 0;
+	hipStream_t st = e->st;
+	const int64_t n = e->nc + n_new;
+	unsigned int hflag[4] = {0, 0, 0, 0};
+	int64_t o = e->o, gb0 = e->gb, cur = 0, gbp = 0, Bl = 0;
+	int oty = e->oty, cty = 0;
+	const int64_t gb_base = e->gb - 1; // the block that starts at run o is block 1 of the piece, the one before it (it starts at run 0 of the piece) block 0
+	bool ended = false;
 	const double fe_t0 = fe_now();
-	int64_t fe_iter = 0;
-	uint8_t *width = nullptr, *E = nullptr, *hE = nullptr;
-	uint16_t *Cn = nullptr, *hCn = nullptr;
-	uint64_t *P = nullptr, *out = nullptr, *host = nullptr;
-	int64_t *lists = nullptr, *hlists = nullptr, *bs = nullptr, *scal = nullptr;
-	unsigned int *flag = nullptr, hflag[4];
-	void *tmp = nullptr;
-	size_t tb = 0;
-	const int64_t K = (nr + FE_CHUNK - 1) / FE_CHUNK;
-	int64_t o = 0, gb0 = 0, B = 0;
-	int oty = 0; // header type of the block that starts at run o
-	*z_out = nullptr, *n_words = 0;
-	if (nr <= 0 || n_sym <= 0) return -3;
-	if (hipMalloc(&width, (size_t)nr + 16) != hipSuccess || hipMalloc(&P, (size_t)(nr + 1) * 8) != hipSuccess || hipMalloc(&bs, (size_t)(nr + 2) * 8) != hipSuccess ||
-		hipMalloc(&E, (size_t)K * FE_ENTRIES * 2) != hipSuccess || hipMalloc(&Cn, (size_t)K * FE_ENTRIES * 4) != hipSuccess || hipMalloc(&lists, (size_t)(K + 1) * 24) != hipSuccess ||
-		hipMalloc(&scal, 64) != hipSuccess || hipMalloc(&flag, 16) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
-	hE = (uint8_t*)malloc((size_t)K * FE_ENTRIES * 2), hCn = (uint16_t*)malloc((size_t)K * FE_ENTRIES * 4), hlists = (int64_t*)malloc((size_t)(K + 1) * 24);
-	if (!hE || !hCn || !hlists) { ret = -1; goto done; }
-	FE_HIP(rocprim::exclusive_scan(nullptr, tb, rocprim::make_transform_iterator(width, fe_widen()), P, (uint64_t)0, (size_t)(nr + 1 < FE_SCAN_PIECE ? nr + 1 : FE_SCAN_PIECE), rocprim::plus<uint64_t>(), st));
-	tb += 256;
-	if (hipMalloc(&tmp, tb) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
-	FE_HIP(hipMemsetAsync(flag, 0, 16, st));
-	hipLaunchKernelGGL(k_fe_width, FE_GRID_LOOP(nr + 1), d_words, nr, n_sym, width, flag);
-	if ((K * FE_ENTRIES * 2 + 255) / 256 >= ((int64_t)1 << 32) / 256 || nr >= ((int64_t)1 << 36)) { ret = 1; goto done; } // (the table kernel's thread per entry: 2^36 runs and more go to the host's encoder)
-	if (fe_scan_widths(st, tmp, tb, width, P, nr + 1) < 0) { (void)hipGetLastError(); ret = -2; goto done; }
-	if (fmd_debug()) {
-		unsigned long long hb[2] = { 0ull, ~0ull }, *db = nullptr;
-		unsigned int hf = 0;
-		if (hipMalloc(&db, 16) == hipSuccess) {
-			(void)hipMemcpyAsync(db, hb, 16, hipMemcpyHostToDevice, st);
-			hipLaunchKernelGGL(k_fe_check_scan, dim3(8192), dim3(256), 0, st, (const uint8_t*)width, (const uint64_t*)P, nr + 1, db);
-			(void)hipMemcpyAsync(hb, db, 16, hipMemcpyDeviceToHost, st);
-			(void)hipMemcpyAsync(&hf, flag, 4, hipMemcpyDeviceToHost, st);
-			(void)hipStreamSynchronize(st);
-			(void)hipFree(db);
-			fprintf(stderr, "[fmdenc] %lld runs, %lld symbols: %llu of the bit offsets are not the running sum of the widths (first at run %lld); width flags %u\n", (long long)nr, (long long)n_sym, hb[0], (long long)hb[1], hf);
-		}
+	if (e->finished || n_new < 0 || n > e->cap || n <= 0 || (!final && n < FE_PIECE_MIN)) return -3;
+	const int64_t nr = final ? n : n - 1; // (the end of the last run of a piece that is not the last is not known yet: the run waits for the next piece)
+	int64_t n_sym = e->n_sym;
+	if (!final) {
+		uint64_t lastw = 0;
+		if (hipMemcpyAsync(&lastw, e->w + n - 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return -2; }
+		n_sym = (int64_t)(lastw >> 3);
 	}
-	hipLaunchKernelGGL(k_fe_table, FE_GRID(K * FE_ENTRIES * 2), K, nr, n_sym, (const uint64_t*)P, d_words, E, Cn, flag);
-	FE_HIP(hipMemcpyAsync(hE, E, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
-	FE_HIP(hipMemcpyAsync(hCn, Cn, (size_t)K * FE_ENTRIES * 4, hipMemcpyDeviceToHost, st));
+	const int64_t K = (nr + FE_CHUNK - 1) / FE_CHUNK;
+	const int64_t k_stop = final ? K : (nr - FE_ENTRIES) / FE_CHUNK; // chunks 0 .. k_stop-1 end at least FE_ENTRIES runs in front of the piece's end: the chain that leaves them is still inside
+	const uint64_t *d_words = e->w, *P = e->P;
+	int64_t *bs = e->bs, *lists = e->lists, *hlists = e->hlists, *scal = e->scal;
+	unsigned int *flag = e->flag;
+	if (K > e->Kcap || (!final && k_stop < 1)) return -3;
+	++e->pieces;
+	FE_HIP(hipMemsetAsync(flag, 0, 16, st));
+	FE_HIP(hipMemsetAsync(bs, 0, 8, st)); // block 0 starts at run 0
+	hipLaunchKernelGGL(k_fe_width, FE_GRID_LOOP(nr + 1), d_words, nr, n_sym, e->width, flag);
+	if (fe_scan_widths(st, e->tmp, e->tb, e->width, e->P, nr + 1) < 0) { (void)hipGetLastError(); ret = -2; goto done; }
+	hipLaunchKernelGGL(k_fe_table, FE_GRID(K * FE_ENTRIES * 2), K, nr, n_sym, P, d_words, e->E, e->Cn, flag);
+	FE_HIP(hipMemcpyAsync(e->hE, e->E, (size_t)K * FE_ENTRIES * 2, hipMemcpyDeviceToHost, st));
+	FE_HIP(hipMemcpyAsync(e->hCn, e->Cn, (size_t)K * FE_ENTRIES * 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipMemcpyAsync(hflag, flag, 4, hipMemcpyDeviceToHost, st));
 	FE_HIP(hipStreamSynchronize(st));
 	if (hflag[0] & 1u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] a code of 64 bits or more\n"); ret = 1; goto done; }
-	if (fmd_debug()) fprintf(stderr, "[fmdenc] tables of %lld chunks on the host after %.3f s\n", (long long)K, fe_now() - fe_t0);
 	// the chain, one superblock at a time: the host walks the chunk tables
 	for (;;) {
-		if (fmd_debug() && (fe_iter < 4 || (fe_iter & 15) == 0)) fprintf(stderr, "[fmdenc] superblock %lld: run %lld of %lld, block %lld, %.3f s\n", (long long)fe_iter, (long long)o, (long long)nr, (long long)gb0, fe_now() - fe_t0);
-		++fe_iter;
-		const int64_t s = gb0 | (FE_SB_BLOCKS - 1); // global index of this superblock's last block
+		const int64_t s = gb0 | (FE_SB_BLOCKS - 1); // global number of this superblock's last block
 		const int64_t k0 = o / FE_CHUNK;
-		int64_t *ids = hlists, *ent = hlists + (K + 1), *bas = hlists + 2 * (K + 1), nl = 0, c1[3];
-		hipLaunchKernelGGL(k_fe_chain1, dim3(1), dim3(1), 0, st, o, oty, (k0 + 1) * FE_CHUNK < nr ? (k0 + 1) * FE_CHUNK : nr, nr, n_sym, (const uint64_t*)P, d_words, scal);
+		if (!final && k0 >= k_stop) { cur = o, cty = oty, gbp = gb0; break; } // (the block at hand begins too close to the piece's end: it waits)
+		int64_t *ids = hlists, *ent = hlists + (e->Kcap + 1), *bas = hlists + 2 * (e->Kcap + 1), nl = 0, c1[3];
+		hipLaunchKernelGGL(k_fe_chain1, dim3(1), dim3(1), 0, st, o, oty, (k0 + 1) * FE_CHUNK < nr ? (k0 + 1) * FE_CHUNK : nr, nr, n_sym, P, d_words, scal);
 		FE_HIP(hipMemcpyAsync(c1, scal, 24, hipMemcpyDeviceToHost, st));
 		FE_HIP(hipStreamSynchronize(st));
-		ids[nl] = k0, ent[nl] = o << 1 | oty, bas[nl] = gb0, ++nl;
-		int64_t cur = c1[0], gb = gb0 + c1[1]; // the block that starts at run cur has global index gb
-		int cty = (int)c1[2];
-		for (int64_t k = k0 + 1; cur < nr && gb <= s; ++k) {
+		ids[nl] = k0, ent[nl] = o << 1 | oty, bas[nl] = gb0 - gb_base, ++nl;
+		int64_t gb = gb0 + c1[1]; // the block that starts at run cur has global number gb
+		cur = c1[0], cty = (int)c1[2];
+		for (int64_t k = k0 + 1; cur < nr && gb <= s && (final || k < k_stop); ++k) {
 			const int64_t d = cur - k * FE_CHUNK;
 			if (d < 0 || d >= FE_ENTRIES) { if (fmd_debug()) fprintf(stderr, "[fmdenc] the chain left its chunk: run %lld in chunk %lld of %lld (block %lld)\n", (long long)cur, (long long)k, (long long)K, (long long)gb); ret = -3; goto done; }
-			ids[nl] = k, ent[nl] = cur << 1 | cty, bas[nl] = gb, ++nl;
+			ids[nl] = k, ent[nl] = cur << 1 | cty, bas[nl] = gb - gb_base, ++nl;
 			const int64_t te = (k * FE_ENTRIES + d) * 2 + cty;
-			gb += hCn[te];
-			cur = ((k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr) + (hE[te] & 0x7F);
-			cty = hE[te] >> 7;
+			gb += e->hCn[te];
+			cur = ((k + 1) * FE_CHUNK < nr ? (k + 1) * FE_CHUNK : nr) + (e->hE[te] & 0x7F);
+			cty = e->hE[te] >> 7;
 		}
 		FE_HIP(hipMemcpyAsync(lists, ids, (size_t)nl * 8, hipMemcpyHostToDevice, st));
-		FE_HIP(hipMemcpyAsync(lists + (K + 1), ent, (size_t)nl * 8, hipMemcpyHostToDevice, st));
-		FE_HIP(hipMemcpyAsync(lists + 2 * (K + 1), bas, (size_t)nl * 8, hipMemcpyHostToDevice, st));
-		hipLaunchKernelGGL(k_fe_emit, FE_GRID(nl), nl, (const int64_t*)lists, (const int64_t*)(lists + (K + 1)), (const int64_t*)(lists + 2 * (K + 1)), nr, n_sym, (const uint64_t*)P, d_words, s, bs, flag);
-		if (gb <= s) { if (fmd_debug()) fprintf(stderr, "[fmdenc] the data end in superblock %lld: block %lld <= %lld, run %lld, %lld chunks listed\n", (long long)fe_iter, (long long)gb, (long long)s, (long long)cur, (long long)nl); B = gb; FE_HIP(hipStreamSynchronize(st)); break; } // the data end before this superblock does
-		hipLaunchKernelGGL(k_fe_special, dim3(1), dim3(1), 0, st, (const uint64_t*)P, d_words, nr, n_sym, (const int64_t*)bs, s, scal, flag);
+		FE_HIP(hipMemcpyAsync(lists + (e->Kcap + 1), ent, (size_t)nl * 8, hipMemcpyHostToDevice, st));
+		FE_HIP(hipMemcpyAsync(lists + 2 * (e->Kcap + 1), bas, (size_t)nl * 8, hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_fe_emit, FE_GRID(nl), nl, (const int64_t*)lists, (const int64_t*)(lists + (e->Kcap + 1)), (const int64_t*)(lists + 2 * (e->Kcap + 1)), nr, n_sym, P, d_words, s - gb_base, bs, flag);
+		FE_HIP(hipStreamSynchronize(st)); // (the host's lists are rewritten by the next superblock)
+		if (gb <= s) { // the superblock goes on behind this piece -- or the data end in it
+			gbp = gb;
+			ended = final && cur >= nr;
+			if (!ended && final) { ret = -3; goto done; }
+			break;
+		}
+		hipLaunchKernelGGL(k_fe_special, dim3(1), dim3(1), 0, st, P, d_words, nr, n_sym, (const int64_t*)bs, s - gb_base, scal, flag);
 		{
 			int64_t sp[2];
 			FE_HIP(hipMemcpyAsync(sp, scal, 16, hipMemcpyDeviceToHost, st));
 			FE_HIP(hipStreamSynchronize(st));
 			o = sp[0], oty = (int)sp[1];
-			if (fmd_debug() && o >= nr) {
-				int64_t hb2[2] = {0, 0};
-				(void)hipMemcpy(hb2, bs + s - 1, 16, hipMemcpyDeviceToHost);
-				fprintf(stderr, "[fmdenc] superblock %lld ends the data: next run %lld >= %lld; its last block %lld starts at run %lld, the one before at %lld; chain had reached run %lld, block %lld\n", (long long)fe_iter, (long long)o, (long long)nr, (long long)s, (long long)hb2[1], (long long)hb2[0], (long long)cur, (long long)gb);
-			}
 		}
 		gb0 = s + 1;
-		if (o >= nr) { B = gb0; break; }
+		if (o >= nr) {
+			if (!final) { ret = -3; goto done; } // (cannot be: the last block of a superblock began in a chunk that ends FE_ENTRIES runs in front of the piece's end)
+			gbp = gb0, cur = nr, ended = true;
+			break;
+		}
 	}
+	Bl = gbp - gb_base; // the piece's number of the block that starts at `cur`: behind the data (final), or the one that waits for the next piece
+	if (Bl < 1 || (!ended && Bl < 2)) { if (fmd_debug()) fprintf(stderr, "[fmdenc] piece %lld of %lld runs: no block completed\n", (long long)e->pieces, (long long)n); ret = -3; goto done; }
 	{
-		const int64_t nrv = nr;
-		FE_HIP(hipMemcpyAsync(bs + B, &nrv, 8, hipMemcpyHostToDevice, st));
+		const int64_t endrun = ended ? nr : cur;
+		FE_HIP(hipMemcpyAsync(bs + Bl, &endrun, 8, hipMemcpyHostToDevice, st));
 		FE_HIP(hipStreamSynchronize(st));
 	}
-	if (fmd_debug()) fprintf(stderr, "[fmdenc] %lld blocks in %lld superblocks after %.3f s\n", (long long)B, (long long)fe_iter, fe_now() - fe_t0);
-	if (hipMalloc(&out, (size_t)(8 * B + 8) * 8) != hipSuccess) { (void)hipGetLastError(); ret = -1; goto done; }
-	hipLaunchKernelGGL(k_fe_pack, FE_GRID(B + 1), d_words, nr, n_sym, (const int64_t*)bs, B, out, flag, flag + 1);
-	FE_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, st));
-	FE_HIP(hipStreamSynchronize(st));
-	if (hflag[0] & 11u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a 64-bit header\n", hflag[0]); ret = 1; goto done; } // (not produced here: the host's encoder writes such an index)
-	if (hflag[0] & 4u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: the packer met a block it cannot write\n", hflag[0]); ret = -3; goto done; }
-	if (hflag[0] & 11u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a 64-bit header\n", hflag[0]); ret = 1; goto done; }
 	{
-		const int64_t tailw = hflag[1] == 4u ? 4 : 2; // header words of the trailing header-only block (rld0.c:211)
-		if ((host = (uint64_t*)malloc((size_t)(8 * B + 8) * 8)) == nullptr) { ret = -1; goto done; }
-		FE_HIP(hipMemcpy(host, out, (size_t)(8 * B + tailw) * 8, hipMemcpyDeviceToHost));
-		*z_out = host, *n_words = 8 * B + tailw, host = nullptr;
+		const int64_t nfull = Bl - 1; // blocks 1 .. Bl-1 are complete
+		if (8 * (nfull + 1) + 8 > e->out_cap) {
+			if (e->out) (void)hipFree(e->out);
+			e->out = nullptr, e->out_cap = 8 * (nfull + 1) + 8 + (nfull >> 2) * 8;
+			if (hipMalloc(&e->out, (size_t)e->out_cap * 8) != hipSuccess) { (void)hipGetLastError(); e->out_cap = 0; ret = -1; goto done; }
+		}
+		hipLaunchKernelGGL(k_fe_pack, FE_GRID(nfull + 1), d_words, nr, n_sym, (const int64_t*)bs, (int64_t)1, nfull, ended ? 1 : 0, e->out, flag, flag + 1);
+		FE_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, st));
+		FE_HIP(hipStreamSynchronize(st));
+		if (hflag[0] & 11u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: a block needs a 64-bit header\n", hflag[0]); ret = 1; goto done; } // (not produced here: the host's encoder writes such an index)
+		if (hflag[0] & 4u) { if (fmd_debug()) fprintf(stderr, "[fmdenc] flags %u: the packer met a block it cannot write\n", hflag[0]); ret = -3; goto done; }
+		const int64_t tailw = !ended ? 0 : hflag[1] == 4u ? 4 : 2; // header words of the trailing header-only block (rld0.c:211)
+		const int64_t nw = 8 * nfull + tailw;
+		if (e->host_n + nw > e->host_cap) {
+			const int64_t want = ended ? e->host_n + nw : (e->host_n + nw) + ((e->host_n + nw) >> 1) + 1024;
+			uint64_t *nh = (uint64_t*)realloc(e->host, (size_t)want * 8);
+			if (!nh) { ret = -1; goto done; }
+			e->host = nh, e->host_cap = want;
+		}
+		if (nw > 0) FE_HIP(hipMemcpy(e->host + e->host_n, e->out, (size_t)nw * 8, hipMemcpyDeviceToHost));
+		e->host_n += nw;
 	}
+	if (ended) e->finished = 1;
+	else { // what is left of the piece, from the start of its last complete block on, moves to the front
+		int64_t cs = 0;
+		FE_HIP(hipMemcpy(&cs, bs + Bl - 1, 8, hipMemcpyDeviceToHost));
+		const int64_t keep = n - cs;
+		if (cs < 0 || cs > cur || keep > FE_CARRY_MAX) { if (fmd_debug()) fprintf(stderr, "[fmdenc] piece %lld: %lld runs to carry over (from run %lld of %lld)\n", (long long)e->pieces, (long long)keep, (long long)cs, (long long)n); ret = -3; goto done; }
+		FE_HIP(hipMemcpyAsync(e->carry, e->w + cs, (size_t)keep * 8, hipMemcpyDeviceToDevice, st));
+		FE_HIP(hipMemcpyAsync(e->w, e->carry, (size_t)keep * 8, hipMemcpyDeviceToDevice, st));
+		FE_HIP(hipStreamSynchronize(st));
+		e->nc = keep, e->o = cur - cs, e->oty = cty, e->gb = gbp;
+	}
+	if (fmd_debug()) fprintf(stderr, "[fmdenc] piece %lld: %lld runs (%lld carried in), %lld blocks%s, %.3f s\n", (long long)e->pieces, (long long)n, (long long)(n - n_new), (long long)(Bl - 1), ended ? ", the last" : "", fe_now() - fe_t0);
 done:
-	free(host); free(hE); free(hCn); free(hlists);
-	{
-		void *all[] = { width, P, out, E, Cn, lists, bs, scal, flag, tmp };
-		for (void *p : all) if (p) (void)hipFree(p);
-	}
 	return ret;
+}
+
+/* d_words: nr words start << 3 | sym of the maximal runs of a BWT of n_sym symbols (device), all at once.  On success (0) *z_out is a malloc'ed host array of
+ * *n_words words: the FMD data section incl. the trailing header.  1: this index needs block headers wider than 32 bits somewhere (pack on the host);
+ * < 0: -1 out of memory, -2 HIP error, -3 internal. */
+int rb3fmd_encode(hipStream_t st, int64_t n_sym, int64_t nr, const uint64_t *d_words, uint64_t **z_out, int64_t *n_words)
+{
+	rb3fmd_enc *e = nullptr;
+	*z_out = nullptr, *n_words = 0;
+	if (nr <= 0 || n_sym <= 0) return -3;
+	int r = rb3fmd_enc_begin(st, n_sym, nr + 16, &e);
+	if (r < 0) return r;
+	if (hipMemcpyAsync(rb3fmd_enc_buffer(e, nullptr), d_words, (size_t)nr * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipGetLastError(); rb3fmd_enc_abort(e); return -2; }
+	r = rb3fmd_enc_piece(e, nr, 1);
+	if (r != 0) { rb3fmd_enc_abort(e); return r; }
+	return rb3fmd_enc_end(e, z_out, n_words);
 }
 
 /* ------------------------------------------------------------------------------------------ */

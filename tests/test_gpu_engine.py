@@ -1290,6 +1290,40 @@ def test_interval_sharded_merge_peer_rounds(oracle, world, skew):
     assert np.array_equal(np.concatenate([x[2] for x in res[0]]), want)
 
 
+@pytest.mark.parametrize("kind", ["random", "copies", "mixed"])
+def test_fmd_packed_a_piece_at_a_time(kind):
+    """rb3gpu_export_fmd_words packs the runs a PIECE at a time (rb3fmd_enc_*, round 6: device memory per run of a piece, not of the index): with pieces of
+    32 k runs (tune fmd_piece; 64 M by default) -- dozens of pieces, each handing its last complete block, the block that has begun and the run whose end is
+    not known yet to the next -- the word stream is the one a single piece gives, which every .fmd test holds against the reference's bytes.
+    random: short runs, 16-bit block headers; copies: runs of thousands, mostly 32-bit headers; mixed: a repetitive part in front of a random one."""
+    from ropebwt3_amd import Rb3Gpu
+    rng = np.random.default_rng({"random": 1, "copies": 2, "mixed": 3}[kind])
+    if kind == "random":
+        t = util.make_text([util.random_genome(rng, 1500000)], rev=False)
+    elif kind == "copies":
+        g = util.random_genome(rng, 50000)
+        t = util.make_text([util.mutate(rng, g, 0.0001) for _ in range(3000)], rev=False)
+    else:
+        g = util.random_genome(rng, 8000)
+        t = util.make_text([util.mutate(rng, g, 0.0004) for _ in range(1200)] + [util.random_genome(rng, 400000)], rev=False)
+    h = Rb3Gpu(verbose=1)
+    try:
+        d, dtw = h.sort_text(t)
+        h.from_plain_dev(d, t.size)
+        h.dev_free(d), h.dev_free(dtw)
+        one = h.export_fmd_words()
+        runs = int(np.count_nonzero(np.diff(h.export_plain().astype(np.int16))) + 1)
+        assert runs > 2 * 32768, runs
+        for piece in (32768, 50000):
+            h.tune("fmd_piece", piece)
+            many = h.export_fmd_words()
+            assert many.size == one.size and np.array_equal(many, one), (kind, piece, runs, many.size, one.size)
+        types = {int(one[8 * b] >> 62) for b in range(1, one.size // 8, 97)}
+        assert (types == {0}) if kind == "random" else (1 in types) if kind == "copies" else True, types   # (16-bit headers only / blocks of 16 k symbols and more among them)
+    finally:
+        h.close()
+
+
 def test_buffer_bytes_account_for_the_handle(oracle):
     """rb3gpu_buffer_bytes: the buffers a handle reports add up to no more than its peak, the current slot array holds the index, and the
     stretch table is there at its fixed size once a merge with tentative records has run"""

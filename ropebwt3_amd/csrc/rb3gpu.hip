@@ -325,12 +325,19 @@ static VmRange *vm_find(rb3gpu_t *h, const void *p)
 
 static int vm_map_chunk(rb3gpu_t *h, VmRange *r, size_t off, hipMemGenericAllocationHandle_t hd, size_t size)
 {
-	if (hipMemMap((char*)r->va + off, size, 0, hd, 0) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENOMEM; }
+	{ const hipError_t e = hipMemMap((char*)r->va + off, size, 0, hd, 0);
+	  if (e != hipSuccess) { if (h->tn.log_alloc) fprintf(stderr, "[M::rb3gpu] hipMemMap(%p + %zu, %zu): %s\n", r->va, off, size, hipGetErrorString(e)); (void)hipGetLastError(); return RB3GPU_ENOMEM; } }
 	// (this device only: the ranges are buffers that nothing but this handle's kernels touch -- what peers pull over xGMI are ordinary allocations)
 	hipMemAccessDesc ad;
 	memset(&ad, 0, sizeof(ad));
 	ad.location.type = hipMemLocationTypeDevice, ad.location.id = h->dev, ad.flags = hipMemAccessFlagsProtReadWrite;
-	if (hipMemSetAccess((char*)r->va + off, size, &ad, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap((char*)r->va + off, size); return RB3GPU_ENOMEM; }
+	{ // Access for the new chunk alone -- or, where this runtime answers "invalid argument" to that (ROCm 7.2: for about half of all (address, size) pairs behind a first
+	  // chunk -- tools/ubench/vmm_probe.cpp; at the scale of BASELINE configs[4] most growths of the slot arrays and of the rebuild's scratch came back like that and fell onto
+	  // hipMalloc / hipMemCreate of the WHOLE buffer, 0.5-1.8 s apiece: 7.5 of a build's 19 s), for everything mapped so far from the range's base, which it always takes.
+		hipError_t e = hipMemSetAccess((char*)r->va + off, size, &ad, 1);
+		if (e != hipSuccess && off > 0) { (void)hipGetLastError(); e = hipMemSetAccess(r->va, off + size, &ad, 1); }
+		if (e != hipSuccess) { if (h->tn.log_alloc) fprintf(stderr, "[M::rb3gpu] hipMemSetAccess(%p + %zu, %zu): %s\n", r->va, off, size, hipGetErrorString(e)); (void)hipGetLastError(); (void)hipMemUnmap((char*)r->va + off, size); return RB3GPU_ENOMEM; }
+	}
 	return 0;
 }
 
@@ -348,10 +355,14 @@ static int vm_ensure(rb3gpu_t *h, void **p, size_t *cap, size_t bytes)
 		want = (want + G - 1) / G * G;
 		if (want > h->vm_total) want = h->vm_total;
 		if (want < (bytes + G - 1) / G * G) want = (bytes + G - 1) / G * G;
-		if (hipMemAddressReserve(&r->va, want, G, nullptr, 0) != hipSuccess || r->va == nullptr) { (void)hipGetLastError(); delete r; return RB3GPU_ENOMEM; }
+		if (hipMemAddressReserve(&r->va, want, G, nullptr, 0) != hipSuccess || r->va == nullptr) {
+			if (h->tn.log_alloc) fprintf(stderr, "[M::rb3gpu] vm_ensure: no address range of %.1f MB (%s)\n", (double)want / 1e6, hipGetErrorString(hipGetLastError()));
+			(void)hipGetLastError(); delete r; return RB3GPU_ENOMEM;
+		}
 		r->va_size = want;
 		h->vmr.push_back(r);
 	}
+	if (bytes > r->va_size && h->tn.log_alloc) fprintf(stderr, "[M::rb3gpu] vm_ensure: %.1f MB asked of a range of %.1f MB: it moves\n", (double)bytes / 1e6, (double)r->va_size / 1e6);
 	if (bytes > r->va_size) { // the reserved range is used up (the buffer grew more than eightfold): a larger one, the same physical chunks mapped into it -- nothing is copied
 		size_t want = r->va_size * 4 > bytes * 2 ? r->va_size * 4 : bytes * 2;
 		want = (want + G - 1) / G * G;
@@ -383,8 +394,9 @@ static int vm_ensure(rb3gpu_t *h, void **p, size_t *cap, size_t bytes)
 		hipMemGenericAllocationHandle_t hd;
 		hipError_t e = hipMemCreate(&hd, inc, &prop, 0);
 		if (e == hipErrorOutOfMemory && !h->garbage.empty()) { (void)hipGetLastError(); garbage_collect(h, true); e = hipMemCreate(&hd, inc, &prop, 0); }
+		if (e != hipSuccess && h->tn.log_alloc) fprintf(stderr, "[M::rb3gpu] vm_ensure: hipMemCreate of %.1f MB failed (%s)\n", (double)inc / 1e6, hipGetErrorString(e));
 		if (e != hipSuccess) { (void)hipGetLastError(); if (r->mapped == 0) { (void)hipMemAddressFree(r->va, r->va_size); h->vmr.erase(std::find(h->vmr.begin(), h->vmr.end(), r)); delete r; } return RB3GPU_ENOMEM; }
-		if (vm_map_chunk(h, r, r->mapped, hd, inc) < 0) { (void)hipMemRelease(hd); if (r->mapped == 0) { (void)hipMemAddressFree(r->va, r->va_size); h->vmr.erase(std::find(h->vmr.begin(), h->vmr.end(), r)); delete r; } return RB3GPU_ENOMEM; }
+		if (vm_map_chunk(h, r, r->mapped, hd, inc) < 0) { if (h->tn.log_alloc) fprintf(stderr, "[M::rb3gpu] vm_ensure: %.1f MB could not be mapped behind %.1f MB of a range of %.1f MB\n", (double)inc / 1e6, (double)r->mapped / 1e6, (double)r->va_size / 1e6); (void)hipMemRelease(hd); if (r->mapped == 0) { (void)hipMemAddressFree(r->va, r->va_size); h->vmr.erase(std::find(h->vmr.begin(), h->vmr.end(), r)); delete r; } return RB3GPU_ENOMEM; }
 		r->hs.push_back(std::make_pair(hd, inc));
 		r->mapped += inc;
 		h->bytes_owned += (int64_t)inc;

@@ -16,7 +16,7 @@ t1=$(date +%s.%N)
 echo "generated $NH haplotypes of $LEN bp in $(python -c "print(round($t1 - $t0, 1))") s: $(du -sh $D | cut -f1)" >&2
 RB3GPU_LF_CHECK=${LF_CHECK:-64} RB3_VERBOSE=4 timeout ${BUILD_TIMEOUT:-2400} ropebwt3_amd/ropebwt3-amd build -d ${EXTRA} -o $D/out.fmd $FILES 2> gpurun_out/prof/r6_scale_hap.err; rc=$?
 t2=$(date +%s.%N)
-ls -la $D/out.fmd >&2
+ls -la $D/out.fmd >&2; md5sum $D/out.fmd | cut -c1-32 > gpurun_out/prof/r6_scale_hap_md5.txt; cat gpurun_out/prof/r6_scale_hap_md5.txt >&2
 python tools/r6/scale_summary.py "cfg5-shape: $NH haplotypes x $LEN bp in contigs of 40-135 Mbp, build -d, rc=$rc, fmd $(stat -c %s $D/out.fmd 2>/dev/null) bytes" gpurun_out/prof/r6_scale_hap.err $(python -c "print(round($t2 - $t1, 2))") | tee gpurun_out/prof/r6_scale_hap.json | cut -c1-1500
 grep -v "merge of \|\[prof\]" gpurun_out/prof/r6_scale_hap.err | tail -25 | cut -c1-260 > gpurun_out/prof/r6_scale_hap_tail.txt
 gzip -f gpurun_out/prof/r6_scale_hap.err

@@ -357,6 +357,11 @@ typedef struct rb3gpu_comm_s {
 	 * streams wait for, not a host synchronisation).  With it the lock-step rounds of rb3gpu_sh_merge[_text] run as PEER ROUNDS: one kernel per
 	 * rank and round that writes the next states straight into the owner's receive buffer over xGMI, no read-back, no all-gather, no all-to-all. */
 	int (*stream_barrier)(void *ctx, void *stream);
+	/* may be NULL (then a device pointer means the same on every rank: threads of one process).  Ranks that are PROCESSES name a device buffer to each other
+	 * by a handle of 8 words (peer_export: 0 or a negative code) which all_gather carries and the other side turns into a pointer of its own address space
+	 * (peer_import: NULL if it cannot) -- HIP IPC memory handles in rb3gpu_ipc_peer_enable below. */
+	int (*peer_export)(void *ctx, void *d_ptr, int64_t handle[8]);
+	void *(*peer_import)(void *ctx, int rank, const int64_t handle[8]);
 } rb3gpu_comm_t;
 int rb3gpu_sh_merge(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bounds, int64_t len, const uint8_t *d_bwt, const uint64_t *d_tw,
 		int64_t n_chains, const int64_t *chain_tp, int commit, int64_t *n_rounds);
@@ -385,6 +390,15 @@ void rb3gpu_group_destroy(rb3gpu_group_t *g);
 int rb3gpu_rccl_unique_id(char id[RB3GPU_RCCL_ID_BYTES]);
 int rb3gpu_rccl_comm_create(rb3gpu_t *h, int rank, int world, const char id[RB3GPU_RCCL_ID_BYTES], rb3gpu_comm_t *comm);
 void rb3gpu_rccl_comm_destroy(rb3gpu_comm_t *comm);
+
+/* PEER ROUNDS for ranks that are PROCESSES of one node (bench.py --gpus N, torchrun: one process per GPU): wraps a communicator of world > 1 -- any of the above --
+ * so that it offers stream_barrier / peer_export / peer_import: the receive buffers and counter tables are shared through HIP IPC memory handles
+ * (hipIpcGetMemHandle / hipIpcOpenMemHandle, opened once per buffer), the streams wait for each other through interprocess events, and the host processes
+ * meet at a spin barrier in POSIX shared memory -- no RCCL call and no host synchronisation per lock-step round.  COLLECTIVE: every rank calls it with its
+ * handle and its communicator; it returns 0 on every rank (enabled everywhere) or RB3GPU_EUNSUP on every rank (some rank could not: the communicator is
+ * left as it was).  rb3gpu_ipc_peer_disable undoes it (before the wrapped communicator is destroyed). */
+int rb3gpu_ipc_peer_enable(rb3gpu_t *h, rb3gpu_comm_t *comm);
+void rb3gpu_ipc_peer_disable(rb3gpu_comm_t *comm);
 
 /* The interval-sharded index as ONE object for a single-process host program (`ropebwt3-amd build --gpus N --interval`): N handles,
  * one per device, a thread per handle (they live as long as the object), the thread-group communicator above between them.  Nothing of

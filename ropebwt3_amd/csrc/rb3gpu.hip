@@ -3625,9 +3625,30 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 		if (peer) {
 			if (buf_ensure(h, h->shc, (size_t)world * (size_t)n_chains * 16) < 0 || buf_ensure(h, h->shn, (size_t)world * (size_t)n_chains * 16) < 0) can = 0; // (no room: the others must hear of it)
 			cur = (ShState*)h->shc.p, nxt = (ShState*)h->shn.p;
-			int64_t mine4[4] = { can, (int64_t)(intptr_t)h->shc.p, (int64_t)(intptr_t)h->shn.p, (int64_t)(intptr_t)h->shk.p };
-			if ((r = comm->all_gather(comm->ctx, mine4, 4, all4.data())) < 0) return r;
-			for (int q = 0; q < world; ++q) peer = peer && all4[(size_t)q * 4] != 0;
+			// the three buffers the other ranks write into: as pointers (threads of one process), or as the handles the communicator makes of them (processes: HIP IPC)
+			int64_t mine25[25];
+			memset(mine25, 0, sizeof(mine25));
+			void *mybuf[3] = { h->shc.p, h->shn.p, h->shk.p };
+			for (int i = 0; i < 3 && can; ++i) {
+				if (comm->peer_export) { if (mybuf[i] == nullptr || comm->peer_export(comm->ctx, mybuf[i], mine25 + 1 + 8 * i) < 0) can = 0; }
+				else mine25[1 + 8 * i] = (int64_t)(intptr_t)mybuf[i];
+			}
+			mine25[0] = can;
+			std::vector<int64_t> all25((size_t)world * 25);
+			if ((r = comm->all_gather(comm->ctx, mine25, 25, all25.data())) < 0) return r;
+			for (int q = 0; q < world; ++q) peer = peer && all25[(size_t)q * 25] != 0;
+			int64_t ok = 1;
+			for (int q = 0; q < world && peer; ++q)
+				for (int i = 0; i < 3; ++i) {
+					void *ptr = q == rank ? mybuf[i] : comm->peer_import ? comm->peer_import(comm->ctx, q, all25.data() + (size_t)q * 25 + 1 + 8 * i) : (void*)(intptr_t)all25[(size_t)q * 25 + 1 + 8 * i];
+					if (ptr == nullptr) ok = 0;
+					all4[(size_t)q * 4 + 1 + i] = (int64_t)(intptr_t)ptr;
+				}
+			if (peer && comm->peer_import) { // (a rank that could not map a buffer of another one: everybody hears of it)
+				std::vector<int64_t> oks((size_t)world);
+				if ((r = comm->all_gather(comm->ctx, &ok, 1, oks.data())) < 0) return r;
+				for (int q = 0; q < world; ++q) peer = peer && oks[(size_t)q] != 0;
+			}
 			if (!cur || !nxt) return RB3GPU_ENOMEM;
 		}
 	}

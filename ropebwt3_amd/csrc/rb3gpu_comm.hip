@@ -15,6 +15,12 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sched.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -123,6 +129,112 @@ static int group_stream_barrier(void *ctx, void *stream)
 
 static void group_abort_cb(void *ctx) { rb3gpu_group_abort(((GroupMember*)ctx)->g); }
 
+/* ---- peer rounds for ranks that are PROCESSES of one node: HIP IPC (rb3gpu_ipc_peer_enable) ---- */
+
+struct IpcShm { std::atomic<uint32_t> count, gen, aborted; };
+
+struct IpcPeer {
+	rb3gpu_comm_t inner;            // the communicator underneath: its collectives are passed through
+	int rank = 0, world = 1, dev = 0, par = 0;
+	IpcShm *shm = nullptr;
+	hipEvent_t ev[2] = { nullptr, nullptr };                  // this rank's, interprocess
+	hipEvent_t pev[RB3GPU_SH_MAXIV][2];                       // the other ranks', opened here
+	struct Open { int64_t key[8]; void *ptr; int rank; unsigned long used; };
+	std::vector<Open> open;         // buffers of other ranks mapped into this process, by handle
+	unsigned long tick = 0;
+};
+
+static int ipc_all_gather(void *ctx, const int64_t *send, int n, int64_t *recv) { IpcPeer *p = (IpcPeer*)ctx; return p->inner.all_gather(p->inner.ctx, send, n, recv); }
+static int ipc_all_to_all(void *ctx, const rb3gpu_state_t *d_send, int64_t stride, const int64_t *send_cnt, rb3gpu_state_t *d_recv, const int64_t *recv_cnt, void *stream)
+{
+	IpcPeer *p = (IpcPeer*)ctx;
+	return p->inner.all_to_all(p->inner.ctx, d_send, stride, send_cnt, d_recv, recv_cnt, stream);
+}
+static void ipc_abort(void *ctx)
+{
+	IpcPeer *p = (IpcPeer*)ctx;
+	if (p->shm) p->shm->aborted.store(1u, std::memory_order_release);
+	if (p->inner.abort) p->inner.abort(p->inner.ctx);
+}
+
+/* the processes meet (nobody waits for a device): a spin barrier in shared memory; a rank that has given up makes the others return */
+static int ipc_barrier(IpcPeer *p)
+{
+	IpcShm *b = p->shm;
+	if (b->aborted.load(std::memory_order_acquire)) return RB3GPU_ESTATE;
+	const uint32_t my = b->gen.load(std::memory_order_acquire);
+	if (b->count.fetch_add(1u, std::memory_order_acq_rel) + 1u == (uint32_t)p->world) {
+		b->count.store(0u, std::memory_order_relaxed);
+		b->gen.store(my + 1u, std::memory_order_release);
+	} else {
+		unsigned long spins = 0;
+		while (b->gen.load(std::memory_order_acquire) == my && !b->aborted.load(std::memory_order_relaxed)) {
+			if (++spins < 4000) __builtin_ia32_pause(); else sched_yield();
+			if (spins > 4000ul + 60000000ul) { b->aborted.store(1u, std::memory_order_release); break; } // (a rank that died: minutes of yields, then everybody gives up)
+		}
+	}
+	return b->aborted.load(std::memory_order_acquire) ? RB3GPU_ESTATE : 0;
+}
+
+static int ipc_stream_barrier(void *ctx, void *stream)
+{
+	IpcPeer *p = (IpcPeer*)ctx;
+	hipStream_t st = (hipStream_t)stream;
+	if (hipSetDevice(p->dev) != hipSuccess) { ipc_abort(p); return RB3GPU_ENODEV; }
+	const int q = p->par;
+	p->par ^= 1;
+	if (hipEventRecord(p->ev[q], st) != hipSuccess) { (void)hipGetLastError(); ipc_abort(p); return RB3GPU_ENODEV; }
+	int r;
+	if ((r = ipc_barrier(p)) < 0) return r;
+	for (int o = 0; o < p->world; ++o)
+		if (o != p->rank && hipStreamWaitEvent(st, p->pev[o][q], 0) != hipSuccess) { (void)hipGetLastError(); ipc_abort(p); return RB3GPU_ENODEV; }
+	return 0;
+}
+
+static int ipc_peer_export(void *ctx, void *d_ptr, int64_t handle[8])
+{
+	(void)ctx;
+	hipIpcMemHandle_t hd;
+	static_assert(sizeof(hd) == 64, "an IPC memory handle is 8 words");
+	if (hipIpcGetMemHandle(&hd, d_ptr) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	memcpy(handle, &hd, 64);
+	return 0;
+}
+
+static void *ipc_peer_import(void *ctx, int rank, const int64_t handle[8])
+{
+	IpcPeer *p = (IpcPeer*)ctx;
+	++p->tick;
+	for (auto &o : p->open)
+		if (o.rank == rank && memcmp(o.key, handle, 64) == 0) { o.used = p->tick; return o.ptr; }
+	// a rank shows three buffers at a time (two receive buffers, its counters): more than six mappings of one rank are buffers it has replaced since
+	int n_of = 0;
+	size_t oldest = 0;
+	for (size_t i = 0; i < p->open.size(); ++i)
+		if (p->open[i].rank == rank) { if (n_of == 0 || p->open[i].used < p->open[oldest].used) oldest = i; ++n_of; }
+	if (n_of >= 6) { (void)hipIpcCloseMemHandle(p->open[oldest].ptr); (void)hipGetLastError(); p->open.erase(p->open.begin() + (long)oldest); }
+	hipIpcMemHandle_t hd;
+	memcpy(&hd, handle, 64);
+	void *ptr = nullptr;
+	if (hipSetDevice(p->dev) != hipSuccess || hipIpcOpenMemHandle(&ptr, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess || ptr == nullptr) { (void)hipGetLastError(); return nullptr; }
+	IpcPeer::Open o;
+	memcpy(o.key, handle, 64), o.ptr = ptr, o.rank = rank, o.used = p->tick;
+	p->open.push_back(o);
+	return ptr;
+}
+
+static void ipc_free(IpcPeer *p)
+{
+	if (!p) return;
+	(void)hipSetDevice(p->dev);
+	for (auto &o : p->open) (void)hipIpcCloseMemHandle(o.ptr);
+	for (int i = 0; i < 2; ++i) if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+	for (int o = 0; o < p->world; ++o) for (int i = 0; i < 2; ++i) if (o != p->rank && p->pev[o][i]) (void)hipEventDestroy(p->pev[o][i]);
+	if (p->shm) munmap(p->shm, 4096);
+	(void)hipGetLastError();
+	delete p;
+}
+
 extern "C" {
 
 rb3gpu_group_t *rb3gpu_group_create(int world)
@@ -157,6 +269,7 @@ int rb3gpu_group_comm(rb3gpu_group_t *g, int rank, rb3gpu_t *h, rb3gpu_comm_t *c
 		if (d != m->dev) { int can = 0; if (hipDeviceCanAccessPeer(&can, m->dev, d) != hipSuccess || !can) reach = false; }
 	(void)hipGetLastError();
 	comm->stream_barrier = reach && !getenv("RB3GPU_NO_PEER_ROUNDS") ? group_stream_barrier : nullptr;
+	comm->peer_export = nullptr, comm->peer_import = nullptr; // (threads of one process: a device pointer is what it is)
 	return 0;
 }
 
@@ -167,6 +280,73 @@ void rb3gpu_group_abort(rb3gpu_group_t *g)
 	g->aborted.store(1, std::memory_order_release);
 	pthread_cond_broadcast(&g->cv);
 	pthread_mutex_unlock(&g->mtx);
+}
+
+int rb3gpu_ipc_peer_enable(rb3gpu_t *h, rb3gpu_comm_t *comm)
+{
+	if (!h || !comm || !comm->all_gather || comm->world < 2 || comm->world > RB3GPU_SH_MAXIV || comm->stream_barrier) return RB3GPU_EINVAL;
+	IpcPeer *p = new (std::nothrow) IpcPeer;
+	if (!p) return RB3GPU_ENOMEM;
+	memset(p->pev, 0, sizeof(p->pev));
+	p->inner = *comm, p->rank = comm->rank, p->world = comm->world, p->dev = rb3gpu_device_of(h);
+	const int W = p->world;
+	int64_t ok = 1;
+	// 1. the barrier: rank 0 makes the shared-memory object, everybody maps it, rank 0 takes the name away again
+	int64_t name8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	std::vector<int64_t> all((size_t)W * 16);
+	int fd = -1;
+	if (p->rank == 0) {
+		struct timespec ts;
+		clock_gettime(CLOCK_MONOTONIC, &ts);
+		snprintf((char*)name8, 63, "/rb3gpu_%d_%ld%09ld", (int)getpid(), (long)ts.tv_sec, (long)ts.tv_nsec);
+		fd = shm_open((const char*)name8, O_CREAT | O_EXCL | O_RDWR, 0600);
+		if (fd < 0 || ftruncate(fd, 4096) != 0) ok = 0;
+	}
+	if (comm->all_gather(comm->ctx, name8, 8, all.data()) < 0) { if (fd >= 0) { close(fd); shm_unlink((const char*)name8); } delete p; return RB3GPU_ENODEV; }
+	char name[64];
+	memcpy(name, all.data(), 64), name[63] = 0; // (rank 0's)
+	if (p->rank != 0 && name[0]) fd = shm_open(name, O_RDWR, 0600);
+	if (fd >= 0) {
+		void *m = mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+		close(fd);
+		if (m != MAP_FAILED) p->shm = (IpcShm*)m; // (a fresh object is all zero: count, generation and the abort flag start at 0)
+	}
+	if (!p->shm) ok = 0;
+	// 2. two interprocess events per rank, everybody opens everybody else's
+	int64_t evh[16];
+	memset(evh, 0, sizeof(evh));
+	if (hipSetDevice(p->dev) != hipSuccess) ok = 0;
+	for (int i = 0; i < 2 && ok; ++i) {
+		hipIpcEventHandle_t eh;
+		static_assert(sizeof(eh) == 64, "an IPC event handle is 8 words");
+		if (hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming | hipEventInterprocess) != hipSuccess || hipIpcGetEventHandle(&eh, p->ev[i]) != hipSuccess) { (void)hipGetLastError(); ok = 0; break; }
+		memcpy(evh + 8 * i, &eh, 64);
+	}
+	if (comm->all_gather(comm->ctx, evh, 16, all.data()) < 0) { if (p->rank == 0 && name[0]) shm_unlink(name); ipc_free(p); return RB3GPU_ENODEV; }
+	if (p->rank == 0 && name[0]) shm_unlink(name); // (everybody has mapped it -- or has failed to, and says so below)
+	for (int o = 0; o < W && ok; ++o)
+		for (int i = 0; i < 2 && ok && o != p->rank; ++i) {
+			hipIpcEventHandle_t eh;
+			memcpy(&eh, all.data() + (size_t)o * 16 + 8 * i, 64);
+			if (hipIpcOpenEventHandle(&p->pev[o][i], eh) != hipSuccess) { (void)hipGetLastError(); p->pev[o][i] = nullptr; ok = 0; }
+		}
+	// 3. everywhere or nowhere
+	std::vector<int64_t> oks((size_t)W);
+	if (comm->all_gather(comm->ctx, &ok, 1, oks.data()) < 0) { ipc_free(p); return RB3GPU_ENODEV; }
+	for (int o = 0; o < W; ++o) ok = ok && oks[(size_t)o] != 0;
+	if (!ok) { ipc_free(p); return RB3GPU_EUNSUP; }
+	comm->ctx = p;
+	comm->all_gather = ipc_all_gather, comm->all_to_all = p->inner.all_to_all ? ipc_all_to_all : nullptr, comm->abort = ipc_abort;
+	comm->stream_barrier = ipc_stream_barrier, comm->peer_export = ipc_peer_export, comm->peer_import = ipc_peer_import;
+	return 0;
+}
+
+void rb3gpu_ipc_peer_disable(rb3gpu_comm_t *comm)
+{
+	if (!comm || comm->stream_barrier != ipc_stream_barrier || !comm->ctx) return;
+	IpcPeer *p = (IpcPeer*)comm->ctx;
+	*comm = p->inner;
+	ipc_free(p);
 }
 
 void rb3gpu_group_destroy(rb3gpu_group_t *g)
@@ -327,7 +507,7 @@ int rb3gpu_rccl_comm_create(rb3gpu_t *h, int rank, int world, const char id[RB3G
 	}
 	comm->ctx = c, comm->rank = rank, comm->world = world;
 	comm->all_gather = rccl_all_gather, comm->all_to_all = rccl_all_to_all, comm->abort = rccl_abort_cb;
-	comm->stream_barrier = nullptr; // (processes: a pointer of another rank means nothing here)
+	comm->stream_barrier = nullptr, comm->peer_export = nullptr, comm->peer_import = nullptr; // (processes: a pointer of another rank means nothing here -- rb3gpu_ipc_peer_enable wraps this communicator for peer rounds)
 	return 0;
 }
 

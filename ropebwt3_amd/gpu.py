@@ -123,6 +123,8 @@ SYMBOLS = {
     "rb3gpu_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rb3gpu_rccl_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_rccl_comm_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_ipc_peer_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rb3gpu_ipc_peer_disable": (None, [ctypes.c_void_p]),
     "rb3gpu_merge_text_step_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
     "rb3gpu_walkers_step_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_shard_split": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
@@ -151,7 +153,8 @@ ABORT_F = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 
 class CommStruct(ctypes.Structure):
     _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
-                ("all_gather", ctypes.c_void_p), ("all_to_all", ctypes.c_void_p), ("abort", ctypes.c_void_p), ("stream_barrier", ctypes.c_void_p)]
+                ("all_gather", ctypes.c_void_p), ("all_to_all", ctypes.c_void_p), ("abort", ctypes.c_void_p), ("stream_barrier", ctypes.c_void_p),
+                ("peer_export", ctypes.c_void_p), ("peer_import", ctypes.c_void_p)]
 
 _libs = {}
 
@@ -644,6 +647,21 @@ class CommGroup:
 
 class GroupComm:
     struct = None
+
+
+def ipc_peer_enable(engine, comm):
+    """rb3gpu_ipc_peer_enable: PEER ROUNDS for ranks that are processes of one node (HIP IPC memory and event handles, a spin barrier in shared memory) on top
+    of any communicator of world > 1.  COLLECTIVE: every rank calls it.  True: enabled on every rank; False: not available (the communicator is as it was)."""
+    r = engine._lib.rb3gpu_ipc_peer_enable(engine._h, ctypes.addressof(comm.struct))
+    if r == 0:
+        return True
+    if r == -7:
+        return False
+    raise Rb3GpuError(int(r), "rb3gpu_ipc_peer_enable")
+
+
+def ipc_peer_disable(engine, comm):
+    engine._lib.rb3gpu_ipc_peer_disable(ctypes.addressof(comm.struct))
 
 
 class RcclComm:

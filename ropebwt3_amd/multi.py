@@ -364,15 +364,27 @@ def sh_comm(h, dist, rank, world, dev, driver="rccl"):
     driver "rccl": the library's own (rb3gpu_rccl_*: grouped ncclSend/ncclRecv on the engine's stream; the 128-byte id travels
     through torch.distributed); "torch": two callbacks over torch.distributed (all_gather of the split sizes, all_to_all of views
     of the engine's send regions) -- also what "rccl" falls back to when librccl cannot be loaded.  Returns (comm, label)."""
+    import os
     import torch
-    from ropebwt3_amd import RcclComm, CallbackComm, Rb3GpuError
+    from ropebwt3_amd import RcclComm, CallbackComm, Rb3GpuError, ipc_peer_enable
+
+    def with_peer_rounds(comm, label):
+        """the ranks are processes of ONE node: the lock-step rounds as peer rounds through HIP IPC where every rank can (collective; RB3_NO_IPC_PEER=1: never)"""
+        if world > 1 and not os.environ.get("RB3_NO_IPC_PEER"):
+            try:
+                if ipc_peer_enable(h, comm):
+                    label += " + PEER ROUNDS between the processes (rb3gpu_ipc_peer_enable: HIP IPC memory and event handles, a barrier in shared memory; the collectives above only carry the handles and the final exchange)"
+            except Rb3GpuError as e:
+                label += " [rb3gpu_ipc_peer_enable failed: %r]" % (e,)
+        return comm, label
+
     why = ""
     if driver == "rccl":
         try:
             box = [RcclComm.unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(box, src=0)
-            return RcclComm(h, rank, world, box[0]), "rb3gpu_rccl (ncclSend/ncclRecv grouped per round, on the engine's stream)"
+            return with_peer_rounds(RcclComm(h, rank, world, box[0]), "rb3gpu_rccl (ncclSend/ncclRecv grouped per round, on the engine's stream)")
         except (Rb3GpuError, OSError) as e:   # (every rank fails alike: the library is the same on all of them)
             why = " [rb3gpu_rccl unavailable: %r]" % (e,)
 
@@ -398,7 +410,7 @@ def sh_comm(h, dist, rank, world, dev, driver="rccl"):
             if got.size:
                 h.dev_upload_to(d_recv, got)
 
-        return CallbackComm(rank, world, all_gather_g, exchange_g), "callbacks over gloo through host memory (ranks share a GPU: test mode)"
+        return with_peer_rounds(CallbackComm(rank, world, all_gather_g, exchange_g), "callbacks over gloo through host memory (ranks share a GPU: test mode)")
 
     def all_gather(vec):
         v = torch.as_tensor(np.ascontiguousarray(vec, dtype=np.int64), device=dev)
@@ -423,7 +435,7 @@ def sh_comm(h, dist, rank, world, dev, driver="rccl"):
             outs[0].copy_(ins[0])
         torch.cuda.synchronize()
 
-    return CallbackComm(rank, world, all_gather, exchange), "callbacks over torch.distributed (all_gather_into_tensor + all_to_all of views of the engine's send regions)" + why
+    return with_peer_rounds(CallbackComm(rank, world, all_gather, exchange), "callbacks over torch.distributed (all_gather_into_tensor + all_to_all of views of the engine's send regions)" + why)
 
 
 def merge_interval_text(engine, comm, bounds, d_tprev, d_tw_slice, n2, sent_tp, commit=True, stats=None):

@@ -1620,7 +1620,7 @@ def test_interval_sharded_merge_through_callbacks(oracle):
         assert not errs, errs
 
 
-def _gloo_sh_worker(rank, world, port, q):
+def _gloo_sh_worker(rank, world, port, q, ipc=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
@@ -1652,12 +1652,21 @@ def _gloo_sh_worker(rank, world, port, q):
                 h.dev_upload_to(d_recv, got)
 
         comm = CallbackComm(rank, world, all_gather, exchange)
+        if ipc:   # peer rounds between PROCESSES: receive buffers shared through HIP IPC handles, interprocess events, a barrier in shared memory
+            from ropebwt3_amd import ipc_peer_enable, ipc_peer_disable
+            assert ipc_peer_enable(h, comm) and comm.struct.stream_barrier and comm.struct.peer_import
         h.from_plain(cur[bounds[rank]:bounds[rank + 1]])
+        nround = 0
         for b, t2 in enumerate(batches):
             d_bwt, d_tw = h.sort_text(t2)
-            bounds, _ = h.sh_merge(comm, bounds, d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+            bounds, nr = h.sh_merge(comm, bounds, d_bwt, d_tw, t2.size, np.flatnonzero(t2 == 0))
+            nround += nr
             h.dev_free(d_bwt), h.dev_free(d_tw)
             _check_interval(h, np.random.default_rng(rank), want[b + 1], bounds, rank)
+        assert h.stats()["n_peer_rounds"] == (nround if ipc else 0), (h.stats()["n_peer_rounds"], nround)
+        if ipc:
+            ipc_peer_disable(h, comm)
+            assert not comm.struct.stream_barrier
         h.close()
         q.put((rank, True, ""))
     except BaseException as e:
@@ -1689,6 +1698,25 @@ def test_interval_sharded_merge_c_path_over_gloo():
     q = ctx.Queue()
     world = 2
     procs = [ctx.Process(target=_gloo_sh_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_interval_sharded_merge_peer_rounds_between_processes(world):
+    """PEER ROUNDS where the ranks are PROCESSES (rb3gpu_ipc_peer_enable over the gloo callbacks; what bench.py --gpus N runs): every rank's receive buffers and
+    counter tables mapped into the others through HIP IPC memory handles, interprocess events for the streams, a spin barrier in POSIX shared memory for the
+    hosts -- all rounds counted as peer rounds, the intervals the oracle's after every merge"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_sh_worker, args=(r, world, port, q, True)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))

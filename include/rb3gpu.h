@@ -393,8 +393,9 @@ void rb3gpu_rccl_comm_destroy(rb3gpu_comm_t *comm);
 
 /* PEER ROUNDS for ranks that are PROCESSES of one node (bench.py --gpus N, torchrun: one process per GPU): wraps a communicator of world > 1 -- any of the above --
  * so that it offers stream_barrier / peer_export / peer_import: the receive buffers and counter tables are shared through HIP IPC memory handles
- * (hipIpcGetMemHandle / hipIpcOpenMemHandle, opened once per buffer), the streams wait for each other through interprocess events, and the host processes
- * meet at a spin barrier in POSIX shared memory -- no RCCL call and no host synchronisation per lock-step round.  COLLECTIVE: every rank calls it with its
+ * (hipIpcGetMemHandle / hipIpcOpenMemHandle, opened once per buffer); between two rounds every rank waits for its own stream and the processes meet at a spin
+ * barrier in POSIX shared memory (streams of different processes cannot wait for each other on this runtime: hipStreamWaitEvent refuses events that came through
+ * hipIpcOpenEventHandle) -- one host synchronisation per lock-step round, but no collective, no read-back, no copy.  COLLECTIVE: every rank calls it with its
  * handle and its communicator; it returns 0 on every rank (enabled everywhere) or RB3GPU_EUNSUP on every rank (some rank could not: the communicator is
  * left as it was).  rb3gpu_ipc_peer_disable undoes it (before the wrapped communicator is destroyed). */
 int rb3gpu_ipc_peer_enable(rb3gpu_t *h, rb3gpu_comm_t *comm);

@@ -193,6 +193,8 @@ struct rb3gpu_s {
 	// scratch, grown on demand and kept between calls
 	Buf b2, pos, post, tcnt, tpre, ctot, ctot2, gstat, gpre, jg, misc, xbuf, wl, wls, dl, dlx, wstat, wplane, wruns, gslots, glist, pslots, lbst; // (wls: the sentinels' text positions of a device-made walker list -- a buffer of its own, NOT dlx, which tent_masks() hands out as the wide drop-out masks and may reallocate: ADVICE r5)
 	Buf shc, shn, shs, shr, shk;
+	Buf shp0, shp1;        // peer rounds: the two receive buffers the OTHER ranks write into -- buffers of their own, never reused by the merge's last phase: a rank that is
+	                       // another process has them mapped (HIP IPC), and a mapping of a buffer its owner has replaced meanwhile is what a merge must never meet
 	Buf twb; // the text-order words of a batch that came as its BWT only (merge_plain_via_tw) // interval-sharded merge (rb3gpu_sh_merge): states of this and of the next round, send regions, landed (row, insertion point) pairs, counters
 	// a merge in progress (rb3gpu_mg_begin .. rb3gpu_mg_finish)
 	int mg_active = 0;
@@ -823,7 +825,7 @@ void rb3gpu_destroy(rb3gpu_t *h)
 #endif
 	index_drop(h);
 	ib_release(h, 0), ib_release(h, 1);
-	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk, &h->twb };
+	Buf *all[] = { &h->b2, &h->pos, &h->post, &h->tcnt, &h->tpre, &h->ctot, &h->ctot2, &h->gstat, &h->gpre, &h->jg, &h->misc, &h->xbuf, &h->wl, &h->wls, &h->dl, &h->dlx, &h->wstat, &h->wplane, &h->wruns, &h->gslots, &h->glist, &h->pslots, &h->lbst, &h->shc, &h->shn, &h->shs, &h->shr, &h->shk, &h->twb, &h->shp0, &h->shp1 };
 	for (Buf *b : all) buf_release(h, *b);
 	garbage_collect(h, true);
 	for (int i = 0; i < 8; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -3586,12 +3588,13 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 	int64_t n_cur = 0;
 	for (int64_t i = 0; i < n_chains; ++i)
 		if (chain_tp[i] < 0 || chain_tp[i] >= len) return RB3GPU_EINVAL;
-	auto first_states = [&]() -> int { // every chain starts on the rank that owns ka = m1
+	ShState *pr0 = nullptr, *pr1 = nullptr; // peer rounds: this rank's two receive buffers
+	auto first_states = [&](ShState *dst) -> int { // every chain starts on the rank that owns ka = m1
 		n_cur = 0;
 		if (rank != owner0) return 0;
 		std::vector<ShState> st((size_t)n_chains);
 		for (int64_t i = 0; i < n_chains; ++i) st[(size_t)i].tp = chain_tp[i], st[(size_t)i].ka = m1;
-		HIPCHK(hipMemcpyAsync(cur, st.data(), (size_t)n_chains * 16, hipMemcpyHostToDevice, h->st));
+		HIPCHK(hipMemcpyAsync(dst, st.data(), (size_t)n_chains * 16, hipMemcpyHostToDevice, h->st));
 		HIPCHK(hipStreamSynchronize(h->st));
 		n_cur = n_chains;
 		return 0;
@@ -3615,44 +3618,55 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 	// synchronisations and three barriers -- is gone, and nothing that returns a value crosses a link (VERDICT r5 "next" 8).  The ranks agree on
 	// the path first; the receive buffers then hold a region of n_chains states per source.
 	bool peer = false;
+	static const bool ipc_dbg = getenv("RB3GPU_IPC_DEBUG") != nullptr; // (read once per process: where does a sharded merge between processes stand?)
+#define RB3_IPC_DBG(...) do { if (ipc_dbg) { fprintf(stderr, "[ipc debug] rank %d: ", rank); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } while (0)
 	std::vector<int64_t> all4((size_t)world * 4);
 	if (world > 1) {
 		int64_t can = comm->stream_barrier != nullptr && world <= RB3_SH_MAXPEER && h->tn.sh_host_rounds <= 0 ? 1 : 0;
 		std::vector<int64_t> can_all((size_t)world);
+		RB3_IPC_DBG("merge of %lld symbols, %lld chains: can %lld", (long long)len, (long long)n_chains, (long long)can);
 		if ((r = comm->all_gather(comm->ctx, &can, 1, can_all.data())) < 0) return r;
 		peer = true;
 		for (int q = 0; q < world; ++q) peer = peer && can_all[(size_t)q] != 0;
 		if (peer) {
-			if (buf_ensure(h, h->shc, (size_t)world * (size_t)n_chains * 16) < 0 || buf_ensure(h, h->shn, (size_t)world * (size_t)n_chains * 16) < 0) can = 0; // (no room: the others must hear of it)
-			cur = (ShState*)h->shc.p, nxt = (ShState*)h->shn.p;
+			if (buf_ensure(h, h->shp0, (size_t)world * (size_t)n_chains * 16) < 0 || buf_ensure(h, h->shp1, (size_t)world * (size_t)n_chains * 16) < 0) can = 0; // (no room: the others must hear of it)
+			pr0 = (ShState*)h->shp0.p, pr1 = (ShState*)h->shp1.p;
+			RB3_IPC_DBG("agreed (%d), buffers %p %p %p", (int)peer, h->shp0.p, h->shp1.p, h->shk.p);
 			// the three buffers the other ranks write into: as pointers (threads of one process), or as the handles the communicator makes of them (processes: HIP IPC)
 			int64_t mine25[25];
 			memset(mine25, 0, sizeof(mine25));
-			void *mybuf[3] = { h->shc.p, h->shn.p, h->shk.p };
+			void *mybuf[3] = { h->shp0.p, h->shp1.p, h->shk.p };
 			for (int i = 0; i < 3 && can; ++i) {
 				if (comm->peer_export) { if (mybuf[i] == nullptr || comm->peer_export(comm->ctx, mybuf[i], mine25 + 1 + 8 * i) < 0) can = 0; }
 				else mine25[1 + 8 * i] = (int64_t)(intptr_t)mybuf[i];
 			}
 			mine25[0] = can;
 			std::vector<int64_t> all25((size_t)world * 25);
+			RB3_IPC_DBG("exported (can %lld)", (long long)can);
 			if ((r = comm->all_gather(comm->ctx, mine25, 25, all25.data())) < 0) return r;
+			RB3_IPC_DBG("handles gathered");
 			for (int q = 0; q < world; ++q) peer = peer && all25[(size_t)q * 25] != 0;
 			int64_t ok = 1;
-			for (int q = 0; q < world && peer; ++q)
+			for (int q = 0; q < world && peer; ++q) { // (processes: the buffers of ONE rank at a time are mapped by the others while that rank waits -- two processes opening each other's handles at the same moment did not come back)
 				for (int i = 0; i < 3; ++i) {
 					void *ptr = q == rank ? mybuf[i] : comm->peer_import ? comm->peer_import(comm->ctx, q, all25.data() + (size_t)q * 25 + 1 + 8 * i) : (void*)(intptr_t)all25[(size_t)q * 25 + 1 + 8 * i];
 					if (ptr == nullptr) ok = 0;
 					all4[(size_t)q * 4 + 1 + i] = (int64_t)(intptr_t)ptr;
 				}
+				if (comm->peer_import && (r = comm->stream_barrier(comm->ctx, (void*)h->st)) < 0) return r;
+			}
+			RB3_IPC_DBG("imported (ok %lld)", (long long)ok);
 			if (peer && comm->peer_import) { // (a rank that could not map a buffer of another one: everybody hears of it)
 				std::vector<int64_t> oks((size_t)world);
 				if ((r = comm->all_gather(comm->ctx, &ok, 1, oks.data())) < 0) return r;
 				for (int q = 0; q < world; ++q) peer = peer && oks[(size_t)q] != 0;
 			}
-			if (!cur || !nxt) return RB3GPU_ENOMEM;
+			if (peer && (!pr0 || !pr1)) return RB3GPU_ENOMEM;
+			RB3_IPC_DBG("buffers exchanged: peer %d", (int)peer);
 		}
 	}
-	if ((r = first_states()) < 0) return r;
+	if ((r = first_states(peer ? pr0 : cur)) < 0) return r;
+	RB3_IPC_DBG("first states up");
 	unsigned long long hc_stack[RB3_SH_MAXIV + 2], *hc = h->hm_pin ? h->hm_pin : hc_stack;
 	const IdxView iv = view_of(h);
 	int64_t rows = 0, rounds = 0;
@@ -3674,6 +3688,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 		unsigned long long *shk = (unsigned long long*)h->shk.p;
 		HIPCHK(hipMemsetAsync(rb, 0, 8, h->st));
 		{ const unsigned long long n0 = (unsigned long long)n_cur; HIPCHK(hipMemcpyAsync(shk + RB3_SH_CIN_WORD(1), &n0, 8, hipMemcpyHostToDevice, h->st)); HIPCHK(hipStreamSynchronize(h->st)); } // round 0 finds the first states in region 0, "from rank 0"
+		RB3_IPC_DBG("%lld rounds, room for %lld records", (long long)longest, (long long)rec_cap);
 		if ((r = comm->stream_barrier(comm->ctx, (void*)h->st)) < 0) return r; // (nobody writes into a table that its owner has not cleared yet)
 		const int S = h->tn.sh_states ? h->tn.sh_states : n_chains >= ((int64_t)1 << 15) ? 8 : 1;
 		const int BS = S == 8 && (h->tn.sh_block ? h->tn.sh_block == 1024 : n_chains < ((int64_t)3 << 20)) ? 1024 : 256;
@@ -3687,7 +3702,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 				pe.dst[q] = (ShState*)(intptr_t)all4[(size_t)q * 4 + ((k & 1) ? 1 : 2)];
 				pe.cin[q] = (unsigned long long*)(intptr_t)all4[(size_t)q * 4 + 3] + RB3_SH_CIN_WORD(k & 1);
 			}
-			const ShState *in = (k & 1) ? nxt : cur;
+			const ShState *in = (k & 1) ? pr1 : pr0;
 			unsigned long long *c_add = d_cnt[k % 3], *c_clr = d_cnt[(k + 1) % 3];
 #define RB3_SH_ROUNDP(SS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<SS>), dim3(nblk), dim3(256), 0, h->st, iv, a, n_chains, in, d_tw, (ShRec*)h->shr.p, (ShState*)nullptr, (int64_t)0, c_add, c_clr, d_bad, d_tprev, (const unsigned long long*)nullptr, rb + k, pe)
 			if (BS == 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sh_round<8, 1024>), dim3(nblk), dim3(1024), 0, h->st, iv, a, n_chains, in, d_tw, (ShRec*)h->shr.p, (ShState*)nullptr, (int64_t)0, c_add, c_clr, d_bad, d_tprev, (const unsigned long long*)nullptr, rb + k, pe);
@@ -3695,6 +3710,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 #undef RB3_SH_ROUNDP
 			if ((r = comm->stream_barrier(comm->ctx, (void*)h->st)) < 0) return r;
 		}
+		RB3_IPC_DBG("rounds queued");
 		unsigned long long fin[4 + RB3_SH_MAXPEER];
 		memset(fin, 0, sizeof(fin));
 		HIPCHK(hipMemcpyAsync(&fin[0], rb + longest, 8, hipMemcpyDeviceToHost, h->st));
@@ -3707,6 +3723,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 		if ((r = comm->all_gather(comm->ctx, ok2, 2, ok_all.data())) < 0) return r;
 		bool ok = true;
 		for (int q = 0; q < world; ++q) ok = ok && ok_all[(size_t)q * 2] != 0, tot_rows += ok_all[(size_t)q * 2 + 1];
+		RB3_IPC_DBG("rounds done: %llu rows here, ok %d, %lld rows in all", fin[0], (int)ok, (long long)tot_rows);
 		if (ok && tot_rows == len) {
 			walked = true, rows = (int64_t)fin[0], rounds = longest;
 			h->stt.n_lf_steps += rows, h->stt.n_rank_launches += longest, h->stt.n_peer_rounds += longest;
@@ -3714,7 +3731,7 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 			if (h->opt.verbose >= 2) fprintf(stderr, "[W::rb3gpu] sharded merge, rank %d: peer rounds gave up (%llu rows recorded here of %lld in all, room for %lld; %llu states left, %llu misrouted, %llu rounds without room); once more with the rounds driven by the host\n",
 					rank, fin[0], (long long)len, (long long)rec_cap, fin[1], fin[2], fin[3]);
 			HIPCHK(hipMemsetAsync(h->shk.p, 0, (size_t)RB3_SH_CNT_WORDS * 8, h->st));
-			if ((r = first_states()) < 0) return r;
+			if ((r = first_states(cur)) < 0) return r;
 			if ((r = comm->stream_barrier(comm->ctx, (void*)h->st)) < 0) return r; // (every rank is done with the peer rounds' buffers)
 		}
 	}

@@ -135,10 +135,8 @@ struct IpcShm { std::atomic<uint32_t> count, gen, aborted; };
 
 struct IpcPeer {
 	rb3gpu_comm_t inner;            // the communicator underneath: its collectives are passed through
-	int rank = 0, world = 1, dev = 0, par = 0;
+	int rank = 0, world = 1, dev = 0;
 	IpcShm *shm = nullptr;
-	hipEvent_t ev[2] = { nullptr, nullptr };                  // this rank's, interprocess
-	hipEvent_t pev[RB3GPU_SH_MAXIV][2];                       // the other ranks', opened here
 	struct Open { int64_t key[8]; void *ptr; int rank; unsigned long used; };
 	std::vector<Open> open;         // buffers of other ranks mapped into this process, by handle
 	unsigned long tick = 0;
@@ -176,19 +174,17 @@ static int ipc_barrier(IpcPeer *p)
 	return b->aborted.load(std::memory_order_acquire) ? RB3GPU_ESTATE : 0;
 }
 
+/* Between processes the streams cannot wait for each other: on this runtime (ROCm 7.2) hipStreamWaitEvent answers "invalid argument" to an event that came through
+ * hipIpcOpenEventHandle.  So a rank waits for ITS OWN stream -- its round's kernel and with it every store into the other ranks' buffers is done --, then the
+ * processes meet at the barrier in shared memory: one host synchronisation per round, but still no collective, no read-back and no copy. */
 static int ipc_stream_barrier(void *ctx, void *stream)
 {
 	IpcPeer *p = (IpcPeer*)ctx;
 	hipStream_t st = (hipStream_t)stream;
-	if (hipSetDevice(p->dev) != hipSuccess) { ipc_abort(p); return RB3GPU_ENODEV; }
-	const int q = p->par;
-	p->par ^= 1;
-	if (hipEventRecord(p->ev[q], st) != hipSuccess) { (void)hipGetLastError(); ipc_abort(p); return RB3GPU_ENODEV; }
-	int r;
-	if ((r = ipc_barrier(p)) < 0) return r;
-	for (int o = 0; o < p->world; ++o)
-		if (o != p->rank && hipStreamWaitEvent(st, p->pev[o][q], 0) != hipSuccess) { (void)hipGetLastError(); ipc_abort(p); return RB3GPU_ENODEV; }
-	return 0;
+	hipError_t e = hipSetDevice(p->dev);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) { fprintf(stderr, "[E::rb3gpu] peer rounds between processes, rank %d: %s\n", p->rank, hipGetErrorString(e)); (void)hipGetLastError(); ipc_abort(p); return RB3GPU_ENODEV; }
+	return ipc_barrier(p);
 }
 
 static int ipc_peer_export(void *ctx, void *d_ptr, int64_t handle[8])
@@ -196,7 +192,7 @@ static int ipc_peer_export(void *ctx, void *d_ptr, int64_t handle[8])
 	(void)ctx;
 	hipIpcMemHandle_t hd;
 	static_assert(sizeof(hd) == 64, "an IPC memory handle is 8 words");
-	if (hipIpcGetMemHandle(&hd, d_ptr) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	{ const hipError_t e = hipIpcGetMemHandle(&hd, d_ptr); if (e != hipSuccess) { fprintf(stderr, "[E::rb3gpu] peer rounds between processes: hipIpcGetMemHandle(%p): %s\n", d_ptr, hipGetErrorString(e)); (void)hipGetLastError(); return RB3GPU_ENODEV; } }
 	memcpy(handle, &hd, 64);
 	return 0;
 }
@@ -216,7 +212,8 @@ static void *ipc_peer_import(void *ctx, int rank, const int64_t handle[8])
 	hipIpcMemHandle_t hd;
 	memcpy(&hd, handle, 64);
 	void *ptr = nullptr;
-	if (hipSetDevice(p->dev) != hipSuccess || hipIpcOpenMemHandle(&ptr, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess || ptr == nullptr) { (void)hipGetLastError(); return nullptr; }
+	{ hipError_t e = hipSetDevice(p->dev); if (e == hipSuccess) e = hipIpcOpenMemHandle(&ptr, hd, hipIpcMemLazyEnablePeerAccess);
+	  if (e != hipSuccess || ptr == nullptr) { fprintf(stderr, "[E::rb3gpu] peer rounds between processes, rank %d: hipIpcOpenMemHandle of a buffer of rank %d: %s\n", p->rank, rank, hipGetErrorString(e)); (void)hipGetLastError(); return nullptr; } }
 	IpcPeer::Open o;
 	memcpy(o.key, handle, 64), o.ptr = ptr, o.rank = rank, o.used = p->tick;
 	p->open.push_back(o);
@@ -228,8 +225,6 @@ static void ipc_free(IpcPeer *p)
 	if (!p) return;
 	(void)hipSetDevice(p->dev);
 	for (auto &o : p->open) (void)hipIpcCloseMemHandle(o.ptr);
-	for (int i = 0; i < 2; ++i) if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
-	for (int o = 0; o < p->world; ++o) for (int i = 0; i < 2; ++i) if (o != p->rank && p->pev[o][i]) (void)hipEventDestroy(p->pev[o][i]);
 	if (p->shm) munmap(p->shm, 4096);
 	(void)hipGetLastError();
 	delete p;
@@ -287,7 +282,6 @@ int rb3gpu_ipc_peer_enable(rb3gpu_t *h, rb3gpu_comm_t *comm)
 	if (!h || !comm || !comm->all_gather || comm->world < 2 || comm->world > RB3GPU_SH_MAXIV || comm->stream_barrier) return RB3GPU_EINVAL;
 	IpcPeer *p = new (std::nothrow) IpcPeer;
 	if (!p) return RB3GPU_ENOMEM;
-	memset(p->pev, 0, sizeof(p->pev));
 	p->inner = *comm, p->rank = comm->rank, p->world = comm->world, p->dev = rb3gpu_device_of(h);
 	const int W = p->world;
 	int64_t ok = 1;
@@ -312,24 +306,13 @@ int rb3gpu_ipc_peer_enable(rb3gpu_t *h, rb3gpu_comm_t *comm)
 		if (m != MAP_FAILED) p->shm = (IpcShm*)m; // (a fresh object is all zero: count, generation and the abort flag start at 0)
 	}
 	if (!p->shm) ok = 0;
-	// 2. two interprocess events per rank, everybody opens everybody else's
-	int64_t evh[16];
-	memset(evh, 0, sizeof(evh));
+	// 2. (a second all-gather: everybody has mapped the object -- or has failed to, and says so below -- before rank 0 takes its name away)
 	if (hipSetDevice(p->dev) != hipSuccess) ok = 0;
-	for (int i = 0; i < 2 && ok; ++i) {
-		hipIpcEventHandle_t eh;
-		static_assert(sizeof(eh) == 64, "an IPC event handle is 8 words");
-		if (hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming | hipEventInterprocess) != hipSuccess || hipIpcGetEventHandle(&eh, p->ev[i]) != hipSuccess) { (void)hipGetLastError(); ok = 0; break; }
-		memcpy(evh + 8 * i, &eh, 64);
+	{
+		int64_t dummy = 0;
+		if (comm->all_gather(comm->ctx, &dummy, 1, all.data()) < 0) { if (p->rank == 0 && name[0]) shm_unlink(name); ipc_free(p); return RB3GPU_ENODEV; }
 	}
-	if (comm->all_gather(comm->ctx, evh, 16, all.data()) < 0) { if (p->rank == 0 && name[0]) shm_unlink(name); ipc_free(p); return RB3GPU_ENODEV; }
-	if (p->rank == 0 && name[0]) shm_unlink(name); // (everybody has mapped it -- or has failed to, and says so below)
-	for (int o = 0; o < W && ok; ++o)
-		for (int i = 0; i < 2 && ok && o != p->rank; ++i) {
-			hipIpcEventHandle_t eh;
-			memcpy(&eh, all.data() + (size_t)o * 16 + 8 * i, 64);
-			if (hipIpcOpenEventHandle(&p->pev[o][i], eh) != hipSuccess) { (void)hipGetLastError(); p->pev[o][i] = nullptr; ok = 0; }
-		}
+	if (p->rank == 0 && name[0]) shm_unlink(name);
 	// 3. everywhere or nowhere
 	std::vector<int64_t> oks((size_t)W);
 	if (comm->all_gather(comm->ctx, &ok, 1, oks.data()) < 0) { ipc_free(p); return RB3GPU_ENODEV; }

@@ -368,9 +368,12 @@ def sh_comm(h, dist, rank, world, dev, driver="rccl"):
     import torch
     from ropebwt3_amd import RcclComm, CallbackComm, Rb3GpuError, ipc_peer_enable
 
-    def with_peer_rounds(comm, label):
-        """the ranks are processes of ONE node: the lock-step rounds as peer rounds through HIP IPC where every rank can (collective; RB3_NO_IPC_PEER=1: never)"""
-        if world > 1 and not os.environ.get("RB3_NO_IPC_PEER"):
+    def with_peer_rounds(comm, label, default_on=False):
+        """the ranks are processes of ONE node: the lock-step rounds as peer rounds through HIP IPC where every rank can (collective).  On by default where the
+        ranks share a GPU (test mode: run on hardware, tests/test_gpu_engine.py); between DISTINCT devices it has never run -- a mapping that does not come back
+        would cost the leg its number --, so there it waits for RB3_IPC_PEER=1 (RB3_NO_IPC_PEER=1: never)"""
+        on = (default_on or os.environ.get("RB3_IPC_PEER") == "1") and not os.environ.get("RB3_NO_IPC_PEER")
+        if world > 1 and on:
             try:
                 if ipc_peer_enable(h, comm):
                     label += " + PEER ROUNDS between the processes (rb3gpu_ipc_peer_enable: HIP IPC memory and event handles, a barrier in shared memory; the collectives above only carry the handles and the final exchange)"
@@ -410,7 +413,7 @@ def sh_comm(h, dist, rank, world, dev, driver="rccl"):
             if got.size:
                 h.dev_upload_to(d_recv, got)
 
-        return with_peer_rounds(CallbackComm(rank, world, all_gather_g, exchange_g), "callbacks over gloo through host memory (ranks share a GPU: test mode)")
+        return with_peer_rounds(CallbackComm(rank, world, all_gather_g, exchange_g), "callbacks over gloo through host memory (ranks share a GPU: test mode)", default_on=True)
 
     def all_gather(vec):
         v = torch.as_tensor(np.ascontiguousarray(vec, dtype=np.int64), device=dev)

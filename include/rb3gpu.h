@@ -359,7 +359,8 @@ typedef struct rb3gpu_comm_s {
 	int (*stream_barrier)(void *ctx, void *stream);
 	/* may be NULL (then a device pointer means the same on every rank: threads of one process).  Ranks that are PROCESSES name a device buffer to each other
 	 * by a handle of 8 words (peer_export: 0 or a negative code) which all_gather carries and the other side turns into a pointer of its own address space
-	 * (peer_import: NULL if it cannot) -- HIP IPC memory handles in rb3gpu_ipc_peer_enable below. */
+	 * (peer_import: NULL if it cannot; with handle == NULL: the rank named is about to replace its buffers -- whatever is mapped of them here is given up, NULL is
+	 * returned) -- HIP IPC memory handles in rb3gpu_ipc_peer_enable below. */
 	int (*peer_export)(void *ctx, void *d_ptr, int64_t handle[8]);
 	void *(*peer_import)(void *ctx, int rank, const int64_t handle[8]);
 } rb3gpu_comm_t;

@@ -3623,11 +3623,21 @@ static int sh_merge_impl(rb3gpu_t *h, const rb3gpu_comm_t *comm, int64_t *iv_bou
 	std::vector<int64_t> all4((size_t)world * 4);
 	if (world > 1) {
 		int64_t can = comm->stream_barrier != nullptr && world <= RB3_SH_MAXPEER && h->tn.sh_host_rounds <= 0 ? 1 : 0;
-		std::vector<int64_t> can_all((size_t)world);
-		RB3_IPC_DBG("merge of %lld symbols, %lld chains: can %lld", (long long)len, (long long)n_chains, (long long)can);
-		if ((r = comm->all_gather(comm->ctx, &can, 1, can_all.data())) < 0) return r;
+		// (a rank that must replace its receive buffers -- more chains than any batch before -- says so first: between processes the others give their mappings of them up
+		// before they go; a mapping of a buffer that its owner has freed is what a later merge must never meet)
+		const size_t pneed = (size_t)world * (size_t)n_chains * 16;
+		int64_t cg[2] = { can, can && (h->shp0.p == nullptr || h->shp0.cap < pneed || h->shp1.p == nullptr || h->shp1.cap < pneed) ? 1 : 0 };
+		std::vector<int64_t> can_all((size_t)world * 2);
+		RB3_IPC_DBG("merge of %lld symbols, %lld chains: can %lld, new buffers %lld", (long long)len, (long long)n_chains, (long long)can, (long long)cg[1]);
+		if ((r = comm->all_gather(comm->ctx, cg, 2, can_all.data())) < 0) return r;
 		peer = true;
-		for (int q = 0; q < world; ++q) peer = peer && can_all[(size_t)q] != 0;
+		for (int q = 0; q < world; ++q) peer = peer && can_all[(size_t)q * 2] != 0;
+		if (peer && comm->peer_import) {
+			bool any = false;
+			for (int q = 0; q < world; ++q)
+				if (can_all[(size_t)q * 2 + 1] != 0) { any = true; if (q != rank) (void)comm->peer_import(comm->ctx, q, nullptr); }
+			if (any && (r = comm->stream_barrier(comm->ctx, (void*)h->st)) < 0) return r; // (everybody has let go)
+		}
 		if (peer) {
 			if (buf_ensure(h, h->shp0, (size_t)world * (size_t)n_chains * 16) < 0 || buf_ensure(h, h->shp1, (size_t)world * (size_t)n_chains * 16) < 0) can = 0; // (no room: the others must hear of it)
 			pr0 = (ShState*)h->shp0.p, pr1 = (ShState*)h->shp1.p;

@@ -200,6 +200,12 @@ static int ipc_peer_export(void *ctx, void *d_ptr, int64_t handle[8])
 static void *ipc_peer_import(void *ctx, int rank, const int64_t handle[8])
 {
 	IpcPeer *p = (IpcPeer*)ctx;
+	if (handle == nullptr) { // that rank is about to replace its buffers: what is mapped of them here goes first
+		(void)hipSetDevice(p->dev);
+		for (size_t i = 0; i < p->open.size(); )
+			if (p->open[i].rank == rank) { (void)hipIpcCloseMemHandle(p->open[i].ptr); (void)hipGetLastError(); p->open.erase(p->open.begin() + (long)i); } else ++i;
+		return nullptr;
+	}
 	++p->tick;
 	for (auto &o : p->open)
 		if (o.rank == rank && memcmp(o.key, handle, 64) == 0) { o.used = p->tick; return o.ptr; }

@@ -1625,7 +1625,7 @@ def _gloo_sh_worker(rank, world, port, q, ipc=False):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     import torch.distributed as dist
-    from ropebwt3_amd import Rb3Gpu, CallbackComm, multi
+    from ropebwt3_amd import Rb3Gpu, CallbackComm, multi, host
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -1663,6 +1663,15 @@ def _gloo_sh_worker(rank, world, port, q, ipc=False):
             nround += nr
             h.dev_free(d_bwt), h.dev_free(d_tw)
             _check_interval(h, np.random.default_rng(rank), want[b + 1], bounds, rank)
+        if ipc:   # a batch of more chains than any before: every rank replaces its receive buffers -- the other processes give their mappings of them up first
+            g0 = util.random_genome(np.random.default_rng(7), 30000)
+            t3 = util.make_text(util.reads_from(np.random.default_rng(8), g0, 9000, 60, err=0.01))
+            w3 = orc.merge(want[-1], host.build_bwt(t3.copy()))
+            d_bwt, d_tw = h.sort_text(t3)
+            bounds, nr = h.sh_merge(comm, bounds, d_bwt, d_tw, t3.size, np.flatnonzero(t3 == 0))
+            nround += nr
+            h.dev_free(d_bwt), h.dev_free(d_tw)
+            _check_interval(h, np.random.default_rng(rank), w3, bounds, rank)
         assert h.stats()["n_peer_rounds"] == (nround if ipc else 0), (h.stats()["n_peer_rounds"], nround)
         if ipc:
             ipc_peer_disable(h, comm)

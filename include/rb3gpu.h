@@ -437,6 +437,9 @@ int rb3gpu_shard_bounds(const rb3gpu_shard_t *s, int64_t *bounds);
 /* the HIP device and stream of a handle (for communicators implemented outside the library) */
 int rb3gpu_device_of(const rb3gpu_t *h);
 void *rb3gpu_stream_of(const rb3gpu_t *h);
+/* wait for a stream handed to a communicator's all_to_all (a communicator that moves the send regions with anything that is not ordered behind that stream -- the
+ * runtime's synchronous copies, a library on another stream -- calls this first: the engine's streams are non-blocking) */
+int rb3gpu_stream_sync(void *stream);
 
 /* Diagnostic switches of a handle (no reference analogue; none is needed in normal use).  Each key is also read ONCE from
  * the environment variable RB3GPU_<KEY> when the handle is created; the merge path itself never calls getenv().

@@ -4030,6 +4030,12 @@ int rb3gpu_dev_download(rb3gpu_t *h, void *dst, const void *d_src, int64_t n_byt
 	return 0;
 }
 
+int rb3gpu_stream_sync(void *stream)
+{
+	if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return RB3GPU_ENODEV; }
+	return 0;
+}
+
 int rb3gpu_dev_free(rb3gpu_t *h, void *d_ptr)
 {
 	if (!h) return RB3GPU_EINVAL;

@@ -123,6 +123,7 @@ SYMBOLS = {
     "rb3gpu_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "rb3gpu_rccl_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_rccl_comm_destroy": (None, [ctypes.c_void_p]),
+    "rb3gpu_stream_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "rb3gpu_ipc_peer_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rb3gpu_ipc_peer_disable": (None, [ctypes.c_void_p]),
     "rb3gpu_merge_text_step_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
@@ -715,6 +716,11 @@ class CallbackComm:
             try:
                 sc = np.ctypeslib.as_array(send_cnt, shape=(self.world,)).copy()
                 rc = np.ctypeslib.as_array(recv_cnt, shape=(self.world,)).copy()
+                # The send regions are complete ON THE ENGINE'S STREAM (include/rb3gpu.h): a callable that reads them with the runtime's synchronous copies -- the null
+                # stream, which does not wait for a non-blocking stream -- must not start before that stream is done.  (The merge's last phase, the exchange with the owners
+                # of the text ranges, calls this right behind the kernel that fills the regions: eight processes lost rows there, four got away with it.)
+                if stream:
+                    load_library().rb3gpu_stream_sync(stream)
                 exchange(int(d_send or 0), int(stride), sc, int(d_recv or 0), rc)
                 return 0
             except BaseException as e:

@@ -562,6 +562,9 @@ def interval_leg(args, h, dist, rank, world, dev, local_rank, shared_gpu, barrie
     from tests import util
     out = None
     n_index, reads_per_gpu = (1 << 26) * world, (500000 if world > 1 else 100000)   # (large batches amortise the per-symbol collectives: config 4 has 46 M chains per batch)
+    if shared_gpu and world > 2:   # TEST MODE: every rank sorts and holds the whole batch on the ONE device (~100 B per symbol and rank): four ranks ran out of memory at 604 M symbols
+        reads_per_gpu = min(reads_per_gpu, 5000000 // (world * world))
+        n_index = (1 << 24) * world   # (... and the index text as well)
     rng = np.random.default_rng(31)
     g = util.random_genome(rng, n_index // 2 - 1)
     t1 = util.make_text([g])

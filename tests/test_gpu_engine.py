@@ -1734,6 +1734,26 @@ def test_interval_sharded_merge_peer_rounds_between_processes(world):
     assert all(r[1] for r in res), res
 
 
+@pytest.mark.parametrize("world,ipc", [(8, False), (8, True)])
+def test_batch_sharded_merge_between_processes(world, ipc):
+    """rb3gpu_sh_merge_text between eight PROCESSES over the gloo callbacks (what bench.py --gpus 8 runs where the ranks share a GPU): the exchange with the owners of
+    the text ranges is called right behind the kernel that fills the send regions, and a communicator that reads them with the runtime's synchronous copies must
+    wait for the engine's (non-blocking) stream first -- CallbackComm does (rb3gpu_stream_sync); without it eight processes lost rows where four got away with it"""
+    import socket
+    import torch.multiprocessing as mp
+    from tools import probe_gloo_text
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=probe_gloo_text.worker, args=(r, world, port, q, ipc, 20000)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+
+
 def test_rccl_communicator_world_of_one(oracle):
     """the RCCL communicator of the library (librccl loaded at run time; one process per GPU) on the one GPU there is: communicator of
     world 1, its all-gather, its grouped send/recv (a rank sending to itself) called directly, and a merge through it"""
